@@ -1,0 +1,123 @@
+"""Shared oracle helpers (numpy, float64).  TEST INFRASTRUCTURE ONLY.
+
+Follows /root/reference/lycoris/functional/general.py:
+  * factorization      -> general.py:14-56
+  * FUNC_LIST dispatch -> general.py:6 (F.linear / F.conv2d); conv arguments are
+    the ``kw_dict`` of modules/base.py:101-121 (stride, padding, dilation, groups=1)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def factorization(dimension: int, factor: int = -1):
+    """Split ``dimension`` into (m, n), m <= n, m*n == dimension.
+
+    Restates general.py:14-56: if ``factor`` divides the dimension, the split is
+    (factor, dimension/factor) ordered ascending; otherwise walk the divisors
+    upward from 1 while the pair keeps getting more balanced (m + n does not
+    grow) and m stays <= factor (factor < 0 means "no cap").
+    """
+    dimension = int(dimension)
+    factor = int(factor)
+    if factor > 0 and dimension % factor == 0:
+        lo, hi = factor, dimension // factor
+        return (lo, hi) if lo <= hi else (hi, lo)
+    cap = dimension if factor < 0 else factor
+    m, n = 1, dimension
+    best_sum = m + n
+    while m < n:
+        cand = m + 1
+        while dimension % cand:
+            cand += 1
+        other = dimension // cand
+        if cand + other > best_sum or cand > cap:
+            break
+        m, n = cand, other
+        # NB: the reference never updates its running "length" (general.py:43,49),
+        # so the comparison is always against 1 + dimension.
+    return (m, n) if m <= n else (n, m)
+
+
+# ----------------------------------------------------------------------------
+# dense ops: y = op(x, W) and their adjoints
+# ----------------------------------------------------------------------------
+def _pair(v):
+    if isinstance(v, (tuple, list)):
+        return int(v[0]), int(v[1])
+    return int(v), int(v)
+
+
+def _im2col(x, kh, kw, stride, padding, dilation):
+    """x:[B,C,H,W] -> cols:[B, C*kh*kw, Ho*Wo] (channel-major, then kh, kw)."""
+    B, C, H, W = x.shape
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    dh, dw = _pair(dilation)
+    Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    xp = np.zeros((B, C, H + 2 * ph, W + 2 * pw), dtype=x.dtype)
+    xp[:, :, ph:ph + H, pw:pw + W] = x
+    cols = np.empty((B, C, kh, kw, Ho, Wo), dtype=x.dtype)
+    for i in range(kh):
+        for j in range(kw):
+            hs, ws = i * dh, j * dw
+            cols[:, :, i, j] = xp[:, :, hs:hs + sh * (Ho - 1) + 1:sh, ws:ws + sw * (Wo - 1) + 1:sw]
+    return cols.reshape(B, C * kh * kw, Ho * Wo), (Ho, Wo)
+
+
+def _col2im(cols, xshape, kh, kw, stride, padding, dilation, Ho, Wo):
+    B, C, H, W = xshape
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    dh, dw = _pair(dilation)
+    xp = np.zeros((B, C, H + 2 * ph, W + 2 * pw), dtype=cols.dtype)
+    cols = cols.reshape(B, C, kh, kw, Ho, Wo)
+    for i in range(kh):
+        for j in range(kw):
+            hs, ws = i * dh, j * dw
+            xp[:, :, hs:hs + sh * (Ho - 1) + 1:sh, ws:ws + sw * (Wo - 1) + 1:sw] += cols[:, :, i, j]
+    return xp[:, :, ph:ph + H, pw:pw + W]
+
+
+def dense_forward(x, w, conv_args=None):
+    """op(x, W) of FUNC_LIST (general.py:6): F.linear for 2-D W, F.conv2d for 4-D W."""
+    x = np.asarray(x, dtype=np.float64)
+    w = np.asarray(w, dtype=np.float64)
+    if w.ndim == 2:
+        return x @ w.T
+    assert w.ndim == 4, "oracle covers Linear and Conv2d only"
+    ca = conv_args or {}
+    assert int(ca.get("groups", 1)) == 1
+    O, C, kh, kw = w.shape
+    cols, (Ho, Wo) = _im2col(x, kh, kw, ca.get("stride", 1), ca.get("padding", 0), ca.get("dilation", 1))
+    y = np.einsum("ok,bkm->bom", w.reshape(O, -1), cols)
+    return y.reshape(x.shape[0], O, Ho, Wo)
+
+
+def dense_backward(x, w, g, conv_args=None):
+    """Adjoint of dense_forward: returns (dx, dW) for upstream gradient g."""
+    x = np.asarray(x, dtype=np.float64)
+    w = np.asarray(w, dtype=np.float64)
+    g = np.asarray(g, dtype=np.float64)
+    if w.ndim == 2:
+        dx = g @ w
+        dw = g.reshape(-1, g.shape[-1]).T @ x.reshape(-1, x.shape[-1])
+        return dx, dw
+    ca = conv_args or {}
+    O, C, kh, kw = w.shape
+    st, pd, dl = ca.get("stride", 1), ca.get("padding", 0), ca.get("dilation", 1)
+    cols, (Ho, Wo) = _im2col(x, kh, kw, st, pd, dl)
+    g2 = g.reshape(g.shape[0], O, Ho * Wo)
+    dw = np.einsum("bom,bkm->ok", g2, cols).reshape(w.shape)
+    dcols = np.einsum("ok,bom->bkm", w.reshape(O, -1), g2)
+    dx = _col2im(dcols, x.shape, kh, kw, st, pd, dl, Ho, Wo)
+    return dx, dw
+
+
+def rel_err(a, b):
+    """Norm-wise relative error ||a-b|| / ||b|| (the metric of SURVEY 8d)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = np.linalg.norm(b)
+    return float(np.linalg.norm(a - b) / den) if den > 0 else float(np.linalg.norm(a - b))

@@ -1,0 +1,56 @@
+"""Evaluate the numpy oracle on a golden case (shared by CPU and GPU tests)."""
+import numpy as np
+
+import oracle
+
+
+def conv_args_of(meta):
+    lk = meta["layer"]
+    if lk["kind"] == "linear":
+        return None
+    return {"stride": lk.get("stride", 1), "padding": lk.get("padding", 0), "dilation": lk.get("dilation", 1)}
+
+
+def oracle_eval(meta, a):
+    """Returns (delta, grads dict keyed like the golden file: 'dx', 'g.<param name>')."""
+    algo = meta["algo"]
+    ca = conv_args_of(meta)
+    x, g, W = a["x"], a["g"], a["W"]
+    scalar = float(a["p.scalar"]) if "p.scalar" in a else 1.0
+    eff = meta["scale"] * scalar * meta["multiplier"]
+    out = {}
+    if algo == "locon":
+        down, up = a["p.lora_down.weight"], a["p.lora_up.weight"]
+        delta = oracle.locon.forward(x, down, up, eff, ca)
+        dx, dd, du = oracle.locon.backward(x, g, down, up, eff, ca)
+        out = {"dx": dx, "g.lora_down.weight": dd, "g.lora_up.weight": du}
+        dscalar = (du * up).sum() / scalar if "p.scalar" in a else None
+    elif algo == "loha":
+        ws = [a["p.hada_w1_a"], a["p.hada_w1_b"], a["p.hada_w2_a"], a["p.hada_w2_b"]]
+        delta = oracle.loha.forward(x, *ws, eff, W.shape, ca)
+        dx, g1a, g1b, g2a, g2b = oracle.loha.backward(x, g, *ws, eff, W.shape, ca)
+        out = {"dx": dx, "g.hada_w1_a": g1a, "g.hada_w1_b": g1b, "g.hada_w2_a": g2a, "g.hada_w2_b": g2b}
+        dscalar = (g1a * ws[0]).sum() / scalar if "p.scalar" in a else None
+    elif algo == "lokr":
+        kw = {k: a.get("p.lokr_" + k) for k in ("w1", "w1_a", "w1_b", "w2", "w2_a", "w2_b")}
+        args = dict(w1=kw["w1"], w1a=kw["w1_a"], w1b=kw["w1_b"], w2=kw["w2"], w2a=kw["w2_a"], w2b=kw["w2_b"],
+                    scale=eff, kshape=tuple(W.shape[2:]), conv_args=ca)
+        delta = oracle.lokr.forward(x, **args)
+        gr = oracle.lokr.backward(x, g, **args)
+        out = {"dx": gr.pop("dx")}
+        for k, v in gr.items():
+            out["g.lokr_" + k.replace("w1a", "w1_a").replace("w1b", "w1_b").replace("w2a", "w2_a").replace("w2b", "w2_b")] = v
+        k1 = "w1" if kw["w1"] is not None else "w1_a"
+        dscalar = (out["g.lokr_" + k1] * kw[k1]).sum() / scalar if "p.scalar" in a else None
+    elif algo == "ia3":
+        on_input = bool(meta["mod"].get("train_on_input", False))
+        w = a["p.weight"]
+        delta = oracle.ia3.forward(x, W, w, meta["multiplier"], on_input, ca)
+        dx, dw = oracle.ia3.backward(x, g, W, w, meta["multiplier"], on_input, ca)
+        out = {"dx": dx, "g.weight": dw}
+        dscalar = None
+    else:
+        raise KeyError(algo)
+    if dscalar is not None:
+        out["g.scalar"] = np.asarray(dscalar)
+    return delta, out
