@@ -1,0 +1,71 @@
+/* lycoris_amd.h -- C ABI of the MI355X (gfx950) adapter hot path.
+ *
+ * Drop-in boundary for the LyCORIS adapter forward/backward.  The
+ * reference is pure Python over ATen; each entry point below replaces the ATen call sequence of one
+ * reference function, named in the comment above it (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM); activations are row-major and contiguous;
+ *   - `dtype` selects the activation element type (x, g, y, dx, base ...): LYC_F32 / LYC_F16 / LYC_BF16;
+ *   - adapter factors and their gradients are always fp32 (callers with 16-bit factors convert the
+ *     small tensors); arithmetic accumulates in fp32; fp32 factors are fed to the matrix cores as
+ *     hi + lo pairs so the only rounding is the final store of a `dtype` output;
+ *   - gradient outputs marked "+=" are accumulated with fp32 atomics: the caller zero-fills them
+ *     (or passes a slice of its gradient arena); buffers marked "scratch, zeroed" likewise;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work: no allocation, no
+ *     synchronisation, no host reads, so they are legal inside hipGraph capture;
+ *   - return value 0 = success; otherwise an LYC_ERR_* code and lyc_last_error() (thread-local) says why.
+ *     Nothing is enqueued when an argument check fails.
+ */
+#ifndef LYCORIS_AMD_H
+#define LYCORIS_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { LYC_F32 = 0, LYC_F16 = 1, LYC_BF16 = 2 };
+enum { LYC_OK = 0, LYC_ERR_ARG = 1, LYC_ERR_UNSUPPORTED = 2, LYC_ERR_LAUNCH = 3 };
+
+#define LYC_ABI_VERSION 1
+int lyc_abi_version(void);
+const char* lyc_last_error(void);
+
+/* ---- LoKr on nn.Linear -------------------------------------------------------------------------
+ * replaces lycoris/modules/lokr.py:543-566 (forward: make_kron + dense F.linear) and the factored
+ * bypass lycoris/functional/lokr.py:154-247 / modules/lokr.py:468-538.
+ *   w1:[a,b]  w2:[c,d]  x:[M, b*d]  y:[M, a*c]
+ *   y[m, p*c+q] = alpha * sum_u w1[p,u] * sum_v w2[q,v] * x[m, u*d+v]          (== x @ (kron(w1,w2)*alpha)^T)
+ * bwd: dx = g @ (kron(w1,w2)*alpha);  dw1 += , dw2 +=  (gradients of sum(g*y) w.r.t. w1, w2)          */
+int lyc_lokr_linear_fwd(const void* x, const float* w1, const float* w2, void* y, int64_t M, int a, int b, int c,
+                        int d, float alpha, int dtype, void* stream);
+int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const float* w2, void* dx, float* dw1,
+                        float* dw2, int64_t M, int a, int b, int c, int d, float alpha, int dtype, void* stream);
+
+/* ---- LoCon on nn.Linear ------------------------------------------------------------------------
+ * replaces lycoris/modules/locon.py:309-332 (forward: make_weight + dense F.linear) and the bypass
+ * lycoris/functional/locon.py:64-85 / modules/locon.py:286-304.
+ *   down:[r,I]  up:[O,r]  x:[M,I]  y:[M,O];   y = alpha * (x @ down^T) @ up^T
+ *   t :[M,r] fp32 scratch, zeroed; on return t = x @ down^T (keep it for the backward call)
+ *   dt:[M,r] fp32 scratch, zeroed; d_down += , d_up +=                                                 */
+int lyc_locon_linear_fwd(const void* x, const float* down, const float* up, float* t, void* y, int64_t M, int I,
+                         int O, int r, float alpha, int dtype, void* stream);
+int lyc_locon_linear_bwd(const void* g, const void* x, const float* down, const float* up, const float* t,
+                         float* dt, void* dx, float* d_down, float* d_up, int64_t M, int I, int O, int r,
+                         float alpha, int dtype, void* stream);
+
+/* ---- (IA)^3 per-channel scale ------------------------------------------------------------------
+ * replaces lycoris/modules/ia3.py:91-102,129-144 (rebuild path).  Tensors are [outer, C, inner]
+ * (Linear: inner = 1; NCHW Conv2d: inner = H*W).
+ *   lyc_chan_scale : out = in * (s0 + w[c]*mult) - bias[c] * w[c]*mult        (bias may be NULL)
+ *   lyc_chan_reduce: dw[c] += mult * sum a * (b - bias[c])                                             */
+int lyc_chan_scale(const void* in, const float* w, const float* bias, void* out, int64_t outer, int64_t C,
+                   int64_t inner, float s0, float mult, int dtype, void* stream);
+int lyc_chan_reduce(const void* a, const void* b, const float* bias, float* dw, int64_t outer, int64_t C,
+                    int64_t inner, float mult, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LYCORIS_AMD_H */

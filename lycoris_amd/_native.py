@@ -1,0 +1,105 @@
+"""ctypes binding of the C-ABI library ``liblycoris_amd.so`` (include/lycoris_amd.h).
+
+There is deliberately NO fallback: if the shared library is missing or an entry point fails, the
+caller gets a RuntimeError.  PyTorch is only used for device memory and streams here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch
+
+_LIB_NAME = "liblycoris_amd.so"
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+ABI_VERSION = 1
+
+LYC_F32, LYC_F16, LYC_BF16 = 0, 1, 2
+_DTYPE_CODE = {torch.float32: LYC_F32, torch.float16: LYC_F16, torch.bfloat16: LYC_BF16}
+
+_vp, _fp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes; mirrors include/lycoris_amd.h one to one (tests/test_abi.py checks the header against this)
+SIGNATURES = {
+    "lyc_lokr_linear_fwd": [_vp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    "lyc_lokr_linear_bwd": [_vp, _vp, _fp, _fp, _vp, _fp, _fp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    "lyc_locon_linear_fwd": [_vp, _fp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
+    "lyc_locon_linear_bwd": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _fp, _fp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
+    "lyc_chan_scale": [_vp, _fp, _fp, _vp, _i64, _i64, _i64, _f32, _f32, _i32, _vp],
+    "lyc_chan_reduce": [_vp, _vp, _fp, _fp, _i64, _i64, _i64, _f32, _i32, _vp],
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises NativeLibraryError when it cannot."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIB_PATH):
+            raise NativeLibraryError(
+                f"{_LIB_NAME} not found at {_LIB_PATH}. lycoris_amd has no fallback path: build the HIP library "
+                "first (python -c 'import __graft_entry__ as g; g.build()' or make -C lycoris_amd/csrc)."
+            )
+        try:
+            lib = ctypes.CDLL(_LIB_PATH)
+        except OSError as e:  # missing ROCm runtime etc.
+            raise NativeLibraryError(f"cannot load {_LIB_PATH}: {e}") from e
+        lib.lyc_abi_version.restype = ctypes.c_int
+        lib.lyc_abi_version.argtypes = []
+        lib.lyc_last_error.restype = ctypes.c_char_p
+        lib.lyc_last_error.argtypes = []
+        got = lib.lyc_abi_version()
+        if got != ABI_VERSION:
+            raise NativeLibraryError(f"{_LIB_PATH}: ABI version {got}, expected {ABI_VERSION}; rebuild the library")
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError -> missing export, fail loudly
+            fn.restype = ctypes.c_int
+            fn.argtypes = argtypes
+        _lib = lib
+        return _lib
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.lyc_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{name} failed (code {rc}): {msg}")
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    try:
+        return _DTYPE_CODE[dtype]
+    except KeyError:
+        raise TypeError(f"lycoris_amd supports float32/float16/bfloat16 activations, got {dtype}") from None
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_device(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"lycoris_amd: {what} is on {t.device}; the adapter hot path only runs on the MI355X HIP device "
+            "(there is no CPU fallback by design)."
+        )

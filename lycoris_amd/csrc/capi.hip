@@ -1,0 +1,272 @@
+// capi.hip -- C ABI launchers (include/lycoris_amd.h).  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/lycoris_amd.h"
+#include "ia3_kernels.h"
+#include "lokr_kernels.h"
+#include "skinny_kernels.h"
+
+using namespace lyc;
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(LYC_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return LYC_OK;
+}
+
+inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+inline long round_up(long a, long b) { return cdiv(a, b) * b; }
+
+#define DISPATCH_DTYPE(dtype, ...)                                   \
+  switch (dtype) {                                                   \
+    case LYC_BF16: { using T = __bf16; __VA_ARGS__; } break;         \
+    case LYC_F16: { using T = _Float16; __VA_ARGS__; } break;        \
+    case LYC_F32: { using T = float; __VA_ARGS__; } break;           \
+    default: return fail(LYC_ERR_ARG, "unknown dtype %d", dtype);    \
+  }
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+void launch_kron(const KronArgs& ka, hipStream_t st) {
+  const int TM = KronCfg<T>::RT / ka.Gin;
+  const bool wide = (ka.N % 64 == 0) || ka.N >= 256;
+  dim3 grid((unsigned)cdiv(ka.M, TM), (unsigned)cdiv(ka.N, wide ? 64 : 32));
+  if (wide)
+    hipLaunchKernelGGL((kron_kernel<T, 64>), grid, dim3(NTHREADS), 0, st, ka);
+  else
+    hipLaunchKernelGGL((kron_kernel<T, 32>), grid, dim3(NTHREADS), 0, st, ka);
+}
+
+template <typename T>
+void launch_kron_dw2(KronDw2Args da, hipStream_t st) {
+  const long rows_total = da.M * da.Gs;
+  const int mi = da.I <= 64 ? 4 : da.I <= 128 ? 8 : da.I <= 192 ? 12 : 16;
+  const long tiles = cdiv(da.I, 16 * mi) * cdiv(da.J, 64);
+  long split = cdiv(512, tiles);
+  const long max_split = cdiv(rows_total, 64);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  da.rows_per_block = round_up(cdiv(rows_total, split), 32);
+  split = cdiv(rows_total, da.rows_per_block);
+  dim3 grid((unsigned)cdiv(da.I, 16 * mi), (unsigned)cdiv(da.J, 64), (unsigned)split);
+  switch (mi) {
+    case 4: hipLaunchKernelGGL((kron_dw2_kernel<T, 4>), grid, dim3(NTHREADS), 0, st, da); break;
+    case 8: hipLaunchKernelGGL((kron_dw2_kernel<T, 8>), grid, dim3(NTHREADS), 0, st, da); break;
+    case 12: hipLaunchKernelGGL((kron_dw2_kernel<T, 12>), grid, dim3(NTHREADS), 0, st, da); break;
+    default: hipLaunchKernelGGL((kron_dw2_kernel<T, 16>), grid, dim3(NTHREADS), 0, st, da); break;
+  }
+}
+
+int check_kron_dims(int64_t M, int a, int b, int c, int d) {
+  if (M < 0 || a < 1 || b < 1 || c < 1 || d < 1) return fail(LYC_ERR_ARG, "lokr: bad dims M=%ld a=%d b=%d c=%d d=%d", (long)M, a, b, c, d);
+  if (a > 128 || b > 128)
+    return fail(LYC_ERR_UNSUPPORTED, "lokr: w1 is %dx%d; the small Kronecker factor is limited to 128x128", a, b);
+  return LYC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+void launch_skinny_nt(SkinnyArgs sa, hipStream_t st) {
+  constexpr int BK = SkinnyCfg<T>::BK;
+  const long mt = cdiv(sa.M, 64);
+  long split = cdiv(256, mt);
+  const long max_split = cdiv(sa.K, 2 * BK);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  sa.chunk = round_up(cdiv(sa.K, split), BK);
+  split = cdiv(sa.K, sa.chunk);
+  const int ni = sa.Nn <= 16 ? 1 : sa.Nn <= 32 ? 2 : sa.Nn <= 64 ? 4 : 8;
+  dim3 grid((unsigned)mt, (unsigned)split, (unsigned)cdiv(sa.Nn, 16 * ni));
+  switch (ni) {
+    case 1: hipLaunchKernelGGL((skinny_nt_kernel<T, 1>), grid, dim3(NTHREADS), 0, st, sa); break;
+    case 2: hipLaunchKernelGGL((skinny_nt_kernel<T, 2>), grid, dim3(NTHREADS), 0, st, sa); break;
+    case 4: hipLaunchKernelGGL((skinny_nt_kernel<T, 4>), grid, dim3(NTHREADS), 0, st, sa); break;
+    default: hipLaunchKernelGGL((skinny_nt_kernel<T, 8>), grid, dim3(NTHREADS), 0, st, sa); break;
+  }
+}
+
+template <typename T>
+void launch_expand_nt(const SkinnyArgs& sa, hipStream_t st) {
+  dim3 grid((unsigned)cdiv(sa.M, 64), (unsigned)cdiv(sa.Nn, 128));
+  hipLaunchKernelGGL((expand_nt_kernel<T>), grid, dim3(NTHREADS), 0, st, sa);
+}
+
+template <typename T>
+void launch_skinny_tn(SkinnyArgs sa, hipStream_t st) {
+  const long it = cdiv(sa.K, 64);  // output row tiles
+  long split = cdiv(512, it);
+  const long max_split = cdiv(sa.M, 64);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  sa.chunk = round_up(cdiv(sa.M, split), 32);
+  split = cdiv(sa.M, sa.chunk);
+  const int ni = sa.Nn <= 16 ? 1 : sa.Nn <= 32 ? 2 : sa.Nn <= 64 ? 4 : 8;
+  dim3 grid((unsigned)it, (unsigned)split, (unsigned)cdiv(sa.Nn, 16 * ni));
+  switch (ni) {
+    case 1: hipLaunchKernelGGL((skinny_tn_kernel<T, 1>), grid, dim3(NTHREADS), 0, st, sa); break;
+    case 2: hipLaunchKernelGGL((skinny_tn_kernel<T, 2>), grid, dim3(NTHREADS), 0, st, sa); break;
+    case 4: hipLaunchKernelGGL((skinny_tn_kernel<T, 4>), grid, dim3(NTHREADS), 0, st, sa); break;
+    default: hipLaunchKernelGGL((skinny_tn_kernel<T, 8>), grid, dim3(NTHREADS), 0, st, sa); break;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int lyc_abi_version(void) { return LYC_ABI_VERSION; }
+const char* lyc_last_error(void) { return g_err; }
+
+int lyc_lokr_linear_fwd(const void* x, const float* w1, const float* w2, void* y, int64_t M, int a, int b, int c,
+                        int d, float alpha, int dtype, void* stream) {
+  if (int rc = check_kron_dims(M, a, b, c, d)) return rc;
+  if (!x || !w1 || !w2 || !y) return fail(LYC_ERR_ARG, "lokr_linear_fwd: null pointer");
+  if (M == 0) return LYC_OK;
+  KronArgs ka{};
+  ka.x = x; ka.y = y; ka.w1 = w1; ka.w2 = w2; ka.dw1 = nullptr; ka.xref = nullptr;
+  ka.M = M; ka.Gin = b; ka.K = d; ka.Gout = a; ka.N = c;
+  ka.s1o = b; ka.s1i = 1; ka.s2n = d; ka.s2k = 1; ka.alpha = alpha;
+  DISPATCH_DTYPE(dtype, launch_kron<T>(ka, (hipStream_t)stream));
+  return check_launch("lokr_linear_fwd");
+}
+
+int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const float* w2, void* dx, float* dw1,
+                        float* dw2, int64_t M, int a, int b, int c, int d, float alpha, int dtype, void* stream) {
+  if (int rc = check_kron_dims(M, a, b, c, d)) return rc;
+  if (!g || !x || !w1 || !w2) return fail(LYC_ERR_ARG, "lokr_linear_bwd: null pointer");
+  if (M == 0) return LYC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dx || dw1) {
+    // dx[m, u*d+v] = alpha * sum_p w1[p,u] * sum_q w2[q,v] * g[m, p*c+q]: the same kernel on (w1^T, w2^T),
+    // with the w1 gradient taken from its stage-1 result (GZ) against x.
+    if (!dx) return fail(LYC_ERR_ARG, "lokr_linear_bwd: dw1 requires dx (they share one pass over g)");
+    KronArgs ka{};
+    ka.x = g; ka.y = dx; ka.w1 = w1; ka.w2 = w2; ka.dw1 = dw1; ka.xref = dw1 ? x : nullptr;
+    ka.M = M; ka.Gin = a; ka.K = c; ka.Gout = b; ka.N = d;
+    ka.s1o = 1; ka.s1i = b; ka.s2n = 1; ka.s2k = d; ka.alpha = alpha;
+    DISPATCH_DTYPE(dtype, launch_kron<T>(ka, st));
+    if (int rc = check_launch("lokr_linear_bwd(dx)")) return rc;
+  }
+  if (dw2) {
+    KronDw2Args da{};
+    da.M = M; da.alpha = alpha; da.out = dw2;
+    if (d <= c) {  // rows of the output tile run over the smaller side (v), mix applied to g
+      da.Q = x; da.Gs = b; da.I = d; da.P = g; da.Gt = a; da.J = c;
+      da.W = w1; da.ws = 1; da.wt = b;  // W[s=u, t=p] = w1[p, u]
+      da.os = 1; da.oj = d;             // out(i=v, j=q) -> dw2[q*d + v]
+    } else {
+      da.Q = g; da.Gs = a; da.I = c; da.P = x; da.Gt = b; da.J = d;
+      da.W = w1; da.ws = b; da.wt = 1;  // W[s=p, t=u] = w1[p, u]
+      da.os = d; da.oj = 1;             // out(i=q, j=v) -> dw2[q*d + v]
+    }
+    DISPATCH_DTYPE(dtype, launch_kron_dw2<T>(da, st));
+    if (int rc = check_launch("lokr_linear_bwd(dw2)")) return rc;
+  }
+  return LYC_OK;
+}
+
+int lyc_locon_linear_fwd(const void* x, const float* down, const float* up, float* t, void* y, int64_t M, int I,
+                         int O, int r, float alpha, int dtype, void* stream) {
+  if (M < 0 || I < 1 || O < 1 || r < 1) return fail(LYC_ERR_ARG, "locon_linear_fwd: bad dims");
+  if (!x || !down || !up || !t || !y) return fail(LYC_ERR_ARG, "locon_linear_fwd: null pointer");
+  if (M == 0) return LYC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  SkinnyArgs s1{};
+  s1.A = x; s1.B = down; s1.out = t; s1.M = M; s1.K = I; s1.Nn = r; s1.lda = I;
+  s1.bn = I; s1.bk = 1; s1.os = r; s1.oj = 1; s1.alpha = 1.0f;
+  DISPATCH_DTYPE(dtype, launch_skinny_nt<T>(s1, st));
+  SkinnyArgs s2{};
+  s2.A = t; s2.B = up; s2.out = y; s2.M = M; s2.K = r; s2.Nn = O; s2.lda = r;
+  s2.bn = r; s2.bk = 1; s2.os = O; s2.oj = 1; s2.alpha = alpha;
+  DISPATCH_DTYPE(dtype, launch_expand_nt<T>(s2, st));
+  return check_launch("locon_linear_fwd");
+}
+
+int lyc_locon_linear_bwd(const void* g, const void* x, const float* down, const float* up, const float* t,
+                         float* dt, void* dx, float* d_down, float* d_up, int64_t M, int I, int O, int r,
+                         float alpha, int dtype, void* stream) {
+  if (M < 0 || I < 1 || O < 1 || r < 1) return fail(LYC_ERR_ARG, "locon_linear_bwd: bad dims");
+  if (!g || !x || !down || !up || !dt) return fail(LYC_ERR_ARG, "locon_linear_bwd: null pointer");
+  if (d_up && !t) return fail(LYC_ERR_ARG, "locon_linear_bwd: d_up needs t from the forward call");
+  if (M == 0) return LYC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  {  // dt[m, n] = alpha * sum_o g[m, o] * up[o, n]
+    SkinnyArgs s{};
+    s.A = g; s.B = up; s.out = dt; s.M = M; s.K = O; s.Nn = r; s.lda = O;
+    s.bn = 1; s.bk = r; s.os = r; s.oj = 1; s.alpha = alpha;
+    DISPATCH_DTYPE(dtype, launch_skinny_nt<T>(s, st));
+  }
+  if (d_up) {  // d_up[o, n] += alpha * sum_m g[m, o] * t[m, n]
+    SkinnyArgs s{};
+    s.A = g; s.B = t; s.out = d_up; s.M = M; s.K = O; s.Nn = r; s.lda = O;
+    s.bn = 1; s.bk = r; s.os = r; s.oj = 1; s.alpha = alpha;
+    DISPATCH_DTYPE(dtype, launch_skinny_tn<T>(s, st));
+  }
+  if (dx) {  // dx[m, i] = sum_n dt[m, n] * down[n, i]
+    SkinnyArgs s{};
+    s.A = dt; s.B = down; s.out = dx; s.M = M; s.K = r; s.Nn = I; s.lda = r;
+    s.bn = 1; s.bk = I; s.os = I; s.oj = 1; s.alpha = 1.0f;
+    DISPATCH_DTYPE(dtype, launch_expand_nt<T>(s, st));
+  }
+  if (d_down) {  // d_down[n, i] += sum_m dt[m, n] * x[m, i]
+    SkinnyArgs s{};
+    s.A = x; s.B = dt; s.out = d_down; s.M = M; s.K = I; s.Nn = r; s.lda = I;
+    s.bn = 1; s.bk = r; s.os = 1; s.oj = I; s.alpha = 1.0f;
+    DISPATCH_DTYPE(dtype, launch_skinny_tn<T>(s, st));
+  }
+  return check_launch("locon_linear_bwd");
+}
+
+int lyc_chan_scale(const void* in, const float* w, const float* bias, void* out, int64_t outer, int64_t C,
+                   int64_t inner, float s0, float mult, int dtype, void* stream) {
+  if (outer < 0 || C < 1 || inner < 1) return fail(LYC_ERR_ARG, "chan_scale: bad dims");
+  if (!in || !w || !out) return fail(LYC_ERR_ARG, "chan_scale: null pointer");
+  const long total = outer * C * inner;
+  if (total == 0) return LYC_OK;
+  ChanArgs ca{};
+  ca.a_in = in; ca.out = out; ca.w = w; ca.bias = bias; ca.outer = outer; ca.C = C; ca.inner = inner;
+  ca.s0 = s0; ca.mult = mult;
+  long blocks = cdiv(total, (long)NTHREADS * 8);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((chan_scale_kernel<T>), dim3((unsigned)blocks), dim3(NTHREADS), 0,
+                                           (hipStream_t)stream, ca));
+  return check_launch("chan_scale");
+}
+
+int lyc_chan_reduce(const void* a, const void* b, const float* bias, float* dw, int64_t outer, int64_t C,
+                    int64_t inner, float mult, int dtype, void* stream) {
+  if (outer < 0 || C < 1 || inner < 1) return fail(LYC_ERR_ARG, "chan_reduce: bad dims");
+  if (!a || !b || !dw) return fail(LYC_ERR_ARG, "chan_reduce: null pointer");
+  if (outer == 0) return LYC_OK;
+  ChanArgs ca{};
+  ca.a_in = a; ca.b_in = b; ca.dw = dw; ca.bias = bias; ca.outer = outer; ca.C = C; ca.inner = inner;
+  ca.mult = mult;
+  dim3 grid;
+  if (inner == 1) {
+    const long ct = cdiv(C, 64);
+    long slabs = cdiv(1024, ct);
+    const long max_slabs = cdiv(outer, 16);
+    if (slabs > max_slabs) slabs = max_slabs;
+    if (slabs < 1) slabs = 1;
+    grid = dim3((unsigned)ct, (unsigned)slabs);
+  } else {
+    if (outer > 65535) return fail(LYC_ERR_UNSUPPORTED, "chan_reduce: outer=%ld too large for the conv layout", (long)outer);
+    grid = dim3((unsigned)C, (unsigned)outer);
+  }
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, ca));
+  return check_launch("chan_reduce");
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+// ia3_kernels.h -- (IA)^3 per-channel scale kernels, gfx950 (HBM-bound streaming).
+//
+// Reference semantics (rebuild path, lycoris/modules/ia3.py:91-102, 129-144):
+//   out-side : y = base + op(x, W * (w*mult) by rows) = base + (base - bias) * (w[o] * mult)
+//   in-side  : y = base + op(x * (w[i]*mult), W)       (the dense op itself stays with rocBLAS / MIOpen)
+// Tensors are viewed as [outer, C, inner] (Linear: inner = 1; NCHW conv: inner = H*W).
+//
+//   chan_scale_kernel   : out = a_in * (s0 + w[c]*mult) [- bias[c] * w[c]*mult]
+//   chan_reduce_kernel  : dw[c] += mult * sum_{outer, inner} g * (b - bias[c])
+#pragma once
+#include "tile.h"
+
+namespace lyc {
+
+struct ChanArgs {
+  const void* a_in;    // T [outer, C, inner]
+  const void* b_in;    // T, second operand of the reduction
+  void* out;           // T
+  const float* w;      // [C]
+  const float* bias;   // [C] or nullptr
+  float* dw;           // [C] fp32, accumulated atomically
+  long outer;
+  long C;
+  long inner;
+  float s0, mult;
+};
+
+// out[o, c, i] = a[o, c, i] * (s0 + w[c] * mult) - bias[c] * w[c] * mult
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void chan_scale_kernel(ChanArgs a) {
+  constexpr int VEC = TT<T>::VEC;
+  const T* in = static_cast<const T*>(a.a_in);
+  T* out = static_cast<T*>(a.out);
+  const long total = a.outer * a.C * a.inner;
+  const bool vec_ok = ((a.inner == 1 ? a.C : a.inner) % VEC == 0) && vec_aligned<T>(in, VEC) && vec_aligned<T>(out, VEC);
+  const long stride = (long)gridDim.x * NTHREADS;
+  if (vec_ok) {
+    const long nvec = total / VEC;
+    for (long v = (long)blockIdx.x * NTHREADS + threadIdx.x; v < nvec; v += stride) {
+      const long e0 = v * VEC;
+      T iv[VEC], ov[VEC];
+      *reinterpret_cast<u32x4*>(iv) = *reinterpret_cast<const u32x4*>(in + e0);
+      if (a.inner == 1) {
+        const long c0 = e0 % a.C;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float wm = a.w[c0 + e] * a.mult;
+          const float b = a.bias ? a.bias[c0 + e] : 0.f;
+          ov[e] = TT<T>::from_f(TT<T>::to_f(iv[e]) * (a.s0 + wm) - b * wm);
+        }
+      } else {
+        const long c = (e0 / a.inner) % a.C;
+        const float wm = a.w[c] * a.mult;
+        const float b = a.bias ? a.bias[c] : 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) ov[e] = TT<T>::from_f(TT<T>::to_f(iv[e]) * (a.s0 + wm) - b * wm);
+      }
+      *reinterpret_cast<u32x4*>(out + e0) = *reinterpret_cast<u32x4*>(ov);
+    }
+  } else {
+    for (long e = (long)blockIdx.x * NTHREADS + threadIdx.x; e < total; e += stride) {
+      const long c = (e / a.inner) % a.C;
+      const float wm = a.w[c] * a.mult;
+      const float b = a.bias ? a.bias[c] : 0.f;
+      out[e] = TT<T>::from_f(TT<T>::to_f(in[e]) * (a.s0 + wm) - b * wm);
+    }
+  }
+}
+
+// dw[c] += mult * sum_{o, i} a[o, c, i] * (b[o, c, i] - bias[c])
+// Linear layout (inner == 1): block (x, y) owns 64 channels x a slab of rows; lanes run along channels
+// (coalesced), the 4 waves take interleaved rows, then LDS + one atomic per channel.
+// Conv layout (inner > 1): one block per (outer index, channel); the plane is reduced with wave shuffles.
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void chan_reduce_kernel(ChanArgs a) {
+  const T* A = static_cast<const T*>(a.a_in);
+  const T* B = static_cast<const T*>(a.b_in);
+  __shared__ float red[NTHREADS];
+  const int tid = threadIdx.x;
+  if (a.inner == 1) {
+    const long c = (long)blockIdx.x * 64 + (tid & 63);
+    const long rows_per = (a.outer + gridDim.y - 1) / gridDim.y;
+    const long rbeg = (long)blockIdx.y * rows_per;
+    long rend = rbeg + rows_per;
+    if (rend > a.outer) rend = a.outer;
+    float s = 0.f;
+    if (c < a.C) {
+      const float b = a.bias ? a.bias[c] : 0.f;
+      for (long r = rbeg + (tid >> 6); r < rend; r += NWAVES)
+        s = fmaf(TT<T>::to_f(A[r * a.C + c]), TT<T>::to_f(B[r * a.C + c]) - b, s);
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (tid < 64 && c < a.C) {
+      const float t = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+      __hip_atomic_fetch_add(a.dw + c, a.mult * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
+    const long c = blockIdx.x;
+    const long o = blockIdx.y;
+    const float b = a.bias ? a.bias[c] : 0.f;
+    const T* pa = A + (o * a.C + c) * a.inner;
+    const T* pb = B + (o * a.C + c) * a.inner;
+    float s = 0.f;
+    for (long i = tid; i < a.inner; i += NTHREADS) s = fmaf(TT<T>::to_f(pa[i]), TT<T>::to_f(pb[i]) - b, s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_fetch_add(a.dw + c, a.mult * (red[0] + red[1] + red[2] + red[3]), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+}  // namespace lyc

@@ -1,0 +1,64 @@
+"""Helpers for the -m gpu parity tests (HIP path vs the numpy oracle on identical, pre-rounded inputs)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import oracle
+
+# Tolerances (norm-wise relative error):
+#  * fp32 activations: MFMA fp32 accumulate vs float64 oracle.
+#  * fp32-emitted quantities (all factor gradients) on 16-bit activations: factors/intermediates enter the matrix
+#    cores as hi+lo pairs, so only fp32 accumulation error remains -> well inside the north-star 1e-3.
+#  * 16-bit stored outputs (y, dx): compared with the float64 oracle evaluated on the same rounded inputs AND
+#    rounded to the same storage type; the residual is rounding-boundary flips only -> 1e-3 (north-star bound).
+TOL = {
+    "f32_out": {torch.float32: 2e-5, torch.float16: 1e-4, torch.bfloat16: 1e-4},
+    "store_out": {torch.float32: 2e-5, torch.float16: 1e-3, torch.bfloat16: 1e-3},
+}
+NP_OF = {torch.float32: np.float32, torch.float16: np.float16}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(shape, dtype, gen, scale=1.0):
+    """Random tensor already rounded to `dtype`, returned as (device tensor, float64 numpy of the SAME values)."""
+    t = (torch.randn(*shape, generator=gen, dtype=torch.float32) * scale).to(dtype)
+    return t.to(dev()), t.double().numpy()
+
+
+def round_like(a64, dtype):
+    """Round a float64 oracle result to the storage dtype, back to float64."""
+    return torch.from_numpy(np.ascontiguousarray(a64)).to(dtype).double().numpy()
+
+
+def err(got: torch.Tensor, want64, dtype=None):
+    g = got.detach().double().cpu().numpy()
+    w = want64 if dtype is None else round_like(want64, dtype)
+    return oracle.general.rel_err(g.reshape(w.shape), w)
+
+
+_REPORT = {}
+
+
+def record(test, key, value, bound):
+    _REPORT.setdefault(test, {})[key] = {"err": value, "bound": bound}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump(_REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def check(test, errs: dict, bounds: dict):
+    bad = []
+    for k, v in errs.items():
+        record(test, k, v, bounds[k])
+        if not (v <= bounds[k]):
+            bad.append(f"{k}: {v:.3e} > {bounds[k]:.1e}")
+    assert not bad, f"{test}: " + "; ".join(bad)
