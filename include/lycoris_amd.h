@@ -26,6 +26,9 @@ extern "C" {
 #endif
 
 enum { LYC_F32 = 0, LYC_F16 = 1, LYC_BF16 = 2 };
+/* OR-able into `dtype`: the row-matrix side of the call (dx of the *_linear_bwd entry points, dcols of lyc_col2im)
+ * is fp32 instead of `dtype`.  Used by the Conv2d lowering so that col2im sums un-rounded rows and rounds once. */
+enum { LYC_F32_ROWS = 0x100 };
 enum { LYC_OK = 0, LYC_ERR_ARG = 1, LYC_ERR_UNSUPPORTED = 2, LYC_ERR_LAUNCH = 3 };
 
 #define LYC_ABI_VERSION 1
@@ -64,6 +67,36 @@ int lyc_chan_scale(const void* in, const float* w, const float* bias, void* out,
                    int64_t inner, float s0, float mult, int dtype, void* stream);
 int lyc_chan_reduce(const void* a, const void* b, const float* bias, float* dw, int64_t outer, int64_t C,
                     int64_t inner, float mult, int dtype, void* stream);
+
+/* ---- LoHa on nn.Linear -------------------------------------------------------------------------
+ * replaces lycoris/modules/loha.py:301-322 (forward) and lycoris/functional/loha.py:10-30
+ * (HadaWeight.forward / .backward).   w1a,w2a:[O,r]  w1b,w2b:[r,I]
+ *   dW = ((w1a @ w1b) * (w2a @ w2b)) * alpha ;  y = x @ dW^T
+ * `wplanes` is caller-owned scratch of lyc_loha_workspace_bytes(O, I, dtype) bytes: fwd fills it with the
+ * hi/lo matrix-core operand images of dW (both orientations), bwd reads it (pass the same buffer).
+ * `gw` is [O,I] fp32 scratch (no need to clear).  d_w* +=                                              */
+int64_t lyc_loha_workspace_bytes(int O, int I, int dtype);
+int lyc_loha_linear_fwd(const void* x, const float* w1a, const float* w1b, const float* w2a, const float* w2b,
+                        void* wplanes, void* y, int64_t M, int I, int O, int r, float alpha, int dtype,
+                        void* stream);
+int lyc_loha_linear_bwd(const void* g, const void* x, const float* w1a, const float* w1b, const float* w2a,
+                        const float* w2b, const void* wplanes, float* gw, void* dx, float* d_w1a, float* d_w1b,
+                        float* d_w2a, float* d_w2b, int64_t M, int I, int O, int r, float alpha, int dtype,
+                        void* stream);
+
+/* ---- Conv2d lowering (NCHW, groups = 1) --------------------------------------------------------
+ * The Conv2d form of every adapter (F.conv2d in lycoris/functional/general.py:6, kw_dict of
+ * lycoris/modules/base.py:101-121) is evaluated as its Linear entry point on the im2col view
+ *   cols[(b,oh,ow), c*kh*kw + i*kw + j] = x[b, c, oh*sh-ph+i*dh, ow*sw-pw+j*dw]
+ * which matches the reference's own [r, I*kh*kw] / [c, d*kh*kw] conv factor layouts:
+ *   rows = lyc_im2col(x); y_rows = lyc_<algo>_linear_fwd(rows, ...); y = lyc_rows_to_nchw(y_rows)
+ *   backward: g_rows = lyc_nchw_to_rows(g); ... ; dx = lyc_col2im(d_rows)                              */
+int lyc_im2col(const void* x, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw, int sh,
+               int sw, int ph, int pw, int dh, int dw, int dtype, void* stream);
+int lyc_col2im(const void* dcols, void* dx, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw, int sh,
+               int sw, int ph, int pw, int dh, int dw, int dtype, void* stream);
+int lyc_nchw_to_rows(const void* t, void* rows, int64_t B, int64_t C, int64_t P, int dtype, void* stream);
+int lyc_rows_to_nchw(const void* rows, void* t, int64_t B, int64_t C, int64_t P, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

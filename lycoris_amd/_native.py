@@ -28,7 +28,16 @@ SIGNATURES = {
     "lyc_locon_linear_bwd": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _fp, _fp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_chan_scale": [_vp, _fp, _fp, _vp, _i64, _i64, _i64, _f32, _f32, _i32, _vp],
     "lyc_chan_reduce": [_vp, _vp, _fp, _fp, _i64, _i64, _i64, _f32, _i32, _vp],
+    "lyc_loha_linear_fwd": [_vp, _fp, _fp, _fp, _fp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
+    "lyc_loha_linear_bwd": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _fp, _vp, _fp, _fp, _fp, _fp, _i64, _i32, _i32, _i32,
+                            _f32, _i32, _vp],
+    "lyc_im2col": [_vp, _vp, _i64, _i64, _i64, _i64] + [_i32] * 8 + [_i32, _vp],
+    "lyc_col2im": [_vp, _vp, _i64, _i64, _i64, _i64] + [_i32] * 8 + [_i32, _vp],
+    "lyc_nchw_to_rows": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
+    "lyc_rows_to_nchw": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
 }
+# entry points that return something other than a status code
+VALUE_SIGNATURES = {"lyc_loha_workspace_bytes": ([_i32, _i32, _i32], ctypes.c_int64)}
 
 _lock = threading.Lock()
 _lib = None
@@ -69,6 +78,10 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError -> missing export, fail loudly
             fn.restype = ctypes.c_int
+            fn.argtypes = argtypes
+        for name, (argtypes, restype) in VALUE_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
             fn.argtypes = argtypes
         _lib = lib
         return _lib

@@ -4,6 +4,8 @@
 #include <stdio.h>
 
 #include "../../include/lycoris_amd.h"
+#include "conv_kernels.h"
+#include "dense_kernels.h"
 #include "ia3_kernels.h"
 #include "lokr_kernels.h"
 #include "skinny_kernels.h"
@@ -30,12 +32,12 @@ int check_launch(const char* what) {
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 inline long round_up(long a, long b) { return cdiv(a, b) * b; }
 
-#define DISPATCH_DTYPE(dtype, ...)                                   \
-  switch (dtype) {                                                   \
+#define DISPATCH_DTYPE(dtype_, ...)                                  \
+  switch ((dtype_) & 0xff) {                                                   \
     case LYC_BF16: { using T = __bf16; __VA_ARGS__; } break;         \
     case LYC_F16: { using T = _Float16; __VA_ARGS__; } break;        \
     case LYC_F32: { using T = float; __VA_ARGS__; } break;           \
-    default: return fail(LYC_ERR_ARG, "unknown dtype %d", dtype);    \
+    default: return fail(LYC_ERR_ARG, "unknown dtype %d", (int)(dtype_));    \
   }
 
 // ------------------------------------------------------------------------------------------------
@@ -155,7 +157,7 @@ int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const flo
     KronArgs ka{};
     ka.x = g; ka.y = dx; ka.w1 = w1; ka.w2 = w2; ka.dw1 = dw1; ka.xref = dw1 ? x : nullptr;
     ka.M = M; ka.Gin = a; ka.K = c; ka.Gout = b; ka.N = d;
-    ka.s1o = 1; ka.s1i = b; ka.s2n = 1; ka.s2k = d; ka.alpha = alpha;
+    ka.s1o = 1; ka.s1i = b; ka.s2n = 1; ka.s2k = d; ka.alpha = alpha; ka.out_f32 = (dtype & LYC_F32_ROWS) ? 1 : 0;
     DISPATCH_DTYPE(dtype, launch_kron<T>(ka, st));
     if (int rc = check_launch("lokr_linear_bwd(dx)")) return rc;
   }
@@ -217,7 +219,7 @@ int lyc_locon_linear_bwd(const void* g, const void* x, const float* down, const 
   if (dx) {  // dx[m, i] = sum_n dt[m, n] * down[n, i]
     SkinnyArgs s{};
     s.A = dt; s.B = down; s.out = dx; s.M = M; s.K = r; s.Nn = I; s.lda = r;
-    s.bn = 1; s.bk = I; s.os = I; s.oj = 1; s.alpha = 1.0f;
+    s.bn = 1; s.bk = I; s.os = I; s.oj = 1; s.alpha = 1.0f; s.out_f32 = (dtype & LYC_F32_ROWS) ? 1 : 0;
     DISPATCH_DTYPE(dtype, launch_expand_nt<T>(s, st));
   }
   if (d_down) {  // d_down[n, i] += sum_m dt[m, n] * x[m, i]
@@ -267,6 +269,163 @@ int lyc_chan_reduce(const void* a, const void* b, const float* bias, float* dw, 
   }
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, ca));
   return check_launch("chan_reduce");
+}
+
+
+// ---- LoHa ------------------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+struct LohaPlanes {
+  char *nh, *nl, *th, *tl;
+  long ldn, ldt;
+};
+LohaPlanes loha_planes(void* base, int O, int I, size_t esz) {
+  LohaPlanes p;
+  p.ldn = round_up(I, 16 / (long)esz);
+  p.ldt = round_up(O, 16 / (long)esz);
+  char* b = static_cast<char*>(base);
+  const size_t n = (size_t)O * p.ldn * esz, t = (size_t)I * p.ldt * esz;
+  p.nh = b; p.nl = b + n; p.th = b + 2 * n; p.tl = b + 2 * n + t;
+  return p;
+}
+size_t esize(int dtype) { return (dtype & 0xff) == LYC_F32 ? 4 : 2; }
+}  // namespace
+}  // extern "C++"
+
+int64_t lyc_loha_workspace_bytes(int O, int I, int dtype) {
+  const long esz = (long)esize(dtype);
+  return 2 * ((int64_t)O * round_up(I, 16 / esz) + (int64_t)I * round_up(O, 16 / esz)) * esz;
+}
+
+int lyc_loha_linear_fwd(const void* x, const float* w1a, const float* w1b, const float* w2a, const float* w2b,
+                        void* wplanes, void* y, int64_t M, int I, int O, int r, float alpha, int dtype,
+                        void* stream) {
+  if (M < 0 || I < 1 || O < 1 || r < 1) return fail(LYC_ERR_ARG, "loha_linear_fwd: bad dims");
+  if (!x || !w1a || !w1b || !w2a || !w2b || !wplanes || !y) return fail(LYC_ERR_ARG, "loha_linear_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  LohaPlanes pl = loha_planes(wplanes, O, I, esize(dtype));
+  LohaArgs la{};
+  la.w1a = w1a; la.w1b = w1b; la.w2a = w2a; la.w2b = w2b; la.O = O; la.I = I; la.R = r; la.scale = alpha;
+  la.Wn_h = pl.nh; la.Wn_l = pl.nl; la.Wt_h = pl.th; la.Wt_l = pl.tl; la.ldn = pl.ldn; la.ldt = pl.ldt;
+  dim3 rg((unsigned)cdiv(O, LOHA_T), (unsigned)cdiv(I, LOHA_T));
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((loha_rebuild_kernel<T>), rg, dim3(NTHREADS), 0, st, la));
+  if (M > 0) {
+    GemmArgs ga{};
+    ga.A = x; ga.Bh = pl.nh; ga.Bl = pl.nl; ga.out = y; ga.M = M; ga.N = O; ga.K = I;
+    ga.lda = I; ga.ldb = pl.ldn; ga.ldo = O; ga.alpha = 1.0f;
+    dim3 gg((unsigned)cdiv(M, 128), (unsigned)cdiv(O, 128));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_nt_kernel<T>), gg, dim3(NTHREADS), 0, st, ga));
+  }
+  return check_launch("loha_linear_fwd");
+}
+
+int lyc_loha_linear_bwd(const void* g, const void* x, const float* w1a, const float* w1b, const float* w2a,
+                        const float* w2b, const void* wplanes, float* gw, void* dx, float* d_w1a, float* d_w1b,
+                        float* d_w2a, float* d_w2b, int64_t M, int I, int O, int r, float alpha, int dtype,
+                        void* stream) {
+  if (M < 0 || I < 1 || O < 1 || r < 1) return fail(LYC_ERR_ARG, "loha_linear_bwd: bad dims");
+  if (!g || !x || !w1a || !w1b || !w2a || !w2b || !wplanes) return fail(LYC_ERR_ARG, "loha_linear_bwd: null pointer");
+  const bool want_factors = d_w1a || d_w1b || d_w2a || d_w2b;
+  if (want_factors && !(d_w1a && d_w1b && d_w2a && d_w2b && gw))
+    return fail(LYC_ERR_ARG, "loha_linear_bwd: factor gradients come as a set of four and need the gw scratch");
+  if (M == 0) return LYC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  LohaPlanes pl = loha_planes(const_cast<void*>(wplanes), O, I, esize(dtype));
+  if (dx) {  // dx = g @ dW : B operand rows = i, K = o  -> the transposed planes
+    GemmArgs ga{};
+    ga.A = g; ga.Bh = pl.th; ga.Bl = pl.tl; ga.out = dx; ga.M = M; ga.N = I; ga.K = O;
+    ga.lda = O; ga.ldb = pl.ldt; ga.ldo = I; ga.alpha = 1.0f; ga.out_f32 = (dtype & LYC_F32_ROWS) ? 1 : 0;
+    dim3 gg((unsigned)cdiv(M, 128), (unsigned)cdiv(I, 128));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_nt_kernel<T>), gg, dim3(NTHREADS), 0, st, ga));
+  }
+  if (want_factors) {  // G = g^T x (fp32, [O, I]), then the Hadamard chain rule on the factors
+    GemmArgs ga{};
+    ga.A = g; ga.Bh = x; ga.out = gw; ga.M = O; ga.N = I; ga.K = M;
+    ga.lda = O; ga.ldb = I; ga.ldo = I; ga.alpha = 1.0f; ga.atomic = 0; ga.chunk = M;
+    dim3 gg((unsigned)cdiv(O, 128), (unsigned)cdiv(I, 128), 1);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_tn_kernel<T>), gg, dim3(NTHREADS), 0, st, ga));
+    LohaArgs la{};
+    la.w1a = w1a; la.w1b = w1b; la.w2a = w2a; la.w2b = w2b; la.O = O; la.I = I; la.R = r; la.scale = alpha;
+    la.G = gw; la.d_w1a = d_w1a; la.d_w1b = d_w1b; la.d_w2a = d_w2a; la.d_w2b = d_w2b;
+    dim3 fg((unsigned)cdiv(O, LOHA_T), (unsigned)cdiv(I, LOHA_T));
+    hipLaunchKernelGGL(loha_factor_grad_kernel, fg, dim3(NTHREADS), 0, st, la);
+  }
+  return check_launch("loha_linear_bwd");
+}
+
+// ---- Conv2d lowering -------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+int conv_geom(ConvGeom& cg, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int ph,
+              int pw, int dh, int dw) {
+  if (B < 0 || C < 1 || H < 1 || W < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0 || dh < 1 || dw < 1)
+    return fail(LYC_ERR_ARG, "conv lowering: bad geometry");
+  cg.B = B; cg.C = C; cg.H = H; cg.W = W; cg.kh = kh; cg.kw = kw; cg.sh = sh; cg.sw = sw; cg.ph = ph; cg.pw = pw;
+  cg.dh = dh; cg.dw = dw;
+  cg.Ho = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1;
+  cg.Wo = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
+  if (cg.Ho < 1 || cg.Wo < 1) return fail(LYC_ERR_ARG, "conv lowering: empty output");
+  return LYC_OK;
+}
+unsigned stream_blocks(long total) {
+  long b = cdiv(total, (long)NTHREADS * 4);
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+}  // namespace
+}  // extern "C++"
+
+int lyc_im2col(const void* x, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw, int sh,
+               int sw, int ph, int pw, int dh, int dw, int dtype, void* stream) {
+  ConvGeom cg{};
+  if (int rc = conv_geom(cg, B, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw)) return rc;
+  if (!x || !cols) return fail(LYC_ERR_ARG, "im2col: null pointer");
+  if (B == 0) return LYC_OK;
+  const long total = cg.B * cg.Ho * cg.Wo * cg.C * kh * kw;
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((im2col_kernel<T>), dim3(stream_blocks(total)), dim3(NTHREADS), 0,
+                                           (hipStream_t)stream, static_cast<const T*>(x), static_cast<T*>(cols), cg));
+  return check_launch("im2col");
+}
+
+int lyc_col2im(const void* dcols, void* dx, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw, int sh,
+               int sw, int ph, int pw, int dh, int dw, int dtype, void* stream) {
+  ConvGeom cg{};
+  if (int rc = conv_geom(cg, B, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw)) return rc;
+  if (!dcols || !dx) return fail(LYC_ERR_ARG, "col2im: null pointer");
+  if (B == 0) return LYC_OK;
+  const long total = cg.B * cg.C * cg.H * cg.W;
+  if (dtype & LYC_F32_ROWS) {
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((col2im_kernel<T, float>), dim3(stream_blocks(total)), dim3(NTHREADS), 0,
+                                             (hipStream_t)stream, static_cast<const float*>(dcols), static_cast<T*>(dx), cg));
+  } else {
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((col2im_kernel<T, T>), dim3(stream_blocks(total)), dim3(NTHREADS), 0,
+                                             (hipStream_t)stream, static_cast<const T*>(dcols), static_cast<T*>(dx), cg));
+  }
+  return check_launch("col2im");
+}
+
+extern "C++" {
+namespace {
+template <bool TO_ROWS>
+int launch_nchw_rows(const void* in, void* out, int64_t B, int64_t C, int64_t P, int dtype, void* stream) {
+  if (B < 0 || C < 1 || P < 1) return fail(LYC_ERR_ARG, "nchw<->rows: bad dims");
+  if (!in || !out) return fail(LYC_ERR_ARG, "nchw<->rows: null pointer");
+  if (B == 0) return LYC_OK;
+  if (B > 65535 || cdiv(C, 32) > 65535) return fail(LYC_ERR_UNSUPPORTED, "nchw<->rows: grid too large");
+  dim3 grid((unsigned)cdiv(P, 32), (unsigned)cdiv(C, 32), (unsigned)B);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((nchw_rows_kernel<T, TO_ROWS>), grid, dim3(NTHREADS), 0, (hipStream_t)stream,
+                                           static_cast<const T*>(in), static_cast<T*>(out), (long)B, (long)C, (long)P));
+  return check_launch("nchw<->rows");
+}
+}  // namespace
+}  // extern "C++"
+
+int lyc_nchw_to_rows(const void* t, void* rows, int64_t B, int64_t C, int64_t P, int dtype, void* stream) {
+  return launch_nchw_rows<true>(t, rows, B, C, P, dtype, stream);
+}
+int lyc_rows_to_nchw(const void* rows, void* t, int64_t B, int64_t C, int64_t P, int dtype, void* stream) {
+  return launch_nchw_rows<false>(rows, t, B, C, P, dtype, stream);
 }
 
 }  // extern "C"

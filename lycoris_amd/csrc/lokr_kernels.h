@@ -31,6 +31,7 @@ struct KronArgs {
   int Gin, K, Gout, N;
   long s1o, s1i, s2n, s2k;
   float alpha;
+  int out_f32;       // write y as fp32 rows (LYC_F32_ROWS)
 };
 
 template <typename T>
@@ -120,6 +121,11 @@ __global__ __launch_bounds__(NTHREADS) void kron_kernel(KronArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[4 * e4 + e] = fmaf(w, h[e], o[4 * e4 + e]);
           }
+        }
+        if (a.out_f32) {
+          float* dstf = static_cast<float*>(a.y) + gm * ldy + (long)po * N + gn;
+          for (int e = 0; e < NV && gn + e < N; ++e) dstf[e] = a.alpha * o[e];
+          continue;
         }
         T ov[NV];
 #pragma unroll

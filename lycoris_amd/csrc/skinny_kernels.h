@@ -29,6 +29,7 @@ struct SkinnyArgs {
   long os, oj;       // output element (row, col) at row * os + col * oj
   long chunk;        // contraction elements per workgroup (multiple of the K tile)
   float alpha;
+  int out_f32;       // expand_nt: write fp32 rows instead of T (LYC_F32_ROWS)
 };
 
 template <typename T>
@@ -84,7 +85,6 @@ __global__ __launch_bounds__(NTHREADS) void expand_nt_kernel(SkinnyArgs a) {
   T* Bl = Bh + TN * LD;
   float* Os = reinterpret_cast<float*>(smem);
   const float* A = static_cast<const float*>(a.A);
-  T* out = static_cast<T*>(a.out);
   const int wave = threadIdx.x >> 6;
   const long m0 = (long)blockIdx.x * TM;
   const long n0 = (long)blockIdx.y * TN;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(NTHREADS) void expand_nt_kernel(SkinnyArgs a) {
   }
   acc_to_lds<1, NI>(Os, LDO, acc, wave * 16, 0, a.alpha);
   __syncthreads();
-  store_tile<T, TM, TN>(out, a.os, Os, LDO, m0, a.M, n0, a.Nn, vec_aligned<T>(out, a.os));
+  store_tile<T, TM, TN>(a.out, a.os, Os, LDO, m0, a.M, n0, a.Nn, a.out_f32 != 0);
 }
 
 // out32[i, n] += alpha * sum_k A[k, i] * B[k, n]     (A row-major [Kd, I], contraction over its rows)

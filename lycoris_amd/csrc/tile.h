@@ -86,6 +86,12 @@ __device__ __forceinline__ f32x4 zero4() {
   return z;
 }
 
+// true when `p` and a row pitch of `ld` elements keep every VEC-aligned column 16-byte aligned
+template <typename T>
+__host__ __device__ __forceinline__ bool vec_aligned(const void* p, long ld) {
+  return ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) && ((ld * (long)sizeof(T)) % 16 == 0);
+}
+
 // hi/lo split of an fp32 value into two T values (T = float: lo unused).
 template <typename T>
 __device__ __forceinline__ void split_f(float v, T& hi, T& lo) {
@@ -344,41 +350,47 @@ __device__ __forceinline__ void acc_atomic_add(float* dst, long rs, long cs, lon
       }
 }
 
-// Cooperative coalesced store of an fp32 LDS tile to a T-typed row-major global matrix
-// (16 bytes per lane when alignment allows), optionally adding a T-typed `addend` (fused base + delta).
+// Cooperative coalesced store of an fp32 LDS tile to a row-major global matrix (16 bytes per lane when alignment
+// allows).  The destination holds T elements, or fp32 when `dst_f32` (LYC_F32_ROWS: un-rounded rows for col2im).
 template <typename T, int ROWS, int COLS>
-__device__ __forceinline__ void store_tile(T* __restrict__ dst, long ld_dst, const float* __restrict__ tile, int ld_tile,
-                                           long row0, long rows_total, long col0, long cols_total, bool vec_ok) {
-  constexpr int VEC = TT<T>::VEC;
+__device__ __forceinline__ void store_tile(void* __restrict__ dst_, long ld_dst, const float* __restrict__ tile,
+                                           int ld_tile, long row0, long rows_total, long col0, long cols_total,
+                                           bool dst_f32) {
   const int tid = threadIdx.x;
-  if (vec_ok) {
-    constexpr int VPR = COLS / VEC;
+  if (dst_f32 || sizeof(T) == 4) {
+    float* dst = static_cast<float*>(dst_);
+    const bool vec_ok = vec_aligned<float>(dst, ld_dst);
+    constexpr int VPR = COLS / 4;
     for (int v = tid; v < ROWS * VPR; v += NTHREADS) {
-      const int r = v / VPR, c = (v % VPR) * VEC;
+      const int r = v / VPR, c = (v % VPR) * 4;
       const long gr = row0 + r, gc = col0 + c;
       if (gr >= rows_total || gc >= cols_total) continue;
-      T tmp[VEC];
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) tmp[e] = TT<T>::from_f(tile[r * ld_tile + c + e]);
-      if (gc + VEC <= cols_total) {
-        *reinterpret_cast<u32x4*>(dst + gr * ld_dst + gc) = *reinterpret_cast<u32x4*>(tmp);
+      const f32x4 val = *reinterpret_cast<const f32x4*>(tile + r * ld_tile + c);
+      if (vec_ok && gc + 4 <= cols_total) {
+        *reinterpret_cast<f32x4*>(dst + gr * ld_dst + gc) = val;
       } else {
-        for (int e = 0; e < VEC && gc + e < cols_total; ++e) dst[gr * ld_dst + gc + e] = tmp[e];
+        for (int e = 0; e < 4 && gc + e < cols_total; ++e) dst[gr * ld_dst + gc + e] = val[e];
       }
     }
-  } else {
-    for (int e = tid; e < ROWS * COLS; e += NTHREADS) {
-      const int r = e / COLS, c = e % COLS;
-      const long gr = row0 + r, gc = col0 + c;
-      if (gr < rows_total && gc < cols_total) dst[gr * ld_dst + gc] = TT<T>::from_f(tile[r * ld_tile + c]);
+    return;
+  }
+  T* dst = static_cast<T*>(dst_);
+  constexpr int VEC = TT<T>::VEC;
+  const bool vec_ok = vec_aligned<T>(dst, ld_dst);
+  constexpr int VPR = COLS / VEC;
+  for (int v = tid; v < ROWS * VPR; v += NTHREADS) {
+    const int r = v / VPR, c = (v % VPR) * VEC;
+    const long gr = row0 + r, gc = col0 + c;
+    if (gr >= rows_total || gc >= cols_total) continue;
+    T tmp[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) tmp[e] = TT<T>::from_f(tile[r * ld_tile + c + e]);
+    if (vec_ok && gc + VEC <= cols_total) {
+      *reinterpret_cast<u32x4*>(dst + gr * ld_dst + gc) = *reinterpret_cast<u32x4*>(tmp);
+    } else {
+      for (int e = 0; e < VEC && gc + e < cols_total; ++e) dst[gr * ld_dst + gc + e] = tmp[e];
     }
   }
-}
-
-// true when `p` and a row pitch of `ld` elements keep every VEC-aligned column 16-byte aligned
-template <typename T>
-__host__ __device__ __forceinline__ bool vec_aligned(const void* p, long ld) {
-  return ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) && ((ld * (long)sizeof(T)) % 16 == 0);
 }
 
 }  // namespace lyc

@@ -1,0 +1,295 @@
+"""Adapter module base: the plug boundary between a host model's nn.Linear / nn.Conv2d and the HIP kernels.
+
+Interface contract taken from the reference (lycoris/modules/base.py): constructor bookkeeping (:71-198),
+forward patching with a per-layer wrapper stack (``apply_to`` :271-287, ``restore`` :289-324), ``merge_to``
+(:326-342), ``onfly_merge`` / ``onfly_restore`` (:344-374), state-dict customisation (:11-61) and the registry
+class methods ``algo_check`` / ``extract_state_dict`` / ``make_module_from_state_dict`` (:236-246).  The same
+attribute names (``_lycoris_wrappers``, ``_lycoris_original_forward``) are used on the wrapped layer so native
+and reference adapters can be stacked on one layer.
+
+What is NOT here on purpose: any CPU arithmetic for ``forward``.  ``forward`` always runs the HIP kernels and
+raises on CPU tensors.  ``get_diff_weight`` / ``merge_to`` materialise dW with plain tensor ops -- that is the
+definition of merging, it is off the training hot path.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_STACK = "_lycoris_wrappers"
+_ORIG = "_lycoris_original_forward"
+
+
+def _unsupported(what: str):
+    return NotImplementedError(
+        f"lycoris_amd: {what} is not on the native path (see DESIGN.md, 'out of scope / next'); "
+        "there is no silent fallback."
+    )
+
+
+class LycorisBaseModule(nn.Module):
+    name: str = "base"
+    support_module: set = set()
+    weight_list: list = []
+    weight_list_det: list = []
+
+    def __init__(self, lora_name, org_module: nn.Module, multiplier=1.0, dropout=0.0, rank_dropout=0.0,
+                 module_dropout=0.0, rank_dropout_scale=False, bypass_mode=None, **kwargs):
+        super().__init__()
+        self.lora_name = lora_name
+        self.not_supported = False
+        self.module = type(org_module)
+        self.kw_dict = {}
+        if isinstance(org_module, nn.Linear):
+            self.module_type = "linear"
+            self.shape = (org_module.out_features, org_module.in_features)
+            self.op = F.linear
+            self.dim = org_module.out_features
+        elif isinstance(org_module, (nn.Conv1d, nn.Conv2d, nn.Conv3d)):
+            nd = {nn.Conv1d: 1, nn.Conv2d: 2, nn.Conv3d: 3}[next(c for c in (nn.Conv1d, nn.Conv2d, nn.Conv3d)
+                                                                  if isinstance(org_module, c))]
+            self.module_type = f"conv{nd}d"
+            self.shape = (org_module.out_channels, org_module.in_channels, *org_module.kernel_size)
+            self.op = (F.conv1d, F.conv2d, F.conv3d)[nd - 1]
+            self.dim = org_module.out_channels
+            self.kw_dict = {"stride": org_module.stride, "padding": org_module.padding,
+                            "dilation": org_module.dilation, "groups": org_module.groups}
+        elif isinstance(org_module, nn.LayerNorm):
+            self.module_type = "layernorm"
+            self.shape = tuple(org_module.normalized_shape)
+            self.op = F.layer_norm
+            self.dim = org_module.normalized_shape[0]
+            self.kw_dict = {"normalized_shape": org_module.normalized_shape, "eps": org_module.eps}
+        elif isinstance(org_module, nn.GroupNorm):
+            self.module_type = "groupnorm"
+            self.shape = (org_module.num_channels,)
+            self.op = F.group_norm
+            self.group_num = org_module.num_groups
+            self.dim = org_module.num_channels
+            self.kw_dict = {"num_groups": org_module.num_groups, "eps": org_module.eps}
+        else:
+            self.not_supported = True
+            self.module_type = "unknown"
+
+        self.register_buffer("dtype_tensor", torch.tensor(0.0), persistent=False)
+        # A Linear subclass that is not exactly nn.Linear is treated as quantised by the reference and forced into
+        # bypass mode (base.py:162-177).  Natively both modes are the same factored computation on x.
+        self.is_quant = isinstance(org_module, nn.Linear) and type(org_module).__name__ != "Linear"
+        if self.is_quant and bypass_mode is None:
+            bypass_mode = True
+        self.bypass_mode = bypass_mode
+        self.dropout = dropout
+        self.rank_dropout = rank_dropout
+        self.rank_dropout_scale = rank_dropout_scale
+        self.module_dropout = module_dropout
+        if (dropout or 0) or (rank_dropout or 0) or (module_dropout or 0):
+            raise _unsupported("dropout / rank_dropout / module_dropout")
+        self.drop = nn.Identity()
+        self.rank_drop = nn.Identity()
+        self.multiplier = multiplier
+        self.org_forward = org_module.forward
+        self.org_module = [org_module]  # list: keeps the frozen layer out of this module's parameters
+
+    # ---- registry protocol (lycoris/modules/__init__.py:33-46) -------------------------------------------------
+    @classmethod
+    def algo_check(cls, state_dict, lora_name):
+        return any(f"{lora_name}.{k}" in state_dict for k in cls.weight_list_det)
+
+    @classmethod
+    def extract_state_dict(cls, state_dict, lora_name):
+        return [state_dict.get(f"{lora_name}.{k}", None) for k in cls.weight_list]
+
+    @classmethod
+    def make_module_from_state_dict(cls, lora_name, orig_module, *weights):
+        raise NotImplementedError
+
+    @classmethod
+    def parametrize(cls, org_module, attr, *args, **kwargs):
+        raise _unsupported("torch parametrize integration")
+
+    # ---- small accessors ----------------------------------------------------------------------------------------
+    @property
+    def dtype(self):
+        return self.dtype_tensor.dtype
+
+    @property
+    def device(self):
+        return self.dtype_tensor.device
+
+    @property
+    def org_weight(self):
+        return self.org_module[0].weight
+
+    @org_weight.setter
+    def org_weight(self, value):
+        self.org_module[0].weight.data.copy_(value)
+
+    def _current_weight(self):
+        return self.org_module[0].weight.detach()
+
+    def _current_bias(self):
+        b = self.org_module[0].bias
+        return None if b is None else b.detach()
+
+    # ---- state dict -----------------------------------------------------------------------------------------------
+    def custom_state_dict(self):
+        return None
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        custom = self.custom_state_dict()
+        if custom is None:
+            return super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        if args:  # legacy positional form (destination, prefix, keep_vars)
+            destination = args[0] if destination is None else destination
+            if len(args) > 1 and prefix == "":
+                prefix = args[1]
+        if destination is None:
+            destination = OrderedDict()
+            destination._metadata = OrderedDict()
+        if hasattr(destination, "_metadata"):
+            destination._metadata[prefix[:-1]] = dict(version=self._version)
+        for key, value in custom.items():
+            destination[prefix + key] = value
+        return destination
+
+    def _reset_scalar_after_load(self, module, incompatible_keys):
+        # checkpoints store `first factor * scalar`; the gate itself restarts at 1 (locon.py:184-196)
+        incompatible_keys.missing_keys[:] = [k for k in incompatible_keys.missing_keys if "scalar" not in k]
+        scalar = getattr(self, "scalar", None)
+        if scalar is not None:
+            with torch.no_grad():
+                scalar.fill_(1.0)
+
+    # ---- attach / detach -----------------------------------------------------------------------------------------
+    def apply_to(self, **kwargs):
+        if self.not_supported:
+            return
+        layer = self.org_module[0]
+        if not hasattr(layer, _ORIG):
+            setattr(layer, _ORIG, layer.forward)
+        stack = [w for w in getattr(layer, _STACK, []) if w is not self]
+        self.org_forward = layer.forward  # whatever is currently on top (the bare layer or another adapter)
+        stack.append(self)
+        setattr(layer, _STACK, stack)
+        layer.forward = self.forward
+
+    def restore(self):
+        if self.not_supported:
+            return
+        layer = self.org_module[0]
+        stack = list(getattr(layer, _STACK, []))
+        original = getattr(layer, _ORIG, self.org_forward)
+        if self in stack:
+            pos = stack.index(self)
+            stack.pop(pos)
+            if pos < len(stack):  # the adapter that sat on top of us now calls what we used to call
+                stack[pos].org_forward = self.org_forward
+        if stack:
+            setattr(layer, _STACK, stack)
+            layer.forward = stack[-1].forward
+        else:
+            layer.forward = original
+            layer.__dict__.pop(_STACK, None)
+            layer.__dict__.pop(_ORIG, None)
+
+    # ---- merging (inference / export; plain tensor math by definition) ---------------------------------------
+    def get_diff_weight(self, multiplier=1.0, shape=None, device=None):
+        raise NotImplementedError
+
+    def get_merged_weight(self, multiplier=1.0, shape=None, device=None):
+        raise NotImplementedError
+
+    def _own_device_dtype(self):
+        p = next(self.parameters())
+        return p.device, p.dtype
+
+    def merge_to(self, multiplier=1.0):
+        if self.not_supported:
+            return
+        dev, dt = self._own_device_dtype()
+        self.to(self.org_weight)
+        weight, bias = self.get_merged_weight(multiplier, self.org_weight.shape, self.org_weight.device)
+        self.org_weight = weight.to(self.org_weight)
+        if bias is not None:
+            layer = self.org_module[0]
+            bias = bias.to(self.org_weight)
+            if layer.bias is not None:
+                layer.bias.data.copy_(bias)
+            else:
+                layer.bias = nn.Parameter(bias)
+        self.to(dev, dt)
+
+    def onfly_merge(self, multiplier=1.0):
+        if self.not_supported:
+            return
+        dev, dt = self._own_device_dtype()
+        self.to(self.org_weight)
+        layer = self.org_module[0]
+        self.cached_org_weight = self.org_weight.data.cpu()
+        self.cached_org_bias = None if layer.bias is None else layer.bias.data.cpu()
+        weight, bias = self.get_merged_weight(multiplier, self.org_weight.shape, self.org_weight.device)
+        self.org_weight = weight
+        if bias is not None:
+            bias = bias.to(self.org_weight)
+            if layer.bias is not None:
+                layer.bias.data.copy_(bias)
+            else:
+                layer.bias = nn.Parameter(bias)
+        self.to(dev, dt)
+
+    def onfly_restore(self):
+        if self.not_supported:
+            return
+        self.org_weight = self.cached_org_weight.to(self.org_weight)
+        if self.cached_org_bias is not None:
+            self.org_module[0].bias.data.copy_(self.cached_org_bias.to(self.org_weight))
+        del self.cached_org_weight
+        del self.cached_org_bias
+
+    @torch.no_grad()
+    def apply_max_norm(self, max_norm, device=None):
+        return None, None
+
+    # ---- hot path (implemented by the algorithms) -------------------------------------------------------------
+    def bypass_forward_diff(self, x, scale=1):
+        raise NotImplementedError
+
+    def bypass_forward(self, x, scale=1):
+        return self.org_forward(x) + self.bypass_forward_diff(x, scale=scale)
+
+    def forward(self, x, *args, **kwargs):
+        """base + delta.  The rebuild path and the bypass path of the reference are the same mathematical function
+        (rebuild semantics are canonical); natively both are the factored evaluation on x."""
+        base = self.org_forward(x, *args, **kwargs)
+        return base + self.bypass_forward_diff(x, scale=self.multiplier)
+
+    # ---- helpers for subclasses --------------------------------------------------------------------------------
+    def _conv_geometry(self):
+        if self.module_type != "conv2d":
+            raise _unsupported(f"{self.module_type} layers")
+        return self.kw_dict
+
+    def _gate(self, first_factor: torch.Tensor) -> torch.Tensor:
+        """Fold the learnable `scalar` gate into the first factor (its gradient then flows through autograd)."""
+        if isinstance(self.scalar, nn.Parameter):
+            return first_factor * self.scalar
+        return first_factor
+
+    def _init_scale(self, lora_dim, alpha, rs_lora, use_scalar, force_unit_scale=False):
+        """alpha / rank bookkeeping shared by LoCon / LoHa / LoKr (e.g. locon.py:131-152)."""
+        if isinstance(alpha, torch.Tensor):
+            alpha = float(alpha.detach().float())
+        alpha = lora_dim if alpha is None or alpha == 0 else alpha
+        if force_unit_scale:
+            alpha = lora_dim
+        r_factor = lora_dim ** 0.5 if rs_lora else lora_dim
+        self.scale = alpha / r_factor
+        self.register_buffer("alpha", torch.tensor(alpha * (lora_dim / r_factor)))
+        if use_scalar:
+            self.scalar = nn.Parameter(torch.tensor(0.0))
+        else:
+            self.register_buffer("scalar", torch.tensor(1.0), persistent=False)
+        self.register_load_state_dict_post_hook(self._reset_scalar_after_load)

@@ -1,0 +1,106 @@
+"""LoCon / LoRA adapter module on the native path (interface of lycoris/modules/locon.py).
+
+Parameters live in real ``lora_down`` / ``lora_up`` submodules exactly like upstream (locon.py:74-105), so
+checkpoints interchange and sd-scripts' LoRA+ grouping (substring "lora_up", kohya.py:678) keeps working.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..functional.general import conv_args
+from .base import LycorisBaseModule, _unsupported
+
+
+class LoConModule(LycorisBaseModule):
+    name = "locon"
+    support_module = {"linear", "conv1d", "conv2d", "conv3d"}
+    weight_list = ["lora_up.weight", "lora_down.weight", "lora_mid.weight", "alpha", "dora_scale"]
+    weight_list_det = ["lora_up.weight"]
+
+    def __init__(self, lora_name, org_module: nn.Module, multiplier=1.0, lora_dim=4, alpha=1, dropout=0.0,
+                 rank_dropout=0.0, module_dropout=0.0, use_tucker=False, use_scalar=False, rank_dropout_scale=False,
+                 weight_decompose=False, wd_on_out=True, bypass_mode=None, rs_lora=False, **kwargs):
+        super().__init__(lora_name, org_module, multiplier, dropout, rank_dropout, module_dropout,
+                         rank_dropout_scale, bypass_mode)
+        if self.module_type not in self.support_module:
+            raise ValueError(f"{self.module_type} is not supported in LoRA/LoCon algo.")
+        if self.module_type in ("conv1d", "conv3d"):
+            raise _unsupported(f"LoCon on {self.module_type}")
+        if weight_decompose:
+            raise _unsupported("weight_decompose (DoRA)")
+        self.lora_dim = lora_dim
+        self.rs_lora = rs_lora
+        self.wd = False
+        self.tucker = False
+        if self.module_type == "conv2d":
+            self.isconv = True
+            k = org_module.kernel_size
+            if use_tucker and any(i != 1 for i in k):
+                raise _unsupported("use_tucker (lora_mid) for k>1 convolutions")
+            self.lora_down = nn.Conv2d(org_module.in_channels, lora_dim, k, org_module.stride, org_module.padding,
+                                       bias=False)
+            self.lora_up = nn.Conv2d(lora_dim, org_module.out_channels, 1, bias=False)
+        else:
+            self.isconv = False
+            self.lora_down = nn.Linear(org_module.in_features, lora_dim, bias=False)
+            self.lora_up = nn.Linear(lora_dim, org_module.out_features, bias=False)
+        self._init_scale(lora_dim, alpha, rs_lora, use_scalar)
+        nn.init.kaiming_uniform_(self.lora_down.weight, a=math.sqrt(5))
+        if use_scalar:
+            nn.init.kaiming_uniform_(self.lora_up.weight, a=math.sqrt(5))
+        else:
+            nn.init.zeros_(self.lora_up.weight)
+
+    @classmethod
+    def make_module_from_state_dict(cls, lora_name, orig_module, up, down, mid, alpha, dora_scale):
+        mod = cls(lora_name, orig_module, 1, down.size(0), float(alpha), use_tucker=mid is not None,
+                  weight_decompose=dora_scale is not None)
+        mod.lora_up.weight.data.copy_(up)
+        mod.lora_down.weight.data.copy_(down)
+        return mod
+
+    def custom_state_dict(self):
+        return {"alpha": self.alpha, "lora_up.weight": self.lora_up.weight * self.scalar,
+                "lora_down.weight": self.lora_down.weight}
+
+    # ---- dW materialisation (merge / export / max-norm only) -----------------------------------------------------
+    def make_weight(self, device=None):
+        up = self.lora_up.weight.to(device)
+        down = self.lora_down.weight.to(device)
+        w = up.reshape(up.size(0), -1) @ down.reshape(down.size(0), -1)
+        return w.reshape(self.shape) * self.scalar.to(device)
+
+    def get_diff_weight(self, multiplier=1, shape=None, device=None):
+        diff = self.make_weight(device=device) * (self.scale * multiplier)
+        if shape is not None:
+            diff = diff.view(shape)
+        return (diff if device is None else diff.to(device)), None
+
+    def get_merged_weight(self, multiplier=1, shape=None, device=None):
+        diff = self.get_diff_weight(multiplier=1, shape=shape, device=device)[0]
+        return self.org_weight + diff * multiplier, None
+
+    @torch.no_grad()
+    def apply_max_norm(self, max_norm, device=None):
+        orig_norm = self.make_weight(device).norm() * self.scale
+        norm = torch.clamp(orig_norm, max_norm / 2)
+        desired = torch.clamp(norm, max=max_norm)
+        ratio = desired.cpu() / norm.cpu()
+        scaled = norm != desired
+        if scaled:
+            self.scalar *= ratio
+        return scaled, orig_norm * ratio
+
+    # ---- hot path --------------------------------------------------------------------------------------------------
+    def bypass_forward_diff(self, x, scale=1):
+        """delta = up(down(x)) * scalar * alpha/r * scale  (locon.py:286-304 and :309-332 compute the same function)."""
+        alpha = self.scale * scale
+        up = self._gate(self.lora_up.weight)
+        if not self.isconv:
+            return ops.locon_linear(x, self.lora_down.weight, up, alpha)
+        stride, padding, dilation = conv_args(self.kw_dict)
+        return ops.locon_conv2d(x, self.lora_down.weight, up, alpha, stride, padding, dilation)

@@ -1,0 +1,99 @@
+"""LoHa adapter module on the native path (interface of lycoris/modules/loha.py)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..functional.general import conv_args
+from .base import LycorisBaseModule, _unsupported
+
+
+class LohaModule(LycorisBaseModule):
+    name = "loha"
+    support_module = {"linear", "conv1d", "conv2d", "conv3d"}
+    weight_list = ["hada_w1_a", "hada_w1_b", "hada_w2_a", "hada_w2_b", "hada_t1", "hada_t2", "alpha", "dora_scale"]
+    weight_list_det = ["hada_w1_a"]
+
+    def __init__(self, lora_name, org_module: nn.Module, multiplier=1.0, lora_dim=4, alpha=1, dropout=0.0,
+                 rank_dropout=0.0, module_dropout=0.0, use_tucker=False, use_scalar=False, rank_dropout_scale=False,
+                 weight_decompose=False, wd_on_out=True, bypass_mode=None, rs_lora=False, **kwargs):
+        super().__init__(lora_name, org_module, multiplier, dropout, rank_dropout, module_dropout,
+                         rank_dropout_scale, bypass_mode)
+        if self.module_type not in self.support_module:
+            raise ValueError(f"{self.module_type} is not supported in LoHa algo.")
+        if self.module_type in ("conv1d", "conv3d"):
+            raise _unsupported(f"LoHa on {self.module_type}")
+        if weight_decompose:
+            raise _unsupported("weight_decompose (DoRA)")
+        self.lora_dim = lora_dim
+        self.rs_lora = rs_lora
+        self.wd = False
+        self.tucker = False
+        out_dim, in_flat = self.shape[0], self.shape[1]
+        if self.module_type == "conv2d":
+            k = org_module.kernel_size
+            if use_tucker and any(i != 1 for i in k):
+                raise _unsupported("use_tucker (hada_t1/t2) for k>1 convolutions")
+            in_flat = self.shape[1] * k[0] * k[1]  # non-Tucker conv factors are [r, I*kh*kw] (loha.py:76)
+        self.hada_w1_a = nn.Parameter(torch.empty(out_dim, lora_dim))
+        self.hada_w1_b = nn.Parameter(torch.empty(lora_dim, in_flat))
+        self.hada_w2_a = nn.Parameter(torch.empty(out_dim, lora_dim))
+        self.hada_w2_b = nn.Parameter(torch.empty(lora_dim, in_flat))
+        self._init_scale(lora_dim, alpha, rs_lora, use_scalar)
+        nn.init.normal_(self.hada_w1_b, std=1)
+        nn.init.normal_(self.hada_w1_a, std=0.1)
+        nn.init.normal_(self.hada_w2_b, std=1)
+        if use_scalar:
+            nn.init.normal_(self.hada_w2_a, std=0.1)
+        else:
+            nn.init.zeros_(self.hada_w2_a)
+
+    @classmethod
+    def make_module_from_state_dict(cls, lora_name, orig_module, w1a, w1b, w2a, w2b, t1, t2, alpha, dora_scale):
+        mod = cls(lora_name, orig_module, 1, w1b.size(0), float(alpha), use_tucker=t1 is not None,
+                  weight_decompose=dora_scale is not None)
+        for p, v in ((mod.hada_w1_a, w1a), (mod.hada_w1_b, w1b), (mod.hada_w2_a, w2a), (mod.hada_w2_b, w2b)):
+            p.data.copy_(v)
+        return mod
+
+    def custom_state_dict(self):
+        return {"alpha": self.alpha, "hada_w1_a": self.hada_w1_a * self.scalar, "hada_w1_b": self.hada_w1_b,
+                "hada_w2_a": self.hada_w2_a, "hada_w2_b": self.hada_w2_b}
+
+    # ---- dW materialisation (merge / export / max-norm only) -----------------------------------------------------
+    def get_weight(self, shape):
+        w = (self.hada_w1_a @ self.hada_w1_b) * (self.hada_w2_a @ self.hada_w2_b) * self.scale
+        return w if shape is None else w.reshape(shape)
+
+    def get_diff_weight(self, multiplier=1, shape=None, device=None):
+        # NB upstream multiplies by self.scale a second time here (loha.py:228-230 with :206); the trained
+        # forward uses scale once, and merging must reproduce the trained forward, so scale is applied once.
+        diff = self.get_weight(shape) * self.scalar * multiplier
+        return (diff if device is None else diff.to(device)), None
+
+    def get_merged_weight(self, multiplier=1, shape=None, device=None):
+        diff = self.get_diff_weight(multiplier=1, shape=shape, device=device)[0]
+        return self.org_weight + diff * multiplier, None
+
+    @torch.no_grad()
+    def apply_max_norm(self, max_norm, device=None):
+        orig_norm = (self.get_weight(self.shape) * self.scalar).norm()
+        norm = torch.clamp(orig_norm, max_norm / 2)
+        desired = torch.clamp(norm, max=max_norm)
+        ratio = desired.cpu() / norm.cpu()
+        scaled = norm != desired
+        if scaled:
+            self.scalar *= ratio
+        return scaled, orig_norm * ratio
+
+    # ---- hot path --------------------------------------------------------------------------------------------------
+    def bypass_forward_diff(self, x, scale=1):
+        """delta = op(x, ((w1a w1b) * (w2a w2b)) * alpha/r * scalar * scale)  (loha.py:294-299 and :301-322)."""
+        alpha = self.scale * scale
+        w1a = self._gate(self.hada_w1_a)
+        if self.module_type == "linear":
+            return ops.loha_linear(x, w1a, self.hada_w1_b, self.hada_w2_a, self.hada_w2_b, alpha)
+        stride, padding, dilation = conv_args(self.kw_dict)
+        return ops.loha_conv2d(x, w1a, self.hada_w1_b, self.hada_w2_a, self.hada_w2_b, alpha, tuple(self.shape),
+                               stride, padding, dilation)

@@ -1,0 +1,202 @@
+"""LoKr adapter module on the native path (interface of lycoris/modules/lokr.py).
+
+Shape logic (which of lokr_w1 | lokr_w1_a/b and lokr_w2 | lokr_w2_a/b exist, their sizes, the alpha/scale rule) is
+pinned against the reference by tests/golden/shape_cases.json.
+"""
+from __future__ import annotations
+
+import logging
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..functional.general import conv_args, factorization
+from ..functional.lokr import make_kron
+from .base import LycorisBaseModule, _unsupported
+
+logger = logging.getLogger("LyCORIS")
+_warned = set()
+
+
+def _warn_full_matrix(lora_dim, dim, factor):
+    key = (lora_dim, dim, factor)
+    if key not in _warned:
+        _warned.add(key)
+        logger.warning(f"lora_dim {lora_dim} is too large for dim={dim} and factor={factor}, using full matrix mode.")
+
+
+class LokrModule(LycorisBaseModule):
+    name = "kron"
+    support_module = {"linear", "conv1d", "conv2d", "conv3d"}
+    weight_list = ["lokr_w1", "lokr_w1_a", "lokr_w1_b", "lokr_w2", "lokr_w2_a", "lokr_w2_b", "lokr_t1", "lokr_t2",
+                   "alpha", "dora_scale"]
+    weight_list_det = ["lokr_w1", "lokr_w1_a"]
+
+    def __init__(self, lora_name, org_module: nn.Module, multiplier=1.0, lora_dim=4, alpha=1, dropout=0.0,
+                 rank_dropout=0.0, module_dropout=0.0, use_tucker=False, use_scalar=False, decompose_both=False,
+                 factor: int = -1, rank_dropout_scale=False, weight_decompose=False, wd_on_out=True,
+                 full_matrix=False, bypass_mode=None, rs_lora=False, unbalanced_factorization=False, **kwargs):
+        super().__init__(lora_name, org_module, multiplier, dropout, rank_dropout, module_dropout,
+                         rank_dropout_scale, bypass_mode)
+        if self.module_type not in self.support_module:
+            raise ValueError(f"{self.module_type} is not supported in LoKr algo.")
+        if self.module_type in ("conv1d", "conv3d"):
+            raise _unsupported(f"LoKr on {self.module_type}")
+        if weight_decompose:
+            raise _unsupported("weight_decompose (DoRA)")
+        factor = int(factor)
+        self.lora_dim = lora_dim
+        self.full_matrix = full_matrix
+        self.rs_lora = rs_lora
+        self.wd = False
+        self.tucker = False
+        is_conv = self.module_type == "conv2d"
+        out_dim, in_dim = self.shape[0], self.shape[1]
+        ksize = tuple(self.shape[2:])
+        in_m, in_n = factorization(in_dim, factor)
+        out_l, out_k = factorization(out_dim, factor)
+        if unbalanced_factorization:
+            out_l, out_k = out_k, out_l
+        if is_conv and use_tucker and any(i != 1 for i in ksize):
+            raise _unsupported("use_tucker (lokr_t2) for k>1 convolutions")
+
+        # small factor w1: [out_l, in_m] (optionally rank-decomposed)
+        self.use_w1 = not (decompose_both and lora_dim < max(out_l, in_m) / 2 and not full_matrix)
+        if self.use_w1:
+            self.lokr_w1 = nn.Parameter(torch.empty(out_l, in_m))
+        else:
+            self.lokr_w1_a = nn.Parameter(torch.empty(out_l, lora_dim))
+            self.lokr_w1_b = nn.Parameter(torch.empty(lora_dim, in_m))
+        # big factor w2: [out_k, in_n(, kh, kw)] (full when the rank would not save anything, lokr.py:109-136, 159-167)
+        low_rank_w2 = lora_dim < max(out_k, in_n) / 2 and not full_matrix
+        self.use_w2 = not low_rank_w2
+        if self.use_w2:
+            if not full_matrix:
+                _warn_full_matrix(lora_dim, max(in_dim, out_dim), factor)
+            self.lokr_w2 = nn.Parameter(torch.empty(out_k, in_n, *ksize))
+        else:
+            kprod = 1
+            for i in ksize:
+                kprod *= i
+            self.lokr_w2_a = nn.Parameter(torch.empty(out_k, lora_dim))
+            self.lokr_w2_b = nn.Parameter(torch.empty(lora_dim, in_n * kprod))
+        self._kron_dims = (out_l, in_m, out_k, in_n)
+
+        self._init_scale(lora_dim, alpha, rs_lora, use_scalar, force_unit_scale=self.use_w1 and self.use_w2)
+        if self.use_w2:
+            if use_scalar:
+                nn.init.kaiming_uniform_(self.lokr_w2, a=math.sqrt(5))
+            else:
+                nn.init.zeros_(self.lokr_w2)
+        else:
+            nn.init.kaiming_uniform_(self.lokr_w2_a, a=math.sqrt(5))
+            if use_scalar:
+                nn.init.kaiming_uniform_(self.lokr_w2_b, a=math.sqrt(5))
+            else:
+                nn.init.zeros_(self.lokr_w2_b)
+        if self.use_w1:
+            nn.init.kaiming_uniform_(self.lokr_w1, a=math.sqrt(5))
+        else:
+            nn.init.kaiming_uniform_(self.lokr_w1_a, a=math.sqrt(5))
+            nn.init.kaiming_uniform_(self.lokr_w1_b, a=math.sqrt(5))
+
+    @classmethod
+    def make_module_from_state_dict(cls, lora_name, orig_module, w1, w1a, w1b, w2, w2a, w2b, _, t2, alpha,
+                                    dora_scale):
+        """Rebuild a module from checkpoint tensors: find the ``factor`` that reproduces the stored factor shapes."""
+        if t2 is not None or dora_scale is not None:
+            raise _unsupported("LoKr checkpoints with lokr_t2 / dora_scale")
+        full_matrix = w1a is None and w2a is None
+        lora_dim = w1a.size(1) if w1a is not None else (w2a.size(1) if w2a is not None else 1)
+        a, b = (w1.shape if w1 is not None else (w1a.size(0), w1b.size(1)))
+        c = w2.size(0) if w2 is not None else w2a.size(0)
+        probe = cls.__new__(cls)  # only to read the wrapped layer's dims through the base bookkeeping
+        nn.Module.__init__(probe)
+        LycorisBaseModule.__init__(probe, lora_name, orig_module)
+        out_dim, in_dim = probe.shape[0], probe.shape[1]
+        d = in_dim // b
+        candidates = [-1] + sorted({a, b, c, d, max(a, b), min(a, b)})
+        factor = None
+        for f in candidates:
+            if f == 0:
+                continue
+            if factorization(out_dim, f) == (a, c) and factorization(in_dim, f) == (b, d):
+                factor = f
+                break
+        if factor is None:
+            raise ValueError(f"cannot infer LoKr factor for {lora_name}: w1 {a}x{b}, layer {out_dim}x{in_dim}")
+        mod = cls(lora_name, orig_module, 1, lora_dim, float(alpha), decompose_both=w1 is None and w2 is None,
+                  factor=factor, full_matrix=full_matrix)
+        with torch.no_grad():
+            for name, val in (("lokr_w1", w1), ("lokr_w1_a", w1a), ("lokr_w1_b", w1b), ("lokr_w2", w2),
+                              ("lokr_w2_a", w2a), ("lokr_w2_b", w2b)):
+                if val is not None:
+                    getattr(mod, name).copy_(val)
+        return mod
+
+    def custom_state_dict(self):
+        sd = {"alpha": self.alpha}
+        if self.use_w1:
+            sd["lokr_w1"] = self.lokr_w1 * self.scalar
+        else:
+            sd["lokr_w1_a"] = self.lokr_w1_a * self.scalar
+            sd["lokr_w1_b"] = self.lokr_w1_b
+        if self.use_w2:
+            sd["lokr_w2"] = self.lokr_w2
+        else:
+            sd["lokr_w2_a"] = self.lokr_w2_a
+            sd["lokr_w2_b"] = self.lokr_w2_b
+        return sd
+
+    # ---- factors -------------------------------------------------------------------------------------------------
+    def _w1_full(self):
+        return self.lokr_w1 if self.use_w1 else self.lokr_w1_a @ self.lokr_w1_b
+
+    def _w2_full(self):
+        if self.use_w2:
+            return self.lokr_w2
+        out_k, in_n = self._kron_dims[2], self._kron_dims[3]
+        return (self.lokr_w2_a @ self.lokr_w2_b).reshape(out_k, in_n, *self.shape[2:])
+
+    # ---- dW materialisation (merge / export / max-norm only) -----------------------------------------------------
+    def get_weight(self, shape):
+        w = make_kron(self._w1_full(), self._w2_full(), self.scale)
+        return w if shape is None else w.view(shape)
+
+    def get_diff_weight(self, multiplier=1, shape=None, device=None):
+        # scale applied once (upstream applies it twice here, lokr.py:383-385 with :370)
+        diff = self.get_weight(shape) * self.scalar * multiplier
+        return (diff if device is None else diff.to(device)), None
+
+    def get_merged_weight(self, multiplier=1, shape=None, device=None):
+        diff = self.get_diff_weight(multiplier=1, shape=shape, device=device)[0]
+        return self.org_weight + diff * multiplier, None
+
+    @torch.no_grad()
+    def apply_max_norm(self, max_norm, device=None):
+        orig_norm = self.get_weight(self.shape).norm()
+        norm = torch.clamp(orig_norm, max_norm / 2)
+        desired = torch.clamp(norm, max=max_norm)
+        ratio = desired.cpu() / norm.cpu()
+        scaled = norm != desired
+        if scaled:
+            factors = [p for n, p in self.named_parameters() if n.startswith("lokr_")]
+            for p in factors:
+                p *= ratio ** (1 / len(factors))
+        return scaled, orig_norm * ratio
+
+    # ---- hot path --------------------------------------------------------------------------------------------------
+    def bypass_forward_diff(self, h, scale=1):
+        """delta = (w1 (x) w2) h * alpha/r * scalar * scale, Kronecker-factored.
+
+        Unlike upstream's bypass (lokr.py:538) this includes ``self.scale``, i.e. it equals the rebuild
+        path lokr.py:543-566, which is the canonical semantics."""
+        alpha = self.scale * scale
+        w1 = self._gate(self._w1_full())
+        w2 = self._w2_full()
+        if self.module_type == "linear":
+            return ops.lokr_linear(h, w1, w2, alpha)
+        stride, padding, dilation = conv_args(self.kw_dict)
+        return ops.lokr_conv2d(h, w1, w2, alpha, stride, padding, dilation)

@@ -1,15 +1,21 @@
-"""Autograd-level wrappers over the C ABI (one Function per fused forward/backward pair).
+"""Autograd-level wrappers over the C ABI.
 
-Shapes follow the kernels: activations are flattened to [M, features] (Linear) and must be contiguous;
-factors are fp32 (16-bit factors are up-converted -- they are tiny); factor gradients come back in the
-factor's dtype.  ``alpha`` is a Python float (scale * multiplier); a learnable ``scalar`` gate is folded
-into the first factor by the caller so its gradient flows through ordinary autograd.
+Every adapter algorithm is a "row core": kernels that act on an activation row matrix [M, features]
+(``fwd``/``bwd`` below call the C entry points of include/lycoris_amd.h).  Two generic autograd Functions wrap a
+core: ``_AdapterLinear`` (nn.Linear: rows = x.view(-1, I)) and ``_AdapterConv2d`` (nn.Conv2d, NCHW: rows = im2col
+view, outputs transposed back, col2im accumulating un-rounded fp32 rows in backward).
+
+Factors are fp32 for the kernels (16-bit factors are up-converted -- they are tiny); factor gradients are returned
+in the factor's dtype.  ``alpha`` is a Python float (scale * multiplier); a learnable ``scalar`` gate is folded into
+the first factor by the caller so its gradient flows through ordinary autograd.
 """
 from __future__ import annotations
 
 import torch
 
 from . import _native as N
+
+F32_ROWS = 0x100  # LYC_F32_ROWS
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -19,90 +25,235 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
-def _flat2d(x: torch.Tensor, feat: int) -> torch.Tensor:
-    if x.shape[-1] != feat:
-        raise ValueError(f"expected last dim {feat}, got {tuple(x.shape)}")
-    x2 = x.reshape(-1, feat)
-    return x2 if x2.is_contiguous() else x2.contiguous()
-
-
-class _LokrLinear(torch.autograd.Function):
-    """y = x @ (kron(w1, w2) * alpha)^T without materialising the Kronecker product."""
+# ---------------------------------------------------------------------------------------------------------------
+# row cores
+# ---------------------------------------------------------------------------------------------------------------
+class _LokrCore:
+    """factors = (w1:[a,b], w2:[c,d]);  y = rows @ (kron(w1, w2) * alpha)^T"""
+    n_factors = 2
 
     @staticmethod
-    def forward(ctx, x, w1, w2, alpha):
+    def dims(fs):
+        (a, b), (c, d) = fs[0].shape, fs[1].shape
+        return b * d, a * c
+
+    @staticmethod
+    def fwd(rows, fs, alpha):
+        (a, b), (c, d) = fs[0].shape, fs[1].shape
+        y = torch.empty((rows.shape[0], a * c), dtype=rows.dtype, device=rows.device)
+        N.call("lyc_lokr_linear_fwd", N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(y), rows.shape[0], a, b, c, d,
+               alpha, N.dtype_code(rows.dtype), N.stream_ptr(rows.device))
+        return y, ()
+
+    @staticmethod
+    def bwd(g, rows, fs, saved, alpha, need_x, need_f, f32_rows):
+        (a, b), (c, d) = fs[0].shape, fs[1].shape
+        want_dx = need_x or need_f[0]  # the w1 gradient shares the pass over g that produces dx
+        code = N.dtype_code(rows.dtype) | (F32_ROWS if f32_rows else 0)
+        dx = None
+        if want_dx:
+            dx = torch.empty(rows.shape, dtype=torch.float32 if f32_rows else rows.dtype, device=rows.device)
+        dw1 = torch.zeros_like(fs[0]) if need_f[0] else None
+        dw2 = torch.zeros_like(fs[1]) if need_f[1] else None
+        N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(dx), N.ptr(dw1),
+               N.ptr(dw2), rows.shape[0], a, b, c, d, alpha, code, N.stream_ptr(rows.device))
+        return (dx if need_x else None), [dw1, dw2]
+
+
+class _LoconCore:
+    """factors = (down:[r,I], up:[O,r]);  y = alpha * (rows @ down^T) @ up^T, rank-r intermediate kept in fp32"""
+    n_factors = 2
+
+    @staticmethod
+    def dims(fs):
+        return fs[0].shape[1], fs[1].shape[0]
+
+    @staticmethod
+    def fwd(rows, fs, alpha):
+        r, I = fs[0].shape
+        O = fs[1].shape[0]
+        M = rows.shape[0]
+        t = torch.zeros((M, r), dtype=torch.float32, device=rows.device)
+        y = torch.empty((M, O), dtype=rows.dtype, device=rows.device)
+        N.call("lyc_locon_linear_fwd", N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(t), N.ptr(y), M, I, O, r,
+               alpha, N.dtype_code(rows.dtype), N.stream_ptr(rows.device))
+        return y, (t,)
+
+    @staticmethod
+    def bwd(g, rows, fs, saved, alpha, need_x, need_f, f32_rows):
+        r, I = fs[0].shape
+        O = fs[1].shape[0]
+        M = rows.shape[0]
+        code = N.dtype_code(rows.dtype) | (F32_ROWS if f32_rows else 0)
+        dt = torch.zeros((M, r), dtype=torch.float32, device=rows.device)
+        dx = torch.empty(rows.shape, dtype=torch.float32 if f32_rows else rows.dtype, device=rows.device) if need_x else None
+        dd = torch.zeros_like(fs[0]) if need_f[0] else None
+        du = torch.zeros_like(fs[1]) if need_f[1] else None
+        N.call("lyc_locon_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(saved[0]), N.ptr(dt),
+               N.ptr(dx), N.ptr(dd), N.ptr(du), M, I, O, r, alpha, code, N.stream_ptr(rows.device))
+        return dx, [dd, du]
+
+
+class _LohaCore:
+    """factors = (w1a:[O,r], w1b:[r,I], w2a:[O,r], w2b:[r,I]);  y = rows @ (((w1a w1b) * (w2a w2b)) * alpha)^T.
+    The dense dW operand images live in a scratch buffer written by the forward kernels and re-read by backward."""
+    n_factors = 4
+
+    @staticmethod
+    def dims(fs):
+        return fs[1].shape[1], fs[0].shape[0]
+
+    @staticmethod
+    def fwd(rows, fs, alpha):
+        O, r = fs[0].shape
+        I = fs[1].shape[1]
+        M = rows.shape[0]
+        code = N.dtype_code(rows.dtype)
+        ws = torch.empty(int(N.load().lyc_loha_workspace_bytes(O, I, code)), dtype=torch.uint8, device=rows.device)
+        y = torch.empty((M, O), dtype=rows.dtype, device=rows.device)
+        N.call("lyc_loha_linear_fwd", N.ptr(rows), *[N.ptr(t) for t in fs], N.ptr(ws), N.ptr(y), M, I, O, r, alpha,
+               code, N.stream_ptr(rows.device))
+        return y, (ws,)
+
+    @staticmethod
+    def bwd(g, rows, fs, saved, alpha, need_x, need_f, f32_rows):
+        O, r = fs[0].shape
+        I = fs[1].shape[1]
+        M = rows.shape[0]
+        code = N.dtype_code(rows.dtype) | (F32_ROWS if f32_rows else 0)
+        any_f = any(need_f)
+        dx = torch.empty(rows.shape, dtype=torch.float32 if f32_rows else rows.dtype, device=rows.device) if need_x else None
+        grads = [torch.zeros_like(t) for t in fs] if any_f else [None] * 4
+        gw = torch.empty((O, I), dtype=torch.float32, device=rows.device) if any_f else None
+        N.call("lyc_loha_linear_bwd", N.ptr(g), N.ptr(rows), *[N.ptr(t) for t in fs], N.ptr(saved[0]), N.ptr(gw),
+               N.ptr(dx), *[N.ptr(t) for t in grads], M, I, O, r, alpha, code, N.stream_ptr(rows.device))
+        return dx, grads
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Conv2d lowering helpers (no autograd: used inside the Functions)
+# ---------------------------------------------------------------------------------------------------------------
+def _conv_out(H, W, k, s, p, d):
+    Ho = (H + 2 * p[0] - d[0] * (k[0] - 1) - 1) // s[0] + 1
+    Wo = (W + 2 * p[1] - d[1] * (k[1] - 1) - 1) // s[1] + 1
+    return Ho, Wo
+
+
+def _is_pointwise(geom):
+    k, s, p, d = geom
+    return k == (1, 1) and s == (1, 1) and p == (0, 0)
+
+
+def _to_rows(t):  # [B, C, *sp] -> [B*P, C]
+    B, C = t.shape[0], t.shape[1]
+    P = t[0, 0].numel()
+    rows = torch.empty((B * P, C), dtype=t.dtype, device=t.device)
+    N.call("lyc_nchw_to_rows", N.ptr(t), N.ptr(rows), B, C, P, N.dtype_code(t.dtype), N.stream_ptr(t.device))
+    return rows
+
+
+def _from_rows(rows, B, spatial):  # [B*P, C] -> [B, C, *sp]
+    C = rows.shape[1]
+    out = torch.empty((B, C, *spatial), dtype=rows.dtype, device=rows.device)
+    N.call("lyc_rows_to_nchw", N.ptr(rows), N.ptr(out), B, C, out[0, 0].numel(), N.dtype_code(rows.dtype),
+           N.stream_ptr(rows.device))
+    return out
+
+
+def _im2col(x, geom):
+    k, s, p, d = geom
+    B, C, H, W = x.shape
+    Ho, Wo = _conv_out(H, W, k, s, p, d)
+    cols = torch.empty((B * Ho * Wo, C * k[0] * k[1]), dtype=x.dtype, device=x.device)
+    N.call("lyc_im2col", N.ptr(x), N.ptr(cols), B, C, H, W, k[0], k[1], s[0], s[1], p[0], p[1], d[0], d[1],
+           N.dtype_code(x.dtype), N.stream_ptr(x.device))
+    return cols
+
+
+def _col2im(dcols, xshape, dtype, geom):
+    k, s, p, d = geom
+    B, C, H, W = xshape
+    dx = torch.empty(xshape, dtype=dtype, device=dcols.device)
+    code = N.dtype_code(dtype) | (F32_ROWS if dcols.dtype == torch.float32 and dtype != torch.float32 else 0)
+    N.call("lyc_col2im", N.ptr(dcols), N.ptr(dx), B, C, H, W, k[0], k[1], s[0], s[1], p[0], p[1], d[0], d[1], code,
+           N.stream_ptr(dcols.device))
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# generic autograd Functions
+# ---------------------------------------------------------------------------------------------------------------
+def _grads_to(params, grads, needs):
+    return [g.to(p.dtype) if (need and g is not None) else None for p, g, need in zip(params, grads, needs)]
+
+
+class _AdapterLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, core, alpha, x, *factors):
         N.require_device(x, "input")
-        a, b = w1.shape
-        c, d = w2.shape
-        x2 = _flat2d(x, b * d)
-        w1f, w2f = _f32c(w1), _f32c(w2)
-        y = torch.empty((x2.shape[0], a * c), dtype=x.dtype, device=x.device)
-        N.call("lyc_lokr_linear_fwd", N.ptr(x2), N.ptr(w1f), N.ptr(w2f), N.ptr(y), x2.shape[0], a, b, c, d,
-               float(alpha), N.dtype_code(x.dtype), N.stream_ptr(x.device))
-        ctx.save_for_backward(x2, w1, w2)
-        ctx.alpha = float(alpha)
-        ctx.xshape = x.shape
-        return y.view(*x.shape[:-1], a * c)
-
-    @staticmethod
-    def backward(ctx, g):
-        x2, w1, w2 = ctx.saved_tensors
-        a, b = w1.shape
-        c, d = w2.shape
-        g2 = _flat2d(g, a * c)
-        w1f, w2f = _f32c(w1), _f32c(w2)
-        need_x, need_w1, need_w2 = ctx.needs_input_grad[:3]
-        M = x2.shape[0]
-        dx = torch.empty_like(x2) if (need_x or need_w1) else None
-        dw1 = torch.zeros_like(w1f) if need_w1 else None
-        dw2 = torch.zeros_like(w2f) if need_w2 else None
-        N.call("lyc_lokr_linear_bwd", N.ptr(g2), N.ptr(x2), N.ptr(w1f), N.ptr(w2f), N.ptr(dx), N.ptr(dw1),
-               N.ptr(dw2), M, a, b, c, d, ctx.alpha, N.dtype_code(x2.dtype), N.stream_ptr(x2.device))
-        return (dx.view(ctx.xshape) if need_x else None,
-                dw1.to(w1.dtype) if need_w1 else None,
-                dw2.to(w2.dtype) if need_w2 else None, None)
-
-
-class _LoconLinear(torch.autograd.Function):
-    """y = alpha * (x @ down^T) @ up^T with the rank-r intermediate kept in fp32."""
-
-    @staticmethod
-    def forward(ctx, x, down, up, alpha):
-        N.require_device(x, "input")
-        r, I = down.shape
-        O = up.shape[0]
-        x2 = _flat2d(x, I)
-        df, uf = _f32c(down), _f32c(up)
-        M = x2.shape[0]
-        t = torch.zeros((M, r), dtype=torch.float32, device=x.device)
-        y = torch.empty((M, O), dtype=x.dtype, device=x.device)
-        N.call("lyc_locon_linear_fwd", N.ptr(x2), N.ptr(df), N.ptr(uf), N.ptr(t), N.ptr(y), M, I, O, r,
-               float(alpha), N.dtype_code(x.dtype), N.stream_ptr(x.device))
-        ctx.save_for_backward(x2, down, up, t)
-        ctx.alpha = float(alpha)
-        ctx.xshape = x.shape
+        fs = [_f32c(t) for t in factors]
+        I, O = core.dims(fs)
+        if x.shape[-1] != I:
+            raise ValueError(f"adapter expects {I} input features, got {tuple(x.shape)}")
+        rows = x.reshape(-1, I)
+        rows = rows if rows.is_contiguous() else rows.contiguous()
+        y, saved = core.fwd(rows, fs, float(alpha))
+        ctx.save_for_backward(rows, *factors, *saved)
+        ctx.meta = (core, float(alpha), x.shape, len(factors))
         return y.view(*x.shape[:-1], O)
 
     @staticmethod
     def backward(ctx, g):
-        x2, down, up, t = ctx.saved_tensors
-        r, I = down.shape
-        O = up.shape[0]
-        g2 = _flat2d(g, O)
-        df, uf = _f32c(down), _f32c(up)
-        need_x, need_d, need_u = ctx.needs_input_grad[:3]
-        M = x2.shape[0]
-        dt = torch.zeros((M, r), dtype=torch.float32, device=g.device)
-        dx = torch.empty_like(x2) if need_x else None
-        dd = torch.zeros_like(df) if need_d else None
-        du = torch.zeros_like(uf) if need_u else None
-        N.call("lyc_locon_linear_bwd", N.ptr(g2), N.ptr(x2), N.ptr(df), N.ptr(uf), N.ptr(t), N.ptr(dt), N.ptr(dx),
-               N.ptr(dd), N.ptr(du), M, I, O, r, ctx.alpha, N.dtype_code(x2.dtype), N.stream_ptr(x2.device))
-        return (dx.view(ctx.xshape) if need_x else None,
-                dd.to(down.dtype) if need_d else None,
-                du.to(up.dtype) if need_u else None, None)
+        core, alpha, xshape, nf = ctx.meta
+        rows, factors, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + nf], ctx.saved_tensors[1 + nf:]
+        fs = [_f32c(t) for t in factors]
+        g2 = g.reshape(-1, g.shape[-1])
+        g2 = g2 if g2.is_contiguous() else g2.contiguous()
+        need_x, need_f = ctx.needs_input_grad[2], list(ctx.needs_input_grad[3:])
+        dx, grads = core.bwd(g2, rows, fs, saved, alpha, need_x, need_f, False)
+        return (None, None, dx.view(xshape) if need_x else None, *_grads_to(factors, grads, need_f))
 
 
+class _AdapterConv2d(torch.autograd.Function):
+    """Conv2d (NCHW, groups=1) form of a row core.  factors are the 2-D views ([.., I*kh*kw]) of the conv factors."""
+
+    @staticmethod
+    def forward(ctx, core, alpha, geom, x, *factors):
+        N.require_device(x, "input")
+        if x.dim() != 4:
+            raise ValueError(f"Conv2d adapter expects NCHW input, got shape {tuple(x.shape)}")
+        x = x.contiguous()
+        fs = [_f32c(t) for t in factors]
+        k, s, p, d = geom
+        B, C, H, W = x.shape
+        I, O = core.dims(fs)
+        if I != C * k[0] * k[1]:
+            raise ValueError(f"adapter expects {I} = C*kh*kw im2col features, input has C={C}, kernel={k}")
+        rows = _to_rows(x) if _is_pointwise(geom) else _im2col(x, geom)
+        y_rows, saved = core.fwd(rows, fs, float(alpha))
+        ctx.save_for_backward(rows, *factors, *saved)
+        ctx.meta = (core, float(alpha), geom, x.shape, len(factors))
+        return _from_rows(y_rows, B, _conv_out(H, W, k, s, p, d))
+
+    @staticmethod
+    def backward(ctx, g):
+        core, alpha, geom, xshape, nf = ctx.meta
+        rows, factors, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + nf], ctx.saved_tensors[1 + nf:]
+        fs = [_f32c(t) for t in factors]
+        g_rows = _to_rows(g.contiguous())
+        need_x, need_f = ctx.needs_input_grad[3], list(ctx.needs_input_grad[4:])
+        pointwise = _is_pointwise(geom)
+        # k > 1: col2im sums up to kh*kw row entries per pixel -> keep them in fp32 and round once
+        dx_rows, grads = core.bwd(g_rows, rows, fs, saved, alpha, need_x, need_f, not pointwise)
+        dx = None
+        if need_x:
+            dx = _from_rows(dx_rows, xshape[0], xshape[2:]) if pointwise else _col2im(dx_rows, xshape, rows.dtype, geom)
+        return (None, None, None, dx, *_grads_to(factors, grads, need_f))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# (IA)^3 per-channel affine
+# ---------------------------------------------------------------------------------------------------------------
 def _chan_dims(t: torch.Tensor, chan_dim: int):
     C = t.shape[chan_dim]
     outer = 1
@@ -158,13 +309,47 @@ class _ChanAffine(torch.autograd.Function):
         return da, dw, None, None, None, None
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# public functional entry points
+# ---------------------------------------------------------------------------------------------------------------
 def lokr_linear(x, w1, w2, alpha=1.0):
-    return _LokrLinear.apply(x, w1, w2, alpha)
+    """w1:[a,b]  w2:[c,d]  x:[..., b*d] -> [..., a*c]"""
+    return _AdapterLinear.apply(_LokrCore, alpha, x, w1, w2)
 
 
 def locon_linear(x, down, up, alpha=1.0):
-    return _LoconLinear.apply(x, down, up, alpha)
+    """down:[r,I]  up:[O,r]"""
+    return _AdapterLinear.apply(_LoconCore, alpha, x, down, up)
+
+
+def loha_linear(x, w1a, w1b, w2a, w2b, alpha=1.0):
+    """w*a:[O,r]  w*b:[r,I]"""
+    return _AdapterLinear.apply(_LohaCore, alpha, x, w1a, w1b, w2a, w2b)
 
 
 def chan_affine(a, w, bias=None, s0=0.0, mult=1.0, chan_dim=-1):
     return _ChanAffine.apply(a, w, bias, s0, mult, chan_dim)
+
+
+def _geom(ksize, stride, padding, dilation):
+    return (tuple(int(v) for v in ksize), tuple(stride), tuple(padding), tuple(dilation))
+
+
+def locon_conv2d(x, down, up, alpha, stride, padding, dilation):
+    """down:[r, I, kh, kw]  up:[O, r, 1, 1]"""
+    r, O = down.shape[0], up.shape[0]
+    return _AdapterConv2d.apply(_LoconCore, alpha, _geom(down.shape[2:], stride, padding, dilation), x,
+                                down.reshape(r, -1), up.reshape(O, r))
+
+
+def loha_conv2d(x, w1a, w1b, w2a, w2b, alpha, shape, stride, padding, dilation):
+    """w*a:[O, r]  w*b:[r, I*kh*kw];  shape = (O, I, kh, kw)"""
+    return _AdapterConv2d.apply(_LohaCore, alpha, _geom(shape[2:], stride, padding, dilation), x, w1a,
+                                w1b.reshape(w1b.shape[0], -1), w2a, w2b.reshape(w2b.shape[0], -1))
+
+
+def lokr_conv2d(x, w1, w2, alpha, stride, padding, dilation):
+    """w1:[a, b]  w2:[c, d, kh, kw].  The channel index u*d + v makes im2col's (channel, kh, kw) column order the
+    grouped (u, (v, kh, kw)) order of the Kronecker kernel, so w2 is simply viewed as [c, d*kh*kw]."""
+    return _AdapterConv2d.apply(_LokrCore, alpha, _geom(w2.shape[2:], stride, padding, dilation), x, w1,
+                                w2.reshape(w2.shape[0], -1))

@@ -1,0 +1,134 @@
+"""GPU parity: LoHa Linear and the Conv2d forms of LoCon / LoHa / LoKr (ops level, all dtypes) vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gpu_util import TOL, check, err, rnd
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+IDS = ["f32", "bf16", "f16"]
+
+LOHA_SHAPES = [(64, 64, 128, 8), (200, 320, 640, 32), (77, 200, 72, 5), (33, 50, 70, 40), (1, 128, 128, 4)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("shape", LOHA_SHAPES, ids=[str(s) for s in LOHA_SHAPES])
+def test_loha_linear(shape, dtype):
+    from lycoris_amd import ops
+    M, I, O, r = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    x, x64 = rnd((M, I), dtype, gen)
+    g, g64 = rnd((M, O), dtype, gen, 1.0 / np.sqrt(O))
+    w1a, a1 = rnd((O, r), torch.float32, gen, 0.1)
+    w1b, b1 = rnd((r, I), torch.float32, gen, 1.0)
+    w2a, a2 = rnd((O, r), torch.float32, gen, 0.1)
+    w2b, b2 = rnd((r, I), torch.float32, gen, 1.0)
+    alpha = 0.5
+    ts = [x, w1a, w1b, w2a, w2b]
+    for t in ts:
+        t.requires_grad_(True)
+    y = ops.loha_linear(x, w1a, w1b, w2a, w2b, alpha)
+    grads = torch.autograd.grad(y, ts, g)
+    torch.cuda.synchronize()
+    y_ref = oracle.loha.forward(x64, a1, b1, a2, b2, alpha)
+    ref = oracle.loha.backward(x64, g64, a1, b1, a2, b2, alpha)
+    names = ["dx", "d_w1a", "d_w1b", "d_w2a", "d_w2b"]
+    errs = {"y": err(y, y_ref, dtype), "dx": err(grads[0], ref[0], dtype)}
+    bounds = {"y": TOL["store_out"][dtype], "dx": TOL["store_out"][dtype]}
+    for n, gr, rf in zip(names[1:], grads[1:], ref[1:]):
+        errs[n] = err(gr, rf)
+        bounds[n] = TOL["f32_out"][dtype]
+    check(f"loha_linear[{shape},{dtype}]", errs, bounds)
+
+
+# (B, C, H, W, O, k, stride, pad, dil)
+CONV_SHAPES = [
+    (2, 16, 12, 12, 32, 3, 1, 1, 1),
+    (1, 24, 9, 11, 16, 3, 2, 1, 1),
+    (2, 16, 8, 8, 24, 1, 1, 0, 1),
+    (1, 8, 10, 9, 8, 3, 1, 2, 2),
+    (3, 32, 16, 16, 64, 3, 1, 1, 1),
+]
+
+
+def _ca(s, p, d):
+    return {"stride": s, "padding": p, "dilation": d}
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("shape", CONV_SHAPES, ids=[str(s) for s in CONV_SHAPES])
+def test_locon_conv2d(shape, dtype):
+    from lycoris_amd import ops
+    B, C, H, W, O, k, s, p, d = shape
+    r = 4
+    gen = torch.Generator().manual_seed(sum(shape))
+    x, x64 = rnd((B, C, H, W), dtype, gen)
+    down, d64 = rnd((r, C, k, k), torch.float32, gen, 0.1)
+    up, u64 = rnd((O, r, 1, 1), torch.float32, gen, 0.1)
+    y_ref = oracle.locon.forward(x64, d64, u64, 1.25, _ca(s, p, d))
+    g, g64 = rnd(y_ref.shape, dtype, gen, 1.0 / np.sqrt(O))
+    for t in (x, down, up):
+        t.requires_grad_(True)
+    y = ops.locon_conv2d(x, down, up, 1.25, (s, s), (p, p), (d, d))
+    dx, dd, du = torch.autograd.grad(y, [x, down, up], g)
+    torch.cuda.synchronize()
+    dx_r, dd_r, du_r = oracle.locon.backward(x64, g64, d64, u64, 1.25, _ca(s, p, d))
+    errs = {"y": err(y, y_ref, dtype), "dx": err(dx, dx_r, dtype), "d_down": err(dd, dd_r), "d_up": err(du, du_r)}
+    bounds = {"y": TOL["store_out"][dtype], "dx": TOL["store_out"][dtype], "d_down": TOL["f32_out"][dtype], "d_up": TOL["f32_out"][dtype]}
+    check(f"locon_conv2d[{shape},{dtype}]", errs, bounds)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("shape", CONV_SHAPES, ids=[str(s) for s in CONV_SHAPES])
+def test_lokr_conv2d(shape, dtype):
+    from lycoris_amd import ops
+    B, C, H, W, O, k, s, p, d = shape
+    a_, b_ = 4, 4
+    c_, d_ = O // a_, C // b_
+    gen = torch.Generator().manual_seed(sum(shape) + 1)
+    x, x64 = rnd((B, C, H, W), dtype, gen)
+    w1, w1_64 = rnd((a_, b_), torch.float32, gen, 0.3)
+    w2, w2_64 = rnd((c_, d_, k, k), torch.float32, gen, 0.1)
+    y_ref = oracle.lokr.forward(x64, w1=w1_64, w2=w2_64, scale=0.9, kshape=(k, k), conv_args=_ca(s, p, d))
+    g, g64 = rnd(y_ref.shape, dtype, gen, 1.0 / np.sqrt(O))
+    for t in (x, w1, w2):
+        t.requires_grad_(True)
+    y = ops.lokr_conv2d(x, w1, w2, 0.9, (s, s), (p, p), (d, d))
+    dx, dw1, dw2 = torch.autograd.grad(y, [x, w1, w2], g)
+    torch.cuda.synchronize()
+    gr = oracle.lokr.backward(x64, g64, w1=w1_64, w2=w2_64, scale=0.9, kshape=(k, k), conv_args=_ca(s, p, d))
+    errs = {"y": err(y, y_ref, dtype), "dx": err(dx, gr["dx"], dtype), "dw1": err(dw1, gr["w1"]), "dw2": err(dw2, gr["w2"])}
+    bounds = {"y": TOL["store_out"][dtype], "dx": TOL["store_out"][dtype], "dw1": TOL["f32_out"][dtype], "dw2": TOL["f32_out"][dtype]}
+    check(f"lokr_conv2d[{shape},{dtype}]", errs, bounds)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("shape", CONV_SHAPES[:3], ids=[str(s) for s in CONV_SHAPES[:3]])
+def test_loha_conv2d(shape, dtype):
+    from lycoris_amd import ops
+    B, C, H, W, O, k, s, p, d = shape
+    r = 4
+    gen = torch.Generator().manual_seed(sum(shape) + 2)
+    x, x64 = rnd((B, C, H, W), dtype, gen)
+    w1a, a1 = rnd((O, r), torch.float32, gen, 0.1)
+    w1b, b1 = rnd((r, C * k * k), torch.float32, gen, 1.0)
+    w2a, a2 = rnd((O, r), torch.float32, gen, 0.1)
+    w2b, b2 = rnd((r, C * k * k), torch.float32, gen, 1.0)
+    wshape = (O, C, k, k)
+    y_ref = oracle.loha.forward(x64, a1, b1, a2, b2, 0.5, wshape, _ca(s, p, d))
+    g, g64 = rnd(y_ref.shape, dtype, gen, 1.0 / np.sqrt(O))
+    ts = [x, w1a, w1b, w2a, w2b]
+    for t in ts:
+        t.requires_grad_(True)
+    y = ops.loha_conv2d(x, w1a, w1b, w2a, w2b, 0.5, wshape, (s, s), (p, p), (d, d))
+    grads = torch.autograd.grad(y, ts, g)
+    torch.cuda.synchronize()
+    ref = oracle.loha.backward(x64, g64, a1, b1, a2, b2, 0.5, wshape, _ca(s, p, d))
+    errs = {"y": err(y, y_ref, dtype), "dx": err(grads[0], ref[0], dtype)}
+    bounds = {"y": TOL["store_out"][dtype], "dx": TOL["store_out"][dtype]}
+    for n, gr, rf in zip(["d_w1a", "d_w1b", "d_w2a", "d_w2b"], grads[1:], ref[1:]):
+        errs[n] = err(gr, rf)
+        bounds[n] = TOL["f32_out"][dtype]
+    check(f"loha_conv2d[{shape},{dtype}]", errs, bounds)

@@ -1,0 +1,72 @@
+"""GPU parity of the native *modules* against the golden vectors produced by the real reference modules
+(tests/golden/make_golden.py): forward delta, dx and every parameter gradient, Linear and Conv2d."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import golden_case_names
+from gpu_util import check, dev, err
+
+pytestmark = pytest.mark.gpu
+
+
+def build(meta, a, dtype):
+    from lycoris_amd.modules import IA3Module, LoConModule, LohaModule, LokrModule
+    algos = {"locon": LoConModule, "loha": LohaModule, "lokr": LokrModule, "ia3": IA3Module}
+    lk = dict(meta["layer"])
+    kind = lk.pop("kind")
+    bias = "bias" in a
+    if kind == "linear":
+        layer = nn.Linear(lk["cin"], lk["cout"], bias=bias)
+    else:
+        layer = nn.Conv2d(lk["cin"], lk["cout"], lk["k"], lk["stride"], lk["padding"], lk.get("dilation", 1), bias=bias)
+    with torch.no_grad():
+        layer.weight.copy_(torch.from_numpy(a["W"]))
+        if bias:
+            layer.bias.copy_(torch.from_numpy(a["bias"]))
+    layer = layer.to(dev(), dtype).requires_grad_(False)
+    mod = algos[meta["algo"]]("t", layer, meta["multiplier"], **meta["mod"])
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            p.copy_(torch.from_numpy(a["p." + n]))
+    return layer, mod.to(dev())
+
+
+@pytest.mark.parametrize("name", golden_case_names())
+def test_module_matches_reference_golden(name, golden_cases):
+    meta, a = golden_cases[name]
+    dtype = torch.float32
+    layer, mod = build(meta, a, dtype)
+    x = torch.from_numpy(a["x"]).to(dev(), dtype).requires_grad_(True)
+    g = torch.from_numpy(a["g"]).to(dev(), dtype)
+    base = layer(x)
+    dx_base, = torch.autograd.grad(base, x, g)
+    mod.apply_to()
+    out = layer(x)
+    params = list(mod.named_parameters())
+    grads = torch.autograd.grad(out, [x] + [p for _, p in params], g)
+    mod.restore()
+    assert layer.forward.__func__ is type(layer).forward  # restore() put the original forward back
+    torch.cuda.synchronize()
+    errs = {"delta": err(out - base, a["delta"]), "dx": err(grads[0] - dx_base, a["dx"])}
+    for (n, _), gr in zip(params, grads[1:]):
+        errs["g." + n] = err(gr, a["g." + n])
+    # fp32 end to end; delta/dx are differences of fp32 tensors dominated by `base`, hence the looser bound there
+    bounds = {k: (2e-4 if k in ("delta", "dx") else 5e-5) for k in errs}
+    check(f"module_golden[{name}]", errs, bounds)
+
+
+@pytest.mark.parametrize("name", ["locon_linear", "lokr_linear_full", "loha_linear", "ia3_linear_out", "lokr_conv3_full"])
+def test_module_bypass_mode_equals_rebuild_semantics(name, golden_cases):
+    """bypass_mode=True must give the same numbers (rebuild semantics are canonical; upstream's LoKr
+    bypass drops `scale` (D5) and its IA3 bypass scales the bias (D9) -- the native path does neither)."""
+    meta, a = golden_cases[name]
+    meta = dict(meta, mod=dict(meta["mod"], bypass_mode=True))
+    layer, mod = build(meta, a, torch.float32)
+    x = torch.from_numpy(a["x"]).to(dev(), torch.float32)
+    base = layer(x)
+    mod.apply_to()
+    out = layer(x)
+    mod.restore()
+    check(f"module_bypass[{name}]", {"delta": err(out - base, a["delta"])}, {"delta": 2e-4})
