@@ -228,8 +228,8 @@ class LycorisBaseModule(nn.Module):
         dev, dt = self._own_device_dtype()
         self.to(self.org_weight)
         layer = self.org_module[0]
-        self.cached_org_weight = self.org_weight.data.cpu()
-        self.cached_org_bias = None if layer.bias is None else layer.bias.data.cpu()
+        self.cached_org_weight = self.org_weight.data.cpu().clone()  # clone: .cpu() aliases a CPU weight
+        self.cached_org_bias = None if layer.bias is None else layer.bias.data.cpu().clone()
         weight, bias = self.get_merged_weight(multiplier, self.org_weight.shape, self.org_weight.device)
         self.org_weight = weight
         if bias is not None:

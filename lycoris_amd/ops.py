@@ -17,6 +17,49 @@ from . import _native as N
 
 F32_ROWS = 0x100  # LYC_F32_ROWS
 
+# Fused gradient accumulation (optional): when a factor handed to an adapter op is a leaf Parameter whose .grad
+# already exists as a contiguous fp32 tensor (e.g. a view of lycoris_amd.grad_sync's arena), the backward kernels
+# accumulate straight into it (their outputs are "+=" anyway) and autograd gets None for that input -- no temporary,
+# no zero-fill, no separate accumulate kernel.  `_ACCUM["callback"]` is told which parameters were updated so a
+# gradient-sync object can count them like a post-accumulate hook would.
+_ACCUM = {"enabled": False, "callback": None}
+
+
+def fused_grad_accumulation(enabled: bool = True, callback=None):
+    _ACCUM["enabled"] = bool(enabled)
+    _ACCUM["callback"] = callback
+
+
+def _grad_targets(factors, needs):
+    """Per factor: the tensor the kernel should accumulate into (existing .grad or a fresh zero buffer) and whether
+    the result has to be handed back to autograd."""
+    bufs, hand_back = [], []
+    for t, need in zip(factors, needs):
+        if not need:
+            bufs.append(None)
+            hand_back.append(False)
+            continue
+        g = t.grad if (_ACCUM["enabled"] and t.is_leaf) else None
+        if g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == t.device:
+            bufs.append(g)
+            hand_back.append(False)
+        else:
+            bufs.append(torch.zeros(t.shape, dtype=torch.float32, device=t.device))
+            hand_back.append(True)
+    return bufs, hand_back
+
+
+def _finish_grads(factors, bufs, hand_back):
+    out = []
+    for t, b, hb in zip(factors, bufs, hand_back):
+        if hb:
+            out.append(b.to(t.dtype))
+        else:
+            out.append(None)
+            if b is not None and _ACCUM["callback"] is not None:
+                _ACCUM["callback"](t)
+    return out
+
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     t = t.detach()
@@ -46,18 +89,17 @@ class _LokrCore:
         return y, ()
 
     @staticmethod
-    def bwd(g, rows, fs, saved, alpha, need_x, need_f, f32_rows):
+    def bwd(g, rows, fs, saved, alpha, need_x, need_f, f32_rows, bufs):
         (a, b), (c, d) = fs[0].shape, fs[1].shape
         want_dx = need_x or need_f[0]  # the w1 gradient shares the pass over g that produces dx
         code = N.dtype_code(rows.dtype) | (F32_ROWS if f32_rows else 0)
         dx = None
         if want_dx:
             dx = torch.empty(rows.shape, dtype=torch.float32 if f32_rows else rows.dtype, device=rows.device)
-        dw1 = torch.zeros_like(fs[0]) if need_f[0] else None
-        dw2 = torch.zeros_like(fs[1]) if need_f[1] else None
+        dw1, dw2 = bufs
         N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(dx), N.ptr(dw1),
                N.ptr(dw2), rows.shape[0], a, b, c, d, alpha, code, N.stream_ptr(rows.device))
-        return (dx if need_x else None), [dw1, dw2]
+        return (dx if need_x else None)
 
 
 class _LoconCore:
@@ -80,18 +122,17 @@ class _LoconCore:
         return y, (t,)
 
     @staticmethod
-    def bwd(g, rows, fs, saved, alpha, need_x, need_f, f32_rows):
+    def bwd(g, rows, fs, saved, alpha, need_x, need_f, f32_rows, bufs):
         r, I = fs[0].shape
         O = fs[1].shape[0]
         M = rows.shape[0]
         code = N.dtype_code(rows.dtype) | (F32_ROWS if f32_rows else 0)
         dt = torch.zeros((M, r), dtype=torch.float32, device=rows.device)
         dx = torch.empty(rows.shape, dtype=torch.float32 if f32_rows else rows.dtype, device=rows.device) if need_x else None
-        dd = torch.zeros_like(fs[0]) if need_f[0] else None
-        du = torch.zeros_like(fs[1]) if need_f[1] else None
+        dd, du = bufs
         N.call("lyc_locon_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(saved[0]), N.ptr(dt),
                N.ptr(dx), N.ptr(dd), N.ptr(du), M, I, O, r, alpha, code, N.stream_ptr(rows.device))
-        return dx, [dd, du]
+        return dx
 
 
 class _LohaCore:
@@ -116,18 +157,20 @@ class _LohaCore:
         return y, (ws,)
 
     @staticmethod
-    def bwd(g, rows, fs, saved, alpha, need_x, need_f, f32_rows):
+    def bwd(g, rows, fs, saved, alpha, need_x, need_f, f32_rows, bufs):
         O, r = fs[0].shape
         I = fs[1].shape[1]
         M = rows.shape[0]
         code = N.dtype_code(rows.dtype) | (F32_ROWS if f32_rows else 0)
         any_f = any(need_f)
         dx = torch.empty(rows.shape, dtype=torch.float32 if f32_rows else rows.dtype, device=rows.device) if need_x else None
-        grads = [torch.zeros_like(t) for t in fs] if any_f else [None] * 4
+        grads = list(bufs)
+        if any_f and not all(need_f):  # the factor-gradient kernel produces the four gradients as a set
+            grads = [b if b is not None else torch.zeros_like(t) for b, t in zip(bufs, fs)]
         gw = torch.empty((O, I), dtype=torch.float32, device=rows.device) if any_f else None
         N.call("lyc_loha_linear_bwd", N.ptr(g), N.ptr(rows), *[N.ptr(t) for t in fs], N.ptr(saved[0]), N.ptr(gw),
                N.ptr(dx), *[N.ptr(t) for t in grads], M, I, O, r, alpha, code, N.stream_ptr(rows.device))
-        return dx, grads
+        return dx
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -183,10 +226,6 @@ def _col2im(dcols, xshape, dtype, geom):
 # ---------------------------------------------------------------------------------------------------------------
 # generic autograd Functions
 # ---------------------------------------------------------------------------------------------------------------
-def _grads_to(params, grads, needs):
-    return [g.to(p.dtype) if (need and g is not None) else None for p, g, need in zip(params, grads, needs)]
-
-
 class _AdapterLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, core, alpha, x, *factors):
@@ -210,8 +249,9 @@ class _AdapterLinear(torch.autograd.Function):
         g2 = g.reshape(-1, g.shape[-1])
         g2 = g2 if g2.is_contiguous() else g2.contiguous()
         need_x, need_f = ctx.needs_input_grad[2], list(ctx.needs_input_grad[3:])
-        dx, grads = core.bwd(g2, rows, fs, saved, alpha, need_x, need_f, False)
-        return (None, None, dx.view(xshape) if need_x else None, *_grads_to(factors, grads, need_f))
+        bufs, hand_back = _grad_targets(factors, need_f)
+        dx = core.bwd(g2, rows, fs, saved, alpha, need_x, need_f, False, bufs)
+        return (None, None, dx.view(xshape) if need_x else None, *_finish_grads(factors, bufs, hand_back))
 
 
 class _AdapterConv2d(torch.autograd.Function):
@@ -244,11 +284,12 @@ class _AdapterConv2d(torch.autograd.Function):
         need_x, need_f = ctx.needs_input_grad[3], list(ctx.needs_input_grad[4:])
         pointwise = _is_pointwise(geom)
         # k > 1: col2im sums up to kh*kw row entries per pixel -> keep them in fp32 and round once
-        dx_rows, grads = core.bwd(g_rows, rows, fs, saved, alpha, need_x, need_f, not pointwise)
+        bufs, hand_back = _grad_targets(factors, need_f)
+        dx_rows = core.bwd(g_rows, rows, fs, saved, alpha, need_x, need_f, not pointwise, bufs)
         dx = None
         if need_x:
             dx = _from_rows(dx_rows, xshape[0], xshape[2:]) if pointwise else _col2im(dx_rows, xshape, rows.dtype, geom)
-        return (None, None, None, dx, *_grads_to(factors, grads, need_f))
+        return (None, None, None, dx, *_finish_grads(factors, bufs, hand_back))
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,90 @@
+"""N > 1 path of the adapter-gradient sync, covered with world_size-2 gloo processes on CPU."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, bucket_bytes, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lycoris_amd.grad_sync import AdapterGradSync
+        torch.manual_seed(0)  # identical replicas
+        params = [torch.nn.Parameter(torch.randn(s)) for s in [(8, 8), (160, 16), (3,), (40, 5), ()]]
+        sync = AdapterGradSync(params, bucket_bytes=bucket_bytes)
+        assert sync.world_size == world
+        results = []
+        for step in range(2):
+            sync.zero_grad()
+            torch.manual_seed(100 * step + rank)  # different data per rank
+            loss = sum((p * torch.randn_like(p)).sum() for p in params)
+            loss.backward()
+            loss2 = sum((p ** 2).sum() for p in params[:3])  # gradient accumulation: second backward
+            sync_hooks_fired = [b.pending for b in sync.buckets]
+            sync.finish()
+            results.append([p.grad.clone() for p in params])
+            # every .grad is still a view of the arena
+            for p in params:
+                assert p.grad.untyped_storage().data_ptr() == sync.arenas[p.dtype].untyped_storage().data_ptr()
+        # reference: same computation, gradients averaged by hand
+        want = []
+        for step in range(2):
+            acc = None
+            for r in range(world):
+                torch.manual_seed(100 * step + r)
+                gs = [torch.randn_like(p) for p in params]
+                acc = gs if acc is None else [a + g for a, g in zip(acc, gs)]
+            want.append([a / world for a in acc])
+        ok = all(torch.allclose(g, w, atol=1e-6) for gs, ws in zip(results, want) for g, w in zip(gs, ws))
+        out.put((rank, ok, len(sync.buckets), sync.payload_bytes))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [1 << 30, 1024, 1])
+def test_gradients_are_averaged_across_two_ranks(bucket_bytes):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(out.get(timeout=5) for _ in range(2))
+    assert [g[1] for g in got] == [True, True], got
+    n_buckets = got[0][2]
+    assert n_buckets == (1 if bucket_bytes == 1 << 30 else (5 if bucket_bytes == 1 else n_buckets))
+    assert got[0][3] == 4 * (64 + 2560 + 3 + 200 + 1)
+
+
+def test_single_process_arena_semantics():
+    from lycoris_amd.grad_sync import AdapterGradSync
+    params = [torch.nn.Parameter(torch.randn(4, 4)), torch.nn.Parameter(torch.randn(7))]
+    sync = AdapterGradSync(params)
+    assert sync.world_size == 1 and len(sync.buckets) == 1
+    (params[0].sum() * 2 + params[1].sum()).backward()
+    sync.finish()
+    assert torch.all(params[0].grad == 2) and torch.all(params[1].grad == 1)
+    arena = sync.arenas[torch.float32]
+    assert float(arena.sum()) == 2 * 16 + 7
+    sync.zero_grad()
+    assert float(arena.abs().sum()) == 0 and float(params[0].grad.abs().sum()) == 0
+    params[0].grad = None  # e.g. optimizer.zero_grad(set_to_none=True)
+    sync.zero_grad()
+    assert params[0].grad is not None and params[0].grad.untyped_storage().data_ptr() == arena.untyped_storage().data_ptr()
+    sync.remove()
