@@ -7,6 +7,8 @@
 #include "conv_kernels.h"
 #include "dense_kernels.h"
 #include "ia3_kernels.h"
+#include "kron_dw2_fast.h"
+#include "kron_fast.h"
 #include "lokr_kernels.h"
 #include "skinny_kernels.h"
 
@@ -42,7 +44,27 @@ inline long round_up(long a, long b) { return cdiv(a, b) * b; }
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
+bool kron_fast_ok(const KronArgs& ka) {
+  if constexpr (sizeof(T) != 2) {
+    return false;
+  } else {
+    return ka.Gin == ka.Gout && (16 % ka.Gin) == 0 && (ka.K % 8) == 0 &&
+           (reinterpret_cast<uintptr_t>(ka.x) & 15u) == 0;
+  }
+}
+
+template <typename T>
 void launch_kron(const KronArgs& ka, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    if (kron_fast_ok<T>(ka)) {
+      dim3 grid((unsigned)cdiv(ka.M, KF_RT / ka.Gin), (unsigned)cdiv(ka.N, KF_TQ));
+      if (ka.dw1)
+        hipLaunchKernelGGL((kron_fast_kernel<T, true>), grid, dim3(NTHREADS), kron_fast_lds_bytes(true), st, ka);
+      else
+        hipLaunchKernelGGL((kron_fast_kernel<T, false>), grid, dim3(NTHREADS), kron_fast_lds_bytes(false), st, ka);
+      return;
+    }
+  }
   const int TM = KronCfg<T>::RT / ka.Gin;
   const bool wide = (ka.N % 64 == 0) || ka.N >= 256;
   dim3 grid((unsigned)cdiv(ka.M, TM), (unsigned)cdiv(ka.N, wide ? 64 : 32));
@@ -50,6 +72,36 @@ void launch_kron(const KronArgs& ka, hipStream_t st) {
     hipLaunchKernelGGL((kron_kernel<T, 64>), grid, dim3(NTHREADS), 0, st, ka);
   else
     hipLaunchKernelGGL((kron_kernel<T, 32>), grid, dim3(NTHREADS), 0, st, ka);
+}
+
+template <typename T, int NJ>
+void launch_kron_dw2_fast_nj(KronDw2Args da, hipStream_t st) {
+  const long rows_total = da.M * da.Gs;
+  const long tiles = cdiv(da.I, DW_TI) * cdiv(da.J, 32 * NJ);
+  const long ksteps = cdiv(rows_total, DW_BK);
+  long split = cdiv(320, tiles);
+  if (split > ksteps / 2) split = ksteps / 2;
+  if (split < 1) split = 1;
+  da.rows_per_block = round_up(cdiv(rows_total, split), DW_BK);
+  split = cdiv(rows_total, da.rows_per_block);
+  dim3 grid((unsigned)cdiv(da.I, DW_TI), (unsigned)cdiv(da.J, 32 * NJ), (unsigned)split);
+  hipLaunchKernelGGL((kron_dw2_fast_kernel<T, NJ>), grid, dim3(NTHREADS), 0, st, da);
+}
+
+template <typename T>
+bool launch_kron_dw2_fast(const KronDw2Args& da, hipStream_t st) {
+  if constexpr (sizeof(T) != 2) {
+    return false;
+  } else {
+    const bool ok = da.Gs == da.Gt && (16 % da.Gs) == 0 && (da.I % 8) == 0 && (da.J % 8) == 0 &&
+                    (reinterpret_cast<uintptr_t>(da.Q) & 15u) == 0 && (reinterpret_cast<uintptr_t>(da.P) & 15u) == 0;
+    if (!ok) return false;
+    if (da.J <= 32) launch_kron_dw2_fast_nj<T, 1>(da, st);
+    else if (da.J <= 64) launch_kron_dw2_fast_nj<T, 2>(da, st);
+    else if (da.J <= 96) launch_kron_dw2_fast_nj<T, 3>(da, st);
+    else launch_kron_dw2_fast_nj<T, 5>(da, st);
+    return true;
+  }
 }
 
 template <typename T>
@@ -164,6 +216,22 @@ int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const flo
   if (dw2) {
     KronDw2Args da{};
     da.M = M; da.alpha = alpha; da.out = dw2;
+    bool done = false;
+    if (a == b && (dtype & 0xff) != LYC_F32) {
+      // fast path orientation: rows of the tile run over q (exact operand g), the w1 mix is applied to x on the
+      // matrix cores; the output tile is [q][v] with v contiguous in dw2, so the atomics are coalesced
+      da.Q = g; da.Gs = a; da.I = c; da.P = x; da.Gt = b; da.J = d;
+      da.W = w1; da.ws = b; da.wt = 1; da.os = d; da.oj = 1;
+      switch (dtype & 0xff) {
+        case LYC_BF16: done = launch_kron_dw2_fast<__bf16>(da, st); break;
+        case LYC_F16: done = launch_kron_dw2_fast<_Float16>(da, st); break;
+        default: break;
+      }
+      if (done) {
+        if (int rc = check_launch("lokr_linear_bwd(dw2 fast)")) return rc;
+        return LYC_OK;
+      }
+    }
     if (d <= c) {  // rows of the output tile run over the smaller side (v), mix applied to g
       da.Q = x; da.Gs = b; da.I = d; da.P = g; da.Gt = a; da.J = c;
       da.W = w1; da.ws = 1; da.wt = b;  // W[s=u, t=p] = w1[p, u]

@@ -20,6 +20,14 @@ LOKR_SHAPES = [
     (130, 16, 2, 12, 50),     # a != b, TM = 64
     (19, 2, 32, 36, 5),       # large Gin
     (1, 8, 8, 40, 160),       # single row (time-embedding projections)
+    # fast path (Gin == Gout | 16, K % 8 == 0) corner cases
+    (50, 4, 4, 24, 200),      # G=4, two K chunks (160 + 40), N < 64
+    (37, 16, 16, 20, 96),     # G=16, ragged rows, N not a multiple of 8
+    (100, 8, 8, 72, 640),     # four full K chunks, N = 64 + 8
+    (9, 2, 2, 100, 8),        # G=2, K = 8
+    (20, 1, 1, 64, 64),       # G=1 (plain x @ w2^T scaled by w1[0,0])
+    (64, 8, 8, 17, 328),      # K = 2 chunks + 8, odd N (scalar stores)
+    (300, 8, 8, 1280, 160),   # ff.net.0.proj factors at reduced M
 ]
 
 
