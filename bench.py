@@ -235,7 +235,9 @@ def roofline(protos, algo, dtype, dev):
         y = torch.empty(M, O, device=dev, dtype=dtype)
         dx = torch.empty(M, I, device=dev, dtype=dtype)
         dw1 = torch.zeros_like(w1)
-        calls.append((count, rows, g, y, dx, w1.contiguous(), w2, dw1, (M, a, b, c, d)))
+        ws = torch.empty(int(N.load().lyc_lokr_bwd_workspace_bytes(M, a, b, c, d, N.dtype_code(dtype))) + 16,
+                         dtype=torch.uint8, device=dev)
+        calls.append((count, rows, g, y, dx, w1.contiguous(), w2, dw1, ws, (M, a, b, c, d)))
         # fwd: read rows, write y; bwd-dx(+dw1): read g, read rows, write dx; factors read in both
         alg_bytes += count * (esz * (M * I + M * O) + esz * (M * O + 2 * M * I) + 2 * 4 * (a * b + c * d))
     code = N.dtype_code(dtype)
@@ -246,11 +248,11 @@ def roofline(protos, algo, dtype, dev):
             nonlocal n_launch
             n = 0
             sp = N.stream_ptr(dev)
-            for count, rows, g, y, dx, w1, w2, dw1, (M, a, b, c, d) in calls:
+            for count, rows, g, y, dx, w1, w2, dw1, ws, (M, a, b, c, d) in calls:
                 for _ in range(count):
                     N.call("lyc_lokr_linear_fwd", N.ptr(rows), N.ptr(w1), N.ptr(w2), N.ptr(y), M, a, b, c, d, 1.0, code, sp)
                     N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(w1), N.ptr(w2), N.ptr(dx), N.ptr(dw1),
-                           None, M, a, b, c, d, 1.0, code, sp)
+                           None, N.ptr(ws), M, a, b, c, d, 1.0, code, sp)
                     n += 2
             n_launch = n
         run()

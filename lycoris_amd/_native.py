@@ -13,7 +13,7 @@ import torch
 
 _LIB_NAME = "liblycoris_amd.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 LYC_F32, LYC_F16, LYC_BF16 = 0, 1, 2
 _DTYPE_CODE = {torch.float32: LYC_F32, torch.float16: LYC_F16, torch.bfloat16: LYC_BF16}
@@ -23,7 +23,7 @@ _vp, _fp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, c
 # name -> argtypes; mirrors include/lycoris_amd.h one to one (tests/test_abi.py checks the header against this)
 SIGNATURES = {
     "lyc_lokr_linear_fwd": [_vp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
-    "lyc_lokr_linear_bwd": [_vp, _vp, _fp, _fp, _vp, _fp, _fp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    "lyc_lokr_linear_bwd": [_vp, _vp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_locon_linear_fwd": [_vp, _fp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_locon_linear_bwd": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _fp, _fp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_chan_scale": [_vp, _fp, _fp, _vp, _i64, _i64, _i64, _f32, _f32, _i32, _vp],
@@ -37,7 +37,10 @@ SIGNATURES = {
     "lyc_rows_to_nchw": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
 }
 # entry points that return something other than a status code
-VALUE_SIGNATURES = {"lyc_loha_workspace_bytes": ([_i32, _i32, _i32], ctypes.c_int64)}
+VALUE_SIGNATURES = {
+    "lyc_loha_workspace_bytes": ([_i32, _i32, _i32], ctypes.c_int64),
+    "lyc_lokr_bwd_workspace_bytes": ([_i64, _i32, _i32, _i32, _i32, _i32], ctypes.c_int64),
+}
 
 _lock = threading.Lock()
 _lib = None

@@ -2,13 +2,14 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/lycoris_amd.h"
 #include "conv_kernels.h"
 #include "dense_kernels.h"
 #include "ia3_kernels.h"
-#include "kron_dw2_fast.h"
-#include "kron_fast.h"
+#include "kron3.h"
+#include "kron_dw2s.h"
 #include "lokr_kernels.h"
 #include "skinny_kernels.h"
 
@@ -53,18 +54,52 @@ bool kron_fast_ok(const KronArgs& ka) {
   }
 }
 
-template <typename T>
-void launch_kron(const KronArgs& ka, hipStream_t st) {
-  if constexpr (sizeof(T) == 2) {
-    if (kron_fast_ok<T>(ka)) {
-      dim3 grid((unsigned)cdiv(ka.M, KF_RT / ka.Gin), (unsigned)cdiv(ka.N, KF_TQ));
-      if (ka.dw1)
-        hipLaunchKernelGGL((kron_fast_kernel<T, true>), grid, dim3(NTHREADS), kron_fast_lds_bytes(true), st, ka);
-      else
-        hipLaunchKernelGGL((kron_fast_kernel<T, false>), grid, dim3(NTHREADS), kron_fast_lds_bytes(false), st, ka);
-      return;
-    }
+// development override of the tile heuristics: LYC_K3_NI = 2 | 4
+int k3_ni_override() {
+  static const int v = [] { const char* e = getenv("LYC_K3_NI"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
+template <typename T, int NI, bool DW1>
+void launch_kron3_inst(const KronArgs& ka, dim3 grid, hipStream_t st) {
+  const int lds = kron3_lds_bytes(NI, ka.K > K3_KC ? 2 : 1);
+  if (lds > 64 * 1024) {  // more than the default dynamic-LDS window: opt in once per instantiation
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&kron3_kernel<T, NI, DW1>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kron3_lds_bytes(NI, 2));
+    (void)once;
   }
+  hipLaunchKernelGGL((kron3_kernel<T, NI, DW1>), grid, dim3(NTHREADS), lds, st, ka);
+}
+
+// 64-column tiles halve the x re-reads and the per-column w2 conversions; 32-column tiles double the workgroup count.
+// Small problems (fewer 64-wide tiles than ~1.5 per CU) are latency-bound and take the narrow tile.
+inline int kron3_pick_ni(const KronArgs& ka) {
+  if (int o = k3_ni_override()) return o;
+  const long mt = cdiv(ka.M, K3_RT / ka.Gin);
+  return (mt * cdiv(ka.N, 64) >= 384 && ka.N > 32) ? 4 : 2;
+}
+
+// returns the number of workgroups (= number of dw1 partials when ka.dw1_ws is set)
+template <typename T>
+long launch_kron3(const KronArgs& ka, hipStream_t st) {
+  const int ni = kron3_pick_ni(ka);
+  dim3 grid((unsigned)cdiv(ka.M, K3_RT / ka.Gin), (unsigned)cdiv(ka.N, 16 * ni));
+  if (ni == 4) {
+    if (ka.dw1) launch_kron3_inst<T, 4, true>(ka, grid, st);
+    else launch_kron3_inst<T, 4, false>(ka, grid, st);
+  } else {
+    if (ka.dw1) launch_kron3_inst<T, 2, true>(ka, grid, st);
+    else launch_kron3_inst<T, 2, false>(ka, grid, st);
+  }
+  return (long)grid.x * grid.y;
+}
+
+template <typename T>
+long launch_kron(KronArgs ka, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    if (kron_fast_ok<T>(ka)) return launch_kron3<T>(ka, st);
+  }
+  ka.dw1_ws = nullptr;  // the generic kernel accumulates dw1 with atomics
   const int TM = KronCfg<T>::RT / ka.Gin;
   const bool wide = (ka.N % 64 == 0) || ka.N >= 256;
   dim3 grid((unsigned)cdiv(ka.M, TM), (unsigned)cdiv(ka.N, wide ? 64 : 32));
@@ -72,36 +107,56 @@ void launch_kron(const KronArgs& ka, hipStream_t st) {
     hipLaunchKernelGGL((kron_kernel<T, 64>), grid, dim3(NTHREADS), 0, st, ka);
   else
     hipLaunchKernelGGL((kron_kernel<T, 32>), grid, dim3(NTHREADS), 0, st, ka);
+  return 0;
 }
 
-template <typename T, int NJ>
-void launch_kron_dw2_fast_nj(KronDw2Args da, hipStream_t st) {
-  const long rows_total = da.M * da.Gs;
-  const long tiles = cdiv(da.I, DW_TI) * cdiv(da.J, 32 * NJ);
-  const long ksteps = cdiv(rows_total, DW_BK);
-  long split = cdiv(320, tiles);
-  if (split > ksteps / 2) split = ksteps / 2;
-  if (split < 1) split = 1;
-  da.rows_per_block = round_up(cdiv(rows_total, split), DW_BK);
-  split = cdiv(rows_total, da.rows_per_block);
-  dim3 grid((unsigned)cdiv(da.I, DW_TI), (unsigned)cdiv(da.J, 32 * NJ), (unsigned)split);
-  hipLaunchKernelGGL((kron_dw2_fast_kernel<T, NJ>), grid, dim3(NTHREADS), 0, st, da);
+// dW2 streaming kernel: tile and split-K selection (see kron_dw2s.h).  dw1 partial reduction rides in an extra z slice.
+template <typename T, int MI, int NJ, int U>
+void launch_dw2s_inst(KronDw2sArgs da, long tiles_i, long tiles_j, hipStream_t st) {
+  const bool red = da.dw1_ws != nullptr;
+  dim3 grid((unsigned)tiles_i, (unsigned)tiles_j, (unsigned)(da.nsplit + (red ? 1 : 0)));
+  hipLaunchKernelGGL((kron_dw2s_kernel<T, MI, NJ, U>), grid, dim3(NTHREADS), 0, st, da);
+}
+
+int dw2s_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
 }
 
 template <typename T>
-bool launch_kron_dw2_fast(const KronDw2Args& da, hipStream_t st) {
-  if constexpr (sizeof(T) != 2) {
-    return false;
-  } else {
-    const bool ok = da.Gs == da.Gt && (16 % da.Gs) == 0 && (da.I % 8) == 0 && (da.J % 8) == 0 &&
-                    (reinterpret_cast<uintptr_t>(da.Q) & 15u) == 0 && (reinterpret_cast<uintptr_t>(da.P) & 15u) == 0;
-    if (!ok) return false;
-    if (da.J <= 32) launch_kron_dw2_fast_nj<T, 1>(da, st);
-    else if (da.J <= 64) launch_kron_dw2_fast_nj<T, 2>(da, st);
-    else if (da.J <= 96) launch_kron_dw2_fast_nj<T, 3>(da, st);
-    else launch_kron_dw2_fast_nj<T, 5>(da, st);
-    return true;
+void launch_dw2s(KronDw2sArgs da, hipStream_t st) {
+  static const int target_blocks = dw2s_env("LYC_DW2_BLOCKS", 512);       // development overrides
+  static const int atomic_budget = dw2s_env("LYC_DW2_ATOMICS", 600000);   // fp32 atomics per launch (~0.3 / ns)
+  static const int force_big = dw2s_env("LYC_DW2_BIG", -1);
+  const long rows_total = da.M * da.G;
+  auto plan = [&](int mi, int nj, long& tiles, long& split) {
+    tiles = cdiv(da.I, 16 * mi) * cdiv(da.J, 16 * nj);
+    long smax = atomic_budget / ((long)da.I * da.J);
+    if (smax < 1) smax = 1;
+    const long srows = rows_total / 128 > 0 ? rows_total / 128 : 1;
+    split = cdiv(target_blocks, tiles);
+    if (split > smax) split = smax;
+    if (split > srows) split = srows;
+    if (split < 1) split = 1;
+  };
+  long t44, s44, t22, s22;
+  plan(4, 4, t44, s44);
+  plan(2, 2, t22, s22);
+  bool big = t44 * s44 >= (target_blocks * 3) / 4;
+  if (force_big >= 0) big = force_big != 0;
+  long split = big ? s44 : s22;
+  da.rows_per_block = round_up(cdiv(rows_total, split), 32);
+  da.nsplit = (int)cdiv(rows_total, da.rows_per_block);
+  const long tiles = big ? t44 : t22;
+  if (da.dw1_ws != nullptr) {
+    long r = da.dw1_nblk / 64;
+    if (r > 16) r = 16;
+    if (r > tiles) r = tiles;
+    if (r < 1) r = 1;
+    da.dw1_red = (int)r;
   }
+  if (big) launch_dw2s_inst<T, 4, 4, 1>(da, cdiv(da.I, 64), cdiv(da.J, 64), st);
+  else launch_dw2s_inst<T, 2, 2, 4>(da, cdiv(da.I, 32), cdiv(da.J, 32), st);
 }
 
 template <typename T>
@@ -196,53 +251,82 @@ int lyc_lokr_linear_fwd(const void* x, const float* w1, const float* w2, void* y
   return check_launch("lokr_linear_fwd");
 }
 
+int64_t lyc_lokr_bwd_workspace_bytes(int64_t M, int a, int b, int c, int d, int dtype) {
+  (void)c; (void)dtype;
+  if (M <= 0 || a < 1 || b < 1 || d < 1 || a != b || a > 16) return 0;  // only the 16-bit fast path uses the scratch
+  // one G x G fp32 partial per workgroup of the dx launch, whose narrowest tiling is 128 rows x 32 columns
+  return (int64_t)cdiv(M, K3_RT / a) * cdiv(d, 32) * a * b * (int64_t)sizeof(float);
+}
+
 int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const float* w2, void* dx, float* dw1,
-                        float* dw2, int64_t M, int a, int b, int c, int d, float alpha, int dtype, void* stream) {
+                        float* dw2, void* ws, int64_t M, int a, int b, int c, int d, float alpha, int dtype,
+                        void* stream) {
   if (int rc = check_kron_dims(M, a, b, c, d)) return rc;
   if (!g || !x || !w1 || !w2) return fail(LYC_ERR_ARG, "lokr_linear_bwd: null pointer");
   if (M == 0) return LYC_OK;
   hipStream_t st = (hipStream_t)stream;
+  const bool is16 = (dtype & 0xff) != LYC_F32;
+  long dw1_partials = 0;  // > 0: the dx launch left that many [a*b] partials in ws
   if (dx || dw1) {
     // dx[m, u*d+v] = alpha * sum_p w1[p,u] * sum_q w2[q,v] * g[m, p*c+q]: the same kernel on (w1^T, w2^T),
     // with the w1 gradient taken from its stage-1 result (GZ) against x.
     if (!dx) return fail(LYC_ERR_ARG, "lokr_linear_bwd: dw1 requires dx (they share one pass over g)");
     KronArgs ka{};
     ka.x = g; ka.y = dx; ka.w1 = w1; ka.w2 = w2; ka.dw1 = dw1; ka.xref = dw1 ? x : nullptr;
+    ka.dw1_ws = (dw1 && ws) ? static_cast<float*>(ws) : nullptr;
     ka.M = M; ka.Gin = a; ka.K = c; ka.Gout = b; ka.N = d;
     ka.s1o = 1; ka.s1i = b; ka.s2n = 1; ka.s2k = d; ka.alpha = alpha; ka.out_f32 = (dtype & LYC_F32_ROWS) ? 1 : 0;
-    DISPATCH_DTYPE(dtype, launch_kron<T>(ka, st));
+    long nblk = 0;
+    DISPATCH_DTYPE(dtype, nblk = launch_kron<T>(ka, st));
     if (int rc = check_launch("lokr_linear_bwd(dx)")) return rc;
+    if (ka.dw1_ws) dw1_partials = nblk;  // 0 when the generic kernel ran (it used atomics)
   }
+  KronDw2sArgs ra{};  // w1-gradient reduction request
+  if (dw1_partials > 0) {
+    ra.dw1_ws = static_cast<const float*>(ws); ra.dw1 = dw1; ra.dw1_nblk = (int)dw1_partials; ra.dw1_n = a * b;
+    ra.dw1_red = 1;
+  }
+  bool reduced = dw1_partials == 0;
   if (dw2) {
-    KronDw2Args da{};
-    da.M = M; da.alpha = alpha; da.out = dw2;
     bool done = false;
-    if (a == b && (dtype & 0xff) != LYC_F32) {
-      // fast path orientation: rows of the tile run over q (exact operand g), the w1 mix is applied to x on the
-      // matrix cores; the output tile is [q][v] with v contiguous in dw2, so the atomics are coalesced
-      da.Q = g; da.Gs = a; da.I = c; da.P = x; da.Gt = b; da.J = d;
-      da.W = w1; da.ws = b; da.wt = 1; da.os = d; da.oj = 1;
+    if (is16 && a == b && (16 % a) == 0 && (c % 8) == 0 && (d % 8) == 0 &&
+        (reinterpret_cast<uintptr_t>(g) & 15u) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+      // rows of the tile run over q (exact operand g), the w1 mix is applied to x on the matrix cores; the output
+      // tile is [q][v] with v contiguous in dw2
+      KronDw2sArgs da = ra;
+      da.Q = g; da.P = x; da.W = w1; da.out = dw2; da.M = M; da.G = a; da.I = c; da.J = d;
+      da.ws = b; da.wt = 1; da.os = d; da.alpha = alpha;
       switch (dtype & 0xff) {
-        case LYC_BF16: done = launch_kron_dw2_fast<__bf16>(da, st); break;
-        case LYC_F16: done = launch_kron_dw2_fast<_Float16>(da, st); break;
+        case LYC_BF16: launch_dw2s<__bf16>(da, st); done = true; break;
+        case LYC_F16: launch_dw2s<_Float16>(da, st); done = true; break;
         default: break;
       }
       if (done) {
-        if (int rc = check_launch("lokr_linear_bwd(dw2 fast)")) return rc;
-        return LYC_OK;
+        if (int rc = check_launch("lokr_linear_bwd(dw2)")) return rc;
+        reduced = true;
       }
     }
-    if (d <= c) {  // rows of the output tile run over the smaller side (v), mix applied to g
-      da.Q = x; da.Gs = b; da.I = d; da.P = g; da.Gt = a; da.J = c;
-      da.W = w1; da.ws = 1; da.wt = b;  // W[s=u, t=p] = w1[p, u]
-      da.os = 1; da.oj = d;             // out(i=v, j=q) -> dw2[q*d + v]
-    } else {
-      da.Q = g; da.Gs = a; da.I = c; da.P = x; da.Gt = b; da.J = d;
-      da.W = w1; da.ws = b; da.wt = 1;  // W[s=p, t=u] = w1[p, u]
-      da.os = d; da.oj = 1;             // out(i=q, j=v) -> dw2[q*d + v]
+    if (!done) {
+      KronDw2Args da{};
+      da.M = M; da.alpha = alpha; da.out = dw2;
+      if (d <= c) {  // rows of the output tile run over the smaller side (v), mix applied to g
+        da.Q = x; da.Gs = b; da.I = d; da.P = g; da.Gt = a; da.J = c;
+        da.W = w1; da.ws = 1; da.wt = b;  // W[s=u, t=p] = w1[p, u]
+        da.os = 1; da.oj = d;             // out(i=v, j=q) -> dw2[q*d + v]
+      } else {
+        da.Q = g; da.Gs = a; da.I = c; da.P = x; da.Gt = b; da.J = d;
+        da.W = w1; da.ws = b; da.wt = 1;  // W[s=p, t=u] = w1[p, u]
+        da.os = d; da.oj = 1;             // out(i=q, j=v) -> dw2[q*d + v]
+      }
+      DISPATCH_DTYPE(dtype, launch_kron_dw2<T>(da, st));
+      if (int rc = check_launch("lokr_linear_bwd(dw2)")) return rc;
     }
-    DISPATCH_DTYPE(dtype, launch_kron_dw2<T>(da, st));
-    if (int rc = check_launch("lokr_linear_bwd(dw2)")) return rc;
+  }
+  if (!reduced) {  // partials were written but no dW2 launch carried the reduction
+    long r = dw1_partials / 64;
+    ra.dw1_red = (int)(r > 16 ? 16 : r < 1 ? 1 : r);
+    hipLaunchKernelGGL(kron_dw1_reduce_kernel, dim3((unsigned)ra.dw1_red), dim3(NTHREADS), 0, st, ra);
+    if (int rc = check_launch("lokr_linear_bwd(dw1 reduce)")) return rc;
   }
   return LYC_OK;
 }

@@ -1,0 +1,417 @@
+// kron3.h -- Kronecker (LoKr) row kernel for 16-bit activations, gfx950.  Third generation: built around the measured
+// cost structure of the SDXL shapes (benchmarks/kbench.cpp, benchmarks/ktrace.cpp): launches are 2-10 us long, so the
+// serial latency chain of one workgroup and the fp32 atomics decide the time, not peak bandwidth.
+//
+//   S1[(m,u), n]   = sum_k x3[(m,u), k] * w2[n, k]                      stage 1, v_mfma_f32_16x16x32 (w2 = hi + lo)
+//   y [(m,p), n]   = alpha * sum_u w1[p,u] * S1[(m,u), n]                stage 2, v_mfma_f32_16x16x16 in registers
+//   dW1[p,u]      += alpha * sum_{m,n} S1[(m,u), n] * xref[(m,p), n]     backward only, in registers
+//
+// Taken when Gin == Gout == G, 16 % G == 0, K % 8 == 0, x 16-byte aligned (every SDXL / SD1.5 layer, factor 1..16).
+//
+//   * x fragments go HBM -> registers (a row of x3 is used by exactly one wave); each fragment register is re-loaded
+//     for the next K chunk right after its last MFMA, so the loads of chunk c+1 fly under the MFMAs of chunk c;
+//   * the w2 chunk is converted fp32 -> hi/lo once per workgroup into a DOUBLE-buffered LDS tile [n][k] (row pitch
+//     = 16 mod 32 elements: conflict-free ds_read_b128 fragments), one barrier per chunk;
+//   * the w1 values are fetched at kernel start but first touched in the epilogue (no early round trip);
+//   * stage 2 is computed transposed: D[n, (m,p)] = S1^T (accumulator registers used as the A operand) x (I (x) w1)^T,
+//     which leaves each lane with 4 CONSECUTIVE n of one output row -> 8-byte global stores straight from registers,
+//     no LDS image, no barrier;
+//   * the w1 gradient also stays in registers: S1 hi/lo are transposed by an MFMA with the identity and fed back as the
+//     A operand against 8-byte xref fragments; one 64-lane atomic instruction per workgroup (same-line fp32 atomics
+//     serialise at ~16 ns each on this chip, so the count of atomic instructions is what matters).
+#pragma once
+#include <type_traits>
+
+#include "lokr_kernels.h"
+
+namespace lyc {
+
+template <typename T>
+struct Mma16;
+template <>
+struct Mma16<__bf16> {
+  typedef __attribute__((ext_vector_type(4))) short frag;
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Mma16<_Float16> {
+  typedef __attribute__((ext_vector_type(4))) _Float16 frag;
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int K3_RT = 128;          // stage-1 rows per workgroup (4 waves x 32)
+constexpr int K3_KC = 160;          // K chunk: the SDXL / SD1.5 factor dims are multiples of 160 or fit in one chunk
+constexpr int K3_KS = K3_KC / 32;   // MFMA k-steps per chunk
+constexpr int K3_LDB = K3_KC + 16;  // LDS row pitch of the w2 tiles (elements): 88 dwords = 8 mod 16
+
+// one hi/lo tile pair per buffer; a second buffer only when K needs more than one chunk
+__host__ __device__ constexpr int kron3_lds_bytes(int NI, int nbuf) {
+  const int b = nbuf * 2 * 16 * NI * K3_LDB * 2;
+  return b > 4096 ? b : 4096;  // the w1-gradient reduction scratch needs 4 KiB
+}
+
+enum { K3_W2_ROWS = 0, K3_W2_COLS = 1, K3_W2_SCALAR = 2 };
+
+// The vector modes load whole float4s only: ROWS needs K % 4 == 0 (the fast path has K % 8 == 0), COLS needs N % 4 == 0.
+__device__ __forceinline__ int k3_w2_mode(const float* w2, long s2n, long s2k, int N, int K) {
+  const bool aligned = (reinterpret_cast<uintptr_t>(w2) & 15u) == 0;
+  if (s2k == 1 && aligned && (s2n % 4 == 0) && (K % 4 == 0)) return K3_W2_ROWS;
+  if (s2n == 1 && aligned && (s2k % 4 == 0) && (N % 4 == 0)) return K3_W2_COLS;
+  return K3_W2_SCALAR;
+}
+
+template <typename T>
+__device__ __forceinline__ void k3_split4(const f32x4& v, T (&hi)[4], T (&lo)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split_f<T>(v[e], hi[e], lo[e]);
+}
+
+// w2 chunk: global -> registers -> LDS, in 4 (n) x 4 (k) blocks so that both orientations run the same instruction
+// stream.  Element (n, k) lives at w2[n * s2n + k * s2k], one of the strides is 1:
+//   ROWS (k contiguous): the four float4 of a block are its n rows (read along k), written as they are;
+//   COLS (n contiguous): the four float4 are its k rows (read along n), transposed in registers when written.
+// Consecutive threads walk the contiguous dimension.  SCALAR (odd strides / alignment) goes element-wise at store time.
+template <int TQ>
+struct K3Raw {
+  static constexpr int NQ = TQ / 4, KQ = K3_KC / 4;
+  static constexpr int N_BLK = (NQ * KQ + NTHREADS - 1) / NTHREADS;  // blocks per thread
+  static constexpr int NRAW = 4 * N_BLK;
+};
+
+template <int TQ>
+__device__ __forceinline__ void k3_load_w2(f32x4 (&raw)[K3Raw<TQ>::NRAW], int mode, const float* __restrict__ w2,
+                                           long s2n, long s2k, long n0, int N, long k0, int K) {
+  using R = K3Raw<TQ>;
+  if (mode == K3_W2_SCALAR) return;
+  const bool rows = (mode == K3_W2_ROWS);
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < R::N_BLK; ++it) {
+    const int b = tid + NTHREADS * it;
+    const int nq = rows ? b / R::KQ : b % R::NQ;
+    const int kq = rows ? b % R::KQ : b / R::NQ;
+    const long gn = n0 + 4 * nq, gk = k0 + 4 * kq;
+    const bool blk_ok = (b < R::NQ * R::KQ) && gn < N && gk < K;
+    // ROWS: float4 j = row gn + j, columns gk .. gk+3 (K % 4 == 0: whole);  COLS: float4 j = k row gk + j, n gn .. gn+3
+    // unconditional loads from a clamped (always valid) address, zeroed by a select: no exec-mask branches, so all
+    // loads of a chunk issue back to back
+    const long jstride = rows ? s2n : s2k;
+    const long jlimit = rows ? (long)N - gn : (long)K - gk;
+    const float* base = blk_ok ? w2 + gn * s2n + gk * s2k : w2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = blk_ok && j < jlimit;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? base + j * jstride : w2);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      raw[4 * it + j] = ok ? v : z;
+    }
+  }
+}
+
+template <typename T, int TQ>
+__device__ __forceinline__ void k3_store_w2(T* __restrict__ Bh, T* __restrict__ Bl,
+                                            const f32x4 (&raw)[K3Raw<TQ>::NRAW], int mode,
+                                            const float* __restrict__ w2, long s2n, long s2k, long n0, int N, long k0,
+                                            int K) {
+  using R = K3Raw<TQ>;
+  const int tid = threadIdx.x;
+  if (mode != K3_W2_SCALAR) {
+    const bool rows = (mode == K3_W2_ROWS);
+#pragma unroll
+    for (int it = 0; it < R::N_BLK; ++it) {
+      const int b = tid + NTHREADS * it;
+      const int nq = rows ? b / R::KQ : b % R::NQ;
+      const int kq = rows ? b % R::KQ : b / R::NQ;
+      if (b < R::NQ * R::KQ) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // LDS row n = 4 nq + e, columns 4 kq .. 4 kq + 3
+          const f32x4 t = {raw[4 * it][e], raw[4 * it + 1][e], raw[4 * it + 2][e], raw[4 * it + 3][e]};
+          const f32x4 r = raw[4 * it + e];
+          f32x4 v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = rows ? r[q] : t[q];
+          T h[4], l[4];
+          k3_split4<T>(v, h, l);
+          *reinterpret_cast<u32x2*>(Bh + (4 * nq + e) * K3_LDB + 4 * kq) = *reinterpret_cast<u32x2*>(h);
+          *reinterpret_cast<u32x2*>(Bl + (4 * nq + e) * K3_LDB + 4 * kq) = *reinterpret_cast<u32x2*>(l);
+        }
+      }
+    }
+  } else {  // unaligned / odd strides: element-wise, straight from global
+    for (int e = tid; e < TQ * K3_KC; e += NTHREADS) {
+      int n, k;
+      if (s2k == 1) {
+        n = e / K3_KC;
+        k = e % K3_KC;
+      } else {
+        n = e % TQ;
+        k = e / TQ;
+      }
+      const long gn = n0 + n, gk = k0 + k;
+      const float v = (gn < N && gk < K) ? w2[gn * s2n + gk * s2k] : 0.f;
+      T h, l;
+      split_f<T>(v, h, l);
+      Bh[n * K3_LDB + k] = h;
+      Bl[n * K3_LDB + k] = l;
+    }
+  }
+}
+
+// The body is a device function so that the fused backward launch (kron_bwd_fused_kernel) can run it as one role.
+// `bx`, `by`: tile coordinates (M tile, N tile).  `smem`: kron3_lds_bytes(NI, K > K3_KC ? 2 : 1) bytes, 16-byte aligned.
+template <typename T, int NI, bool WITH_DW1>
+__device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx, int by, int nbx) {
+  constexpr int MI = 2, TQ = 16 * NI;
+  constexpr int PLANE = TQ * K3_LDB;  // elements per hi or lo tile
+  T* Bbase = reinterpret_cast<T*>(smem);
+  using F8 = typename TT<T>::frag;
+  using F4 = typename Mma16<T>::frag;
+  using RW = K3Raw<TQ>;
+
+  const T* x = static_cast<const T*>(a.x);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int G = a.Gin, K = a.K, N = a.N;
+  const int lg = 31 - __builtin_clz((unsigned)G);  // G is a power of two (16 % G == 0)
+  const int TM = K3_RT >> lg;
+  const long n0 = (long)by * TQ;
+  const long row0 = ((long)bx * TM) << lg;
+  long rows_end = row0 + K3_RT;
+  if (rows_end > (a.M << lg)) rows_end = a.M << lg;
+  LYC_STAMP(0);
+
+  // (I (x) w1) block operand, raw fp32: lane (j = li, g) holds k = 4g .. 4g+3 of column j; converted in the epilogue
+  float w1raw[4];
+  {
+    const int mi_ = li >> lg, po = li & (G - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kk = 4 * g + j;
+      const float v = a.w1[po * a.s1o + (kk & (G - 1)) * a.s1i];  // always in range; selected, not branched
+      w1raw[j] = ((kk >> lg) == mi_) ? v : 0.f;
+    }
+  }
+
+  // this lane's two activation rows
+  const long gr0 = row0 + wave * 32 + li, gr1 = gr0 + 16;
+  const bool ok0 = gr0 < rows_end, ok1 = gr1 < rows_end;
+  const T* xr0 = x + (ok0 ? gr0 : row0) * K + 8 * g;  // out-of-range rows read row0 (valid) and are zeroed by a select
+  const T* xr1 = x + (ok1 ? gr1 : row0) * K + 8 * g;
+  auto load_frag_x = [&](bool ok, const T* p, long kk) -> F8 {
+    const bool k_ok = kk + 8 * g < K;  // K % 8 == 0: a fragment is all in or all out
+    const u32x4 v = *reinterpret_cast<const u32x4*>(p + (k_ok ? kk : 0));
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    const u32x4 r = (ok && k_ok) ? v : z;
+    return *reinterpret_cast<const F8*>(&r);
+  };
+
+  const int w2mode = k3_w2_mode(a.w2, a.s2n, a.s2k, N, K);
+  F8 af[MI][K3_KS];
+  f32x4 raw[RW::NRAW];
+#pragma unroll
+  for (int ks = 0; ks < K3_KS; ++ks) {
+    af[0][ks] = load_frag_x(ok0, xr0, ks * 32);
+    af[1][ks] = load_frag_x(ok1, xr1, ks * 32);
+  }
+  k3_load_w2<TQ>(raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, K);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = zero4();
+
+  LYC_STAMP(1);
+  k3_store_w2<T, TQ>(Bbase, Bbase + PLANE, raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, K);
+  LYC_STAMP(2);
+  __syncthreads();
+  LYC_STAMP(3);
+
+  // one chunk: NKS k-steps of MFMAs from (af, LDS tile); with MORE the fragment registers of each k-step are re-loaded
+  // for the next chunk as soon as they are free.  Straight-line code (no per-k-step branches), so the compiler hoists the
+  // ds_read_b128 fragment reads over the MFMAs.
+  auto chunk = [&](auto nks_tag, auto more_tag, const T* Bh, const T* Bl, long knext) {
+    constexpr int NKS = decltype(nks_tag)::value;
+    constexpr bool MORE = decltype(more_tag)::value;
+#pragma unroll
+    for (int ks = 0; ks < K3_KS; ++ks) {
+      if (ks < NKS) {
+        const int kofs = ks * 32 + 8 * g;
+        F8 bh[NI], bl[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          bh[ni] = *reinterpret_cast<const F8*>(Bh + (16 * ni + li) * K3_LDB + kofs);
+          bl[ni] = *reinterpret_cast<const F8*>(Bl + (16 * ni + li) * K3_LDB + kofs);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[0][ni] = TT<T>::mma(af[0][ks], bh[ni], acc[0][ni]);
+          acc[1][ni] = TT<T>::mma(af[1][ks], bh[ni], acc[1][ni]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[0][ni] = TT<T>::mma(af[0][ks], bl[ni], acc[0][ni]);
+          acc[1][ni] = TT<T>::mma(af[1][ks], bl[ni], acc[1][ni]);
+        }
+      }
+      if constexpr (MORE) {
+        af[0][ks] = load_frag_x(ok0, xr0, knext + ks * 32);
+        af[1][ks] = load_frag_x(ok1, xr1, knext + ks * 32);
+      }
+    }
+  };
+  auto last_chunk = [&](int nks, const T* Bh, const T* Bl) {
+    switch (nks) {
+      case 1: chunk(std::integral_constant<int, 1>{}, std::false_type{}, Bh, Bl, 0); break;
+      case 2: chunk(std::integral_constant<int, 2>{}, std::false_type{}, Bh, Bl, 0); break;
+      case 3: chunk(std::integral_constant<int, 3>{}, std::false_type{}, Bh, Bl, 0); break;
+      case 4: chunk(std::integral_constant<int, 4>{}, std::false_type{}, Bh, Bl, 0); break;
+      default: chunk(std::integral_constant<int, K3_KS>{}, std::false_type{}, Bh, Bl, 0); break;
+    }
+  };
+  static_assert(K3_KS == 5, "last_chunk dispatch assumes 5 k-steps per chunk");
+
+  int buf = 0;
+  for (long k0 = 0; k0 < K; k0 += K3_KC) {
+    const long krem = K - k0;
+    const T* Bh = Bbase + buf * 2 * PLANE;
+    const T* Bl = Bh + PLANE;
+    if (krem > K3_KC) {
+      k3_load_w2<TQ>(raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, k0 + K3_KC, K);
+      chunk(std::integral_constant<int, K3_KS>{}, std::true_type{}, Bh, Bl, k0 + K3_KC);
+      T* Nh = Bbase + (buf ^ 1) * 2 * PLANE;
+      k3_store_w2<T, TQ>(Nh, Nh + PLANE, raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, k0 + K3_KC, K);
+      __syncthreads();
+      buf ^= 1;
+    } else {
+      last_chunk((int)((krem + 31) / 32), Bh, Bl);
+    }
+  }
+  LYC_STAMP(4);
+
+  // ---- epilogue, all in registers ----
+  F4 a2h, a2l;
+  {
+    T h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_f<T>(w1raw[j], h[j], l[j]);
+    a2h = *reinterpret_cast<F4*>(h);
+    a2l = *reinterpret_cast<F4*>(l);
+  }
+  F4 ident;  // identity as a B operand: B[k = 4g+e][j = li]
+  {
+    T idv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) idv[e] = TT<T>::from_f((4 * g + e) == li ? 1.f : 0.f);
+    ident = *reinterpret_cast<F4*>(idv);
+  }
+  const long ldy = (long)G * N;
+  const bool y_vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & (a.out_f32 ? 15u : 7u)) == 0);
+  f32x4 cdw = zero4();
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const long R = row0 + wave * 32 + mi * 16 + li;  // output row (m, po) of this lane
+    const bool row_ok = R < rows_end;
+    const long rofs = (R >> lg) * ldy + (R & (G - 1)) * (long)N;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const long gn = n0 + 16 * ni + 4 * g;  // first of this lane's 4 output columns
+      T h[4], l[4];
+      k3_split4<T>(acc[mi][ni], h, l);
+      const F4 sh = *reinterpret_cast<F4*>(h), sl = *reinterpret_cast<F4*>(l);
+      f32x4 yv = zero4();
+      yv = Mma16<T>::mma(sh, a2h, yv);
+      yv = Mma16<T>::mma(sl, a2h, yv);
+      yv = Mma16<T>::mma(sh, a2l, yv);
+      if (row_ok && gn < N) {
+        if (a.out_f32) {
+          float* dst = static_cast<float*>(a.y) + rofs + gn;
+          const f32x4 o = {a.alpha * yv[0], a.alpha * yv[1], a.alpha * yv[2], a.alpha * yv[3]};
+          if (y_vec && gn + 4 <= N) {
+            *reinterpret_cast<f32x4*>(dst) = o;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (gn + e < N) dst[e] = o[e];
+          }
+        } else {
+          T* dst = static_cast<T*>(a.y) + rofs + gn;
+          T o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = TT<T>::from_f(a.alpha * yv[e]);
+          if (y_vec && gn + 4 <= N) {
+            *reinterpret_cast<u32x2*>(dst) = *reinterpret_cast<u32x2*>(o);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (gn + e < N) dst[e] = o[e];
+          }
+        }
+      }
+      if constexpr (WITH_DW1) {
+        // S1 (hi, lo) transposed through the matrix core: lane (li = row, 4g+e = n) -- exact, the values are T
+        const f32x4 th = Mma16<T>::mma(sh, ident, zero4());
+        const f32x4 tl = Mma16<T>::mma(sl, ident, zero4());
+        T thv[4], tlv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          thv[e] = TT<T>::from_f(th[e]);
+          tlv[e] = TT<T>::from_f(tl[e]);
+        }
+        // xref fragment: B[k = n][j = row li]
+        const T* xr = static_cast<const T*>(a.xref) + rofs + gn;
+        T bv[4];
+        const bool r_vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.xref) & 7u) == 0);
+        if (r_vec) {  // gn + 4 <= N or gn >= N; clamped address + select
+          const bool ok = row_ok && gn < N;
+          const u32x2 v = *reinterpret_cast<const u32x2*>(ok ? xr : static_cast<const T*>(a.xref));
+          const u32x2 z = {0u, 0u};
+          *reinterpret_cast<u32x2*>(bv) = ok ? v : z;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[e] = (row_ok && gn + e < N) ? xr[e] : TT<T>::from_f(0.f);
+        }
+        const F4 bf = *reinterpret_cast<F4*>(bv);
+        cdw = Mma16<T>::mma(*reinterpret_cast<F4*>(thv), bf, cdw);
+        cdw = Mma16<T>::mma(*reinterpret_cast<F4*>(tlv), bf, cdw);
+      }
+    }
+  }
+  LYC_STAMP(5);
+
+  if constexpr (WITH_DW1) {
+    // cdw: D[i = (m', u)][j = (m'', po)], lane (col j = li, rows 4g+r); only the diagonal blocks m' == m'' count.
+    // Cross-wave sum through LDS (the w2 tiles are dead: every wave is past the last chunk barrier or K fit in one
+    // chunk and everybody passed the first barrier... other waves may still READ the last tile -> barrier first).
+    float* red = reinterpret_cast<float*>(smem);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * g + r) * 16 + li] = cdw[r];
+    __syncthreads();
+    if (tid < G * G) {
+      const int u = tid >> lg, po = tid & (G - 1);
+      float s = 0.f;
+      for (int b = 0; b < (16 >> lg); ++b) {
+        const int e = ((b << lg) + u) * 16 + (b << lg) + po;
+        s += red[e] + red[256 + e] + red[512 + e] + red[768 + e];
+      }
+      const long e = (long)po * a.s1o + (long)u * a.s1i;  // position in dw1 memory order
+      if (a.dw1_ws != nullptr)  // partial of this workgroup; summed in fixed order by kron_dw2s_kernel's reducer slice
+        a.dw1_ws[((long)by * nbx + bx) * (G * G) + e] = a.alpha * s;
+      else
+        __hip_atomic_fetch_add(a.dw1 + e, a.alpha * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    LYC_STAMP(6);
+  }
+}
+
+template <typename T, int NI, bool WITH_DW1>
+__global__ __launch_bounds__(NTHREADS) void kron3_kernel(KronArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char k3_smem[];
+  kron3_body<T, NI, WITH_DW1>(a, k3_smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+
+}  // namespace lyc

@@ -1,0 +1,275 @@
+// kron_dw2s.h -- LoKr w2-gradient kernel for 16-bit activations, gfx950 ("s" = streaming waves).
+//
+//   dW2[i, j] += alpha * sum_{r = (m, s)} Q[r, i] * Z[r, j],     Z[(m, s), j] = sum_t W[s, t] * P[(m, t), j]
+//
+// A "TN" GEMM whose K dimension is the M * G flat rows (thousands) and whose output is the small w2 matrix.  Measured
+// on MI355X (benchmarks/atomic_bench.cpp): fp32 atomics retire at ~0.3 elements/ns chip-wide, so the old design (big
+// output tiles x ~100 row slabs = millions of atomics) spent 3/4 of its time in the atomic units.  This version:
+//   * small output tiles (16 MI x 16 NJ) and FEW row slabs: the split factor is chosen by the host so that the atomic
+//     traffic stays below ~0.4 M elements per launch; with one slab the tile is added with plain loads/stores;
+//   * the 4 waves of a workgroup split the ROWS of the slab (32-row steps, round robin) and each keeps a full copy of the
+//     output tile in registers: no barrier in the main loop, no shared staging -- each wave transposes its own 32-row
+//     Q / P blocks through a private LDS tile (4 x 8 register blocks, v_perm_b32, 8-byte writes);
+//   * the G x G mix runs on the matrix cores (v_mfma_f32_16x16x16, (I (x) W) hi/lo x P) and its accumulator layout is
+//     fed straight back as the B operand of the main v_mfma_f32_16x16x32 with a permuted K index (see below);
+//   * one cross-wave reduction through LDS at the end.
+// The extra z-slice of the grid reduces the per-workgroup w1-gradient partials written by kron3_kernel (fixed order,
+// no same-address atomic storm: 320 one-line atomics cost ~10 us on this chip).
+#pragma once
+#include "kron3.h"
+
+namespace lyc {
+
+struct KronDw2sArgs {
+  const void* Q;    // [M, G * I]   exact operand, contributes the output rows i
+  const void* P;    // [M, G * J]   operand that is mixed with W, contributes the output columns j
+  const float* W;   // element (s, t) at s * ws + t * wt
+  float* out;       // element (i, j) at i * os + j   (j contiguous)
+  long M;
+  int G, I, J;
+  long ws, wt, os;
+  long rows_per_block;  // flat (m, s) rows handled by one workgroup (multiple of 32)
+  int nsplit;           // row slabs (grid.z of the main part)
+  float alpha;
+  // w1-gradient partial reduction (runs in grid slice z == nsplit; nullptr = nothing to do)
+  const float* dw1_ws;  // [dw1_nblk][dw1_n] partials, already in dw1 memory order
+  float* dw1;
+  int dw1_nblk, dw1_n, dw1_red;  // partial blocks, elements per partial, reducer workgroups
+};
+
+constexpr int DS_LD = 36;  // LDS row pitch (elements) of the transposed [col][32 rows] tiles: 18 dwords
+
+template <int MI, int NJ>
+__host__ __device__ constexpr int kron_dw2s_lds_bytes() {
+  const int stage = NWAVES * 16 * (MI + NJ) * DS_LD * 2;
+  const int red = (NWAVES - 1) * MI * NJ * 256 * 4;
+  return stage > red ? stage : red;
+}
+
+__device__ __forceinline__ void dw1_reduce_role(const KronDw2sArgs& a, int r, float* lds) {
+  // reducer r of dw1_red sums partial blocks r, r + dw1_red, ...; 256 threads = (256 / n) lanes per element
+  const int n = a.dw1_n;  // G * G <= 256, a power of two
+  const int tid = threadIdx.x;
+  const int e = tid % n, part = tid / n, nparts = NTHREADS / n;
+  float s = 0.f;
+  for (int b = r + a.dw1_red * part; b < a.dw1_nblk; b += a.dw1_red * nparts) s += a.dw1_ws[(long)b * n + e];
+  lds[tid] = s;
+  __syncthreads();
+  if (tid < n) {
+    float t = 0.f;
+    for (int p = 0; p < nparts; ++p) t += lds[p * n + tid];
+    if (a.dw1_red == 1)
+      a.dw1[tid] += t;
+    else
+      __hip_atomic_fetch_add(a.dw1 + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// U = 32-row steps per prefetch group: the loads of two groups (2 * U * NB * 4 x 16 bytes per lane) are in flight while a
+// group is processed -- with ~1 wave per SIMD (small problems) only instruction-level parallelism hides the HBM latency.
+template <typename T, int MI, int NJ, int U>
+__global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
+  constexpr int TI = 16 * MI, TJ = 16 * NJ, NC = TI + TJ;
+  constexpr int NB = (NC + 63) / 64;  // 4 x 8 blocks per lane per 32-row step
+  __shared__ __attribute__((aligned(16))) char smem[kron_dw2s_lds_bytes<MI, NJ>()];
+  using F8 = typename TT<T>::frag;
+  using F4 = typename Mma16<T>::frag;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  if ((int)blockIdx.z == a.nsplit) {  // w1-gradient reducer slice
+    const int r = (int)(blockIdx.x + blockIdx.y * gridDim.x);
+    if (a.dw1_ws != nullptr && r < a.dw1_red) dw1_reduce_role(a, r, reinterpret_cast<float*>(smem));
+    return;
+  }
+
+  const T* Q = static_cast<const T*>(a.Q);
+  const T* P = static_cast<const T*>(a.P);
+  const int G = a.G;
+  const int lg = 31 - __builtin_clz((unsigned)G);
+  const long i0 = (long)blockIdx.x * TI, j0 = (long)blockIdx.y * TJ;
+  const long rows_total = a.M << lg;
+  const long rbeg = (long)blockIdx.z * a.rows_per_block;
+  long rend = rbeg + a.rows_per_block;
+  if (rend > rows_total) rend = rows_total;
+  T* tile = reinterpret_cast<T*>(smem) + wave * NC * DS_LD;  // this wave's private [NC cols][32 rows] tile
+
+  // this lane's 4 x 8 blocks: block b < TI: Q columns 8*(b % (TI/8)), rows 4*(b / (TI/8)); else P likewise
+  const T* bsrc[NB];
+  int bcol[NB], brow[NB];
+  bool bok[NB];
+  long bld[NB];
+#pragma unroll
+  for (int it = 0; it < NB; ++it) {
+    const int b = lane + 64 * it;
+    const bool isq = b < TI;
+    const int bb = isq ? b : b - TI;
+    const int ncg = isq ? TI / 8 : TJ / 8;
+    const int cg = bb % ncg, rg = bb / ncg;
+    const long gc = (isq ? i0 : j0) + 8 * cg;
+    const long ntot = isq ? a.I : a.J;
+    bok[it] = (b < NC) && gc < ntot;  // I, J % 8 == 0: a block column group is all in or all out
+    bld[it] = ntot;
+    bsrc[it] = (isq ? Q : P) + (bok[it] ? gc : 0);
+    bcol[it] = (isq ? 0 : TI) + 8 * cg;
+    brow[it] = 4 * rg;
+  }
+
+  auto load_step = [&](u32x4 (&raw)[NB][4], long r0) {
+#pragma unroll
+    for (int it = 0; it < NB; ++it)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long r = r0 + brow[it] + j;
+        const bool ok = bok[it] && r < rend;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(bsrc[it] + (ok ? r : rbeg) * bld[it]);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        raw[it][j] = ok ? v : z;
+      }
+  };
+  auto store_step = [&](const u32x4 (&raw)[NB][4]) {
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      if (lane + 64 * it < NC) {
+        T* dst = tile + bcol[it] * DS_LD + brow[it];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          u32x2 lo, hi;
+          lo[0] = __builtin_amdgcn_perm(raw[it][1][w], raw[it][0][w], 0x05040100u);
+          lo[1] = __builtin_amdgcn_perm(raw[it][3][w], raw[it][2][w], 0x05040100u);
+          hi[0] = __builtin_amdgcn_perm(raw[it][1][w], raw[it][0][w], 0x07060302u);
+          hi[1] = __builtin_amdgcn_perm(raw[it][3][w], raw[it][2][w], 0x07060302u);
+          *reinterpret_cast<u32x2*>(dst + (2 * w) * DS_LD) = lo;
+          *reinterpret_cast<u32x2*>(dst + (2 * w + 1) * DS_LD) = hi;
+        }
+      }
+    }
+  };
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) acc[mi][nj] = zero4();
+
+  // this wave's 32-row steps are rbeg + 32 * (wave + NWAVES * t); a group is U consecutive steps of the wave
+  constexpr long STEP = 32 * NWAVES, GROUP = STEP * U;
+  u32x4 rawA[U][NB][4], rawB[U][NB][4];
+  auto load_group = [&](u32x4 (&raw)[U][NB][4], long r0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_step(raw[u], r0 + STEP * u);
+  };
+  long r0 = rbeg + 32 * wave;
+  load_group(rawA, r0);
+  if (r0 + GROUP < rend) load_group(rawB, r0 + GROUP);
+
+  // mix operand (I (x) W) for one 16x16 block: lane (i = li, g) holds k = 4g .. 4g+3 (raw; split below)
+  F4 a2h, a2l;
+  {
+    const int mi_ = li >> lg, s_ = li & (G - 1);
+    T h[4], l[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int kk = 4 * g + jj;
+      const float w = a.W[s_ * a.ws + (kk & (G - 1)) * a.wt];
+      split_f<T>(((kk >> lg) == mi_) ? w : 0.f, h[jj], l[jj]);
+    }
+    a2h = *reinterpret_cast<F4*>(h);
+    a2l = *reinterpret_cast<F4*>(l);
+  }
+
+
+  auto process_step = [&](const u32x4 (&raw)[NB][4]) {
+    store_step(raw);
+    // mix: Z blocks of the NJ column blocks, both 16-row halves, kept as hi/lo B fragments of the main MFMA.
+    // K index permutation of the main MFMA: element e < 4 of lane group g <-> row 4g+e, e >= 4 <-> row 16 + 4g + e - 4
+    // (the accumulator layout of the two mix results); the A operand below is read with the same permutation.
+    F8 zh[NJ], zl[NJ];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+      T hh[8], ll[8];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const F4 pf = *reinterpret_cast<const F4*>(tile + (TI + 16 * nj + li) * DS_LD + 16 * rb + 4 * g);
+        f32x4 z = zero4();
+        z = Mma16<T>::mma(a2h, pf, z);
+        z = Mma16<T>::mma(a2l, pf, z);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_f<T>(z[e], hh[4 * rb + e], ll[4 * rb + e]);
+      }
+      zh[nj] = *reinterpret_cast<F8*>(hh);
+      zl[nj] = *reinterpret_cast<F8*>(ll);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const T* qrow = tile + (16 * mi + li) * DS_LD + 4 * g;
+      const u32x2 a0 = *reinterpret_cast<const u32x2*>(qrow);
+      const u32x2 a1 = *reinterpret_cast<const u32x2*>(qrow + 16);
+      const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
+      const F8 af = *reinterpret_cast<const F8*>(&av);
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) acc[mi][nj] = TT<T>::mma(af, zh[nj], acc[mi][nj]);
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) acc[mi][nj] = TT<T>::mma(af, zl[nj], acc[mi][nj]);
+    }
+  };
+  auto process_group = [&](const u32x4 (&raw)[U][NB][4], long r0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (r0 + STEP * u < rend) process_step(raw[u]);
+  };
+  while (r0 < rend) {
+    process_group(rawA, r0);
+    if (r0 + 2 * GROUP < rend) load_group(rawA, r0 + 2 * GROUP);
+    r0 += GROUP;
+    if (r0 >= rend) break;
+    process_group(rawB, r0);
+    if (r0 + 2 * GROUP < rend) load_group(rawB, r0 + 2 * GROUP);
+    r0 += GROUP;
+  }
+
+  // cross-wave reduction: waves 1..3 publish, wave 0 sums and updates the output tile
+  float* red = reinterpret_cast<float*>(smem);
+  __syncthreads();  // the staging tiles are dead
+  if (wave > 0) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj)
+        *reinterpret_cast<f32x4*>(red + (((wave - 1) * MI + mi) * NJ + nj) * 256 + lane * 4) = acc[mi][nj];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const bool plain = a.nsplit == 1;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) {
+        f32x4 s = acc[mi][nj];
+#pragma unroll
+        for (int w = 0; w < NWAVES - 1; ++w) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((w * MI + mi) * NJ + nj) * 256 + lane * 4);
+          s += o;
+        }
+        const long gj = j0 + 16 * nj + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long gi = i0 + 16 * mi + 4 * g + r;
+          if (gi < a.I && gj < a.J) {
+            float* dst = a.out + gi * a.os + gj;
+            if (plain)
+              *dst += a.alpha * s[r];
+            else
+              __hip_atomic_fetch_add(dst, a.alpha * s[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+  }
+}
+
+// stand-alone reduction of the w1-gradient partials (used when the caller asks for dw1 but not dw2)
+__global__ __launch_bounds__(NTHREADS) void kron_dw1_reduce_kernel(KronDw2sArgs a) {
+  __shared__ float lds[NTHREADS];
+  if ((int)blockIdx.x < a.dw1_red) dw1_reduce_role(a, (int)blockIdx.x, lds);
+}
+
+}  // namespace lyc

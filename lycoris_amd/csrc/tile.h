@@ -22,6 +22,24 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
+// Development-only phase stamps (benchmarks/kbench.cpp builds the kernels with -DLYC_TRACE): thread 0 of workgroup
+// LYC_TRACE_BLOCK records the shader clock at each LYC_STAMP(i); the product build compiles them out.
+#ifdef LYC_TRACE
+__device__ unsigned long long lyc_trace_buf[64];
+#ifndef LYC_TRACE_BLOCK
+#define LYC_TRACE_BLOCK 0
+#endif
+#define LYC_STAMP(i)                                                                                           \
+  do {                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y == LYC_TRACE_BLOCK) \
+      lyc_trace_buf[i] = __builtin_readcyclecounter();                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+#else
+#define LYC_STAMP(i) do {} while (0)
+#endif
+
 constexpr int WAVE = 64;
 constexpr int NTHREADS = 256;  // every kernel in this library runs 4 waves per workgroup
 constexpr int NWAVES = NTHREADS / WAVE;

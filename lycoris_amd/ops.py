@@ -97,8 +97,13 @@ class _LokrCore:
         if want_dx:
             dx = torch.empty(rows.shape, dtype=torch.float32 if f32_rows else rows.dtype, device=rows.device)
         dw1, dw2 = bufs
+        ws = None
+        if dw1 is not None:  # scratch for the per-workgroup w1-gradient partials (caching allocator: no sync, no memset)
+            nbytes = int(N.load().lyc_lokr_bwd_workspace_bytes(rows.shape[0], a, b, c, d, code & 0xff))
+            if nbytes:
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=rows.device)
         N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(dx), N.ptr(dw1),
-               N.ptr(dw2), rows.shape[0], a, b, c, d, alpha, code, N.stream_ptr(rows.device))
+               N.ptr(dw2), N.ptr(ws), rows.shape[0], a, b, c, d, alpha, code, N.stream_ptr(rows.device))
         return (dx if need_x else None)
 
 
