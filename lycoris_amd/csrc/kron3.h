@@ -181,6 +181,7 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
   const long row0 = ((long)bx * TM) << lg;
   long rows_end = row0 + K3_RT;
   if (rows_end > (a.M << lg)) rows_end = a.M << lg;
+  LYC_TRACE_DECL;
   LYC_STAMP(0);
 
   // (I (x) w1) block operand, raw fp32: lane (j = li, g) holds k = 4g .. 4g+3 of column j; converted in the epilogue
@@ -381,6 +382,7 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
     }
   }
   LYC_STAMP(5);
+  LYC_TRACE_FLUSH();
 
   if constexpr (WITH_DW1) {
     // cdw: D[i = (m', u)][j = (m'', po)], lane (col j = li, rows 4g+r); only the diagonal blocks m' == m'' count.

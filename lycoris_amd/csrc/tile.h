@@ -22,22 +22,30 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
-// Development-only phase stamps (benchmarks/kbench.cpp builds the kernels with -DLYC_TRACE): thread 0 of workgroup
-// LYC_TRACE_BLOCK records the shader clock at each LYC_STAMP(i); the product build compiles them out.
+// Development-only phase stamps (benchmarks/ktrace.cpp builds the kernels with -DLYC_TRACE).  The shader clock is read
+// into registers at each LYC_STAMP(i) and written out once by LYC_TRACE_FLUSH(): a store per stamp would sit in the
+// vmcnt queue and lengthen every later s_waitcnt vmcnt, i.e. distort exactly what is being measured.
 #ifdef LYC_TRACE
-__device__ unsigned long long lyc_trace_buf[64];
+__device__ unsigned long long lyc_trace_buf[32];
 #ifndef LYC_TRACE_BLOCK
 #define LYC_TRACE_BLOCK 0
 #endif
-#define LYC_STAMP(i)                                                                                           \
+#define LYC_TRACE_DECL unsigned long long lyc_t[32] = {0}
+#define LYC_STAMP(i)                                   \
+  do {                                                 \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    lyc_t[i] = __builtin_readcyclecounter();           \
+    __builtin_amdgcn_sched_barrier(0);                 \
+  } while (0)
+#define LYC_TRACE_FLUSH()                                                                                      \
   do {                                                                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
     if (threadIdx.x == 0 && blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y == LYC_TRACE_BLOCK) \
-      lyc_trace_buf[i] = __builtin_readcyclecounter();                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
+      _Pragma("unroll") for (int i_ = 0; i_ < 32; ++i_) lyc_trace_buf[i_] = lyc_t[i_];                         \
   } while (0)
 #else
+#define LYC_TRACE_DECL do {} while (0)
 #define LYC_STAMP(i) do {} while (0)
+#define LYC_TRACE_FLUSH() do {} while (0)
 #endif
 
 constexpr int WAVE = 64;
