@@ -60,15 +60,22 @@ int k3_ni_override() {
   return v;
 }
 
-template <typename T, int NI, bool DW1>
-void launch_kron3_inst(const KronArgs& ka, dim3 grid, hipStream_t st) {
-  const int lds = kron3_lds_bytes(NI, ka.K > K3_KC ? 2 : 1);
+template <typename T, int NI, bool DW1, bool GATHER>
+void launch_kron3_inst2(const KronArgs& ka, dim3 grid, hipStream_t st) {
+  const long nseg = (ka.gat.mode ? ka.gat.taps : 1) * cdiv(ka.K, kron3_kc(NI));
+  const int lds = kron3_lds_bytes(NI, nseg > 1 ? 2 : 1);
   if (lds > 64 * 1024) {  // more than the default dynamic-LDS window: opt in once per instantiation
-    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&kron3_kernel<T, NI, DW1>),
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&kron3_kernel<T, NI, DW1, GATHER>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kron3_lds_bytes(NI, 2));
     (void)once;
   }
-  hipLaunchKernelGGL((kron3_kernel<T, NI, DW1>), grid, dim3(NTHREADS), lds, st, ka);
+  hipLaunchKernelGGL((kron3_kernel<T, NI, DW1, GATHER>), grid, dim3(NTHREADS), lds, st, ka);
+}
+
+template <typename T, int NI, bool DW1>
+void launch_kron3_inst(const KronArgs& ka, dim3 grid, hipStream_t st) {
+  if (ka.gat.mode) launch_kron3_inst2<T, NI, DW1, true>(ka, grid, st);
+  else launch_kron3_inst2<T, NI, DW1, false>(ka, grid, st);
 }
 
 // 64-column tiles halve the x re-reads and the per-column w2 conversions; 32-column tiles double the workgroup count.

@@ -44,13 +44,16 @@ struct Mma16<_Float16> {
 };
 
 constexpr int K3_RT = 128;          // stage-1 rows per workgroup (4 waves x 32)
-constexpr int K3_KC = 160;          // K chunk: the SDXL / SD1.5 factor dims are multiples of 160 or fit in one chunk
-constexpr int K3_KS = K3_KC / 32;   // MFMA k-steps per chunk
-constexpr int K3_LDB = K3_KC + 16;  // LDS row pitch of the w2 tiles (elements): 88 dwords = 8 mod 16
+// K chunk per LDS tile (template parameter KC, a multiple of 32):
+//   160 for the narrow tile (NI = 2, small latency-bound problems: the SDXL / SD1.5 factor dims are multiples of 160 or
+//       fit in one chunk, so most launches have a single segment and a single barrier);
+//    96 for the wide tile (NI = 4, throughput-bound problems: fewer live registers -> 3-4 waves per SIMD).
+// LDS row pitch of the w2 tiles = KC + 16 elements (8 mod 16 dwords: conflict-free ds_read_b128 fragments).
+__host__ __device__ constexpr int kron3_kc(int NI) { return NI == 2 ? 160 : 96; }
 
-// one hi/lo tile pair per buffer; a second buffer only when K needs more than one chunk
+// one hi/lo tile pair per buffer; a second buffer only when there is more than one segment
 __host__ __device__ constexpr int kron3_lds_bytes(int NI, int nbuf) {
-  const int b = nbuf * 2 * 16 * NI * K3_LDB * 2;
+  const int b = nbuf * 2 * 16 * NI * (kron3_kc(NI) + 16) * 2;
   return b > 4096 ? b : 4096;  // the w1-gradient reduction scratch needs 4 KiB
 }
 
@@ -75,17 +78,17 @@ __device__ __forceinline__ void k3_split4(const f32x4& v, T (&hi)[4], T (&lo)[4]
 //   ROWS (k contiguous): the four float4 of a block are its n rows (read along k), written as they are;
 //   COLS (n contiguous): the four float4 are its k rows (read along n), transposed in registers when written.
 // Consecutive threads walk the contiguous dimension.  SCALAR (odd strides / alignment) goes element-wise at store time.
-template <int TQ>
+template <int TQ, int KC>
 struct K3Raw {
-  static constexpr int NQ = TQ / 4, KQ = K3_KC / 4;
+  static constexpr int NQ = TQ / 4, KQ = KC / 4;
   static constexpr int N_BLK = (NQ * KQ + NTHREADS - 1) / NTHREADS;  // blocks per thread
   static constexpr int NRAW = 4 * N_BLK;
 };
 
-template <int TQ>
-__device__ __forceinline__ void k3_load_w2(f32x4 (&raw)[K3Raw<TQ>::NRAW], int mode, const float* __restrict__ w2,
+template <int TQ, int KC>
+__device__ __forceinline__ void k3_load_w2(f32x4 (&raw)[(K3Raw<TQ, KC>::NRAW)], int mode, const float* __restrict__ w2,
                                            long s2n, long s2k, long n0, int N, long k0, int K) {
-  using R = K3Raw<TQ>;
+  using R = K3Raw<TQ, KC>;
   if (mode == K3_W2_SCALAR) return;
   const bool rows = (mode == K3_W2_ROWS);
   const int tid = threadIdx.x;
@@ -112,12 +115,13 @@ __device__ __forceinline__ void k3_load_w2(f32x4 (&raw)[K3Raw<TQ>::NRAW], int mo
   }
 }
 
-template <typename T, int TQ>
+template <typename T, int TQ, int KC>
 __device__ __forceinline__ void k3_store_w2(T* __restrict__ Bh, T* __restrict__ Bl,
-                                            const f32x4 (&raw)[K3Raw<TQ>::NRAW], int mode,
+                                            const f32x4 (&raw)[(K3Raw<TQ, KC>::NRAW)], int mode,
                                             const float* __restrict__ w2, long s2n, long s2k, long n0, int N, long k0,
                                             int K) {
-  using R = K3Raw<TQ>;
+  using R = K3Raw<TQ, KC>;
+  constexpr int K3_LDB = KC + 16, K3_KC = KC;
   const int tid = threadIdx.x;
   if (mode != K3_W2_SCALAR) {
     const bool rows = (mode == K3_W2_ROWS);
@@ -163,14 +167,15 @@ __device__ __forceinline__ void k3_store_w2(T* __restrict__ Bh, T* __restrict__ 
 
 // The body is a device function so that the fused backward launch (kron_bwd_fused_kernel) can run it as one role.
 // `bx`, `by`: tile coordinates (M tile, N tile).  `smem`: kron3_lds_bytes(NI, K > K3_KC ? 2 : 1) bytes, 16-byte aligned.
-template <typename T, int NI, bool WITH_DW1>
+template <typename T, int NI, bool WITH_DW1, bool GATHER>
 __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx, int by, int nbx) {
   constexpr int MI = 2, TQ = 16 * NI;
+  constexpr int K3_KC = kron3_kc(NI), K3_KS = K3_KC / 32, K3_LDB = K3_KC + 16;
   constexpr int PLANE = TQ * K3_LDB;  // elements per hi or lo tile
   T* Bbase = reinterpret_cast<T*>(smem);
   using F8 = typename TT<T>::frag;
   using F4 = typename Mma16<T>::frag;
-  using RW = K3Raw<TQ>;
+  using RW = K3Raw<TQ, K3_KC>;
 
   const T* x = static_cast<const T*>(a.x);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
@@ -196,11 +201,48 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
     }
   }
 
-  // this lane's two activation rows
+  // this lane's two stage-1 rows (dst pixel, group).  With a gather the operand row of tap t comes from another pixel.
   const long gr0 = row0 + wave * 32 + li, gr1 = gr0 + 16;
   const bool ok0 = gr0 < rows_end, ok1 = gr1 < rows_end;
-  const T* xr0 = x + (ok0 ? gr0 : row0) * K + 8 * g;  // out-of-range rows read row0 (valid) and are zeroed by a select
-  const T* xr1 = x + (ok1 ? gr1 : row0) * K + 8 * g;
+  const int taps = GATHER ? a.gat.taps : 1;
+  int pb[2], ph_[2], pw_[2];  // (image, h, w) of the two destination pixels
+  if constexpr (GATHER) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const long pix = ((r ? (ok1 ? gr1 : row0) : (ok0 ? gr0 : row0)) >> lg);
+      const int hw = a.gat.Hd * a.gat.Wd;
+      pb[r] = (int)(pix / hw);
+      const int rem = (int)(pix - (long)pb[r] * hw);
+      ph_[r] = rem / a.gat.Wd;
+      pw_[r] = rem - ph_[r] * a.gat.Wd;
+    }
+  }
+  // row base pointer (+ 8g) and validity of lane row r for tap t
+  auto row_src = [&](int r, int t, const T*& p, bool& ok) {
+    const long gr = r ? gr1 : gr0;
+    const bool rok = r ? ok1 : ok0;
+    if constexpr (!GATHER) {
+      ok = rok;
+      p = x + (rok ? gr : row0) * K + 8 * g;
+      return;
+    }
+    const int i = t / a.gat.kw, j = t - i * a.gat.kw;
+    int hs, ws;
+    bool v;
+    if (a.gat.mode == 1) {
+      hs = ph_[r] * a.gat.sh - a.gat.ph + i * a.gat.dh;
+      ws = pw_[r] * a.gat.sw - a.gat.pw + j * a.gat.dw;
+      v = hs >= 0 && hs < a.gat.Hs && ws >= 0 && ws < a.gat.Ws;
+    } else {
+      const int hn = ph_[r] + a.gat.ph - i * a.gat.dh, wn = pw_[r] + a.gat.pw - j * a.gat.dw;
+      hs = hn / a.gat.sh;
+      ws = wn / a.gat.sw;
+      v = hn >= 0 && wn >= 0 && hs * a.gat.sh == hn && ws * a.gat.sw == wn && hs < a.gat.Hs && ws < a.gat.Ws;
+    }
+    ok = rok && v;
+    const long spix = ok ? ((long)pb[r] * a.gat.Hs + hs) * a.gat.Ws + ws : 0;
+    p = x + ((spix << lg) + (gr & (G - 1))) * K + 8 * g;
+  };
   auto load_frag_x = [&](bool ok, const T* p, long kk) -> F8 {
     const bool k_ok = kk + 8 * g < K;  // K % 8 == 0: a fragment is all in or all out
     const u32x4 v = *reinterpret_cast<const u32x4*>(p + (k_ok ? kk : 0));
@@ -212,12 +254,18 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
   const int w2mode = k3_w2_mode(a.w2, a.s2n, a.s2k, N, K);
   F8 af[MI][K3_KS];
   f32x4 raw[RW::NRAW];
+  {
+    const T *p0, *p1;
+    bool v0, v1;
+    row_src(0, 0, p0, v0);
+    row_src(1, 0, p1, v1);
 #pragma unroll
-  for (int ks = 0; ks < K3_KS; ++ks) {
-    af[0][ks] = load_frag_x(ok0, xr0, ks * 32);
-    af[1][ks] = load_frag_x(ok1, xr1, ks * 32);
+    for (int ks = 0; ks < K3_KS; ++ks) {
+      af[0][ks] = load_frag_x(v0, p0, ks * 32);
+      af[1][ks] = load_frag_x(v1, p1, ks * 32);
+    }
   }
-  k3_load_w2<TQ>(raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, K);
+  k3_load_w2<TQ, K3_KC>(raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, K);
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -226,7 +274,7 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = zero4();
 
   LYC_STAMP(1);
-  k3_store_w2<T, TQ>(Bbase, Bbase + PLANE, raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, K);
+  k3_store_w2<T, TQ, K3_KC>(Bbase, Bbase + PLANE, raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, K);
   LYC_STAMP(2);
   __syncthreads();
   LYC_STAMP(3);
@@ -234,7 +282,8 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
   // one chunk: NKS k-steps of MFMAs from (af, LDS tile); with MORE the fragment registers of each k-step are re-loaded
   // for the next chunk as soon as they are free.  Straight-line code (no per-k-step branches), so the compiler hoists the
   // ds_read_b128 fragment reads over the MFMAs.
-  auto chunk = [&](auto nks_tag, auto more_tag, const T* Bh, const T* Bl, long knext) {
+  auto chunk = [&](auto nks_tag, auto more_tag, const T* Bh, const T* Bl, const T* np0, bool nv0, const T* np1,
+                   bool nv1, long knext) {
     constexpr int NKS = decltype(nks_tag)::value;
     constexpr bool MORE = decltype(more_tag)::value;
 #pragma unroll
@@ -258,37 +307,56 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
           acc[1][ni] = TT<T>::mma(af[1][ks], bl[ni], acc[1][ni]);
         }
       }
-      if constexpr (MORE) {
-        af[0][ks] = load_frag_x(ok0, xr0, knext + ks * 32);
-        af[1][ks] = load_frag_x(ok1, xr1, knext + ks * 32);
+      if constexpr (MORE) {  // the fragment registers of this k-step are free again: fetch the next segment's
+        af[0][ks] = load_frag_x(nv0, np0, knext + ks * 32);
+        af[1][ks] = load_frag_x(nv1, np1, knext + ks * 32);
       }
     }
   };
-  auto last_chunk = [&](int nks, const T* Bh, const T* Bl) {
+  auto run_chunk = [&](int nks, auto more_tag, const T* Bh, const T* Bl, const T* np0, bool nv0, const T* np1, bool nv1,
+                       long knext) {
     switch (nks) {
-      case 1: chunk(std::integral_constant<int, 1>{}, std::false_type{}, Bh, Bl, 0); break;
-      case 2: chunk(std::integral_constant<int, 2>{}, std::false_type{}, Bh, Bl, 0); break;
-      case 3: chunk(std::integral_constant<int, 3>{}, std::false_type{}, Bh, Bl, 0); break;
-      case 4: chunk(std::integral_constant<int, 4>{}, std::false_type{}, Bh, Bl, 0); break;
-      default: chunk(std::integral_constant<int, K3_KS>{}, std::false_type{}, Bh, Bl, 0); break;
+      case 1: chunk(std::integral_constant<int, 1>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext); break;
+      case 2: chunk(std::integral_constant<int, 2>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext); break;
+      case 3: chunk(std::integral_constant<int, 3>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext); break;
+      case 4: chunk(std::integral_constant<int, (K3_KS < 4 ? K3_KS : 4)>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext); break;
+      default: chunk(std::integral_constant<int, K3_KS>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext); break;
     }
   };
-  static_assert(K3_KS == 5, "last_chunk dispatch assumes 5 k-steps per chunk");
+  static_assert(K3_KS == 5 || K3_KS == 3, "run_chunk dispatch assumes 3 or 5 k-steps per chunk");
 
-  int buf = 0;
-  for (long k0 = 0; k0 < K; k0 += K3_KC) {
+  // segments: (tap, chunk of K3_KC within the K columns of the tap); one LDS w2 tile per segment, double buffered
+  const int cpt = (K + K3_KC - 1) / K3_KC;
+  const int nseg = taps * cpt;
+  int buf = 0, tap = 0;
+  long k0 = 0;
+  for (int sgm = 0; sgm < nseg; ++sgm) {
     const long krem = K - k0;
+    const int nks = krem >= K3_KC ? K3_KS : (int)((krem + 31) / 32);
     const T* Bh = Bbase + buf * 2 * PLANE;
     const T* Bl = Bh + PLANE;
-    if (krem > K3_KC) {
-      k3_load_w2<TQ>(raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, k0 + K3_KC, K);
-      chunk(std::integral_constant<int, K3_KS>{}, std::true_type{}, Bh, Bl, k0 + K3_KC);
+    if (sgm + 1 < nseg) {
+      int ntap = tap;
+      long nk0 = k0 + K3_KC;
+      if (nk0 >= K) {
+        nk0 = 0;
+        ++ntap;
+      }
+      const T *np0 = nullptr, *np1 = nullptr;
+      bool nv0 = false, nv1 = false;
+      row_src(0, ntap, np0, nv0);
+      row_src(1, ntap, np1, nv1);
+      const float* w2n = GATHER ? a.w2 + (long)ntap * a.gat.s2t : a.w2;
+      k3_load_w2<TQ, K3_KC>(raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, K);
+      run_chunk(nks, std::true_type{}, Bh, Bl, np0, nv0, np1, nv1, nk0);
       T* Nh = Bbase + (buf ^ 1) * 2 * PLANE;
-      k3_store_w2<T, TQ>(Nh, Nh + PLANE, raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, k0 + K3_KC, K);
+      k3_store_w2<T, TQ, K3_KC>(Nh, Nh + PLANE, raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, K);
       __syncthreads();
       buf ^= 1;
+      tap = ntap;
+      k0 = nk0;
     } else {
-      last_chunk((int)((krem + 31) / 32), Bh, Bl);
+      run_chunk(nks, std::false_type{}, Bh, Bl, nullptr, false, nullptr, false, 0);
     }
   }
   LYC_STAMP(4);
@@ -410,10 +478,10 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
   }
 }
 
-template <typename T, int NI, bool WITH_DW1>
+template <typename T, int NI, bool WITH_DW1, bool GATHER>
 __global__ __launch_bounds__(NTHREADS) void kron3_kernel(KronArgs a) {
   extern __shared__ __attribute__((aligned(16))) char k3_smem[];
-  kron3_body<T, NI, WITH_DW1>(a, k3_smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+  kron3_body<T, NI, WITH_DW1, GATHER>(a, k3_smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
 }  // namespace lyc

@@ -20,6 +20,19 @@
 
 namespace lyc {
 
+// Pixel-row gather of the stage-1 operand: the implicit-GEMM form of Conv2d on NHWC row matrices.  The stage-1 rows
+// are (destination pixel, group); for tap (i, j) of the kh x kw window the operand row comes from the source pixel
+//   mode 1 (forward,  dst = output pixel): hs = hd*sh - ph + i*dh                       (ws likewise)
+//   mode 2 (backward, dst = input pixel) : hs = (hd + ph - i*dh) / sh, if divisible     (the transposed conv)
+// rows that fall outside the source image (padding) read as zero.  The K dimension runs over (tap, K per tap).
+struct KronGather {
+  int mode;            // 0 = no gather (nn.Linear / 1x1 rows)
+  int taps, kw;        // kh * kw, kw
+  int Hs, Ws, Hd, Wd;  // source / destination spatial sizes
+  int sh, sw, ph, pw, dh, dw;
+  long s2t;            // w2 element offset per tap
+};
+
 struct KronArgs {
   const void* x;     // [M, Gin * K]
   void* y;           // [M, Gout * N]
@@ -33,6 +46,7 @@ struct KronArgs {
   long s1o, s1i, s2n, s2k;
   float alpha;
   int out_f32;       // write y as fp32 rows (LYC_F32_ROWS)
+  KronGather gat;    // kron3 only
 };
 
 template <typename T>
