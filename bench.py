@@ -62,7 +62,10 @@ class Layer:
             cin, ksz = spec["C"], (spec["k"], spec["k"])
         f32 = dict(device=dev, dtype=torch.float32, generator=gen)
         if algo == "lokr":  # factor=8, full-matrix w2 (lora_dim >= 10000): w1 [8,8], w2 [O/8, I/8(,k,k)]
-            self.params = [torch.randn(FACTOR, FACTOR, **f32) * 0.3, torch.randn(O // FACTOR, cin // FACTOR, *ksz, **f32) * 0.05]
+            w2 = torch.randn(O // FACTOR, cin // FACTOR, *ksz, **f32) * 0.05
+            if ksz:  # conv factor kept in channels_last memory: the implicit-GEMM kernels read / write it in place
+                w2 = w2.contiguous(memory_format=torch.channels_last)
+            self.params = [torch.randn(FACTOR, FACTOR, **f32) * 0.3, w2]
         elif algo == "locon":  # dim 16 / conv_dim 8
             r = 16 if not ksz or ksz == (1, 1) else 8
             self.params = [torch.randn(r, cin, *ksz, **f32) * 0.05, torch.randn(O, r, *([1] * len(ksz)), **f32) * 0.05]

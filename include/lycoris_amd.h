@@ -51,6 +51,28 @@ int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const flo
                         float* dw2, void* ws, int64_t M, int a, int b, int c, int d, float alpha, int dtype,
                         void* stream);
 
+/* ---- LoKr on nn.Conv2d (groups = 1): implicit GEMM, no im2col -------------------------------------
+ * replaces lycoris/modules/lokr.py:543-566 with F.conv2d (functional/general.py:6) and the grouped-conv bypass
+ * lycoris/functional/lokr.py:195-247.  Activations are NHWC ROW matrices (channels contiguous):
+ *   x_rows:[B*H*W, b*d]   y_rows / g_rows:[B*Ho*Wo, a*c]   dx_rows:[B*H*W, b*d]
+ * (lyc_nchw_to_rows / lyc_rows_to_nchw convert; a channels_last tensor already is such a matrix).
+ *   w1:[a,b]   w2p:[c, kh*kw, d] = the reference's lokr_w2 [c, d, kh, kw] with the kernel window moved in front of
+ *   the input-channel index (w2.permute(0,2,3,1): free when the parameter is kept in channels_last memory format);
+ *   dw2p has the same layout.
+ *   y[(b,ho,wo), p*c+q] = alpha * sum_u w1[p,u] * sum_{i,j,v} w2[q,v,i,j] * x[(b, ho*sh-ph+i*dh, wo*sw-pw+j*dw), u*d+v]
+ * The kernel window is walked inside the kernels (pixel-row gather, zero outside the image); dx is the transposed
+ * convolution with all taps summed in fp32 registers and rounded once.  Requires 16-bit activations, a == b in
+ * {4, 8, 16}, c % 8 == d % 8 == 0, 16-byte aligned rows; returns LYC_ERR_UNSUPPORTED otherwise (use the im2col
+ * lowering below).  `ws`: optional scratch of lyc_lokr_conv2d_bwd_workspace_bytes(...) bytes, as for the Linear form. */
+int lyc_lokr_conv2d_fwd(const void* x_rows, const float* w1, const float* w2p, void* y_rows, int64_t B, int64_t H,
+                        int64_t W, int a, int b, int c, int d, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                        int dw, float alpha, int dtype, void* stream);
+int64_t lyc_lokr_conv2d_bwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int a, int b, int d);
+int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1, const float* w2p, void* dx_rows,
+                        float* dw1, float* dw2p, void* ws, int64_t B, int64_t H, int64_t W, int a, int b, int c, int d,
+                        int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float alpha, int dtype,
+                        void* stream);
+
 /* ---- LoCon on nn.Linear ------------------------------------------------------------------------
  * replaces lycoris/modules/locon.py:309-332 (forward: make_weight + dense F.linear) and the bypass
  * lycoris/functional/locon.py:64-85 / modules/locon.py:286-304.

@@ -24,6 +24,8 @@ _vp, _fp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, c
 SIGNATURES = {
     "lyc_lokr_linear_fwd": [_vp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_lokr_linear_bwd": [_vp, _vp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    "lyc_lokr_conv2d_fwd": [_vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
+    "lyc_lokr_conv2d_bwd": [_vp, _vp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_locon_linear_fwd": [_vp, _fp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_locon_linear_bwd": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _fp, _fp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_chan_scale": [_vp, _fp, _fp, _vp, _i64, _i64, _i64, _f32, _f32, _i32, _vp],
@@ -40,6 +42,7 @@ SIGNATURES = {
 VALUE_SIGNATURES = {
     "lyc_loha_workspace_bytes": ([_i32, _i32, _i32], ctypes.c_int64),
     "lyc_lokr_bwd_workspace_bytes": ([_i64, _i32, _i32, _i32, _i32, _i32], ctypes.c_int64),
+    "lyc_lokr_conv2d_bwd_workspace_bytes": ([_i64, _i64, _i64, _i32, _i32, _i32], ctypes.c_int64),
 }
 
 _lock = threading.Lock()

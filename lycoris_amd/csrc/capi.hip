@@ -122,7 +122,10 @@ template <typename T, int MI, int NJ, int U>
 void launch_dw2s_inst(KronDw2sArgs da, long tiles_i, long tiles_j, hipStream_t st) {
   const bool red = da.dw1_ws != nullptr;
   dim3 grid((unsigned)tiles_i, (unsigned)tiles_j, (unsigned)(da.nsplit + (red ? 1 : 0)));
-  hipLaunchKernelGGL((kron_dw2s_kernel<T, MI, NJ, U>), grid, dim3(NTHREADS), 0, st, da);
+  if (da.gat.mode)
+    hipLaunchKernelGGL((kron_dw2s_kernel<T, MI, NJ, U, true>), grid, dim3(NTHREADS), 0, st, da);
+  else
+    hipLaunchKernelGGL((kron_dw2s_kernel<T, MI, NJ, U, false>), grid, dim3(NTHREADS), 0, st, da);
 }
 
 int dw2s_env(const char* name, int dflt) {
@@ -334,6 +337,113 @@ int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const flo
     ra.dw1_red = (int)(r > 16 ? 16 : r < 1 ? 1 : r);
     hipLaunchKernelGGL(kron_dw1_reduce_kernel, dim3((unsigned)ra.dw1_red), dim3(NTHREADS), 0, st, ra);
     if (int rc = check_launch("lokr_linear_bwd(dw1 reduce)")) return rc;
+  }
+  return LYC_OK;
+}
+
+// ---- LoKr on nn.Conv2d: implicit GEMM on NHWC row matrices (no im2col) -------------------------------------
+extern "C++" {
+namespace {
+struct ConvDims {
+  long Ho, Wo;
+  int taps;
+};
+int lokr_conv_check(ConvDims& cd, int64_t B, int64_t H, int64_t W, int a, int b, int c, int d, int kh, int kw, int sh,
+                    int sw, int ph, int pw, int dh, int dw, int dtype, const void* p0, const void* p1) {
+  if (B < 0 || H < 1 || W < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0 || dh < 1 || dw < 1)
+    return fail(LYC_ERR_ARG, "lokr_conv2d: bad geometry");
+  if (int rc = check_kron_dims(B * H * W, a, b, c, d)) return rc;
+  cd.Ho = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1;
+  cd.Wo = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
+  cd.taps = kh * kw;
+  if (cd.Ho < 1 || cd.Wo < 1) return fail(LYC_ERR_ARG, "lokr_conv2d: empty output");
+  const bool ok = (dtype & 0xff) != LYC_F32 && a == b && (a == 4 || a == 8 || a == 16) && (c % 8) == 0 && (d % 8) == 0 &&
+                  (reinterpret_cast<uintptr_t>(p0) & 15u) == 0 && (reinterpret_cast<uintptr_t>(p1) & 15u) == 0 &&
+                  H * W < (1 << 30) && cd.Ho * cd.Wo < (1 << 30);
+  if (!ok)
+    return fail(LYC_ERR_UNSUPPORTED,
+                "lokr_conv2d: the implicit-GEMM path needs 16-bit activations, a == b in {4, 8, 16}, c, d multiples of 8 "
+                "and 16-byte aligned rows; use the im2col lowering (lyc_im2col + lyc_lokr_linear_*) otherwise");
+  return LYC_OK;
+}
+KronGather make_gather(int mode, const ConvDims& cd, int64_t H, int64_t W, int kw, int sh, int sw, int ph, int pw, int dh,
+                       int dw, long s2t) {
+  KronGather gt{};
+  gt.mode = mode; gt.taps = cd.taps; gt.kw = kw;
+  if (mode == 1) { gt.Hs = (int)H; gt.Ws = (int)W; gt.Hd = (int)cd.Ho; gt.Wd = (int)cd.Wo; }
+  else { gt.Hs = (int)cd.Ho; gt.Ws = (int)cd.Wo; gt.Hd = (int)H; gt.Wd = (int)W; }
+  gt.sh = sh; gt.sw = sw; gt.ph = ph; gt.pw = pw; gt.dh = dh; gt.dw = dw; gt.s2t = s2t;
+  return gt;
+}
+}  // namespace
+}  // extern "C++"
+
+int lyc_lokr_conv2d_fwd(const void* x_rows, const float* w1, const float* w2p, void* y_rows, int64_t B, int64_t H,
+                        int64_t W, int a, int b, int c, int d, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                        int dw, float alpha, int dtype, void* stream) {
+  if (!x_rows || !w1 || !w2p || !y_rows) return fail(LYC_ERR_ARG, "lokr_conv2d_fwd: null pointer");
+  ConvDims cd{};
+  if (int rc = lokr_conv_check(cd, B, H, W, a, b, c, d, kh, kw, sh, sw, ph, pw, dh, dw, dtype, x_rows, y_rows)) return rc;
+  if (B == 0) return LYC_OK;
+  KronArgs ka{};
+  ka.x = x_rows; ka.y = y_rows; ka.w1 = w1; ka.w2 = w2p;
+  ka.M = B * cd.Ho * cd.Wo; ka.Gin = b; ka.K = d; ka.Gout = a; ka.N = c;
+  ka.s1o = b; ka.s1i = 1; ka.s2n = (long)cd.taps * d; ka.s2k = 1; ka.alpha = alpha;
+  ka.gat = make_gather(1, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
+  switch (dtype & 0xff) {
+    case LYC_BF16: launch_kron3<__bf16>(ka, (hipStream_t)stream); break;
+    default: launch_kron3<_Float16>(ka, (hipStream_t)stream); break;
+  }
+  return check_launch("lokr_conv2d_fwd");
+}
+
+int64_t lyc_lokr_conv2d_bwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int a, int b, int d) {
+  if (B <= 0 || H < 1 || W < 1 || a < 1 || a != b || a > 16 || d < 1) return 0;
+  return (int64_t)cdiv(B * H * W, K3_RT / a) * cdiv(d, 32) * a * b * (int64_t)sizeof(float);
+}
+
+int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1, const float* w2p, void* dx_rows,
+                        float* dw1, float* dw2p, void* ws, int64_t B, int64_t H, int64_t W, int a, int b, int c, int d,
+                        int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float alpha, int dtype,
+                        void* stream) {
+  if (!g_rows || !x_rows || !w1 || !w2p) return fail(LYC_ERR_ARG, "lokr_conv2d_bwd: null pointer");
+  ConvDims cd{};
+  if (int rc = lokr_conv_check(cd, B, H, W, a, b, c, d, kh, kw, sh, sw, ph, pw, dh, dw, dtype, x_rows, g_rows)) return rc;
+  if (dw1 && !dx_rows) return fail(LYC_ERR_ARG, "lokr_conv2d_bwd: dw1 requires dx (they share one pass over g)");
+  if (B == 0) return LYC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool bf = (dtype & 0xff) == LYC_BF16;
+  long dw1_partials = 0;
+  if (dx_rows) {
+    // transposed convolution: destination rows are INPUT pixels, the operand rows come from g (output pixels)
+    KronArgs ka{};
+    ka.x = g_rows; ka.y = dx_rows; ka.w1 = w1; ka.w2 = w2p; ka.dw1 = dw1; ka.xref = dw1 ? x_rows : nullptr;
+    ka.dw1_ws = (dw1 && ws) ? static_cast<float*>(ws) : nullptr;
+    ka.M = B * H * W; ka.Gin = a; ka.K = c; ka.Gout = b; ka.N = d;
+    ka.s1o = 1; ka.s1i = b; ka.s2n = 1; ka.s2k = (long)cd.taps * d; ka.alpha = alpha;
+    ka.gat = make_gather(2, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
+    const long nblk = bf ? launch_kron3<__bf16>(ka, st) : launch_kron3<_Float16>(ka, st);
+    if (int rc = check_launch("lokr_conv2d_bwd(dx)")) return rc;
+    if (ka.dw1_ws) dw1_partials = nblk;
+  }
+  KronDw2sArgs ra{};
+  if (dw1_partials > 0) {
+    ra.dw1_ws = static_cast<const float*>(ws); ra.dw1 = dw1; ra.dw1_nblk = (int)dw1_partials; ra.dw1_n = a * b;
+    ra.dw1_red = 1;
+  }
+  if (dw2p) {
+    KronDw2sArgs da = ra;
+    da.Q = g_rows; da.P = x_rows; da.W = w1; da.out = dw2p; da.M = B * cd.Ho * cd.Wo; da.G = a; da.I = c;
+    da.J = cd.taps * d; da.Jt = d; da.ws = b; da.wt = 1; da.os = (long)cd.taps * d; da.alpha = alpha;
+    da.gat = make_gather(1, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
+    if (bf) launch_dw2s<__bf16>(da, st);
+    else launch_dw2s<_Float16>(da, st);
+    if (int rc = check_launch("lokr_conv2d_bwd(dw2)")) return rc;
+  } else if (dw1_partials > 0) {
+    long r = dw1_partials / 64;
+    ra.dw1_red = (int)(r > 16 ? 16 : r < 1 ? 1 : r);
+    hipLaunchKernelGGL(kron_dw1_reduce_kernel, dim3((unsigned)ra.dw1_red), dim3(NTHREADS), 0, st, ra);
+    if (int rc = check_launch("lokr_conv2d_bwd(dw1 reduce)")) return rc;
   }
   return LYC_OK;
 }

@@ -35,6 +35,10 @@ struct KronDw2sArgs {
   const float* dw1_ws;  // [dw1_nblk][dw1_n] partials, already in dw1 memory order
   float* dw1;
   int dw1_nblk, dw1_n, dw1_red;  // partial blocks, elements per partial, reducer workgroups
+  // implicit Conv2d (GATHER kernels): the J columns are (tap, Jt columns per tap); the P row of destination (= output)
+  // pixel row r and tap t is the source (= input) pixel row given by gat (mode 1); P rows hold Jt elements per group
+  KronGather gat;
+  int Jt;
 };
 
 constexpr int DS_LD = 36;  // LDS row pitch (elements) of the transposed [col][32 rows] tiles: 18 dwords
@@ -67,7 +71,7 @@ __device__ __forceinline__ void dw1_reduce_role(const KronDw2sArgs& a, int r, fl
 
 // U = 32-row steps per prefetch group: the loads of two groups (2 * U * NB * 4 x 16 bytes per lane) are in flight while a
 // group is processed -- with ~1 wave per SIMD (small problems) only instruction-level parallelism hides the HBM latency.
-template <typename T, int MI, int NJ, int U>
+template <typename T, int MI, int NJ, int U, bool GATHER>
 __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
   constexpr int TI = 16 * MI, TJ = 16 * NJ, NC = TI + TJ;
   constexpr int NB = (NC + 63) / 64;  // 4 x 8 blocks per lane per 32-row step
@@ -95,8 +99,8 @@ __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
 
   // this lane's 4 x 8 blocks: block b < TI: Q columns 8*(b % (TI/8)), rows 4*(b / (TI/8)); else P likewise
   const T* bsrc[NB];
-  int bcol[NB], brow[NB];
-  bool bok[NB];
+  int bcol[NB], brow[NB], btap[NB];
+  bool bok[NB], bgat[NB];
   long bld[NB];
 #pragma unroll
   for (int it = 0; it < NB; ++it) {
@@ -109,22 +113,49 @@ __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
     const long ntot = isq ? a.I : a.J;
     bok[it] = (b < NC) && gc < ntot;  // I, J % 8 == 0: a block column group is all in or all out
     bld[it] = ntot;
-    bsrc[it] = (isq ? Q : P) + (bok[it] ? gc : 0);
+    bgat[it] = false;
+    btap[it] = 0;
+    long csrc = bok[it] ? gc : 0;
+    if constexpr (GATHER) {
+      if (!isq) {  // P column (tap, v): rows are gathered per tap, Jt elements per (pixel, group) row
+        btap[it] = (int)(csrc / a.Jt);
+        csrc -= (long)btap[it] * a.Jt;
+        bld[it] = a.Jt;
+        bgat[it] = true;
+      }
+    }
+    bsrc[it] = (isq ? Q : P) + csrc;
     bcol[it] = (isq ? 0 : TI) + 8 * cg;
     brow[it] = 4 * rg;
   }
 
   auto load_step = [&](u32x4 (&raw)[NB][4], long r0) {
 #pragma unroll
-    for (int it = 0; it < NB; ++it)
+    for (int it = 0; it < NB; ++it) {
+      long rbase = r0 + brow[it];  // first of the block's 4 flat rows; the gather maps it to another pixel's rows
+      bool gok = true;
+      if constexpr (GATHER) {
+        if (bgat[it]) {  // the 4 rows share one pixel (G % 4 == 0, rbase % 4 == 0)
+          const long pix = (rbase < rend ? rbase : rbeg) >> lg;
+          const int hw = a.gat.Hd * a.gat.Wd;
+          const int pb = (int)(pix / hw);
+          const int rem = (int)(pix - (long)pb * hw);
+          const int hd = rem / a.gat.Wd, wd = rem - hd * a.gat.Wd;
+          const int ti = btap[it] / a.gat.kw, tj = btap[it] - ti * a.gat.kw;
+          const int hs = hd * a.gat.sh - a.gat.ph + ti * a.gat.dh, ws = wd * a.gat.sw - a.gat.pw + tj * a.gat.dw;
+          gok = hs >= 0 && hs < a.gat.Hs && ws >= 0 && ws < a.gat.Ws;
+          const long spix = gok ? ((long)pb * a.gat.Hs + hs) * a.gat.Ws + ws : 0;
+          rbase = (spix << lg) + (rbase & (G - 1));
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const long r = r0 + brow[it] + j;
-        const bool ok = bok[it] && r < rend;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(bsrc[it] + (ok ? r : rbeg) * bld[it]);
+        const bool ok = bok[it] && gok && (r0 + brow[it] + j) < rend;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(bsrc[it] + (ok ? rbase + j : (GATHER ? 0 : rbeg)) * bld[it]);
         const u32x4 z = {0u, 0u, 0u, 0u};
         raw[it][j] = ok ? v : z;
       }
+    }
   };
   auto store_step = [&](const u32x4 (&raw)[NB][4]) {
 #pragma unroll

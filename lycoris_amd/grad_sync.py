@@ -67,7 +67,10 @@ class AdapterGradSync:
             start, members = 0, []
             for p in plist:
                 n = p.numel()
-                p.grad = arena[off:off + n].view_as(p)
+                # same memory layout as the parameter (e.g. channels_last conv factors): kernels that write
+                # gradients in the parameter's own layout can then accumulate straight into the arena
+                dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                p.grad = arena[off:off + n].as_strided(p.shape, p.stride()) if dense else arena[off:off + n].view_as(p)
                 members.append(p)
                 off += n
                 if (off - start) * esz >= bucket_bytes:
@@ -115,7 +118,10 @@ class AdapterGradSync:
                 if p.dtype != dtype:
                     continue
                 n = p.numel()
-                p.grad = arena[off:off + n].view_as(p)
+                # same memory layout as the parameter (e.g. channels_last conv factors): kernels that write
+                # gradients in the parameter's own layout can then accumulate straight into the arena
+                dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                p.grad = arena[off:off + n].as_strided(p.shape, p.stride()) if dense else arena[off:off + n].view_as(p)
                 off += n
 
     def _on_grad_ready(self, p):

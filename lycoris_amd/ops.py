@@ -298,6 +298,96 @@ class _AdapterConv2d(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# LoKr Conv2d: implicit GEMM on NHWC rows (no im2col)
+# ---------------------------------------------------------------------------------------------------------------
+def _rows_view(t):
+    """[B, C, H, W] -> ([B*H*W, C] NHWC row matrix, made_copy).  A channels_last tensor already is one."""
+    B, C, H, W = t.shape
+    if t.is_contiguous(memory_format=torch.channels_last) and not (C == 1 or H * W == 1):
+        return t.permute(0, 2, 3, 1).reshape(B * H * W, C), False
+    return _to_rows(t.contiguous()), True
+
+
+def _lokr_conv_implicit_ok(x, w1, w2):
+    a, b = w1.shape
+    c, d = w2.shape[0], w2.shape[1]
+    return (x.dtype in (torch.bfloat16, torch.float16) and a == b and a in (4, 8, 16) and c % 8 == 0 and d % 8 == 0
+            and x.shape[2] * x.shape[3] < (1 << 30))
+
+
+class _LokrConv2dImplicit(torch.autograd.Function):
+    """LoKr on nn.Conv2d without materialising im2col: lyc_lokr_conv2d_fwd / _bwd (include/lycoris_amd.h).
+    w2 is the reference's [c, d, kh, kw] parameter; the kernels want [c, kh*kw, d] (window in front of the channel
+    index), which is a free view when the parameter lives in channels_last memory format and one small copy otherwise."""
+
+    @staticmethod
+    def forward(ctx, alpha, geom, x, w1, w2):
+        N.require_device(x, "input")
+        k, s, p, d_ = geom
+        B, C, H, W = x.shape
+        a, b = w1.shape
+        c, d = w2.shape[0], w2.shape[1]
+        if C != b * d:
+            raise ValueError(f"adapter expects {b * d} input channels, got {tuple(x.shape)}")
+        rows, copied = _rows_view(x)
+        w1f = _f32c(w1)
+        w2p = _f32c(w2.detach().permute(0, 2, 3, 1))  # [c, kh, kw, d]; no copy for channels_last fp32 parameters
+        Ho, Wo = _conv_out(H, W, k, s, p, d_)
+        y_rows = torch.empty((B * Ho * Wo, a * c), dtype=x.dtype, device=x.device)
+        N.call("lyc_lokr_conv2d_fwd", N.ptr(rows), N.ptr(w1f), N.ptr(w2p), N.ptr(y_rows), B, H, W, a, b, c, d, k[0], k[1],
+               s[0], s[1], p[0], p[1], d_[0], d_[1], float(alpha), N.dtype_code(x.dtype), N.stream_ptr(x.device))
+        ctx.save_for_backward(rows, w1, w2)
+        ctx.meta = (float(alpha), geom, x.shape, (Ho, Wo), not copied)
+        if not copied:  # channels_last in -> channels_last out, no transposes at all
+            return y_rows.view(B, Ho, Wo, a * c).permute(0, 3, 1, 2)
+        return _from_rows(y_rows, B, (Ho, Wo))
+
+    @staticmethod
+    def backward(ctx, g):
+        alpha, geom, xshape, (Ho, Wo), x_cl = ctx.meta
+        rows, w1, w2 = ctx.saved_tensors
+        k, s, p, d_ = geom
+        B, C, H, W = xshape
+        a, b = w1.shape
+        c, d = w2.shape[0], w2.shape[1]
+        g_rows, _ = _rows_view(g)
+        need_x, need_w1, need_w2 = ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        w1f = _f32c(w1)
+        w2p = _f32c(w2.detach().permute(0, 2, 3, 1))
+        code = N.dtype_code(rows.dtype)
+        dx_rows = torch.empty((B * H * W, C), dtype=rows.dtype, device=rows.device) if (need_x or need_w1) else None
+        (dw1,), hb1 = _grad_targets([w1], [need_w1])
+        # dw2 in the kernels' [c, kh, kw, d] layout: straight into w2.grad when that has the same memory layout
+        dw2p, hb2 = None, False
+        if need_w2:
+            gr = w2.grad if (_ACCUM["enabled"] and w2.is_leaf) else None
+            if (gr is not None and gr.dtype == torch.float32 and gr.device == w2.device
+                    and gr.permute(0, 2, 3, 1).is_contiguous()):
+                dw2p = gr.permute(0, 2, 3, 1)
+            else:
+                dw2p, hb2 = torch.zeros((c, k[0], k[1], d), dtype=torch.float32, device=rows.device), True
+        ws = None
+        if dw1 is not None:
+            nbytes = int(N.load().lyc_lokr_conv2d_bwd_workspace_bytes(B, H, W, a, b, d))
+            if nbytes:
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=rows.device)
+        N.call("lyc_lokr_conv2d_bwd", N.ptr(g_rows), N.ptr(rows), N.ptr(w1f), N.ptr(w2p), N.ptr(dx_rows), N.ptr(dw1),
+               N.ptr(dw2p), N.ptr(ws), B, H, W, a, b, c, d, k[0], k[1], s[0], s[1], p[0], p[1], d_[0], d_[1], alpha, code,
+               N.stream_ptr(rows.device))
+        dx = None
+        if need_x:
+            dx = dx_rows.view(B, H, W, C).permute(0, 3, 1, 2) if x_cl else _from_rows(dx_rows, B, (H, W))
+        gw1 = _finish_grads([w1], [dw1], hb1)[0]
+        gw2 = None
+        if need_w2:
+            if hb2:
+                gw2 = dw2p.permute(0, 3, 1, 2).to(w2.dtype)
+            elif _ACCUM["callback"] is not None:
+                _ACCUM["callback"](w2)
+        return None, None, dx, gw1, gw2
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # (IA)^3 per-channel affine
 # ---------------------------------------------------------------------------------------------------------------
 def _chan_dims(t: torch.Tensor, chan_dim: int):
@@ -397,5 +487,7 @@ def loha_conv2d(x, w1a, w1b, w2a, w2b, alpha, shape, stride, padding, dilation):
 def lokr_conv2d(x, w1, w2, alpha, stride, padding, dilation):
     """w1:[a, b]  w2:[c, d, kh, kw].  The channel index u*d + v makes im2col's (channel, kh, kw) column order the
     grouped (u, (v, kh, kw)) order of the Kronecker kernel, so w2 is simply viewed as [c, d*kh*kw]."""
-    return _AdapterConv2d.apply(_LokrCore, alpha, _geom(w2.shape[2:], stride, padding, dilation), x, w1,
-                                w2.reshape(w2.shape[0], -1))
+    geom = _geom(w2.shape[2:], stride, padding, dilation)
+    if x.dim() == 4 and not _is_pointwise(geom) and _lokr_conv_implicit_ok(x, w1, w2):
+        return _LokrConv2dImplicit.apply(alpha, geom, x, w1, w2)
+    return _AdapterConv2d.apply(_LokrCore, alpha, geom, x, w1, w2.reshape(w2.shape[0], -1))

@@ -53,6 +53,19 @@ CONV_SHAPES = [
 ]
 
 
+# shapes that take the implicit-GEMM LoKr path (a == b in {4, 8}, c, d multiples of 8): (..., factor)
+LOKR_IMPLICIT_SHAPES = [
+    (2, 32, 12, 12, 64, 3, 1, 1, 1, 4),     # 3x3 same
+    (1, 64, 9, 11, 32, 3, 2, 1, 1, 4),      # stride 2, odd spatial size
+    (1, 32, 10, 9, 32, 3, 1, 2, 2, 4),      # dilation 2
+    (2, 64, 8, 8, 128, 3, 1, 1, 1, 8),      # factor 8, d = 8
+    (1, 32, 7, 7, 32, 5, 1, 2, 1, 4),       # 5x5 window
+    (1, 128, 6, 5, 64, 3, 1, 0, 1, 8),      # no padding (valid conv)
+    (3, 320, 9, 9, 320, 3, 1, 1, 1, 8),     # SDXL resnet channels at a small spatial size (d = 40: ragged k-steps)
+    (1, 64, 5, 5, 64, 3, 2, 0, 1, 4),       # stride 2 without padding
+]
+
+
 def _ca(s, p, d):
     return {"stride": s, "padding": p, "dilation": d}
 
@@ -102,6 +115,35 @@ def test_lokr_conv2d(shape, dtype):
     errs = {"y": err(y, y_ref, dtype), "dx": err(dx, gr["dx"], dtype), "dw1": err(dw1, gr["w1"]), "dw2": err(dw2, gr["w2"])}
     bounds = {"y": TOL["store_out"][dtype], "dx": TOL["store_out"][dtype], "dw1": TOL["f32_out"][dtype], "dw2": TOL["f32_out"][dtype]}
     check(f"lokr_conv2d[{shape},{dtype}]", errs, bounds)
+
+
+@pytest.mark.parametrize("layout", ["contiguous", "channels_last"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", LOKR_IMPLICIT_SHAPES, ids=[str(s) for s in LOKR_IMPLICIT_SHAPES])
+def test_lokr_conv2d_implicit(shape, dtype, layout):
+    """The im2col-free path: pixel-row gather inside the kernels, all taps summed in fp32, w2 in [c, kh, kw, d] order."""
+    from lycoris_amd import ops
+    B, C, H, W, O, k, s, p, d, f = shape
+    c_, d_ = O // f, C // f
+    gen = torch.Generator().manual_seed(sum(shape) + 7)
+    x, x64 = rnd((B, C, H, W), dtype, gen)
+    w1, w1_64 = rnd((f, f), torch.float32, gen, 0.3)
+    w2, w2_64 = rnd((c_, d_, k, k), torch.float32, gen, 0.1)
+    assert ops._lokr_conv_implicit_ok(x, w1, w2)
+    if layout == "channels_last":
+        x = x.contiguous(memory_format=torch.channels_last)
+        w2 = w2.contiguous(memory_format=torch.channels_last)
+    y_ref = oracle.lokr.forward(x64, w1=w1_64, w2=w2_64, scale=0.9, kshape=(k, k), conv_args=_ca(s, p, d))
+    g, g64 = rnd(y_ref.shape, dtype, gen, 1.0 / np.sqrt(O))
+    for t in (x, w1, w2):
+        t.requires_grad_(True)
+    y = ops.lokr_conv2d(x, w1, w2, 0.9, (s, s), (p, p), (d, d))
+    dx, dw1, dw2 = torch.autograd.grad(y, [x, w1, w2], g)
+    torch.cuda.synchronize()
+    gr = oracle.lokr.backward(x64, g64, w1=w1_64, w2=w2_64, scale=0.9, kshape=(k, k), conv_args=_ca(s, p, d))
+    errs = {"y": err(y, y_ref, dtype), "dx": err(dx, gr["dx"], dtype), "dw1": err(dw1, gr["w1"]), "dw2": err(dw2, gr["w2"])}
+    bounds = {"y": TOL["store_out"][dtype], "dx": TOL["store_out"][dtype], "dw1": TOL["f32_out"][dtype], "dw2": TOL["f32_out"][dtype]}
+    check(f"lokr_conv2d_implicit[{shape},{dtype},{layout}]", errs, bounds)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
