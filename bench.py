@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", default="all", help="'all' or 'linear' (development)")
+    ap.add_argument("--profile-ops", action="store_true", help="development: torch.profiler table of one eager pass")
     return ap.parse_args()
 
 
@@ -144,10 +145,22 @@ def main():
             proto.params = params
             outs.append((proto.forward(), proto))
             proto.params = saved
+        # dx is computed and handed back; the factor gradients are accumulated into the arena by the kernels themselves.
+        # (autograd.grad instead of .backward(): the layer instances of one shape share their activation buffers, and
+        # .backward() would add an artificial "x.grad += dx" elementwise kernel per layer on top of the hot path.)
         for y, proto in reversed(outs):
-            torch.autograd.backward(y, proto.g)
-        for proto, _ in protos:
-            proto.x.grad = None
+            torch.autograd.grad(y, [proto.x], proto.g)
+
+    if args.profile_ops:
+        from torch.profiler import ProfilerActivity, profile
+        sync.zero_grad()
+        compute_pass()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            compute_pass()
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))
+        return
 
     # ---- capture one step's compute in a hipGraph -------------------------------------------------------------
     side = torch.cuda.Stream()

@@ -44,6 +44,20 @@ int main(int argc, char** argv) {
       }
       if (rep == 0) printf("grid %u x %u\n", grid.x, grid.y);
     }
+    if (!strcmp(mode, "dw2")) {
+      KronDw2sArgs da{};
+      da.Q = g; da.P = x; da.W = w1; da.out = dw2; da.M = M; da.G = G; da.I = c; da.J = d; da.ws = G; da.wt = 1; da.os = d; da.alpha = 1.f;
+      const long rows_total = M * G;
+      const long tiles = cdiv(c, 32) * cdiv(d, 32);
+      long split = cdiv(512, tiles), smax = 600000 / ((long)c * d); if (smax < 1) smax = 1;
+      if (split > smax) split = smax;
+      if (split > rows_total / 128) split = rows_total / 128 > 0 ? rows_total / 128 : 1;
+      da.rows_per_block = cdiv(cdiv(rows_total, split), 32) * 32;
+      da.nsplit = (int)cdiv(rows_total, da.rows_per_block);
+      dim3 grid((unsigned)cdiv(c, 32), (unsigned)cdiv(d, 32), (unsigned)da.nsplit);
+      hipLaunchKernelGGL((kron_dw2s_kernel<__bf16, 2, 2, 4, false>), grid, dim3(NTHREADS), 0, 0, da);
+      if (rep == 0) printf("grid %u x %u x %u rows/block %ld\n", grid.x, grid.y, grid.z, da.rows_per_block);
+    }
     if (timing) continue;
 #ifdef LYC_TRACE
     CK(hipDeviceSynchronize());

@@ -152,7 +152,11 @@ void launch_dw2s(KronDw2sArgs da, hipStream_t st) {
   long t44, s44, t22, s22;
   plan(4, 4, t44, s44);
   plan(2, 2, t22, s22);
-  bool big = t44 * s44 >= (target_blocks * 3) / 4;
+  // 64 x 64 tiles read 128-byte row segments (the 32 x 32 tile's 64-byte segments halve the address-coalescer rate) and
+  // do 4x the matrix work per loaded byte: they win whenever there are enough rows to split (measured: M*G >= 16k) and
+  // the padding of I, J to multiples of 64 does not waste more than half of the tile.
+  const double eff44 = (double)da.I * da.J / ((double)round_up(da.I, 64) * round_up(da.J, 64));
+  bool big = rows_total >= 16384 && eff44 >= 0.5;
   if (force_big >= 0) big = force_big != 0;
   long split = big ? s44 : s22;
   da.rows_per_block = round_up(cdiv(rows_total, split), 32);

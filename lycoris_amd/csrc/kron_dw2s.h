@@ -43,10 +43,13 @@ struct KronDw2sArgs {
 
 constexpr int DS_LD = 36;  // LDS row pitch (elements) of the transposed [col][32 rows] tiles: 18 dwords
 
+// per wave: two private transposed tiles [16 (MI + NJ) cols][DS_LD] (double buffer); afterwards the same memory holds the
+// cross-wave reduction image [4 waves][<= 8 tiles][256] fp32
 template <int MI, int NJ>
 __host__ __device__ constexpr int kron_dw2s_lds_bytes() {
-  const int stage = NWAVES * 16 * (MI + NJ) * DS_LD * 2;
-  const int red = (NWAVES - 1) * MI * NJ * 256 * 4;
+  const int stage = NWAVES * 2 * 16 * (MI + NJ) * DS_LD * 2;
+  const int tiles = MI * NJ < 8 ? MI * NJ : 8;
+  const int red = NWAVES * tiles * 256 * 4;
   return stage > red ? stage : red;
 }
 
@@ -79,7 +82,10 @@ __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
   using F8 = typename TT<T>::frag;
   using F4 = typename Mma16<T>::frag;
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the row bookkeeping in SGPRs
+  LYC_TRACE_DECL;
+  LYC_STAMP(0);
   if ((int)blockIdx.z == a.nsplit) {  // w1-gradient reducer slice
     const int r = (int)(blockIdx.x + blockIdx.y * gridDim.x);
     if (a.dw1_ws != nullptr && r < a.dw1_red) dw1_reduce_role(a, r, reinterpret_cast<float*>(smem));
@@ -95,27 +101,28 @@ __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
   const long rbeg = (long)blockIdx.z * a.rows_per_block;
   long rend = rbeg + a.rows_per_block;
   if (rend > rows_total) rend = rows_total;
-  T* tile = reinterpret_cast<T*>(smem) + wave * NC * DS_LD;  // this wave's private [NC cols][32 rows] tile
+  T* tile0 = reinterpret_cast<T*>(smem) + wave * 2 * NC * DS_LD;  // this wave's private [NC cols][32 rows] tiles
+  T* tile1 = tile0 + NC * DS_LD;
 
-  // this lane's 4 x 8 blocks: block b < TI: Q columns 8*(b % (TI/8)), rows 4*(b / (TI/8)); else P likewise
-  const T* bsrc[NB];
+  // this lane's 4 x 8 blocks: block b < TI: Q columns 8*(b % (TI/8)), rows 4*(b / (TI/8)); else P likewise.
+  // Column groups beyond I / J read column 0 instead: they only feed output rows / columns that are never stored.
+  const T* bptr[NB];  // address of (row 0 + brow, column) of the block's operand
+  long bld[NB];       // row pitch (elements)
   int bcol[NB], brow[NB], btap[NB];
-  bool bok[NB], bgat[NB];
-  long bld[NB];
+  bool bgat[NB];
 #pragma unroll
   for (int it = 0; it < NB; ++it) {
     const int b = lane + 64 * it;
     const bool isq = b < TI;
-    const int bb = isq ? b : b - TI;
+    const int bb = isq ? b : (b < NC ? b - TI : 0);
     const int ncg = isq ? TI / 8 : TJ / 8;
     const int cg = bb % ncg, rg = bb / ncg;
     const long gc = (isq ? i0 : j0) + 8 * cg;
     const long ntot = isq ? a.I : a.J;
-    bok[it] = (b < NC) && gc < ntot;  // I, J % 8 == 0: a block column group is all in or all out
+    long csrc = gc < ntot ? gc : 0;  // I, J % 8 == 0: a block column group is all in or all out
     bld[it] = ntot;
     bgat[it] = false;
     btap[it] = 0;
-    long csrc = bok[it] ? gc : 0;
     if constexpr (GATHER) {
       if (!isq) {  // P column (tap, v): rows are gathered per tap, Jt elements per (pixel, group) row
         btap[it] = (int)(csrc / a.Jt);
@@ -124,16 +131,41 @@ __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
         bgat[it] = true;
       }
     }
-    bsrc[it] = (isq ? Q : P) + csrc;
     bcol[it] = (isq ? 0 : TI) + 8 * cg;
     brow[it] = 4 * rg;
+    bptr[it] = (isq ? Q : P) + csrc + (GATHER ? 0 : (long)brow[it] * bld[it]);
   }
 
+  // one 32-row step: global -> registers.  Steps are requested in increasing row order (rbeg + 32 wave, + 128, ...), so
+  // the non-gather path keeps one running byte pointer per block and advances it by a precomputed increment: steps that
+  // lie completely inside the slab (all but possibly the last) cost 2 VALU adds per 16-byte load and no selects.
+  const char* pcur[NB];
+  long pinc[NB], prow[NB];
+#pragma unroll
+  for (int it = 0; it < NB; ++it) {
+    prow[it] = bld[it] * (long)sizeof(T);
+    pinc[it] = 32 * NWAVES * prow[it];
+    pcur[it] = reinterpret_cast<const char*>(bptr[it]) + (rbeg + 32 * wave) * prow[it];
+  }
   auto load_step = [&](u32x4 (&raw)[NB][4], long r0) {
+    if constexpr (!GATHER) {
+      if (r0 + 32 <= rend) {
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) raw[it][j] = *reinterpret_cast<const u32x4*>(pcur[it] + j * prow[it]);
+          pcur[it] += pinc[it];
+        }
+        return;
+      }
+#pragma unroll
+      for (int it = 0; it < NB; ++it) pcur[it] += pinc[it];
+    }
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
       long rbase = r0 + brow[it];  // first of the block's 4 flat rows; the gather maps it to another pixel's rows
       bool gok = true;
+      const T* src = bptr[it];
       if constexpr (GATHER) {
         if (bgat[it]) {  // the 4 rows share one pixel (G % 4 == 0, rbase % 4 == 0)
           const long pix = (rbase < rend ? rbase : rbeg) >> lg;
@@ -147,17 +179,19 @@ __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
           const long spix = gok ? ((long)pb * a.gat.Hs + hs) * a.gat.Ws + ws : 0;
           rbase = (spix << lg) + (rbase & (G - 1));
         }
+      } else {
+        src -= (long)brow[it] * bld[it];  // bptr already includes the block's row offset
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bool ok = bok[it] && gok && (r0 + brow[it] + j) < rend;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(bsrc[it] + (ok ? rbase + j : (GATHER ? 0 : rbeg)) * bld[it]);
+        const bool ok = gok && (r0 + brow[it] + j) < rend;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + (ok ? rbase + j : 0) * bld[it]);
         const u32x4 z = {0u, 0u, 0u, 0u};
         raw[it][j] = ok ? v : z;
       }
     }
   };
-  auto store_step = [&](const u32x4 (&raw)[NB][4]) {
+  auto store_step = [&](const u32x4 (&raw)[NB][4], T* tile) {
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
       if (lane + 64 * it < NC) {
@@ -187,13 +221,16 @@ __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
   u32x4 rawA[U][NB][4], rawB[U][NB][4];
   auto load_group = [&](u32x4 (&raw)[U][NB][4], long r0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) load_step(raw[u], r0 + STEP * u);
+    for (int u = 0; u < U; ++u)
+      if (r0 + STEP * u < rend) load_step(raw[u], r0 + STEP * u);
   };
   long r0 = rbeg + 32 * wave;
+  LYC_STAMP(1);
   load_group(rawA, r0);
-  if (r0 + GROUP < rend) load_group(rawB, r0 + GROUP);
+  load_group(rawB, r0 + GROUP);
+  LYC_STAMP(2);
 
-  // mix operand (I (x) W) for one 16x16 block: lane (i = li, g) holds k = 4g .. 4g+3 (raw; split below)
+  // mix operand (I (x) W) for one 16x16 block: lane (i = li, g) holds k = 4g .. 4g+3
   F4 a2h, a2l;
   {
     const int mi_ = li >> lg, s_ = li & (G - 1);
@@ -208,9 +245,7 @@ __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
     a2l = *reinterpret_cast<F4*>(l);
   }
 
-
-  auto process_step = [&](const u32x4 (&raw)[NB][4]) {
-    store_step(raw);
+  auto compute_step = [&](const T* tile) {
     // mix: Z blocks of the NJ column blocks, both 16-row halves, kept as hi/lo B fragments of the main MFMA.
     // K index permutation of the main MFMA: element e < 4 of lane group g <-> row 4g+e, e >= 4 <-> row 16 + 4g + e - 4
     // (the accumulator layout of the two mix results); the A operand below is read with the same permutation.
@@ -243,58 +278,74 @@ __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
       for (int nj = 0; nj < NJ; ++nj) acc[mi][nj] = TT<T>::mma(af, zl[nj], acc[mi][nj]);
     }
   };
-  auto process_group = [&](const u32x4 (&raw)[U][NB][4], long r0) {
+  // One group: the transposed image of step u+1 is written (other tile) before the MFMAs of step u are issued, so the
+  // VALU transposes / LDS writes of the next step overlap the matrix work of this one.  `first` of the next group comes
+  // from the other register set.
+  T* cur = tile0;  // tile holding the transposed image of the step about to be computed
+  T* nxt = tile1;
+  auto process_group = [&](const u32x4 (&raw)[U][NB][4], const u32x4 (&next0)[NB][4], long r0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (r0 + STEP * u < rend) process_step(raw[u]);
+    for (int u = 0; u < U; ++u) {
+      if (r0 + STEP * u >= rend) break;
+      if (r0 + STEP * (u + 1) < rend) {
+        if (u + 1 < U) store_step(raw[u + 1 < U ? u + 1 : 0], nxt);
+        else store_step(next0, nxt);
+      }
+      compute_step(cur);
+      T* t = cur;
+      cur = nxt;
+      nxt = t;
+    }
   };
+  LYC_STAMP(3);
+  if (r0 < rend) store_step(rawA[0], cur);
   while (r0 < rend) {
-    process_group(rawA, r0);
-    if (r0 + 2 * GROUP < rend) load_group(rawA, r0 + 2 * GROUP);
+    process_group(rawA, rawB[0], r0);
+    load_group(rawA, r0 + 2 * GROUP);
     r0 += GROUP;
     if (r0 >= rend) break;
-    process_group(rawB, r0);
-    if (r0 + 2 * GROUP < rend) load_group(rawB, r0 + 2 * GROUP);
+    process_group(rawB, rawA[0], r0);
+    load_group(rawB, r0 + 2 * GROUP);
     r0 += GROUP;
   }
 
-  // cross-wave reduction: waves 1..3 publish, wave 0 sums and updates the output tile
+  // cross-wave reduction through LDS: every wave publishes its tiles, wave w sums and stores tiles t = w (mod 4)
   float* red = reinterpret_cast<float*>(smem);
-  __syncthreads();  // the staging tiles are dead
-  if (wave > 0) {
+  constexpr int NT = MI * NJ, TB = NT < 8 ? NT : 8;  // tiles per batch (LDS budget)
+  const bool plain = a.nsplit == 1;
+  LYC_STAMP(4);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+  for (int t0 = 0; t0 < NT; t0 += TB) {
+    __syncthreads();  // the staging tiles (or the previous batch) are dead
 #pragma unroll
-      for (int nj = 0; nj < NJ; ++nj)
-        *reinterpret_cast<f32x4*>(red + (((wave - 1) * MI + mi) * NJ + nj) * 256 + lane * 4) = acc[mi][nj];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    const bool plain = a.nsplit == 1;
+    for (int t = 0; t < TB; ++t) {
+      const int mi = (t0 + t) / NJ, nj = (t0 + t) % NJ;
+      *reinterpret_cast<f32x4*>(red + (wave * TB + t) * 256 + lane * 4) = acc[mi][nj];
+    }
+    __syncthreads();
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int tt = 0; tt < TB / NWAVES; ++tt) {
+      const int t = tt * NWAVES + wave;  // this wave's tile of the batch
+      const int mi = (t0 + t) / NJ, nj = (t0 + t) % NJ;
+      f32x4 s = zero4();
 #pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) {
-        f32x4 s = acc[mi][nj];
+      for (int w = 0; w < NWAVES; ++w) s += *reinterpret_cast<const f32x4*>(red + (w * TB + t) * 256 + lane * 4);
+      const long gj = j0 + 16 * nj + li;
 #pragma unroll
-        for (int w = 0; w < NWAVES - 1; ++w) {
-          const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((w * MI + mi) * NJ + nj) * 256 + lane * 4);
-          s += o;
-        }
-        const long gj = j0 + 16 * nj + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const long gi = i0 + 16 * mi + 4 * g + r;
-          if (gi < a.I && gj < a.J) {
-            float* dst = a.out + gi * a.os + gj;
-            if (plain)
-              *dst += a.alpha * s[r];
-            else
-              __hip_atomic_fetch_add(dst, a.alpha * s[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+      for (int r = 0; r < 4; ++r) {
+        const long gi = i0 + 16 * mi + 4 * g + r;
+        if (gi < a.I && gj < a.J) {
+          float* dst = a.out + gi * a.os + gj;
+          if (plain)
+            *dst += a.alpha * s[r];
+          else
+            __hip_atomic_fetch_add(dst, a.alpha * s[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+    }
   }
+  LYC_STAMP(6);
+  LYC_TRACE_FLUSH();
 }
 
 // stand-alone reduction of the w1-gradient partials (used when the caller asks for dw1 but not dw2)
