@@ -28,6 +28,10 @@ from benchmarks.sdxl_shapes import algorithmic_bytes, layer_rows, sdxl_unet_laye
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md ("8.0 TB/s spec")
 FACTOR = 8
+# HBM bytes per launch of the dominant kernels from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+# runs, gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md; benchmarks/pmc_summary.py writes the numbers to
+# profiles/): counters cannot be collected inside the timed run, so the committed measurement is quoted here.
+PMC_TRAFFIC = {"kron3": None, "dw2s": None}
 
 
 def parse():
@@ -231,66 +235,100 @@ def main():
 
 # ------------------------------------------------------------------------------------------------------------------
 def roofline(protos, algo, dtype, dev):
-    """Dominant kernel of the step = the Kronecker kernel (`kron_kernel`: forward and backward-dx launches of every
-    layer).  `achieved` = algorithmic bytes of those launches / their average duration, measured here with HIP
-    events on the launch stream around a hipGraph that contains exactly those launches (one per layer and
-    direction, same shapes and counts as one step).  HBM-bound (AI 20-200 flop/B < ridge ~300)."""
+    """Roofline of the dominant kernel family of the step, measured live with HIP events on the launch stream.
+
+    The LoKr step launches two kernel families per adapted Linear layer (Conv2d layers use the same kernels through
+    the pixel-row gather and are left out of this leg: 49 of 788 layers):
+      * `lyc::kron3_kernel`    -- forward, and backward dx (+ w1-gradient partials): HBM-bound (AI 20-200 flop/B);
+      * `lyc::kron_dw2s_kernel` -- w2 gradient (split-K TN GEMM over the M*G rows).
+    Three hipGraphs holding exactly the launches one step makes for the Linear layers (same shapes, same counts, the
+    count instances rotate over distinct factor buffers) are replayed and timed: forward only, dW2 only, whole
+    backward.  kron3 time = forward + (backward - dW2).  The family with the larger time is reported; `achieved` =
+    algorithmic bytes of its launches / its time (activations moved once: fwd x + y, bwd-dx g + x + dx,
+    dW2 g + x, plus the fp32 factors)."""
     from lycoris_amd import _native as N
     if algo != "lokr":
         return None
     esz = torch.empty((), dtype=dtype).element_size()
-    calls, alg_bytes = [], 0
+    code = N.dtype_code(dtype)
+    calls, bytes_fwd, bytes_dx, bytes_dw2, n_layers = [], 0, 0, 0, 0
     for proto, count in protos:
         s = proto.spec
+        if s["kind"] != "linear":
+            continue
         M, I, O = layer_rows(s)
-        w1, w2 = proto.params[0].detach(), proto.params[1].detach().reshape(proto.params[1].shape[0], -1).contiguous()
+        w1 = proto.params[0].detach().contiguous()
+        w2 = proto.params[1].detach().contiguous()
         a, b = w1.shape
         c, d = w2.shape
-        rows = proto.x.detach().reshape(-1, I) if s["kind"] == "linear" else torch.randn(M, I, device=dev, dtype=dtype)
+        rows = proto.x.detach().reshape(-1, I)
         g = torch.randn(M, O, device=dev, dtype=dtype)
         y = torch.empty(M, O, device=dev, dtype=dtype)
         dx = torch.empty(M, I, device=dev, dtype=dtype)
-        dw1 = torch.zeros_like(w1)
-        ws = torch.empty(int(N.load().lyc_lokr_bwd_workspace_bytes(M, a, b, c, d, N.dtype_code(dtype))) + 16,
-                         dtype=torch.uint8, device=dev)
-        calls.append((count, rows, g, y, dx, w1.contiguous(), w2, dw1, ws, (M, a, b, c, d)))
-        # fwd: read rows, write y; bwd-dx(+dw1): read g, read rows, write dx; factors read in both
-        alg_bytes += count * (esz * (M * I + M * O) + esz * (M * O + 2 * M * I) + 2 * 4 * (a * b + c * d))
-    code = N.dtype_code(dtype)
+        dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
+        ws = torch.empty(int(N.load().lyc_lokr_bwd_workspace_bytes(M, a, b, c, d, code)) + 16, dtype=torch.uint8, device=dev)
+        calls.append((count, rows, g, y, dx, w1, w2, dw1, dw2, ws, (M, a, b, c, d)))
+        fac = 4 * (a * b + c * d)
+        bytes_fwd += count * (esz * (M * I + M * O) + fac)
+        bytes_dx += count * (esz * (M * O + 2 * M * I) + fac)
+        bytes_dw2 += count * (esz * (M * O + M * I) + fac)
+        n_layers += count
     st = torch.cuda.Stream()
-    n_launch = 0
-    with torch.cuda.stream(st):
-        def run():
-            nonlocal n_launch
-            n = 0
+
+    def timed(issue):
+        with torch.cuda.stream(st):
             sp = N.stream_ptr(dev)
-            for count, rows, g, y, dx, w1, w2, dw1, ws, (M, a, b, c, d) in calls:
-                for _ in range(count):
-                    N.call("lyc_lokr_linear_fwd", N.ptr(rows), N.ptr(w1), N.ptr(w2), N.ptr(y), M, a, b, c, d, 1.0, code, sp)
-                    N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(w1), N.ptr(w2), N.ptr(dx), N.ptr(dw1),
-                           None, N.ptr(ws), M, a, b, c, d, 1.0, code, sp)
-                    n += 2
-            n_launch = n
-        run()
-        torch.cuda.synchronize()
-        gph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gph, stream=st):
-            run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 5
-        gph.replay()
-        e0.record(st)
-        for _ in range(reps):
+            issue(sp)  # eager warm-up
+            torch.cuda.synchronize()
+            gph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gph, stream=st):
+                issue(sp)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps, best = 5, float("inf")
             gph.replay()
-        e1.record(st)
-        e1.synchronize()
-        total_ms = e0.elapsed_time(e1) / reps
-    avg_us = total_ms * 1e3 / n_launch
-    achieved = alg_bytes / (total_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "lyc::kron_kernel (LoKr forward + backward-dx/dw1 launches)",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "launches_per_step": n_launch, "avg_launch_us": round(avg_us, 2),
-            "algorithmic_bytes_per_launch": int(alg_bytes / n_launch)}
+            for _ in range(3):
+                e0.record(st)
+                for _ in range(reps):
+                    gph.replay()
+                e1.record(st)
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1) / reps)
+        return best  # ms per pass over all Linear layers
+
+    def fwd(sp):
+        for count, rows, g, y, dx, w1, w2, dw1, dw2, ws, (M, a, b, c, d) in calls:
+            for _ in range(count):
+                N.call("lyc_lokr_linear_fwd", N.ptr(rows), N.ptr(w1), N.ptr(w2), N.ptr(y), M, a, b, c, d, 1.0, code, sp)
+
+    def only_dw2(sp):
+        for count, rows, g, y, dx, w1, w2, dw1, dw2, ws, (M, a, b, c, d) in calls:
+            for _ in range(count):
+                N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(w1), N.ptr(w2), None, None, N.ptr(dw2), None,
+                       M, a, b, c, d, 1.0, code, sp)
+
+    def bwd(sp):
+        for count, rows, g, y, dx, w1, w2, dw1, dw2, ws, (M, a, b, c, d) in calls:
+            for _ in range(count):
+                N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(w1), N.ptr(w2), N.ptr(dx), N.ptr(dw1),
+                       N.ptr(dw2), N.ptr(ws), M, a, b, c, d, 1.0, code, sp)
+
+    t_fwd, t_dw2, t_bwd = timed(fwd), timed(only_dw2), timed(bwd)
+    t_k3 = t_fwd + max(t_bwd - t_dw2, 0.0)
+    fam = {
+        "kron3": ("lyc::kron3_kernel (LoKr forward + backward-dx/dW1 launches of the 739 Linear layers)", t_k3,
+                  bytes_fwd + bytes_dx, 2 * n_layers),
+        "dw2s": ("lyc::kron_dw2s_kernel (LoKr dW2 launches of the 739 Linear layers)", t_dw2, bytes_dw2, n_layers),
+    }
+    key = "kron3" if t_k3 >= t_dw2 else "dw2s"
+    name, t_ms, nbytes, n_launch = fam[key]
+    achieved = nbytes / (t_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC.get(key),
+            "launches_per_step": n_launch, "avg_launch_us": round(t_ms * 1e3 / n_launch, 2),
+            "algorithmic_bytes_per_launch": int(nbytes / n_launch),
+            "families_ms": {"kron3_fwd": round(t_fwd, 3), "kron3_bwd": round(max(t_bwd - t_dw2, 0.0), 3),
+                            "dw2s": round(t_dw2, 3)},
+            "hot_path_gbs": round((bytes_fwd + bytes_dx) / ((t_fwd + t_bwd) * 1e-3) / 1e9, 1)}
 
 
 def cpu_baseline(algo):

@@ -92,10 +92,25 @@ static float time_graph(hipStream_t st, hipGraphExec_t ge, int reps) {
   return ms / reps;
 }
 
+// KB_EAGER=1: plain launches instead of a hipGraph (rocprofv3 --pmc cannot sample inside graph replays)
+static const bool g_eager = getenv("KB_EAGER") != nullptr;
+
 template <typename F>
 static float bench(hipStream_t st, int nlaunch, int reps, F&& fn) {
   for (int i = 0; i < 2; ++i) fn(i);  // warm-up, eager
   CK(hipStreamSynchronize(st));
+  if (g_eager) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < nlaunch; ++i) fn(i);
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3f / nlaunch;
+  }
   hipGraph_t g;
   hipGraphExec_t ge;
   CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));

@@ -1,0 +1,60 @@
+"""Summarise rocprofv3 --pmc passes into HBM bytes per launch for each kernel (development / evidence tool).
+
+    python benchmarks/pmc_summary.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass>
+
+Follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are collected in SEPARATE
+passes (FETCH_SIZE needs 3 of the 4 TCC slots, WRITE_SIZE 2); the counters are in KiB-like units of the fabric request
+counters and are CALIBRATED here on the 1 GiB -> 1 GiB `copy16` kernel that benchmarks/kbench runs first in the same
+process (known byte counts): on gfx950 FETCH_SIZE reads half of the bytes of a wide coalesced stream, so the read factor
+comes out near 2.0; the write factor is whatever the copy shows.  Prints one line per kernel: launches, raw counters,
+calibrated bytes per launch."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+
+def load(d, counter):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def short(name):
+    for key in ("kron3_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "copy16", "kron_kernel", "kron_dw2_kernel"):
+        if key in name:
+            return key + name.split(key)[1][:34]
+    return name[:60]
+
+
+def main():
+    fdir, wdir = sys.argv[1], sys.argv[2]
+    fetch, write = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
+    gib = float(1 << 30)
+    cal_r = cal_w = None
+    for k, v in fetch.items():
+        if "copy16" in k and max(v) > 0:
+            cal_r = gib / max(v)  # bytes per counter unit, from the 1 GiB read
+    for k, v in write.items():
+        if "copy16" in k and max(v) > 0:
+            cal_w = gib / max(v)
+    print(f"calibration on copy16 (1 GiB read, 1 GiB written): read {cal_r} B/unit, write {cal_w} B/unit "
+          f"(1024 B/unit would be the nominal KiB unit)")
+    print(f"{'kernel':60s} {'n':>6s} {'FETCH_SIZE':>12s} {'WRITE_SIZE':>12s} {'read MB':>9s} {'write MB':>9s} {'HBM MB/launch':>14s}")
+    for k in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(k, []), write.get(k, [])
+        if not f and not w:
+            continue
+        fm = sum(f) / len(f) if f else 0.0
+        wm = sum(w) / len(w) if w else 0.0
+        rb = fm * (cal_r or 1024.0)
+        wb = wm * (cal_w or 1024.0)
+        print(f"{short(k):60s} {max(len(f), len(w)):6d} {fm:12.1f} {wm:12.1f} {rb / 1e6:9.2f} {wb / 1e6:9.2f} {(rb + wb) / 1e6:14.2f}")
+
+
+if __name__ == "__main__":
+    main()

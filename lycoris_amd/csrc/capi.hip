@@ -120,8 +120,9 @@ long launch_kron(KronArgs ka, hipStream_t st) {
 // dW2 streaming kernel: tile and split-K selection (see kron_dw2s.h).  dw1 partial reduction rides in an extra z slice.
 template <typename T, int MI, int NJ, int U>
 void launch_dw2s_inst(KronDw2sArgs da, long tiles_i, long tiles_j, hipStream_t st) {
-  const bool red = da.dw1_ws != nullptr;
-  dim3 grid((unsigned)tiles_i, (unsigned)tiles_j, (unsigned)(da.nsplit + (red ? 1 : 0)));
+  da.tiles_i = (int)tiles_i;
+  da.tiles_j = (int)tiles_j;
+  dim3 grid((unsigned)(tiles_i * tiles_j * da.grid_split + (da.dw1_ws != nullptr ? da.dw1_red : 0)));
   if (da.gat.mode)
     hipLaunchKernelGGL((kron_dw2s_kernel<T, MI, NJ, U, true>), grid, dim3(NTHREADS), 0, st, da);
   else
@@ -159,13 +160,13 @@ void launch_dw2s(KronDw2sArgs da, hipStream_t st) {
   bool big = rows_total >= 16384 && eff44 >= 0.5;
   if (force_big >= 0) big = force_big != 0;
   long split = big ? s44 : s22;
+  if (split > 8) split -= split % 8;  // slabs in multiples of 8: one XCD per slab (see the kernel's block mapping)
   da.rows_per_block = round_up(cdiv(rows_total, split), 32);
   da.nsplit = (int)cdiv(rows_total, da.rows_per_block);
-  const long tiles = big ? t44 : t22;
+  da.grid_split = da.nsplit > 8 ? (int)round_up(da.nsplit, 8) : da.nsplit;
   if (da.dw1_ws != nullptr) {
     long r = da.dw1_nblk / 64;
     if (r > 16) r = 16;
-    if (r > tiles) r = tiles;
     if (r < 1) r = 1;
     da.dw1_red = (int)r;
   }

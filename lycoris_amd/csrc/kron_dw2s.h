@@ -29,7 +29,9 @@ struct KronDw2sArgs {
   int G, I, J;
   long ws, wt, os;
   long rows_per_block;  // flat (m, s) rows handled by one workgroup (multiple of 32)
-  int nsplit;           // row slabs (grid.z of the main part)
+  int nsplit;           // row slabs that hold rows (slabs at or beyond it are empty padding of the grid)
+  int tiles_i, tiles_j; // output tiles; the grid is 1-D: tiles_i * tiles_j * grid_split (+ dw1_red reducer workgroups)
+  int grid_split;       // slabs in the grid: a multiple of 8 when > 8, so that a slab's tiles share one XCD (L2)
   float alpha;
   // w1-gradient partial reduction (runs in grid slice z == nsplit; nullptr = nothing to do)
   const float* dw1_ws;  // [dw1_nblk][dw1_n] partials, already in dw1 memory order
@@ -86,19 +88,35 @@ __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the row bookkeeping in SGPRs
   LYC_TRACE_DECL;
   LYC_STAMP(0);
-  if ((int)blockIdx.z == a.nsplit) {  // w1-gradient reducer slice
-    const int r = (int)(blockIdx.x + blockIdx.y * gridDim.x);
+  // Workgroup -> (output tile, row slab).  Workgroup b runs on XCD b % 8 (observed dispatch order; speed only): all
+  // tiles of a slab are given to one XCD so that the slab's Q / P rows are fetched from HBM once and re-read from that
+  // XCD's L2 by the other tiles (measured without it: 8x the algorithmic bytes at the fabric, rocprofv3 FETCH_SIZE).
+  const int ntile = a.tiles_i * a.tiles_j;
+  const int b_ = (int)blockIdx.x;
+  if (b_ >= ntile * a.grid_split) {  // w1-gradient reducer workgroups ride at the end of the grid
+    const int r = b_ - ntile * a.grid_split;
     if (a.dw1_ws != nullptr && r < a.dw1_red) dw1_reduce_role(a, r, reinterpret_cast<float*>(smem));
     return;
   }
+  int slab, tile;
+  if ((a.grid_split & 7) == 0) {
+    const int k = b_ >> 3;
+    slab = (b_ & 7) + 8 * (k / ntile);
+    tile = k % ntile;
+  } else {
+    slab = b_ / ntile;
+    tile = b_ % ntile;
+  }
+  if (slab >= a.nsplit) return;  // padding slab
+  const int tile_x = tile % a.tiles_i, tile_y = tile / a.tiles_i;
 
   const T* Q = static_cast<const T*>(a.Q);
   const T* P = static_cast<const T*>(a.P);
   const int G = a.G;
   const int lg = 31 - __builtin_clz((unsigned)G);
-  const long i0 = (long)blockIdx.x * TI, j0 = (long)blockIdx.y * TJ;
+  const long i0 = (long)tile_x * TI, j0 = (long)tile_y * TJ;
   const long rows_total = a.M << lg;
-  const long rbeg = (long)blockIdx.z * a.rows_per_block;
+  const long rbeg = (long)slab * a.rows_per_block;
   long rend = rbeg + a.rows_per_block;
   if (rend > rows_total) rend = rows_total;
   T* tile0 = reinterpret_cast<T*>(smem) + wave * 2 * NC * DS_LD;  // this wave's private [NC cols][32 rows] tiles
