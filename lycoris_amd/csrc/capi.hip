@@ -137,7 +137,7 @@ int dw2s_env(const char* name, int dflt) {
 template <typename T>
 void launch_dw2s(KronDw2sArgs da, hipStream_t st) {
   static const int target_blocks = dw2s_env("LYC_DW2_BLOCKS", 512);       // development overrides
-  static const int atomic_budget = dw2s_env("LYC_DW2_ATOMICS", 600000);   // fp32 atomics per launch (~0.3 / ns)
+  static const int atomic_budget = dw2s_env("LYC_DW2_ATOMICS", 620000);   // fp32 atomics per launch (~0.3 / ns)
   static const int force_big = dw2s_env("LYC_DW2_BIG", -1);
   const long rows_total = da.M * da.G;
   auto plan = [&](int mi, int nj, long& tiles, long& split) {
@@ -160,7 +160,17 @@ void launch_dw2s(KronDw2sArgs da, hipStream_t st) {
   bool big = rows_total >= 16384 && eff44 >= 0.5;
   if (force_big >= 0) big = force_big != 0;
   long split = big ? s44 : s22;
-  if (split > 8) split -= split % 8;  // slabs in multiples of 8: one XCD per slab (see the kernel's block mapping)
+  const long tiles = big ? t44 : t22;
+  while (split > 1 && tiles * split > target_blocks) --split;  // one resident round: 2 workgroups per CU
+  if (split > 8) {
+    // slabs are dealt round-robin to the 8 XCDs (kernel block mapping): anything but a multiple of 8 leaves some XCDs
+    // with one slab more than the others (measured: 9 slabs run 1.6x slower than 8).  Round up when the workgroup cap
+    // and the atomic budget allow it, else down.
+    const long down = split - split % 8, up = down + 8;
+    const bool up_ok = split % 8 != 0 && tiles * up <= target_blocks &&
+                       (double)up * da.I * da.J <= (double)atomic_budget;
+    split = (split % 8 == 0) ? split : (up_ok ? up : down);
+  }
   da.rows_per_block = round_up(cdiv(rows_total, split), 32);
   da.nsplit = (int)cdiv(rows_total, da.rows_per_block);
   da.grid_split = da.nsplit > 8 ? (int)round_up(da.nsplit, 8) : da.nsplit;
