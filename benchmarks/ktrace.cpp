@@ -54,8 +54,8 @@ int main(int argc, char** argv) {
       if (split > rows_total / 128) split = rows_total / 128 > 0 ? rows_total / 128 : 1;
       da.rows_per_block = cdiv(cdiv(rows_total, split), 32) * 32;
       da.nsplit = (int)cdiv(rows_total, da.rows_per_block);
-      da.tiles_i = (int)cdiv(c, 32); da.tiles_j = (int)cdiv(d, 32); da.grid_split = da.nsplit;
-      dim3 grid((unsigned)(da.tiles_i * da.tiles_j * da.grid_split));
+      da.tiles_i = (int)cdiv(c, 32); da.tiles_j = (int)cdiv(d, 32);
+      dim3 grid((unsigned)(((da.tiles_i * da.tiles_j * da.nsplit + 7) / 8) * 8));
       hipLaunchKernelGGL((kron_dw2s_kernel<__bf16, 2, 2, 4, false>), grid, dim3(NTHREADS), 0, 0, da);
       if (rep == 0) printf("grid %u rows/block %ld\n", grid.x, da.rows_per_block);
     }

@@ -122,7 +122,7 @@ template <typename T, int MI, int NJ, int U>
 void launch_dw2s_inst(KronDw2sArgs da, long tiles_i, long tiles_j, hipStream_t st) {
   da.tiles_i = (int)tiles_i;
   da.tiles_j = (int)tiles_j;
-  dim3 grid((unsigned)(tiles_i * tiles_j * da.grid_split + (da.dw1_ws != nullptr ? da.dw1_red : 0)));
+  dim3 grid((unsigned)(round_up(tiles_i * tiles_j * da.nsplit, 8) + (da.dw1_ws != nullptr ? da.dw1_red : 0)));
   if (da.gat.mode)
     hipLaunchKernelGGL((kron_dw2s_kernel<T, MI, NJ, U, true>), grid, dim3(NTHREADS), 0, st, da);
   else
@@ -163,17 +163,15 @@ void launch_dw2s(KronDw2sArgs da, hipStream_t st) {
   const long tiles = big ? t44 : t22;
   while (split > 1 && tiles * split > target_blocks) --split;  // one resident round: 2 workgroups per CU
   if (split > 8) {
-    // slabs are dealt round-robin to the 8 XCDs (kernel block mapping): anything but a multiple of 8 leaves some XCDs
-    // with one slab more than the others (measured: 9 slabs run 1.6x slower than 8).  Round up when the workgroup cap
-    // and the atomic budget allow it, else down.
+    // the work items are dealt to the 8 XCDs in contiguous eighths of the slab-major order (kernel block mapping): with a
+    // multiple of 8 slabs no slab straddles two XCDs (measured: 41 slabs run 1.7x slower than 40).  Round up when the
+    // workgroup cap and the atomic budget allow it, else down if that costs little parallelism.
     const long down = split - split % 8, up = down + 8;
-    const bool up_ok = split % 8 != 0 && tiles * up <= target_blocks &&
-                       (double)up * da.I * da.J <= (double)atomic_budget;
-    split = (split % 8 == 0) ? split : (up_ok ? up : down);
+    const bool up_ok = tiles * up <= target_blocks && (double)up * da.I * da.J <= (double)atomic_budget;
+    if (split % 8 != 0) split = up_ok ? up : (down * 10 >= split * 9 ? down : split);  // give up at most 10 % of the slabs
   }
   da.rows_per_block = round_up(cdiv(rows_total, split), 32);
   da.nsplit = (int)cdiv(rows_total, da.rows_per_block);
-  da.grid_split = da.nsplit > 8 ? (int)round_up(da.nsplit, 8) : da.nsplit;
   if (da.dw1_ws != nullptr) {
     long r = da.dw1_nblk / 64;
     if (r > 16) r = 16;

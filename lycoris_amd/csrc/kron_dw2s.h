@@ -29,9 +29,8 @@ struct KronDw2sArgs {
   int G, I, J;
   long ws, wt, os;
   long rows_per_block;  // flat (m, s) rows handled by one workgroup (multiple of 32)
-  int nsplit;           // row slabs that hold rows (slabs at or beyond it are empty padding of the grid)
-  int tiles_i, tiles_j; // output tiles; the grid is 1-D: tiles_i * tiles_j * grid_split (+ dw1_red reducer workgroups)
-  int grid_split;       // slabs in the grid: a multiple of 8 when > 8, so that a slab's tiles share one XCD (L2)
+  int nsplit;           // row slabs
+  int tiles_i, tiles_j; // output tiles; the grid is 1-D: round_up(tiles_i * tiles_j * nsplit, 8) (+ dw1_red reducers)
   float alpha;
   // w1-gradient partial reduction (runs in grid slice z == nsplit; nullptr = nothing to do)
   const float* dw1_ws;  // [dw1_nblk][dw1_n] partials, already in dw1 memory order
@@ -88,27 +87,35 @@ __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the row bookkeeping in SGPRs
   LYC_TRACE_DECL;
   LYC_STAMP(0);
-  // Workgroup -> (output tile, row slab).  Workgroup b runs on XCD b % 8 (observed dispatch order; speed only): all
-  // tiles of a slab are given to one XCD so that the slab's Q / P rows are fetched from HBM once and re-read from that
-  // XCD's L2 by the other tiles (measured without it: 8x the algorithmic bytes at the fabric, rocprofv3 FETCH_SIZE).
+  // Workgroup -> (output tile, row slab).  Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only),
+  // and each XCD has its own L2.  The work items are put in an order in which neighbours share operand data and every XCD
+  // is dealt one CONTIGUOUS eighth of that order:
+  //   >= 8 slabs: slab-major -- all tiles of a slab re-read the slab's Q / P rows from one L2;
+  //   <  8 slabs: Q-column-major -- the tiles of a column group of Q (the big operand) sit on one XCD.
+  // Measured without it (rocprofv3 FETCH_SIZE): 8x the algorithmic bytes crossing the fabric.
   const int ntile = a.tiles_i * a.tiles_j;
+  const int nwork = ntile * a.nsplit;
+  const int per = (nwork + 7) >> 3;
   const int b_ = (int)blockIdx.x;
-  if (b_ >= ntile * a.grid_split) {  // w1-gradient reducer workgroups ride at the end of the grid
-    const int r = b_ - ntile * a.grid_split;
+  if (b_ >= per * 8) {  // w1-gradient reducer workgroups ride at the end of the grid
+    const int r = b_ - per * 8;
     if (a.dw1_ws != nullptr && r < a.dw1_red) dw1_reduce_role(a, r, reinterpret_cast<float*>(smem));
     return;
   }
-  int slab, tile;
-  if ((a.grid_split & 7) == 0) {
-    const int k = b_ >> 3;
-    slab = (b_ & 7) + 8 * (k / ntile);
-    tile = k % ntile;
+  const int o = (b_ & 7) * per + (b_ >> 3);
+  if (o >= nwork) return;  // padding of the last XCD's share
+  int slab, tile_x, tile_y;
+  if (a.nsplit >= 8) {
+    slab = o / ntile;
+    const int tile = o - slab * ntile;
+    tile_y = tile / a.tiles_i;
+    tile_x = tile - tile_y * a.tiles_i;
   } else {
-    slab = b_ / ntile;
-    tile = b_ % ntile;
+    tile_x = o / (a.tiles_j * a.nsplit);
+    const int rem = o - tile_x * (a.tiles_j * a.nsplit);
+    tile_y = rem / a.nsplit;
+    slab = rem - tile_y * a.nsplit;
   }
-  if (slab >= a.nsplit) return;  // padding slab
-  const int tile_x = tile % a.tiles_i, tile_y = tile / a.tiles_i;
 
   const T* Q = static_cast<const T*>(a.Q);
   const T* P = static_cast<const T*>(a.P);
