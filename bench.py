@@ -31,7 +31,8 @@ FACTOR = 8
 # HBM bytes per launch of the dominant kernels from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
 # runs, gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md; benchmarks/pmc_summary.py writes the numbers to
 # profiles/): counters cannot be collected inside the timed run, so the committed measurement is quoted here.
-PMC_TRAFFIC = {"kron3": None, "dw2s": None}
+# profiles/r01_pmc_bench_linear.txt (739 Linear layers, 2 eager passes): kron3 1.19x, dw2s 2.2x the algorithmic bytes
+PMC_TRAFFIC = {"kron3": 11331968, "dw2s": 17305621}
 
 
 def parse():
@@ -45,6 +46,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", default="all", help="'all' or 'linear' (development)")
     ap.add_argument("--profile-ops", action="store_true", help="development: torch.profiler table of one eager pass")
+    ap.add_argument("--pmc-pass", type=int, default=0,
+                    help="run N eager compute passes and exit (for rocprofv3 --pmc, which cannot sample inside graph replays)")
     return ap.parse_args()
 
 
@@ -155,6 +158,12 @@ def main():
         for y, proto in reversed(outs):
             torch.autograd.grad(y, [proto.x], proto.g)
 
+    if args.pmc_pass:
+        for _ in range(args.pmc_pass):
+            sync.zero_grad()
+            compute_pass()
+        torch.cuda.synchronize()
+        return
     if args.profile_ops:
         from torch.profiler import ProfilerActivity, profile
         sync.zero_grad()

@@ -42,8 +42,14 @@ def main():
     for k, v in write.items():
         if "copy16" in k and max(v) > 0:
             cal_w = gib / max(v)
-    print(f"calibration on copy16 (1 GiB read, 1 GiB written): read {cal_r} B/unit, write {cal_w} B/unit "
-          f"(1024 B/unit would be the nominal KiB unit)")
+    if cal_r is None or cal_w is None:
+        # no copy16 in this run: use the factors measured by `KB_EAGER=1 rocprofv3 --pmc ... benchmarks/kbench`
+        # (profiles/r01_pmc_kbench.txt): FETCH_SIZE counts half of a wide coalesced read on gfx950
+        cal_r, cal_w = cal_r or 2047.96, cal_w or 1024.0
+        print(f"calibration: read {cal_r} B/unit, write {cal_w} B/unit (from the copy16 run of benchmarks/kbench)")
+    else:
+        print(f"calibration on copy16 (1 GiB read, 1 GiB written): read {cal_r} B/unit, write {cal_w} B/unit "
+              f"(1024 B/unit would be the nominal KiB unit)")
     print(f"{'kernel':60s} {'n':>6s} {'FETCH_SIZE':>12s} {'WRITE_SIZE':>12s} {'read MB':>9s} {'write MB':>9s} {'HBM MB/launch':>14s}")
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, []), write.get(k, [])
@@ -54,6 +60,13 @@ def main():
         rb = fm * (cal_r or 1024.0)
         wb = wm * (cal_w or 1024.0)
         print(f"{short(k):60s} {max(len(f), len(w)):6d} {fm:12.1f} {wm:12.1f} {rb / 1e6:9.2f} {wb / 1e6:9.2f} {(rb + wb) / 1e6:14.2f}")
+    for fam in ("kron3_kernel", "kron_dw2s_kernel"):
+        fs = [v for k, vs in fetch.items() if fam in k for v in vs]
+        ws_ = [v for k, vs in write.items() if fam in k for v in vs]
+        if fs and ws_:
+            rb, wb = sum(fs) * cal_r, sum(ws_) * cal_w
+            print(f"FAMILY {fam}: {len(fs)} launches, read {rb / 1e6:.1f} MB + write {wb / 1e6:.1f} MB "
+                  f"=> {(rb / len(fs) + wb / len(ws_)):.0f} bytes per launch")
 
 
 if __name__ == "__main__":
