@@ -36,11 +36,11 @@ int main(int argc, char** argv) {
       const int ni = getenv("LYC_K3_NI") ? atoi(getenv("LYC_K3_NI")) : 4;
       dim3 grid((unsigned)cdiv(M, K3_RT / G), (unsigned)cdiv(ka.N, 16 * ni));
       if (ni == 4) {
-        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 4, true, false>), grid, dim3(NTHREADS), kron3_lds_bytes(4, 2), 0, ka);
-        else hipLaunchKernelGGL((kron3_kernel<__bf16, 4, false, false>), grid, dim3(NTHREADS), kron3_lds_bytes(4, 2), 0, ka);
+        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 4, true, 0>), grid, dim3(NTHREADS), kron3_lds_bytes(4, 2), 0, ka);
+        else hipLaunchKernelGGL((kron3_kernel<__bf16, 4, false, 0>), grid, dim3(NTHREADS), kron3_lds_bytes(4, 2), 0, ka);
       } else {
-        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 2, true, false>), grid, dim3(NTHREADS), kron3_lds_bytes(2, 2), 0, ka);
-        else hipLaunchKernelGGL((kron3_kernel<__bf16, 2, false, false>), grid, dim3(NTHREADS), kron3_lds_bytes(2, 2), 0, ka);
+        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 2, true, 0>), grid, dim3(NTHREADS), kron3_lds_bytes(2, 2), 0, ka);
+        else hipLaunchKernelGGL((kron3_kernel<__bf16, 2, false, 0>), grid, dim3(NTHREADS), kron3_lds_bytes(2, 2), 0, ka);
       }
       if (rep == 0) printf("grid %u x %u\n", grid.x, grid.y);
     }

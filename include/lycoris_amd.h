@@ -63,13 +63,15 @@ int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const flo
  * The kernel window is walked inside the kernels (pixel-row gather, zero outside the image); dx is the transposed
  * convolution with all taps summed in fp32 registers and rounded once.  Requires 16-bit activations, a == b in
  * {4, 8, 16}, c % 8 == d % 8 == 0, 16-byte aligned rows; returns LYC_ERR_UNSUPPORTED otherwise (use the im2col
- * lowering below).  `ws`: optional scratch of lyc_lokr_conv2d_bwd_workspace_bytes(...) bytes, as for the Linear form. */
+ * lowering below).  `ws`: optional scratch of lyc_lokr_conv2d_bwd_workspace_bytes(...) bytes, as for the Linear form.
+ * `w2t`: optional second copy of the factor as [kh*kw, c, d] (w2.permute(2,3,0,1)); with it (and stride 1) the
+ * transposed convolution runs over the flat (tap, q) index in full K segments instead of one short segment per tap. */
 int lyc_lokr_conv2d_fwd(const void* x_rows, const float* w1, const float* w2p, void* y_rows, int64_t B, int64_t H,
                         int64_t W, int a, int b, int c, int d, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
                         int dw, float alpha, int dtype, void* stream);
 int64_t lyc_lokr_conv2d_bwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int a, int b, int d);
-int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1, const float* w2p, void* dx_rows,
-                        float* dw1, float* dw2p, void* ws, int64_t B, int64_t H, int64_t W, int a, int b, int c, int d,
+int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1, const float* w2p, const float* w2t,
+                        void* dx_rows, float* dw1, float* dw2p, void* ws, int64_t B, int64_t H, int64_t W, int a, int b, int c, int d,
                         int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float alpha, int dtype,
                         void* stream);
 

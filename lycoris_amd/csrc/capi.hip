@@ -60,9 +60,10 @@ int k3_ni_override() {
   return v;
 }
 
-template <typename T, int NI, bool DW1, bool GATHER>
+template <typename T, int NI, bool DW1, int GATHER>
 void launch_kron3_inst2(const KronArgs& ka, dim3 grid, hipStream_t st) {
-  const long nseg = (ka.gat.mode ? ka.gat.taps : 1) * cdiv(ka.K, kron3_kc(NI));
+  const long nseg = GATHER == 2 ? cdiv((long)ka.gat.taps * ka.K, kron3_kc(NI))
+                                : (ka.gat.mode ? ka.gat.taps : 1) * cdiv(ka.K, kron3_kc(NI));
   const int lds = kron3_lds_bytes(NI, nseg > 1 ? 2 : 1);
   if (lds > 64 * 1024) {  // more than the default dynamic-LDS window: opt in once per instantiation
     static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&kron3_kernel<T, NI, DW1, GATHER>),
@@ -74,8 +75,9 @@ void launch_kron3_inst2(const KronArgs& ka, dim3 grid, hipStream_t st) {
 
 template <typename T, int NI, bool DW1>
 void launch_kron3_inst(const KronArgs& ka, dim3 grid, hipStream_t st) {
-  if (ka.gat.mode) launch_kron3_inst2<T, NI, DW1, true>(ka, grid, st);
-  else launch_kron3_inst2<T, NI, DW1, false>(ka, grid, st);
+  if (ka.gat.mode && ka.gat.flat) launch_kron3_inst2<T, NI, DW1, 2>(ka, grid, st);
+  else if (ka.gat.mode) launch_kron3_inst2<T, NI, DW1, 1>(ka, grid, st);
+  else launch_kron3_inst2<T, NI, DW1, 0>(ka, grid, st);
 }
 
 // 64-column tiles halve the x re-reads and the per-column w2 conversions; 32-column tiles double the workgroup count.
@@ -403,6 +405,7 @@ int lyc_lokr_conv2d_fwd(const void* x_rows, const float* w1, const float* w2p, v
   ka.M = B * cd.Ho * cd.Wo; ka.Gin = b; ka.K = d; ka.Gout = a; ka.N = c;
   ka.s1o = b; ka.s1i = 1; ka.s2n = (long)cd.taps * d; ka.s2k = 1; ka.alpha = alpha;
   ka.gat = make_gather(1, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
+  ka.gat.flat = cd.taps <= 64;  // w2p[q][t][v] is contiguous in the flat (tap, v) index: s2n = taps * d, s2k = 1
   switch (dtype & 0xff) {
     case LYC_BF16: launch_kron3<__bf16>(ka, (hipStream_t)stream); break;
     default: launch_kron3<_Float16>(ka, (hipStream_t)stream); break;
@@ -415,8 +418,8 @@ int64_t lyc_lokr_conv2d_bwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int
   return (int64_t)cdiv(B * H * W, K3_RT / a) * cdiv(d, 32) * a * b * (int64_t)sizeof(float);
 }
 
-int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1, const float* w2p, void* dx_rows,
-                        float* dw1, float* dw2p, void* ws, int64_t B, int64_t H, int64_t W, int a, int b, int c, int d,
+int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1, const float* w2p, const float* w2t,
+                        void* dx_rows, float* dw1, float* dw2p, void* ws, int64_t B, int64_t H, int64_t W, int a, int b, int c, int d,
                         int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float alpha, int dtype,
                         void* stream) {
   if (!g_rows || !x_rows || !w1 || !w2p) return fail(LYC_ERR_ARG, "lokr_conv2d_bwd: null pointer");
@@ -435,6 +438,11 @@ int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1,
     ka.M = B * H * W; ka.Gin = a; ka.K = c; ka.Gout = b; ka.N = d;
     ka.s1o = 1; ka.s1i = b; ka.s2n = 1; ka.s2k = (long)cd.taps * d; ka.alpha = alpha;
     ka.gat = make_gather(2, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
+    if (w2t && sh == 1 && sw == 1 && cd.taps <= 64) {
+      // stride 1: the source pixel of tap t is base - offset[t], so K can run over the flat (tap, q) index with full
+      // segments; that needs the factor as [taps, c, d]: element (n = v, k = t*c + q) at w2t[k * d + v]
+      ka.w2 = w2t; ka.s2n = 1; ka.s2k = d; ka.gat.flat = 1;
+    }
     const long nblk = bf ? launch_kron3<__bf16>(ka, st) : launch_kron3<_Float16>(ka, st);
     if (int rc = check_launch("lokr_conv2d_bwd(dx)")) return rc;
     if (ka.dw1_ws) dw1_partials = nblk;

@@ -165,46 +165,34 @@ __device__ __forceinline__ void k3_store_w2(T* __restrict__ Bh, T* __restrict__ 
   }
 }
 
-// The body is a device function so that the fused backward launch (kron_bwd_fused_kernel) can run it as one role.
-// `bx`, `by`: tile coordinates (M tile, N tile).  `smem`: kron3_lds_bytes(NI, K > K3_KC ? 2 : 1) bytes, 16-byte aligned.
-template <typename T, int NI, bool WITH_DW1, bool GATHER>
-__device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx, int by, int nbx) {
+// Stage 1 of the factored kernels: acc[mi][ni] (16x16 tiles, wave tile 32 rows x 16 NI columns) =
+//   sum over segments of  x3[row, k] * w2[n0 + n, k]      (x exact T from HBM, w2 fp32 -> hi/lo through LDS)
+// for the workgroup's 128 stage-1 rows starting at row0 (rows >= rows_end read as zero).  Shared by the LoKr kernel
+// (kron3_body) and the LoCon kernel (locon3.h: N = rank).  `smem`: kron3_lds_bytes(NI, segments > 1 ? 2 : 1) bytes.
+// GM: 0 = plain rows, 1 = pixel-row gather with one K segment sequence per tap (any geometry), 2 = gather over the
+// FLAT K index (tap, k) -- the source pixel of tap t is base + offset[t] (forward with any stride, backward with stride
+// 1), so segments are full K3_KC chunks however short the per-tap rows are (C = 320 convs have 40 columns per tap).
+template <typename T, int NI, int GM>
+__device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long row0, long rows_end, long n0,
+                                          f32x4 (&acc)[2][NI]) {
+  constexpr bool GATHER = GM != 0;
+  constexpr bool FLAT = GM == 2;
   constexpr int MI = 2, TQ = 16 * NI;
   constexpr int K3_KC = kron3_kc(NI), K3_KS = K3_KC / 32, K3_LDB = K3_KC + 16;
   constexpr int PLANE = TQ * K3_LDB;  // elements per hi or lo tile
   T* Bbase = reinterpret_cast<T*>(smem);
   using F8 = typename TT<T>::frag;
-  using F4 = typename Mma16<T>::frag;
   using RW = K3Raw<TQ, K3_KC>;
-
   const T* x = static_cast<const T*>(a.x);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int G = a.Gin, K = a.K, N = a.N;
-  const int lg = 31 - __builtin_clz((unsigned)G);  // G is a power of two (16 % G == 0)
-  const int TM = K3_RT >> lg;
-  const long n0 = (long)by * TQ;
-  const long row0 = ((long)bx * TM) << lg;
-  long rows_end = row0 + K3_RT;
-  if (rows_end > (a.M << lg)) rows_end = a.M << lg;
-  LYC_TRACE_DECL;
-  LYC_STAMP(0);
-
-  // (I (x) w1) block operand, raw fp32: lane (j = li, g) holds k = 4g .. 4g+3 of column j; converted in the epilogue
-  float w1raw[4];
-  {
-    const int mi_ = li >> lg, po = li & (G - 1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int kk = 4 * g + j;
-      const float v = a.w1[po * a.s1o + (kk & (G - 1)) * a.s1i];  // always in range; selected, not branched
-      w1raw[j] = ((kk >> lg) == mi_) ? v : 0.f;
-    }
-  }
+  const int lg = 31 - __builtin_clz((unsigned)G);
 
   // this lane's two stage-1 rows (dst pixel, group).  With a gather the operand row of tap t comes from another pixel.
   const long gr0 = row0 + wave * 32 + li, gr1 = gr0 + 16;
   const bool ok0 = gr0 < rows_end, ok1 = gr1 < rows_end;
-  const int taps = GATHER ? a.gat.taps : 1;
+  const int taps = (GATHER && !FLAT) ? a.gat.taps : 1;              // segment sequences
+  const int Kloop = FLAT ? a.gat.taps * K : K;                        // K extent of one sequence
   int pb[2], ph_[2], pw_[2];  // (image, h, w) of the two destination pixels
   if constexpr (GATHER) {
 #pragma unroll
@@ -217,6 +205,56 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
       pw_[r] = rem - ph_[r] * a.gat.Wd;
     }
   }
+  // FLAT: per row, the flat source row index of tap offset 0 and the bit mask of the taps that fall inside the image;
+  // per tap, the source-row offset (LDS table).  Fragment 8g..8g+7 of a k-step never straddles taps (K % 8 == 0).
+  __shared__ long k3_tapoff[FLAT ? 64 : 1];
+  long frow[2] = {0, 0};
+  unsigned long long fmask[2] = {0ull, 0ull};
+  if constexpr (FLAT) {
+    const int kh = a.gat.taps / a.gat.kw;
+    if (tid < a.gat.taps) {
+      const int i = tid / a.gat.kw, j = tid - i * a.gat.kw;
+      const long off = (long)i * a.gat.dh * a.gat.Ws + (long)j * a.gat.dw;
+      k3_tapoff[tid] = (a.gat.mode == 1 ? off : -off) << lg;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const long gr = r ? gr1 : gr0;
+      const int h0 = a.gat.mode == 1 ? ph_[r] * a.gat.sh - a.gat.ph : ph_[r] + a.gat.ph;
+      const int w0 = a.gat.mode == 1 ? pw_[r] * a.gat.sw - a.gat.pw : pw_[r] + a.gat.pw;
+      const int sgn = a.gat.mode == 1 ? 1 : -1;
+      unsigned long long wm = 0ull;
+      for (int j = 0; j < a.gat.kw; ++j) {
+        const int ws = w0 + sgn * j * a.gat.dw;
+        if (ws >= 0 && ws < a.gat.Ws) wm |= 1ull << j;
+      }
+      unsigned long long m = 0ull;
+      for (int i = 0; i < kh; ++i) {
+        const int hs = h0 + sgn * i * a.gat.dh;
+        if (hs >= 0 && hs < a.gat.Hs) m |= wm << (i * a.gat.kw);
+      }
+      fmask[r] = (r ? ok1 : ok0) ? m : 0ull;
+      frow[r] = ((((long)pb[r] * a.gat.Hs + h0) * a.gat.Ws + w0) << lg) + (gr & (G - 1));
+    }
+    __syncthreads();  // the tap table
+  }
+  // FLAT fragment of lane row r for the k-step starting at flat index kk (uniform)
+  auto load_frag_flat = [&](int r, long kk) -> F8 {
+    int tap = (int)(kk / K);
+    int rem = (int)(kk - (long)tap * K) + 8 * g;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+      if (rem >= K) {
+        rem -= K;
+        ++tap;
+      }
+    const bool ok = tap < a.gat.taps && ((fmask[r] >> tap) & 1ull);
+    const long srow = frow[r] + k3_tapoff[ok ? tap : 0];
+    const u32x4 v = *reinterpret_cast<const u32x4*>(ok ? x + srow * K + rem : x);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    const u32x4 o = ok ? v : z;
+    return *reinterpret_cast<const F8*>(&o);
+  };
   // row base pointer (+ 8g) and validity of lane row r for tap t
   auto row_src = [&](int r, int t, const T*& p, bool& ok) {
     const long gr = r ? gr1 : gr0;
@@ -251,10 +289,16 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
     return *reinterpret_cast<const F8*>(&r);
   };
 
-  const int w2mode = k3_w2_mode(a.w2, a.s2n, a.s2k, N, K);
+  const int w2mode = k3_w2_mode(a.w2, a.s2n, a.s2k, N, Kloop);
   F8 af[MI][K3_KS];
   f32x4 raw[RW::NRAW];
-  {
+  if constexpr (FLAT) {
+#pragma unroll
+    for (int ks = 0; ks < K3_KS; ++ks) {
+      af[0][ks] = load_frag_flat(0, ks * 32);
+      af[1][ks] = load_frag_flat(1, ks * 32);
+    }
+  } else {
     const T *p0, *p1;
     bool v0, v1;
     row_src(0, 0, p0, v0);
@@ -265,19 +309,15 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
       af[1][ks] = load_frag_x(v1, p1, ks * 32);
     }
   }
-  k3_load_w2<TQ, K3_KC>(raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, K);
+  k3_load_w2<TQ, K3_KC>(raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, Kloop);
 
-  f32x4 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = zero4();
 
-  LYC_STAMP(1);
-  k3_store_w2<T, TQ, K3_KC>(Bbase, Bbase + PLANE, raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, K);
-  LYC_STAMP(2);
+  k3_store_w2<T, TQ, K3_KC>(Bbase, Bbase + PLANE, raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, Kloop);
   __syncthreads();
-  LYC_STAMP(3);
 
   // one chunk: NKS k-steps of MFMAs from (af, LDS tile); with MORE the fragment registers of each k-step are re-loaded
   // for the next chunk as soon as they are free.  Straight-line code (no per-k-step branches), so the compiler hoists the
@@ -308,8 +348,13 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
         }
       }
       if constexpr (MORE) {  // the fragment registers of this k-step are free again: fetch the next segment's
-        af[0][ks] = load_frag_x(nv0, np0, knext + ks * 32);
-        af[1][ks] = load_frag_x(nv1, np1, knext + ks * 32);
+        if constexpr (FLAT) {
+          af[0][ks] = load_frag_flat(0, knext + ks * 32);
+          af[1][ks] = load_frag_flat(1, knext + ks * 32);
+        } else {
+          af[0][ks] = load_frag_x(nv0, np0, knext + ks * 32);
+          af[1][ks] = load_frag_x(nv1, np1, knext + ks * 32);
+        }
       }
     }
   };
@@ -326,31 +371,33 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
   static_assert(K3_KS == 5 || K3_KS == 3, "run_chunk dispatch assumes 3 or 5 k-steps per chunk");
 
   // segments: (tap, chunk of K3_KC within the K columns of the tap); one LDS w2 tile per segment, double buffered
-  const int cpt = (K + K3_KC - 1) / K3_KC;
+  const int cpt = (Kloop + K3_KC - 1) / K3_KC;
   const int nseg = taps * cpt;
   int buf = 0, tap = 0;
   long k0 = 0;
   for (int sgm = 0; sgm < nseg; ++sgm) {
-    const long krem = K - k0;
+    const long krem = Kloop - k0;
     const int nks = krem >= K3_KC ? K3_KS : (int)((krem + 31) / 32);
     const T* Bh = Bbase + buf * 2 * PLANE;
     const T* Bl = Bh + PLANE;
     if (sgm + 1 < nseg) {
       int ntap = tap;
       long nk0 = k0 + K3_KC;
-      if (nk0 >= K) {
+      if (nk0 >= Kloop) {
         nk0 = 0;
         ++ntap;
       }
       const T *np0 = nullptr, *np1 = nullptr;
       bool nv0 = false, nv1 = false;
-      row_src(0, ntap, np0, nv0);
-      row_src(1, ntap, np1, nv1);
-      const float* w2n = GATHER ? a.w2 + (long)ntap * a.gat.s2t : a.w2;
-      k3_load_w2<TQ, K3_KC>(raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, K);
+      if constexpr (!FLAT) {
+        row_src(0, ntap, np0, nv0);
+        row_src(1, ntap, np1, nv1);
+      }
+      const float* w2n = (GATHER && !FLAT) ? a.w2 + (long)ntap * a.gat.s2t : a.w2;
+      k3_load_w2<TQ, K3_KC>(raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, Kloop);
       run_chunk(nks, std::true_type{}, Bh, Bl, np0, nv0, np1, nv1, nk0);
       T* Nh = Bbase + (buf ^ 1) * 2 * PLANE;
-      k3_store_w2<T, TQ, K3_KC>(Nh, Nh + PLANE, raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, K);
+      k3_store_w2<T, TQ, K3_KC>(Nh, Nh + PLANE, raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, Kloop);
       __syncthreads();
       buf ^= 1;
       tap = ntap;
@@ -359,6 +406,40 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
       run_chunk(nks, std::false_type{}, Bh, Bl, nullptr, false, nullptr, false, 0);
     }
   }
+}
+
+// The body is a device function so that the fused backward launch (kron_bwd_fused_kernel) can run it as one role.
+// `bx`, `by`: tile coordinates (M tile, N tile).  `smem`: kron3_lds_bytes(NI, K > K3_KC ? 2 : 1) bytes, 16-byte aligned.
+template <typename T, int NI, bool WITH_DW1, int GM>
+__device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx, int by, int nbx) {
+  constexpr int MI = 2, TQ = 16 * NI;
+  using F4 = typename Mma16<T>::frag;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int G = a.Gin, N = a.N;
+  const int lg = 31 - __builtin_clz((unsigned)G);  // G is a power of two (16 % G == 0)
+  const int TM = K3_RT >> lg;
+  const long n0 = (long)by * TQ;
+  const long row0 = ((long)bx * TM) << lg;
+  long rows_end = row0 + K3_RT;
+  if (rows_end > (a.M << lg)) rows_end = a.M << lg;
+  LYC_TRACE_DECL;
+  LYC_STAMP(0);
+
+  // (I (x) w1) block operand, raw fp32: lane (j = li, g) holds k = 4g .. 4g+3 of column j; converted in the epilogue
+  float w1raw[4];
+  {
+    const int mi_ = li >> lg, po = li & (G - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kk = 4 * g + j;
+      const float v = a.w1[po * a.s1o + (kk & (G - 1)) * a.s1i];  // always in range; selected, not branched
+      w1raw[j] = ((kk >> lg) == mi_) ? v : 0.f;
+    }
+  }
+
+  f32x4 acc[MI][NI];
+  k3_stage1<T, NI, GM>(a, smem, row0, rows_end, n0, acc);
   LYC_STAMP(4);
 
   // ---- epilogue, all in registers ----
@@ -478,10 +559,10 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
   }
 }
 
-template <typename T, int NI, bool WITH_DW1, bool GATHER>
+template <typename T, int NI, bool WITH_DW1, int GM>
 __global__ __launch_bounds__(NTHREADS) void kron3_kernel(KronArgs a) {
   extern __shared__ __attribute__((aligned(16))) char k3_smem[];
-  kron3_body<T, NI, WITH_DW1, GATHER>(a, k3_smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+  kron3_body<T, NI, WITH_DW1, GM>(a, k3_smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
 }  // namespace lyc

@@ -30,7 +30,9 @@ struct KronGather {
   int taps, kw;        // kh * kw, kw
   int Hs, Ws, Hd, Wd;  // source / destination spatial sizes
   int sh, sw, ph, pw, dh, dw;
-  long s2t;            // w2 element offset per tap
+  long s2t;            // w2 element offset per tap (per-tap segments)
+  int flat;            // 1: the K index is the flat (tap, k) index and w2 is addressed by it (s2n, s2k); needs
+                       //    source pixel = base + offset[tap]: forward with any stride, backward with stride 1
 };
 
 struct KronArgs {

@@ -371,7 +371,9 @@ class _LokrConv2dImplicit(torch.autograd.Function):
             nbytes = int(N.load().lyc_lokr_conv2d_bwd_workspace_bytes(B, H, W, a, b, d))
             if nbytes:
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=rows.device)
-        N.call("lyc_lokr_conv2d_bwd", N.ptr(g_rows), N.ptr(rows), N.ptr(w1f), N.ptr(w2p), N.ptr(dx_rows), N.ptr(dw1),
+        # stride 1: a [kh, kw, c, d] copy of the (small) factor lets the transposed convolution use full K segments
+        w2t = w2.detach().float().permute(2, 3, 0, 1).contiguous() if (dx_rows is not None and s == (1, 1)) else None
+        N.call("lyc_lokr_conv2d_bwd", N.ptr(g_rows), N.ptr(rows), N.ptr(w1f), N.ptr(w2p), N.ptr(w2t), N.ptr(dx_rows), N.ptr(dw1),
                N.ptr(dw2p), N.ptr(ws), B, H, W, a, b, c, d, k[0], k[1], s[0], s[1], p[0], p[1], d_[0], d_[1], alpha, code,
                N.stream_ptr(rows.device))
         dx = None
