@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--layers", default="all", help="'all' or 'linear' (development)")
+    ap.add_argument("--layers", default="all", help="'all', 'linear' or 'conv' (development)")
     ap.add_argument("--profile-ops", action="store_true", help="development: torch.profiler table of one eager pass")
     ap.add_argument("--pmc-pass", type=int, default=0,
                     help="run N eager compute passes and exit (for rocprofv3 --pmc, which cannot sample inside graph replays)")
@@ -106,6 +106,8 @@ def build_workload(algo, dtype, dev, which):
     layers = []
     for spec in sdxl_unet_layers(1):
         if which == "linear" and spec["kind"] != "linear":
+            continue
+        if which == "conv" and spec["kind"] != "conv":
             continue
         # one Layer object (static tensors) per *distinct* shape; `count` instances share the activations but own
         # their parameters would cost 788 x activations; instead every instance has its own parameters + grads
@@ -192,9 +194,8 @@ def main():
 
     def step():
         graph.replay()
-        if world > 1:
-            for b in sync.buckets:  # mean all-reduce of the arena slices on the side stream
-                sync._launch(b)
+        if world > 1:  # mean all-reduce of the arena buckets on the side stream, joined before the optimizer
+            sync.all_reduce_now()
             sync.finish()
         opt.step()
 

@@ -152,6 +152,14 @@ class AdapterGradSync:
             return None
         return work
 
+    def all_reduce_now(self):
+        """Launch the collective of every bucket that has not been launched in this step -- for callers whose backward
+        does not fire the autograd hooks (fused accumulation straight into the arena, or a replayed hipGraph)."""
+        for b in self.buckets:
+            if b.pending > 0 or b.work is None:
+                b.pending = 0
+                self._launch(b)
+
     def finish(self):
         """Call after backward, before optimizer.step(): flushes buckets whose hooks did not all fire (unused
         parameters) and makes the compute stream wait for the collectives."""
@@ -165,6 +173,7 @@ class AdapterGradSync:
                 b.work = None
         if self.side_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
+        self._reset_pending()
         self._reset_pending()
 
     def remove(self):

@@ -54,6 +54,47 @@ def _worker(rank, world, port, bucket_bytes, out):
         dist.destroy_process_group()
 
 
+def _worker_direct(rank, world, port, out):
+    """bench.py's pattern: gradients written straight into the arena (no autograd hooks), then all_reduce_now()."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lycoris_amd.grad_sync import AdapterGradSync
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.randn(s)) for s in [(8, 8), (160, 16), (3,)]]
+        sync = AdapterGradSync(params, bucket_bytes=256)
+        ok = True
+        for step in range(3):  # no zero_grad() between steps 1 and 2: finish() must re-arm the buckets itself
+            if step != 2:
+                sync.zero_grad()
+            for p in params:
+                p.grad.add_(float(rank + 1 + step))  # "kernel" accumulating into the arena
+            sync.all_reduce_now()
+            sync.finish()
+            want = sum(r + 1 + step for r in range(world)) / world
+            if step == 2:  # accumulated on top of the averaged step-1 values, which are equal on every rank
+                want = want + sum(r + 1 + 1 for r in range(world)) / world
+            ok = ok and all(torch.allclose(p.grad, torch.full_like(p, want)) for p in params)
+        out.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_direct_arena_writes_then_all_reduce_now():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_direct, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(out.get(timeout=5) for _ in range(2))
+    assert [g[1] for g in got] == [True, True], got
+
+
 @pytest.mark.parametrize("bucket_bytes", [1 << 30, 1024, 1])
 def test_gradients_are_averaged_across_two_ranks(bucket_bytes):
     ctx = mp.get_context("spawn")
