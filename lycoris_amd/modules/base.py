@@ -85,9 +85,9 @@ class LycorisBaseModule(nn.Module):
         self.rank_dropout = rank_dropout
         self.rank_dropout_scale = rank_dropout_scale
         self.module_dropout = module_dropout
-        if (dropout or 0) or (rank_dropout or 0) or (module_dropout or 0):
-            raise _unsupported("dropout / rank_dropout / module_dropout")
-        self.drop = nn.Identity()
+        # dropout variants (reference: locon.py:210-217,292-304,310-312, loha.py:220-225, lokr.py:375-380,544-546), all
+        # applied around the kernels without materialising dW -- see forward() below
+        self.drop = nn.Dropout(dropout) if dropout else nn.Identity()
         self.rank_drop = nn.Identity()
         self.multiplier = multiplier
         self.org_forward = org_module.forward
@@ -260,11 +260,33 @@ class LycorisBaseModule(nn.Module):
     def bypass_forward(self, x, scale=1):
         return self.org_forward(x) + self.bypass_forward_diff(x, scale=scale)
 
+    def _rank_dropout_mask(self, delta):
+        """The reference's rebuild path drops ROWS of dW (`torch.rand(weight.size(0)) > rank_dropout`, optionally
+        rescaled by the keep rate): a per-output-channel factor on the delta, so nothing has to be rebuilt."""
+        drop = (torch.rand(self.dim, device=delta.device) > self.rank_dropout).to(torch.float32)
+        if self.rank_dropout_scale:
+            drop = drop / drop.mean()
+        return drop
+
     def forward(self, x, *args, **kwargs):
         """base + delta.  The rebuild path and the bypass path of the reference are the same mathematical function
-        (rebuild semantics are canonical); natively both are the factored evaluation on x."""
+        (rebuild semantics are canonical); natively both are the factored evaluation on x.
+
+        Dropout variants (training mode only): `module_dropout` skips the adapter for the whole call; `rank_dropout`
+        scales the delta per output channel (rebuild-path semantics, see _rank_dropout_mask) with the native
+        per-channel kernel; plain `dropout` acts on the delta in bypass mode, as upstream's LoCon does (upstream
+        ignores it on the rebuild path and for LoHa / LoKr)."""
+        if self.module_dropout and self.training and float(torch.rand(1)) < self.module_dropout:
+            return self.org_forward(x, *args, **kwargs)
         base = self.org_forward(x, *args, **kwargs)
-        return base + self.bypass_forward_diff(x, scale=self.multiplier)
+        delta = self.bypass_forward_diff(x, scale=self.multiplier)
+        if self.rank_dropout and self.training:
+            from .. import ops
+            chan_dim = 1 if self.module_type.startswith("conv") else -1
+            delta = ops.chan_affine(delta.contiguous(), self._rank_dropout_mask(delta), None, 0.0, 1.0, chan_dim)
+        if self.bypass_mode and self.training and self.name in ("locon", "lora"):
+            delta = self.drop(delta)
+        return base + delta
 
     # ---- helpers for subclasses --------------------------------------------------------------------------------
     def _conv_geometry(self):

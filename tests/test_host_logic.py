@@ -163,9 +163,12 @@ def test_no_cpu_fallback_and_unsupported_features_fail_loudly():
         layer(torch.randn(2, 16))
     mod.restore()
     assert layer(torch.randn(2, 16)).shape == (2, 16)
-    for kw in (dict(dropout=0.1), dict(rank_dropout=0.1), dict(module_dropout=0.1), dict(weight_decompose=True)):
-        with pytest.raises(NotImplementedError):
-            LoConModule("m", nn.Linear(8, 8), 1.0, 2, 1, **kw)
+    with pytest.raises(NotImplementedError):
+        LoConModule("m", nn.Linear(8, 8), 1.0, 2, 1, weight_decompose=True)
+    # the dropout variants are on the native path (applied around the kernels, tests/test_gpu_dropout.py)
+    m = LoConModule("m", nn.Linear(8, 8), 1.0, 2, 1, dropout=0.1, rank_dropout=0.2, module_dropout=0.3,
+                    rank_dropout_scale=True)
+    assert (m.dropout, m.rank_dropout, m.module_dropout, m.rank_dropout_scale) == (0.1, 0.2, 0.3, True)
     with pytest.raises(NotImplementedError):
         LokrModule("m", nn.Conv2d(8, 8, 3), 1.0, 2, 1, use_tucker=True, factor=2)
     with pytest.raises(NotImplementedError):
