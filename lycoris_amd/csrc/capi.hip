@@ -1,5 +1,6 @@
 // capi.hip -- C ABI launchers (include/lycoris_amd.h).  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -579,6 +580,43 @@ LohaPlanes loha_planes(void* base, int O, int I, size_t esz) {
   return p;
 }
 size_t esize(int dtype) { return (dtype & 0xff) == LYC_F32 ? 4 : 2; }
+
+// LoHa's Hadamard product of two rank-r matrices is full rank: once the dW operand planes exist, the three contractions
+// (y = x dW^T, dx = g dW, G = g^T x) are PLAIN dense GEMMs -- the one place where the vendor library is the right tool
+// (hand-written kernels are for the fused / factored ops).  Row-major C[m, n] = op(A) op(B) is issued as the
+// column-major product C^T = op(B)^T op(A)^T.  One handle per host thread; calls only enqueue on `st`.
+rocblas_handle rb_handle(hipStream_t st) {
+  thread_local rocblas_handle h = nullptr;
+  if (!h) {
+    if (rocblas_create_handle(&h) != rocblas_status_success) {
+      h = nullptr;
+      return nullptr;
+    }
+    rocblas_set_pointer_mode(h, rocblas_pointer_mode_host);
+  }
+  if (rocblas_set_stream(h, st) != rocblas_status_success) return nullptr;
+  return h;
+}
+// C[M, N] (ldc) = alpha * A' * B' + beta * C, all row-major.
+//   a_t == false: A is [M, K] (lda)      a_t == true: A is [K, M] (lda)
+//   b_t == false: B is [K, N] (ldb)      b_t == true: B is [N, K] (ldb)
+int rb_gemm(hipStream_t st, bool a_t, bool b_t, long M, long N, long K, const void* A, long lda, const void* B, long ldb,
+            void* C, long ldc, rocblas_datatype in_t, rocblas_datatype out_t, float alpha, float beta, const char* what) {
+  rocblas_handle h = rb_handle(st);
+  if (!h) return fail(LYC_ERR_LAUNCH, "%s: rocBLAS handle unavailable", what);
+  // column-major view: C^T [N x M] = op(B) [N x K] * op(A) [K x M]
+  const rocblas_operation opB = b_t ? rocblas_operation_transpose : rocblas_operation_none;   // B row-major [N,K] = cm [K,N]
+  const rocblas_operation opA = a_t ? rocblas_operation_transpose : rocblas_operation_none;   // A row-major [K,M] = cm [M,K]
+  const rocblas_status rs =
+      rocblas_gemm_ex(h, opB, opA, (rocblas_int)N, (rocblas_int)M, (rocblas_int)K, &alpha, B, in_t, (rocblas_int)ldb, A, in_t,
+                      (rocblas_int)lda, &beta, C, out_t, (rocblas_int)ldc, C, out_t, (rocblas_int)ldc,
+                      rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
+  if (rs != rocblas_status_success) return fail(LYC_ERR_LAUNCH, "%s: rocblas_gemm_ex failed (%d)", what, (int)rs);
+  return LYC_OK;
+}
+rocblas_datatype rb_type(int dtype) {
+  return (dtype & 0xff) == LYC_BF16 ? rocblas_datatype_bf16_r : rocblas_datatype_f16_r;
+}
 }  // namespace
 }  // extern "C++"
 
@@ -599,7 +637,16 @@ int lyc_loha_linear_fwd(const void* x, const float* w1a, const float* w1b, const
   la.Wn_h = pl.nh; la.Wn_l = pl.nl; la.Wt_h = pl.th; la.Wt_l = pl.tl; la.ldn = pl.ldn; la.ldt = pl.ldt;
   dim3 rg((unsigned)cdiv(O, LOHA_T), (unsigned)cdiv(I, LOHA_T));
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((loha_rebuild_kernel<T>), rg, dim3(NTHREADS), 0, st, la));
-  if (M > 0) {
+  if (int rc = check_launch("loha_linear_fwd(rebuild)")) return rc;
+  if (M > 0 && (dtype & 0xff) != LYC_F32) {
+    // y = x (Wh + Wl)^T: the lo plane first (its result is ~2^-9 of y, so rounding it to T costs ~2^-18 relative), then
+    // the hi plane accumulated on top in fp32 inside the GEMM and rounded once
+    const rocblas_datatype t = rb_type(dtype);
+    if (int rc = rb_gemm(st, false, true, M, O, I, x, I, pl.nl, pl.ldn, y, O, t, t, 1.0f, 0.0f, "loha_linear_fwd")) return rc;
+    if (int rc = rb_gemm(st, false, true, M, O, I, x, I, pl.nh, pl.ldn, y, O, t, t, 1.0f, 1.0f, "loha_linear_fwd")) return rc;
+    return LYC_OK;
+  }
+  if (M > 0) {  // fp32 activations: exact fp32 MFMA kernel
     GemmArgs ga{};
     ga.A = x; ga.Bh = pl.nh; ga.Bl = pl.nl; ga.out = y; ga.M = M; ga.N = O; ga.K = I;
     ga.lda = I; ga.ldb = pl.ldn; ga.ldo = O; ga.alpha = 1.0f;
@@ -621,7 +668,13 @@ int lyc_loha_linear_bwd(const void* g, const void* x, const float* w1a, const fl
   if (M == 0) return LYC_OK;
   hipStream_t st = (hipStream_t)stream;
   LohaPlanes pl = loha_planes(const_cast<void*>(wplanes), O, I, esize(dtype));
-  if (dx) {  // dx = g @ dW : B operand rows = i, K = o  -> the transposed planes
+  const bool lib = (dtype & 0xff) != LYC_F32;
+  if (dx && lib) {  // dx = g (Wh + Wl): [M,O] x [O,I], same lo-then-hi order as the forward
+    const rocblas_datatype t = rb_type(dtype);
+    const rocblas_datatype to = (dtype & LYC_F32_ROWS) ? rocblas_datatype_f32_r : t;
+    if (int rc = rb_gemm(st, false, false, M, I, O, g, O, pl.nl, pl.ldn, dx, I, t, to, 1.0f, 0.0f, "loha_linear_bwd(dx)")) return rc;
+    if (int rc = rb_gemm(st, false, false, M, I, O, g, O, pl.nh, pl.ldn, dx, I, t, to, 1.0f, 1.0f, "loha_linear_bwd(dx)")) return rc;
+  } else if (dx) {  // dx = g @ dW : B operand rows = i, K = o  -> the transposed planes
     GemmArgs ga{};
     ga.A = g; ga.Bh = pl.th; ga.Bl = pl.tl; ga.out = dx; ga.M = M; ga.N = I; ga.K = O;
     ga.lda = O; ga.ldb = pl.ldt; ga.ldo = I; ga.alpha = 1.0f; ga.out_f32 = (dtype & LYC_F32_ROWS) ? 1 : 0;
@@ -629,11 +682,17 @@ int lyc_loha_linear_bwd(const void* g, const void* x, const float* w1a, const fl
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_nt_kernel<T>), gg, dim3(NTHREADS), 0, st, ga));
   }
   if (want_factors) {  // G = g^T x (fp32, [O, I]), then the Hadamard chain rule on the factors
-    GemmArgs ga{};
-    ga.A = g; ga.Bh = x; ga.out = gw; ga.M = O; ga.N = I; ga.K = M;
-    ga.lda = O; ga.ldb = I; ga.ldo = I; ga.alpha = 1.0f; ga.atomic = 0; ga.chunk = M;
-    dim3 gg((unsigned)cdiv(O, 128), (unsigned)cdiv(I, 128), 1);
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_tn_kernel<T>), gg, dim3(NTHREADS), 0, st, ga));
+    if (lib) {
+      if (int rc = rb_gemm(st, true, false, O, I, M, g, O, x, I, gw, I, rb_type(dtype), rocblas_datatype_f32_r, 1.0f, 0.0f,
+                           "loha_linear_bwd(G)"))
+        return rc;
+    } else {
+      GemmArgs ga{};
+      ga.A = g; ga.Bh = x; ga.out = gw; ga.M = O; ga.N = I; ga.K = M;
+      ga.lda = O; ga.ldb = I; ga.ldo = I; ga.alpha = 1.0f; ga.atomic = 0; ga.chunk = M;
+      dim3 gg((unsigned)cdiv(O, 128), (unsigned)cdiv(I, 128), 1);
+      DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_tn_kernel<T>), gg, dim3(NTHREADS), 0, st, ga));
+    }
     LohaArgs la{};
     la.w1a = w1a; la.w1b = w1b; la.w2a = w2a; la.w2b = w2b; la.O = O; la.I = I; la.R = r; la.scale = alpha;
     la.G = gw; la.d_w1a = d_w1a; la.d_w1b = d_w1b; la.d_w2a = d_w2a; la.d_w2b = d_w2b;

@@ -275,26 +275,49 @@ __global__ __launch_bounds__(NTHREADS) void loha_factor_grad_kernel(LohaArgs a) 
     }
     __syncthreads();
     const int q = tid & 63;  // row (o) or column (i) index inside the tile
-    for (int rr = tid >> 6; rr < LOHA_RC; rr += NWAVES) {
-      if (r0 + rr >= a.R) break;
-      float da1 = 0.f, da2 = 0.f, db1 = 0.f, db2 = 0.f;
+    constexpr int NRR = LOHA_RC / NWAVES;
+    float da1[NRR], da2[NRR];
+#pragma unroll
+    for (int k = 0; k < NRR; ++k) {
+      const int rr = (tid >> 6) + NWAVES * k;
+      float a1 = 0.f, a2 = 0.f, db1 = 0.f, db2 = 0.f;
       for (int j = 0; j < LOHA_T; ++j) {
         // d_wXa[o=q, rr] : sum over i=j of T[q][j] * b[rr][j];   d_wXb[rr, i=q] : sum over o=j of a[j][rr] * T[j][q]
-        da1 = fmaf(sT1[q * LT + j], sB1[rr * LOHA_T + j], da1);
-        da2 = fmaf(sT2[q * LT + j], sB2[rr * LOHA_T + j], da2);
+        a1 = fmaf(sT1[q * LT + j], sB1[rr * LOHA_T + j], a1);
+        a2 = fmaf(sT2[q * LT + j], sB2[rr * LOHA_T + j], a2);
         db1 = fmaf(sA1[j * (LOHA_RC + 1) + rr], sT1[j * LT + q], db1);
         db2 = fmaf(sA2[j * (LOHA_RC + 1) + rr], sT2[j * LT + q], db2);
       }
-      if (o0 + q < a.O) {
-        __hip_atomic_fetch_add(a.d_w1a + (o0 + q) * a.R + r0 + rr, da1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(a.d_w2a + (o0 + q) * a.R + r0 + rr, da2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (i0 + q < a.I) {
+      da1[k] = a1;
+      da2[k] = a2;
+      if (r0 + rr < a.R && i0 + q < a.I) {  // lane = q: 64 consecutive floats per atomic instruction
         __hip_atomic_fetch_add(a.d_w1b + (long)(r0 + rr) * a.I + i0 + q, db1, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(a.d_w2b + (long)(r0 + rr) * a.I + i0 + q, db2, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
       }
+    }
+    // The [O, R] gradients are contiguous along rr: with lane = o one atomic instruction touched 64 different cache
+    // lines, and the same-line serialisation of fp32 atomics made this kernel 30 % of the LoHa step.  Transpose the
+    // partial sums through the (now dead) a-factor tiles and issue the atomics with lane = rr: two lines per instruction.
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NRR; ++k) {
+      const int rr = (tid >> 6) + NWAVES * k;
+      sA1[q * (LOHA_RC + 1) + rr] = da1[k];
+      sA2[q * (LOHA_RC + 1) + rr] = da2[k];
+    }
+    __syncthreads();
+    {
+      const int rl = tid & (LOHA_RC - 1), og = tid / LOHA_RC;
+      if (r0 + rl < a.R)
+        for (int o = og; o < LOHA_T; o += NTHREADS / LOHA_RC)
+          if (o0 + o < a.O) {
+            __hip_atomic_fetch_add(a.d_w1a + (o0 + o) * a.R + r0 + rl, sA1[o * (LOHA_RC + 1) + rl], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(a.d_w2a + (o0 + o) * a.R + r0 + rl, sA2[o * (LOHA_RC + 1) + rl], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+          }
     }
   }
 }
