@@ -1,12 +1,13 @@
 // ktrace.cpp -- phase timeline of one workgroup of a kernel (development tool).
 // Built with -DLYC_TRACE so that the LYC_STAMP() points of the kernel headers record the shader clock.
-//   benchmarks/ktrace M I O [fwd|bwd|dw2]
+//   benchmarks/ktrace M I O [fwd|bwd|dw2 | lfwd|lbwd (rank-16 bneck_kernel; KT_NS = column slices, KT_NW = 4|8)]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "../lycoris_amd/csrc/kron3.h"
 #include "../lycoris_amd/csrc/kron_dw2s.h"
+#include "../lycoris_amd/csrc/lowrank.h"
 
 using namespace lyc;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1);} } while (0)
@@ -58,6 +59,47 @@ int main(int argc, char** argv) {
       dim3 grid((unsigned)(((da.tiles_i * da.tiles_j * da.nsplit + 7) / 8) * 8));
       hipLaunchKernelGGL((kron_dw2s_kernel<__bf16, 2, 2, 4, false>), grid, dim3(NTHREADS), 0, 0, da);
       if (rep == 0) printf("grid %u rows/block %ld\n", grid.x, da.rows_per_block);
+    }
+    if (!strcmp(mode, "lfwd") || !strcmp(mode, "lbwd")) {
+      const int r = 16;
+      static float *dn = nullptr, *up = nullptr, *mid = nullptr;
+      if (!dn) { CK(hipMalloc(&dn, (size_t)r * I * 4)); CK(hipMalloc(&up, (size_t)r * O * 4)); CK(hipMalloc(&mid, (size_t)M * r * 4));
+                 CK(hipMemset(dn, 0, (size_t)r * I * 4)); CK(hipMemset(up, 0, (size_t)r * O * 4)); }
+      const bool bw = !strcmp(mode, "lbwd");
+      BneckArgs b{};
+      if (!bw) { b.A = x; b.lda = I; b.K1 = I; b.F1 = dn; b.f1n = I; b.f1k = 1; b.F2 = up; b.f2n = r; b.f2k = 1; b.N2 = O; b.out = y; b.ldo = O; }
+      else { b.A = g; b.lda = O; b.K1 = O; b.F1 = up; b.f1n = 1; b.f1k = r; b.F2 = dn; b.f2n = 1; b.f2k = I; b.N2 = I; b.out = dx; b.ldo = I; }
+      b.M = M; b.R = r; b.mid = mid; b.alpha1 = b.alpha2 = 1.f;
+      const int ns = getenv("KT_NS") ? atoi(getenv("KT_NS")) : 1, nw = getenv("KT_NW") ? atoi(getenv("KT_NW")) : 8;
+      b.nsplit = ns;
+      dim3 grid((unsigned)cdiv(M, 16), (unsigned)ns);
+      if (nw == 8) {
+        if (!bw) hipLaunchKernelGGL((bneck_kernel<__bf16, 8, 1, 1, true, true>), grid, dim3(512), 0, 0, b);
+        else hipLaunchKernelGGL((bneck_kernel<__bf16, 8, 1, 1, false, false>), grid, dim3(512), 0, 0, b);
+      } else {
+        if (!bw) hipLaunchKernelGGL((bneck_kernel<__bf16, 4, 1, 1, true, true>), grid, dim3(256), 0, 0, b);
+        else hipLaunchKernelGGL((bneck_kernel<__bf16, 4, 1, 1, false, false>), grid, dim3(256), 0, 0, b);
+      }
+      if (rep == 0) printf("grid %u x %u, %d waves\n", grid.x, grid.y, nw);
+    }
+    if (!strcmp(mode, "ltn")) {  // both factor gradients (KT_TIME only; KT_CV = 2|4|8, KT_SPLIT = row slabs)
+      const int r = 16;
+      static float *t = nullptr, *dtm = nullptr, *dd = nullptr, *du = nullptr;
+      if (!t) { CK(hipMalloc(&t, (size_t)M * r * 4)); CK(hipMalloc(&dtm, (size_t)M * r * 4)); CK(hipMalloc(&dd, (size_t)r * I * 4)); CK(hipMalloc(&du, (size_t)r * O * 4));
+                CK(hipMemset(t, 0, (size_t)M * r * 4)); CK(hipMemset(dtm, 0, (size_t)M * r * 4)); }
+      const int cv = getenv("KT_CV") ? atoi(getenv("KT_CV")) : 2, split = getenv("KT_SPLIT") ? atoi(getenv("KT_SPLIT")) : 14;
+      LowrankTnArgs a{};
+      a.M = M; a.R = r;
+      a.p[0].act = g; a.p[0].ld = O; a.p[0].C = O; a.p[0].mid = t; a.p[0].out = du; a.p[0].os = r; a.p[0].oj = 1; a.p[0].alpha = 1.f;
+      a.p[1].act = x; a.p[1].ld = I; a.p[1].C = I; a.p[1].mid = dtm; a.p[1].out = dd; a.p[1].os = 1; a.p[1].oj = I; a.p[1].alpha = 1.f;
+      a.p[0].tiles = (int)cdiv(O, 16 * cv); a.p[1].tiles = (int)cdiv(I, 16 * cv);
+      a.rows_per_slab = cdiv(cdiv(M, split), 4) * 4; a.nsplit = (int)cdiv(M, a.rows_per_slab);
+      dim3 grid((unsigned)cdiv((long)(a.p[0].tiles + a.p[1].tiles) * a.nsplit, 4));
+      if (cv == 8) hipLaunchKernelGGL((lowrank_tn_kernel<__bf16, 1, 8>), grid, dim3(256), 0, 0, a);
+      else if (cv == 4) hipLaunchKernelGGL((lowrank_tn_kernel<__bf16, 1, 4>), grid, dim3(256), 0, 0, a);
+      else if (cv == 1) hipLaunchKernelGGL((lowrank_tn_kernel<__bf16, 1, 1>), grid, dim3(256), 0, 0, a);
+      else hipLaunchKernelGGL((lowrank_tn_kernel<__bf16, 1, 2>), grid, dim3(256), 0, 0, a);
+      if (rep == 0) printf("grid %u (cv %d, %d slabs of %ld rows)\n", grid.x, cv, a.nsplit, a.rows_per_slab);
     }
     if (timing) continue;
 #ifdef LYC_TRACE

@@ -12,6 +12,7 @@
 #include "kron3.h"
 #include "kron_dw2s.h"
 #include "lokr_kernels.h"
+#include "lowrank.h"
 #include "skinny_kernels.h"
 
 using namespace lyc;
@@ -257,6 +258,143 @@ void launch_skinny_tn(SkinnyArgs sa, hipStream_t st) {
     default: hipLaunchKernelGGL((skinny_tn_kernel<T, 8>), grid, dim3(NTHREADS), 0, st, sa); break;
   }
 }
+// ------------------------------------------------------------------------------------------------
+// rank-r (LoCon) fast path: lowrank.h
+int lr_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+bool bneck_ok(const BneckArgs& b, int dtype) {
+  const int dt = dtype & 0xff;
+  if (dt != LYC_BF16 && dt != LYC_F16) return false;
+  return b.R >= 1 && b.R <= 64 && (b.K1 % 8) == 0 && (b.lda % 8) == 0 && (reinterpret_cast<uintptr_t>(b.A) & 15u) == 0;
+}
+
+template <typename T, int NW, int MI, int RT>
+void launch_bneck_v(BneckArgs b, bool vec, hipStream_t st) {
+  // few row tiles (M = 1024 gives 64): also split the output columns over gridDim.y so that every CU gets a share of
+  // the expand stage; each slice repeats the reduce stage (its operands come from L2).  Measured best on the SDXL shapes
+  // (benchmarks/kt_lowrank.sh): as many slices as keep the grid within one round of 256 workgroups, at most 8.
+  static const int force_ns = lr_env("LYC_BN_NS", 0);
+  const long rows = cdiv(b.M, 16 * MI);
+  long ns = b.out != nullptr ? 256 / rows : 1;
+  if (ns > cdiv(b.N2, 16 * NW)) ns = cdiv(b.N2, 16 * NW);
+  if (ns > 8) ns = 8;
+  if (ns < 1) ns = 1;
+  if (force_ns) ns = force_ns;
+  b.nsplit = (int)ns;
+  const dim3 grid((unsigned)rows, (unsigned)ns);
+  if (vec)
+    hipLaunchKernelGGL((bneck_kernel<T, NW, MI, RT, true, true>), grid, dim3(NW * 64), 0, st, b);
+  else
+    hipLaunchKernelGGL((bneck_kernel<T, NW, MI, RT, false, false>), grid, dim3(NW * 64), 0, st, b);
+}
+
+template <typename T, int RT>
+void launch_bneck_rt(const BneckArgs& b, hipStream_t st) {
+  static const int force_nw = lr_env("LYC_BN_NW", 0), force_mi = lr_env("LYC_BN_MI", 0);
+  const bool vec = b.f1k == 1 && (b.f1n % 4) == 0 && (reinterpret_cast<uintptr_t>(b.F1) & 15u) == 0 && b.f2k == 1 &&
+                   (b.f2n % 4) == 0 && (b.R % 4) == 0 && (reinterpret_cast<uintptr_t>(b.F2) & 15u) == 0;
+  int mi = b.M >= 8192 ? 2 : 1;
+  if (force_mi) mi = force_mi;
+  int nw = (mi == 1 && b.K1 >= 8192) ? 8 : 4;  // 8 waves only pay when the reduce stage is very long
+  if (force_nw && mi == 1) nw = force_nw;
+  if (mi == 2)
+    launch_bneck_v<T, 4, 2, RT>(b, vec, st);
+  else if (nw == 8)
+    launch_bneck_v<T, 8, 1, RT>(b, vec, st);
+  else
+    launch_bneck_v<T, 4, 1, RT>(b, vec, st);
+}
+
+template <typename T>
+void launch_bneck(const BneckArgs& b, hipStream_t st) {
+  if (b.R <= 16)
+    launch_bneck_rt<T, 1>(b, st);
+  else if (b.R <= 32)
+    launch_bneck_rt<T, 2>(b, st);
+  else
+    launch_bneck_rt<T, 4>(b, st);
+}
+
+void launch_bneck_dt(const BneckArgs& b, int dtype, hipStream_t st) {
+  if ((dtype & 0xff) == LYC_BF16)
+    launch_bneck<__bf16>(b, st);
+  else
+    launch_bneck<_Float16>(b, st);
+}
+
+// largest CV in {8, 4, 2} usable for problem p (0 = none)
+int tn_cv_ok(const LowrankTnProb& p, int cv) {
+  return (p.C % cv) == 0 && (p.ld % cv) == 0 && (reinterpret_cast<uintptr_t>(p.act) % (2 * cv)) == 0;
+}
+
+template <typename T, int RT>
+void launch_tn_rt(LowrankTnArgs& a, int cv, hipStream_t st) {
+  for (int i = 0; i < 2; ++i) a.p[i].tiles = a.p[i].act ? (int)cdiv(a.p[i].C, 16 * cv) : 0;
+  const long waves = (long)(a.p[0].tiles + a.p[1].tiles) * a.nsplit;
+  const dim3 grid((unsigned)cdiv(waves, NWAVES));
+  switch (cv) {
+    case 8: hipLaunchKernelGGL((lowrank_tn_kernel<T, RT, 8>), grid, dim3(NTHREADS), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((lowrank_tn_kernel<T, RT, 4>), grid, dim3(NTHREADS), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((lowrank_tn_kernel<T, RT, 1>), grid, dim3(NTHREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL((lowrank_tn_kernel<T, RT, 2>), grid, dim3(NTHREADS), 0, st, a); break;
+  }
+}
+
+// both factor gradients of a rank-r layer in one launch; false = shapes the fast kernel does not take
+bool launch_lowrank_tn(LowrankTnArgs a, int dtype, hipStream_t st) {
+  static const int atomic_budget = lr_env("LYC_TN_ATOMICS", 800000), wave_target = lr_env("LYC_TN_WAVES", 1400);
+  static const int force_cv = lr_env("LYC_TN_CV", 0), force_split = lr_env("LYC_TN_SPLIT", 0);
+  const int dt = dtype & 0xff;
+  if ((dt != LYC_BF16 && dt != LYC_F16) || a.R > 64) return false;
+  long csum = 0;
+  for (int i = 0; i < 2; ++i)
+    if (a.p[i].act) {
+      if (!tn_cv_ok(a.p[i], 1)) return false;
+      csum += a.p[i].C;
+    }
+  if (csum == 0) return true;
+  // Row slabs: ~160-256 rows per wave measured best (benchmarks/kt_lowrank.sh) -- shorter slabs multiply the atomics,
+  // longer ones leave the wave a long serial chain; bounded by the atomic budget.
+  long split = a.M / 160;
+  const long cap = atomic_budget / ((long)a.R * csum);
+  if (split > cap) split = cap;
+  if (split < 2 && a.M >= 64) split = 2;
+  if (split < 1) split = 1;
+  if (force_split) split = force_split;
+  a.rows_per_slab = round_up(cdiv(a.M, split), 4);
+  a.nsplit = (int)cdiv(a.M, a.rows_per_slab);
+  // columns per lane: 1 (most waves) unless the layer is so wide that 2 still gives thousands of waves
+  int cv = 1;
+  for (int c = 8; c >= 2; c >>= 1) {
+    bool ok = true;
+    long tiles = 0;
+    for (int i = 0; i < 2; ++i)
+      if (a.p[i].act) {
+        ok = ok && tn_cv_ok(a.p[i], c);
+        tiles += cdiv(a.p[i].C, 16 * c);
+      }
+    if (ok && tiles * a.nsplit >= wave_target) {
+      cv = c;
+      break;
+    }
+  }
+  if (force_cv) cv = force_cv;
+  const int rt = a.R <= 16 ? 1 : a.R <= 32 ? 2 : 4;
+  if (dt == LYC_BF16) {
+    if (rt == 1) launch_tn_rt<__bf16, 1>(a, cv, st);
+    else if (rt == 2) launch_tn_rt<__bf16, 2>(a, cv, st);
+    else launch_tn_rt<__bf16, 4>(a, cv, st);
+  } else {
+    if (rt == 1) launch_tn_rt<_Float16, 1>(a, cv, st);
+    else if (rt == 2) launch_tn_rt<_Float16, 2>(a, cv, st);
+    else launch_tn_rt<_Float16, 4>(a, cv, st);
+  }
+  return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -476,6 +614,17 @@ int lyc_locon_linear_fwd(const void* x, const float* down, const float* up, floa
   if (!x || !down || !up || !t || !y) return fail(LYC_ERR_ARG, "locon_linear_fwd: null pointer");
   if (M == 0) return LYC_OK;
   hipStream_t st = (hipStream_t)stream;
+  {  // one launch: t = x down^T (kept for the backward pass), y = alpha * t up^T
+    BneckArgs b{};
+    b.A = x; b.lda = I; b.M = M; b.K1 = I; b.F1 = down; b.f1n = I; b.f1k = 1; b.R = r; b.mid = t;
+    b.F2 = up; b.f2n = r; b.f2k = 1; b.N2 = O; b.out = y; b.ldo = O; b.out_f32 = 0; b.alpha1 = 1.0f; b.alpha2 = alpha;
+    if (bneck_ok(b, dtype)) {
+      launch_bneck_dt(b, dtype, st);
+      return check_launch("locon_linear_fwd");
+    }
+  }
+  // general shapes / fp32 activations: split-K kernels that accumulate into t
+  if (hipMemsetAsync(t, 0, (size_t)M * r * sizeof(float), st) != hipSuccess) return check_launch("locon_linear_fwd(memset)");
   SkinnyArgs s1{};
   s1.A = x; s1.B = down; s1.out = t; s1.M = M; s1.K = I; s1.Nn = r; s1.lda = I;
   s1.bn = I; s1.bk = 1; s1.os = r; s1.oj = 1; s1.alpha = 1.0f;
@@ -495,7 +644,36 @@ int lyc_locon_linear_bwd(const void* g, const void* x, const float* down, const 
   if (d_up && !t) return fail(LYC_ERR_ARG, "locon_linear_bwd: d_up needs t from the forward call");
   if (M == 0) return LYC_OK;
   hipStream_t st = (hipStream_t)stream;
-  {  // dt[m, n] = alpha * sum_o g[m, o] * up[o, n]
+  bool fast_rows = false;
+  {  // one launch: dt = alpha * g up (kept for d_down), dx = dt down
+    BneckArgs b{};
+    b.A = g; b.lda = O; b.M = M; b.K1 = O; b.F1 = up; b.f1n = 1; b.f1k = r; b.R = r; b.mid = dt;
+    b.F2 = down; b.f2n = 1; b.f2k = I; b.N2 = I; b.out = dx; b.ldo = I; b.out_f32 = (dtype & LYC_F32_ROWS) ? 1 : 0;
+    b.alpha1 = alpha; b.alpha2 = 1.0f;
+    if (bneck_ok(b, dtype)) {
+      launch_bneck_dt(b, dtype, st);
+      if (int rc = check_launch("locon_linear_bwd(dx)")) return rc;
+      fast_rows = true;
+    }
+  }
+  if (fast_rows) {  // both factor gradients in one launch
+    LowrankTnArgs ta{};
+    ta.M = M; ta.R = r;
+    int np = 0;
+    if (d_up) {
+      LowrankTnProb& p = ta.p[np++];
+      p.act = g; p.ld = O; p.C = O; p.mid = t; p.out = d_up; p.os = r; p.oj = 1; p.alpha = alpha;
+    }
+    if (d_down) {
+      LowrankTnProb& p = ta.p[np++];
+      p.act = x; p.ld = I; p.C = I; p.mid = dt; p.out = d_down; p.os = 1; p.oj = I; p.alpha = 1.0f;
+    }
+    if (np == 0) return LYC_OK;
+    if (launch_lowrank_tn(ta, dtype, st)) return check_launch("locon_linear_bwd(factor gradients)");
+  } else if (hipMemsetAsync(dt, 0, (size_t)M * r * sizeof(float), st) != hipSuccess) {
+    return check_launch("locon_linear_bwd(memset)");
+  }
+  if (!fast_rows) {  // dt[m, n] = alpha * sum_o g[m, o] * up[o, n]
     SkinnyArgs s{};
     s.A = g; s.B = up; s.out = dt; s.M = M; s.K = O; s.Nn = r; s.lda = O;
     s.bn = 1; s.bk = r; s.os = r; s.oj = 1; s.alpha = alpha;
@@ -507,7 +685,7 @@ int lyc_locon_linear_bwd(const void* g, const void* x, const float* down, const 
     s.bn = 1; s.bk = r; s.os = r; s.oj = 1; s.alpha = alpha;
     DISPATCH_DTYPE(dtype, launch_skinny_tn<T>(s, st));
   }
-  if (dx) {  // dx[m, i] = sum_n dt[m, n] * down[n, i]
+  if (dx && !fast_rows) {  // dx[m, i] = sum_n dt[m, n] * down[n, i]
     SkinnyArgs s{};
     s.A = dt; s.B = down; s.out = dx; s.M = M; s.K = r; s.Nn = I; s.lda = r;
     s.bn = 1; s.bk = I; s.os = I; s.oj = 1; s.alpha = 1.0f; s.out_f32 = (dtype & LYC_F32_ROWS) ? 1 : 0;

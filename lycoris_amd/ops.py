@@ -120,7 +120,7 @@ class _LoconCore:
         r, I = fs[0].shape
         O = fs[1].shape[0]
         M = rows.shape[0]
-        t = torch.zeros((M, r), dtype=torch.float32, device=rows.device)
+        t = torch.empty((M, r), dtype=torch.float32, device=rows.device)  # written by the call
         y = torch.empty((M, O), dtype=rows.dtype, device=rows.device)
         N.call("lyc_locon_linear_fwd", N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(t), N.ptr(y), M, I, O, r,
                alpha, N.dtype_code(rows.dtype), N.stream_ptr(rows.device))
@@ -132,7 +132,7 @@ class _LoconCore:
         O = fs[1].shape[0]
         M = rows.shape[0]
         code = N.dtype_code(rows.dtype) | (F32_ROWS if f32_rows else 0)
-        dt = torch.zeros((M, r), dtype=torch.float32, device=rows.device)
+        dt = torch.empty((M, r), dtype=torch.float32, device=rows.device)  # scratch, written by the call
         dx = torch.empty(rows.shape, dtype=torch.float32 if f32_rows else rows.dtype, device=rows.device) if need_x else None
         dd, du = bufs
         N.call("lyc_locon_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(saved[0]), N.ptr(dt),

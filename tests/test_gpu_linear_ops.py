@@ -61,6 +61,16 @@ LOCON_SHAPES = [  # (M, I, O, r)
     (130, 96, 200, 40),      # rank > 32
     (5, 1280, 320, 136),     # rank > 128 (two skinny tiles)
     (1, 1280, 1280, 8),
+    # fused rank-r path (16-bit, I % 8 == 0 forward / O % 8 == 0 backward, r <= 64) corner cases
+    (300, 1280, 1280, 16),   # SDXL attention projection, ragged last row tile
+    (100, 72, 40, 6),        # rank not a multiple of 4: element-wise factor loads
+    (50, 24, 36, 12),        # forward fused, backward on the general kernels (O % 8 != 0)
+    (33, 40, 50, 8),         # output width not a multiple of 4: scalar stores
+    (70, 40, 24, 20),        # two rank tiles
+    (45, 128, 72, 64),       # four rank tiles
+    (9000, 64, 32, 8),       # 32-row workgroups (M >= 8192), ragged end, many row slabs in the gradient kernel
+    (4100, 64, 64, 16),      # 4-wave workgroups
+    (260, 2560, 640, 32),    # long K, rank 32
 ]
 
 
@@ -84,6 +94,25 @@ def test_locon_linear(shape, dtype):
     errs = {"y": err(y, y_ref, dtype), "dx": err(dx, dx_ref, dtype), "d_down": err(dd, dd_ref), "d_up": err(du, du_ref)}
     bounds = {"y": TOL["store_out"][dtype], "dx": TOL["store_out"][dtype], "d_down": TOL["f32_out"][dtype], "d_up": TOL["f32_out"][dtype]}
     check(f"locon_linear[{shape},{dtype}]", errs, bounds)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_locon_linear_no_input_grad(dtype):
+    """first layer of a network: x does not require grad -> the backward call gets dx = NULL"""
+    from lycoris_amd import ops
+    M, I, O, r = 150, 320, 640, 16
+    gen = torch.Generator().manual_seed(5)
+    x, x64 = rnd((M, I), dtype, gen)
+    g, g64 = rnd((M, O), dtype, gen, 1.0 / np.sqrt(O))
+    down, d64 = rnd((r, I), torch.float32, gen, 0.05)
+    up, u64 = rnd((O, r), torch.float32, gen, 0.05)
+    down.requires_grad_(True); up.requires_grad_(True)
+    y = ops.locon_linear(x, down, up, 0.5)
+    dd, du = torch.autograd.grad(y, [down, up], g)
+    torch.cuda.synchronize()
+    _, dd_ref, du_ref = oracle.locon.backward(x64, g64, d64, u64, 0.5)
+    check("locon_linear[no dx]", {"d_down": err(dd, dd_ref), "d_up": err(du, du_ref)},
+          {"d_down": TOL["f32_out"][dtype], "d_up": TOL["f32_out"][dtype]})
 
 
 CHAN_SHAPES = [((64, 128), -1), ((3, 77, 1280), -1), ((33, 50), -1), ((2, 16, 9, 11), 1), ((4, 320, 16, 16), 1)]
