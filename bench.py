@@ -28,6 +28,7 @@ from benchmarks.sdxl_shapes import algorithmic_bytes, layer_rows, sdxl_unet_laye
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md ("8.0 TB/s spec")
 FACTOR = 8
+ALGO_LABEL = {"lokr": "LoKr factor=8", "locon": "LoCon dim=16 conv_dim=8", "loha": "LoHa dim=32"}
 # HBM bytes per launch of the dominant kernels from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
 # runs, gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md; benchmarks/pmc_summary.py writes the numbers to
 # profiles/): counters cannot be collected inside the timed run, so the committed measurement is quoted here.
@@ -76,7 +77,10 @@ class Layer:
             self.params = [torch.randn(FACTOR, FACTOR, **f32) * 0.3, w2]
         elif algo == "locon":  # dim 16 / conv_dim 8
             r = 16 if not ksz or ksz == (1, 1) else 8
-            self.params = [torch.randn(r, cin, *ksz, **f32) * 0.05, torch.randn(O, r, *([1] * len(ksz)), **f32) * 0.05]
+            down = torch.randn(r, cin, *ksz, **f32) * 0.05
+            if ksz:  # channels_last lora_down: the implicit-GEMM kernels read / write it in place
+                down = down.contiguous(memory_format=torch.channels_last)
+            self.params = [down, torch.randn(O, r, *([1] * len(ksz)), **f32) * 0.05]
         else:  # loha dim 32
             r = 32
             kk = ksz[0] * ksz[1] if ksz else 1
@@ -221,7 +225,7 @@ def main():
     value = world * args.steps / elapsed  # whole-job: every rank processes its own batch (weak scaling)
 
     result = {
-        "metric": "SDXL UNet adapter train steps/sec (bs=1/GPU), LoKr factor=8", "value": round(value, 3),
+        "metric": "SDXL UNet adapter train steps/sec (bs=1/GPU), " + ALGO_LABEL[args.algo], "value": round(value, 3),
         "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",

@@ -31,7 +31,7 @@ enum { LYC_F32 = 0, LYC_F16 = 1, LYC_BF16 = 2 };
 enum { LYC_F32_ROWS = 0x100 };
 enum { LYC_OK = 0, LYC_ERR_ARG = 1, LYC_ERR_UNSUPPORTED = 2, LYC_ERR_LAUNCH = 3 };
 
-#define LYC_ABI_VERSION 2
+#define LYC_ABI_VERSION 3
 int lyc_abi_version(void);
 const char* lyc_last_error(void);
 
@@ -79,13 +79,33 @@ int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1,
  * replaces lycoris/modules/locon.py:309-332 (forward: make_weight + dense F.linear) and the bypass
  * lycoris/functional/locon.py:64-85 / modules/locon.py:286-304.
  *   down:[r,I]  up:[O,r]  x:[M,I]  y:[M,O];   y = alpha * (x @ down^T) @ up^T
- *   t :[M,r] fp32 scratch, zeroed; on return t = x @ down^T (keep it for the backward call)
- *   dt:[M,r] fp32 scratch, zeroed; d_down += , d_up +=                                                 */
+ *   t :[M,r] fp32, written by fwd (t = x @ down^T; keep it for the backward call), no need to clear it
+ *   dt:[M,r] fp32 scratch written by bwd; d_down += , d_up += (caller-zeroed or .grad)
+ * 16-bit activations with I % 8 == 0 (fwd) / O % 8 == 0 (bwd) and r <= 64 run the fused kernels of csrc/lowrank.h:
+ * one launch forward (reduce + expand), two backward (dt/dx, both factor gradients); other shapes and fp32
+ * activations take the general split-K kernels.                                                       */
 int lyc_locon_linear_fwd(const void* x, const float* down, const float* up, float* t, void* y, int64_t M, int I,
                          int O, int r, float alpha, int dtype, void* stream);
 int lyc_locon_linear_bwd(const void* g, const void* x, const float* down, const float* up, const float* t,
                          float* dt, void* dx, float* d_down, float* d_up, int64_t M, int I, int O, int r,
                          float alpha, int dtype, void* stream);
+
+/* LoCon on nn.Conv2d without im2col (reference: lycoris/modules/locon.py:286-332 with F.conv2d -- lora_down is the
+ * kh x kw convolution [r, C, kh, kw], lora_up the 1x1 convolution [O, r, 1, 1]; functional/locon.py:64-85).
+ * x_rows / g_rows / y_rows / dx_rows are NHWC pixel rows ([B*H*W, C] resp. [B*Ho*Wo, O]; a channels_last tensor as is,
+ * lyc_nchw_to_rows otherwise).  down_p is lora_down as [r, kh, kw, C] (a channels_last parameter viewed with
+ * permute(0, 2, 3, 1)), up is [O, r]; d_down_p / d_up have the same layouts and are accumulated ("+=").
+ * t ([B*Ho*Wo, r] fp32) is written by fwd and read by bwd; dt is scratch of the same size.
+ * Taken for 16-bit activations, C % 16 == 0, O % 8 == 0, r in {4, 8, 12, 16} with kh*kw*r <= 144; LYC_ERR_UNSUPPORTED
+ * otherwise (use lyc_im2col + lyc_locon_linear_*).  Three launches in bwd: dt = alpha g up; dx = transposed convolution
+ * of dt (gathered in LDS, no col2im); both factor gradients. */
+int lyc_locon_conv2d_fwd(const void* x_rows, const float* down_p, const float* up, float* t, void* y_rows, int64_t B,
+                         int64_t H, int64_t W, int C, int O, int r, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                         int dw, float alpha, int dtype, void* stream);
+int lyc_locon_conv2d_bwd(const void* g_rows, const void* x_rows, const float* down_p, const float* up, const float* t,
+                         float* dt, void* dx_rows, float* d_down_p, float* d_up, int64_t B, int64_t H, int64_t W, int C,
+                         int O, int r, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float alpha,
+                         int dtype, void* stream);
 
 /* ---- (IA)^3 per-channel scale ------------------------------------------------------------------
  * replaces lycoris/modules/ia3.py:91-102,129-144 (rebuild path).  Tensors are [outer, C, inner]

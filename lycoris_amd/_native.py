@@ -13,7 +13,7 @@ import torch
 
 _LIB_NAME = "liblycoris_amd.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 LYC_F32, LYC_F16, LYC_BF16 = 0, 1, 2
 _DTYPE_CODE = {torch.float32: LYC_F32, torch.float16: LYC_F16, torch.bfloat16: LYC_BF16}
@@ -28,6 +28,8 @@ SIGNATURES = {
     "lyc_lokr_conv2d_bwd": [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_locon_linear_fwd": [_vp, _fp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_locon_linear_bwd": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _fp, _fp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
+    "lyc_locon_conv2d_fwd": [_vp, _fp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 11 + [_f32, _i32, _vp],
+    "lyc_locon_conv2d_bwd": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _fp, _fp, _i64, _i64, _i64] + [_i32] * 11 + [_f32, _i32, _vp],
     "lyc_chan_scale": [_vp, _fp, _fp, _vp, _i64, _i64, _i64, _f32, _f32, _i32, _vp],
     "lyc_chan_reduce": [_vp, _vp, _fp, _fp, _i64, _i64, _i64, _f32, _i32, _vp],
     "lyc_loha_linear_fwd": [_vp, _fp, _fp, _fp, _fp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],

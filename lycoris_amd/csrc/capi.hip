@@ -285,6 +285,12 @@ void launch_bneck_v(BneckArgs b, bool vec, hipStream_t st) {
   if (force_ns) ns = force_ns;
   b.nsplit = (int)ns;
   const dim3 grid((unsigned)rows, (unsigned)ns);
+  if constexpr (RT == 1) {
+    if (b.gat.mode != 0) {  // implicit Conv2d forward (vector factor layouts only; checked by the caller)
+      hipLaunchKernelGGL((bneck_kernel<T, NW, MI, RT, true, true, true>), grid, dim3(NW * 64), 0, st, b);
+      return;
+    }
+  }
   if (vec)
     hipLaunchKernelGGL((bneck_kernel<T, NW, MI, RT, true, true>), grid, dim3(NW * 64), 0, st, b);
   else
@@ -326,7 +332,8 @@ void launch_bneck_dt(const BneckArgs& b, int dtype, hipStream_t st) {
 }
 
 // largest CV in {8, 4, 2} usable for problem p (0 = none)
-int tn_cv_ok(const LowrankTnProb& p, int cv) {
+int tn_cv_ok(const LowrankTnProb& p, int cv, int ct = 0) {
+  if (ct > 0 && (ct % (16 * cv)) != 0) return 0;  // gathered columns: a 16 cv tile must lie inside one tap
   return (p.C % cv) == 0 && (p.ld % cv) == 0 && (reinterpret_cast<uintptr_t>(p.act) % (2 * cv)) == 0;
 }
 
@@ -335,6 +342,17 @@ void launch_tn_rt(LowrankTnArgs& a, int cv, hipStream_t st) {
   for (int i = 0; i < 2; ++i) a.p[i].tiles = a.p[i].act ? (int)cdiv(a.p[i].C, 16 * cv) : 0;
   const long waves = (long)(a.p[0].tiles + a.p[1].tiles) * a.nsplit;
   const dim3 grid((unsigned)cdiv(waves, NWAVES));
+  if constexpr (RT == 1) {
+    if (a.gat.mode != 0) {
+      switch (cv) {
+        case 8: hipLaunchKernelGGL((lowrank_tn_kernel<T, RT, 8, true>), grid, dim3(NTHREADS), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((lowrank_tn_kernel<T, RT, 4, true>), grid, dim3(NTHREADS), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((lowrank_tn_kernel<T, RT, 2, true>), grid, dim3(NTHREADS), 0, st, a); break;
+        default: hipLaunchKernelGGL((lowrank_tn_kernel<T, RT, 1, true>), grid, dim3(NTHREADS), 0, st, a); break;
+      }
+      return;
+    }
+  }
   switch (cv) {
     case 8: hipLaunchKernelGGL((lowrank_tn_kernel<T, RT, 8>), grid, dim3(NTHREADS), 0, st, a); break;
     case 4: hipLaunchKernelGGL((lowrank_tn_kernel<T, RT, 4>), grid, dim3(NTHREADS), 0, st, a); break;
@@ -352,7 +370,7 @@ bool launch_lowrank_tn(LowrankTnArgs a, int dtype, hipStream_t st) {
   long csum = 0;
   for (int i = 0; i < 2; ++i)
     if (a.p[i].act) {
-      if (!tn_cv_ok(a.p[i], 1)) return false;
+      if (!tn_cv_ok(a.p[i], 1, (i == 1 && a.gat.mode) ? a.Ct : 0)) return false;
       csum += a.p[i].C;
     }
   if (csum == 0) return true;
@@ -373,7 +391,7 @@ bool launch_lowrank_tn(LowrankTnArgs a, int dtype, hipStream_t st) {
     long tiles = 0;
     for (int i = 0; i < 2; ++i)
       if (a.p[i].act) {
-        ok = ok && tn_cv_ok(a.p[i], c);
+        ok = ok && tn_cv_ok(a.p[i], c, (i == 1 && a.gat.mode) ? a.Ct : 0);
         tiles += cdiv(a.p[i].C, 16 * c);
       }
     if (ok && tiles * a.nsplit >= wave_target) {
@@ -666,7 +684,7 @@ int lyc_locon_linear_bwd(const void* g, const void* x, const float* down, const 
     }
     if (d_down) {
       LowrankTnProb& p = ta.p[np++];
-      p.act = x; p.ld = I; p.C = I; p.mid = dt; p.out = d_down; p.os = 1; p.oj = I; p.alpha = 1.0f;
+      p.act = x; p.ld = I; p.C = I; p.mid = dt; p.out = d_down; p.os = 1; p.oj = I; p.alpha = 1.0f; p.swap = 1;
     }
     if (np == 0) return LYC_OK;
     if (launch_lowrank_tn(ta, dtype, st)) return check_launch("locon_linear_bwd(factor gradients)");
@@ -698,6 +716,104 @@ int lyc_locon_linear_bwd(const void* g, const void* x, const float* down, const 
     DISPATCH_DTYPE(dtype, launch_skinny_tn<T>(s, st));
   }
   return check_launch("locon_linear_bwd");
+}
+
+// ---- LoCon on Conv2d without im2col (reference: modules/locon.py:286-332 with F.conv2d; lora_down is the kh x kw conv,
+// lora_up the 1x1 conv).  Rows are NHWC pixel rows; down_p is lora_down as [r, kh, kw, C] (a channels_last parameter
+// viewed with permute(0, 2, 3, 1)), up is [O, r].
+extern "C++" {
+namespace {
+int locon_conv_check(ConvDims& cd, int64_t B, int64_t H, int64_t W, int C, int O, int r, int kh, int kw, int sh, int sw,
+                     int ph, int pw, int dh, int dw, int dtype, const void* p0, const void* p1) {
+  if (B < 0 || H < 1 || W < 1 || C < 1 || O < 1 || r < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0 ||
+      dh < 1 || dw < 1)
+    return fail(LYC_ERR_ARG, "locon_conv2d: bad geometry");
+  cd.Ho = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1;
+  cd.Wo = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
+  cd.taps = kh * kw;
+  if (cd.Ho < 1 || cd.Wo < 1) return fail(LYC_ERR_ARG, "locon_conv2d: empty output");
+  const int dt = dtype & 0xff;
+  const bool ok = (dt == LYC_BF16 || dt == LYC_F16) && (C % 16) == 0 && (O % 8) == 0 && (r % 4) == 0 && r <= 16 &&
+                  cd.taps <= 64 && cd.taps * r <= 16 * GEXP_KT && (reinterpret_cast<uintptr_t>(p0) & 15u) == 0 &&
+                  (reinterpret_cast<uintptr_t>(p1) & 15u) == 0 && H * W < (1 << 30) && cd.Ho * cd.Wo < (1 << 30);
+  if (!ok)
+    return fail(LYC_ERR_UNSUPPORTED,
+                "locon_conv2d: the implicit-GEMM path needs 16-bit activations, C %% 16 == 0, O %% 8 == 0, rank in {4, 8, 12, "
+                "16} with kh * kw * rank <= 144 and 16-byte aligned rows; use the im2col lowering (lyc_im2col + "
+                "lyc_locon_linear_*) otherwise");
+  return LYC_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int lyc_locon_conv2d_fwd(const void* x_rows, const float* down_p, const float* up, float* t, void* y_rows, int64_t B,
+                         int64_t H, int64_t W, int C, int O, int r, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                         int dw, float alpha, int dtype, void* stream) {
+  if (!x_rows || !down_p || !up || !t || !y_rows) return fail(LYC_ERR_ARG, "locon_conv2d_fwd: null pointer");
+  ConvDims cd{};
+  if (int rc = locon_conv_check(cd, B, H, W, C, O, r, kh, kw, sh, sw, ph, pw, dh, dw, dtype, x_rows, y_rows)) return rc;
+  if (B == 0) return LYC_OK;
+  if ((reinterpret_cast<uintptr_t>(down_p) & 15u) || (reinterpret_cast<uintptr_t>(up) & 15u))
+    return fail(LYC_ERR_ARG, "locon_conv2d_fwd: factors must be 16-byte aligned");
+  BneckArgs b{};
+  b.A = x_rows; b.lda = C; b.M = B * cd.Ho * cd.Wo; b.K1 = cd.taps * C; b.F1 = down_p; b.f1n = (long)cd.taps * C; b.f1k = 1;
+  b.R = r; b.mid = t; b.F2 = up; b.f2n = r; b.f2k = 1; b.N2 = O; b.out = y_rows; b.ldo = O; b.alpha1 = 1.0f; b.alpha2 = alpha;
+  b.gat = make_gather(1, cd, H, W, kw, sh, sw, ph, pw, dh, dw, 0); b.Ck = C;
+  launch_bneck_dt(b, dtype, (hipStream_t)stream);
+  return check_launch("locon_conv2d_fwd");
+}
+
+int lyc_locon_conv2d_bwd(const void* g_rows, const void* x_rows, const float* down_p, const float* up, const float* t,
+                         float* dt, void* dx_rows, float* d_down_p, float* d_up, int64_t B, int64_t H, int64_t W, int C,
+                         int O, int r, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float alpha,
+                         int dtype, void* stream) {
+  if (!g_rows || !x_rows || !down_p || !up || !dt) return fail(LYC_ERR_ARG, "locon_conv2d_bwd: null pointer");
+  if (d_up && !t) return fail(LYC_ERR_ARG, "locon_conv2d_bwd: d_up needs t from the forward call");
+  ConvDims cd{};
+  if (int rc = locon_conv_check(cd, B, H, W, C, O, r, kh, kw, sh, sw, ph, pw, dh, dw, dtype, x_rows, g_rows)) return rc;
+  if (B == 0) return LYC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const long Mo = B * cd.Ho * cd.Wo, Mi = B * H * W;
+  {  // dt[p_out, n] = alpha * sum_o g[p_out, o] * up[o, n]   (reduce stage only)
+    BneckArgs b{};
+    b.A = g_rows; b.lda = O; b.M = Mo; b.K1 = O; b.F1 = up; b.f1n = 1; b.f1k = r; b.R = r; b.mid = dt;
+    b.F2 = up; b.f2n = 1; b.f2k = 1; b.N2 = 0; b.out = nullptr; b.alpha1 = alpha; b.alpha2 = 1.0f;
+    launch_bneck_dt(b, dtype, st);
+    if (int rc = check_launch("locon_conv2d_bwd(dt)")) return rc;
+  }
+  if (dx_rows) {  // transposed convolution of dt with lora_down
+    GexpArgs ga{};
+    ga.mid = dt; ga.F2 = down_p; ga.out = dx_rows; ga.M = Mi; ga.R = r; ga.C = C;
+    ga.gat = make_gather(2, cd, H, W, kw, sh, sw, ph, pw, dh, dw, 0);
+    const long rows = cdiv(Mi, 16);
+    long ns = 256 / rows;
+    if (ns > cdiv(C, 64)) ns = cdiv(C, 64);
+    if (ns > 8) ns = 8;
+    if (ns < 1) ns = 1;
+    const dim3 grid((unsigned)rows, (unsigned)ns);
+    if ((dtype & 0xff) == LYC_BF16)
+      hipLaunchKernelGGL((gexp_kernel<__bf16, 4>), grid, dim3(256), 0, st, ga);
+    else
+      hipLaunchKernelGGL((gexp_kernel<_Float16, 4>), grid, dim3(256), 0, st, ga);
+    if (int rc = check_launch("locon_conv2d_bwd(dx)")) return rc;
+  }
+  if (d_up || d_down_p) {
+    LowrankTnArgs ta{};
+    ta.M = Mo; ta.R = r;
+    if (d_up) {
+      LowrankTnProb& p = ta.p[0];
+      p.act = g_rows; p.ld = O; p.C = O; p.mid = t; p.out = d_up; p.os = r; p.oj = 1; p.alpha = alpha;
+    }
+    if (d_down_p) {  // d_down_p[n, (tap, c)] += sum_p dt[p, n] * x[src(p, tap), c]
+      LowrankTnProb& p = ta.p[1];
+      p.act = x_rows; p.ld = C; p.C = cd.taps * C; p.mid = dt; p.out = d_down_p; p.os = 1; p.oj = (long)cd.taps * C;
+      p.alpha = 1.0f; p.swap = 1;
+      ta.gat = make_gather(1, cd, H, W, kw, sh, sw, ph, pw, dh, dw, 0); ta.Ct = C;
+    }
+    if (!launch_lowrank_tn(ta, dtype, st)) return fail(LYC_ERR_UNSUPPORTED, "locon_conv2d_bwd: factor-gradient shapes");
+    return check_launch("locon_conv2d_bwd(factor gradients)");
+  }
+  return LYC_OK;
 }
 
 int lyc_chan_scale(const void* in, const float* w, const float* bias, void* out, int64_t outer, int64_t C,

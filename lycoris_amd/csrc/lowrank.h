@@ -58,6 +58,11 @@ struct BneckArgs {
   int out_f32;
   float alpha1, alpha2;
   int nsplit;       // gridDim.y: each y slice repeats stage 1 and expands its share of the N2 column tiles
+  // implicit Conv2d forward (GAT kernels): A holds the NHWC pixel rows [B * Hs * Ws, Ck]; the K1 = taps * Ck flat index
+  // is (tap, channel); the A row of output pixel m and tap t is the source pixel given by gat (mode 1), zero outside
+  // the image.  Ck % 16 == 0 (a lane's 16 K elements never straddle taps).
+  KronGather gat;
+  int Ck;
 };
 
 // hi/lo split of 8 consecutive fp32 (two float4) into two 16-bit x 8 MFMA fragments
@@ -91,7 +96,7 @@ __host__ __device__ constexpr int bneck_lds_bytes() {
 // NW waves per workgroup, MI 16-row tiles per workgroup, RT 16-wide rank tiles (R <= 16 RT).
 // F1V: F1 rows are K-contiguous and 16-byte aligned (forward: down[r, I]); otherwise element-wise loads with the given
 // strides (backward: up^T -- 16 lanes walk the contiguous rank index).  F2V likewise for F2 along k (forward: up[O, r]).
-template <typename T, int NW, int MI, int RT, bool F1V, bool F2V>
+template <typename T, int NW, int MI, int RT, bool F1V, bool F2V, bool GAT = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void bneck_kernel(BneckArgs a) {
   constexpr int D = RT == 4 ? 2 : 3;  // stage-1 steps in flight per wave (register budget)
   constexpr int D2 = RT == 1 ? 8 : RT == 2 ? 4 : 2;  // stage-2 column tiles in flight per wave
@@ -112,11 +117,41 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 
   // ---------------- stage 1: acc[mi][rt] = sum_k A[m, k] * F1[n, k] over this wave's k-steps ----------------
   const T* arow[MI];
+  unsigned long long tmask[MI];  // GAT: taps of this lane's pixel that fall inside the image
+  __shared__ int lr_tapoff[GAT ? 64 : 1];  // GAT: source-row offset of tap t relative to tap 0
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     long r = m0 + 16 * mi + li;
     if (r >= a.M) r = a.M - 1;  // rows past the end only feed accumulator rows that are never stored
-    arow[mi] = A + r * a.lda;
+    if constexpr (!GAT) {
+      arow[mi] = A + r * a.lda;
+      tmask[mi] = 0ull;
+    } else {
+      const int hw = a.gat.Hd * a.gat.Wd;
+      const int pb = (int)(r / hw);
+      const int rem = (int)(r - (long)pb * hw);
+      const int ho = rem / a.gat.Wd, wo = rem - ho * a.gat.Wd;
+      const int h0 = ho * a.gat.sh - a.gat.ph, w0 = wo * a.gat.sw - a.gat.pw;
+      const int kh = a.gat.taps / a.gat.kw;
+      unsigned long long wm = 0ull, m = 0ull;
+      for (int j = 0; j < a.gat.kw; ++j) {
+        const int ws = w0 + j * a.gat.dw;
+        if (ws >= 0 && ws < a.gat.Ws) wm |= 1ull << j;
+      }
+      for (int i = 0; i < kh; ++i) {
+        const int hs = h0 + i * a.gat.dh;
+        if (hs >= 0 && hs < a.gat.Hs) m |= wm << (i * a.gat.kw);
+      }
+      tmask[mi] = m;
+      arow[mi] = A + (((long)pb * a.gat.Hs + h0) * a.gat.Ws + w0) * a.Ck;  // tap 0's pixel (may lie outside: masked)
+    }
+  }
+  if constexpr (GAT) {
+    if (tid < a.gat.taps) {
+      const int i = tid / a.gat.kw, j = tid - i * a.gat.kw;
+      lr_tapoff[tid] = i * a.gat.dh * a.gat.Ws + j * a.gat.dw;
+    }
+    __syncthreads();
   }
   const float* frow[RT];
   bool fok[RT];
@@ -129,20 +164,31 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
   struct Step {
     u32x4 av[MI][2];
     f32x4 fv[RT][4];
-    bool k0ok, k1ok;
+    bool k0ok[MI], k1ok[MI];
   };
-  // Loads are unconditional from clamped (valid) addresses; the k >= K1 mask is applied to A in compute_step, one ring
-  // round later (a select next to the load would make the compiler wait for the load right there).  F1 needs no k mask:
-  // where k >= K1 the A fragment is zero and the clamped F1 data is ordinary factor data.
+  // Loads are unconditional from clamped (valid) addresses; the k >= K1 (and, GAT, outside-the-image) mask is applied to
+  // A in compute_step, one ring round later (a select next to the load would make the compiler wait for the load right
+  // there).  F1 needs no k mask: where k >= K1 the A fragment is zero and the clamped F1 data is ordinary factor data.
   auto load_step = [&](Step& S, int s) {
     const int kk = s * 64 + 16 * g;  // this lane: k = kk .. kk + 15
-    const bool k0ok = kk < K1, k1ok = kk + 8 < K1;  // K1 % 8 == 0: a 16-byte piece is all in or all out
-    S.k0ok = k0ok;
-    S.k1ok = k1ok;
+    const bool k0in = kk < K1, k1in = kk + 8 < K1;  // K1 % 8 == 0: a 16-byte piece is all in or all out
+    int tap = 0, ck = kk;
+    long toff = 0;
+    if constexpr (GAT) {
+      tap = k0in ? kk / a.Ck : 0;  // Ck % 16 == 0: both pieces lie in one tap
+      ck = kk - tap * a.Ck;
+      toff = (long)lr_tapoff[tap] * a.Ck + ck;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      S.av[mi][0] = *reinterpret_cast<const u32x4*>(arow[mi] + (k0ok ? kk : 0));
-      S.av[mi][1] = *reinterpret_cast<const u32x4*>(arow[mi] + (k1ok ? kk + 8 : 0));
+      bool v = true;
+      if constexpr (GAT) v = (tmask[mi] >> tap) & 1ull;
+      const bool o0 = k0in && v, o1 = k1in && v;
+      S.k0ok[mi] = o0;
+      S.k1ok[mi] = o1;
+      const T* p = GAT ? arow[mi] + toff : arow[mi] + kk;
+      S.av[mi][0] = *reinterpret_cast<const u32x4*>(o0 ? p : A);
+      S.av[mi][1] = *reinterpret_cast<const u32x4*>(o1 ? p + 8 : A);
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -185,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const u32x4 zu = {0u, 0u, 0u, 0u};
-        const u32x4 m0v = S.k0ok ? S.av[mi][0] : zu, m1v = S.k1ok ? S.av[mi][1] : zu;
+        const u32x4 m0v = S.k0ok[mi] ? S.av[mi][0] : zu, m1v = S.k1ok[mi] ? S.av[mi][1] : zu;
         const F8 a0 = *reinterpret_cast<const F8*>(&m0v);
         const F8 a1 = *reinterpret_cast<const F8*>(&m1v);
         acc[mi][rt] = TT<T>::mma(a0, bh0, acc[mi][rt]);
@@ -350,6 +396,8 @@ struct LowrankTnProb {
   long os, oj;
   float alpha;
   int tiles;         // ceil(C / (16 CV))
+  int swap;          // 1: the output is contiguous along c (os == 1): compute the transposed tile so that the 16 lanes of
+                     //    an atomic instruction walk c instead of n (4 cache lines per instruction instead of 64)
 };
 
 struct LowrankTnArgs {
@@ -358,6 +406,11 @@ struct LowrankTnArgs {
   int R;
   int nsplit;          // row slabs
   long rows_per_slab;  // multiple of 4
+  // implicit Conv2d (GAT kernels), problem p[1] only: its act holds the NHWC input pixel rows [B * Hs * Ws, Ct], its C
+  // columns are the flat (tap, channel) index (C = taps * Ct, Ct % (16 CV) == 0) and the Act row of output pixel m and tap
+  // t is the source pixel given by gat (mode 1), zero outside the image
+  KronGather gat;
+  int Ct;
 };
 
 template <typename T, int CV>
@@ -372,7 +425,7 @@ template <typename T>
 struct LrVec<T, 1> { typedef uint16_t type; };
 
 // One wave per (column tile of 16 CV, row slab).  CV in {1, 2, 4, 8} columns per lane (C % CV == 0, ld % CV == 0, aligned).
-template <typename T, int RT, int CV>
+template <typename T, int RT, int CV, bool GAT = false>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 4))) void lowrank_tn_kernel(LowrankTnArgs a) {
   constexpr int D = CV * RT <= 4 ? 16 : 8;  // 4-row steps in flight
   using V = typename LrVec<T, CV>::type;
@@ -392,7 +445,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 4))
   float* out = second ? a.p[1].out : a.p[0].out;
   const long os = second ? a.p[1].os : a.p[0].os, oj = second ? a.p[1].oj : a.p[0].oj;
   const float alpha = second ? a.p[1].alpha : a.p[0].alpha;
+  const bool swap = (second ? a.p[1].swap : a.p[0].swap) != 0;
   const int R = a.R;
+  const bool gat = GAT && second;
 
   const long rbeg = (long)slab * a.rows_per_slab;
   long rend = rbeg + a.rows_per_slab;
@@ -401,7 +456,24 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 4))
   const int c0 = tile * 16 * CV;
   const int cl = c0 + CV * li;        // this lane's first column
   const bool cok = cl < C;            // C % CV == 0: all CV columns in or out
-  const T* abase = act + (cok ? cl : 0);
+  // GAT: the tile lies inside one tap; the lane walks the output pixels of its slab and keeps (image, h, w) of the pixel
+  // of its NEXT load incrementally (load_step is called with r increasing by 4 each time)
+  int tap_i = 0, tap_j = 0, gb = 0, gh = 0, gw = 0;
+  const T* abase;
+  if (gat) {
+    const int tap = c0 / a.Ct;
+    tap_i = tap / a.gat.kw;
+    tap_j = tap - tap_i * a.gat.kw;
+    abase = act + (cok ? cl - tap * a.Ct : 0);
+    const long m = rbeg + g;
+    const int hw = a.gat.Hd * a.gat.Wd;
+    gb = (int)(m / hw);
+    const int rem = (int)(m - (long)gb * hw);
+    gh = rem / a.gat.Wd;
+    gw = rem - gh * a.gat.Wd;
+  } else {
+    abase = act + (cok ? cl : 0);
+  }
   bool nok[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) nok[rt] = 16 * rt + li < R;
@@ -417,9 +489,24 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 4))
   // that are never stored.
   auto load_step = [&](Step& S, long r) {  // rows r .. r + 3, this lane: row r + g
     long m = r + g;
-    S.ok = m < rend && cok;
+    bool ok = m < rend && cok;
     if (m >= rend) m = rbeg;
-    S.av = *reinterpret_cast<const V*>(abase + m * ld);
+    long arow = m;
+    if (GAT && gat) {
+      const int hs = gh * a.gat.sh - a.gat.ph + tap_i * a.gat.dh, ws = gw * a.gat.sw - a.gat.pw + tap_j * a.gat.dw;
+      ok = ok && hs >= 0 && hs < a.gat.Hs && ws >= 0 && ws < a.gat.Ws;
+      arow = ok ? ((long)gb * a.gat.Hs + hs) * a.gat.Ws + ws : 0;
+      gw += 4;  // the pixel of the next call
+      while (gw >= a.gat.Wd) {
+        gw -= a.gat.Wd;
+        if (++gh >= a.gat.Hd) {
+          gh = 0;
+          ++gb;
+        }
+      }
+    }
+    S.ok = ok;
+    S.av = *reinterpret_cast<const V*>(abase + arow * ld);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) S.mv[rt] = mid[m * R + (nok[rt] ? 16 * rt + li : 0)];
   };
@@ -437,7 +524,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 4))
     for (int j = 0; j < CV; ++j) {
       const float af = S.ok ? TT<T>::to_f(e[j]) : 0.f;
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, S.mv[rt], acc[j][rt], 0, 0, 0);
+      for (int rt = 0; rt < RT; ++rt) {
+        const float mv = S.mv[rt];
+        acc[j][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(swap ? mv : af, swap ? af : mv, acc[j][rt], 0, 0, 0);
+      }
     }
   };
   {
@@ -457,17 +547,17 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 4))
       }
     }
   }
-  // accumulator element (j, rt)[q]: column c = c0 + CV * (4 g + q) + j, rank index n = 16 rt + li
+  // accumulator element (j, rt)[q]: column c = c0 + CV * (4 g + q) + j, rank index n = 16 rt + li;
+  // swapped:                           column c = c0 + CV * li + j,          rank index n = 16 rt + 4 g + q
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const int n = 16 * rt + li;
-    if (n >= R) continue;
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int j = 0; j < CV; ++j) {
-        const int c = c0 + CV * (4 * g + q) + j;
-        if (c >= C) continue;
+        const int n = 16 * rt + (swap ? 4 * g + q : li);
+        const int c = c0 + CV * (swap ? li : 4 * g + q) + j;
+        if (n >= R || c >= C) continue;
         float* o = out + (long)c * os + (long)n * oj;
         const float v = acc[j][rt][q] * alpha;
         if (a.nsplit == 1)
@@ -475,6 +565,130 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 4))
         else
           __hip_atomic_fetch_add(o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Input gradient of the implicit Conv2d rank-r layer ("gather, then expand"):
+//   dx[p, c] = sum_{tap, n} dt[src(p, tap), n] * down[n, tap, c]          p = input pixel, src = output pixel (gat mode 2)
+// A workgroup owns 16 input pixels: it gathers their taps * R intermediate values into LDS (hi / lo planes, zero where
+// the tap falls outside the output or between its strides) and then runs the expand stage of bneck_kernel over the C
+// output channels with K = taps * R (<= 144) -- no col2im, no atomics.
+struct GexpArgs {
+  const float* mid;  // dt [B * Hs * Ws, R] (source = OUTPUT pixels)
+  const float* F2;   // down as [R][taps][C]: element (n, tap, c) at (n * taps + tap) * C + c
+  void* out;         // dx rows [M, C] (destination = INPUT pixels), T
+  long M;
+  int R, C;
+  KronGather gat;    // mode 2
+};
+
+constexpr int GEXP_KT = 9;           // k tiles of 16: taps * R <= 144
+constexpr int GEXP_KP = 16 * GEXP_KT + 8;  // LDS row pitch (elements): 8-byte fragments, rows 304 bytes apart
+
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gexp_kernel(GexpArgs a) {
+  constexpr int D2 = 2;
+  __shared__ __attribute__((aligned(16))) T midh[16 * GEXP_KP];
+  __shared__ __attribute__((aligned(16))) T midl[16 * GEXP_KP];
+  using F4 = typename Mma16<T>::frag;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long m0 = (long)blockIdx.x * 16;
+  const int R = a.R, C = a.C, taps = a.gat.taps;
+  const int K2 = taps * R, KT = (K2 + 15) >> 4;  // R % 4 == 0
+
+  // gather: piece (m, tap, q) = 4 consecutive rank values of one tap of one pixel
+  for (int idx = tid; idx < 16 * GEXP_KT * 4; idx += NW * 64) {
+    const int m = idx / (GEXP_KT * 4), kq = idx - m * (GEXP_KT * 4);  // k = 4 kq
+    const int tap = (4 * kq) / R, nn = 4 * kq - tap * R;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const long pix = m0 + m;
+    if (4 * kq < K2 && pix < a.M) {
+      const int hw = a.gat.Hd * a.gat.Wd;
+      const int pb = (int)(pix / hw);
+      const int rem = (int)(pix - (long)pb * hw);
+      const int h = rem / a.gat.Wd, w = rem - h * a.gat.Wd;
+      const int i = tap / a.gat.kw, j = tap - i * a.gat.kw;
+      const int hn = h + a.gat.ph - i * a.gat.dh, wn = w + a.gat.pw - j * a.gat.dw;
+      const int hs = hn / a.gat.sh, ws = wn / a.gat.sw;
+      if (hn >= 0 && wn >= 0 && hs * a.gat.sh == hn && ws * a.gat.sw == wn && hs < a.gat.Hs && ws < a.gat.Ws)
+        v = *reinterpret_cast<const f32x4*>(a.mid + (((long)pb * a.gat.Hs + hs) * a.gat.Ws + ws) * R + nn);
+    }
+    T h4[4] __attribute__((aligned(8))), l4[4] __attribute__((aligned(8)));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_f<T>(v[e], h4[e], l4[e]);
+    *reinterpret_cast<u32x2*>(midh + m * GEXP_KP + 4 * kq) = *reinterpret_cast<const u32x2*>(h4);
+    *reinterpret_cast<u32x2*>(midl + m * GEXP_KP + 4 * kq) = *reinterpret_cast<const u32x2*>(l4);
+  }
+  __syncthreads();
+
+  F4 bh[GEXP_KT], bl[GEXP_KT];  // B operand: lane (pixel li, k = 16 kt + 4 g .. + 3)
+  long koff[GEXP_KT];           // F2 offset of this lane's first k of tile kt (its 4 k share one tap: R % 4 == 0)
+#pragma unroll
+  for (int kt = 0; kt < GEXP_KT; ++kt) {
+    bh[kt] = *reinterpret_cast<const F4*>(midh + li * GEXP_KP + 16 * kt + 4 * g);
+    bl[kt] = *reinterpret_cast<const F4*>(midl + li * GEXP_KP + 16 * kt + 4 * g);
+    const int k = 16 * kt + 4 * g;
+    const int tap = k < K2 ? k / R : 0, nn = k < K2 ? k - tap * R : 0;  // k >= K2: mid is zero there, any valid address
+    koff[kt] = ((long)nn * taps + tap) * C;
+  }
+  const long estride = (long)taps * C;  // next rank index
+  const int ntiles_all = (C + 15) >> 4;
+  const int tper = (ntiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int tbeg = (int)blockIdx.y * tper;
+  const int ntiles = tbeg + tper < ntiles_all ? tbeg + tper : ntiles_all;
+  auto load_f2 = [&](f32x4 (&fr)[GEXP_KT], int tile) {
+    const int n = 16 * tile + li;
+    const float* p = a.F2 + ((tile < ntiles && n < C) ? n : 0);
+#pragma unroll
+    for (int kt = 0; kt < GEXP_KT; ++kt)
+      if (kt < KT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fr[kt][e] = p[koff[kt] + (16 * kt + 4 * g + e < K2 ? e : 0) * estride];
+      }
+  };
+  const bool vec = (C & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7u) == 0;
+  auto do_tile = [&](f32x4 (&fr)[GEXP_KT], int tile) {
+    f32x4 y = zero4();
+#pragma unroll
+    for (int kt = 0; kt < GEXP_KT; ++kt)
+      if (kt < KT) {
+        LR_USE(fr[kt]);
+        F4 ah, al;
+        lr_split4<T>(fr[kt], ah, al);
+        y = Mma16<T>::mma(ah, bh[kt], y);
+        y = Mma16<T>::mma(al, bh[kt], y);
+        y = Mma16<T>::mma(ah, bl[kt], y);
+      }
+    const long m = m0 + li;
+    const int n = 16 * tile + 4 * g;
+    const bool ok = tile < ntiles && m < a.M;
+    T v[4] __attribute__((aligned(8)));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = TT<T>::from_f(y[e]);
+    T* o = static_cast<T*>(a.out) + m * C + n;
+    if (vec && n + 4 <= C) {
+      if (ok) *reinterpret_cast<u32x2*>(o) = *reinterpret_cast<const u32x2*>(v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (ok && n + e < C) o[e] = v[e];
+    }
+  };
+  f32x4 fr[D2][GEXP_KT];
+#pragma unroll
+  for (int j = 0; j < D2; ++j) {
+    load_f2(fr[j], tbeg + wave + j * NW);
+    LR_LOAD_FENCE();
+  }
+  for (int tile = tbeg + wave; tile < ntiles; tile += D2 * NW) {
+#pragma unroll
+    for (int j = 0; j < D2; ++j) {
+      do_tile(fr[j], tile + j * NW);
+      LR_LOAD_FENCE();
+      load_f2(fr[j], tile + (j + D2) * NW);
+      LR_LOAD_FENCE();
+    }
   }
 }
 

@@ -389,6 +389,82 @@ class _LokrConv2dImplicit(torch.autograd.Function):
         return None, None, dx, gw1, gw2
 
 
+def _locon_conv_implicit_ok(x, down, up):
+    r, C = down.shape[0], down.shape[1]
+    taps = down.shape[2] * down.shape[3]
+    return (x.dtype in (torch.bfloat16, torch.float16) and C % 16 == 0 and up.shape[0] % 8 == 0 and r % 4 == 0 and r <= 16
+            and taps <= 64 and taps * r <= 144 and x.shape[2] * x.shape[3] < (1 << 30))
+
+
+def _cl_grad_target(p, need, shape_p):
+    """Gradient buffer for a 4-D parameter whose kernels work on the permute(0, 2, 3, 1) (window-major) layout:
+    p.grad itself when it is fp32 and lives in that layout (channels_last), else a fresh zero buffer to hand back."""
+    if not need:
+        return None, False
+    gr = p.grad if (_ACCUM["enabled"] and p.is_leaf) else None
+    if (gr is not None and gr.dtype == torch.float32 and gr.device == p.device and gr.permute(0, 2, 3, 1).is_contiguous()):
+        return gr.permute(0, 2, 3, 1), False
+    return torch.zeros(shape_p, dtype=torch.float32, device=p.device), True
+
+
+class _LoconConv2dImplicit(torch.autograd.Function):
+    """LoCon on nn.Conv2d without materialising im2col / col2im: lyc_locon_conv2d_fwd / _bwd (include/lycoris_amd.h).
+    down is the reference's lora_down.weight [r, C, kh, kw] (the kernels read it as [r, kh, kw, C]: a free view of a
+    channels_last parameter, one small copy otherwise), up is lora_up.weight [O, r, 1, 1]."""
+
+    @staticmethod
+    def forward(ctx, alpha, geom, x, down, up):
+        N.require_device(x, "input")
+        k, s, p, d_ = geom
+        B, C, H, W = x.shape
+        r, O = down.shape[0], up.shape[0]
+        if C != down.shape[1]:
+            raise ValueError(f"adapter expects {down.shape[1]} input channels, got {tuple(x.shape)}")
+        rows, copied = _rows_view(x)
+        down_p = _f32c(down.detach().permute(0, 2, 3, 1))
+        up2 = _f32c(up.detach().reshape(O, r))
+        Ho, Wo = _conv_out(H, W, k, s, p, d_)
+        t = torch.empty((B * Ho * Wo, r), dtype=torch.float32, device=x.device)
+        y_rows = torch.empty((B * Ho * Wo, O), dtype=x.dtype, device=x.device)
+        N.call("lyc_locon_conv2d_fwd", N.ptr(rows), N.ptr(down_p), N.ptr(up2), N.ptr(t), N.ptr(y_rows), B, H, W, C, O, r,
+               k[0], k[1], s[0], s[1], p[0], p[1], d_[0], d_[1], float(alpha), N.dtype_code(x.dtype), N.stream_ptr(x.device))
+        ctx.save_for_backward(rows, down, up, t)
+        ctx.meta = (float(alpha), geom, x.shape, (Ho, Wo), not copied)
+        if not copied:  # channels_last in -> channels_last out
+            return y_rows.view(B, Ho, Wo, O).permute(0, 3, 1, 2)
+        return _from_rows(y_rows, B, (Ho, Wo))
+
+    @staticmethod
+    def backward(ctx, g):
+        alpha, geom, xshape, (Ho, Wo), x_cl = ctx.meta
+        rows, down, up, t = ctx.saved_tensors
+        k, s, p, d_ = geom
+        B, C, H, W = xshape
+        r, O = down.shape[0], up.shape[0]
+        g_rows, _ = _rows_view(g)
+        need_x, need_d, need_u = ctx.needs_input_grad[2], ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        down_p = _f32c(down.detach().permute(0, 2, 3, 1))
+        up2 = _f32c(up.detach().reshape(O, r))
+        dt = torch.empty((B * Ho * Wo, r), dtype=torch.float32, device=rows.device)
+        dx_rows = torch.empty((B * H * W, C), dtype=rows.dtype, device=rows.device) if need_x else None
+        ddp, hbd = _cl_grad_target(down, need_d, (r, k[0], k[1], C))
+        (du,), hbu = _grad_targets([up], [need_u])
+        N.call("lyc_locon_conv2d_bwd", N.ptr(g_rows), N.ptr(rows), N.ptr(down_p), N.ptr(up2), N.ptr(t), N.ptr(dt),
+               N.ptr(dx_rows), N.ptr(ddp), N.ptr(du), B, H, W, C, O, r, k[0], k[1], s[0], s[1], p[0], p[1], d_[0], d_[1],
+               alpha, N.dtype_code(rows.dtype), N.stream_ptr(rows.device))
+        dx = None
+        if need_x:
+            dx = dx_rows.view(B, H, W, C).permute(0, 3, 1, 2) if x_cl else _from_rows(dx_rows, B, (H, W))
+        gd = None
+        if need_d:
+            if hbd:
+                gd = ddp.permute(0, 3, 1, 2).to(down.dtype)
+            elif _ACCUM["callback"] is not None:
+                _ACCUM["callback"](down)
+        gu = _finish_grads([up], [du], hbu)[0]
+        return None, None, dx, gd, gu
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # (IA)^3 per-channel affine
 # ---------------------------------------------------------------------------------------------------------------
@@ -476,8 +552,10 @@ def _geom(ksize, stride, padding, dilation):
 def locon_conv2d(x, down, up, alpha, stride, padding, dilation):
     """down:[r, I, kh, kw]  up:[O, r, 1, 1]"""
     r, O = down.shape[0], up.shape[0]
-    return _AdapterConv2d.apply(_LoconCore, alpha, _geom(down.shape[2:], stride, padding, dilation), x,
-                                down.reshape(r, -1), up.reshape(O, r))
+    geom = _geom(down.shape[2:], stride, padding, dilation)
+    if x.dim() == 4 and not _is_pointwise(geom) and _locon_conv_implicit_ok(x, down, up):
+        return _LoconConv2dImplicit.apply(alpha, geom, x, down, up)
+    return _AdapterConv2d.apply(_LoconCore, alpha, geom, x, down.reshape(r, -1), up.reshape(O, r))
 
 
 def loha_conv2d(x, w1a, w1b, w2a, w2b, alpha, shape, stride, padding, dilation):

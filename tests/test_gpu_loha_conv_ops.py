@@ -146,6 +146,49 @@ def test_lokr_conv2d_implicit(shape, dtype, layout):
     check(f"lokr_conv2d_implicit[{shape},{dtype},{layout}]", errs, bounds)
 
 
+# shapes that take the implicit-GEMM LoCon path (C % 16 == 0, O % 8 == 0, rank in {4, 8, 12, 16}): (..., rank)
+LOCON_IMPLICIT_SHAPES = [
+    (2, 32, 12, 12, 64, 3, 1, 1, 1, 8),     # 3x3 same
+    (1, 64, 9, 11, 32, 3, 2, 1, 1, 4),      # stride 2, odd spatial size
+    (1, 32, 10, 9, 32, 3, 1, 2, 2, 8),      # dilation 2
+    (2, 48, 8, 8, 128, 3, 1, 1, 1, 16),     # rank 16: K = 144 in the input-gradient kernel
+    (1, 32, 7, 7, 40, 5, 1, 2, 1, 4),       # 5x5 window (25 taps), output width not a multiple of 16
+    (1, 128, 6, 5, 64, 3, 1, 0, 1, 12),     # no padding, rank 12
+    (3, 320, 9, 9, 320, 3, 1, 1, 1, 8),     # SDXL resnet channels at a small spatial size
+    (1, 64, 5, 5, 64, 3, 2, 0, 1, 8),       # stride 2 without padding
+    (1, 16, 40, 37, 24, 3, 1, 1, 1, 8),     # many pixels: several row slabs in the gradient kernel
+]
+
+
+@pytest.mark.parametrize("layout", ["contiguous", "channels_last"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", LOCON_IMPLICIT_SHAPES, ids=[str(s) for s in LOCON_IMPLICIT_SHAPES])
+def test_locon_conv2d_implicit(shape, dtype, layout):
+    """The im2col-free LoCon path: gathered reduce stage, LDS-gathered transposed convolution for dx, gathered factor
+    gradient; lora_down in [r, kh, kw, C] order."""
+    from lycoris_amd import ops
+    B, C, H, W, O, k, s, p, d, r = shape
+    gen = torch.Generator().manual_seed(sum(shape) + 11)
+    x, x64 = rnd((B, C, H, W), dtype, gen)
+    down, d64 = rnd((r, C, k, k), torch.float32, gen, 0.1)
+    up, u64 = rnd((O, r, 1, 1), torch.float32, gen, 0.1)
+    assert ops._locon_conv_implicit_ok(x, down, up)
+    if layout == "channels_last":
+        x = x.contiguous(memory_format=torch.channels_last)
+        down = down.contiguous(memory_format=torch.channels_last)
+    y_ref = oracle.locon.forward(x64, d64, u64, 1.25, _ca(s, p, d))
+    g, g64 = rnd(y_ref.shape, dtype, gen, 1.0 / np.sqrt(O))
+    for t in (x, down, up):
+        t.requires_grad_(True)
+    y = ops.locon_conv2d(x, down, up, 1.25, (s, s), (p, p), (d, d))
+    dx, dd, du = torch.autograd.grad(y, [x, down, up], g)
+    torch.cuda.synchronize()
+    dx_r, dd_r, du_r = oracle.locon.backward(x64, g64, d64, u64, 1.25, _ca(s, p, d))
+    errs = {"y": err(y, y_ref, dtype), "dx": err(dx, dx_r, dtype), "d_down": err(dd, dd_r), "d_up": err(du, du_r)}
+    bounds = {"y": TOL["store_out"][dtype], "dx": TOL["store_out"][dtype], "d_down": TOL["f32_out"][dtype], "d_up": TOL["f32_out"][dtype]}
+    check(f"locon_conv2d_implicit[{shape},{dtype},{layout}]", errs, bounds)
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("shape", CONV_SHAPES[:3], ids=[str(s) for s in CONV_SHAPES[:3]])
 def test_loha_conv2d(shape, dtype):
