@@ -141,7 +141,7 @@ int dw2s_env(const char* name, int dflt) {
 template <typename T>
 void launch_dw2s(KronDw2sArgs da, hipStream_t st) {
   static const int target_blocks = dw2s_env("LYC_DW2_BLOCKS", 512);       // development overrides
-  static const int atomic_budget = dw2s_env("LYC_DW2_ATOMICS", 620000);   // fp32 atomics per launch (~0.3 / ns)
+  static const int atomic_budget = dw2s_env("LYC_DW2_ATOMICS", 620000);   // fp32 atomics per launch (~300 / ns)
   static const int force_big = dw2s_env("LYC_DW2_BIG", -1);
   const long rows_total = da.M * da.G;
   auto plan = [&](int mi, int nj, long& tiles, long& split) {

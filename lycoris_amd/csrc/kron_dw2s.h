@@ -3,7 +3,7 @@
 //   dW2[i, j] += alpha * sum_{r = (m, s)} Q[r, i] * Z[r, j],     Z[(m, s), j] = sum_t W[s, t] * P[(m, t), j]
 //
 // A "TN" GEMM whose K dimension is the M * G flat rows (thousands) and whose output is the small w2 matrix.  Measured
-// on MI355X (benchmarks/atomic_bench.cpp): fp32 atomics retire at ~0.3 elements/ns chip-wide, so the old design (big
+// on MI355X (benchmarks/atomic_bench.cpp): fp32 atomics retire at ~300 elements/ns chip-wide (whole lines; fewer when scattered), so the old design (big
 // output tiles x ~100 row slabs = millions of atomics) spent 3/4 of its time in the atomic units.  This version:
 //   * small output tiles (16 MI x 16 NJ) and FEW row slabs: the split factor is chosen by the host so that the atomic
 //     traffic stays below ~0.4 M elements per launch; with one slab the tile is added with plain loads/stores;
