@@ -11,6 +11,7 @@
 #include "ia3_kernels.h"
 #include "kron3.h"
 #include "kron_dw2s.h"
+#include "loha_mfma.h"
 #include "lokr_kernels.h"
 #include "lowrank.h"
 #include "skinny_kernels.h"
@@ -930,7 +931,12 @@ int lyc_loha_linear_fwd(const void* x, const float* w1a, const float* w1b, const
   la.w1a = w1a; la.w1b = w1b; la.w2a = w2a; la.w2b = w2b; la.O = O; la.I = I; la.R = r; la.scale = alpha;
   la.Wn_h = pl.nh; la.Wn_l = pl.nl; la.Wt_h = pl.th; la.Wt_l = pl.tl; la.ldn = pl.ldn; la.ldt = pl.ldt;
   dim3 rg((unsigned)cdiv(O, LOHA_T), (unsigned)cdiv(I, LOHA_T));
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((loha_rebuild_kernel<T>), rg, dim3(NTHREADS), 0, st, la));
+  switch (dtype & 0xff) {  // the transposed planes are only read by the fp32-activation GEMM kernels
+    case LYC_BF16: hipLaunchKernelGGL((loha_rebuild_mfma_kernel<__bf16, false>), rg, dim3(NTHREADS), 0, st, la); break;
+    case LYC_F16: hipLaunchKernelGGL((loha_rebuild_mfma_kernel<_Float16, false>), rg, dim3(NTHREADS), 0, st, la); break;
+    case LYC_F32: hipLaunchKernelGGL((loha_rebuild_mfma_kernel<float, true>), rg, dim3(NTHREADS), 0, st, la); break;
+    default: return fail(LYC_ERR_ARG, "unknown dtype %d", dtype);
+  }
   if (int rc = check_launch("loha_linear_fwd(rebuild)")) return rc;
   if (M > 0 && (dtype & 0xff) != LYC_F32) {
     // y = x (Wh + Wl)^T: the lo plane first (its result is ~2^-9 of y, so rounding it to T costs ~2^-18 relative), then
@@ -990,8 +996,26 @@ int lyc_loha_linear_bwd(const void* g, const void* x, const float* w1a, const fl
     LohaArgs la{};
     la.w1a = w1a; la.w1b = w1b; la.w2a = w2a; la.w2b = w2b; la.O = O; la.I = I; la.R = r; la.scale = alpha;
     la.G = gw; la.d_w1a = d_w1a; la.d_w1b = d_w1b; la.d_w2a = d_w2a; la.d_w2b = d_w2b;
-    dim3 fg((unsigned)cdiv(O, LOHA_T), (unsigned)cdiv(I, LOHA_T));
-    hipLaunchKernelGGL(loha_factor_grad_kernel, fg, dim3(NTHREADS), 0, st, la);
+    // NO x nt tiles per workgroup (fewer atomics: the a-side gradients stay in registers over nt column tiles, the
+    // b-side over NO row tiles) as long as ~512 workgroups remain; ranks > 32 go tile by tile, chunk by chunk
+    const long tiles_o = cdiv(O, LOHA_T), tiles_j = cdiv(I, LOHA_T);
+    static const int lh_wgs = lr_env("LYC_LOHA_WGS", 512);
+    long per = (tiles_o * tiles_j) / lh_wgs;
+    int no = 1;
+    LohaGradGeom gm{1};
+    if (r <= LOHA_RC && per >= 2) {
+      no = per >= 8 ? 4 : 2;
+      if (no > tiles_o) no = tiles_o >= 2 ? 2 : 1;
+      gm.nt = (int)(per / no);
+      if (gm.nt < 1) gm.nt = 1;
+      if (gm.nt > tiles_j) gm.nt = (int)tiles_j;
+    }
+    dim3 fg((unsigned)cdiv(tiles_o, no), (unsigned)cdiv(tiles_j, gm.nt));
+    switch (no) {
+      case 4: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<4>), fg, dim3(NTHREADS), 0, st, la, gm); break;
+      case 2: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<2>), fg, dim3(NTHREADS), 0, st, la, gm); break;
+      default: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<1>), fg, dim3(NTHREADS), 0, st, la, gm); break;
+    }
   }
   return check_launch("loha_linear_bwd");
 }

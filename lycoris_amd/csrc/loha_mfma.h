@@ -1,0 +1,269 @@
+// loha_mfma.h -- the LoHa-specific kernels on the fp32 matrix core, gfx950.
+//
+// Reference: HadaWeight.forward / backward (lycoris/functional/loha.py:10-30):
+//   dW = (w1a w1b) * (w2a w2b) * s                                                      (rebuild)
+//   T1 = s G * (w2a w2b), T2 = s G * (w1a w1b)        G = g^T x, fp32 [O, I]
+//   d_w1a += T1 w1b^T, d_w1b += w1a^T T1, d_w2a += T2 w2b^T, d_w2b += w2a^T T2                  (factor gradients)
+// All of it is rank-r x 64 x 64 products on fp32 data.  v_mfma_f32_16x16x4_f32 takes one fp32 value per lane for
+// (row, k) / (k, column): exact products, no hi/lo split, operands read from row-major LDS tiles as they are.  The
+// first version of these kernels did the products on the VALU out of LDS (LDS-issue bound, ~36 k cycles per 64x64 tile);
+// here a tile costs 192 MFMAs per wave (~6 k cycles).  What is left is the fp32 atomics of the factor gradients (they
+// are paid per touched cache line, see lowrank.h): a workgroup therefore owns NO x NT tiles -- the w*a gradients of its
+// rows accumulate in registers over the NT column tiles, the w*b gradients of a column tile over the NO row tiles -- and
+// every wave emits whole 64-byte runs.
+#pragma once
+#include "dense_kernels.h"
+
+namespace lyc {
+
+constexpr int LH_AP = LOHA_RC + 1;  // pitch of the a-factor tiles [64 o][32 r]
+constexpr int LH_BP = LOHA_T + 4;   // pitch of the b-factor tiles [32 r][64 i]
+constexpr int LH_TP = LOHA_T + 4;   // pitch of the T tiles [64 o][64 i]
+
+__device__ __forceinline__ float lh_mma(float a, float b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  return 0.f;
+}
+
+// a-factor rows o0 .. o0+63, rank chunk r0 .. r0+31 -> [64][LH_AP]   (zero outside)
+__device__ __forceinline__ void lh_stage_a(const LohaArgs& a, long o0, int r0, float* sA1, float* sA2) {
+  for (int e = threadIdx.x; e < LOHA_T * LOHA_RC; e += NTHREADS) {
+    const int o = e / LOHA_RC, rr = e % LOHA_RC;
+    const bool ok = (o0 + o < a.O) && (r0 + rr < a.R);
+    const long idx = ok ? (o0 + o) * a.R + r0 + rr : 0;
+    const float v1 = a.w1a[idx], v2 = a.w2a[idx];
+    sA1[o * LH_AP + rr] = ok ? v1 : 0.f;
+    sA2[o * LH_AP + rr] = ok ? v2 : 0.f;
+  }
+}
+// b-factor columns i0 .. i0+63, rank chunk -> [32][LH_BP]
+__device__ __forceinline__ void lh_stage_b(const LohaArgs& a, long i0, int r0, float* sB1, float* sB2) {
+  for (int e = threadIdx.x; e < LOHA_RC * LOHA_T; e += NTHREADS) {
+    const int rb = e / LOHA_T, i = e % LOHA_T;
+    const bool ok = (r0 + rb < a.R) && (i0 + i < a.I);
+    const long idx = ok ? (long)(r0 + rb) * a.I + i0 + i : 0;
+    const float v1 = a.w1b[idx], v2 = a.w2b[idx];
+    sB1[rb * LH_BP + i] = ok ? v1 : 0.f;
+    sB2[rb * LH_BP + i] = ok ? v2 : 0.f;
+  }
+}
+
+// dW hi/lo planes.  Computed transposed (A = b-factor^T, B = a-factor^T) so that a lane ends up with 4 consecutive i of
+// one row o: 8-byte stores of the K-contiguous planes.  WT: also write the transposed planes (fp32-activation path).
+template <typename T, bool WT>
+__global__ __launch_bounds__(NTHREADS) void loha_rebuild_mfma_kernel(LohaArgs a) {
+  __shared__ __attribute__((aligned(16))) float sm[2 * LOHA_T * LH_AP + 2 * LOHA_RC * LH_BP];
+  float* sA1 = sm;
+  float* sA2 = sA1 + LOHA_T * LH_AP;
+  float* sB1 = sA2 + LOHA_T * LH_AP;
+  float* sB2 = sB1 + LOHA_RC * LH_BP;
+  const long o0 = (long)blockIdx.x * LOHA_T, i0 = (long)blockIdx.y * LOHA_T;
+  const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+  f32x4 p1[4], p2[4];  // [ti]: rows i = 16 ti + 4 g + q, column o = 16 wave + li
+#pragma unroll
+  for (int t = 0; t < 4; ++t) p1[t] = p2[t] = zero4();
+  for (int r0 = 0; r0 < a.R; r0 += LOHA_RC) {
+    if (r0) __syncthreads();
+    lh_stage_a(a, o0, r0, sA1, sA2);
+    lh_stage_b(a, i0, r0, sB1, sB2);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < LOHA_RC / 4; ++ks) {
+      const float b1 = sA1[(16 * wave + li) * LH_AP + 4 * ks + g], b2 = sA2[(16 * wave + li) * LH_AP + 4 * ks + g];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        lh_mma(sB1[(4 * ks + g) * LH_BP + 16 * t + li], b1, p1[t]);
+        lh_mma(sB2[(4 * ks + g) * LH_BP + 16 * t + li], b2, p2[t]);
+      }
+    }
+  }
+  T* nh = static_cast<T*>(a.Wn_h);
+  T* nl = static_cast<T*>(a.Wn_l);
+  const long o = o0 + 16 * wave + li;
+  const bool vec = (a.ldn % 4) == 0 && (reinterpret_cast<uintptr_t>(nh) & 7u) == 0 &&
+                   (!TT<T>::SPLIT || (reinterpret_cast<uintptr_t>(nl) & 7u) == 0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const long i = i0 + 16 * t + 4 * g;
+    T hi[4] __attribute__((aligned(16))), lo[4] __attribute__((aligned(16)));
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q] = p1[t][q] * p2[t][q] * a.scale;
+      split_f<T>(v[q], hi[q], lo[q]);
+    }
+    if (o < a.O && i < a.I) {
+      bool done = false;
+      if constexpr (sizeof(T) == 2) {
+        if (vec && i + 4 <= a.I) {
+          *reinterpret_cast<u32x2*>(nh + o * a.ldn + i) = *reinterpret_cast<const u32x2*>(hi);
+          *reinterpret_cast<u32x2*>(nl + o * a.ldn + i) = *reinterpret_cast<const u32x2*>(lo);
+          done = true;
+        }
+      }
+      if (!done) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (i + q < a.I) {
+            nh[o * a.ldn + i + q] = hi[q];
+            if constexpr (TT<T>::SPLIT) nl[o * a.ldn + i + q] = lo[q];
+          }
+      }
+      if constexpr (WT) {
+        T* th = static_cast<T*>(a.Wt_h);
+        T* tl = static_cast<T*>(a.Wt_l);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (i + q < a.I) {
+            th[(i + q) * a.ldt + o] = hi[q];
+            if constexpr (TT<T>::SPLIT) tl[(i + q) * a.ldt + o] = lo[q];
+          }
+      }
+    }
+  }
+}
+
+struct LohaGradGeom {
+  int nt;  // column tiles per workgroup (runtime); row tiles per workgroup = template NO
+};
+
+// One workgroup: row tiles ob*NO .. +NO-1, column tiles jb*nt .. +nt-1 (R <= 32: a single rank chunk stays resident;
+// larger ranks run with NO = nt = 1 and loop over the chunks).
+template <int NO>
+__global__ __launch_bounds__(NTHREADS) void loha_factor_grad_mfma_kernel(LohaArgs a, LohaGradGeom gm) {
+  __shared__ __attribute__((aligned(16))) float sm[2 * LOHA_T * LH_AP + 2 * LOHA_RC * LH_BP + 2 * LOHA_T * LH_TP];
+  float* sA1 = sm;
+  float* sA2 = sA1 + LOHA_T * LH_AP;
+  float* sB1 = sA2 + LOHA_T * LH_AP;
+  float* sB2 = sB1 + LOHA_RC * LH_BP;
+  float* sT1 = sB2 + LOHA_RC * LH_BP;
+  float* sT2 = sT1 + LOHA_T * LH_TP;
+  const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+  const long ob = (long)blockIdx.x * NO;  // first row tile
+  const long jb = (long)blockIdx.y * gm.nt;
+  const long tiles_j = (a.I + LOHA_T - 1) / LOHA_T;
+  const int nchunk = (a.R + LOHA_RC - 1) / LOHA_RC;
+
+  f32x4 da1[NO][2], da2[NO][2];  // d_w*a of row tile os: rows o = 16 wave + 4 g + q, column r = 16 rt + li
+#pragma unroll
+  for (int os = 0; os < NO; ++os)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) da1[os][rt] = da2[os][rt] = zero4();
+
+  auto emit_a = [&](int os, int r0) {
+    const long o = (ob + os) * LOHA_T + 16 * wave + 4 * g;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = r0 + 16 * rt + li;
+        if (o + q < a.O && r < a.R) {
+          __hip_atomic_fetch_add(a.d_w1a + (o + q) * a.R + r, da1[os][rt][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(a.d_w2a + (o + q) * a.R + r, da2[os][rt][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        da1[os][rt][q] = 0.f;
+        da2[os][rt][q] = 0.f;
+      }
+  };
+
+  for (long jt = jb; jt < jb + gm.nt && jt < tiles_j; ++jt) {
+    const long i0 = jt * LOHA_T;
+    f32x4 db1[2], db2[2];  // d_w*b of this column tile: rows r = 16 rt + 4 g + q, column i = 16 wave + li
+#pragma unroll
+    for (int os = 0; os < NO; ++os) {
+      const long o0 = (ob + os) * LOHA_T;
+      if (o0 >= a.O) break;
+      // ---- products over all rank chunks: wave rows o = 16 wave + 4 g + q, columns i = 16 c + li
+      f32x4 p1[4], p2[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) p1[c] = p2[c] = zero4();
+      for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();  // previous users of the factor tiles / T tiles are done
+        lh_stage_a(a, o0, ch * LOHA_RC, sA1, sA2);
+        lh_stage_b(a, i0, ch * LOHA_RC, sB1, sB2);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < LOHA_RC / 4; ++ks) {
+          const float a1 = sA1[(16 * wave + li) * LH_AP + 4 * ks + g], a2 = sA2[(16 * wave + li) * LH_AP + 4 * ks + g];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            lh_mma(a1, sB1[(4 * ks + g) * LH_BP + 16 * c + li], p1[c]);
+            lh_mma(a2, sB2[(4 * ks + g) * LH_BP + 16 * c + li], p2[c]);
+          }
+        }
+      }
+      // ---- T1 = s G * P2, T2 = s G * P1 -> LDS [o][i]
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ol = 16 * wave + 4 * g + q, il = 16 * c + li;
+          const bool ok = (o0 + ol < a.O) && (i0 + il < a.I);
+          const float gv = a.G[ok ? (o0 + ol) * a.I + i0 + il : 0];
+          const float gs = ok ? gv * a.scale : 0.f;
+          sT1[ol * LH_TP + il] = gs * p2[c][q];
+          sT2[ol * LH_TP + il] = gs * p1[c][q];
+        }
+      // ---- contractions, one rank chunk at a time (the last staged chunk is still resident)
+      for (int ch = nchunk - 1; ch >= 0; --ch) {
+        if (ch != nchunk - 1) {
+          __syncthreads();
+          lh_stage_a(a, o0, ch * LOHA_RC, sA1, sA2);
+          lh_stage_b(a, i0, ch * LOHA_RC, sB1, sB2);
+        }
+        __syncthreads();  // T tiles (and re-staged factors) visible
+        if (os == 0 || nchunk > 1) {
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) db1[rt] = db2[rt] = zero4();
+        }
+#pragma unroll 4
+        for (int ks = 0; ks < LOHA_T / 4; ++ks) {
+          // d_w*a[o, r] += sum_i T[o, i] b[r, i]:  A = T (row o = 16 wave + li, k = i), B = b^T (k = i, column r)
+          const float t1 = sT1[(16 * wave + li) * LH_TP + 4 * ks + g], t2 = sT2[(16 * wave + li) * LH_TP + 4 * ks + g];
+          // d_w*b[r, i] += sum_o a[o, r] T[o, i]:  A = a^T (row r, k = o), B = T (k = o, column i = 16 wave + li)
+          const float u1 = sT1[(4 * ks + g) * LH_TP + 16 * wave + li], u2 = sT2[(4 * ks + g) * LH_TP + 16 * wave + li];
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            lh_mma(t1, sB1[(16 * rt + li) * LH_BP + 4 * ks + g], da1[os][rt]);
+            lh_mma(t2, sB2[(16 * rt + li) * LH_BP + 4 * ks + g], da2[os][rt]);
+            lh_mma(sA1[(4 * ks + g) * LH_AP + 16 * rt + li], u1, db1[rt]);
+            lh_mma(sA2[(4 * ks + g) * LH_AP + 16 * rt + li], u2, db2[rt]);
+          }
+        }
+        if (nchunk > 1) {  // several chunks: nothing can stay in registers, emit per chunk (NO == nt == 1 here)
+          emit_a(os, ch * LOHA_RC);
+          const long i = i0 + 16 * wave + li;
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int r = ch * LOHA_RC + 16 * rt + 4 * g + q;
+              if (r < a.R && i < a.I) {
+                __hip_atomic_fetch_add(a.d_w1b + (long)r * a.I + i, db1[rt][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(a.d_w2b + (long)r * a.I + i, db2[rt][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+        }
+      }
+    }
+    if (nchunk == 1) {  // d_w*b of this column tile, summed over the NO row tiles
+      const long i = i0 + 16 * wave + li;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 16 * rt + 4 * g + q;
+          if (r < a.R && i < a.I) {
+            __hip_atomic_fetch_add(a.d_w1b + (long)r * a.I + i, db1[rt][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(a.d_w2b + (long)r * a.I + i, db2[rt][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+    }
+  }
+  if (nchunk == 1) {
+#pragma unroll
+    for (int os = 0; os < NO; ++os) emit_a(os, 0);
+  }
+}
+
+}  // namespace lyc

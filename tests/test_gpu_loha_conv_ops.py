@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
 DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 IDS = ["f32", "bf16", "f16"]
 
-LOHA_SHAPES = [(64, 64, 128, 8), (200, 320, 640, 32), (77, 200, 72, 5), (33, 50, 70, 40), (1, 128, 128, 4)]
+LOHA_SHAPES = [(64, 64, 128, 8), (200, 320, 640, 32), (77, 200, 72, 5), (33, 50, 70, 40), (1, 128, 128, 4),
+               (48, 2560, 2048, 16),   # 1280 tiles: 2 row tiles per workgroup in the factor-gradient kernel
+               (40, 4160, 4096, 8)]    # 4160 tiles: 4 x 2 tiles per workgroup, ragged last column group
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
