@@ -247,6 +247,82 @@ def main():
         dist.destroy_process_group()
 
 
+def _timed_graph(issue, dev):
+    """ms per replay of a hipGraph holding the launches `issue(stream_ptr)` makes; HIP events on the launch stream"""
+    from lycoris_amd import _native as N
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        sp = N.stream_ptr(dev)
+        issue(sp)  # eager warm-up
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph, stream=st):
+            issue(sp)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps, best = 5, float("inf")
+        gph.replay()
+        for _ in range(3):
+            e0.record(st)
+            for _ in range(reps):
+                gph.replay()
+            e1.record(st)
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) / reps)
+    return best
+
+
+def roofline_locon(protos, dtype, dev):
+    """LoCon: the three launches per adapted Linear layer (`bneck_kernel` forward, `bneck_kernel` backward-dx,
+    `lowrank_tn_kernel` factor gradients), timed as two hipGraphs (all forward launches, all backward launches) with
+    HIP events.  Algorithmic bytes: fwd x + y + t, bwd g + dx + dt, gradients g + x + t + dt, fp32 factors."""
+    from lycoris_amd import _native as N
+    esz = torch.empty((), dtype=dtype).element_size()
+    code = N.dtype_code(dtype)
+    calls, nbytes, n_layers = [], 0, 0
+    for proto, count in protos:
+        s = proto.spec
+        if s["kind"] != "linear":
+            continue
+        M, I, O = layer_rows(s)
+        down = proto.params[0].detach().contiguous()
+        up = proto.params[1].detach().contiguous()
+        r = down.shape[0]
+        rows = proto.x.detach().reshape(-1, I)
+        g = torch.randn(M, O, device=dev, dtype=dtype)
+        y = torch.empty(M, O, device=dev, dtype=dtype)
+        dx = torch.empty(M, I, device=dev, dtype=dtype)
+        t = torch.empty(M, r, device=dev, dtype=torch.float32)
+        dt = torch.empty(M, r, device=dev, dtype=torch.float32)
+        dd, du = torch.zeros_like(down), torch.zeros_like(up)
+        calls.append((count, rows, g, y, dx, down, up, t, dt, dd, du, (M, I, O, r)))
+        fac = 4 * r * (I + O)
+        nbytes += count * (esz * (M * I + M * O) + 4 * M * r + fac)            # forward
+        nbytes += count * (esz * (M * O + M * I) + 4 * M * r + fac)            # backward dx
+        nbytes += count * (esz * (M * O + M * I) + 8 * M * r + 2 * fac)        # factor gradients
+        n_layers += count
+
+    def fwd(sp):
+        for count, rows, g, y, dx, down, up, t, dt, dd, du, (M, I, O, r) in calls:
+            for _ in range(count):
+                N.call("lyc_locon_linear_fwd", N.ptr(rows), N.ptr(down), N.ptr(up), N.ptr(t), N.ptr(y), M, I, O, r, 1.0, code, sp)
+
+    def bwd(sp):
+        for count, rows, g, y, dx, down, up, t, dt, dd, du, (M, I, O, r) in calls:
+            for _ in range(count):
+                N.call("lyc_locon_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(down), N.ptr(up), N.ptr(t), N.ptr(dt), N.ptr(dx),
+                       N.ptr(dd), N.ptr(du), M, I, O, r, 1.0, code, sp)
+
+    t_fwd, t_bwd = _timed_graph(fwd, dev), _timed_graph(bwd, dev)
+    t_ms, n_launch = t_fwd + t_bwd, 3 * n_layers
+    achieved = nbytes / (t_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "lyc::bneck_kernel (forward, backward-dx) + lyc::lowrank_tn_kernel (factor gradients): the "
+                                      "three LoCon launches of the 739 Linear layers",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None, "launches_per_step": n_launch, "avg_launch_us": round(t_ms * 1e3 / n_launch, 2),
+            "algorithmic_bytes_per_launch": int(nbytes / n_launch),
+            "families_ms": {"forward": round(t_fwd, 3), "backward": round(t_bwd, 3)}}
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def roofline(protos, algo, dtype, dev):
     """Roofline of the dominant kernel family of the step, measured live with HIP events on the launch stream.
@@ -261,6 +337,8 @@ def roofline(protos, algo, dtype, dev):
     algorithmic bytes of its launches / its time (activations moved once: fwd x + y, bwd-dx g + x + dx,
     dW2 g + x, plus the fp32 factors)."""
     from lycoris_amd import _native as N
+    if algo == "locon":
+        return roofline_locon(protos, dtype, dev)
     if algo != "lokr":
         return None
     esz = torch.empty((), dtype=dtype).element_size()
