@@ -292,6 +292,13 @@ void launch_bneck_v(BneckArgs b, bool vec, hipStream_t st) {
       return;
     }
   }
+  if constexpr (NW == 4 && RT <= 2 && MI * RT <= 2) {  // coalesced operand loads through the per-wave LDS stage (<= 64 KiB)
+    static const int use_stg = lr_env("LYC_BN_STG", 1);
+    if (vec && use_stg) {
+      hipLaunchKernelGGL((bneck_kernel<T, NW, MI, RT, true, true, false, true>), grid, dim3(NW * 64), 0, st, b);
+      return;
+    }
+  }
   if (vec)
     hipLaunchKernelGGL((bneck_kernel<T, NW, MI, RT, true, true>), grid, dim3(NW * 64), 0, st, b);
   else

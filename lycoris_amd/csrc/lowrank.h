@@ -88,22 +88,30 @@ __device__ __forceinline__ void lr_split4(const f32x4& v, typename Mma16<T>::fra
   lo = *reinterpret_cast<const typename Mma16<T>::frag*>(l);
 }
 
-template <int NW, int MI, int RT>
+// staged stage 1: K elements per wave chunk (128 for the smallest tile, 64 otherwise: static LDS <= 64 KiB), LDS row
+// pitch = chunk + 16 elements (8 mod 16 dwords: conflict-free ds_read_b128 fragments)
+__host__ __device__ constexpr int bneck_kc(int MI, int RT) { return (16 * MI + 32 * RT <= 48) ? 128 : 64; }
+template <int NW, int MI, int RT, bool STG = false>
 __host__ __device__ constexpr int bneck_lds_bytes() {
-  return NW * MI * RT * 256 * 4 + 16 * MI * (16 * RT + 4) * 4;
+  return NW * MI * RT * 256 * 4 + 16 * MI * (16 * RT + 4) * 4 +
+         (STG ? NW * (16 * MI + 32 * RT) * (bneck_kc(MI, RT) + 16) * 2 : 0);
 }
 
 // NW waves per workgroup, MI 16-row tiles per workgroup, RT 16-wide rank tiles (R <= 16 RT).
 // F1V: F1 rows are K-contiguous and 16-byte aligned (forward: down[r, I]); otherwise element-wise loads with the given
 // strides (backward: up^T -- 16 lanes walk the contiguous rank index).  F2V likewise for F2 along k (forward: up[O, r]).
-template <typename T, int NW, int MI, int RT, bool F1V, bool F2V, bool GAT = false>
+// STG (needs F1V, not with GAT): stage 1 through a per-wave LDS stage with COALESCED global loads -- fragment-direct loads
+// give each lane of a quad a different cache line and cost the address unit ~64 cycles per wave instruction instead of 16.
+template <typename T, int NW, int MI, int RT, bool F1V, bool F2V, bool GAT = false, bool STG = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void bneck_kernel(BneckArgs a) {
+  static_assert(!STG || (F1V && !GAT), "staged stage 1: vector factor layout, no gather");
   constexpr int D = RT == 4 ? 2 : 3;  // stage-1 steps in flight per wave (register budget)
   constexpr int D2 = RT == 1 ? 8 : RT == 2 ? 4 : 2;  // stage-2 column tiles in flight per wave
   constexpr int RP = 16 * RT + 4; // LDS row pitch of mid (floats)
-  __shared__ __attribute__((aligned(16))) char smem[bneck_lds_bytes<NW, MI, RT>()];
+  __shared__ __attribute__((aligned(16))) char smem[bneck_lds_bytes<NW, MI, RT, STG>()];
   float* red = reinterpret_cast<float*>(smem);                         // [NW][MI * RT][256]
   float* mids = red + NW * MI * RT * 256;                              // [16 MI][RP]
+  T* stage = reinterpret_cast<T*>(mids + 16 * MI * (16 * RT + 4));     // STG: [NW][16 MI + 32 RT][BN_LDP]
   using F8 = typename TT<T>::frag;
   using F4 = typename Mma16<T>::frag;
 
@@ -242,7 +250,105 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     }
   };
   const int nsteps = (K1 + 63) >> 6;
-  {
+  if constexpr (STG) {
+    // chunk c = K elements [KC c, KC c + KC): this wave takes chunks wave, wave + NW, ...
+    //   A  : KC / 8 lanes walk a row (16 bytes each: KC * 2 contiguous bytes), 64 / (KC / 8) rows per instruction
+    //   F1 : KC / 4 lanes walk a row (16 bytes each: KC * 4 contiguous bytes), 64 / (KC / 4) rows per instruction
+    // registers -> private LDS tiles [row][k] (A as is, F1 split into hi / lo planes) -> ds_read_b128 fragments.
+    constexpr int BN_KC = bneck_kc(MI, RT), BN_LDP = BN_KC + 16;
+    constexpr int APL = BN_KC / 8, ARW = 64 / APL, NA = 16 * MI / ARW;
+    constexpr int FPL = BN_KC / 4, FRW = 64 / FPL, NF = 16 * RT / FRW;
+    T* sA = stage + wave * (16 * MI + 32 * RT) * BN_LDP;
+    T* sFh = sA + 16 * MI * BN_LDP;
+    T* sFl = sFh + 16 * RT * BN_LDP;
+    const int ar = lane / APL, ac = 8 * (lane % APL);
+    const int fr = lane / FPL, fc = 4 * (lane % FPL);
+    const T* aptr[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      long r = m0 + ar + ARW * j;
+      if (r >= a.M) r = a.M - 1;
+      aptr[j] = A + r * a.lda + ac;
+    }
+    const float* fptr[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const int n = fr + FRW * j;
+      fptr[j] = a.F1 + (n < R ? n : 0) * a.f1n + fc;
+    }
+    struct Chunk {
+      u32x4 av[NA];
+      f32x4 fv[NF];
+    };
+    const int nchunks = (K1 + BN_KC - 1) / BN_KC;
+    auto load_chunk = [&](Chunk& C, int c) {
+      const int k0 = c * BN_KC;
+      const bool aok = k0 + ac < K1, fok4 = k0 + fc < K1;  // K1 % 8 == 0: pieces are all in or all out
+#pragma unroll
+      for (int j = 0; j < NA; ++j) C.av[j] = *reinterpret_cast<const u32x4*>(aok ? aptr[j] + k0 : aptr[j] - ac);
+#pragma unroll
+      for (int j = 0; j < NF; ++j) C.fv[j] = *reinterpret_cast<const f32x4*>(fok4 ? fptr[j] + k0 : fptr[j] - fc);
+    };
+    auto write_chunk = [&](Chunk& C, int c) {
+      const int k0 = c * BN_KC;
+      const bool aok = k0 + ac < K1, fok4 = k0 + fc < K1;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        LR_USE(C.av[j]);
+        const u32x4 zu = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(sA + (ar + ARW * j) * BN_LDP + ac) = aok ? C.av[j] : zu;
+      }
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        LR_USE(C.fv[j]);
+        const bool ok = fok4 && (fr + FRW * j) < R;
+        T h4[4] __attribute__((aligned(8))), l4[4] __attribute__((aligned(8)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_f<T>(ok ? C.fv[j][e] : 0.f, h4[e], l4[e]);
+        *reinterpret_cast<u32x2*>(sFh + (fr + FRW * j) * BN_LDP + fc) = *reinterpret_cast<const u32x2*>(h4);
+        *reinterpret_cast<u32x2*>(sFl + (fr + FRW * j) * BN_LDP + fc) = *reinterpret_cast<const u32x2*>(l4);
+      }
+    };
+    auto compute_chunk = [&]() {
+#pragma unroll
+      for (int ks = 0; ks < BN_KC / 32; ++ks) {
+        F8 af[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const F8*>(sA + (16 * mi + li) * BN_LDP + 32 * ks + 8 * g);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const F8 bh = *reinterpret_cast<const F8*>(sFh + (16 * rt + li) * BN_LDP + 32 * ks + 8 * g);
+          const F8 bl = *reinterpret_cast<const F8*>(sFl + (16 * rt + li) * BN_LDP + 32 * ks + 8 * g);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            acc[mi][rt] = TT<T>::mma(af[mi], bh, acc[mi][rt]);
+            acc[mi][rt] = TT<T>::mma(af[mi], bl, acc[mi][rt]);
+          }
+        }
+      }
+    };
+    Chunk c0, c1;
+    load_chunk(c0, wave);
+    LR_LOAD_FENCE();
+    load_chunk(c1, wave + NW);
+    LR_LOAD_FENCE();
+    for (int c = wave; c < nchunks; c += 2 * NW) {
+      write_chunk(c0, c);
+      LR_LOAD_FENCE();
+      load_chunk(c0, c + 2 * NW);
+      LR_LOAD_FENCE();
+      compute_chunk();
+      LR_LOAD_FENCE();
+      if (c + NW < nchunks) {
+        write_chunk(c1, c + NW);
+        LR_LOAD_FENCE();
+        load_chunk(c1, c + 3 * NW);
+        LR_LOAD_FENCE();
+        compute_chunk();
+        LR_LOAD_FENCE();
+      }
+    }
+  } else {
     Step st[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
