@@ -57,6 +57,13 @@ __host__ __device__ constexpr int kron3_lds_bytes(int NI, int nbuf) {
   return b > 4096 ? b : 4096;  // the w1-gradient reduction scratch needs 4 KiB
 }
 
+// GM == 3: x goes HBM -> registers -> a small per-wave LDS tile -> fragments.  A fragment-direct load gives the four lanes
+// of a quad four different rows (four cache lines): the address unit then needs ~64 cycles per wave instruction.  Here
+// four consecutive lanes read 64 contiguous bytes of one row (one 32-column k-step), 16 rows per instruction: ~16 cycles.
+// Per wave: two [32 rows][K3_XP] tiles (one per k-step parity), written and read by the same wave only (no barrier).
+constexpr int K3_XP = 40;  // row pitch (elements) of the x tiles: 80 bytes
+__host__ __device__ constexpr int kron3_xs_bytes() { return 4 * 2 * 32 * K3_XP * 2; }
+
 enum { K3_W2_ROWS = 0, K3_W2_COLS = 1, K3_W2_SCALAR = 2 };
 
 // The vector modes load whole float4s only: ROWS needs K % 4 == 0 (the fast path has K % 8 == 0), COLS needs N % 4 == 0.
@@ -175,8 +182,9 @@ __device__ __forceinline__ void k3_store_w2(T* __restrict__ Bh, T* __restrict__ 
 template <typename T, int NI, int GM>
 __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long row0, long rows_end, long n0,
                                           f32x4 (&acc)[2][NI]) {
-  constexpr bool GATHER = GM != 0;
+  constexpr bool GATHER = GM == 1 || GM == 2;
   constexpr bool FLAT = GM == 2;
+  constexpr bool XS = GM == 3;  // plain rows, x through the per-wave LDS stage (quad-coalesced loads)
   constexpr int MI = 2, TQ = 16 * NI;
   constexpr int K3_KC = kron3_kc(NI), K3_KS = K3_KC / 32, K3_LDB = K3_KC + 16;
   constexpr int PLANE = TQ * K3_LDB;  // elements per hi or lo tile
@@ -292,7 +300,31 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
   const int w2mode = k3_w2_mode(a.w2, a.s2n, a.s2k, N, Kloop);
   F8 af[MI][K3_KS];
   f32x4 raw[RW::NRAW];
-  if constexpr (FLAT) {
+  // XS: this lane's piece of a k-step: rows (lane >> 2) and (lane >> 2) + 16 of the wave's 32, columns 8 (lane & 3) .. + 7
+  const int xs_r = lane >> 2, xs_c = 8 * (lane & 3);
+  const T* xs_p[2] = {x, x};
+  bool xs_v[2] = {false, false};
+  T* xs_tile = nullptr;
+  if constexpr (XS) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const long gr = row0 + wave * 32 + xs_r + 16 * p;
+      xs_v[p] = gr < rows_end;
+      xs_p[p] = x + (xs_v[p] ? gr : row0) * K + xs_c;
+    }
+    xs_tile = reinterpret_cast<T*>(smem + kron3_lds_bytes(NI, Kloop > K3_KC ? 2 : 1)) + wave * 2 * 32 * K3_XP;
+  }
+  auto load_raw_x = [&](int p, long kk) -> F8 {  // unconditional, from a clamped address; masked when written to LDS
+    const u32x4 v = *reinterpret_cast<const u32x4*>(xs_p[p] + (kk + xs_c < K ? kk : 0));
+    return *reinterpret_cast<const F8*>(&v);
+  };
+  if constexpr (XS) {
+#pragma unroll
+    for (int ks = 0; ks < K3_KS; ++ks) {
+      af[0][ks] = load_raw_x(0, ks * 32);
+      af[1][ks] = load_raw_x(1, ks * 32);
+    }
+  } else if constexpr (FLAT) {
 #pragma unroll
     for (int ks = 0; ks < K3_KS; ++ks) {
       af[0][ks] = load_frag_flat(0, ks * 32);
@@ -323,11 +355,24 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
   // for the next chunk as soon as they are free.  Straight-line code (no per-k-step branches), so the compiler hoists the
   // ds_read_b128 fragment reads over the MFMAs.
   auto chunk = [&](auto nks_tag, auto more_tag, const T* Bh, const T* Bl, const T* np0, bool nv0, const T* np1,
-                   bool nv1, long knext) {
+                   bool nv1, long knext, long kcur) {
     constexpr int NKS = decltype(nks_tag)::value;
     constexpr bool MORE = decltype(more_tag)::value;
 #pragma unroll
     for (int ks = 0; ks < K3_KS; ++ks) {
+      F8 a0 = af[0][ks], a1 = af[1][ks];
+      if constexpr (XS) {
+        if (ks < NKS) {  // raw pieces -> this wave's tile -> fragments (LDS operations of one wave execute in order)
+          T* xt = xs_tile + (ks & 1) * 32 * K3_XP;
+          const bool kok = kcur + ks * 32 + xs_c < K;
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          u32x4 r0v = *reinterpret_cast<const u32x4*>(&af[0][ks]), r1v = *reinterpret_cast<const u32x4*>(&af[1][ks]);
+          *reinterpret_cast<u32x4*>(xt + xs_r * K3_XP + xs_c) = (xs_v[0] && kok) ? r0v : z;
+          *reinterpret_cast<u32x4*>(xt + (xs_r + 16) * K3_XP + xs_c) = (xs_v[1] && kok) ? r1v : z;
+          a0 = *reinterpret_cast<const F8*>(xt + li * K3_XP + 8 * g);
+          a1 = *reinterpret_cast<const F8*>(xt + (16 + li) * K3_XP + 8 * g);
+        }
+      }
       if (ks < NKS) {
         const int kofs = ks * 32 + 8 * g;
         F8 bh[NI], bl[NI];
@@ -338,17 +383,20 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          acc[0][ni] = TT<T>::mma(af[0][ks], bh[ni], acc[0][ni]);
-          acc[1][ni] = TT<T>::mma(af[1][ks], bh[ni], acc[1][ni]);
+          acc[0][ni] = TT<T>::mma(a0, bh[ni], acc[0][ni]);
+          acc[1][ni] = TT<T>::mma(a1, bh[ni], acc[1][ni]);
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          acc[0][ni] = TT<T>::mma(af[0][ks], bl[ni], acc[0][ni]);
-          acc[1][ni] = TT<T>::mma(af[1][ks], bl[ni], acc[1][ni]);
+          acc[0][ni] = TT<T>::mma(a0, bl[ni], acc[0][ni]);
+          acc[1][ni] = TT<T>::mma(a1, bl[ni], acc[1][ni]);
         }
       }
       if constexpr (MORE) {  // the fragment registers of this k-step are free again: fetch the next segment's
-        if constexpr (FLAT) {
+        if constexpr (XS) {
+          af[0][ks] = load_raw_x(0, knext + ks * 32);
+          af[1][ks] = load_raw_x(1, knext + ks * 32);
+        } else if constexpr (FLAT) {
           af[0][ks] = load_frag_flat(0, knext + ks * 32);
           af[1][ks] = load_frag_flat(1, knext + ks * 32);
         } else {
@@ -359,13 +407,13 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
     }
   };
   auto run_chunk = [&](int nks, auto more_tag, const T* Bh, const T* Bl, const T* np0, bool nv0, const T* np1, bool nv1,
-                       long knext) {
+                       long knext, long kcur) {
     switch (nks) {
-      case 1: chunk(std::integral_constant<int, 1>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext); break;
-      case 2: chunk(std::integral_constant<int, 2>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext); break;
-      case 3: chunk(std::integral_constant<int, 3>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext); break;
-      case 4: chunk(std::integral_constant<int, (K3_KS < 4 ? K3_KS : 4)>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext); break;
-      default: chunk(std::integral_constant<int, K3_KS>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext); break;
+      case 1: chunk(std::integral_constant<int, 1>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext, kcur); break;
+      case 2: chunk(std::integral_constant<int, 2>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext, kcur); break;
+      case 3: chunk(std::integral_constant<int, 3>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext, kcur); break;
+      case 4: chunk(std::integral_constant<int, (K3_KS < 4 ? K3_KS : 4)>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext, kcur); break;
+      default: chunk(std::integral_constant<int, K3_KS>{}, more_tag, Bh, Bl, np0, nv0, np1, nv1, knext, kcur); break;
     }
   };
   static_assert(K3_KS == 5 || K3_KS == 3, "run_chunk dispatch assumes 3 or 5 k-steps per chunk");
@@ -395,7 +443,7 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
       }
       const float* w2n = (GATHER && !FLAT) ? a.w2 + (long)ntap * a.gat.s2t : a.w2;
       k3_load_w2<TQ, K3_KC>(raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, Kloop);
-      run_chunk(nks, std::true_type{}, Bh, Bl, np0, nv0, np1, nv1, nk0);
+      run_chunk(nks, std::true_type{}, Bh, Bl, np0, nv0, np1, nv1, nk0, k0);
       T* Nh = Bbase + (buf ^ 1) * 2 * PLANE;
       k3_store_w2<T, TQ, K3_KC>(Nh, Nh + PLANE, raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, Kloop);
       __syncthreads();
@@ -403,7 +451,7 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
       tap = ntap;
       k0 = nk0;
     } else {
-      run_chunk(nks, std::false_type{}, Bh, Bl, nullptr, false, nullptr, false, 0);
+      run_chunk(nks, std::false_type{}, Bh, Bl, nullptr, false, nullptr, false, 0, k0);
     }
   }
 }
