@@ -453,6 +453,68 @@ int64_t lyc_lokr_bwd_workspace_bytes(int64_t M, int a, int b, int c, int d, int 
   return (int64_t)cdiv(M, K3_RT / a) * cdiv(d, 32) * a * b * (int64_t)sizeof(float);
 }
 
+// ---- fork / join of independent launches --------------------------------------------------------------------------
+// The two LoKr backward launches of a layer (dx + dW1 partials | dW2) are independent and both latency-bound with about
+// one workgroup per CU, so they were put on separate branches of the captured hipGraph (dW2 on a library-owned side
+// stream between an event fork and an event join).  MEASURED (MI355X, ROCm 7.2, SDXL step): 46.7 ms/step against 36.5
+// ms on a single branch -- every fork / join pair costs more in the graph than the overlap hides.  The code stays as an
+// experiment switch, OFF by default: LYC_FORK_BWD=1 forks while `stream` is being captured, =2 always.
+extern "C++" {
+namespace {
+struct ForkCtx {
+  hipStream_t side = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool tried = false, ok = false;
+};
+thread_local ForkCtx g_fork[16];
+
+int fork_mode() {
+  static const int v = lr_env("LYC_FORK_BWD", 0);
+  return v;
+}
+
+ForkCtx* fork_ctx(bool may_create) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  ForkCtx& f = g_fork[dev];
+  if (!f.tried && may_create) {
+    f.tried = true;
+    f.ok = hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&f.e0, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&f.e1, hipEventDisableTiming) == hipSuccess;
+    (void)hipGetLastError();
+  }
+  return f.ok ? &f : nullptr;
+}
+
+// returns the stream for the forked launch (the side stream), or `st` itself when not forking
+hipStream_t fork_begin(hipStream_t st, ForkCtx*& ctx) {
+  ctx = nullptr;
+  const int mode = fork_mode();
+  if (mode == 0) return st;
+  bool capturing = false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) == hipSuccess) capturing = cs == hipStreamCaptureStatusActive;
+  (void)hipGetLastError();
+  ForkCtx* f = fork_ctx(!capturing);  // the side stream / events are created on an eager call (never inside a capture)
+  if (!f || (mode == 1 && !capturing)) return st;
+  if (hipEventRecord(f->e0, st) != hipSuccess || hipStreamWaitEvent(f->side, f->e0, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return st;
+  }
+  ctx = f;
+  return f->side;
+}
+
+int fork_join(hipStream_t st, ForkCtx* ctx) {
+  if (!ctx) return LYC_OK;
+  if (hipEventRecord(ctx->e1, ctx->side) != hipSuccess || hipStreamWaitEvent(st, ctx->e1, 0) != hipSuccess)
+    return fail(LYC_ERR_LAUNCH, "fork_join: %s", hipGetErrorString(hipGetLastError()));
+  return LYC_OK;
+}
+}  // namespace
+}  // extern "C++"
+
 int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const float* w2, void* dx, float* dw1,
                         float* dw2, void* ws, int64_t M, int a, int b, int c, int d, float alpha, int dtype,
                         void* stream) {
@@ -462,6 +524,22 @@ int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const flo
   hipStream_t st = (hipStream_t)stream;
   const bool is16 = (dtype & 0xff) != LYC_F32;
   long dw1_partials = 0;  // > 0: the dx launch left that many [a*b] partials in ws
+  const bool dw2s_ok = dw2 && is16 && a == b && (16 % a) == 0 && (c % 8) == 0 && (d % 8) == 0 &&
+                       (reinterpret_cast<uintptr_t>(g) & 15u) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+  ForkCtx* fk = nullptr;
+  bool dw2_done = false;
+  if (dw2s_ok && dx) {  // both launches: try to put the dW2 one on a parallel branch (it then cannot carry the dW1 reduction)
+    hipStream_t s2 = fork_begin(st, fk);
+    if (fk) {
+      KronDw2sArgs da{};
+      da.Q = g; da.P = x; da.W = w1; da.out = dw2; da.M = M; da.G = a; da.I = c; da.J = d;
+      da.ws = b; da.wt = 1; da.os = d; da.alpha = alpha;
+      if ((dtype & 0xff) == LYC_BF16) launch_dw2s<__bf16>(da, s2);
+      else launch_dw2s<_Float16>(da, s2);
+      if (int rc = check_launch("lokr_linear_bwd(dw2, forked)")) return rc;
+      dw2_done = true;
+    }
+  }
   if (dx || dw1) {
     // dx[m, u*d+v] = alpha * sum_p w1[p,u] * sum_q w2[q,v] * g[m, p*c+q]: the same kernel on (w1^T, w2^T),
     // with the w1 gradient taken from its stage-1 result (GZ) against x.
@@ -482,10 +560,10 @@ int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const flo
     ra.dw1_red = 1;
   }
   bool reduced = dw1_partials == 0;
-  if (dw2) {
+  if (int rc = fork_join(st, fk)) return rc;
+  if (dw2 && !dw2_done) {
     bool done = false;
-    if (is16 && a == b && (16 % a) == 0 && (c % 8) == 0 && (d % 8) == 0 &&
-        (reinterpret_cast<uintptr_t>(g) & 15u) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+    if (dw2s_ok) {
       // rows of the tile run over q (exact operand g), the w1 mix is applied to x on the matrix cores; the output
       // tile is [q][v] with v contiguous in dw2
       KronDw2sArgs da = ra;
@@ -600,6 +678,21 @@ int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1,
   hipStream_t st = (hipStream_t)stream;
   const bool bf = (dtype & 0xff) == LYC_BF16;
   long dw1_partials = 0;
+  ForkCtx* fk = nullptr;
+  bool dw2_done = false;
+  if (dx_rows && dw2p) {  // dW2 on a parallel branch of a captured graph (see fork_begin)
+    hipStream_t s2 = fork_begin(st, fk);
+    if (fk) {
+      KronDw2sArgs da{};
+      da.Q = g_rows; da.P = x_rows; da.W = w1; da.out = dw2p; da.M = B * cd.Ho * cd.Wo; da.G = a; da.I = c;
+      da.J = cd.taps * d; da.Jt = d; da.ws = b; da.wt = 1; da.os = (long)cd.taps * d; da.alpha = alpha;
+      da.gat = make_gather(1, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
+      if (bf) launch_dw2s<__bf16>(da, s2);
+      else launch_dw2s<_Float16>(da, s2);
+      if (int rc = check_launch("lokr_conv2d_bwd(dw2, forked)")) return rc;
+      dw2_done = true;
+    }
+  }
   if (dx_rows) {
     // transposed convolution: destination rows are INPUT pixels, the operand rows come from g (output pixels)
     KronArgs ka{};
@@ -622,7 +715,8 @@ int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1,
     ra.dw1_ws = static_cast<const float*>(ws); ra.dw1 = dw1; ra.dw1_nblk = (int)dw1_partials; ra.dw1_n = a * b;
     ra.dw1_red = 1;
   }
-  if (dw2p) {
+  if (int rc = fork_join(st, fk)) return rc;
+  if (dw2p && !dw2_done) {
     KronDw2sArgs da = ra;
     da.Q = g_rows; da.P = x_rows; da.W = w1; da.out = dw2p; da.M = B * cd.Ho * cd.Wo; da.G = a; da.I = c;
     da.J = cd.taps * d; da.Jt = d; da.ws = b; da.wt = 1; da.os = (long)cd.taps * d; da.alpha = alpha;
