@@ -33,7 +33,9 @@ ALGO_LABEL = {"lokr": "LoKr factor=8", "locon": "LoCon dim=16 conv_dim=8", "loha
 # runs, gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md; benchmarks/pmc_summary.py writes the numbers to
 # profiles/): counters cannot be collected inside the timed run, so the committed measurement is quoted here.
 # profiles/r01_pmc_bench_linear.txt (739 Linear layers, 2 eager passes): kron3 1.19x, dw2s 2.2x the algorithmic bytes
-PMC_TRAFFIC = {"kron3": 11331968, "dw2s": 17305621}
+PMC_TRAFFIC = {"kron3": 11331968, "dw2s": 17305621,
+               # LoCon (profiles/r01_pmc_bench_locon_linear.txt): bneck_kernel 10.12 MB, lowrank_tn_kernel 10.38 MB per launch
+               "locon3": (2 * 10121569 + 10382384) // 3}
 
 
 def parse():
@@ -318,8 +320,8 @@ def roofline_locon(protos, dtype, dev):
     return {"bound": "hbm", "kernel": "lyc::bneck_kernel (forward, backward-dx) + lyc::lowrank_tn_kernel (factor gradients): the "
                                       "three LoCon launches of the 739 Linear layers",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "launches_per_step": n_launch, "avg_launch_us": round(t_ms * 1e3 / n_launch, 2),
-            "algorithmic_bytes_per_launch": int(nbytes / n_launch),
+            "traffic": PMC_TRAFFIC.get("locon3"), "launches_per_step": n_launch,
+            "avg_launch_us": round(t_ms * 1e3 / n_launch, 2), "algorithmic_bytes_per_launch": int(nbytes / n_launch),
             "families_ms": {"forward": round(t_fwd, 3), "backward": round(t_bwd, 3)}}
 
 

@@ -25,7 +25,8 @@ def load(d, counter):
 
 
 def short(name):
-    for key in ("kron3_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "copy16", "kron_kernel", "kron_dw2_kernel"):
+    for key in ("kron3_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "copy16", "kron_kernel", "kron_dw2_kernel",
+                "bneck_kernel", "lowrank_tn_kernel", "gexp_kernel"):
         if key in name:
             return key + name.split(key)[1][:34]
     return name[:60]
@@ -60,7 +61,7 @@ def main():
         rb = fm * (cal_r or 1024.0)
         wb = wm * (cal_w or 1024.0)
         print(f"{short(k):60s} {max(len(f), len(w)):6d} {fm:12.1f} {wm:12.1f} {rb / 1e6:9.2f} {wb / 1e6:9.2f} {(rb + wb) / 1e6:14.2f}")
-    for fam in ("kron3_kernel", "kron_dw2s_kernel"):
+    for fam in ("kron3_kernel", "kron_dw2s_kernel", "bneck_kernel", "lowrank_tn_kernel", "gexp_kernel"):
         fs = [v for k, vs in fetch.items() if fam in k for v in vs]
         ws_ = [v for k, vs in write.items() if fam in k for v in vs]
         if fs and ws_:
