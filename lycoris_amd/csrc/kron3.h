@@ -26,6 +26,13 @@
 
 namespace lyc {
 
+// compiler + scheduler fence (no instruction): keeps the global loads on either side in source order
+#define LR3_FENCE()                      \
+  do {                                   \
+    asm volatile("" ::: "memory");       \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+
 template <typename T>
 struct Mma16;
 template <>
@@ -94,9 +101,14 @@ struct K3Raw {
 
 template <int TQ, int KC>
 __device__ __forceinline__ void k3_load_w2(f32x4 (&raw)[(K3Raw<TQ, KC>::NRAW)], int mode, const float* __restrict__ w2,
-                                           long s2n, long s2k, long n0, int N, long k0, int K) {
+                                           long s2n, long s2k, long n0, int N, long k0, int K, const void* safe16) {
   using R = K3Raw<TQ, KC>;
-  if (mode == K3_W2_SCALAR) return;
+  // SCALAR mode (unaligned / odd strides) does not use `raw`, but an early return here would make `raw` a PHI of
+  // "loaded" and "undefined": the compiler then copies all of it at the join and waits vmcnt(0) right there, before the
+  // caller's x loads are even issued.  So the loads are issued in every mode, in SCALAR mode from `safe16` (any valid
+  // 16-byte aligned, >= 16-byte buffer: the activations) and ignored.
+  const bool scalar = mode == K3_W2_SCALAR;
+  const float* dflt = scalar ? static_cast<const float*>(safe16) : w2;
   const bool rows = (mode == K3_W2_ROWS);
   const int tid = threadIdx.x;
 #pragma unroll
@@ -105,19 +117,17 @@ __device__ __forceinline__ void k3_load_w2(f32x4 (&raw)[(K3Raw<TQ, KC>::NRAW)], 
     const int nq = rows ? b / R::KQ : b % R::NQ;
     const int kq = rows ? b % R::KQ : b / R::NQ;
     const long gn = n0 + 4 * nq, gk = k0 + 4 * kq;
-    const bool blk_ok = (b < R::NQ * R::KQ) && gn < N && gk < K;
+    const bool blk_ok = !scalar && (b < R::NQ * R::KQ) && gn < N && gk < K;
     // ROWS: float4 j = row gn + j, columns gk .. gk+3 (K % 4 == 0: whole);  COLS: float4 j = k row gk + j, n gn .. gn+3
     // unconditional loads from a clamped (always valid) address, zeroed by a select: no exec-mask branches, so all
     // loads of a chunk issue back to back
     const long jstride = rows ? s2n : s2k;
     const long jlimit = rows ? (long)N - gn : (long)K - gk;
-    const float* base = blk_ok ? w2 + gn * s2n + gk * s2k : w2;
+    const float* base = blk_ok ? w2 + gn * s2n + gk * s2k : dflt;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool ok = blk_ok && j < jlimit;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? base + j * jstride : w2);
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      raw[4 * it + j] = ok ? v : z;
+      raw[4 * it + j] = *reinterpret_cast<const f32x4*>(ok ? base + j * jstride : dflt);  // zeroed in k3_store_w2
     }
   }
 }
@@ -138,10 +148,20 @@ __device__ __forceinline__ void k3_store_w2(T* __restrict__ Bh, T* __restrict__ 
       const int nq = rows ? b / R::KQ : b % R::NQ;
       const int kq = rows ? b % R::KQ : b / R::NQ;
       if (b < R::NQ * R::KQ) {
+        // the loads were unconditional (clamped addresses): zero what lies outside [N) x [K) here, at the point of use
+        const long gn = n0 + 4 * nq, gk = k0 + 4 * kq;
+        const bool blk_ok = gn < N && gk < K;
+        const long jlimit = rows ? (long)N - gn : (long)K - gk;
+        f32x4 rz[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          rz[j] = (blk_ok && j < jlimit) ? raw[4 * it + j] : z;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {  // LDS row n = 4 nq + e, columns 4 kq .. 4 kq + 3
-          const f32x4 t = {raw[4 * it][e], raw[4 * it + 1][e], raw[4 * it + 2][e], raw[4 * it + 3][e]};
-          const f32x4 r = raw[4 * it + e];
+          const f32x4 t = {rz[0][e], rz[1][e], rz[2][e], rz[3][e]};
+          const f32x4 r = rz[e];
           f32x4 v;
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = rows ? r[q] : t[q];
@@ -300,6 +320,11 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
   const int w2mode = k3_w2_mode(a.w2, a.s2n, a.s2k, N, Kloop);
   F8 af[MI][K3_KS];
   f32x4 raw[RW::NRAW];
+  // The w2 loads go out FIRST: vector-memory results return in issue order, and the w2 tile is on the critical path
+  // (convert -> LDS -> barrier -> first MFMA) while the x fragments are only needed at the MFMAs.  Issued behind the ten
+  // x loads (HBM) the L2-resident w2 data could not be touched before all of x had arrived.
+  k3_load_w2<TQ, K3_KC>(raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, Kloop, a.x);
+  LR3_FENCE();
   // XS: this lane's piece of a k-step: rows (lane >> 2) and (lane >> 2) + 16 of the wave's 32, columns 8 (lane & 3) .. + 7
   const int xs_r = lane >> 2, xs_c = 8 * (lane & 3);
   const T* xs_p[2] = {x, x};
@@ -341,8 +366,7 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
       af[1][ks] = load_frag_x(v1, p1, ks * 32);
     }
   }
-  k3_load_w2<TQ, K3_KC>(raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, Kloop);
-
+  LR3_FENCE();  // ... and the x loads before the first use of the w2 data (the scheduler would hoist the conversions)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -442,7 +466,7 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
         row_src(1, ntap, np1, nv1);
       }
       const float* w2n = (GATHER && !FLAT) ? a.w2 + (long)ntap * a.gat.s2t : a.w2;
-      k3_load_w2<TQ, K3_KC>(raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, Kloop);
+      k3_load_w2<TQ, K3_KC>(raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, Kloop, a.x);
       run_chunk(nks, std::true_type{}, Bh, Bl, np0, nv0, np1, nv1, nk0, k0);
       T* Nh = Bbase + (buf ^ 1) * 2 * PLANE;
       k3_store_w2<T, TQ, K3_KC>(Nh, Nh + PLANE, raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, Kloop);
