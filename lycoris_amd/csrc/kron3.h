@@ -199,9 +199,11 @@ __device__ __forceinline__ void k3_store_w2(T* __restrict__ Bh, T* __restrict__ 
 // GM: 0 = plain rows, 1 = pixel-row gather with one K segment sequence per tap (any geometry), 2 = gather over the
 // FLAT K index (tap, k) -- the source pixel of tap t is base + offset[t] (forward with any stride, backward with stride
 // 1), so segments are full K3_KC chunks however short the per-tap rows are (C = 320 convs have 40 columns per tap).
-template <typename T, int NI, int GM>
+// `after_loads()` is invoked once, right behind the issue of the first chunk's w2 and x loads: the place for loads the
+// caller needs only after stage 1 (vector-memory results return in issue order, so they must not precede the w2 loads).
+template <typename T, int NI, int GM, typename Hook>
 __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long row0, long rows_end, long n0,
-                                          f32x4 (&acc)[2][NI]) {
+                                          f32x4 (&acc)[2][NI], Hook&& after_loads) {
   constexpr bool GATHER = GM == 1 || GM == 2;
   constexpr bool FLAT = GM == 2;
   constexpr bool XS = GM == 3;  // plain rows, x through the per-wave LDS stage (quad-coalesced loads)
@@ -366,6 +368,7 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
       af[1][ks] = load_frag_x(v1, p1, ks * 32);
     }
   }
+  after_loads();
   LR3_FENCE();  // ... and the x loads before the first use of the w2 data (the scheduler would hoist the conversions)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -510,8 +513,29 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
     }
   }
 
+  // backward: the xref fragments of the w1 gradient (B[k = n][j = row li], 8 bytes per (mi, ni)) are fetched while stage 1
+  // runs instead of inside the epilogue (they were ~1 us of exposed latency there); masked at use
+  // (plain-row kernels only: the gather variants have no registers to spare -- 2 -> 1 waves per SIMD with it)
+  constexpr bool XPRE = WITH_DW1 && (GM == 0 || GM == 3);
+  u32x2 xrv[MI][NI];
+  const bool xr_vec = WITH_DW1 && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.xref) & 7u) == 0);
+  auto prefetch_xref = [&]() {
+    if constexpr (XPRE) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const long R = row0 + wave * 32 + mi * 16 + li;
+        const long rofs = (R >> lg) * ((long)G * N) + (R & (G - 1)) * (long)N;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const long gn = n0 + 16 * ni + 4 * g;
+          const bool ok = xr_vec && R < rows_end && gn < N;
+          xrv[mi][ni] = *reinterpret_cast<const u32x2*>(static_cast<const T*>(a.xref) + (ok ? rofs + gn : 0));
+        }
+      }
+    }
+  };
   f32x4 acc[MI][NI];
-  k3_stage1<T, NI, GM>(a, smem, row0, rows_end, n0, acc);
+  k3_stage1<T, NI, GM>(a, smem, row0, rows_end, n0, acc, prefetch_xref);
   LYC_STAMP(4);
 
   // ---- epilogue, all in registers ----
@@ -586,11 +610,12 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
         // xref fragment: B[k = n][j = row li]
         const T* xr = static_cast<const T*>(a.xref) + rofs + gn;
         T bv[4];
-        const bool r_vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.xref) & 7u) == 0);
-        if (r_vec) {  // gn + 4 <= N or gn >= N; clamped address + select
+        if (xr_vec) {  // gn + 4 <= N or gn >= N; prefetched from a clamped address, masked here
           const bool ok = row_ok && gn < N;
-          const u32x2 v = *reinterpret_cast<const u32x2*>(ok ? xr : static_cast<const T*>(a.xref));
           const u32x2 z = {0u, 0u};
+          u32x2 v;
+          if constexpr (XPRE) v = xrv[mi][ni];
+          else v = *reinterpret_cast<const u32x2*>(ok ? xr : static_cast<const T*>(a.xref));
           *reinterpret_cast<u32x2*>(bv) = ok ? v : z;
         } else {
 #pragma unroll
