@@ -251,6 +251,16 @@ __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
   };
   long r0 = rbeg + 32 * wave;
   LYC_STAMP(1);
+  // The four W values are requested BEFORE the row groups: vector-memory results return in issue order, so behind the
+  // two preloaded groups they would only become usable once every preloaded row had arrived, and the first step's MFMAs
+  // (which need W and only the first 32 rows) would wait for all of it.
+  float wraw[4];
+  {
+    const int s_ = li & (G - 1);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) wraw[jj] = a.W[s_ * a.ws + ((4 * g + jj) & (G - 1)) * a.wt];
+  }
+  LR3_FENCE();
   load_group(rawA, r0);
   load_group(rawB, r0 + GROUP);
   LYC_STAMP(2);
@@ -258,13 +268,12 @@ __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
   // mix operand (I (x) W) for one 16x16 block: lane (i = li, g) holds k = 4g .. 4g+3
   F4 a2h, a2l;
   {
-    const int mi_ = li >> lg, s_ = li & (G - 1);
+    const int mi_ = li >> lg;
     T h[4], l[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int kk = 4 * g + jj;
-      const float w = a.W[s_ * a.ws + (kk & (G - 1)) * a.wt];
-      split_f<T>(((kk >> lg) == mi_) ? w : 0.f, h[jj], l[jj]);
+      split_f<T>(((kk >> lg) == mi_) ? wraw[jj] : 0.f, h[jj], l[jj]);
     }
     a2h = *reinterpret_cast<F4*>(h);
     a2l = *reinterpret_cast<F4*>(l);

@@ -366,6 +366,38 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     }
   }
 
+  // this y slice's column tiles: [tbeg, ntiles)
+  const int ntiles_all = (a.N2 + 15) >> 4;
+  const int tper = (ntiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int tbeg = (int)blockIdx.y * tper;
+  const int ntiles = tbeg + tper < ntiles_all ? tbeg + tper : ntiles_all;
+  // F2 needs no masks: columns k >= R of mid are zero (their F1 rows were zeroed), tiles / columns past the end are never
+  // stored; the loads only have to come from valid (clamped) addresses.
+  auto load_f2 = [&](f32x4 (&fr)[RT], int tile) {
+    const int n = 16 * tile + li;
+    const float* p = a.F2 + ((tile < ntiles && n < a.N2) ? n : 0) * a.f2n;
+#pragma unroll
+    for (int kt = 0; kt < RT; ++kt) {
+      const int k = 16 * kt + 4 * g;
+      if constexpr (F2V) {  // R % 4 == 0: all in or all out
+        fr[kt] = *reinterpret_cast<const f32x4*>(p + (k < R ? k : 0));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fr[kt][e] = p[(long)(k + e < R ? k + e : 0) * a.f2k];
+      }
+    }
+  };
+  // The first D2 factor tiles of the expand stage are requested now, before the cross-wave sum: they do not depend on it
+  // and their L2 round trip would otherwise be exposed at the start of stage 2 (results return in issue order: behind
+  // the stage-1 loads, which are all consumed by now).
+  f32x4 fr[D2][RT];
+  if (a.out != nullptr) {
+#pragma unroll
+    for (int j = 0; j < D2; ++j) {
+      load_f2(fr[j], tbeg + wave + j * NW);
+      LR_LOAD_FENCE();
+    }
+  }
   LYC_STAMP(1);
   // ---------------- cross-wave sum -> mid (LDS, and HBM for the backward pass) ----------------
 #pragma unroll
@@ -397,27 +429,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
       const f32x4 v = *reinterpret_cast<const f32x4*>(mids + (16 * mi + li) * RP + 16 * kt + 4 * g);
       lr_split4<T>(v, bh[mi][kt], bl[mi][kt]);
     }
-  // this y slice's column tiles: [tbeg, ntiles)
-  const int ntiles_all = (a.N2 + 15) >> 4;
-  const int tper = (ntiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
-  const int tbeg = (int)blockIdx.y * tper;
-  const int ntiles = tbeg + tper < ntiles_all ? tbeg + tper : ntiles_all;
-  // F2 needs no masks: columns k >= R of mid are zero (their F1 rows were zeroed), tiles / columns past the end are never
-  // stored; the loads only have to come from valid (clamped) addresses.
-  auto load_f2 = [&](f32x4 (&fr)[RT], int tile) {
-    const int n = 16 * tile + li;
-    const float* p = a.F2 + ((tile < ntiles && n < a.N2) ? n : 0) * a.f2n;
-#pragma unroll
-    for (int kt = 0; kt < RT; ++kt) {
-      const int k = 16 * kt + 4 * g;
-      if constexpr (F2V) {  // R % 4 == 0: all in or all out
-        fr[kt] = *reinterpret_cast<const f32x4*>(p + (k < R ? k : 0));
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) fr[kt][e] = p[(long)(k + e < R ? k + e : 0) * a.f2k];
-      }
-    }
-  };
   const bool out_vec = a.out_f32 ? ((a.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0)
                                  : ((a.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7u) == 0);
   // FULL: every tile has 16 valid columns and the rows can take vector stores -> one predicated store per tile; the
@@ -466,12 +477,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     }
   };
   auto stage2 = [&](auto full_tag) {
-    f32x4 fr[D2][RT];
-#pragma unroll
-    for (int j = 0; j < D2; ++j) {
-      load_f2(fr[j], tbeg + wave + j * NW);
-      LR_LOAD_FENCE();
-    }
     LYC_STAMP(3);
     for (int tile = tbeg + wave; tile < ntiles; tile += D2 * NW) {
 #pragma unroll
