@@ -183,3 +183,24 @@ def test_missing_native_library_is_an_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_native, "_LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_native.NativeLibraryError, match="no fallback"):
         _native.load()
+
+
+def test_conv_dispatch_predicates():
+    """Which Conv2d calls take the im2col-free kernels is pure shape / dtype logic (the C entry points repeat the same
+    checks and answer LYC_ERR_UNSUPPORTED otherwise): pin it on CPU tensors."""
+    from lycoris_amd import ops
+    bf = torch.bfloat16
+    x = torch.zeros(1, 320, 8, 8, dtype=bf)
+    down, up = torch.zeros(8, 320, 3, 3), torch.zeros(320, 8, 1, 1)
+    assert ops._locon_conv_implicit_ok(x, down, up)
+    assert not ops._locon_conv_implicit_ok(x.float(), down, up)                                  # fp32 activations
+    assert not ops._locon_conv_implicit_ok(torch.zeros(1, 24, 8, 8, dtype=bf), torch.zeros(8, 24, 3, 3), up)   # C % 16
+    assert not ops._locon_conv_implicit_ok(x, torch.zeros(6, 320, 3, 3), torch.zeros(320, 6, 1, 1))            # rank % 4
+    assert not ops._locon_conv_implicit_ok(x, torch.zeros(32, 320, 3, 3), torch.zeros(320, 32, 1, 1))          # rank > 16
+    assert not ops._locon_conv_implicit_ok(x, torch.zeros(16, 320, 5, 5), torch.zeros(320, 16, 1, 1))          # taps*r > 144
+    assert ops._locon_conv_implicit_ok(x, torch.zeros(4, 320, 5, 5), torch.zeros(320, 4, 1, 1))
+    w1, w2 = torch.zeros(8, 8), torch.zeros(40, 40, 3, 3)
+    assert ops._lokr_conv_implicit_ok(x, w1, w2)
+    assert not ops._lokr_conv_implicit_ok(x, torch.zeros(8, 4), torch.zeros(40, 80, 3, 3))        # a != b
+    assert not ops._lokr_conv_implicit_ok(x, torch.zeros(2, 2), torch.zeros(160, 160, 3, 3))      # factor 2
+    assert not ops._lokr_conv_implicit_ok(x.float(), w1, w2)
