@@ -79,12 +79,12 @@ void launch_kron3_inst2(const KronArgs& ka, dim3 grid, hipStream_t st) {
 
 template <typename T, int NI, bool DW1>
 void launch_kron3_inst(const KronArgs& ka, dim3 grid, hipStream_t st) {
-  static const int use_xs = [] { const char* e = getenv("LYC_K3_XS"); return e ? atoi(e) : 1; }();
+  static const int use_xs = [] { const char* e = getenv("LYC_K3_XS"); return e ? atoi(e) : 2; }();
   if (ka.gat.mode && ka.gat.flat) launch_kron3_inst2<T, NI, DW1, 2>(ka, grid, st);
   else if (ka.gat.mode) launch_kron3_inst2<T, NI, DW1, 1>(ka, grid, st);
-  // x through the per-wave LDS stage (quad-coalesced loads): measured -3 % on the forward launches, +2 % on the backward
-  // ones (whose critical path is the w2 tile and the w1-gradient epilogue), so only the launches without dW1 take it
-  else if (use_xs && !DW1 && (ka.K % 32) == 0) launch_kron3_inst2<T, NI, DW1, 3>(ka, grid, st);
+  // x through the per-wave LDS stage (quad-coalesced loads): -3 % on the forward launches, -2 % on the backward ones
+  // (once the w2 tile is requested ahead of x); LYC_K3_XS=0 switches it off, =1 restricts it to the launches without dW1
+  else if (use_xs && (use_xs > 1 || !DW1) && (ka.K % 32) == 0) launch_kron3_inst2<T, NI, DW1, 3>(ka, grid, st);
   else launch_kron3_inst2<T, NI, DW1, 0>(ka, grid, st);
 }
 
