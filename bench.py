@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
-"""Driver benchmark: SDXL UNet adapter train step (bs=1/GPU), LoKr factor=8, bf16, on N MI355X.
+"""Driver benchmark: UNet adapter train step (bs=1/GPU on SDXL; bs=4 on SD1.5), per algorithm, on N MI355X.
 
-One "step" = one pass of the adapter hot path over the 788 adapted layers of the SDXL UNet at 1024x1024
-(synthetic activations of the real shapes, benchmarks/sdxl_shapes.py): adapter forward (delta) and backward
-(dx + factor gradients, accumulated straight into the flat gradient arena) for every layer, the arena zero-fill,
-the data-parallel mean all-reduce of the adapter gradients (N > 1, RCCL) and a fused AdamW update of the adapter
-parameters.  The frozen UNet's own GEMMs / convolutions are not part of the hot path and are not timed.
-The compute of a step is captured once in a hipGraph and replayed.
+One "step" = one pass of the adapter hot path over every adapted layer of the UNet (synthetic activations of the real
+shapes: benchmarks/sdxl_shapes.py = 788 layers at 1024x1024, benchmarks/sd15_shapes.py = 278 layers at 512x512 bs 4):
+adapter forward (delta) and backward (dx + factor gradients accumulated straight into the flat gradient arena) of every
+layer, the arena zero-fill, the data-parallel mean all-reduce of the adapter gradients (N > 1: RCCL, launched bucket by
+bucket between the backward segments so it overlaps the rest of the backward) and a fused AdamW update.  EVERY layer
+instance owns its activation buffers (x and the upstream gradient g): a step reads the ~6 GB a real step reads, from
+HBM, not from the 256 MB Infinity Cache.  The compute of a step is captured in hipGraphs and replayed.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
-Prints ONE JSON line on rank 0 (contract in the task statement) including "roofline" and "cpu_baseline".
+    python bench.py --gpus N --steps K --warmup W [--algo lokr|locon|loha|ia3|mixed] [--model sdxl|sd15] [--dtype ..]
+
+Prints ONE JSON line on rank 0.  Besides the contract fields: "roofline" (dominant kernel family, live HIP-event
+timing, PMC traffic of the same build from profiles/), "cpu_baseline" (reference CPU path, bounded sample),
+"reference_rocm_eager" (the reference's own call sequence through stock PyTorch-ROCm on this GPU, eager vs eager and
+graph vs graph -- the north-star comparator) and "base_plus_adapter" (the step with the frozen layers' own ops in it).
 """
 import argparse
+import hashlib
 import json
 import math
 import os
@@ -23,19 +29,17 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
 
-from benchmarks.sdxl_shapes import algorithmic_bytes, layer_rows, sdxl_unet_layers  # noqa: E402
+from benchmarks.sd15_shapes import sd15_unet_layers  # noqa: E402
+from benchmarks.sdxl_shapes import layer_rows, sdxl_unet_layers  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md ("8.0 TB/s spec")
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: "8.0 TB/s spec")
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak (same guide: "~2.5 PF dense")
 FACTOR = 8
-ALGO_LABEL = {"lokr": "LoKr factor=8", "locon": "LoCon dim=16 conv_dim=8", "loha": "LoHa dim=32"}
-# HBM bytes per launch of the dominant kernels from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-# runs, gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md; benchmarks/pmc_summary.py writes the numbers to
-# profiles/): counters cannot be collected inside the timed run, so the committed measurement is quoted here.
-# profiles/r01_pmc_bench_linear.txt (739 Linear layers, 2 eager passes): kron3 1.19x, dw2s 2.2x the algorithmic bytes
-PMC_TRAFFIC = {"kron3": 11331968, "dw2s": 17305621,
-               # LoCon (profiles/r01_pmc_bench_locon_linear.txt): bneck_kernel 10.12 MB, lowrank_tn_kernel 10.38 MB per launch
-               "locon3": (2 * 10121569 + 10382384) // 3}
+ALGO_LABEL = {"lokr": "LoKr factor=8", "locon": "LoCon dim=16 conv_dim=8", "loha": "LoHa dim=32", "ia3": "(IA)^3",
+              "mixed": "mixed preset (LoCon attn + LoKr FFN + (IA)^3 elsewhere)"}
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
 def parse():
@@ -43,57 +47,110 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--algo", default="lokr", choices=["lokr", "locon", "loha"])
+    ap.add_argument("--algo", default="lokr", choices=list(ALGO_LABEL))
+    ap.add_argument("--preset", default=None, help="alias: --preset mixed == --algo mixed")
+    ap.add_argument("--model", default="sdxl", choices=["sdxl", "sd15"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-reference", action="store_true", help="skip the PyTorch-ROCm eager comparator leg")
+    ap.add_argument("--no-base", action="store_true", help="skip the base+adapter leg")
+    ap.add_argument("--shared-inputs", action="store_true",
+                    help="development: instances of one shape share x / g (cache-resident, the round-1 behaviour)")
+    ap.add_argument("--eager", action="store_true", help="time the step without hipGraph capture (Python-driven)")
+    ap.add_argument("--segments", type=int, default=8, help="backward graph segments (N > 1: collectives in between)")
     ap.add_argument("--layers", default="all", help="'all', 'linear' or 'conv' (development)")
-    ap.add_argument("--profile-ops", action="store_true", help="development: torch.profiler table of one eager pass")
     ap.add_argument("--pmc-pass", type=int, default=0,
                     help="run N eager compute passes and exit (for rocprofv3 --pmc, which cannot sample inside graph replays)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.preset == "mixed":
+        a.algo = "mixed"
+    return a
 
 
-class Layer:
-    """One adapted layer of the workload: static input x, static upstream gradient g, fp32 adapter factors."""
+# ---------------------------------------------------------------------------------------------------------------------
+# workload
+# ---------------------------------------------------------------------------------------------------------------------
+def layer_specs(model, algo):
+    """[(spec, algo_of_layer, count)].  (IA)^3 follows the reference's own preset (config.py:185-195: to_k / to_v on
+    the output side, ff.net.2 on the input side); the mixed preset is BASELINE.json configs[4]."""
+    base = sdxl_unet_layers(1) if model == "sdxl" else sd15_unet_layers(4)
+    if algo == "ia3":
+        if model != "sdxl":
+            raise SystemExit("--algo ia3 is defined on the SDXL shape list")
+        mk = lambda n, M, I, O, side, tag: (dict(kind="linear", M=M, I=I, O=O, count=n, tag=tag, side=side), "ia3", n)
+        return [mk(120, 1024, 1280, 1280, "out", "attn1 to_k/to_v @1280"), mk(20, 4096, 640, 640, "out", "attn1 to_k/to_v @640"),
+                mk(120, 77, 2048, 1280, "out", "attn2 to_k/to_v @1280"), mk(20, 77, 2048, 640, "out", "attn2 to_k/to_v @640"),
+                mk(60, 1024, 5120, 1280, "in", "ff.net.2 @1280"), mk(10, 4096, 2560, 640, "in", "ff.net.2 @640")]
+    out = []
+    for s in base:
+        a = algo
+        if algo == "mixed":
+            a = "locon" if "attn" in s["tag"] else ("lokr" if "ff.net" in s["tag"] else "ia3")
+            s = dict(s, side="out")
+        out.append((s, a, s["count"]))
+    return out
 
-    def __init__(self, spec, algo, dtype, dev, gen):
+
+class Inst:
+    """One adapted layer instance: its own input x, upstream gradient g and fp32 adapter factors."""
+
+    def __init__(self, spec, algo, dtype, dev, gen, share=None):
         from lycoris_amd import ops
-        self.spec, self.algo = spec, algo
-        M, I_eff, O = layer_rows(spec)
-        if spec["kind"] == "linear":
-            self.x = torch.randn(spec["M"], spec["I"], device=dev, dtype=dtype, generator=gen).requires_grad_(True)
-            self.g = torch.randn(spec["M"], O, device=dev, dtype=dtype, generator=gen) / math.sqrt(O)
+        self.ops, self.spec, self.algo = ops, spec, algo
+        M, _, O = layer_rows(spec)
+        lin = spec["kind"] == "linear"
+        if lin:
+            xs, gs = (spec["M"], spec["I"]), (spec["M"], O)
             cin, ksz = spec["I"], ()
         else:
-            self.x = torch.randn(spec["B"], spec["C"], spec["H"], spec["W"], device=dev, dtype=dtype,
-                                 generator=gen).requires_grad_(True)
             ho = (spec["H"] + 2 * spec["pad"] - spec["k"]) // spec["stride"] + 1
-            self.g = torch.randn(spec["B"], O, ho, ho, device=dev, dtype=dtype, generator=gen) / math.sqrt(O)
+            xs, gs = (spec["B"], spec["C"], spec["H"], spec["W"]), (spec["B"], O, ho, ho)
             cin, ksz = spec["C"], (spec["k"], spec["k"])
+        self.cin, self.ksz, self.O = cin, ksz, O
+        if share is not None:
+            self.x, self.g, self.base = share.x, share.g, share.base
+        else:
+            self.base = None
+            if algo == "ia3" and spec.get("side", "out") == "out":
+                # out-side (IA)^3 acts on the frozen layer's OUTPUT: x is not read at all
+                self.base = torch.randn(*gs, device=dev, dtype=dtype, generator=gen).requires_grad_(True)
+                self.x = self.base
+            else:
+                self.x = torch.randn(*xs, device=dev, dtype=dtype, generator=gen).requires_grad_(True)
+            gshape = xs if (algo == "ia3" and spec.get("side") == "in") else gs
+            self.g = torch.randn(*gshape, device=dev, dtype=dtype, generator=gen) / math.sqrt(O)
         f32 = dict(device=dev, dtype=torch.float32, generator=gen)
-        if algo == "lokr":  # factor=8, full-matrix w2 (lora_dim >= 10000): w1 [8,8], w2 [O/8, I/8(,k,k)]
+        if algo == "lokr":  # factor 8, full-matrix w2 (lora_dim >= 10000): w1 [8,8], w2 [O/8, I/8(,k,k)]
             w2 = torch.randn(O // FACTOR, cin // FACTOR, *ksz, **f32) * 0.05
             if ksz:  # conv factor kept in channels_last memory: the implicit-GEMM kernels read / write it in place
                 w2 = w2.contiguous(memory_format=torch.channels_last)
-            self.params = [torch.randn(FACTOR, FACTOR, **f32) * 0.3, w2]
+            ps = [torch.randn(FACTOR, FACTOR, **f32) * 0.3, w2]
         elif algo == "locon":  # dim 16 / conv_dim 8
             r = 16 if not ksz or ksz == (1, 1) else 8
             down = torch.randn(r, cin, *ksz, **f32) * 0.05
-            if ksz:  # channels_last lora_down: the implicit-GEMM kernels read / write it in place
+            if ksz:
                 down = down.contiguous(memory_format=torch.channels_last)
-            self.params = [down, torch.randn(O, r, *([1] * len(ksz)), **f32) * 0.05]
-        else:  # loha dim 32
-            r = 32
-            kk = ksz[0] * ksz[1] if ksz else 1
-            self.params = [torch.randn(O, r, **f32) * 0.1, torch.randn(r, cin * kk, **f32), torch.randn(O, r, **f32) * 0.1,
-                           torch.randn(r, cin * kk, **f32)]
-        self.params = [torch.nn.Parameter(p) for p in self.params]
-        self.ops = ops
+            ps = [down, torch.randn(O, r, *([1] * len(ksz)), **f32) * 0.05]
+        elif algo == "loha":  # dim 32
+            r, kk = 32, (ksz[0] * ksz[1] if ksz else 1)
+            ps = [torch.randn(O, r, **f32) * 0.1, torch.randn(r, cin * kk, **f32), torch.randn(O, r, **f32) * 0.1,
+                  torch.randn(r, cin * kk, **f32)]
+        else:  # ia3: one vector over the scaled channel
+            C = cin if spec.get("side") == "in" else O
+            ps = [torch.randn(*((1, C, 1, 1) if ksz else (C,)), **f32) * 0.1]
+            self.bias = torch.randn(O, **f32) * 0.1 if spec.get("side", "out") == "out" else None
+        self.params = [torch.nn.Parameter(p) for p in ps]
 
     def forward(self):
         ops, s, p = self.ops, self.spec, self.params
-        if s["kind"] == "linear":
+        lin = s["kind"] == "linear"
+        if self.algo == "ia3":
+            chan = -1 if lin else 1
+            if s.get("side", "out") == "out":  # y = base * (1 + w) - bias * w   (rebuild semantics, no GEMM)
+                return ops.chan_affine(self.base, p[0], self.bias, 1.0, 1.0, chan)
+            return ops.chan_affine(self.x, p[0], None, 0.0, 1.0, chan)  # x * w; the dense op on it is the frozen GEMM
+        if lin:
             if self.algo == "lokr":
                 return ops.lokr_linear(self.x, p[0], p[1], 1.0)
             if self.algo == "locon":
@@ -106,23 +163,76 @@ class Layer:
             return ops.locon_conv2d(self.x, p[0], p[1], 1.0, st, pd, dl)
         return ops.loha_conv2d(self.x, p[0], p[1], p[2], p[3], 1.0, (s["O"], s["C"], s["k"], s["k"]), st, pd, dl)
 
+    # ---- the reference's call sequence on the same tensors (PyTorch-ROCm eager comparator) ----------------------
+    def ensure_weight(self):
+        if getattr(self, "W", None) is None:
+            shape = (self.O, self.cin, *self.ksz)
+            self.W = torch.randn(*shape, device=self.x.device, dtype=self.x.dtype) * (1.0 / math.sqrt(self.cin * max(1, len(self.ksz) and self.ksz[0] * self.ksz[1])))
+        return self.W
 
-def build_workload(algo, dtype, dev, which):
+    def base_forward(self, x=None):
+        x = self.x if x is None else x
+        s = self.spec
+        if s["kind"] == "linear":
+            return F.linear(x, self.ensure_weight())
+        return F.conv2d(x, self.ensure_weight(), None, s["stride"], s["pad"])
+
+    def reference_forward(self):
+        """modules/{lokr,locon,loha}.py forward(), rebuild path: dW from the factors in the fp32 parameter dtype, cast to
+        the base-weight dtype, `W + dW - W`, dense op (lokr.py:543-566, locon.py:309-332, loha.py:301-322)."""
+        W, p = self.ensure_weight(), self.params
+        if self.algo == "lokr":
+            f1 = p[0].reshape(*p[0].shape, *([1] * (p[1].dim() - 2)))
+            dW = torch.kron(f1, p[1].contiguous())
+        elif self.algo == "locon":
+            dW = (p[1].reshape(p[1].shape[0], -1) @ p[0].reshape(p[0].shape[0], -1)).reshape(W.shape)
+        elif self.algo == "loha":
+            dW = ((p[0] @ p[1]) * (p[2] @ p[3])).reshape(W.shape)
+        else:
+            raise KeyError(self.algo)
+        delta_w = (W + dW.to(W.dtype)) - W
+        s = self.spec
+        if s["kind"] == "linear":
+            return F.linear(self.x, delta_w)
+        return F.conv2d(self.x, delta_w, None, s["stride"], s["pad"])
+
+
+def build_instances(args, dtype, dev):
     gen = torch.Generator(device=dev).manual_seed(1234)
-    layers = []
-    for spec in sdxl_unet_layers(1):
-        if which == "linear" and spec["kind"] != "linear":
+    insts = []
+    for spec, algo, count in layer_specs(args.model, args.algo):
+        if args.layers == "linear" and spec["kind"] != "linear":
             continue
-        if which == "conv" and spec["kind"] != "conv":
+        if args.layers == "conv" and spec["kind"] != "conv":
             continue
-        # one Layer object (static tensors) per *distinct* shape; `count` instances share the activations but own
-        # their parameters would cost 788 x activations; instead every instance has its own parameters + grads
-        # (what DP all-reduces and AdamW updates) and shares the activation buffers of its shape.
-        proto = Layer(spec, algo, dtype, dev, gen)
-        layers.append((proto, spec["count"]))
-    return layers
+        first = None
+        for _ in range(count):
+            inst = Inst(spec, algo, dtype, dev, gen, share=first if args.shared_inputs else None)
+            first = first or inst
+            insts.append(inst)
+    return insts
 
 
+def forward_all(insts):
+    return [(it.forward(), it) for it in insts]
+
+
+def backward_range(outs, lo, hi):
+    """backward of outs[lo:hi] in reverse order.  autograd.grad instead of .backward(): dx is produced and dropped (a
+    real UNet hands it to the previous layer); the factor gradients go straight into the arena (fused accumulation)."""
+    for y, it in reversed(outs[lo:hi]):
+        torch.autograd.grad(y, [it.x], it.g)
+
+
+def lib_sha():
+    from lycoris_amd import _native
+    h = hashlib.sha256()
+    with open(_native.lib_path(), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,74 +246,71 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
 
-    from lycoris_amd import ops
     from lycoris_amd.grad_sync import AdapterGradSync
 
-    protos = build_workload(args.algo, dtype, dev, args.layers)
-    # every one of the 788 layer instances owns its parameters (DP payload / optimizer state are full size)
-    instances = []
-    for proto, count in protos:
-        for i in range(count):
-            params = proto.params if i == 0 else [torch.nn.Parameter(p.detach().clone()) for p in proto.params]
-            instances.append((proto, params))
-    all_params = [p for _, ps in instances for p in ps]
+    insts = build_instances(args, dtype, dev)
+    all_params = [p for it in insts for p in it.params]
     sync = AdapterGradSync(all_params, bucket_bytes=32 << 20)
-    ops.fused_grad_accumulation(True)
+    sync.attach_fused()  # kernels accumulate into the arena and report to the bucket counters (eager: overlap by hooks)
     opt = torch.optim.AdamW(all_params, lr=1e-4, fused=True)
-    n_layers = len(instances)
-
-    def compute_pass():
-        """adapter forward of every layer, then backward of every layer (reverse order), grads += into the arena"""
-        outs = []
-        for proto, params in instances:
-            saved = proto.params
-            proto.params = params
-            outs.append((proto.forward(), proto))
-            proto.params = saved
-        # dx is computed and handed back; the factor gradients are accumulated into the arena by the kernels themselves.
-        # (autograd.grad instead of .backward(): the layer instances of one shape share their activation buffers, and
-        # .backward() would add an artificial "x.grad += dx" elementwise kernel per layer on top of the hot path.)
-        for y, proto in reversed(outs):
-            torch.autograd.grad(y, [proto.x], proto.g)
+    n_layers = len(insts)
+    act_bytes = sum(t.numel() * t.element_size() for it in insts for t in {id(it.x): it.x, id(it.g): it.g}.values())
 
     if args.pmc_pass:
         for _ in range(args.pmc_pass):
             sync.zero_grad()
-            compute_pass()
+            backward_range(forward_all(insts), 0, n_layers)
+            sync.finish()
         torch.cuda.synchronize()
-        return
-    if args.profile_ops:
-        from torch.profiler import ProfilerActivity, profile
-        sync.zero_grad()
-        compute_pass()
-        torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-            compute_pass()
-            torch.cuda.synchronize()
-        print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))
         return
 
-    # ---- capture one step's compute in a hipGraph -------------------------------------------------------------
+    # ---- one step, eager (Python-driven; collectives launched from inside the backward by the bucket counters) --------
+    def eager_step():
+        sync.zero_grad()
+        backward_range(forward_all(insts), 0, n_layers)
+        sync.finish()
+        opt.step()
+
+    # ---- one step, captured: forward graph + K backward segment graphs; between the segments the buckets whose
+    #      gradients are complete are all-reduced on the side stream (N > 1), overlapping the later segments ----------
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        sync.zero_grad()
-        compute_pass()  # eager warm-up (allocator, lazy init)
+        eager_step()  # warm-up (allocator, lazy init)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    sync.zero_grad()
-    with torch.cuda.graph(graph):
-        for arena in sync.arenas.values():
-            arena.zero_()
-        compute_pass()
 
-    def step():
-        graph.replay()
-        if world > 1:  # mean all-reduce of the arena buckets on the side stream, joined before the optimizer
-            sync.all_reduce_now()
+    graphs, seg_bounds = [], []
+    if not args.eager:
+        sync._sync_enabled = False  # inside a capture nothing may be launched from the callbacks
+        pool = torch.cuda.graph_pool_handle()
+        g_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_fwd, pool=pool):
+            for arena in sync.arenas.values():
+                arena.zero_()
+            outs = forward_all(insts)
+        nseg = max(1, min(args.segments if world > 1 else 1, n_layers))
+        edges = [round(i * n_layers / nseg) for i in range(nseg + 1)]
+        for s in range(nseg, 0, -1):  # backward runs from the last layer to the first
+            lo, hi = edges[s - 1], edges[s]
+            gph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gph, pool=pool):
+                backward_range(outs, lo, hi)
+            graphs.append(gph)
+            seg_bounds.append(insts[lo - 1].params[-1] if lo > 0 else None)  # first parameter NOT yet finished
+        sync._sync_enabled = True
+
+        def step():
+            sync._reset_pending()
+            g_fwd.replay()
+            for gph, upto in zip(graphs, seg_bounds):
+                gph.replay()
+                if world > 1:
+                    sync.launch_ready(upto)  # side stream: waits for this segment, runs beside the next ones
             sync.finish()
-        opt.step()
+            opt.step()
+    else:
+        step = eager_step
 
     def barrier():
         torch.cuda.synchronize()
@@ -224,45 +331,64 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * args.steps / elapsed  # whole-job: every rank processes its own batch (weak scaling)
+    value = world * args.steps / elapsed  # whole job: every rank processes its own batch (weak scaling)
 
+    model_name = "SDXL UNet 1024x1024 bs=1/GPU" if args.model == "sdxl" else "SD1.5 UNet 512x512 bs=4/GPU"
+    n_lin = sum(1 for it in insts if it.spec["kind"] == "linear")
     result = {
-        "metric": "SDXL UNet adapter train steps/sec (bs=1/GPU), " + ALGO_LABEL[args.algo], "value": round(value, 3),
-        "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": f"{'SDXL' if args.model == 'sdxl' else 'SD1.5'} UNet adapter train steps/sec "
+                  f"(bs={'1' if args.model == 'sdxl' else '4'}/GPU), " + ALGO_LABEL[args.algo],
+        "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {
-            "workload": "SDXL UNet 1024x1024 bs=1/GPU, preset full: 788 adapted layers (739 Linear + 49 Conv2d), "
-                        "adapter fwd+bwd + grad all-reduce + fused AdamW; frozen UNet ops not timed",
-            "algo": args.algo, "factor": FACTOR if args.algo == "lokr" else None, "layers": n_layers,
+            "workload": f"{model_name}, preset {'full' if args.algo not in ('ia3', 'mixed') else args.algo}: {n_layers} adapted "
+                        f"layers ({n_lin} Linear + {n_layers - n_lin} Conv2d), adapter fwd+bwd + grad all-reduce + fused "
+                        "AdamW; frozen UNet ops not timed (see base_plus_adapter)",
+            "algo": args.algo, "factor": FACTOR if args.algo in ("lokr", "mixed") else None, "layers": n_layers,
             "adapter_params": sum(p.numel() for p in all_params), "dp_payload_mb": round(sync.payload_bytes / 2**20, 1),
-            "parallelism": f"dp{world}", "graph": "hipGraph replay of the compute pass",
+            "parallelism": f"dp{world}",
+            "graph": "eager (no capture)" if args.eager else
+                     f"hipGraph replay: 1 forward graph + {len(graphs)} backward segment(s)"
+                     + (", bucket all-reduces issued between segments on a side stream" if world > 1 else ""),
+            "inputs": "shared per shape (cache-resident)" if args.shared_inputs else
+                      f"distinct x / g per layer instance: {act_bytes / 1e9:.2f} GB read per step",
         },
     }
-    if rank == 0 and world == 1 and not args.no_roofline:
-        result["roofline"] = roofline(protos, args.algo, dtype, dev)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.algo)
+    extra = rank == 0 and world == 1 and not args.eager
+    if extra and not args.no_roofline:
+        result["roofline"] = roofline(insts, args, dtype, dev)
+    if extra and not args.no_reference and args.algo in ("lokr", "locon", "loha"):
+        result["reference_rocm_eager"] = reference_leg(insts, sync, ms_per_step)
+    if extra and not args.no_base and args.algo in ("lokr", "locon", "loha"):
+        result["base_plus_adapter"] = base_leg(insts, sync)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.algo in ("lokr", "locon", "loha"):
+        result["cpu_baseline"] = cpu_baseline(args.algo, args.model)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def _timed_graph(issue, dev):
-    """ms per replay of a hipGraph holding the launches `issue(stream_ptr)` makes; HIP events on the launch stream"""
-    from lycoris_amd import _native as N
+# ---------------------------------------------------------------------------------------------------------------------
+# measurement legs (rank 0, N = 1)
+# ---------------------------------------------------------------------------------------------------------------------
+_KEEP = []
+
+
+def _graph_ms(fn, reps=4):
+    """ms per call of `fn` replayed from a hipGraph, HIP events on the stream the graph is launched on"""
     st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
-        sp = N.stream_ptr(dev)
-        issue(sp)  # eager warm-up
+        fn()  # warm-up on this stream
         torch.cuda.synchronize()
         gph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gph, stream=st):
-            issue(sp)
+            fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps, best = 5, float("inf")
         gph.replay()
+        best = float("inf")
         for _ in range(3):
             e0.record(st)
             for _ in range(reps):
@@ -270,169 +396,182 @@ def _timed_graph(issue, dev):
             e1.record(st)
             e1.synchronize()
             best = min(best, e0.elapsed_time(e1) / reps)
+    torch.cuda.current_stream().wait_stream(st)
+    _KEEP.append(gph)  # tensors created during the capture (saved activations of a forward leg) live in its pool
     return best
 
 
-def roofline_locon(protos, dtype, dev):
-    """LoCon: the three launches per adapted Linear layer (`bneck_kernel` forward, `bneck_kernel` backward-dx,
-    `lowrank_tn_kernel` factor gradients), timed as two hipGraphs (all forward launches, all backward launches) with
-    HIP events.  Algorithmic bytes: fwd x + y + t, bwd g + dx + dt, gradients g + x + t + dt, fp32 factors."""
-    from lycoris_amd import _native as N
-    esz = torch.empty((), dtype=dtype).element_size()
-    code = N.dtype_code(dtype)
-    calls, nbytes, n_layers = [], 0, 0
-    for proto, count in protos:
-        s = proto.spec
-        if s["kind"] != "linear":
-            continue
-        M, I, O = layer_rows(s)
-        down = proto.params[0].detach().contiguous()
-        up = proto.params[1].detach().contiguous()
-        r = down.shape[0]
-        rows = proto.x.detach().reshape(-1, I)
-        g = torch.randn(M, O, device=dev, dtype=dtype)
-        y = torch.empty(M, O, device=dev, dtype=dtype)
-        dx = torch.empty(M, I, device=dev, dtype=dtype)
-        t = torch.empty(M, r, device=dev, dtype=torch.float32)
-        dt = torch.empty(M, r, device=dev, dtype=torch.float32)
-        dd, du = torch.zeros_like(down), torch.zeros_like(up)
-        calls.append((count, rows, g, y, dx, down, up, t, dt, dd, du, (M, I, O, r)))
-        fac = 4 * r * (I + O)
-        nbytes += count * (esz * (M * I + M * O) + 4 * M * r + fac)            # forward
-        nbytes += count * (esz * (M * O + M * I) + 4 * M * r + fac)            # backward dx
-        nbytes += count * (esz * (M * O + M * I) + 8 * M * r + 2 * fac)        # factor gradients
-        n_layers += count
-
-    def fwd(sp):
-        for count, rows, g, y, dx, down, up, t, dt, dd, du, (M, I, O, r) in calls:
-            for _ in range(count):
-                N.call("lyc_locon_linear_fwd", N.ptr(rows), N.ptr(down), N.ptr(up), N.ptr(t), N.ptr(y), M, I, O, r, 1.0, code, sp)
-
-    def bwd(sp):
-        for count, rows, g, y, dx, down, up, t, dt, dd, du, (M, I, O, r) in calls:
-            for _ in range(count):
-                N.call("lyc_locon_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(down), N.ptr(up), N.ptr(t), N.ptr(dt), N.ptr(dx),
-                       N.ptr(dd), N.ptr(du), M, I, O, r, 1.0, code, sp)
-
-    t_fwd, t_bwd = _timed_graph(fwd, dev), _timed_graph(bwd, dev)
-    t_ms, n_launch = t_fwd + t_bwd, 3 * n_layers
-    achieved = nbytes / (t_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "lyc::bneck_kernel (forward, backward-dx) + lyc::lowrank_tn_kernel (factor gradients): the "
-                                      "three LoCon launches of the 739 Linear layers",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": PMC_TRAFFIC.get("locon3"), "launches_per_step": n_launch,
-            "avg_launch_us": round(t_ms * 1e3 / n_launch, 2), "algorithmic_bytes_per_launch": int(nbytes / n_launch),
-            "families_ms": {"forward": round(t_fwd, 3), "backward": round(t_bwd, 3)}}
+def _wall_ms(fn, reps=2):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
 
 
-# ------------------------------------------------------------------------------------------------------------------
-def roofline(protos, algo, dtype, dev):
-    """Roofline of the dominant kernel family of the step, measured live with HIP events on the launch stream.
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs, gfx950 corrections per MI355X_MICROARCH.md; benchmarks/pmc_summary.py --json writes the file).  Only
+    trusted when it was collected on THIS build of the library (sha of liblycoris_amd.so recorded in the file)."""
+    try:
+        with open(PMC_FILE) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None, "no profiles/pmc_traffic.json"
+    if rec.get("lib_sha16") != lib_sha():
+        return None, f"profiles/pmc_traffic.json was collected on build {rec.get('lib_sha16')}, this is {lib_sha()}"
+    fam = rec.get("families", {}).get(family)
+    return (int(fam["bytes_per_launch"]) if fam else None), rec.get("source", "profiles/pmc_traffic.json")
 
-    The LoKr step launches two kernel families per adapted Linear layer (Conv2d layers use the same kernels through
-    the pixel-row gather and are left out of this leg: 49 of 788 layers):
-      * `lyc::kron3_kernel`    -- forward, and backward dx (+ w1-gradient partials): HBM-bound (AI 20-200 flop/B);
-      * `lyc::kron_dw2s_kernel` -- w2 gradient (split-K TN GEMM over the M*G rows).
-    Three hipGraphs holding exactly the launches one step makes for the Linear layers (same shapes, same counts, the
-    count instances rotate over distinct factor buffers) are replayed and timed: forward only, dW2 only, whole
-    backward.  kron3 time = forward + (backward - dW2).  The family with the larger time is reported; `achieved` =
-    algorithmic bytes of its launches / its time (activations moved once: fwd x + y, bwd-dx g + x + dx,
-    dW2 g + x, plus the fp32 factors)."""
-    from lycoris_amd import _native as N
-    if algo == "locon":
-        return roofline_locon(protos, dtype, dev)
-    if algo != "lokr":
+
+def roofline(insts, args, dtype, dev):
+    """Roofline of the dominant kernel family of the step's nn.Linear launches (the Conv2d layers run the same kernels
+    through the pixel-row gather), measured live: hipGraphs holding exactly those launches -- forward only, backward only --
+    replayed and timed with HIP events on the launch stream.  Every instance reads its own x / g.
+
+    HBM-bound algorithms (LoKr, LoCon, (IA)^3): achieved = algorithmic bytes (fwd x + y, bwd g + x + dx,
+    fp32 factors once per pass) / time.  LoHa is MFMA-bound: achieved = useful flops 3 * 2 * M * O * I / time."""
+    from lycoris_amd import ops
+    algo = args.algo
+    lin = [it for it in insts if it.spec["kind"] == "linear" and it.algo == (algo if algo != "mixed" else "lokr")]
+    if not lin:
         return None
     esz = torch.empty((), dtype=dtype).element_size()
-    code = N.dtype_code(dtype)
-    calls, bytes_fwd, bytes_dx, bytes_dw2, n_layers = [], 0, 0, 0, 0
-    for proto, count in protos:
-        s = proto.spec
-        if s["kind"] != "linear":
+    core = {"lokr": ops._LokrCore, "locon": ops._LoconCore, "loha": ops._LohaCore}.get(lin[0].algo)
+    calls, b_fwd, b_bwd, flops = [], 0, 0, 0
+    for it in lin:
+        M, I, O = layer_rows(it.spec)
+        nfac = 4 * sum(p.numel() for p in it.params)
+        if it.algo == "ia3":
+            C = it.params[0].numel()
+            b_fwd += esz * 2 * M * C + nfac
+            b_bwd += esz * 3 * M * C + 2 * nfac
             continue
-        M, I, O = layer_rows(s)
-        w1 = proto.params[0].detach().contiguous()
-        w2 = proto.params[1].detach().contiguous()
-        a, b = w1.shape
-        c, d = w2.shape
-        rows = proto.x.detach().reshape(-1, I)
-        g = torch.randn(M, O, device=dev, dtype=dtype)
-        y = torch.empty(M, O, device=dev, dtype=dtype)
-        dx = torch.empty(M, I, device=dev, dtype=dtype)
-        dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
-        ws = torch.empty(int(N.load().lyc_lokr_bwd_workspace_bytes(M, a, b, c, d, code)) + 16, dtype=torch.uint8, device=dev)
-        calls.append((count, rows, g, y, dx, w1, w2, dw1, dw2, ws, (M, a, b, c, d)))
-        fac = 4 * (a * b + c * d)
-        bytes_fwd += count * (esz * (M * I + M * O) + fac)
-        bytes_dx += count * (esz * (M * O + 2 * M * I) + fac)
-        bytes_dw2 += count * (esz * (M * O + M * I) + fac)
-        n_layers += count
-    st = torch.cuda.Stream()
+        fs = [ops._f32c(p) for p in it.params]
+        rows = it.x.detach().reshape(-1, I)
+        bufs = [torch.zeros_like(f) for f in fs]
+        calls.append((it, rows, it.g.reshape(-1, O), fs, bufs))
+        b_fwd += esz * (M * I + M * O) + nfac
+        b_bwd += esz * (M * O + 2 * M * I) + 2 * nfac
+        flops += 3 * 2 * M * O * I
+    saved = {}
 
-    def timed(issue):
-        with torch.cuda.stream(st):
-            sp = N.stream_ptr(dev)
-            issue(sp)  # eager warm-up
-            torch.cuda.synchronize()
-            gph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gph, stream=st):
-                issue(sp)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps, best = 5, float("inf")
-            gph.replay()
-            for _ in range(3):
-                e0.record(st)
-                for _ in range(reps):
-                    gph.replay()
-                e1.record(st)
-                e1.synchronize()
-                best = min(best, e0.elapsed_time(e1) / reps)
-        return best  # ms per pass over all Linear layers
+    def fwd():
+        if core is None:  # ia3
+            for it in lin:
+                saved[id(it)] = it.forward()
+            return
+        for it, rows, g, fs, bufs in calls:
+            saved[id(it)] = core.fwd(rows, fs, 1.0)
 
-    def fwd(sp):
-        for count, rows, g, y, dx, w1, w2, dw1, dw2, ws, (M, a, b, c, d) in calls:
-            for _ in range(count):
-                N.call("lyc_lokr_linear_fwd", N.ptr(rows), N.ptr(w1), N.ptr(w2), N.ptr(y), M, a, b, c, d, 1.0, code, sp)
+    def bwd():
+        if core is None:
+            for it in lin:
+                torch.autograd.grad(saved[id(it)], [it.x] + it.params, it.g, retain_graph=True)
+            return
+        for it, rows, g, fs, bufs in calls:
+            core.bwd(g, rows, fs, saved[id(it)][1], 1.0, True, [True] * len(fs), False, bufs)
 
-    def only_dw2(sp):
-        for count, rows, g, y, dx, w1, w2, dw1, dw2, ws, (M, a, b, c, d) in calls:
-            for _ in range(count):
-                N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(w1), N.ptr(w2), None, None, N.ptr(dw2), None,
-                       M, a, b, c, d, 1.0, code, sp)
-
-    def bwd(sp):
-        for count, rows, g, y, dx, w1, w2, dw1, dw2, ws, (M, a, b, c, d) in calls:
-            for _ in range(count):
-                N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(w1), N.ptr(w2), N.ptr(dx), N.ptr(dw1),
-                       N.ptr(dw2), N.ptr(ws), M, a, b, c, d, 1.0, code, sp)
-
-    t_fwd, t_dw2, t_bwd = timed(fwd), timed(only_dw2), timed(bwd)
-    t_k3 = t_fwd + max(t_bwd - t_dw2, 0.0)
-    fam = {
-        "kron3": ("lyc::kron3_kernel (LoKr forward + backward-dx/dW1 launches of the 739 Linear layers)", t_k3,
-                  bytes_fwd + bytes_dx, 2 * n_layers),
-        "dw2s": ("lyc::kron_dw2s_kernel (LoKr dW2 launches of the 739 Linear layers)", t_dw2, bytes_dw2, n_layers),
-    }
-    key = "kron3" if t_k3 >= t_dw2 else "dw2s"
-    name, t_ms, nbytes, n_launch = fam[key]
-    achieved = nbytes / (t_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC.get(key),
-            "launches_per_step": n_launch, "avg_launch_us": round(t_ms * 1e3 / n_launch, 2),
-            "algorithmic_bytes_per_launch": int(nbytes / n_launch),
-            "families_ms": {"kron3_fwd": round(t_fwd, 3), "kron3_bwd": round(max(t_bwd - t_dw2, 0.0), 3),
-                            "dw2s": round(t_dw2, 3)},
-            "hot_path_gbs": round((bytes_fwd + bytes_dx) / ((t_fwd + t_bwd) * 1e-3) / 1e9, 1)}
+    t_fwd = _graph_ms(fwd)
+    t_bwd = _graph_ms(bwd)
+    t_ms = t_fwd + t_bwd
+    n_l = len(lin)
+    launches = {"lokr": 3, "locon": 3, "loha": 7, "ia3": 3}[lin[0].algo]  # kernel launches per layer, fwd + bwd
+    out = {"families_ms": {"forward": round(t_fwd, 3), "backward": round(t_bwd, 3)}, "layers": n_l,
+           "launches_per_layer": launches, "avg_launch_us": round(t_ms * 1e3 / (launches * n_l), 2)}
+    if lin[0].algo == "loha":
+        ach = flops / (t_ms * 1e-3) / 1e12
+        out.update({"bound": "mfma", "kernel": "LoHa dense contractions y = x dW^T, dx = g dW, G = g^T x of the Linear layers "
+                                              "(+ dW rebuild and Hadamard chain rule)",
+                    "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "algorithmic_flops_per_layer": int(flops / n_l)})
+        return out
+    fam = {"lokr": "lokr_linear", "locon": "locon_linear", "ia3": "ia3"}[lin[0].algo]
+    nbytes = b_fwd + b_bwd
+    ach = nbytes / (t_ms * 1e-3) / 1e9
+    traffic, src = pmc_traffic(fam)
+    out.update({"bound": "hbm",
+                "kernel": {"lokr": "lyc::kron3_kernel (forward, backward dx + dW1) + lyc::kron_dw2s_kernel (dW2): the LoKr "
+                                   "launches of the Linear layers",
+                           "locon": "lyc::bneck_kernel (forward, backward-dx) + lyc::lowrank_tn_kernel (factor gradients)",
+                           "ia3": "lyc::chan_scale_kernel / lyc::chan_reduce_kernel"}[lin[0].algo],
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_source": src,
+                "algorithmic_bytes_per_launch": int(nbytes / (launches * n_l)),
+                "forward_gbs": round(b_fwd / (t_fwd * 1e-3) / 1e9, 1), "backward_gbs": round(b_bwd / (t_bwd * 1e-3) / 1e9, 1)})
+    return out
 
 
-def cpu_baseline(algo):
-    """The reference's CPU path (rebuild: kron -> dense op -> autograd), restated in oracle/torch_cpu.py, timed on the
-    host cores of this box on a bounded sample: one instance of every distinct Linear shape and of the 3x3/1x1 conv
-    shapes with <= 4096 output pixels, fp32; the step time is extrapolated with the per-shape counts (the skipped
-    large-conv shapes are charged at the cost of the largest measured conv per output pixel)."""
+def reference_leg(insts, sync, native_graph_ms):
+    """The north-star comparator: the reference's rebuild call sequence (Inst.reference_forward) through stock
+    PyTorch-ROCm on this GPU over the same layer instances, like for like: eager vs eager (Python-driven, what an
+    sd-scripts user gets without whole-step capture) and hipGraph vs hipGraph (kernel time)."""
+    def ref_pass():
+        outs = [(it.reference_forward(), it) for it in insts]
+        for y, it in reversed(outs):
+            torch.autograd.grad(y, [it.x] + it.params, it.g)
+
+    def nat_pass():
+        backward_range(forward_all(insts), 0, len(insts))
+
+    sync._sync_enabled = False
+    try:
+        ref_eager = _wall_ms(ref_pass)
+        nat_eager = _wall_ms(nat_pass)
+        ref_graph = _graph_ms(ref_pass, reps=2)
+        nat_graph = _graph_ms(nat_pass, reps=2)
+    finally:
+        sync._sync_enabled = True
+        for it in insts:
+            it.W = None
+        torch.cuda.empty_cache()
+    return {"what": "adapter fwd+bwd of all layers, reference torch call sequence (kron / matmul -> W + dW - W -> "
+                    "F.linear / F.conv2d -> autograd) vs native ops, same tensors, same GPU",
+            "reference_eager_ms": round(ref_eager, 2), "native_eager_ms": round(nat_eager, 2),
+            "reference_graph_ms": round(ref_graph, 2), "native_graph_ms": round(nat_graph, 2),
+            "speedup_eager_vs_eager": round(ref_eager / nat_eager, 2),
+            "speedup_graph_vs_graph": round(ref_graph / nat_graph, 2)}
+
+
+def base_leg(insts, sync):
+    """the step with the frozen layers' own ops in it (rocBLAS / MIOpen forward + dx-only backward), next to
+    the adapter-only number: base alone, and base + adapter (out = base + delta, one autograd.grad for both)."""
+    def base_pass():
+        outs = [(it.base_forward(), it) for it in insts]
+        for y, it in reversed(outs):
+            torch.autograd.grad(y, [it.x], it.g)
+
+    def both_pass():
+        outs = [(it.base_forward() + it.forward(), it) for it in insts]
+        for y, it in reversed(outs):
+            torch.autograd.grad(y, [it.x], it.g)
+
+    sync._sync_enabled = False
+    try:
+        t_base = _graph_ms(base_pass, reps=2)
+        t_both = _graph_ms(both_pass, reps=2)
+    finally:
+        sync._sync_enabled = True
+        for it in insts:
+            it.W = None
+        torch.cuda.empty_cache()
+    return {"base_only_ms": round(t_base, 2), "base_plus_adapter_ms": round(t_both, 2),
+            "adapter_share": round(max(t_both - t_base, 0.0) / t_both, 3),
+            "what": "frozen F.linear / F.conv2d forward + input-gradient backward of the same layers (random bf16 weights)"}
+
+
+def cpu_baseline(algo, model):
+    """The reference's CPU path (rebuild: dW -> dense op -> autograd), restated in oracle/torch_cpu.py, timed on the host
+    cores of this box on a BOUNDED sample (~15 s): one instance of every distinct Linear shape, fp32 and bf16, 3 reps
+    after a warm-up; conv shapes with <= 4096 output pixels once in fp32 while the budget lasts.  The step time is
+    extrapolated with the per-shape counts (unmeasured conv shapes charged at the measured per-MAC conv cost)."""
     from oracle import torch_cpu
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)  # beyond ~64 threads the small GEMMs only oversubscribe
     torch.set_num_threads(cores)
+    specs = sdxl_unet_layers(1) if model == "sdxl" else sd15_unet_layers(4)
 
     def factors(spec):
         if spec["kind"] == "linear":
@@ -448,22 +587,47 @@ def cpu_baseline(algo):
         return [torch.randn(O, 32) * 0.1, torch.randn(32, cin * kk), torch.randn(O, 32) * 0.1, torch.randn(32, cin * kk)]
 
     t_start = time.perf_counter()
-    total, measured, skipped_px, px_cost = 0.0, 0, 0, 0.0
-    for spec in sdxl_unet_layers(1):
-        M, _, _ = layer_rows(spec)
-        if spec["kind"] == "conv" and (M > 4096 or time.perf_counter() - t_start > 25.0):
-            skipped_px += spec["count"] * M * spec["C"] * spec["O"] * spec["k"] ** 2
+    budget = 18.0
+    tot = {"fp32": 0.0, "bf16": 0.0}
+    seen, measured, conv_macs_left, mac_cost = {}, 0, 0, 0.0
+    r16 = [0.0, 0.0]  # bf16 / fp32 seconds over the shapes timed in both
+    for spec in specs:
+        M, Ie, O = layer_rows(spec)
+        macs = spec["count"] * M * Ie * O
+        key = (spec["kind"], M, Ie, O, spec.get("stride", 1))
+        if key in seen:
+            tot["fp32"] += seen[key]["fp32"] * spec["count"]
+            tot["bf16"] += (seen[key]["bf16"] if seen[key]["bf16"] is not None else float("nan")) * spec["count"]
             continue
-        t = torch_cpu.time_layer(algo, spec, factors, torch.float32, reps=1)
-        total += t * spec["count"]
+        over = time.perf_counter() - t_start > budget
+        if spec["kind"] == "conv" and (M > 4096 or over):
+            conv_macs_left += macs
+            continue
+        if over:
+            conv_macs_left += macs  # charged like a conv MAC (pessimistic for the few remaining Linear shapes)
+            continue
+        t32 = torch_cpu.time_layer(algo, spec, factors, torch.float32, reps=3 if spec["kind"] == "linear" else 1)
+        t16 = None
+        if spec["kind"] == "linear" and t32 < 0.4 and time.perf_counter() - t_start < budget * 0.6:
+            t16 = torch_cpu.time_layer(algo, spec, factors, torch.bfloat16, reps=3)
+            r16[0] += t16
+            r16[1] += t32
+        seen[key] = {"fp32": t32, "bf16": t16}
+        tot["fp32"] += t32 * spec["count"]
+        tot["bf16"] += (t16 if t16 is not None else float("nan")) * spec["count"]
         measured += 1
         if spec["kind"] == "conv":
-            px_cost = max(px_cost, t / (M * spec["C"] * spec["O"] * spec["k"] ** 2))
-    total += skipped_px * px_cost
-    return {"value": round(1.0 / total, 5), "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/torch_cpu.py (reference rebuild path restated in torch CPU ops), fp32, {measured} distinct layer "
-                      f"shapes timed once (best of 2) in {time.perf_counter() - t_start:.1f}s, extrapolated by shape counts "
-                      "to the 788-layer step; conv shapes with > 4096 output pixels charged pro rata"}
+            mac_cost = max(mac_cost, t32 / (M * Ie * O))
+    tot["fp32"] += conv_macs_left * mac_cost
+    # bf16: shapes not timed in bf16 (convs, slow or late shapes) are scaled by the measured bf16 / fp32 ratio
+    ratio16 = r16[0] / r16[1] if r16[1] > 0 else None
+    return {"value": round(1.0 / tot["fp32"], 5), "unit": "steps/s", "cores": cores, "kind": "port",
+            "bf16_over_fp32_time_ratio": round(ratio16, 3) if ratio16 else None,
+            "bf16_value": round(1.0 / (tot["fp32"] * ratio16), 5) if ratio16 else None,
+            "sample": f"oracle/torch_cpu.py (reference rebuild path restated in torch CPU ops), {measured} distinct layer shapes "
+                      f"(Linear: fp32 and bf16, best of 3 after a warm-up; small convs once, fp32) in "
+                      f"{time.perf_counter() - t_start:.1f}s, extrapolated by shape counts to the whole step; conv shapes with "
+                      "> 4096 output pixels charged per MAC at the slowest measured conv"}
 
 
 if __name__ == "__main__":

@@ -32,7 +32,47 @@ def short(name):
     return name[:60]
 
 
+# kernel families of bench.py's roofline legs: every launch the Linear layers of one algorithm make
+FAMILIES = {
+    "lokr_linear": ("kron3_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "kron_kernel", "kron_dw2_kernel", "kron_bwd"),
+    "locon_linear": ("bneck_kernel", "lowrank_tn_kernel", "skinny_", "expand_nt"),
+}
+CAL_R, CAL_W = 2047.96, 1024.0  # bytes per counter unit, calibrated on a 1 GiB copy (profiles/r01_pmc_kbench.txt)
+
+
+def family_json(out_path, triples):
+    """--json OUT algo fetch_dir write_dir [algo fetch_dir write_dir ...]: bytes per launch per family + the build's sha"""
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "lycoris_amd", "liblycoris_amd.so"), "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()[:16]
+    rec = {"lib_sha16": sha, "families": {},
+           "source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
+                     "`bench.py --algo A --pmc-pass 1 --layers linear` (benchmarks/pmc_traffic.sh); read 2048 B/unit "
+                     "(the gfx950 1/2 correction of FETCH_SIZE), write 1024 B/unit, calibrated on a 1 GiB copy"}
+    for algo, fdir, wdir in triples:
+        fetch, write = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
+        keys = FAMILIES[algo + "_linear"]
+        fs = [v for k, vs in fetch.items() if any(x in k for x in keys) for v in vs]
+        ws_ = [v for k, vs in write.items() if any(x in k for x in keys) for v in vs]
+        if not fs or not ws_:
+            continue
+        n = max(len(fs), len(ws_))
+        rec["families"][algo + "_linear"] = {
+            "launches": n, "read_bytes": sum(fs) * CAL_R, "write_bytes": sum(ws_) * CAL_W,
+            "bytes_per_launch": (sum(fs) * CAL_R + sum(ws_) * CAL_W) / n,
+            "kernels": sorted({short(k) for k in list(fetch) + list(write) if any(x in k for x in keys)})}
+    with open(out_path, "w") as f:
+        json.dump(rec, f, indent=1)
+    print(json.dumps(rec, indent=1))
+
+
 def main():
+    if sys.argv[1] == "--json":
+        rest = sys.argv[3:]
+        family_json(sys.argv[2], [tuple(rest[i:i + 3]) for i in range(0, len(rest), 3)])
+        return
     fdir, wdir = sys.argv[1], sys.argv[2]
     fetch, write = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
     gib = float(1 << 30)

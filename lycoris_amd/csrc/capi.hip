@@ -987,7 +987,10 @@ size_t esize(int dtype) { return (dtype & 0xff) == LYC_F32 ? 4 : 2; }
 // (hand-written kernels are for the fused / factored ops).  Row-major C[m, n] = op(A) op(B) is issued as the
 // column-major product C^T = op(B)^T op(A)^T.  One handle per host thread; calls only enqueue on `st`.
 rocblas_handle rb_handle(hipStream_t st) {
-  thread_local rocblas_handle h = nullptr;
+  thread_local rocblas_handle handles[16] = {nullptr};  // one per (host thread, device): a handle is bound to its device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  rocblas_handle& h = handles[dev];
   if (!h) {
     if (rocblas_create_handle(&h) != rocblas_status_success) {
       h = nullptr;

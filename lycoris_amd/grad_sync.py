@@ -11,6 +11,11 @@ every gradient into bucket buffers and back.  Here the adapter gradients *live* 
     ``torch.distributed`` (backend "nccl" is RCCL on ROCm) on a dedicated side HIP stream, overlapping the rest of
     the frozen model's backward; no staging copies;
   * ``finish()`` joins the side stream (event wait, no host sync) before the optimizer step.
+  * gradient accumulation: every backward but the last of an optimizer step runs inside ``no_sync()`` (same contract
+    as DDP); a second un-guarded backward after a bucket has been reduced raises instead of letting replicas diverge.
+  * the kernels' fused accumulation (``ops.fused_grad_accumulation``) bypasses the autograd hooks; ``attach_fused()``
+    routes its per-parameter notification to the same bucket counters, so the collectives are launched from inside
+    the backward pass there too.
 
 The frozen base model is never touched: only adapter parameters are registered.  Do NOT also wrap the network in
 DDP.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by one link, so buckets are
@@ -20,6 +25,7 @@ Works on CPU tensors with the gloo backend too (that is how tests/test_grad_sync
 """
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass, field
 from typing import Iterable, List, Optional
 
@@ -27,12 +33,14 @@ import torch
 import torch.distributed as dist
 
 
-@dataclass
+@dataclass(eq=False)
 class _Bucket:
     flat: torch.Tensor            # slice of the arena
     n_params: int
     pending: int = 0
     work: Optional[object] = None
+    launched: bool = False
+    index: int = 0
     params: List[torch.nn.Parameter] = field(default_factory=list)
 
 
@@ -54,6 +62,8 @@ class AdapterGradSync:
         self.buckets: List[_Bucket] = []
         self._bucket_of = {}
         self._handles = []
+        self._sync_enabled = True
+        self.launch_log: List[int] = []  # bucket indices in launch order of the current step (tests / diagnostics)
         # reverse registration order: the last layers' gradients are ready first during backward
         by_dtype = {}
         for p in reversed(self.params):
@@ -84,7 +94,7 @@ class AdapterGradSync:
 
     # ---- construction helpers --------------------------------------------------------------------------------
     def _close_bucket(self, arena, start, end, members):
-        b = _Bucket(flat=arena[start:end], n_params=len(members), params=list(members))
+        b = _Bucket(flat=arena[start:end], n_params=len(members), params=list(members), index=len(self.buckets))
         for p in members:
             self._bucket_of[p] = b
         self.buckets.append(b)
@@ -93,6 +103,8 @@ class AdapterGradSync:
         for b in self.buckets:
             b.pending = b.n_params
             b.work = None
+            b.launched = False
+        self.launch_log = []
 
     # ---- per-step API ------------------------------------------------------------------------------------------
     @property
@@ -124,13 +136,40 @@ class AdapterGradSync:
                 p.grad = arena[off:off + n].as_strided(p.shape, p.stride()) if dense else arena[off:off + n].view_as(p)
                 off += n
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside this context only accumulate into the arena; the backward
+        that runs outside it (the last micro-batch) counts the gradients and launches the collectives."""
+        prev, self._sync_enabled = self._sync_enabled, False
+        try:
+            yield
+        finally:
+            self._sync_enabled = prev
+
+    def attach_fused(self, enabled: bool = True):
+        """Let the kernels accumulate factor gradients straight into the arena (``ops.fused_grad_accumulation``) and
+        report each finished parameter to the bucket counters, exactly like the autograd hook would."""
+        from . import ops
+        ops.fused_grad_accumulation(enabled, callback=self._on_grad_ready if enabled else None)
+
     def _on_grad_ready(self, p):
-        b = self._bucket_of[p]
+        if not self._sync_enabled:
+            return
+        b = self._bucket_of.get(p)
+        if b is None:
+            return
+        if b.launched:
+            raise RuntimeError(
+                "AdapterGradSync: a gradient arrived for a bucket that was already all-reduced in this step. "
+                "With gradient accumulation run every backward but the last inside `with sync.no_sync():`, and call "
+                "finish() (or zero_grad()) once per optimizer step.")
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
 
     def _launch(self, b: _Bucket):
+        b.launched = True
+        self.launch_log.append(b.index)
         if self.world_size == 1:
             return
         if self.side_stream is not None:
@@ -156,15 +195,26 @@ class AdapterGradSync:
         """Launch the collective of every bucket that has not been launched in this step -- for callers whose backward
         does not fire the autograd hooks (fused accumulation straight into the arena, or a replayed hipGraph)."""
         for b in self.buckets:
-            if b.pending > 0 or b.work is None:
+            if not b.launched:
                 b.pending = 0
                 self._launch(b)
+
+    def launch_ready(self, upto_param=None):
+        """Graph-replay callers (no hooks fire inside a hipGraph): launch the collective of every not-yet-launched
+        bucket whose parameters all come before ``upto_param`` in backward order (None = all of them)."""
+        for b in self.buckets:
+            if b.launched:
+                continue
+            if upto_param is not None and any(q is upto_param for q in b.params):
+                break
+            b.pending = 0
+            self._launch(b)
 
     def finish(self):
         """Call after backward, before optimizer.step(): flushes buckets whose hooks did not all fire (unused
         parameters) and makes the compute stream wait for the collectives."""
         for b in self.buckets:
-            if b.pending > 0:  # not every hook fired (unused parameters, or gradients written by fused accumulation)
+            if not b.launched:  # not every hook fired (unused parameters, no_sync micro-batches, graph replays)
                 b.pending = 0
                 self._launch(b)
         for b in self.buckets:
@@ -173,7 +223,6 @@ class AdapterGradSync:
                 b.work = None
         if self.side_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
-        self._reset_pending()
         self._reset_pending()
 
     def remove(self):

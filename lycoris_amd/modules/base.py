@@ -57,6 +57,13 @@ class LycorisBaseModule(nn.Module):
             self.dim = org_module.out_channels
             self.kw_dict = {"stride": org_module.stride, "padding": org_module.padding,
                             "dilation": org_module.dilation, "groups": org_module.groups}
+            if nd == 2:
+                # fail when the network is BUILT (not at the first training step) for layer variants the kernels do not
+                # take: grouped convolutions, padding="same"/"valid" strings, non-zero padding modes
+                from ..functional.general import conv_args
+                conv_args(self.kw_dict)
+                if getattr(org_module, "padding_mode", "zeros") != "zeros":
+                    raise _unsupported(f"Conv2d padding_mode={org_module.padding_mode!r}")
         elif isinstance(org_module, nn.LayerNorm):
             self.module_type = "layernorm"
             self.shape = tuple(org_module.normalized_shape)

@@ -61,6 +61,16 @@ def _finish_grads(factors, bufs, hand_back):
     return out
 
 
+def _amp(x: torch.Tensor) -> torch.Tensor:
+    """torch.autocast parity with the reference: its F.linear / F.conv2d run in the autocast dtype (modules/locon.py:
+    321-331 under sd-scripts mixed precision: fp32 LayerNorm output in, bf16 delta out).  The native ops take the
+    activation dtype from x, so an fp32 x is cast here (differentiably: dx comes back in fp32) -- the adapter then runs
+    the 16-bit fast path and `base + delta` stays in the autocast dtype.  Factors are left in fp32."""
+    if x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled("cuda"):
+        return x.to(torch.get_autocast_dtype("cuda"))
+    return x
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     t = t.detach()
     if t.dtype != torch.float32:
@@ -517,9 +527,9 @@ class _ChanAffine(torch.autograd.Function):
             da = torch.empty_like(g)
             N.call("lyc_chan_scale", N.ptr(g), N.ptr(wf), None, N.ptr(da), outer, C, inner, s0, mult, code, st)
         if ctx.needs_input_grad[1]:
-            dwf = torch.zeros(C, dtype=torch.float32, device=a.device)
+            (dwf,), hb = _grad_targets([w], [True])  # the reduction kernel adds into its output: straight into w.grad
             N.call("lyc_chan_reduce", N.ptr(g), N.ptr(a), N.ptr(bf), N.ptr(dwf), outer, C, inner, mult, code, st)
-            dw = dwf.reshape(w.shape).to(w.dtype)
+            dw = _finish_grads([w], [dwf], hb)[0]
         return da, dw, None, None, None, None
 
 
@@ -528,21 +538,21 @@ class _ChanAffine(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------------------
 def lokr_linear(x, w1, w2, alpha=1.0):
     """w1:[a,b]  w2:[c,d]  x:[..., b*d] -> [..., a*c]"""
-    return _AdapterLinear.apply(_LokrCore, alpha, x, w1, w2)
+    return _AdapterLinear.apply(_LokrCore, alpha, _amp(x), w1, w2)
 
 
 def locon_linear(x, down, up, alpha=1.0):
     """down:[r,I]  up:[O,r]"""
-    return _AdapterLinear.apply(_LoconCore, alpha, x, down, up)
+    return _AdapterLinear.apply(_LoconCore, alpha, _amp(x), down, up)
 
 
 def loha_linear(x, w1a, w1b, w2a, w2b, alpha=1.0):
     """w*a:[O,r]  w*b:[r,I]"""
-    return _AdapterLinear.apply(_LohaCore, alpha, x, w1a, w1b, w2a, w2b)
+    return _AdapterLinear.apply(_LohaCore, alpha, _amp(x), w1a, w1b, w2a, w2b)
 
 
 def chan_affine(a, w, bias=None, s0=0.0, mult=1.0, chan_dim=-1):
-    return _ChanAffine.apply(a, w, bias, s0, mult, chan_dim)
+    return _ChanAffine.apply(_amp(a), w, bias, s0, mult, chan_dim)
 
 
 def _geom(ksize, stride, padding, dilation):
@@ -552,6 +562,7 @@ def _geom(ksize, stride, padding, dilation):
 def locon_conv2d(x, down, up, alpha, stride, padding, dilation):
     """down:[r, I, kh, kw]  up:[O, r, 1, 1]"""
     r, O = down.shape[0], up.shape[0]
+    x = _amp(x)
     geom = _geom(down.shape[2:], stride, padding, dilation)
     if x.dim() == 4 and not _is_pointwise(geom) and _locon_conv_implicit_ok(x, down, up):
         return _LoconConv2dImplicit.apply(alpha, geom, x, down, up)
@@ -560,13 +571,14 @@ def locon_conv2d(x, down, up, alpha, stride, padding, dilation):
 
 def loha_conv2d(x, w1a, w1b, w2a, w2b, alpha, shape, stride, padding, dilation):
     """w*a:[O, r]  w*b:[r, I*kh*kw];  shape = (O, I, kh, kw)"""
-    return _AdapterConv2d.apply(_LohaCore, alpha, _geom(shape[2:], stride, padding, dilation), x, w1a,
+    return _AdapterConv2d.apply(_LohaCore, alpha, _geom(shape[2:], stride, padding, dilation), _amp(x), w1a,
                                 w1b.reshape(w1b.shape[0], -1), w2a, w2b.reshape(w2b.shape[0], -1))
 
 
 def lokr_conv2d(x, w1, w2, alpha, stride, padding, dilation):
     """w1:[a, b]  w2:[c, d, kh, kw].  The channel index u*d + v makes im2col's (channel, kh, kw) column order the
     grouped (u, (v, kh, kw)) order of the Kronecker kernel, so w2 is simply viewed as [c, d*kh*kw]."""
+    x = _amp(x)
     geom = _geom(w2.shape[2:], stride, padding, dilation)
     if x.dim() == 4 and not _is_pointwise(geom) and _lokr_conv_implicit_ok(x, w1, w2):
         return _LokrConv2dImplicit.apply(alpha, geom, x, w1, w2)

@@ -91,7 +91,7 @@ def dense_forward(x, w, conv_args=None):
     assert int(ca.get("groups", 1)) == 1
     O, C, kh, kw = w.shape
     cols, (Ho, Wo) = _im2col(x, kh, kw, ca.get("stride", 1), ca.get("padding", 0), ca.get("dilation", 1))
-    y = np.einsum("ok,bkm->bom", w.reshape(O, -1), cols)
+    y = np.matmul(w.reshape(O, -1), cols)  # [O, K] @ [B, K, P] -> [B, O, P] (BLAS: full-size layers take seconds)
     return y.reshape(x.shape[0], O, Ho, Wo)
 
 
@@ -109,8 +109,8 @@ def dense_backward(x, w, g, conv_args=None):
     st, pd, dl = ca.get("stride", 1), ca.get("padding", 0), ca.get("dilation", 1)
     cols, (Ho, Wo) = _im2col(x, kh, kw, st, pd, dl)
     g2 = g.reshape(g.shape[0], O, Ho * Wo)
-    dw = np.einsum("bom,bkm->ok", g2, cols).reshape(w.shape)
-    dcols = np.einsum("ok,bom->bkm", w.reshape(O, -1), g2)
+    dw = np.matmul(g2, cols.transpose(0, 2, 1)).sum(axis=0).reshape(w.shape)
+    dcols = np.matmul(w.reshape(O, -1).T, g2)
     dx = _col2im(dcols, x.shape, kh, kw, st, pd, dl, Ho, Wo)
     return dx, dw
 

@@ -5,12 +5,37 @@ lokr.py:544-546), `rank_dropout` drops rows of dW = output channels of the delta
 rate (locon.py:210-217, loha.py:220-225, lokr.py:375-380), plain `dropout` acts on the delta in LoCon's bypass mode
 (locon.py:304).  The random masks cannot be bit-identical to upstream's (different generators); they are reproduced here
 by re-seeding torch and drawing the same calls."""
+import numpy as np
 import pytest
 import torch
 import torch.nn as nn
 
+import oracle
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+
+def _oracle_dw(algo, mod, shape):
+    """float64 dW of the module's current factors, straight from the oracle (independent of the native kernels)."""
+    f = {n: p.detach().double().cpu().numpy() for n, p in mod.named_parameters()}
+    if algo == "locon":
+        return oracle.locon.diff_weight(f["lora_down.weight"], f["lora_up.weight"], mod.scale).reshape(shape)
+    if algo == "loha":
+        return oracle.loha.diff_weight(f["hada_w1_a"], f["hada_w1_b"], f["hada_w2_a"], f["hada_w2_b"], mod.scale, shape)
+    return oracle.lokr.diff_weight(w1=f["lokr_w1"], w2=f["lokr_w2"], scale=mod.scale, kshape=tuple(shape[2:])).reshape(shape)
+
+
+def _expected_delta(x, dw64, row_mask, conv):
+    """The reference's rebuild path with rank_dropout (modules/locon.py:210-217, loha.py:220-225, lokr.py:375-380):
+    rows of dW are multiplied by the mask, then delta = op(x, dW)."""
+    m = np.asarray(row_mask, dtype=np.float64).reshape(-1, *([1] * (dw64.ndim - 1)))
+    ca = {"stride": 1, "padding": 1, "dilation": 1} if conv else None
+    return oracle.general.dense_forward(x.detach().double().cpu().numpy(), dw64 * m, ca)
+
+
+def _close(got, want64, tol=2e-5):
+    return oracle.general.rel_err(got.detach().double().cpu().numpy(), want64) < tol
 
 
 def _mods():
@@ -42,6 +67,8 @@ def test_rank_and_module_dropout(algo, conv):
     delta = layer(x) - base  # no dropout
     plain.restore()
     assert float(delta.detach().abs().max()) > 0
+    dw64 = _oracle_dw(algo, plain, tuple(layer.weight.shape))
+    assert _close(delta, _expected_delta(x, dw64, np.ones(64), conv), 1e-4)  # delta/base are fp32 differences
 
     for scale in (False, True):
         mod = _build(algo, layer, rank_dropout=0.5, rank_dropout_scale=scale)
@@ -56,8 +83,9 @@ def test_rank_and_module_dropout(algo, conv):
         assert 0 < int(mask.sum()) < 64
         if scale:
             mask = mask / mask.mean()
-        want = delta * (mask.view(1, -1, 1, 1) if conv else mask)
-        assert torch.allclose(out - base, want, rtol=1e-4, atol=1e-5)
+        # independent expectation: the ORACLE's dW with its rows masked (not the native delta re-masked)
+        want = _expected_delta(x, dw64, mask.cpu().numpy(), conv)
+        assert _close(out - base, want, 1e-4), oracle.general.rel_err((out - base).detach().double().cpu().numpy(), want)
         mod.eval()  # inference: no dropout
         mod.apply_to()
         assert torch.allclose(layer(x) - base, delta, rtol=1e-4, atol=1e-5)
@@ -91,8 +119,10 @@ def test_locon_bypass_dropout_acts_on_the_delta():
     out = layer(x)
     mod.restore()
     torch.manual_seed(5)
-    want = torch.nn.functional.dropout(delta, 0.25, training=True)
-    assert torch.allclose(out - base, want, rtol=1e-4, atol=1e-5)
+    keep = torch.nn.functional.dropout(torch.ones_like(delta), 0.25, training=True)  # same generator calls: the mask
+    dw64 = _oracle_dw("locon", plain, tuple(layer.weight.shape))
+    want = _expected_delta(x, dw64, np.ones(64), False) * keep.double().cpu().numpy()   # locon.py:304 on the oracle delta
+    assert _close(out - base, want, 1e-4)
     # the rebuild path (bypass_mode unset) ignores plain dropout, as upstream does
     mod2 = _build("locon", layer, dropout=0.25)
     mod2.load_state_dict(state)

@@ -70,3 +70,44 @@ def test_module_bypass_mode_equals_rebuild_semantics(name, golden_cases):
     out = layer(x)
     mod.restore()
     check(f"module_bypass[{name}]", {"delta": err(out - base, a["delta"])}, {"delta": 2e-4})
+
+
+def _rounded_case(a, dtype):
+    """the golden case with the activations / frozen weights pre-rounded to `dtype` (what a 16-bit UNet holds); the
+    adapter parameters stay fp32 (mixed-precision training)"""
+    b = dict(a)
+    for k in ("x", "g", "W", "bias"):
+        if k in b:
+            b[k] = torch.from_numpy(b[k]).to(dtype).double().numpy()
+    return b
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("name", golden_case_names())
+def test_module_16bit_activations_fp32_factors(name, dtype, golden_cases):
+    """Modules in the mixed-precision setup (module-level tests ran in fp32 only): 16-bit frozen
+    layer and activations, fp32 adapter parameters.  `base + delta` in 16 bits cannot be differenced back, so the delta
+    is taken from bypass_forward_diff (the same native call forward() makes) and compared with the oracle evaluated on
+    the rounded inputs."""
+    from golden_util import oracle_eval
+    meta, a = golden_cases[name]
+    a = _rounded_case(a, dtype)
+    layer, mod = build(meta, a, dtype)
+    x = torch.from_numpy(a["x"]).to(dev(), dtype).requires_grad_(True)
+    g = torch.from_numpy(a["g"]).to(dev(), dtype)
+    delta = mod.bypass_forward_diff(x, scale=mod.multiplier)
+    assert delta.dtype == dtype
+    params = list(mod.named_parameters())
+    grads = torch.autograd.grad(delta, [x] + [p for _, p in params], g)
+    torch.cuda.synchronize()
+    want_delta, want = oracle_eval(meta, a)
+    # (IA)^3 goes through the frozen layer's own 16-bit GEMM (one more rounding of its output, as upstream)
+    store = (4e-3 if dtype == torch.bfloat16 else 1e-3) if meta["algo"] == "ia3" else (1e-3)
+    f32 = 4e-3 if meta["algo"] == "ia3" and dtype == torch.bfloat16 else (1e-3 if meta["algo"] == "ia3" else 1e-4)
+    errs = {"delta": err(delta, want_delta, dtype), "dx": err(grads[0], want["dx"], dtype)}
+    bounds = {"delta": store, "dx": store}
+    for (n, p), gr in zip(params, grads[1:]):
+        assert gr.dtype == p.dtype == torch.float32
+        errs["g." + n] = err(gr, want["g." + n])
+        bounds["g." + n] = f32
+    check(f"module_16bit[{name},{dtype}]", errs, bounds)

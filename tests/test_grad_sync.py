@@ -30,10 +30,14 @@ def _worker(rank, world, port, bucket_bytes, out):
         for step in range(2):
             sync.zero_grad()
             torch.manual_seed(100 * step + rank)  # different data per rank
-            loss = sum((p * torch.randn_like(p)).sum() for p in params)
+            noise = [torch.randn_like(p) for p in params]
+            # gradient accumulation: the first micro-batch only accumulates (no_sync), the second one reduces
+            with sync.no_sync():
+                sum((p ** 2).sum() for p in params[:3]).backward()
+                assert sync.launch_log == []
+            loss = sum((p * n).sum() for p, n in zip(params, noise))
             loss.backward()
-            loss2 = sum((p ** 2).sum() for p in params[:3])  # gradient accumulation: second backward
-            sync_hooks_fired = [b.pending for b in sync.buckets]
+            assert sorted(sync.launch_log) == list(range(len(sync.buckets)))  # every bucket went out during backward
             sync.finish()
             results.append([p.grad.clone() for p in params])
             # every .grad is still a view of the arena
@@ -46,6 +50,7 @@ def _worker(rank, world, port, bucket_bytes, out):
             for r in range(world):
                 torch.manual_seed(100 * step + r)
                 gs = [torch.randn_like(p) for p in params]
+                gs = [g + (2 * p.detach() if i < 3 else 0) for i, (g, p) in enumerate(zip(gs, params))]
                 acc = gs if acc is None else [a + g for a, g in zip(acc, gs)]
             want.append([a / world for a in acc])
         ok = all(torch.allclose(g, w, atol=1e-6) for gs, ws in zip(results, want) for g, w in zip(gs, ws))
@@ -129,3 +134,63 @@ def test_single_process_arena_semantics():
     sync.zero_grad()
     assert params[0].grad is not None and params[0].grad.untyped_storage().data_ptr() == arena.untyped_storage().data_ptr()
     sync.remove()
+
+
+def test_unguarded_second_backward_raises():
+    """a second backward after the buckets were reduced must not silently diverge the replicas."""
+    from lycoris_amd.grad_sync import AdapterGradSync
+    params = [torch.nn.Parameter(torch.randn(4, 4)), torch.nn.Parameter(torch.randn(7))]
+    sync = AdapterGradSync(params, bucket_bytes=1)
+    sync.zero_grad()
+    (params[0].sum() + params[1].sum()).backward()
+    with pytest.raises(RuntimeError, match="no_sync"):
+        (params[0].sum() + params[1].sum()).backward()
+    sync.finish()
+    sync.zero_grad()
+    with sync.no_sync():
+        (params[0].sum() + params[1].sum()).backward()
+    (params[0].sum() + params[1].sum()).backward()  # fine: the first one did not count
+    sync.finish()
+    assert torch.all(params[0].grad == 2)
+    sync.remove()
+
+
+def test_bucket_collective_is_issued_before_the_first_layers_backward():
+    """Overlap by construction: with one bucket per layer, the output-side layer's bucket is launched while the
+    input-side layer's backward has not run yet (recorded through a tensor hook on the first layer's output)."""
+    from lycoris_amd.grad_sync import AdapterGradSync
+    l1, l2 = torch.nn.Linear(6, 6), torch.nn.Linear(6, 3)
+    sync = AdapterGradSync(list(l1.parameters()) + list(l2.parameters()), bucket_bytes=1)
+    events = []
+    orig = sync._launch
+    sync._launch = lambda b: (events.append(("launch", id(b.params[0]))), orig(b))[1]
+    h = l1(torch.randn(5, 6))
+    h.register_hook(lambda g: events.append(("l1_backward_starts", None)))
+    l2(h).sum().backward()
+    first_l1 = next(i for i, e in enumerate(events) if e[0] == "l1_backward_starts")
+    l2_ids = {id(p) for p in l2.parameters()}
+    launched_before = {e[1] for e in events[:first_l1] if e[0] == "launch"}
+    assert launched_before and launched_before <= l2_ids, events
+    sync.finish()
+    sync.remove()
+
+
+def test_fused_accumulation_callback_drives_the_buckets():
+    """ops.fused_grad_accumulation(callback=...) is what the kernels call instead of the autograd hooks."""
+    from lycoris_amd import ops
+    from lycoris_amd.grad_sync import AdapterGradSync
+    params = [torch.nn.Parameter(torch.randn(4, 4)), torch.nn.Parameter(torch.randn(7))]
+    sync = AdapterGradSync(params, bucket_bytes=1)
+    sync.attach_fused()
+    try:
+        assert ops._ACCUM["enabled"] and ops._ACCUM["callback"] == sync._on_grad_ready
+        sync.zero_grad()
+        ops._ACCUM["callback"](params[1])  # what _finish_grads() does after a kernel accumulated into p.grad
+        assert sync.launch_log == [0]      # reverse registration order: params[1] sits in bucket 0
+        ops._ACCUM["callback"](params[0])
+        assert sync.launch_log == [0, 1]
+        sync.finish()
+    finally:
+        sync.attach_fused(False)
+        sync.remove()
+    assert not ops._ACCUM["enabled"] and ops._ACCUM["callback"] is None

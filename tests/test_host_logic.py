@@ -175,6 +175,14 @@ def test_no_cpu_fallback_and_unsupported_features_fail_loudly():
         LohaModule("m", nn.Conv1d(8, 8, 3), 1.0, 2, 1)
     with pytest.raises(ValueError):
         LoConModule("m", nn.LayerNorm(8), 1.0, 2, 1)
+    # layer variants the kernels do not take fail when the network is BUILT, not at the first step
+    for cls in (LoConModule, LohaModule, LokrModule):
+        with pytest.raises(NotImplementedError, match="grouped"):
+            cls("m", nn.Conv2d(8, 8, 3, groups=2), 1.0, 2, 1)
+        with pytest.raises(NotImplementedError, match="padding"):
+            cls("m", nn.Conv2d(8, 8, 3, padding="same"), 1.0, 2, 1)
+        with pytest.raises(NotImplementedError, match="padding_mode"):
+            cls("m", nn.Conv2d(8, 8, 3, padding=1, padding_mode="reflect"), 1.0, 2, 1)
 
 
 def test_missing_native_library_is_an_error(monkeypatch, tmp_path):

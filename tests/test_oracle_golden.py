@@ -3,6 +3,7 @@ import json
 import os
 
 import numpy as np
+import torch
 import pytest
 
 import oracle
@@ -44,3 +45,22 @@ def test_factorization_docstring_table():
     assert f(360, -1) == (18, 20) and f(360, 4) == (4, 90) and f(360, 8) == (8, 45) and f(360, 16) == (15, 24)
     assert f(512, -1) == (16, 32) and f(512, 8) == (8, 64)
     assert f(1024, -1) == (32, 32) and f(1024, 16) == (16, 64)
+
+
+def test_oracle_conv_against_torch_float64():
+    """the numpy im2col oracle vs torch's own float64 CPU conv2d + autograd on a mid-size layer (oracle pin for conv)"""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 48, 20, 18))
+    w = rng.standard_normal((40, 48, 3, 3)) * 0.1
+    for s in (1, 2):
+        ca = {"stride": s, "padding": 1, "dilation": 1}
+        y = oracle.general.dense_forward(x, w, ca)
+        g = rng.standard_normal(y.shape)
+        dx, dw = oracle.general.dense_backward(x, w, g, ca)
+        xt = torch.from_numpy(x).requires_grad_(True)
+        wt = torch.from_numpy(w).requires_grad_(True)
+        yt = torch.nn.functional.conv2d(xt, wt, None, s, 1, 1)
+        dxt, dwt = torch.autograd.grad(yt, [xt, wt], torch.from_numpy(g))
+        assert oracle.general.rel_err(y, yt.detach().numpy()) < 1e-13
+        assert oracle.general.rel_err(dx, dxt.numpy()) < 1e-13
+        assert oracle.general.rel_err(dw, dwt.numpy()) < 1e-13
