@@ -469,7 +469,7 @@ def roofline(insts, args, dtype, dev):
     def bwd():
         if core is None:
             for it in lin:
-                torch.autograd.grad(saved[id(it)], [it.x] + it.params, it.g, retain_graph=True)
+                torch.autograd.grad(saved[id(it)], [it.x], it.g, retain_graph=True)  # dw goes into the arena
             return
         for it, rows, g, fs, bufs in calls:
             core.bwd(g, rows, fs, saved[id(it)][1], 1.0, True, [True] * len(fs), False, bufs)

@@ -31,7 +31,7 @@ enum { LYC_F32 = 0, LYC_F16 = 1, LYC_BF16 = 2 };
 enum { LYC_F32_ROWS = 0x100 };
 enum { LYC_OK = 0, LYC_ERR_ARG = 1, LYC_ERR_UNSUPPORTED = 2, LYC_ERR_LAUNCH = 3 };
 
-#define LYC_ABI_VERSION 3
+#define LYC_ABI_VERSION 4
 int lyc_abi_version(void);
 const char* lyc_last_error(void);
 
@@ -132,6 +132,40 @@ int lyc_loha_linear_bwd(const void* g, const void* x, const float* w1a, const fl
                         const float* w2b, const void* wplanes, float* gw, void* dx, float* d_w1a, float* d_w1b,
                         float* d_w2a, float* d_w2b, int64_t M, int I, int O, int r, float alpha, int dtype,
                         void* stream);
+
+/* ---- weight space: merge / diff weight / max-norm / DoRA -----------------------------------------------
+ * Everything the reference does on the [O, I(,kh,kw)]-shaped dW OFF the activation path, with the dW tile rebuilt on
+ * chip from the factors (csrc/wspace.h).  J = I*kh*kw (a conv weight [O, I, kh, kw] is the row-major matrix [O, J]).
+ *
+ *   v[o, j] = coef[ch(o, j)] * (w_scale * W[o, j] + alpha * dW[o, j])
+ *   out  != NULL : out[o, j] = v + beta * out[o, j]        (out_dtype: LYC_F32 / LYC_F16 / LYC_BF16)
+ *   sums != NULL : sums[ch(o, j)] += v * v                  (caller-zeroed)
+ *   ch: chan_mode 0 = one channel (index 0), 1 = output row o, 2 = input channel j / kk  (kk = kh*kw)
+ *   W, coef may be NULL (then w_scale*W = 0, coef = 1).
+ *
+ *   algo 0 LoCon: f0 = lora_down [r, J], f1 = lora_up [O, r]                        dW = up down
+ *        1 LoHa : f0..f3 = w1a [O, r], w1b [r, J], w2a [O, r], w2b [r, J]            dW = (w1a w1b) * (w2a w2b)
+ *        2 LoKr : f0 = w1 [a, b], f1 = w2 viewed [c, J / b]  (O == a*c)              dW = kron(w1, w2)
+ *
+ * replaces: get_diff_weight / merge_to (lycoris/modules/base.py:326-342, locon.py:221-237, loha.py:228-242,
+ * lokr.py:383-397): out = W, beta = 0, w_scale = 1, or out = W in place with W = NULL, beta = 1;
+ * apply_max_norm's dW.norm() (locon.py:273-284, loha.py:281-292, lokr.py:442-466): sums only, chan_mode 0;
+ * apply_weight_decompose (locon.py:239-260, loha.py:244-265, lokr.py:399-420): the norms of W + dW per output row
+ * (wd_on_out) or per input channel are `sums` with W given; the rescaled weight is `out` with coef = scale. */
+int lyc_wspace(int algo, const float* f0, const float* f1, const float* f2, const float* f3, int64_t O, int64_t J, int r,
+               int a, int b, int c, int kk, const void* W, int w_dtype, float w_scale, const float* coef, int chan_mode,
+               void* out, int out_dtype, float beta, float* sums, float alpha, void* stream);
+
+/* Gradient of a weight-space quantity w.r.t. the factors: gw is the dense fp32 gradient [O, J] w.r.t. dW (for DoRA:
+ * 2 * dL/dnorm2[ch] * (W + dW), written by lyc_wspace with coef); the factor gradients are accumulated ("+=").
+ * replaces autograd through `up @ down` (locon.py:198-219), HadaWeight.backward (functional/loha.py:18-30) and
+ * torch.kron's backward (functional/lokr.py:11-20) on a weight-shaped gradient. */
+int lyc_locon_wgrad(const float* gw, const float* down, const float* up, float* d_down, float* d_up, int64_t O, int64_t J,
+                    int r, float alpha, void* stream);
+int lyc_loha_wgrad(const float* gw, const float* w1a, const float* w1b, const float* w2a, const float* w2b, float* d_w1a,
+                   float* d_w1b, float* d_w2a, float* d_w2b, int64_t O, int64_t J, int r, float alpha, void* stream);
+int lyc_lokr_wgrad(const float* gw, const float* w1, const float* w2, float* d_w1, float* d_w2, int a, int b, int c,
+                   int64_t dk, float alpha, void* stream);
 
 /* ---- Conv2d lowering (NCHW, groups = 1) --------------------------------------------------------
  * The Conv2d form of every adapter (F.conv2d in lycoris/functional/general.py:6, kw_dict of

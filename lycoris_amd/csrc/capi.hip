@@ -15,6 +15,7 @@
 #include "lokr_kernels.h"
 #include "lowrank.h"
 #include "skinny_kernels.h"
+#include "wspace.h"
 
 using namespace lyc;
 
@@ -1021,6 +1022,36 @@ int rb_gemm(hipStream_t st, bool a_t, bool b_t, long M, long N, long K, const vo
 rocblas_datatype rb_type(int dtype) {
   return (dtype & 0xff) == LYC_BF16 ? rocblas_datatype_bf16_r : rocblas_datatype_f16_r;
 }
+
+// HadaWeight.backward on a dense fp32 gradient G [O, I] (functional/loha.py:18-30): shared by the activation path
+// (G = g^T x) and the weight-space path (DoRA's norm gradient).
+void launch_loha_factor_grad(const float* gw, const float* w1a, const float* w1b, const float* w2a, const float* w2b,
+                             float* d_w1a, float* d_w1b, float* d_w2a, float* d_w2b, long O, long I, int r, float alpha,
+                             hipStream_t st) {
+  LohaArgs la{};
+  la.w1a = w1a; la.w1b = w1b; la.w2a = w2a; la.w2b = w2b; la.O = O; la.I = I; la.R = r; la.scale = alpha;
+  la.G = gw; la.d_w1a = d_w1a; la.d_w1b = d_w1b; la.d_w2a = d_w2a; la.d_w2b = d_w2b;
+  // NO x nt tiles per workgroup (fewer atomics: the a-side gradients stay in registers over nt column tiles, the
+  // b-side over NO row tiles) as long as ~512 workgroups remain; ranks > 32 go tile by tile, chunk by chunk
+  const long tiles_o = cdiv(O, LOHA_T), tiles_j = cdiv(I, LOHA_T);
+  static const int lh_wgs = lr_env("LYC_LOHA_WGS", 512);
+  long per = (tiles_o * tiles_j) / lh_wgs;
+  int no = 1;
+  LohaGradGeom gm{1};
+  if (r <= LOHA_RC && per >= 2) {
+    no = per >= 8 ? 4 : 2;
+    if (no > tiles_o) no = tiles_o >= 2 ? 2 : 1;
+    gm.nt = (int)(per / no);
+    if (gm.nt < 1) gm.nt = 1;
+    if (gm.nt > tiles_j) gm.nt = (int)tiles_j;
+  }
+  dim3 fg((unsigned)cdiv(tiles_o, no), (unsigned)cdiv(tiles_j, gm.nt));
+  switch (no) {
+    case 4: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<4>), fg, dim3(NTHREADS), 0, st, la, gm); break;
+    case 2: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<2>), fg, dim3(NTHREADS), 0, st, la, gm); break;
+    default: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<1>), fg, dim3(NTHREADS), 0, st, la, gm); break;
+  }
+}
 }  // namespace
 }  // extern "C++"
 
@@ -1102,31 +1133,84 @@ int lyc_loha_linear_bwd(const void* g, const void* x, const float* w1a, const fl
       dim3 gg((unsigned)cdiv(O, 128), (unsigned)cdiv(I, 128), 1);
       DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_tn_kernel<T>), gg, dim3(NTHREADS), 0, st, ga));
     }
-    LohaArgs la{};
-    la.w1a = w1a; la.w1b = w1b; la.w2a = w2a; la.w2b = w2b; la.O = O; la.I = I; la.R = r; la.scale = alpha;
-    la.G = gw; la.d_w1a = d_w1a; la.d_w1b = d_w1b; la.d_w2a = d_w2a; la.d_w2b = d_w2b;
-    // NO x nt tiles per workgroup (fewer atomics: the a-side gradients stay in registers over nt column tiles, the
-    // b-side over NO row tiles) as long as ~512 workgroups remain; ranks > 32 go tile by tile, chunk by chunk
-    const long tiles_o = cdiv(O, LOHA_T), tiles_j = cdiv(I, LOHA_T);
-    static const int lh_wgs = lr_env("LYC_LOHA_WGS", 512);
-    long per = (tiles_o * tiles_j) / lh_wgs;
-    int no = 1;
-    LohaGradGeom gm{1};
-    if (r <= LOHA_RC && per >= 2) {
-      no = per >= 8 ? 4 : 2;
-      if (no > tiles_o) no = tiles_o >= 2 ? 2 : 1;
-      gm.nt = (int)(per / no);
-      if (gm.nt < 1) gm.nt = 1;
-      if (gm.nt > tiles_j) gm.nt = (int)tiles_j;
-    }
-    dim3 fg((unsigned)cdiv(tiles_o, no), (unsigned)cdiv(tiles_j, gm.nt));
-    switch (no) {
-      case 4: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<4>), fg, dim3(NTHREADS), 0, st, la, gm); break;
-      case 2: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<2>), fg, dim3(NTHREADS), 0, st, la, gm); break;
-      default: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<1>), fg, dim3(NTHREADS), 0, st, la, gm); break;
-    }
+    launch_loha_factor_grad(gw, w1a, w1b, w2a, w2b, d_w1a, d_w1b, d_w2a, d_w2b, O, I, r, alpha, st);
   }
   return check_launch("loha_linear_bwd");
+}
+
+
+// ---- weight space: merge / diff weight / max-norm / DoRA (wspace.h) ------------------------------------------------
+int lyc_wspace(int algo, const float* f0, const float* f1, const float* f2, const float* f3, int64_t O, int64_t J, int r,
+               int a, int b, int c, int kk, const void* W, int w_dtype, float w_scale, const float* coef, int chan_mode,
+               void* out, int out_dtype, float beta, float* sums, float alpha, void* stream) {
+  if (O < 1 || J < 1 || kk < 1) return fail(LYC_ERR_ARG, "wspace: bad dims O=%ld J=%ld kk=%d", (long)O, (long)J, kk);
+  if (!f0 || !f1) return fail(LYC_ERR_ARG, "wspace: null factor");
+  if (!out && !sums) return fail(LYC_ERR_ARG, "wspace: nothing to do (out and sums are both NULL)");
+  if (chan_mode < WS_CH_ONE || chan_mode > WS_CH_COL) return fail(LYC_ERR_ARG, "wspace: bad chan_mode %d", chan_mode);
+  if ((W && (w_dtype < 0 || w_dtype > 2)) || (out && (out_dtype < 0 || out_dtype > 2))) return fail(LYC_ERR_ARG, "wspace: bad dtype");
+  WspaceArgs wa{};
+  wa.f0 = f0; wa.f1 = f1; wa.f2 = f2; wa.f3 = f3; wa.O = O; wa.J = J; wa.R = r; wa.a = a; wa.b = b; wa.c = c; wa.kk = kk;
+  wa.W = W; wa.w_dtype = w_dtype; wa.w_scale = w_scale; wa.coef = coef; wa.chan_mode = chan_mode; wa.out = out;
+  wa.out_dtype = out_dtype; wa.beta = beta; wa.sums = sums; wa.alpha = alpha;
+  if (cdiv(J, WS_T) > 65535) return fail(LYC_ERR_UNSUPPORTED, "wspace: J=%ld too wide", (long)J);
+  const dim3 grid((unsigned)cdiv(O, WS_T), (unsigned)cdiv(J, WS_T));
+  hipStream_t st = (hipStream_t)stream;
+  switch (algo) {
+    case WS_LOCON:
+      if (r < 1) return fail(LYC_ERR_ARG, "wspace(locon): rank %d", r);
+      hipLaunchKernelGGL((wspace_kernel<WS_LOCON>), grid, dim3(NTHREADS), 0, st, wa);
+      break;
+    case WS_LOHA:
+      if (r < 1 || !f2 || !f3) return fail(LYC_ERR_ARG, "wspace(loha): needs four factors and a rank");
+      hipLaunchKernelGGL((wspace_kernel<WS_LOHA>), grid, dim3(NTHREADS), 0, st, wa);
+      break;
+    case WS_LOKR:
+      if (a < 1 || b < 1 || c < 1 || (long)a * c != O || J % b != 0)
+        return fail(LYC_ERR_ARG, "wspace(lokr): w1 %dx%d, w2 rows %d do not tile [%ld, %ld]", a, b, c, (long)O, (long)J);
+      wa.dk = J / b;
+      hipLaunchKernelGGL((wspace_kernel<WS_LOKR>), grid, dim3(NTHREADS), 0, st, wa);
+      break;
+    default: return fail(LYC_ERR_ARG, "wspace: unknown algo %d", algo);
+  }
+  return check_launch("wspace");
+}
+
+int lyc_locon_wgrad(const float* gw, const float* down, const float* up, float* d_down, float* d_up, int64_t O, int64_t J,
+                    int r, float alpha, void* stream) {
+  if (O < 1 || J < 1 || r < 1 || !gw || !down || !up) return fail(LYC_ERR_ARG, "locon_wgrad: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (d_up) {  // d_up[o, n] += alpha sum_j Gw[o, j] down[n, j]
+    SkinnyArgs s{};
+    s.A = gw; s.B = down; s.out = d_up; s.M = O; s.K = J; s.Nn = r; s.lda = J; s.bn = J; s.bk = 1; s.os = r; s.oj = 1;
+    s.alpha = alpha;
+    launch_skinny_nt<float>(s, st);
+  }
+  if (d_down) {  // d_down[n, j] += alpha sum_o up[o, n] Gw[o, j]
+    SkinnyArgs s{};
+    s.A = gw; s.B = up; s.out = d_down; s.M = O; s.K = J; s.Nn = r; s.lda = J; s.bn = 1; s.bk = r; s.os = 1; s.oj = J;
+    s.alpha = alpha;
+    launch_skinny_tn<float>(s, st);
+  }
+  return check_launch("locon_wgrad");
+}
+
+int lyc_loha_wgrad(const float* gw, const float* w1a, const float* w1b, const float* w2a, const float* w2b, float* d_w1a,
+                   float* d_w1b, float* d_w2a, float* d_w2b, int64_t O, int64_t J, int r, float alpha, void* stream) {
+  if (O < 1 || J < 1 || r < 1 || !gw || !w1a || !w1b || !w2a || !w2b || !d_w1a || !d_w1b || !d_w2a || !d_w2b)
+    return fail(LYC_ERR_ARG, "loha_wgrad: bad arguments (the four gradients come as a set)");
+  launch_loha_factor_grad(gw, w1a, w1b, w2a, w2b, d_w1a, d_w1b, d_w2a, d_w2b, O, J, r, alpha, (hipStream_t)stream);
+  return check_launch("loha_wgrad");
+}
+
+int lyc_lokr_wgrad(const float* gw, const float* w1, const float* w2, float* d_w1, float* d_w2, int a, int b, int c,
+                   int64_t dk, float alpha, void* stream) {
+  if (a < 1 || b < 1 || c < 1 || dk < 1 || !gw || !w1 || !w2) return fail(LYC_ERR_ARG, "lokr_wgrad: bad arguments");
+  if (cdiv(dk, NTHREADS) > 65535) return fail(LYC_ERR_UNSUPPORTED, "lokr_wgrad: dk=%ld too wide", (long)dk);
+  KronWgradArgs k{};
+  k.gw = gw; k.w1 = w1; k.w2 = w2; k.d_w1 = d_w1; k.d_w2 = d_w2; k.a = a; k.b = b; k.c = c; k.dk = dk; k.alpha = alpha;
+  hipLaunchKernelGGL(kron_wgrad_kernel, dim3((unsigned)c, (unsigned)cdiv(dk, NTHREADS)), dim3(NTHREADS), 0,
+                     (hipStream_t)stream, k);
+  return check_launch("lokr_wgrad");
 }
 
 // ---- Conv2d lowering -------------------------------------------------------------------------------
