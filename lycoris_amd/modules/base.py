@@ -169,6 +169,7 @@ class LycorisBaseModule(nn.Module):
         if scalar is not None:
             with torch.no_grad():
                 scalar.fill_(1.0)
+            self._scalar_scaled = False
 
     # ---- attach / detach -----------------------------------------------------------------------------------------
     def apply_to(self, **kwargs):
@@ -202,12 +203,106 @@ class LycorisBaseModule(nn.Module):
             layer.__dict__.pop(_STACK, None)
             layer.__dict__.pop(_ORIG, None)
 
-    # ---- merging (inference / export; plain tensor math by definition) ---------------------------------------
+    # ---- weight space: merge / export / max-norm / DoRA -----------------------------------------------------------
+    # On the HIP device these run the tile-rebuild kernels of csrc/wspace.h (dW is never written to HBM unless it IS
+    # the requested result); CPU tensors (offline tools) use plain tensor math.
+    _ws_algo = None  # "locon" | "loha" | "lokr": set by the algorithms that have weight-space kernels
+
+    def _ws_factors(self, gated=True):
+        raise NotImplementedError
+
+    def _native_ws(self):
+        return self._ws_algo is not None and self.org_weight.is_cuda and next(self.parameters()).is_cuda
+
     def get_diff_weight(self, multiplier=1.0, shape=None, device=None):
         raise NotImplementedError
 
     def get_merged_weight(self, multiplier=1.0, shape=None, device=None):
         raise NotImplementedError
+
+    def _init_dora(self, org_module, weight_decompose, wd_on_out):
+        """DoRA magnitude vector, initialised to the norms of the frozen weight (locon.py:107-129)."""
+        self.wd = bool(weight_decompose)
+        self.wd_on_out = bool(wd_on_out)
+        if not self.wd:
+            return
+        w = org_module.weight.detach().float().cpu()
+        if self.wd_on_out:
+            n = w.reshape(w.shape[0], -1).norm(dim=1).reshape(w.shape[0], *([1] * (w.dim() - 1)))
+        else:
+            n = w.transpose(0, 1).reshape(w.shape[1], -1).norm(dim=1).reshape(1, w.shape[1], *([1] * (w.dim() - 2)))
+        self.dora_scale = nn.Parameter(n.clone())
+
+    def _dora_s(self, W, multiplier):
+        """per-channel factor of the decomposed weight: multiplier * (dora_scale / ||W + dW|| - 1) + 1
+        (apply_weight_decompose, locon.py:239-260); the norms come from the fused rebuild + norm kernel."""
+        from .. import ops
+        mode = ops.CH_ROW if self.wd_on_out else ops.CH_COL
+        norm2 = ops.weight_norm2(self._ws_algo, W, self._ws_factors(), self.scale, mode)
+        s = self.dora_scale.reshape(-1).float() / (norm2.sqrt() + torch.finfo(self.dora_scale.dtype).eps)
+        if multiplier != 1:
+            s = multiplier * (s - 1) + 1
+        return s
+
+    def _forward_dora(self, x, *args, **kwargs):
+        base = self.org_forward(x, *args, **kwargs)
+        return base + self._dora_delta(x, base)
+
+    def _dora_delta(self, x, base):
+        """delta of the forward with weight_decompose: the reference evaluates op(x, (W + dW) s - W) with a rebuilt
+        weight (locon.py:320-332).  Natively the same function in factored form:
+          wd_on_out : delta = (s - 1) * (x W^T) + s * (x dW^T)             per output channel, no extra GEMM
+          otherwise : delta = ((s - 1) * x) W^T + (s * x) dW^T             per input channel: one frozen-layer GEMM more"""
+        from .. import ops
+        layer = self.org_module[0]
+        W = self._current_weight()
+        s = self._dora_s(W, self.multiplier)
+        chan = 1 if self.module_type.startswith("conv") else -1
+        if self.wd_on_out:
+            delta = self.bypass_forward_diff(x, scale=1)
+            if self.org_forward == getattr(layer, _ORIG, None):  # `base` is x W^T + bias: reuse it
+                plain = ops.chan_affine(base, s - 1, self._current_bias(), 0.0, 1.0, chan)  # (s - 1) * (base - bias)
+            else:  # another adapter sits below: its delta must not be rescaled
+                plain = ops.chan_affine(self.op(x, W, None, **self.kw_dict), s - 1, None, 0.0, 1.0, chan)
+            return plain + ops.chan_affine(delta, s, None, 0.0, 1.0, chan)
+        xs1 = ops.chan_affine(x, s - 1, None, 0.0, 1.0, chan)
+        xs = ops.chan_affine(x, s, None, 0.0, 1.0, chan)
+        return self.op(xs1, W, None, **self.kw_dict) + self.bypass_forward_diff(xs, scale=1)
+
+    def _dora_merge_host(self, weight, multiplier):
+        """apply_weight_decompose (locon.py:239-260) in plain tensor math -- the offline / CPU merge path only"""
+        weight = weight.to(self.dora_scale.dtype)
+        eps = torch.finfo(weight.dtype).eps
+        if self.wd_on_out:
+            n = weight.reshape(weight.shape[0], -1).norm(dim=1).reshape(weight.shape[0], *([1] * (weight.dim() - 1))) + eps
+        else:
+            n = (weight.transpose(0, 1).reshape(weight.shape[1], -1).norm(dim=1)
+                 .reshape(1, weight.shape[1], *([1] * (weight.dim() - 2)))) + eps
+        s = self.dora_scale.to(weight.device) / n
+        if multiplier != 1:
+            s = multiplier * (s - 1) + 1
+        return weight * s
+
+    @torch.no_grad()
+    def _merged_weight_native(self, multiplier):
+        """(W + dW * mult) or, with DoRA, (W + dW) * s -- one pass, written once (get_merged_weight, locon.py:229-237)"""
+        from .. import ops
+        W = self.org_weight
+        if getattr(self, "wd", False):
+            s = self._dora_s(W, multiplier)
+            return ops.diff_weight(self._ws_algo, self._ws_factors(), W.shape, self.scale, W.dtype, W=W, coef=s,
+                                   chan_mode=ops.CH_ROW if self.wd_on_out else ops.CH_COL)
+        return ops.diff_weight(self._ws_algo, self._ws_factors(), W.shape, self.scale * multiplier, W.dtype, W=W)
+
+    @torch.no_grad()
+    def _max_norm_native(self, max_norm, gated=True):
+        """(scaled?, ratio, orig_norm) with ||dW||_F from the factors (no dW tensor); the reference's clamp logic."""
+        from .. import ops
+        orig_norm = ops.sq_norm(self._ws_algo, self._ws_factors(gated), self.shape, self.scale).sqrt()
+        norm = torch.clamp(orig_norm, max_norm / 2)
+        desired = torch.clamp(norm, max=max_norm)
+        ratio = desired.cpu() / norm.cpu()
+        return bool(norm != desired), ratio, orig_norm
 
     def _own_device_dtype(self):
         p = next(self.parameters())
@@ -215,6 +310,11 @@ class LycorisBaseModule(nn.Module):
 
     def merge_to(self, multiplier=1.0):
         if self.not_supported:
+            return
+        if self._native_ws() and not getattr(self, "wd", False) and self.org_weight.is_contiguous():
+            from .. import ops
+            with torch.no_grad():  # W += dW * mult in place, dW tiles rebuilt on chip (no [O, I] temporary)
+                ops.merge_into(self._ws_algo, self._ws_factors(), self.org_module[0].weight.data, self.scale * multiplier)
             return
         dev, dt = self._own_device_dtype()
         self.to(self.org_weight)
@@ -285,6 +385,8 @@ class LycorisBaseModule(nn.Module):
         ignores it on the rebuild path and for LoHa / LoKr)."""
         if self.module_dropout and self.training and float(torch.rand(1)) < self.module_dropout:
             return self.org_forward(x, *args, **kwargs)
+        if getattr(self, "wd", False):
+            return self._forward_dora(x, *args, **kwargs)
         base = self.org_forward(x, *args, **kwargs)
         delta = self.bypass_forward_diff(x, scale=self.multiplier)
         if self.rank_dropout and self.training:
@@ -303,8 +405,8 @@ class LycorisBaseModule(nn.Module):
 
     def _gate(self, first_factor: torch.Tensor) -> torch.Tensor:
         """Fold the learnable `scalar` gate into the first factor (its gradient then flows through autograd)."""
-        if isinstance(self.scalar, nn.Parameter):
-            return first_factor * self.scalar
+        if isinstance(self.scalar, nn.Parameter) or getattr(self, "_scalar_scaled", False):
+            return first_factor * self.scalar  # learnable gate, or a fixed gate that apply_max_norm has moved off 1
         return first_factor
 
     def _init_scale(self, lora_dim, alpha, rs_lora, use_scalar, force_unit_scale=False):

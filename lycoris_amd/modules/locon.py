@@ -17,6 +17,7 @@ from .base import LycorisBaseModule, _unsupported
 
 class LoConModule(LycorisBaseModule):
     name = "locon"
+    _ws_algo = "locon"
     support_module = {"linear", "conv1d", "conv2d", "conv3d"}
     weight_list = ["lora_up.weight", "lora_down.weight", "lora_mid.weight", "alpha", "dora_scale"]
     weight_list_det = ["lora_up.weight"]
@@ -30,11 +31,11 @@ class LoConModule(LycorisBaseModule):
             raise ValueError(f"{self.module_type} is not supported in LoRA/LoCon algo.")
         if self.module_type in ("conv1d", "conv3d"):
             raise _unsupported(f"LoCon on {self.module_type}")
-        if weight_decompose:
-            raise _unsupported("weight_decompose (DoRA)")
+        if weight_decompose and rank_dropout:
+            raise _unsupported("rank_dropout together with weight_decompose")
         self.lora_dim = lora_dim
         self.rs_lora = rs_lora
-        self.wd = False
+        self._init_dora(org_module, weight_decompose, wd_on_out)
         self.tucker = False
         if self.module_type == "conv2d":
             self.isconv = True
@@ -57,15 +58,24 @@ class LoConModule(LycorisBaseModule):
 
     @classmethod
     def make_module_from_state_dict(cls, lora_name, orig_module, up, down, mid, alpha, dora_scale):
+        wd_on_out = dora_scale is None or dora_scale.reshape(-1).numel() == up.size(0) and dora_scale.shape[0] == up.size(0)
         mod = cls(lora_name, orig_module, 1, down.size(0), float(alpha), use_tucker=mid is not None,
-                  weight_decompose=dora_scale is not None)
+                  weight_decompose=dora_scale is not None, wd_on_out=wd_on_out)
         mod.lora_up.weight.data.copy_(up)
         mod.lora_down.weight.data.copy_(down)
+        if dora_scale is not None:
+            mod.dora_scale.data.copy_(dora_scale.reshape(mod.dora_scale.shape))
         return mod
 
     def custom_state_dict(self):
-        return {"alpha": self.alpha, "lora_up.weight": self.lora_up.weight * self.scalar,
-                "lora_down.weight": self.lora_down.weight}
+        sd = {"alpha": self.alpha, "lora_up.weight": self.lora_up.weight * self.scalar,
+              "lora_down.weight": self.lora_down.weight}
+        if self.wd:
+            sd["dora_scale"] = self.dora_scale
+        return sd
+
+    def _ws_factors(self, gated=True):
+        return (self.lora_down.weight, self._gate(self.lora_up.weight) if gated else self.lora_up.weight)
 
     # ---- dW materialisation (merge / export / max-norm only) -----------------------------------------------------
     def make_weight(self, device=None):
@@ -75,17 +85,30 @@ class LoConModule(LycorisBaseModule):
         return w.reshape(self.shape) * self.scalar.to(device)
 
     def get_diff_weight(self, multiplier=1, shape=None, device=None):
+        if self._native_ws():
+            diff = ops.diff_weight("locon", self._ws_factors(), shape or self.shape, self.scale * multiplier)
+            return (diff if device is None else diff.to(device)), None
         diff = self.make_weight(device=device) * (self.scale * multiplier)
         if shape is not None:
             diff = diff.view(shape)
         return (diff if device is None else diff.to(device)), None
 
     def get_merged_weight(self, multiplier=1, shape=None, device=None):
+        if self._native_ws():
+            return self._merged_weight_native(multiplier), None
         diff = self.get_diff_weight(multiplier=1, shape=shape, device=device)[0]
+        if self.wd:
+            return self._dora_merge_host(self.org_weight + diff, multiplier), None
         return self.org_weight + diff * multiplier, None
 
     @torch.no_grad()
     def apply_max_norm(self, max_norm, device=None):
+        if self._native_ws():  # ||dW||_F straight from the factors (locon.py:273-284 builds the full dW for it)
+            scaled, ratio, orig_norm = self._max_norm_native(max_norm)
+            if scaled:
+                self.scalar *= ratio.to(self.scalar.device)
+                self._scalar_scaled = True
+            return scaled, orig_norm * ratio.to(orig_norm.device)
         orig_norm = self.make_weight(device).norm() * self.scale
         norm = torch.clamp(orig_norm, max_norm / 2)
         desired = torch.clamp(norm, max=max_norm)
@@ -93,6 +116,7 @@ class LoConModule(LycorisBaseModule):
         scaled = norm != desired
         if scaled:
             self.scalar *= ratio
+            self._scalar_scaled = True
         return scaled, orig_norm * ratio
 
     # ---- hot path --------------------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@ from .base import LycorisBaseModule, _unsupported
 
 class LohaModule(LycorisBaseModule):
     name = "loha"
+    _ws_algo = "loha"
     support_module = {"linear", "conv1d", "conv2d", "conv3d"}
     weight_list = ["hada_w1_a", "hada_w1_b", "hada_w2_a", "hada_w2_b", "hada_t1", "hada_t2", "alpha", "dora_scale"]
     weight_list_det = ["hada_w1_a"]
@@ -24,11 +25,11 @@ class LohaModule(LycorisBaseModule):
             raise ValueError(f"{self.module_type} is not supported in LoHa algo.")
         if self.module_type in ("conv1d", "conv3d"):
             raise _unsupported(f"LoHa on {self.module_type}")
-        if weight_decompose:
-            raise _unsupported("weight_decompose (DoRA)")
+        if weight_decompose and rank_dropout:
+            raise _unsupported("rank_dropout together with weight_decompose")
         self.lora_dim = lora_dim
         self.rs_lora = rs_lora
-        self.wd = False
+        self._init_dora(org_module, weight_decompose, wd_on_out)
         self.tucker = False
         out_dim, in_flat = self.shape[0], self.shape[1]
         if self.module_type == "conv2d":
@@ -51,15 +52,24 @@ class LohaModule(LycorisBaseModule):
 
     @classmethod
     def make_module_from_state_dict(cls, lora_name, orig_module, w1a, w1b, w2a, w2b, t1, t2, alpha, dora_scale):
+        wd_on_out = dora_scale is None or dora_scale.shape[0] == w1a.size(0)
         mod = cls(lora_name, orig_module, 1, w1b.size(0), float(alpha), use_tucker=t1 is not None,
-                  weight_decompose=dora_scale is not None)
+                  weight_decompose=dora_scale is not None, wd_on_out=wd_on_out)
         for p, v in ((mod.hada_w1_a, w1a), (mod.hada_w1_b, w1b), (mod.hada_w2_a, w2a), (mod.hada_w2_b, w2b)):
             p.data.copy_(v)
+        if dora_scale is not None:
+            mod.dora_scale.data.copy_(dora_scale.reshape(mod.dora_scale.shape))
         return mod
 
     def custom_state_dict(self):
-        return {"alpha": self.alpha, "hada_w1_a": self.hada_w1_a * self.scalar, "hada_w1_b": self.hada_w1_b,
-                "hada_w2_a": self.hada_w2_a, "hada_w2_b": self.hada_w2_b}
+        sd = {"alpha": self.alpha, "hada_w1_a": self.hada_w1_a * self.scalar, "hada_w1_b": self.hada_w1_b,
+              "hada_w2_a": self.hada_w2_a, "hada_w2_b": self.hada_w2_b}
+        if self.wd:
+            sd["dora_scale"] = self.dora_scale
+        return sd
+
+    def _ws_factors(self, gated=True):
+        return (self._gate(self.hada_w1_a) if gated else self.hada_w1_a, self.hada_w1_b, self.hada_w2_a, self.hada_w2_b)
 
     # ---- dW materialisation (merge / export / max-norm only) -----------------------------------------------------
     def get_weight(self, shape):
@@ -69,15 +79,28 @@ class LohaModule(LycorisBaseModule):
     def get_diff_weight(self, multiplier=1, shape=None, device=None):
         # NB upstream multiplies by self.scale a second time here (loha.py:228-230 with :206); the trained
         # forward uses scale once, and merging must reproduce the trained forward, so scale is applied once.
+        if self._native_ws():
+            diff = ops.diff_weight("loha", self._ws_factors(), shape or self.shape, self.scale * multiplier)
+            return (diff if device is None else diff.to(device)), None
         diff = self.get_weight(shape) * self.scalar * multiplier
         return (diff if device is None else diff.to(device)), None
 
     def get_merged_weight(self, multiplier=1, shape=None, device=None):
+        if self._native_ws():
+            return self._merged_weight_native(multiplier), None
         diff = self.get_diff_weight(multiplier=1, shape=shape, device=device)[0]
+        if self.wd:
+            return self._dora_merge_host(self.org_weight + diff, multiplier), None
         return self.org_weight + diff * multiplier, None
 
     @torch.no_grad()
     def apply_max_norm(self, max_norm, device=None):
+        if self._native_ws():  # ||dW||_F from the factors, tile by tile on chip (loha.py:281-292 builds dW)
+            scaled, ratio, orig_norm = self._max_norm_native(max_norm)
+            if scaled:
+                self.scalar *= ratio.to(self.scalar.device)
+                self._scalar_scaled = True
+            return scaled, orig_norm * ratio.to(orig_norm.device)
         orig_norm = (self.get_weight(self.shape) * self.scalar).norm()
         norm = torch.clamp(orig_norm, max_norm / 2)
         desired = torch.clamp(norm, max=max_norm)
@@ -85,6 +108,7 @@ class LohaModule(LycorisBaseModule):
         scaled = norm != desired
         if scaled:
             self.scalar *= ratio
+            self._scalar_scaled = True
         return scaled, orig_norm * ratio
 
     # ---- hot path --------------------------------------------------------------------------------------------------

@@ -29,6 +29,7 @@ def _warn_full_matrix(lora_dim, dim, factor):
 
 class LokrModule(LycorisBaseModule):
     name = "kron"
+    _ws_algo = "lokr"
     support_module = {"linear", "conv1d", "conv2d", "conv3d"}
     weight_list = ["lokr_w1", "lokr_w1_a", "lokr_w1_b", "lokr_w2", "lokr_w2_a", "lokr_w2_b", "lokr_t1", "lokr_t2",
                    "alpha", "dora_scale"]
@@ -44,13 +45,13 @@ class LokrModule(LycorisBaseModule):
             raise ValueError(f"{self.module_type} is not supported in LoKr algo.")
         if self.module_type in ("conv1d", "conv3d"):
             raise _unsupported(f"LoKr on {self.module_type}")
-        if weight_decompose:
-            raise _unsupported("weight_decompose (DoRA)")
+        if weight_decompose and rank_dropout:
+            raise _unsupported("rank_dropout together with weight_decompose")
         factor = int(factor)
         self.lora_dim = lora_dim
         self.full_matrix = full_matrix
         self.rs_lora = rs_lora
-        self.wd = False
+        self._init_dora(org_module, weight_decompose, wd_on_out)
         self.tucker = False
         is_conv = self.module_type == "conv2d"
         out_dim, in_dim = self.shape[0], self.shape[1]
@@ -106,8 +107,8 @@ class LokrModule(LycorisBaseModule):
     def make_module_from_state_dict(cls, lora_name, orig_module, w1, w1a, w1b, w2, w2a, w2b, _, t2, alpha,
                                     dora_scale):
         """Rebuild a module from checkpoint tensors: find the ``factor`` that reproduces the stored factor shapes."""
-        if t2 is not None or dora_scale is not None:
-            raise _unsupported("LoKr checkpoints with lokr_t2 / dora_scale")
+        if t2 is not None:
+            raise _unsupported("LoKr checkpoints with lokr_t2")
         full_matrix = w1a is None and w2a is None
         lora_dim = w1a.size(1) if w1a is not None else (w2a.size(1) if w2a is not None else 1)
         a, b = (w1.shape if w1 is not None else (w1a.size(0), w1b.size(1)))
@@ -128,7 +129,10 @@ class LokrModule(LycorisBaseModule):
         if factor is None:
             raise ValueError(f"cannot infer LoKr factor for {lora_name}: w1 {a}x{b}, layer {out_dim}x{in_dim}")
         mod = cls(lora_name, orig_module, 1, lora_dim, float(alpha), decompose_both=w1 is None and w2 is None,
-                  factor=factor, full_matrix=full_matrix)
+                  factor=factor, full_matrix=full_matrix, weight_decompose=dora_scale is not None,
+                  wd_on_out=dora_scale is None or dora_scale.shape[0] == out_dim)
+        if dora_scale is not None:
+            mod.dora_scale.data.copy_(dora_scale.reshape(mod.dora_scale.shape))
         with torch.no_grad():
             for name, val in (("lokr_w1", w1), ("lokr_w1_a", w1a), ("lokr_w1_b", w1b), ("lokr_w2", w2),
                               ("lokr_w2_a", w2a), ("lokr_w2_b", w2b)):
@@ -138,6 +142,8 @@ class LokrModule(LycorisBaseModule):
 
     def custom_state_dict(self):
         sd = {"alpha": self.alpha}
+        if self.wd:
+            sd["dora_scale"] = self.dora_scale
         if self.use_w1:
             sd["lokr_w1"] = self.lokr_w1 * self.scalar
         else:
@@ -160,6 +166,10 @@ class LokrModule(LycorisBaseModule):
         out_k, in_n = self._kron_dims[2], self._kron_dims[3]
         return (self.lokr_w2_a @ self.lokr_w2_b).reshape(out_k, in_n, *self.shape[2:])
 
+    def _ws_factors(self, gated=True):
+        w1 = self._w1_full()
+        return (self._gate(w1) if gated else w1, self._w2_full())
+
     # ---- dW materialisation (merge / export / max-norm only) -----------------------------------------------------
     def get_weight(self, shape):
         w = make_kron(self._w1_full(), self._w2_full(), self.scale)
@@ -167,25 +177,35 @@ class LokrModule(LycorisBaseModule):
 
     def get_diff_weight(self, multiplier=1, shape=None, device=None):
         # scale applied once (upstream applies it twice here, lokr.py:383-385 with :370)
+        if self._native_ws():
+            diff = ops.diff_weight("lokr", self._ws_factors(), shape or self.shape, self.scale * multiplier)
+            return (diff if device is None else diff.to(device)), None
         diff = self.get_weight(shape) * self.scalar * multiplier
         return (diff if device is None else diff.to(device)), None
 
     def get_merged_weight(self, multiplier=1, shape=None, device=None):
+        if self._native_ws():
+            return self._merged_weight_native(multiplier), None
         diff = self.get_diff_weight(multiplier=1, shape=shape, device=device)[0]
+        if self.wd:
+            return self._dora_merge_host(self.org_weight + diff, multiplier), None
         return self.org_weight + diff * multiplier, None
 
     @torch.no_grad()
     def apply_max_norm(self, max_norm, device=None):
-        orig_norm = self.get_weight(self.shape).norm()
-        norm = torch.clamp(orig_norm, max_norm / 2)
-        desired = torch.clamp(norm, max=max_norm)
-        ratio = desired.cpu() / norm.cpu()
-        scaled = norm != desired
+        if self._native_ws():  # lokr.py:442-466 takes the norm of the un-gated kron(w1, w2) * scale
+            scaled, ratio, orig_norm = self._max_norm_native(max_norm, gated=False)
+        else:
+            orig_norm = self.get_weight(self.shape).norm()
+            norm = torch.clamp(orig_norm, max_norm / 2)
+            desired = torch.clamp(norm, max=max_norm)
+            ratio = desired.cpu() / norm.cpu()
+            scaled = norm != desired
         if scaled:
             factors = [p for n, p in self.named_parameters() if n.startswith("lokr_")]
             for p in factors:
                 p *= ratio ** (1 / len(factors))
-        return scaled, orig_norm * ratio
+        return scaled, orig_norm * ratio.to(orig_norm.device)
 
     # ---- hot path --------------------------------------------------------------------------------------------------
     def bypass_forward_diff(self, h, scale=1):

@@ -583,3 +583,132 @@ def lokr_conv2d(x, w1, w2, alpha, stride, padding, dilation):
     if x.dim() == 4 and not _is_pointwise(geom) and _lokr_conv_implicit_ok(x, w1, w2):
         return _LokrConv2dImplicit.apply(alpha, geom, x, w1, w2)
     return _AdapterConv2d.apply(_LokrCore, alpha, geom, x, w1, w2.reshape(w2.shape[0], -1))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# weight space: merge / diff weight / max-norm / DoRA  (lyc_wspace, lyc_*_wgrad; csrc/wspace.h)
+# ---------------------------------------------------------------------------------------------------------------
+WS_ALGO = {"locon": 0, "loha": 1, "lokr": 2}
+CH_ONE, CH_ROW, CH_COL = 0, 1, 2
+
+
+def _ws_factors(algo, factors, O, J):
+    """fp32 contiguous 2-D views of the factors in the layout lyc_wspace wants, plus (r, a, b, c)."""
+    if algo == "locon":  # (down [r, I(,kh,kw)], up [O, r(,1,1)])
+        down, up = factors
+        r = down.shape[0]
+        return [_f32c(down.reshape(r, -1)), _f32c(up.reshape(O, r)), None, None], (r, 0, 0, 0)
+    if algo == "loha":   # (w1a [O, r], w1b [r, J], w2a, w2b)
+        r = factors[0].shape[1]
+        return [_f32c(factors[0]), _f32c(factors[1].reshape(r, -1)), _f32c(factors[2]), _f32c(factors[3].reshape(r, -1))], (r, 0, 0, 0)
+    w1, w2 = factors     # lokr: w1 [a, b], w2 [c, d(,kh,kw)]
+    a, b = w1.shape
+    c = w2.shape[0]
+    if a * c != O or J % b:
+        raise ValueError(f"LoKr factors {tuple(w1.shape)} x {tuple(w2.shape)} do not tile a [{O}, {J}] weight")
+    return [_f32c(w1), _f32c(w2.reshape(c, -1)), None, None], (0, a, b, c)
+
+
+def _ws_call(algo, fs, dims, O, J, kk, W, w_scale, coef, chan_mode, out, beta, sums, alpha, device):
+    r, a, b, c = dims
+    N.call("lyc_wspace", WS_ALGO[algo], N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(fs[2]), N.ptr(fs[3]), O, J, r, a, b, c, kk,
+           N.ptr(W), N.dtype_code(W.dtype) if W is not None else 0, float(w_scale), N.ptr(coef), chan_mode,
+           N.ptr(out), N.dtype_code(out.dtype) if out is not None else 0, float(beta), N.ptr(sums), float(alpha),
+           N.stream_ptr(device))
+
+
+def _wshape(shape):
+    O = int(shape[0])
+    J = 1
+    for s in shape[1:]:
+        J *= int(s)
+    kk = 1
+    for s in shape[2:]:
+        kk *= int(s)
+    return O, J, kk
+
+
+@torch.no_grad()
+def diff_weight(algo, factors, shape, alpha=1.0, dtype=torch.float32, W=None, coef=None, chan_mode=CH_ONE):
+    """alpha * dW (or coef[ch] * (W + alpha * dW) when W / coef are given) as a new [shape] tensor: the dW tile is rebuilt
+    on chip, only the result is written (get_diff_weight / get_merged_weight of the reference modules)."""
+    O, J, kk = _wshape(shape)
+    dev = factors[0].device
+    fs, dims = _ws_factors(algo, [f.detach() for f in factors], O, J)
+    out = torch.empty(tuple(shape), dtype=dtype, device=dev)
+    Wc = None if W is None else W.detach().contiguous()
+    _ws_call(algo, fs, dims, O, J, kk, Wc, 1.0, None if coef is None else _f32c(coef).reshape(-1), chan_mode, out, 0.0,
+             None, alpha, dev)
+    return out
+
+
+@torch.no_grad()
+def merge_into(algo, factors, W, alpha=1.0):
+    """W += alpha * dW in place, straight from the factors (merge_to, lycoris/modules/base.py:326-342)."""
+    if not W.is_contiguous():
+        raise ValueError("merge_into needs a contiguous weight")
+    O, J, kk = _wshape(W.shape)
+    fs, dims = _ws_factors(algo, [f.detach() for f in factors], O, J)
+    _ws_call(algo, fs, dims, O, J, kk, None, 0.0, None, CH_ONE, W, 1.0, None, alpha, W.device)
+    return W
+
+
+@torch.no_grad()
+def sq_norm(algo, factors, shape, alpha=1.0):
+    """||alpha * dW||_F^2 as a 0-d fp32 tensor, without materialising dW (apply_max_norm, locon.py:273-284)."""
+    O, J, kk = _wshape(shape)
+    dev = factors[0].device
+    fs, dims = _ws_factors(algo, [f.detach() for f in factors], O, J)
+    sums = torch.zeros(1, dtype=torch.float32, device=dev)
+    _ws_call(algo, fs, dims, O, J, kk, None, 0.0, None, CH_ONE, None, 0.0, sums, alpha, dev)
+    return sums[0]
+
+
+class _WeightNorm2(torch.autograd.Function):
+    """norm2[ch] = sum over the channel's slice of (W + alpha * dW)^2 -- DoRA's weight norm (apply_weight_decompose,
+    locon.py:239-260) with the dW tile rebuilt on chip: W is read once, nothing [O, J]-sized is written.
+    backward: d norm2 / d dW = 2 (W + alpha dW), pushed to the factors through the algorithm's weight-space chain
+    rule (lyc_*_wgrad) from a transient fp32 Gw."""
+
+    @staticmethod
+    def forward(ctx, algo, W, alpha, chan_mode, *factors):
+        N.require_device(W, "base weight")
+        O, J, kk = _wshape(W.shape)
+        nch = O if chan_mode == CH_ROW else J // kk
+        fs, dims = _ws_factors(algo, [f.detach() for f in factors], O, J)
+        Wc = W.detach().contiguous()
+        sums = torch.zeros(nch, dtype=torch.float32, device=W.device)
+        _ws_call(algo, fs, dims, O, J, kk, Wc, 1.0, None, chan_mode, None, 0.0, sums, alpha, W.device)
+        ctx.save_for_backward(Wc, *factors)
+        ctx.meta = (algo, float(alpha), chan_mode, (O, J, kk))
+        return sums
+
+    @staticmethod
+    def backward(ctx, gsum):
+        algo, alpha, chan_mode, (O, J, kk) = ctx.meta
+        Wc, factors = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        need = list(ctx.needs_input_grad[4:])
+        if not any(need):
+            return (None,) * (4 + len(factors))
+        fs, dims = _ws_factors(algo, [f.detach() for f in factors], O, J)
+        dev = Wc.device
+        coef = (2.0 * gsum).to(torch.float32).contiguous()
+        gw = torch.empty((O, J), dtype=torch.float32, device=dev)  # 2 g[ch] (W + alpha dW)
+        _ws_call(algo, fs, dims, O, J, kk, Wc, 1.0, coef, chan_mode, gw, 0.0, None, alpha, dev)
+        bufs = [torch.zeros(f.shape, dtype=torch.float32, device=dev) for f in fs if f is not None]
+        st = N.stream_ptr(dev)
+        if algo == "locon":
+            N.call("lyc_locon_wgrad", N.ptr(gw), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(bufs[0]), N.ptr(bufs[1]), O, J, dims[0],
+                   alpha, st)
+        elif algo == "loha":
+            N.call("lyc_loha_wgrad", N.ptr(gw), *[N.ptr(f) for f in fs], *[N.ptr(b) for b in bufs], O, J, dims[0], alpha, st)
+        else:
+            N.call("lyc_lokr_wgrad", N.ptr(gw), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(bufs[0]), N.ptr(bufs[1]), dims[1], dims[2],
+                   dims[3], J // dims[2], alpha, st)
+        grads = [b.reshape(f.shape).to(f.dtype) if n else None for b, f, n in zip(bufs, factors, need)]
+        return (None, None, None, None, *grads)
+
+
+def weight_norm2(algo, W, factors, alpha=1.0, chan_mode=CH_ROW):
+    """differentiable (w.r.t. the factors) squared norms of W + alpha * dW per output row / per input channel"""
+    return _WeightNorm2.apply(algo, W, alpha, chan_mode, *factors)

@@ -13,4 +13,4 @@ Rules:
     ``tests/golden/make_golden.py``; the vectors are committed under
     ``tests/golden/*.npz`` (``tests/test_oracle_golden.py``).
 """
-from . import general, locon, loha, lokr, ia3  # noqa: F401
+from . import dora, general, ia3, locon, loha, lokr  # noqa: F401

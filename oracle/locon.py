@@ -23,13 +23,19 @@ def forward(x, down, up, scale=1.0, conv_args=None):
     return dense_forward(x, diff_weight(down, up, scale), conv_args)
 
 
-def backward(x, g, down, up, scale=1.0, conv_args=None):
-    """Returns (dx, d_down, d_up) of sum(g * forward(x, ...))."""
+def factor_grads(dW, down, up, scale=1.0):
+    """(d_down, d_up) from the dense gradient w.r.t. dW = (up * scale) @ down  (autograd through locon.py:198-219)"""
     down = np.asarray(down, dtype=np.float64)
     up = np.asarray(up, dtype=np.float64)
     r, O = down.shape[0], up.shape[0]
-    dx, dW = dense_backward(x, diff_weight(down, up, scale), g, conv_args)
-    dW2 = dW.reshape(O, -1) * scale
+    dW2 = np.asarray(dW, dtype=np.float64).reshape(O, -1) * scale
     d_up = (dW2 @ down.reshape(r, -1).T).reshape(up.shape)
     d_down = (up.reshape(O, r).T @ dW2).reshape(down.shape)
+    return d_down, d_up
+
+
+def backward(x, g, down, up, scale=1.0, conv_args=None):
+    """Returns (dx, d_down, d_up) of sum(g * forward(x, ...))."""
+    dx, dW = dense_backward(x, diff_weight(down, up, scale), g, conv_args)
+    d_down, d_up = factor_grads(dW, down, up, scale)
     return dx, d_down, d_up

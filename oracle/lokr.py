@@ -34,16 +34,16 @@ def forward(x, w1=None, w1a=None, w1b=None, w2=None, w2a=None, w2b=None, scale=1
     return dense_forward(x, diff_weight(w1, w1a, w1b, w2, w2a, w2b, scale, kshape), conv_args)
 
 
-def backward(x, g, w1=None, w1a=None, w1b=None, w2=None, w2a=None, w2b=None, scale=1.0, kshape=(), conv_args=None):
-    """Returns dict with dx and a gradient for every factor that was given."""
+def factor_grads(dW, w1=None, w1a=None, w1b=None, w2=None, w2a=None, w2b=None, scale=1.0, kshape=()):
+    """dict of gradients for every factor that was given, from the dense gradient w.r.t. dW (torch.kron's backward,
+    functional/lokr.py:11-20, then the low-rank products)"""
     f1, f2 = _full_factors(w1, w1a, w1b, w2, w2a, w2b, kshape)
     a, b = f1.shape
     c, d = f2.shape[:2]
-    dx, dW = dense_backward(x, diff_weight(w1, w1a, w1b, w2, w2a, w2b, scale, kshape), g, conv_args)
-    dW5 = dW.reshape(a, c, b, d, -1) * scale
+    dW5 = np.asarray(dW, dtype=np.float64).reshape(a, c, b, d, -1) * scale
     d_f1 = np.einsum("pquvk,qvk->pu", dW5, f2.reshape(c, d, -1))
     d_f2 = np.einsum("pquvk,pu->qvk", dW5, f1).reshape(f2.shape)
-    out = {"dx": dx}
+    out = {}
     if w1 is not None:
         out["w1"] = d_f1
     else:
@@ -57,4 +57,12 @@ def backward(x, g, w1=None, w1a=None, w1b=None, w2=None, w2a=None, w2b=None, sca
         df2 = d_f2.reshape(c, -1)
         out["w2a"] = df2 @ w2b_.reshape(w2b_.shape[0], -1).T
         out["w2b"] = (w2a_.T @ df2).reshape(w2b_.shape)
+    return out
+
+
+def backward(x, g, w1=None, w1a=None, w1b=None, w2=None, w2a=None, w2b=None, scale=1.0, kshape=(), conv_args=None):
+    """Returns dict with dx and a gradient for every factor that was given."""
+    dx, dW = dense_backward(x, diff_weight(w1, w1a, w1b, w2, w2a, w2b, scale, kshape), g, conv_args)
+    out = {"dx": dx}
+    out.update(factor_grads(dW, w1, w1a, w1b, w2, w2a, w2b, scale, kshape))
     return out

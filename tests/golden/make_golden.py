@@ -45,9 +45,11 @@ def numeric_case(name, algo, layer_kw, mod_kw, xshape, seed, multiplier=0.7):
     layer = make_layer(**layer_kw).double()
     mod = ALGOS[algo]("t", layer, multiplier, **mod_kw).double()
     with torch.no_grad():
-        for p in mod.parameters():
+        for n, p in mod.named_parameters():
             if p.dim() == 0:
                 p.fill_(0.8)  # learnable `scalar`
+            elif n == "dora_scale":
+                p.mul_(1.0 + 0.2 * torch.randn_like(p))  # trained magnitudes: near the weight norms, not equal to them
             else:
                 p.copy_(torch.randn_like(p) * 0.3)
     x = torch.randn(*xshape, dtype=torch.float64, requires_grad=True)
@@ -123,6 +125,17 @@ def main():
                      dict(lora_dim=2, alpha=1, factor=2), (2, 16, 5, 6), 28),
         numeric_case("lokr_conv3_s2_full", "lokr", c3s2, dict(lora_dim=10000, factor=2), (2, 16, 7, 6), 29),
         numeric_case("lokr_conv1_full", "lokr", c1, dict(lora_dim=10000, factor=4), (2, 12, 5, 5), 30),
+        # weight_decompose (DoRA): apply_weight_decompose in the rebuild forward, both norm axes, multiplier != 1
+        numeric_case("dora_locon_linear_out", "locon", lin, dict(lora_dim=4, alpha=2, weight_decompose=True, wd_on_out=True), xl3, 41),
+        numeric_case("dora_locon_linear_in", "locon", lin, dict(lora_dim=4, alpha=2, weight_decompose=True, wd_on_out=False), xl, 42),
+        numeric_case("dora_locon_linear_m1", "locon", lin_nb, dict(lora_dim=3, alpha=1, weight_decompose=True, wd_on_out=True, use_scalar=True), (7, 32), 43, 1.0),
+        numeric_case("dora_locon_conv3_out", "locon", c3, dict(lora_dim=4, alpha=1, weight_decompose=True, wd_on_out=True), xc, 44),
+        numeric_case("dora_locon_conv3_in", "locon", c3, dict(lora_dim=4, alpha=1, weight_decompose=True, wd_on_out=False), xc, 45),
+        numeric_case("dora_loha_linear_out", "loha", lin, dict(lora_dim=4, alpha=2, weight_decompose=True, wd_on_out=True), xl3, 46),
+        numeric_case("dora_loha_conv3_in", "loha", c3, dict(lora_dim=4, alpha=1, weight_decompose=True, wd_on_out=False), xc, 47),
+        numeric_case("dora_lokr_linear_out", "lokr", lin, dict(lora_dim=10000, alpha=1, factor=4, weight_decompose=True, wd_on_out=True), xl3, 48),
+        numeric_case("dora_lokr_linear_in_lowrank", "lokr", lin, dict(lora_dim=2, alpha=1, factor=2, weight_decompose=True, wd_on_out=False), xl, 49),
+        numeric_case("dora_lokr_conv3_out", "lokr", c3, dict(lora_dim=10000, alpha=1, factor=4, weight_decompose=True, wd_on_out=True), xc, 50),
         numeric_case("ia3_linear_out", "ia3", lin, dict(), xl3, 31),
         numeric_case("ia3_linear_in", "ia3", lin, dict(train_on_input=True), xl3, 32),
         numeric_case("ia3_linear_out_nobias", "ia3", lin_nb, dict(), (7, 32), 33),

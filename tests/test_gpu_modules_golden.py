@@ -95,7 +95,11 @@ def test_module_16bit_activations_fp32_factors(name, dtype, golden_cases):
     layer, mod = build(meta, a, dtype)
     x = torch.from_numpy(a["x"]).to(dev(), dtype).requires_grad_(True)
     g = torch.from_numpy(a["g"]).to(dev(), dtype)
-    delta = mod.bypass_forward_diff(x, scale=mod.multiplier)
+    dora = bool(meta["mod"].get("weight_decompose"))
+    if dora:  # the DoRA delta also rescales the frozen layer's own output: hand it the 16-bit base
+        delta = mod._dora_delta(x, layer(x).detach())
+    else:
+        delta = mod.bypass_forward_diff(x, scale=mod.multiplier)
     assert delta.dtype == dtype
     params = list(mod.named_parameters())
     grads = torch.autograd.grad(delta, [x] + [p for _, p in params], g)
@@ -105,6 +109,11 @@ def test_module_16bit_activations_fp32_factors(name, dtype, golden_cases):
     # (measured 2.6e-3 / 4.2e-3 for delta / dx in bf16: two 2^-9 roundings and the library conv's own accumulation order)
     store = (8e-3 if dtype == torch.bfloat16 else 1e-3) if meta["algo"] == "ia3" else (1e-3)
     f32 = 8e-3 if meta["algo"] == "ia3" and dtype == torch.bfloat16 else (1e-3 if meta["algo"] == "ia3" else 1e-4)
+    if dora:
+        # the (s - 1) * (x W^T) part is computed from the frozen layer's 16-bit output (resp. goes through its 16-bit GEMM):
+        # one more 2^-9 (bf16) / 2^-12 (fp16) rounding than the adapter-only deltas, as in the reference
+        store = 8e-3 if dtype == torch.bfloat16 else 1e-3
+        f32 = 8e-3 if dtype == torch.bfloat16 else 1e-3
     errs = {"delta": err(delta, want_delta, dtype), "dx": err(grads[0], want["dx"], dtype)}
     bounds = {"delta": store, "dx": store}
     for (n, p), gr in zip(params, grads[1:]):

@@ -61,9 +61,13 @@ def test_get_diff_weight_matches_reference_forward(name, golden_cases):
         for n, p in mod.named_parameters():
             p.copy_(torch.from_numpy(a["p." + n]))
     dw, _ = mod.get_diff_weight(meta["multiplier"], shape=layer.weight.shape)
+    merged, _ = mod.get_merged_weight(meta["multiplier"], shape=layer.weight.shape)
+    if meta["mod"].get("weight_decompose"):  # DoRA: the merged weight, not W + dW, reproduces the trained forward
+        delta = oracle.general.dense_forward(a["x"], (merged - layer.weight).detach().numpy(), conv_args_of(meta))
+        assert oracle.general.rel_err(delta, a["delta"]) < 1e-12
+        return
     delta = oracle.general.dense_forward(a["x"], dw.detach().numpy(), conv_args_of(meta))
     assert oracle.general.rel_err(delta, a["delta"]) < 1e-12
-    merged, _ = mod.get_merged_weight(meta["multiplier"], shape=layer.weight.shape)
     assert torch.allclose(merged - layer.weight, dw, atol=1e-12)
 
 
@@ -163,8 +167,20 @@ def test_no_cpu_fallback_and_unsupported_features_fail_loudly():
         layer(torch.randn(2, 16))
     mod.restore()
     assert layer(torch.randn(2, 16)).shape == (2, 16)
+    # DoRA is on the native path: the magnitude vector starts at the frozen weight's norms (locon.py:107-129)
+    lin = nn.Linear(8, 6)
+    for cls in (LoConModule, LohaModule, LokrModule):
+        m = cls("m", lin, 1.0, 2, 1, weight_decompose=True, wd_on_out=True)
+        assert m.wd and tuple(m.dora_scale.shape) == (6, 1)
+        assert torch.allclose(m.dora_scale.reshape(-1), lin.weight.detach().norm(dim=1))
+        assert "dora_scale" in m.state_dict()
+        m = cls("m", lin, 1.0, 2, 1, weight_decompose=True, wd_on_out=False)
+        assert tuple(m.dora_scale.shape) == (1, 8)
+        assert torch.allclose(m.dora_scale.reshape(-1), lin.weight.detach().norm(dim=0))
+    m = LoConModule("m", nn.Conv2d(4, 6, 3), 1.0, 2, 1, weight_decompose=True, wd_on_out=False)
+    assert tuple(m.dora_scale.shape) == (1, 4, 1, 1)
     with pytest.raises(NotImplementedError):
-        LoConModule("m", nn.Linear(8, 8), 1.0, 2, 1, weight_decompose=True)
+        LoConModule("m", nn.Linear(8, 8), 1.0, 2, 1, weight_decompose=True, rank_dropout=0.5)
     # the dropout variants are on the native path (applied around the kernels, tests/test_gpu_dropout.py)
     m = LoConModule("m", nn.Linear(8, 8), 1.0, 2, 1, dropout=0.1, rank_dropout=0.2, module_dropout=0.3,
                     rank_dropout_scale=True)

@@ -83,30 +83,16 @@ def test_create_lycoris_builds_native_modules(ref, algo, extra):
     assert wrapper.network_module_dict["lokr"].__module__.startswith("lycoris.modules")
 
 
-def test_unsupported_variant_is_loud_by_default_and_delegated_on_request(ref):
-    """weight_decompose (DoRA) is outside the native path: building it must raise unless the caller opted into
-    install(delegate_unsupported=True), in which case the reference's own module is built (with a warning) and the rest
-    of the network stays native."""
-    import warnings
-
+def test_dora_builds_natively_through_the_reference_wrapper(ref):
+    """weight_decompose (DoRA, `dora_wd=True` in the wrapper's kwargs) is on the native path: create_lycoris builds the
+    native class with a dora_scale parameter; there is no delegation to the reference's torch modules."""
     import lycoris_amd
     from lycoris import LycorisNetwork, create_lycoris
-    import lycoris.modules.locon as ref_locon
-
-    def build(**kw):
-        torch.manual_seed(0)
-        LycorisNetwork.apply_preset({"target_module": ["MLP"], "target_name": []})
-        return create_lycoris(MLP(), 1.0, linear_dim=4, linear_alpha=2.0, algo="lora", **kw)
 
     assert lycoris_amd.install()
-    with pytest.raises(NotImplementedError):
-        build(dora_wd=True)
-    lycoris_amd.uninstall()
-    assert lycoris_amd.install(delegate_unsupported=True)
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        net = build(dora_wd=True)
-    assert any("weight_decompose" in str(x.message) for x in w)
-    assert len(net.loras) == 3 and all(type(m) is ref_locon.LoConModule for m in net.loras)
-    plain = build()
-    assert all(type(m) is lycoris_amd.LoConModule for m in plain.loras)
+    torch.manual_seed(0)
+    LycorisNetwork.apply_preset({"target_module": ["MLP"], "target_name": []})
+    net = create_lycoris(MLP(), 1.0, linear_dim=4, linear_alpha=2.0, algo="lora", dora_wd=True)
+    assert len(net.loras) == 3 and all(type(m) is lycoris_amd.LoConModule and m.wd for m in net.loras)
+    assert all(any(k.endswith("dora_scale") for k in m.state_dict()) for m in net.loras)
+    assert not hasattr(lycoris_amd, "_delegating")
