@@ -1,0 +1,75 @@
+"""Host time per adapted layer, forward + backward, Python-driven (what an sd-scripts user pays without whole-step capture):
+C++ custom-op dispatch vs the ctypes / Python autograd.Function dispatch vs the reference's own torch call sequence.
+Tiny shapes (M = 16): the GPU work is negligible, the wall time between two syncs is host time.
+    python benchmarks/host_overhead.py  -> gpurun_out/host_overhead.json"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+
+from lycoris_amd import ops
+
+dev = torch.device("cuda:0")
+N_LAYERS, REPS = 200, 5
+
+
+def layers(algo):
+    out = []
+    for _ in range(N_LAYERS):
+        x = torch.randn(16, 1280, device=dev, dtype=torch.bfloat16, requires_grad=True)
+        g = torch.randn(16, 1280, device=dev, dtype=torch.bfloat16)
+        if algo == "lokr":
+            fs = [torch.nn.Parameter(torch.randn(8, 8, device=dev)), torch.nn.Parameter(torch.randn(160, 160, device=dev) * 0.05)]
+        else:
+            fs = [torch.nn.Parameter(torch.randn(16, 1280, device=dev) * 0.05), torch.nn.Parameter(torch.randn(1280, 16, device=dev) * 0.05)]
+        W = torch.randn(1280, 1280, device=dev, dtype=torch.bfloat16)
+        out.append((x, g, fs, W))
+    return out
+
+
+def native(algo, ls):
+    fn = ops.lokr_linear if algo == "lokr" else ops.locon_linear
+    ys = [fn(x, fs[0], fs[1], 1.0) for x, g, fs, W in ls]
+    for y, (x, g, fs, W) in zip(reversed(ys), reversed(ls)):
+        torch.autograd.grad(y, [x] + fs, g)
+
+
+def reference(algo, ls):
+    ys = []
+    for x, g, fs, W in ls:
+        dW = torch.kron(fs[0], fs[1]) if algo == "lokr" else fs[1] @ fs[0]
+        ys.append(F.linear(x, (W + dW.to(W.dtype)) - W))
+    for y, (x, g, fs, W) in zip(reversed(ys), reversed(ls)):
+        torch.autograd.grad(y, [x] + fs, g)
+
+
+def wall(fn):
+    fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(REPS):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best / N_LAYERS * 1e6
+
+
+res = {}
+for algo in ("lokr", "locon"):
+    ls = layers(algo)
+    row = {}
+    for mode in ("cpp", "python"):
+        ops.set_dispatch(mode)
+        row[f"native_{mode}_us"] = round(wall(lambda: native(algo, ls)), 1)
+    ops.set_dispatch("cpp")
+    row["reference_torch_us"] = round(wall(lambda: reference(algo, ls)), 1)
+    res[algo] = row
+    print(algo, row, flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump({"what": "host microseconds per adapted layer, fwd + bwd, M = 16 rows (GPU time negligible)", "per_layer": res},
+          open("gpurun_out/host_overhead.json", "w"), indent=1)

@@ -100,6 +100,37 @@ def load():
         return _lib
 
 
+_TORCH_EXT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lyc_torch.so")
+_torch_ext = None
+
+
+def load_torch_ops():
+    """Import the TORCH_LIBRARY(lycoris_amd) extension (csrc/torch_ops.cpp: C++ dispatch + autograd over the C ABI).
+    Like load(): no fallback -- a missing / unloadable extension is an error."""
+    global _torch_ext
+    if _torch_ext is not None:
+        return _torch_ext
+    with _lock:
+        if _torch_ext is not None:
+            return _torch_ext
+        load()  # the C-ABI library first (same ABI check, clearer error)
+        if not os.path.exists(_TORCH_EXT_PATH):
+            raise NativeLibraryError(
+                f"{_TORCH_EXT_PATH} not found: build the custom-op extension first (make -C lycoris_amd/csrc torch_ops, or "
+                "python -c 'import __graft_entry__ as g; g.build()').  lycoris_amd has no fallback path.")
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("lycoris_amd._lyc_torch", _TORCH_EXT_PATH)
+        try:
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+        except (ImportError, OSError) as e:
+            raise NativeLibraryError(f"cannot load {_TORCH_EXT_PATH}: {e}") from e
+        if mod.abi_version() != ABI_VERSION:
+            raise NativeLibraryError(f"{_TORCH_EXT_PATH}: built against ABI {mod.abi_version()}, expected {ABI_VERSION}")
+        _torch_ext = mod
+        return mod
+
+
 def call(name: str, *args):
     lib = load()
     rc = getattr(lib, name)(*args)

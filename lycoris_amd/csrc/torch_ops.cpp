@@ -1,0 +1,788 @@
+// torch_ops.cpp -- PyTorch-ROCm custom ops over the C ABI (include/lycoris_amd.h): TORCH_LIBRARY(lycoris_amd).
+//
+// SURVEY 8b "Native C-ABI layer to export": one forward + one backward schema per kernel family, autograd glue in C++
+// (torch::autograd::Function registered on the Autograd key), Meta kernels for FakeTensor / torch.compile tracing.
+// The reference's per-layer host work is a chain of ATen ops driven from Python (lycoris/modules/lokr.py:543-566);
+// here a layer's forward is ONE dispatcher call and its backward ONE autograd node, all host work in C++:
+// no ctypes, no Python autograd.Function, no per-call Python allocation (~185 us -> tens of us per layer fwd+bwd).
+//
+// Host-only translation unit (g++): the kernels live in liblycoris_amd.so, this file only passes device pointers,
+// sizes and torch's current HIP stream through `extern "C"` calls.
+#include <ATen/ATen.h>
+#include <ATen/autocast_mode.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/custom_function.h>
+#include <torch/extension.h>
+#include <torch/library.h>
+
+#include <mutex>
+
+#include "../../include/lycoris_amd.h"
+
+namespace {
+
+using at::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+constexpr int F32_ROWS = 0x100;
+
+int dtype_code(at::ScalarType t) {
+  switch (t) {
+    case at::kFloat: return LYC_F32;
+    case at::kHalf: return LYC_F16;
+    case at::kBFloat16: return LYC_BF16;
+    default: TORCH_CHECK(false, "lycoris_amd supports float32/float16/bfloat16 activations, got ", t);
+  }
+}
+
+void* stream_of(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+void check_rc(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed (code ", rc, "): ", lyc_last_error()); }
+
+void require_device(const Tensor& t, const char* what) {
+  TORCH_CHECK(t.is_cuda(), "lycoris_amd: ", what, " is on ", t.device(),
+              "; the adapter hot path only runs on the MI355X HIP device (there is no CPU fallback by design).");
+}
+
+// fp32 contiguous, detached view of a (small) factor
+Tensor f32c(const Tensor& t) {
+  Tensor f = t.detach();
+  if (f.scalar_type() != at::kFloat) f = f.to(at::kFloat);
+  return f.contiguous();
+}
+
+const void* cptr(const Tensor& t) { return t.defined() ? t.const_data_ptr() : nullptr; }
+void* mptr(const Tensor& t) { return t.defined() ? t.mutable_data_ptr() : nullptr; }
+const float* cfp(const Tensor& t) { return t.defined() ? t.const_data_ptr<float>() : nullptr; }
+float* mfp(const Tensor& t) { return t.defined() ? t.mutable_data_ptr<float>() : nullptr; }
+
+Tensor rows_of(const Tensor& x, int64_t feat) {
+  Tensor r = x.reshape({-1, feat});
+  return r.is_contiguous() ? r : r.contiguous();
+}
+
+// ---- fused gradient accumulation (mirror of ops.fused_grad_accumulation) ------------------------------------------------
+// When a factor is a leaf whose .grad exists as a contiguous fp32 tensor (e.g. a view of grad_sync's arena) the backward
+// kernels accumulate straight into it and autograd gets an undefined gradient for that input.  `callback` (a Python
+// callable, e.g. AdapterGradSync._on_grad_ready) is told which parameter was updated.
+struct Accum {
+  bool enabled = false;
+  py::object* callback = nullptr;  // leaked on purpose: must not be destroyed after the interpreter has shut down
+  std::mutex mu;
+} g_accum;
+
+void notify(const Tensor& param) {
+  if (g_accum.callback == nullptr) return;
+  py::gil_scoped_acquire gil;
+  if (!g_accum.callback->is_none()) (*g_accum.callback)(param);
+}
+
+// a real device tensor in eager mode (not a FakeTensor / functional wrapper seen while torch.compile traces)
+bool eager_cuda(const Tensor& t) {
+  const c10::DispatchKeySet ks = t.key_set();
+  return t.is_cuda() && !ks.has(c10::DispatchKey::Python) && !ks.has(c10::DispatchKey::Meta) &&
+         !ks.has(c10::DispatchKey::Functionalize);
+}
+
+// the tensor the kernel accumulates into: existing .grad (hand_back = false) or a fresh zero buffer (hand_back = true)
+struct GradTarget {
+  Tensor buf;
+  bool hand_back = false;
+};
+GradTarget grad_target(const Tensor& factor, bool need, c10::optional<at::IntArrayRef> shape = c10::nullopt) {
+  GradTarget g;
+  if (!need) return g;
+  if (g_accum.enabled && factor.is_leaf()) {
+    const Tensor& gr = factor.grad();
+    if (gr.defined() && gr.scalar_type() == at::kFloat && gr.is_contiguous() && gr.device() == factor.device()) {
+      g.buf = gr;
+      return g;
+    }
+  }
+  g.buf = at::zeros(shape.has_value() ? *shape : factor.sizes(), factor.options().dtype(at::kFloat));
+  g.hand_back = true;
+  return g;
+}
+Tensor finish_grad(const Tensor& factor, const GradTarget& g) {
+  if (!g.buf.defined()) return Tensor();
+  if (g.hand_back) return g.buf.reshape(factor.sizes()).to(factor.scalar_type());
+  notify(factor);
+  return Tensor();
+}
+
+// torch.autocast parity (see ops._amp): an fp32 activation is cast to the autocast dtype, differentiably
+Tensor amp(const Tensor& x) {
+  if (x.is_cuda() && x.scalar_type() == at::kFloat && at::autocast::is_autocast_enabled(at::kCUDA))
+    return x.to(at::autocast::get_autocast_dtype(at::kCUDA));
+  return x;
+}
+
+// =====================================================================================================================
+// LoKr on nn.Linear
+// =====================================================================================================================
+Tensor lokr_linear_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha) {
+  require_device(x, "input");
+  const c10::DeviceGuard guard(x.device());
+  TORCH_CHECK(w1.dim() == 2 && w2.dim() == 2, "lokr_linear: w1 [a, b], w2 [c, d]");
+  const int64_t a = w1.size(0), b = w1.size(1), c = w2.size(0), d = w2.size(1);
+  TORCH_CHECK(x.size(-1) == b * d, "adapter expects ", b * d, " input features, got ", x.sizes());
+  Tensor rows = rows_of(x, b * d), f1 = f32c(w1), f2 = f32c(w2);
+  auto oshape = x.sizes().vec();
+  oshape.back() = a * c;
+  Tensor y = at::empty({rows.size(0), a * c}, x.options());
+  check_rc(lyc_lokr_linear_fwd(cptr(rows), cfp(f1), cfp(f2), mptr(y), rows.size(0), (int)a, (int)b, (int)c, (int)d,
+                               (float)alpha, dtype_code(x.scalar_type()), stream_of(x)), "lyc_lokr_linear_fwd");
+  return y.view(oshape);
+}
+
+// dx (or undefined), and the factor gradients accumulated into dw1 / dw2 when those are defined
+Tensor lokr_linear_bwd_into(const Tensor& g, const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, bool need_dx,
+                            const Tensor& dw1, const Tensor& dw2) {
+  const c10::DeviceGuard guard(x.device());
+  const int64_t a = w1.size(0), b = w1.size(1), c = w2.size(0), d = w2.size(1);
+  Tensor rows = rows_of(x, b * d), g2 = rows_of(g, a * c), f1 = f32c(w1), f2 = f32c(w2);
+  const int code = dtype_code(x.scalar_type());
+  const bool want_dx = need_dx || dw1.defined();  // the w1 gradient shares the pass over g that produces dx
+  Tensor dx, ws;
+  if (want_dx) dx = at::empty(rows.sizes(), x.options());
+  if (dw1.defined()) {
+    const int64_t nbytes = lyc_lokr_bwd_workspace_bytes(rows.size(0), (int)a, (int)b, (int)c, (int)d, code);
+    if (nbytes > 0) ws = at::empty({nbytes}, x.options().dtype(at::kByte));
+  }
+  check_rc(lyc_lokr_linear_bwd(cptr(g2), cptr(rows), cfp(f1), cfp(f2), mptr(dx), mfp(dw1), mfp(dw2), mptr(ws), rows.size(0),
+                               (int)a, (int)b, (int)c, (int)d, (float)alpha, code, stream_of(x)), "lyc_lokr_linear_bwd");
+  return need_dx ? dx.view(x.sizes()) : Tensor();
+}
+
+std::tuple<Tensor, Tensor, Tensor> lokr_linear_bwd(const Tensor& g, const Tensor& x, const Tensor& w1, const Tensor& w2,
+                                                   double alpha, bool need_dx, bool need_dw1, bool need_dw2) {
+  Tensor dw1 = need_dw1 ? at::zeros(w1.sizes(), w1.options().dtype(at::kFloat)) : Tensor();
+  Tensor dw2 = need_dw2 ? at::zeros(w2.sizes(), w2.options().dtype(at::kFloat)) : Tensor();
+  Tensor dx = lokr_linear_bwd_into(g, x, w1, w2, alpha, need_dx, dw1, dw2);
+  return {dx.defined() ? dx : at::empty({0}, x.options()), need_dw1 ? dw1.to(w1.scalar_type()) : at::empty({0}, w1.options()),
+          need_dw2 ? dw2.to(w2.scalar_type()) : at::empty({0}, w2.options())};
+}
+
+struct LokrLinearFn : public torch::autograd::Function<LokrLinearFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::lokr_linear", "")
+                         .typed<Tensor(const Tensor&, const Tensor&, const Tensor&, double)>();
+    Tensor y = op.call(x, w1, w2, alpha);
+    ctx->save_for_backward({x, w1, w2});
+    ctx->saved_data["alpha"] = alpha;
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &w1 = saved[1], &w2 = saved[2];
+    const double alpha = ctx->saved_data["alpha"].toDouble();
+    const bool nx = ctx->needs_input_grad(0), n1 = ctx->needs_input_grad(1), n2 = ctx->needs_input_grad(2);
+    Tensor g = grads[0];
+    if (eager_cuda(g) && eager_cuda(x)) {  // eager: accumulate straight into .grad where possible
+      GradTarget t1 = grad_target(w1, n1), t2 = grad_target(w2, n2);
+      Tensor dx = lokr_linear_bwd_into(g, x, w1, w2, alpha, nx, t1.buf, t2.buf);
+      return {dx, finish_grad(w1, t1), finish_grad(w2, t2), Tensor()};
+    }
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_lokr_linear_backward", "")
+                         .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&,
+                                                                   double, bool, bool, bool)>();
+    auto [dx, d1, d2] = op.call(g, x, w1, w2, alpha, nx, n1, n2);
+    return {nx ? dx : Tensor(), n1 ? d1 : Tensor(), n2 ? d2 : Tensor(), Tensor()};
+  }
+};
+
+Tensor lokr_linear_autograd(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha) {
+  return LokrLinearFn::apply(amp(x), w1, w2, alpha);
+}
+
+Tensor lokr_linear_meta(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha) {
+  auto oshape = x.sym_sizes().vec();
+  oshape.back() = w1.sym_size(0) * w2.sym_size(0);
+  return x.new_empty_symint(oshape);
+}
+std::tuple<Tensor, Tensor, Tensor> lokr_linear_bwd_meta(const Tensor& g, const Tensor& x, const Tensor& w1, const Tensor& w2,
+                                                        double alpha, bool need_dx, bool need_dw1, bool need_dw2) {
+  return {need_dx ? at::empty_like(x) : x.new_empty({0}), need_dw1 ? at::empty_like(w1) : w1.new_empty({0}),
+          need_dw2 ? at::empty_like(w2) : w2.new_empty({0})};
+}
+
+// =====================================================================================================================
+// LoCon on nn.Linear
+// =====================================================================================================================
+std::tuple<Tensor, Tensor> locon_linear_fwd(const Tensor& x, const Tensor& down, const Tensor& up, double alpha) {
+  require_device(x, "input");
+  const c10::DeviceGuard guard(x.device());
+  TORCH_CHECK(down.dim() == 2 && up.dim() == 2 && down.size(0) == up.size(1), "locon_linear: down [r, I], up [O, r]");
+  const int64_t r = down.size(0), I = down.size(1), O = up.size(0);
+  TORCH_CHECK(x.size(-1) == I, "adapter expects ", I, " input features, got ", x.sizes());
+  Tensor rows = rows_of(x, I), fd = f32c(down), fu = f32c(up);
+  const int64_t M = rows.size(0);
+  Tensor t = at::empty({M, r}, x.options().dtype(at::kFloat));
+  Tensor y = at::empty({M, O}, x.options());
+  check_rc(lyc_locon_linear_fwd(cptr(rows), cfp(fd), cfp(fu), mfp(t), mptr(y), M, (int)I, (int)O, (int)r, (float)alpha,
+                                dtype_code(x.scalar_type()), stream_of(x)), "lyc_locon_linear_fwd");
+  auto oshape = x.sizes().vec();
+  oshape.back() = O;
+  return {y.view(oshape), t};
+}
+
+Tensor locon_linear_bwd_into(const Tensor& g, const Tensor& x, const Tensor& down, const Tensor& up, const Tensor& t, double alpha,
+                             bool need_dx, const Tensor& dd, const Tensor& du) {
+  const c10::DeviceGuard guard(x.device());
+  const int64_t r = down.size(0), I = down.size(1), O = up.size(0);
+  Tensor rows = rows_of(x, I), g2 = rows_of(g, O), fd = f32c(down), fu = f32c(up);
+  const int64_t M = rows.size(0);
+  Tensor dt = at::empty({M, r}, x.options().dtype(at::kFloat));
+  Tensor dx = need_dx ? at::empty(rows.sizes(), x.options()) : Tensor();
+  check_rc(lyc_locon_linear_bwd(cptr(g2), cptr(rows), cfp(fd), cfp(fu), cfp(t), mfp(dt), mptr(dx), mfp(dd), mfp(du), M, (int)I,
+                                (int)O, (int)r, (float)alpha, dtype_code(x.scalar_type()), stream_of(x)), "lyc_locon_linear_bwd");
+  return need_dx ? dx.view(x.sizes()) : Tensor();
+}
+
+std::tuple<Tensor, Tensor, Tensor> locon_linear_bwd(const Tensor& g, const Tensor& x, const Tensor& down, const Tensor& up,
+                                                    const Tensor& t, double alpha, bool need_dx, bool need_dd, bool need_du) {
+  Tensor dd = need_dd ? at::zeros(down.sizes(), down.options().dtype(at::kFloat)) : Tensor();
+  Tensor du = need_du ? at::zeros(up.sizes(), up.options().dtype(at::kFloat)) : Tensor();
+  Tensor dx = locon_linear_bwd_into(g, x, down, up, t, alpha, need_dx, dd, du);
+  return {dx.defined() ? dx : at::empty({0}, x.options()), need_dd ? dd.to(down.scalar_type()) : at::empty({0}, down.options()),
+          need_du ? du.to(up.scalar_type()) : at::empty({0}, up.options())};
+}
+
+struct LoconLinearFn : public torch::autograd::Function<LoconLinearFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& down, const Tensor& up, double alpha) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_locon_linear_forward", "")
+                         .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, double)>();
+    auto [y, t] = op.call(x, down, up, alpha);
+    ctx->save_for_backward({x, down, up, t});
+    ctx->saved_data["alpha"] = alpha;
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &down = saved[1], &up = saved[2], &t = saved[3];
+    const double alpha = ctx->saved_data["alpha"].toDouble();
+    const bool nx = ctx->needs_input_grad(0), nd = ctx->needs_input_grad(1), nu = ctx->needs_input_grad(2);
+    Tensor g = grads[0];
+    if (eager_cuda(g) && eager_cuda(x)) {
+      GradTarget td = grad_target(down, nd), tu = grad_target(up, nu);
+      Tensor dx = locon_linear_bwd_into(g, x, down, up, t, alpha, nx, td.buf, tu.buf);
+      return {dx, finish_grad(down, td), finish_grad(up, tu), Tensor()};
+    }
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_locon_linear_backward", "")
+                         .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&,
+                                                                   const Tensor&, double, bool, bool, bool)>();
+    auto [dx, dd, du] = op.call(g, x, down, up, t, alpha, nx, nd, nu);
+    return {nx ? dx : Tensor(), nd ? dd : Tensor(), nu ? du : Tensor(), Tensor()};
+  }
+};
+Tensor locon_linear_autograd(const Tensor& x, const Tensor& down, const Tensor& up, double alpha) {
+  return LoconLinearFn::apply(amp(x), down, up, alpha);
+}
+Tensor locon_linear_cuda(const Tensor& x, const Tensor& down, const Tensor& up, double alpha) {
+  return std::get<0>(locon_linear_fwd(x, down, up, alpha));
+}
+std::tuple<Tensor, Tensor> locon_linear_fwd_meta(const Tensor& x, const Tensor& down, const Tensor& up, double alpha) {
+  auto oshape = x.sym_sizes().vec();
+  oshape.back() = up.sym_size(0);
+  c10::SymInt M = x.sym_numel() / x.sym_size(-1);
+  return {x.new_empty_symint(oshape), x.new_empty_symint({M, down.sym_size(0)}, x.options().dtype(at::kFloat))};
+}
+Tensor locon_linear_meta(const Tensor& x, const Tensor& down, const Tensor& up, double alpha) {
+  return std::get<0>(locon_linear_fwd_meta(x, down, up, alpha));
+}
+std::tuple<Tensor, Tensor, Tensor> locon_linear_bwd_meta(const Tensor& g, const Tensor& x, const Tensor& down, const Tensor& up,
+                                                         const Tensor& t, double alpha, bool nx, bool nd, bool nu) {
+  return {nx ? at::empty_like(x) : x.new_empty({0}), nd ? at::empty_like(down) : down.new_empty({0}),
+          nu ? at::empty_like(up) : up.new_empty({0})};
+}
+
+// =====================================================================================================================
+// LoHa on nn.Linear
+// =====================================================================================================================
+std::tuple<Tensor, Tensor> loha_linear_fwd(const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a,
+                                           const Tensor& w2b, double alpha) {
+  require_device(x, "input");
+  const c10::DeviceGuard guard(x.device());
+  const int64_t O = w1a.size(0), r = w1a.size(1), I = w1b.size(1);
+  TORCH_CHECK(x.size(-1) == I, "adapter expects ", I, " input features, got ", x.sizes());
+  Tensor rows = rows_of(x, I), a1 = f32c(w1a), b1 = f32c(w1b), a2 = f32c(w2a), b2 = f32c(w2b);
+  const int code = dtype_code(x.scalar_type());
+  Tensor ws = at::empty({lyc_loha_workspace_bytes((int)O, (int)I, code)}, x.options().dtype(at::kByte));
+  Tensor y = at::empty({rows.size(0), O}, x.options());
+  check_rc(lyc_loha_linear_fwd(cptr(rows), cfp(a1), cfp(b1), cfp(a2), cfp(b2), mptr(ws), mptr(y), rows.size(0), (int)I, (int)O,
+                               (int)r, (float)alpha, code, stream_of(x)), "lyc_loha_linear_fwd");
+  auto oshape = x.sizes().vec();
+  oshape.back() = O;
+  return {y.view(oshape), ws};
+}
+
+Tensor loha_linear_bwd_into(const Tensor& g, const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a,
+                            const Tensor& w2b, const Tensor& ws, double alpha, bool need_dx, Tensor (&d)[4]) {
+  const c10::DeviceGuard guard(x.device());
+  const int64_t O = w1a.size(0), r = w1a.size(1), I = w1b.size(1);
+  Tensor rows = rows_of(x, I), g2 = rows_of(g, O), a1 = f32c(w1a), b1 = f32c(w1b), a2 = f32c(w2a), b2 = f32c(w2b);
+  const bool any = d[0].defined() || d[1].defined() || d[2].defined() || d[3].defined();
+  const Tensor* fs[4] = {&w1a, &w1b, &w2a, &w2b};
+  Tensor tmp[4];
+  if (any)  // the factor-gradient kernel produces the four gradients as a set
+    for (int i = 0; i < 4; ++i) tmp[i] = d[i].defined() ? d[i] : at::zeros(fs[i]->sizes(), fs[i]->options().dtype(at::kFloat));
+  Tensor gw = any ? at::empty({O, I}, x.options().dtype(at::kFloat)) : Tensor();
+  Tensor dx = need_dx ? at::empty(rows.sizes(), x.options()) : Tensor();
+  check_rc(lyc_loha_linear_bwd(cptr(g2), cptr(rows), cfp(a1), cfp(b1), cfp(a2), cfp(b2), cptr(ws), mfp(gw), mptr(dx), mfp(tmp[0]),
+                               mfp(tmp[1]), mfp(tmp[2]), mfp(tmp[3]), rows.size(0), (int)I, (int)O, (int)r, (float)alpha,
+                               dtype_code(x.scalar_type()), stream_of(x)), "lyc_loha_linear_bwd");
+  return need_dx ? dx.view(x.sizes()) : Tensor();
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> loha_linear_bwd(const Tensor& g, const Tensor& x, const Tensor& w1a,
+                                                                   const Tensor& w1b, const Tensor& w2a, const Tensor& w2b,
+                                                                   const Tensor& ws, double alpha, bool need_dx, bool need_f) {
+  const Tensor* fs[4] = {&w1a, &w1b, &w2a, &w2b};
+  Tensor d[4];
+  if (need_f)
+    for (int i = 0; i < 4; ++i) d[i] = at::zeros(fs[i]->sizes(), fs[i]->options().dtype(at::kFloat));
+  Tensor dx = loha_linear_bwd_into(g, x, w1a, w1b, w2a, w2b, ws, alpha, need_dx, d);
+  auto out = [&](int i) { return need_f ? d[i].to(fs[i]->scalar_type()) : at::empty({0}, fs[i]->options()); };
+  return {dx.defined() ? dx : at::empty({0}, x.options()), out(0), out(1), out(2), out(3)};
+}
+
+struct LohaLinearFn : public torch::autograd::Function<LohaLinearFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a,
+                        const Tensor& w2b, double alpha) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_loha_linear_forward", "")
+                         .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&,
+                                                           double)>();
+    auto [y, ws] = op.call(x, w1a, w1b, w2a, w2b, alpha);
+    ctx->save_for_backward({x, w1a, w1b, w2a, w2b, ws});
+    ctx->saved_data["alpha"] = alpha;
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const double alpha = ctx->saved_data["alpha"].toDouble();
+    const bool nx = ctx->needs_input_grad(0);
+    bool nf[4], any = false;
+    for (int i = 0; i < 4; ++i) any = (nf[i] = ctx->needs_input_grad(1 + i)) || any;
+    Tensor g = grads[0];
+    if (eager_cuda(g) && eager_cuda(s[0])) {
+      GradTarget t[4];
+      Tensor d[4];
+      for (int i = 0; i < 4; ++i) {
+        t[i] = grad_target(s[1 + i], nf[i]);
+        d[i] = t[i].buf;
+      }
+      Tensor dx = loha_linear_bwd_into(g, s[0], s[1], s[2], s[3], s[4], s[5], alpha, nx, d);
+      return {dx, finish_grad(s[1], t[0]), finish_grad(s[2], t[1]), finish_grad(s[3], t[2]), finish_grad(s[4], t[3]), Tensor()};
+    }
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_loha_linear_backward", "")
+                         .typed<std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&,
+                                                                                   const Tensor&, const Tensor&, const Tensor&,
+                                                                                   const Tensor&, double, bool, bool)>();
+    auto [dx, d0, d1, d2, d3] = op.call(g, s[0], s[1], s[2], s[3], s[4], s[5], alpha, nx, any);
+    return {nx ? dx : Tensor(), nf[0] ? d0 : Tensor(), nf[1] ? d1 : Tensor(), nf[2] ? d2 : Tensor(), nf[3] ? d3 : Tensor(), Tensor()};
+  }
+};
+Tensor loha_linear_autograd(const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a, const Tensor& w2b,
+                            double alpha) {
+  return LohaLinearFn::apply(amp(x), w1a, w1b, w2a, w2b, alpha);
+}
+Tensor loha_linear_cuda(const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a, const Tensor& w2b, double alpha) {
+  return std::get<0>(loha_linear_fwd(x, w1a, w1b, w2a, w2b, alpha));
+}
+std::tuple<Tensor, Tensor> loha_linear_fwd_meta(const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a,
+                                                const Tensor& w2b, double alpha) {
+  auto oshape = x.sym_sizes().vec();
+  oshape.back() = w1a.sym_size(0);
+  const int64_t O = w1a.size(0), I = w1b.size(1);
+  return {x.new_empty_symint(oshape),
+          x.new_empty({lyc_loha_workspace_bytes((int)O, (int)I, dtype_code(x.scalar_type()))}, x.options().dtype(at::kByte))};
+}
+Tensor loha_linear_meta(const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a, const Tensor& w2b, double alpha) {
+  return std::get<0>(loha_linear_fwd_meta(x, w1a, w1b, w2a, w2b, alpha));
+}
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> loha_linear_bwd_meta(const Tensor& g, const Tensor& x, const Tensor& w1a,
+                                                                        const Tensor& w1b, const Tensor& w2a, const Tensor& w2b,
+                                                                        const Tensor& ws, double alpha, bool nx, bool nf) {
+  auto e = [&](const Tensor& t, bool n) { return n ? at::empty_like(t) : t.new_empty({0}); };
+  return {e(x, nx), e(w1a, nf), e(w1b, nf), e(w2a, nf), e(w2b, nf)};
+}
+
+// =====================================================================================================================
+// (IA)^3 per-channel affine:  out = a * (s0 + w[c] * mult) - bias[c] * w[c] * mult   over dimension chan_dim
+// =====================================================================================================================
+void chan_dims(const Tensor& t, int64_t chan_dim, int64_t& outer, int64_t& C, int64_t& inner) {
+  C = t.size(chan_dim);
+  outer = inner = 1;
+  for (int64_t i = 0; i < chan_dim; ++i) outer *= t.size(i);
+  for (int64_t i = chan_dim + 1; i < t.dim(); ++i) inner *= t.size(i);
+}
+
+Tensor chan_scale(const Tensor& a_in, const Tensor& w, const c10::optional<Tensor>& bias, double s0, double mult, int64_t chan_dim) {
+  require_device(a_in, "input");
+  const c10::DeviceGuard guard(a_in.device());
+  Tensor a = a_in.contiguous();
+  chan_dim = at::maybe_wrap_dim(chan_dim, a.dim());
+  int64_t outer, C, inner;
+  chan_dims(a, chan_dim, outer, C, inner);
+  Tensor wf = f32c(w).reshape({-1});
+  TORCH_CHECK(wf.numel() == C, "(IA)^3 weight has ", wf.numel(), " entries, channel dim has ", C);
+  Tensor bf = (bias.has_value() && bias->defined()) ? f32c(*bias).reshape({-1}) : Tensor();
+  Tensor out = at::empty_like(a);
+  check_rc(lyc_chan_scale(cptr(a), cfp(wf), cfp(bf), mptr(out), outer, C, inner, (float)s0, (float)mult,
+                          dtype_code(a.scalar_type()), stream_of(a)), "lyc_chan_scale");
+  return out;
+}
+
+// dw[c] += mult * sum g * (a - bias[c])   accumulated into `dw` (fp32, C entries)
+void chan_reduce_into(const Tensor& g_in, const Tensor& a_in, const c10::optional<Tensor>& bias, double mult, int64_t chan_dim,
+                      const Tensor& dw) {
+  const c10::DeviceGuard guard(a_in.device());
+  Tensor a = a_in.contiguous(), g = g_in.contiguous();
+  chan_dim = at::maybe_wrap_dim(chan_dim, a.dim());
+  int64_t outer, C, inner;
+  chan_dims(a, chan_dim, outer, C, inner);
+  Tensor bf = (bias.has_value() && bias->defined()) ? f32c(*bias).reshape({-1}) : Tensor();
+  check_rc(lyc_chan_reduce(cptr(g), cptr(a), cfp(bf), mfp(dw), outer, C, inner, (float)mult, dtype_code(a.scalar_type()),
+                           stream_of(a)), "lyc_chan_reduce");
+}
+Tensor chan_reduce(const Tensor& g, const Tensor& a, const c10::optional<Tensor>& bias, const Tensor& w_like, double mult,
+                   int64_t chan_dim) {
+  Tensor dw = at::zeros(w_like.sizes(), w_like.options().dtype(at::kFloat));
+  chan_reduce_into(g, a, bias, mult, chan_dim, dw);
+  return dw.to(w_like.scalar_type());
+}
+
+struct ChanAffineFn : public torch::autograd::Function<ChanAffineFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& a, const Tensor& w, const c10::optional<Tensor>& bias, double s0,
+                        double mult, int64_t chan_dim) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::chan_affine", "")
+                         .typed<Tensor(const Tensor&, const Tensor&, const c10::optional<Tensor>&, double, double, int64_t)>();
+    Tensor out = op.call(a, w, bias, s0, mult, chan_dim);
+    ctx->save_for_backward({a, w, bias.has_value() ? *bias : Tensor()});
+    ctx->saved_data["s0"] = s0;
+    ctx->saved_data["mult"] = mult;
+    ctx->saved_data["chan_dim"] = at::maybe_wrap_dim(chan_dim, a.dim());
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const Tensor &a = s[0], &w = s[1];
+    c10::optional<Tensor> bias = s[2].defined() ? c10::optional<Tensor>(s[2]) : c10::nullopt;
+    const double s0 = ctx->saved_data["s0"].toDouble(), mult = ctx->saved_data["mult"].toDouble();
+    const int64_t chan_dim = ctx->saved_data["chan_dim"].toInt();
+    Tensor g = grads[0], da, dw;
+    static auto scale = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::chan_affine", "")
+                            .typed<Tensor(const Tensor&, const Tensor&, const c10::optional<Tensor>&, double, double, int64_t)>();
+    if (ctx->needs_input_grad(0)) da = scale.call(g, w, c10::nullopt, s0, mult, chan_dim);
+    if (ctx->needs_input_grad(1)) {
+      if (eager_cuda(g) && eager_cuda(a)) {
+        GradTarget t = grad_target(w, true);
+        chan_reduce_into(g, a, bias, mult, chan_dim, t.buf);
+        dw = finish_grad(w, t);
+      } else {
+        static auto red = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_chan_reduce", "")
+                              .typed<Tensor(const Tensor&, const Tensor&, const c10::optional<Tensor>&, const Tensor&, double, int64_t)>();
+        dw = red.call(g, a, bias, w, mult, chan_dim);
+      }
+    }
+    return {da, dw, Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+Tensor chan_affine_autograd(const Tensor& a, const Tensor& w, const c10::optional<Tensor>& bias, double s0, double mult,
+                            int64_t chan_dim) {
+  return ChanAffineFn::apply(amp(a), w, bias, s0, mult, chan_dim);
+}
+Tensor chan_affine_meta(const Tensor& a, const Tensor& w, const c10::optional<Tensor>& bias, double s0, double mult, int64_t chan_dim) {
+  return at::empty_like(a, a.options().memory_format(at::MemoryFormat::Contiguous));
+}
+Tensor chan_reduce_meta(const Tensor& g, const Tensor& a, const c10::optional<Tensor>& bias, const Tensor& w_like, double mult,
+                        int64_t chan_dim) {
+  return at::empty_like(w_like);
+}
+
+// =====================================================================================================================
+// Conv2d without im2col (LoKr, LoCon): NHWC row matrices, see include/lycoris_amd.h
+// =====================================================================================================================
+struct Geom {
+  int kh, kw, sh, sw, ph, pw, dh, dw;
+  int64_t Ho, Wo;
+};
+Geom geom_of(at::IntArrayRef ksize, at::IntArrayRef s, at::IntArrayRef p, at::IntArrayRef d, int64_t H, int64_t W) {
+  Geom g{(int)ksize[0], (int)ksize[1], (int)s[0], (int)s[1], (int)p[0], (int)p[1], (int)d[0], (int)d[1], 0, 0};
+  g.Ho = (H + 2 * g.ph - g.dh * (g.kh - 1) - 1) / g.sh + 1;
+  g.Wo = (W + 2 * g.pw - g.dw * (g.kw - 1) - 1) / g.sw + 1;
+  return g;
+}
+
+// [B, C, H, W] -> [B*H*W, C] NHWC rows; *copied = false when the tensor already is such a matrix (channels_last)
+Tensor rows_view(const Tensor& t, bool* copied) {
+  const int64_t B = t.size(0), C = t.size(1), H = t.size(2), W = t.size(3);
+  if (t.is_contiguous(at::MemoryFormat::ChannelsLast) && !(C == 1 || H * W == 1)) {
+    *copied = false;
+    return t.permute({0, 2, 3, 1}).reshape({B * H * W, C});
+  }
+  Tensor tc = t.contiguous();
+  Tensor rows = at::empty({B * H * W, C}, t.options());
+  check_rc(lyc_nchw_to_rows(cptr(tc), mptr(rows), B, C, H * W, dtype_code(t.scalar_type()), stream_of(t)), "lyc_nchw_to_rows");
+  *copied = true;
+  return rows;
+}
+Tensor from_rows(const Tensor& rows, int64_t B, int64_t H, int64_t W, bool channels_last) {
+  const int64_t C = rows.size(1);
+  if (channels_last) return rows.view({B, H, W, C}).permute({0, 3, 1, 2});
+  Tensor out = at::empty({B, C, H, W}, rows.options());
+  check_rc(lyc_rows_to_nchw(cptr(rows), mptr(out), B, C, H * W, dtype_code(rows.scalar_type()), stream_of(rows)), "lyc_rows_to_nchw");
+  return out;
+}
+
+// gradient buffer of a 4-D parameter whose kernels work in the permute(0, 2, 3, 1) (window-major) layout
+GradTarget cl_grad_target(const Tensor& p, bool need, at::IntArrayRef shape_p) {
+  GradTarget g;
+  if (!need) return g;
+  if (g_accum.enabled && p.is_leaf()) {
+    const Tensor& gr = p.grad();
+    if (gr.defined() && gr.scalar_type() == at::kFloat && gr.device() == p.device() && gr.permute({0, 2, 3, 1}).is_contiguous()) {
+      g.buf = gr.permute({0, 2, 3, 1});
+      return g;
+    }
+  }
+  g.buf = at::zeros(shape_p, p.options().dtype(at::kFloat));
+  g.hand_back = true;
+  return g;
+}
+Tensor cl_finish(const Tensor& p, const GradTarget& g) {
+  if (!g.buf.defined()) return Tensor();
+  if (g.hand_back) return g.buf.permute({0, 3, 1, 2}).to(p.scalar_type());
+  notify(p);
+  return Tensor();
+}
+
+struct LokrConv2dFn : public torch::autograd::Function<LokrConv2dFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha,
+                        std::vector<int64_t> stride, std::vector<int64_t> padding, std::vector<int64_t> dilation) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    require_device(x, "input");
+    TORCH_CHECK(eager_cuda(x), "lycoris_amd::lokr_conv2d is an eager op (its forward / backward are not split into traceable ops yet)");
+    const c10::DeviceGuard dg(x.device());
+    TORCH_CHECK(x.dim() == 4 && w2.dim() == 4, "lokr_conv2d: NCHW input, w2 [c, d, kh, kw]");
+    const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+    const int64_t a = w1.size(0), b = w1.size(1), c = w2.size(0), d = w2.size(1);
+    TORCH_CHECK(C == b * d, "adapter expects ", b * d, " input channels, got ", x.sizes());
+    Geom gm = geom_of({w2.size(2), w2.size(3)}, stride, padding, dilation, H, W);
+    bool copied;
+    Tensor rows = rows_view(x, &copied), f1 = f32c(w1), w2p = f32c(w2.detach().permute({0, 2, 3, 1}));
+    Tensor y = at::empty({B * gm.Ho * gm.Wo, a * c}, x.options());
+    check_rc(lyc_lokr_conv2d_fwd(cptr(rows), cfp(f1), cfp(w2p), mptr(y), B, H, W, (int)a, (int)b, (int)c, (int)d, gm.kh, gm.kw, gm.sh,
+                                 gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, (float)alpha, dtype_code(x.scalar_type()), stream_of(x)),
+             "lyc_lokr_conv2d_fwd");
+    ctx->save_for_backward({rows, w1, w2});
+    ctx->saved_data["alpha"] = alpha;
+    ctx->saved_data["geom"] = std::vector<int64_t>{gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, gm.Ho, gm.Wo, B, C, H, W, !copied};
+    return from_rows(y, B, gm.Ho, gm.Wo, !copied);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const Tensor &rows = s[0], &w1 = s[1], &w2 = s[2];
+    const double alpha = ctx->saved_data["alpha"].toDouble();
+    auto gv = ctx->saved_data["geom"].toIntVector();
+    const int64_t B = gv[10], C = gv[11], H = gv[12], W = gv[13];
+    const bool x_cl = gv[14] != 0;
+    const int64_t a = w1.size(0), b = w1.size(1), c = w2.size(0), d = w2.size(1);
+    const c10::DeviceGuard dg(rows.device());
+    bool cp;
+    Tensor g_rows = rows_view(grads[0], &cp);
+    const bool nx = ctx->needs_input_grad(0), n1 = ctx->needs_input_grad(1), n2 = ctx->needs_input_grad(2);
+    Tensor f1 = f32c(w1), w2p = f32c(w2.detach().permute({0, 2, 3, 1}));
+    const int code = dtype_code(rows.scalar_type());
+    Tensor dx_rows = (nx || n1) ? at::empty({B * H * W, C}, rows.options()) : Tensor();
+    GradTarget t1 = grad_target(w1, n1);
+    GradTarget t2 = cl_grad_target(w2, n2, {c, gv[0], gv[1], d});
+    Tensor ws;
+    if (t1.buf.defined()) {
+      const int64_t nb = lyc_lokr_conv2d_bwd_workspace_bytes(B, H, W, (int)a, (int)b, (int)d);
+      if (nb > 0) ws = at::empty({nb}, rows.options().dtype(at::kByte));
+    }
+    Tensor w2t;  // stride 1: a [kh, kw, c, d] copy lets the transposed convolution use full K segments
+    if (dx_rows.defined() && gv[2] == 1 && gv[3] == 1) w2t = w2.detach().to(at::kFloat).permute({2, 3, 0, 1}).contiguous();
+    check_rc(lyc_lokr_conv2d_bwd(cptr(g_rows), cptr(rows), cfp(f1), cfp(w2p), cfp(w2t), mptr(dx_rows), mfp(t1.buf), mfp(t2.buf),
+                                 mptr(ws), B, H, W, (int)a, (int)b, (int)c, (int)d, (int)gv[0], (int)gv[1], (int)gv[2], (int)gv[3],
+                                 (int)gv[4], (int)gv[5], (int)gv[6], (int)gv[7], (float)alpha, code, stream_of(rows)),
+             "lyc_lokr_conv2d_bwd");
+    Tensor dx = nx ? from_rows(dx_rows, B, H, W, x_cl) : Tensor();
+    return {dx, finish_grad(w1, t1), cl_finish(w2, t2), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+Tensor lokr_conv2d_implicit(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, at::IntArrayRef stride,
+                            at::IntArrayRef padding, at::IntArrayRef dilation) {
+  if (!x.is_cuda() || !eager_cuda(x)) {  // shape propagation only (Meta kernel); the conv ops are not differentiable under tracing
+    at::AutoDispatchBelowADInplaceOrView guard;
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::lokr_conv2d", "")
+                         .typed<Tensor(const Tensor&, const Tensor&, const Tensor&, double, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef)>();
+    return op.call(x, w1, w2, alpha, stride, padding, dilation);
+  }
+  return LokrConv2dFn::apply(amp(x), w1, w2, alpha, stride.vec(), padding.vec(), dilation.vec());
+}
+
+struct LoconConv2dFn : public torch::autograd::Function<LoconConv2dFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& down, const Tensor& up, double alpha,
+                        std::vector<int64_t> stride, std::vector<int64_t> padding, std::vector<int64_t> dilation) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    require_device(x, "input");
+    TORCH_CHECK(eager_cuda(x), "lycoris_amd::locon_conv2d is an eager op (its forward / backward are not split into traceable ops yet)");
+    const c10::DeviceGuard dg(x.device());
+    TORCH_CHECK(x.dim() == 4 && down.dim() == 4, "locon_conv2d: NCHW input, lora_down [r, C, kh, kw]");
+    const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+    const int64_t r = down.size(0), O = up.size(0);
+    TORCH_CHECK(C == down.size(1), "adapter expects ", down.size(1), " input channels, got ", x.sizes());
+    Geom gm = geom_of({down.size(2), down.size(3)}, stride, padding, dilation, H, W);
+    bool copied;
+    Tensor rows = rows_view(x, &copied), down_p = f32c(down.detach().permute({0, 2, 3, 1})), up2 = f32c(up.detach().reshape({O, r}));
+    Tensor t = at::empty({B * gm.Ho * gm.Wo, r}, x.options().dtype(at::kFloat));
+    Tensor y = at::empty({B * gm.Ho * gm.Wo, O}, x.options());
+    check_rc(lyc_locon_conv2d_fwd(cptr(rows), cfp(down_p), cfp(up2), mfp(t), mptr(y), B, H, W, (int)C, (int)O, (int)r, gm.kh, gm.kw,
+                                  gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, (float)alpha, dtype_code(x.scalar_type()), stream_of(x)),
+             "lyc_locon_conv2d_fwd");
+    ctx->save_for_backward({rows, down, up, t});
+    ctx->saved_data["alpha"] = alpha;
+    ctx->saved_data["geom"] = std::vector<int64_t>{gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, gm.Ho, gm.Wo, B, C, H, W, !copied};
+    return from_rows(y, B, gm.Ho, gm.Wo, !copied);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const Tensor &rows = s[0], &down = s[1], &up = s[2], &t = s[3];
+    const double alpha = ctx->saved_data["alpha"].toDouble();
+    auto gv = ctx->saved_data["geom"].toIntVector();
+    const int64_t B = gv[10], C = gv[11], H = gv[12], W = gv[13], Ho = gv[8], Wo = gv[9];
+    const bool x_cl = gv[14] != 0;
+    const int64_t r = down.size(0), O = up.size(0);
+    const c10::DeviceGuard dg(rows.device());
+    bool cp;
+    Tensor g_rows = rows_view(grads[0], &cp);
+    const bool nx = ctx->needs_input_grad(0), nd = ctx->needs_input_grad(1), nu = ctx->needs_input_grad(2);
+    Tensor down_p = f32c(down.detach().permute({0, 2, 3, 1})), up2 = f32c(up.detach().reshape({O, r}));
+    Tensor dt = at::empty({B * Ho * Wo, r}, rows.options().dtype(at::kFloat));
+    Tensor dx_rows = nx ? at::empty({B * H * W, C}, rows.options()) : Tensor();
+    GradTarget td = cl_grad_target(down, nd, {r, gv[0], gv[1], C});
+    GradTarget tu = grad_target(up, nu);
+    check_rc(lyc_locon_conv2d_bwd(cptr(g_rows), cptr(rows), cfp(down_p), cfp(up2), cfp(t), mfp(dt), mptr(dx_rows), mfp(td.buf),
+                                  mfp(tu.buf), B, H, W, (int)C, (int)O, (int)r, (int)gv[0], (int)gv[1], (int)gv[2], (int)gv[3],
+                                  (int)gv[4], (int)gv[5], (int)gv[6], (int)gv[7], (float)alpha, dtype_code(rows.scalar_type()),
+                                  stream_of(rows)), "lyc_locon_conv2d_bwd");
+    Tensor dx = nx ? from_rows(dx_rows, B, H, W, x_cl) : Tensor();
+    return {dx, cl_finish(down, td), finish_grad(up, tu), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+Tensor locon_conv2d_implicit(const Tensor& x, const Tensor& down, const Tensor& up, double alpha, at::IntArrayRef stride,
+                             at::IntArrayRef padding, at::IntArrayRef dilation) {
+  if (!x.is_cuda() || !eager_cuda(x)) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::locon_conv2d", "")
+                         .typed<Tensor(const Tensor&, const Tensor&, const Tensor&, double, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef)>();
+    return op.call(x, down, up, alpha, stride, padding, dilation);
+  }
+  return LoconConv2dFn::apply(amp(x), down, up, alpha, stride.vec(), padding.vec(), dilation.vec());
+}
+
+Tensor lokr_conv2d_eager(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, at::IntArrayRef stride,
+                         at::IntArrayRef padding, at::IntArrayRef dilation) {
+  return LokrConv2dFn::apply(x, w1, w2, alpha, stride.vec(), padding.vec(), dilation.vec());
+}
+Tensor locon_conv2d_eager(const Tensor& x, const Tensor& down, const Tensor& up, double alpha, at::IntArrayRef stride,
+                          at::IntArrayRef padding, at::IntArrayRef dilation) {
+  return LoconConv2dFn::apply(x, down, up, alpha, stride.vec(), padding.vec(), dilation.vec());
+}
+
+Tensor conv2d_meta(const Tensor& x, const Tensor& f0, const Tensor& f1, double alpha, at::IntArrayRef stride, at::IntArrayRef padding,
+                   at::IntArrayRef dilation, bool lokr) {
+  const int64_t kh = lokr ? f1.size(2) : f0.size(2), kw = lokr ? f1.size(3) : f0.size(3);
+  const int64_t O = lokr ? f0.size(0) * f1.size(0) : f1.size(0);
+  Geom gm = geom_of({kh, kw}, stride, padding, dilation, x.size(2), x.size(3));
+  return x.new_empty({x.size(0), O, gm.Ho, gm.Wo});
+}
+Tensor lokr_conv2d_meta(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, at::IntArrayRef s, at::IntArrayRef p,
+                        at::IntArrayRef d) {
+  return conv2d_meta(x, w1, w2, alpha, s, p, d, true);
+}
+Tensor locon_conv2d_meta(const Tensor& x, const Tensor& down, const Tensor& up, double alpha, at::IntArrayRef s, at::IntArrayRef p,
+                         at::IntArrayRef d) {
+  return conv2d_meta(x, down, up, alpha, s, p, d, false);
+}
+
+}  // namespace
+
+TORCH_LIBRARY(lycoris_amd, m) {
+  // public ops: what lycoris_amd.ops / the modules call (autograd-aware)
+  m.def("lokr_linear(Tensor x, Tensor w1, Tensor w2, float alpha) -> Tensor");
+  m.def("locon_linear(Tensor x, Tensor down, Tensor up, float alpha) -> Tensor");
+  m.def("loha_linear(Tensor x, Tensor w1a, Tensor w1b, Tensor w2a, Tensor w2b, float alpha) -> Tensor");
+  m.def("chan_affine(Tensor a, Tensor w, Tensor? bias, float s0, float mult, int chan_dim) -> Tensor");
+  m.def("lokr_conv2d(Tensor x, Tensor w1, Tensor w2, float alpha, int[2] stride, int[2] padding, int[2] dilation) -> Tensor");
+  m.def("locon_conv2d(Tensor x, Tensor down, Tensor up, float alpha, int[2] stride, int[2] padding, int[2] dilation) -> Tensor");
+  // forward / backward kernels as functional ops (what torch.compile traces through)
+  m.def("_lokr_linear_backward(Tensor g, Tensor x, Tensor w1, Tensor w2, float alpha, bool need_dx, bool need_dw1, bool need_dw2) "
+        "-> (Tensor, Tensor, Tensor)");
+  m.def("_locon_linear_forward(Tensor x, Tensor down, Tensor up, float alpha) -> (Tensor, Tensor)");
+  m.def("_locon_linear_backward(Tensor g, Tensor x, Tensor down, Tensor up, Tensor t, float alpha, bool need_dx, bool need_dd, "
+        "bool need_du) -> (Tensor, Tensor, Tensor)");
+  m.def("_loha_linear_forward(Tensor x, Tensor w1a, Tensor w1b, Tensor w2a, Tensor w2b, float alpha) -> (Tensor, Tensor)");
+  m.def("_loha_linear_backward(Tensor g, Tensor x, Tensor w1a, Tensor w1b, Tensor w2a, Tensor w2b, Tensor ws, float alpha, "
+        "bool need_dx, bool need_f) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+  m.def("_chan_reduce(Tensor g, Tensor a, Tensor? bias, Tensor w_like, float mult, int chan_dim) -> Tensor");
+}
+
+TORCH_LIBRARY_IMPL(lycoris_amd, CUDA, m) {
+  m.impl("lokr_linear", lokr_linear_fwd);
+  m.impl("_lokr_linear_backward", lokr_linear_bwd);
+  m.impl("locon_linear", locon_linear_cuda);
+  m.impl("_locon_linear_forward", locon_linear_fwd);
+  m.impl("_locon_linear_backward", locon_linear_bwd);
+  m.impl("loha_linear", loha_linear_cuda);
+  m.impl("_loha_linear_forward", loha_linear_fwd);
+  m.impl("_loha_linear_backward", loha_linear_bwd);
+  m.impl("chan_affine", chan_scale);
+  m.impl("_chan_reduce", chan_reduce);
+  m.impl("lokr_conv2d", lokr_conv2d_eager);    // inference_mode skips the Autograd key
+  m.impl("locon_conv2d", locon_conv2d_eager);
+}
+
+TORCH_LIBRARY_IMPL(lycoris_amd, Meta, m) {
+  m.impl("lokr_linear", lokr_linear_meta);
+  m.impl("_lokr_linear_backward", lokr_linear_bwd_meta);
+  m.impl("locon_linear", locon_linear_meta);
+  m.impl("_locon_linear_forward", locon_linear_fwd_meta);
+  m.impl("_locon_linear_backward", locon_linear_bwd_meta);
+  m.impl("loha_linear", loha_linear_meta);
+  m.impl("_loha_linear_forward", loha_linear_fwd_meta);
+  m.impl("_loha_linear_backward", loha_linear_bwd_meta);
+  m.impl("chan_affine", chan_affine_meta);
+  m.impl("_chan_reduce", chan_reduce_meta);
+  m.impl("lokr_conv2d", lokr_conv2d_meta);
+  m.impl("locon_conv2d", locon_conv2d_meta);
+}
+
+TORCH_LIBRARY_IMPL(lycoris_amd, Autograd, m) {
+  m.impl("lokr_linear", lokr_linear_autograd);
+  m.impl("locon_linear", locon_linear_autograd);
+  m.impl("loha_linear", loha_linear_autograd);
+  m.impl("chan_affine", chan_affine_autograd);
+  m.impl("lokr_conv2d", lokr_conv2d_implicit);
+  m.impl("locon_conv2d", locon_conv2d_implicit);
+}
+
+PYBIND11_MODULE(_lyc_torch, m) {
+  m.doc() = "lycoris_amd: TORCH_LIBRARY(lycoris_amd) custom ops over liblycoris_amd.so";
+  m.def("set_accum", [](bool enabled, py::object callback) {
+    std::lock_guard<std::mutex> lk(g_accum.mu);
+    g_accum.enabled = enabled;
+    if (g_accum.callback == nullptr) g_accum.callback = new py::object();
+    *g_accum.callback = std::move(callback);
+  });
+  m.def("accum_enabled", []() { return g_accum.enabled; });
+  m.def("abi_version", []() { return lyc_abi_version(); });
+}

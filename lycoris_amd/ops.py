@@ -24,10 +24,34 @@ F32_ROWS = 0x100  # LYC_F32_ROWS
 # gradient-sync object can count them like a post-accumulate hook would.
 _ACCUM = {"enabled": False, "callback": None}
 
+# Host dispatch of the public entry points below:
+#   "cpp"    (default) torch.ops.lycoris_amd.* -- TORCH_LIBRARY custom ops, dispatch + autograd in C++ (csrc/torch_ops.cpp)
+#   "python" the ctypes-backed torch.autograd.Function classes of this file (same kernels; kept as the readable
+#            statement of the host logic and as a cross-check in the tests)
+_DISPATCH = {"mode": "cpp", "ext": None}
+
+
+def set_dispatch(mode: str):
+    if mode not in ("cpp", "python"):
+        raise ValueError(mode)
+    _DISPATCH["mode"] = mode
+
+
+def _cpp() -> bool:
+    if _DISPATCH["mode"] != "cpp":
+        return False
+    if _DISPATCH["ext"] is None:
+        ext = N.load_torch_ops()  # raises NativeLibraryError when the extension is missing: no silent fallback
+        ext.set_accum(_ACCUM["enabled"], _ACCUM["callback"])
+        _DISPATCH["ext"] = ext
+    return True
+
 
 def fused_grad_accumulation(enabled: bool = True, callback=None):
     _ACCUM["enabled"] = bool(enabled)
     _ACCUM["callback"] = callback
+    if _DISPATCH["ext"] is not None:
+        _DISPATCH["ext"].set_accum(bool(enabled), callback)
 
 
 def _grad_targets(factors, needs):
@@ -538,20 +562,32 @@ class _ChanAffine(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------------------
 def lokr_linear(x, w1, w2, alpha=1.0):
     """w1:[a,b]  w2:[c,d]  x:[..., b*d] -> [..., a*c]"""
+    N.require_device(x, "input")
+    if _cpp():
+        return torch.ops.lycoris_amd.lokr_linear(x, w1, w2, float(alpha))
     return _AdapterLinear.apply(_LokrCore, alpha, _amp(x), w1, w2)
 
 
 def locon_linear(x, down, up, alpha=1.0):
     """down:[r,I]  up:[O,r]"""
+    N.require_device(x, "input")
+    if _cpp():
+        return torch.ops.lycoris_amd.locon_linear(x, down, up, float(alpha))
     return _AdapterLinear.apply(_LoconCore, alpha, _amp(x), down, up)
 
 
 def loha_linear(x, w1a, w1b, w2a, w2b, alpha=1.0):
     """w*a:[O,r]  w*b:[r,I]"""
+    N.require_device(x, "input")
+    if _cpp():
+        return torch.ops.lycoris_amd.loha_linear(x, w1a, w1b, w2a, w2b, float(alpha))
     return _AdapterLinear.apply(_LohaCore, alpha, _amp(x), w1a, w1b, w2a, w2b)
 
 
 def chan_affine(a, w, bias=None, s0=0.0, mult=1.0, chan_dim=-1):
+    N.require_device(a, "input")
+    if _cpp():
+        return torch.ops.lycoris_amd.chan_affine(a, w, bias, float(s0), float(mult), int(chan_dim))
     return _ChanAffine.apply(_amp(a), w, bias, s0, mult, chan_dim)
 
 
@@ -562,9 +598,12 @@ def _geom(ksize, stride, padding, dilation):
 def locon_conv2d(x, down, up, alpha, stride, padding, dilation):
     """down:[r, I, kh, kw]  up:[O, r, 1, 1]"""
     r, O = down.shape[0], up.shape[0]
+    N.require_device(x, "input")
     x = _amp(x)
     geom = _geom(down.shape[2:], stride, padding, dilation)
     if x.dim() == 4 and not _is_pointwise(geom) and _locon_conv_implicit_ok(x, down, up):
+        if _cpp():
+            return torch.ops.lycoris_amd.locon_conv2d(x, down, up, float(alpha), list(geom[1]), list(geom[2]), list(geom[3]))
         return _LoconConv2dImplicit.apply(alpha, geom, x, down, up)
     return _AdapterConv2d.apply(_LoconCore, alpha, geom, x, down.reshape(r, -1), up.reshape(O, r))
 
@@ -578,9 +617,12 @@ def loha_conv2d(x, w1a, w1b, w2a, w2b, alpha, shape, stride, padding, dilation):
 def lokr_conv2d(x, w1, w2, alpha, stride, padding, dilation):
     """w1:[a, b]  w2:[c, d, kh, kw].  The channel index u*d + v makes im2col's (channel, kh, kw) column order the
     grouped (u, (v, kh, kw)) order of the Kronecker kernel, so w2 is simply viewed as [c, d*kh*kw]."""
+    N.require_device(x, "input")
     x = _amp(x)
     geom = _geom(w2.shape[2:], stride, padding, dilation)
     if x.dim() == 4 and not _is_pointwise(geom) and _lokr_conv_implicit_ok(x, w1, w2):
+        if _cpp():
+            return torch.ops.lycoris_amd.lokr_conv2d(x, w1, w2, float(alpha), list(geom[1]), list(geom[2]), list(geom[3]))
         return _LokrConv2dImplicit.apply(alpha, geom, x, w1, w2)
     return _AdapterConv2d.apply(_LokrCore, alpha, geom, x, w1, w2.reshape(w2.shape[0], -1))
 

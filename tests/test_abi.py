@@ -52,3 +52,42 @@ def test_argument_errors_are_reported_not_crashed():
     with pytest.raises(RuntimeError, match="bad dims"):
         N.call("lyc_chan_scale", None, None, None, None, 4, 0, 1, 1.0, 1.0, N.LYC_F32, None)
     assert N.load().lyc_loha_workspace_bytes(1280, 1280, N.LYC_BF16) == 4 * 1280 * 1280 * 2
+
+
+def test_torch_custom_ops_are_registered_with_meta_kernels():
+    """TORCH_LIBRARY(lycoris_amd): the extension loads on the CPU-only box, every public op has a schema, the Meta kernels
+    give the output shapes (what FakeTensor / torch.compile tracing uses), and C++ autograd runs on meta tensors."""
+    import torch
+    from lycoris_amd import _native
+    ext = _native.load_torch_ops()
+    assert ext.abi_version() == _native.ABI_VERSION
+    ns = torch.ops.lycoris_amd
+    for name in ("lokr_linear", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d",
+                 "_lokr_linear_backward", "_locon_linear_forward", "_locon_linear_backward", "_loha_linear_forward",
+                 "_loha_linear_backward", "_chan_reduce"):
+        assert hasattr(ns, name), name
+    m = dict(device="meta")
+    x = torch.empty(3, 5, 64, dtype=torch.bfloat16, requires_grad=True, **m)
+    w1, w2 = torch.empty(8, 8, requires_grad=True, **m), torch.empty(16, 8, requires_grad=True, **m)
+    y = ns.lokr_linear(x, w1, w2, 1.0)
+    assert y.shape == (3, 5, 128) and y.dtype == torch.bfloat16
+    gx, g1, g2 = torch.autograd.grad(y, [x, w1, w2], torch.empty_like(y))
+    assert gx.shape == x.shape and g1.shape == w1.shape and g2.shape == w2.shape
+    down, up = torch.empty(4, 64, **m), torch.empty(32, 4, **m)
+    y, t = ns._locon_linear_forward(x, down, up, 1.0)
+    assert y.shape == (3, 5, 32) and t.shape == (15, 4) and t.dtype == torch.float32
+    fs = [torch.empty(32, 4, **m), torch.empty(4, 64, **m), torch.empty(32, 4, **m), torch.empty(4, 64, **m)]
+    assert ns.loha_linear(x, *fs, 1.0).shape == (3, 5, 32)
+    assert ns.chan_affine(x, torch.empty(64, **m), None, 1.0, 1.0, -1).shape == x.shape
+    xc = torch.empty(2, 64, 9, 7, dtype=torch.float16, **m)
+    assert ns.lokr_conv2d(xc, torch.empty(8, 8, **m), torch.empty(4, 8, 3, 3, **m), 1.0, [2, 2], [1, 1], [1, 1]).shape == (2, 32, 5, 4)
+    assert ns.locon_conv2d(xc, torch.empty(4, 64, 3, 3, **m), torch.empty(24, 4, 1, 1, **m), 1.0, [1, 1], [1, 1], [1, 1]).shape == (2, 24, 9, 7)
+
+
+def test_cpu_tensors_are_rejected_by_the_custom_op_path():
+    import torch
+    from lycoris_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.lokr_linear(torch.randn(4, 64), torch.randn(8, 8), torch.randn(8, 8), 1.0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.chan_affine(torch.randn(4, 64), torch.randn(64))
