@@ -122,7 +122,9 @@ int lyc_chan_reduce(const void* a, const void* b, const float* bias, float* dw, 
  * (HadaWeight.forward / .backward).   w1a,w2a:[O,r]  w1b,w2b:[r,I]
  *   dW = ((w1a @ w1b) * (w2a @ w2b)) * alpha ;  y = x @ dW^T
  * `wplanes` is caller-owned scratch of lyc_loha_workspace_bytes(O, I, dtype) bytes: fwd fills it with the
- * hi/lo matrix-core operand images of dW (both orientations), bwd reads it (pass the same buffer).
+ * matrix-core operand image of dW -- ONE plane in the activation type for 16-bit activations (dW rounded once, the
+ * reference's `diff_weight.to(base_weight.dtype)`, modules/loha.py:310), the fp32 plane and its transpose for fp32
+ * activations -- and bwd reads it (pass the same buffer).
  * `gw` is [O,I] fp32 scratch (no need to clear).  d_w* +=                                              */
 int64_t lyc_loha_workspace_bytes(int O, int I, int dtype);
 int lyc_loha_linear_fwd(const void* x, const float* w1a, const float* w1b, const float* w2a, const float* w2b,

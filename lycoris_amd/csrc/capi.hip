@@ -977,8 +977,10 @@ LohaPlanes loha_planes(void* base, int O, int I, size_t esz) {
   p.ldn = round_up(I, 16 / (long)esz);
   p.ldt = round_up(O, 16 / (long)esz);
   char* b = static_cast<char*>(base);
-  const size_t n = (size_t)O * p.ldn * esz, t = (size_t)I * p.ldt * esz;
-  p.nh = b; p.nl = b + n; p.th = b + 2 * n; p.tl = b + 2 * n + t;
+  const size_t n = (size_t)O * p.ldn * esz;
+  // 16-bit activations: one plane (dW rounded to the activation type, the library GEMMs transpose by flag);
+  // fp32 activations: the plane and its transpose for the two NT kernels (no hi/lo split in fp32)
+  p.nh = b; p.nl = nullptr; p.th = esz == 4 ? b + n : nullptr; p.tl = nullptr;
   return p;
 }
 size_t esize(int dtype) { return (dtype & 0xff) == LYC_F32 ? 4 : 2; }
@@ -1057,7 +1059,8 @@ void launch_loha_factor_grad(const float* gw, const float* w1a, const float* w1b
 
 int64_t lyc_loha_workspace_bytes(int O, int I, int dtype) {
   const long esz = (long)esize(dtype);
-  return 2 * ((int64_t)O * round_up(I, 16 / esz) + (int64_t)I * round_up(O, 16 / esz)) * esz;
+  const int64_t n = (int64_t)O * round_up(I, 16 / esz) * esz;
+  return esz == 4 ? n + (int64_t)I * round_up(O, 16 / esz) * esz : n;
 }
 
 int lyc_loha_linear_fwd(const void* x, const float* w1a, const float* w1b, const float* w2a, const float* w2b,
@@ -1079,11 +1082,9 @@ int lyc_loha_linear_fwd(const void* x, const float* w1a, const float* w1b, const
   }
   if (int rc = check_launch("loha_linear_fwd(rebuild)")) return rc;
   if (M > 0 && (dtype & 0xff) != LYC_F32) {
-    // y = x (Wh + Wl)^T: the lo plane first (its result is ~2^-9 of y, so rounding it to T costs ~2^-18 relative), then
-    // the hi plane accumulated on top in fp32 inside the GEMM and rounded once
+    // y = x dW^T with dW in the activation type (one plane, one pass: the reference's own semantics)
     const rocblas_datatype t = rb_type(dtype);
-    if (int rc = rb_gemm(st, false, true, M, O, I, x, I, pl.nl, pl.ldn, y, O, t, t, 1.0f, 0.0f, "loha_linear_fwd")) return rc;
-    if (int rc = rb_gemm(st, false, true, M, O, I, x, I, pl.nh, pl.ldn, y, O, t, t, 1.0f, 1.0f, "loha_linear_fwd")) return rc;
+    if (int rc = rb_gemm(st, false, true, M, O, I, x, I, pl.nh, pl.ldn, y, O, t, t, 1.0f, 0.0f, "loha_linear_fwd")) return rc;
     return LYC_OK;
   }
   if (M > 0) {  // fp32 activations: exact fp32 MFMA kernel
@@ -1109,11 +1110,10 @@ int lyc_loha_linear_bwd(const void* g, const void* x, const float* w1a, const fl
   hipStream_t st = (hipStream_t)stream;
   LohaPlanes pl = loha_planes(const_cast<void*>(wplanes), O, I, esize(dtype));
   const bool lib = (dtype & 0xff) != LYC_F32;
-  if (dx && lib) {  // dx = g (Wh + Wl): [M,O] x [O,I], same lo-then-hi order as the forward
+  if (dx && lib) {  // dx = g dW: [M,O] x [O,I] on the same plane
     const rocblas_datatype t = rb_type(dtype);
     const rocblas_datatype to = (dtype & LYC_F32_ROWS) ? rocblas_datatype_f32_r : t;
-    if (int rc = rb_gemm(st, false, false, M, I, O, g, O, pl.nl, pl.ldn, dx, I, t, to, 1.0f, 0.0f, "loha_linear_bwd(dx)")) return rc;
-    if (int rc = rb_gemm(st, false, false, M, I, O, g, O, pl.nh, pl.ldn, dx, I, t, to, 1.0f, 1.0f, "loha_linear_bwd(dx)")) return rc;
+    if (int rc = rb_gemm(st, false, false, M, I, O, g, O, pl.nh, pl.ldn, dx, I, t, to, 1.0f, 0.0f, "loha_linear_bwd(dx)")) return rc;
   } else if (dx) {  // dx = g @ dW : B operand rows = i, K = o  -> the transposed planes
     GemmArgs ga{};
     ga.A = g; ga.Bh = pl.th; ga.Bl = pl.tl; ga.out = dx; ga.M = M; ga.N = I; ga.K = O;

@@ -48,9 +48,11 @@ __device__ __forceinline__ void lh_stage_b(const LohaArgs& a, long i0, int r0, f
   }
 }
 
-// dW hi/lo planes.  Computed transposed (A = b-factor^T, B = a-factor^T) so that a lane ends up with 4 consecutive i of
-// one row o: 8-byte stores of the K-contiguous planes.  WT: also write the transposed planes (fp32-activation path).
-template <typename T, bool WT>
+// dW operand plane(s).  Computed transposed (A = b-factor^T, B = a-factor^T) so that a lane ends up with 4 consecutive i
+// of one row o: 8-byte stores of the K-contiguous plane.  16-bit activations: ONE plane, dW rounded once to the activation
+// type -- exactly the reference's `diff_weight.to(base_weight.dtype)` (modules/loha.py:310); LO adds the residual plane
+// (hi + lo = the fp32 value) for callers that want the un-rounded operand.  WT: also the transposed plane (fp32 path).
+template <typename T, bool WT, bool LO = false>
 __global__ __launch_bounds__(NTHREADS) void loha_rebuild_mfma_kernel(LohaArgs a) {
   __shared__ __attribute__((aligned(16))) float sm[2 * LOHA_T * LH_AP + 2 * LOHA_RC * LH_BP];
   float* sA1 = sm;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(NTHREADS) void loha_rebuild_mfma_kernel(LohaArgs a)
   T* nl = static_cast<T*>(a.Wn_l);
   const long o = o0 + 16 * wave + li;
   const bool vec = (a.ldn % 4) == 0 && (reinterpret_cast<uintptr_t>(nh) & 7u) == 0 &&
-                   (!TT<T>::SPLIT || (reinterpret_cast<uintptr_t>(nl) & 7u) == 0);
+                   (!(TT<T>::SPLIT && LO) || (reinterpret_cast<uintptr_t>(nl) & 7u) == 0);
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const long i = i0 + 16 * t + 4 * g;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(NTHREADS) void loha_rebuild_mfma_kernel(LohaArgs a)
       if constexpr (sizeof(T) == 2) {
         if (vec && i + 4 <= a.I) {
           *reinterpret_cast<u32x2*>(nh + o * a.ldn + i) = *reinterpret_cast<const u32x2*>(hi);
-          *reinterpret_cast<u32x2*>(nl + o * a.ldn + i) = *reinterpret_cast<const u32x2*>(lo);
+          if constexpr (LO) *reinterpret_cast<u32x2*>(nl + o * a.ldn + i) = *reinterpret_cast<const u32x2*>(lo);
           done = true;
         }
       }
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(NTHREADS) void loha_rebuild_mfma_kernel(LohaArgs a)
         for (int q = 0; q < 4; ++q)
           if (i + q < a.I) {
             nh[o * a.ldn + i + q] = hi[q];
-            if constexpr (TT<T>::SPLIT) nl[o * a.ldn + i + q] = lo[q];
+            if constexpr (TT<T>::SPLIT && LO) nl[o * a.ldn + i + q] = lo[q];
           }
       }
       if constexpr (WT) {
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(NTHREADS) void loha_rebuild_mfma_kernel(LohaArgs a)
         for (int q = 0; q < 4; ++q)
           if (i + q < a.I) {
             th[(i + q) * a.ldt + o] = hi[q];
-            if constexpr (TT<T>::SPLIT) tl[(i + q) * a.ldt + o] = lo[q];
+            if constexpr (TT<T>::SPLIT && LO) tl[(i + q) * a.ldt + o] = lo[q];
           }
       }
     }

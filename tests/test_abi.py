@@ -51,7 +51,8 @@ def test_argument_errors_are_reported_not_crashed():
         N.call("lyc_locon_linear_fwd", None, None, None, None, None, 4, 8, 8, 2, 1.0, N.LYC_BF16, None)
     with pytest.raises(RuntimeError, match="bad dims"):
         N.call("lyc_chan_scale", None, None, None, None, 4, 0, 1, 1.0, 1.0, N.LYC_F32, None)
-    assert N.load().lyc_loha_workspace_bytes(1280, 1280, N.LYC_BF16) == 4 * 1280 * 1280 * 2
+    assert N.load().lyc_loha_workspace_bytes(1280, 1280, N.LYC_BF16) == 1280 * 1280 * 2  # one plane
+    assert N.load().lyc_loha_workspace_bytes(1280, 640, N.LYC_F32) == 2 * 1280 * 640 * 4
 
 
 def test_torch_custom_ops_are_registered_with_meta_kernels():

@@ -34,8 +34,8 @@ LINEAR = _linear_shapes()
 IDS = [f"M{m}_{i}to{o}" for m, i, o in LINEAR]
 
 
-def _bounds(dtype, names_store, names_f32):
-    b = {n: TOL["store_out"][dtype] for n in names_store}
+def _bounds(dtype, names_store, names_f32, store="store_out"):
+    b = {n: TOL[store][dtype] for n in names_store}
     b.update({n: TOL["f32_out"][dtype] for n in names_f32})
     return b
 
@@ -109,7 +109,7 @@ def test_loha_linear_fullsize(shape):
     errs = {"y": err(y, y_ref, dtype), "dx": err(grads[0], ref[0], dtype)}
     for n, gr, rf in zip(names[1:], grads[1:], ref[1:]):
         errs[n] = err(gr, rf)
-    check(f"loha_linear_full[{shape}]", errs, _bounds(dtype, ["y", "dx"], names[1:]))
+    check(f"loha_linear_full[{shape}]", errs, _bounds(dtype, ["y", "dx"], names[1:], "loha_store"))
 
 
 # ---- Conv2d at full size ------------------------------------------------------------------------------------------
@@ -202,4 +202,4 @@ def test_loha_conv2d_fullsize(shape):
     errs = {"y": err(y, y_ref, dtype), "dx": err(grads[0], ref[0], dtype)}
     for n, gr, rf in zip(names[1:], grads[1:], ref[1:]):
         errs[n] = err(gr, rf)
-    check(f"loha_conv_full[{shape}]", errs, _bounds(dtype, ["y", "dx"], names[1:]))
+    check(f"loha_conv_full[{shape}]", errs, _bounds(dtype, ["y", "dx"], names[1:], "loha_store"))

@@ -85,7 +85,7 @@ def test_loha_functional(dtype, conv):
     y_ref = oracle.loha.forward(x64, a1, b1, a2, b2, 0.5, shape, ca)
     ref = oracle.loha.backward(x64, g64, a1, b1, a2, b2, 0.5, shape, ca)
     errs = {"y": err(y, y_ref, dtype), "dx": err(grads[0], ref[0], dtype)}
-    b = {"y": TOL["store_out"][dtype], "dx": TOL["store_out"][dtype]}
+    b = {"y": TOL["loha_store"][dtype], "dx": TOL["loha_store"][dtype]}
     for n, gr, rf in zip(["d_w1a", "d_w1b", "d_w2a", "d_w2b"], grads[1:], ref[1:]):
         errs[n], b[n] = err(gr, rf), TOL["f32_out"][dtype]
     check(f"loha_functional[{dtype},{conv}]", errs, b)

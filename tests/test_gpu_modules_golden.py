@@ -108,6 +108,8 @@ def test_module_16bit_activations_fp32_factors(name, dtype, golden_cases):
     # (IA)^3 goes through the frozen layer's own 16-bit GEMM (one more rounding of its output, as upstream)
     # (measured 2.6e-3 / 4.2e-3 for delta / dx in bf16: two 2^-9 roundings and the library conv's own accumulation order)
     store = (8e-3 if dtype == torch.bfloat16 else 1e-3) if meta["algo"] == "ia3" else (1e-3)
+    if meta["algo"] == "loha" and dtype == torch.bfloat16:
+        store = 3e-3  # dW rounded once to bf16 before the contraction, as the reference does (gpu_util.TOL["loha_store"])
     f32 = 8e-3 if meta["algo"] == "ia3" and dtype == torch.bfloat16 else (1e-3 if meta["algo"] == "ia3" else 1e-4)
     if dora:
         # the (s - 1) * (x W^T) part is computed from the frozen layer's 16-bit output (resp. goes through its 16-bit GEMM):
