@@ -2,6 +2,7 @@
 C++ custom-op dispatch vs the ctypes / Python autograd.Function dispatch vs the reference's own torch call sequence.
 Tiny shapes (M = 16): the GPU work is negligible, the wall time between two syncs is host time.
     python benchmarks/host_overhead.py  -> gpurun_out/host_overhead.json"""
+import faulthandler
 import json
 import os
 import sys
@@ -14,6 +15,8 @@ import torch.nn.functional as F
 from lycoris_amd import ops
 
 dev = torch.device("cuda:0")
+faulthandler.enable()
+faulthandler.dump_traceback_later(40, repeat=True)
 N_LAYERS, REPS = 200, 5
 
 

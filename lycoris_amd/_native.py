@@ -52,7 +52,7 @@ VALUE_SIGNATURES = {
     "lyc_lokr_conv2d_bwd_workspace_bytes": ([_i64, _i64, _i64, _i32, _i32, _i32], ctypes.c_int64),
 }
 
-_lock = threading.Lock()
+_lock = threading.RLock()  # re-entrant: load_torch_ops() calls load() while holding it
 _lib = None
 
 

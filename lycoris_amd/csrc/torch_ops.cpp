@@ -86,6 +86,13 @@ bool eager_cuda(const Tensor& t) {
          !ks.has(c10::DispatchKey::Functionalize);
 }
 
+// Fused accumulation is a side effect into .grad, like the Python dispatch's: it happens for every leaf factor that
+// requires grad, whether or not THIS backward call listed it among its inputs (C++ needs_input_grad is per graph task:
+// torch.autograd.grad(y, [x]) would otherwise skip the factor gradients that loss.backward() computes).
+bool accum_wanted(const Tensor& factor) {
+  return g_accum.enabled && factor.defined() && factor.is_leaf() && factor.requires_grad() && factor.grad().defined();
+}
+
 // the tensor the kernel accumulates into: existing .grad (hand_back = false) or a fresh zero buffer (hand_back = true)
 struct GradTarget {
   Tensor buf;
@@ -182,7 +189,7 @@ struct LokrLinearFn : public torch::autograd::Function<LokrLinearFn> {
     const bool nx = ctx->needs_input_grad(0), n1 = ctx->needs_input_grad(1), n2 = ctx->needs_input_grad(2);
     Tensor g = grads[0];
     if (eager_cuda(g) && eager_cuda(x)) {  // eager: accumulate straight into .grad where possible
-      GradTarget t1 = grad_target(w1, n1), t2 = grad_target(w2, n2);
+      GradTarget t1 = grad_target(w1, n1 || accum_wanted(w1)), t2 = grad_target(w2, n2 || accum_wanted(w2));
       Tensor dx = lokr_linear_bwd_into(g, x, w1, w2, alpha, nx, t1.buf, t2.buf);
       return {dx, finish_grad(w1, t1), finish_grad(w2, t2), Tensor()};
     }
@@ -268,7 +275,7 @@ struct LoconLinearFn : public torch::autograd::Function<LoconLinearFn> {
     const bool nx = ctx->needs_input_grad(0), nd = ctx->needs_input_grad(1), nu = ctx->needs_input_grad(2);
     Tensor g = grads[0];
     if (eager_cuda(g) && eager_cuda(x)) {
-      GradTarget td = grad_target(down, nd), tu = grad_target(up, nu);
+      GradTarget td = grad_target(down, nd || accum_wanted(down)), tu = grad_target(up, nu || accum_wanted(up));
       Tensor dx = locon_linear_bwd_into(g, x, down, up, t, alpha, nx, td.buf, tu.buf);
       return {dx, finish_grad(down, td), finish_grad(up, tu), Tensor()};
     }
@@ -373,7 +380,7 @@ struct LohaLinearFn : public torch::autograd::Function<LohaLinearFn> {
       GradTarget t[4];
       Tensor d[4];
       for (int i = 0; i < 4; ++i) {
-        t[i] = grad_target(s[1 + i], nf[i]);
+        t[i] = grad_target(s[1 + i], nf[i] || accum_wanted(s[1 + i]));
         d[i] = t[i].buf;
       }
       Tensor dx = loha_linear_bwd_into(g, s[0], s[1], s[2], s[3], s[4], s[5], alpha, nx, d);
@@ -480,7 +487,7 @@ struct ChanAffineFn : public torch::autograd::Function<ChanAffineFn> {
     static auto scale = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::chan_affine", "")
                             .typed<Tensor(const Tensor&, const Tensor&, const c10::optional<Tensor>&, double, double, int64_t)>();
     if (ctx->needs_input_grad(0)) da = scale.call(g, w, c10::nullopt, s0, mult, chan_dim);
-    if (ctx->needs_input_grad(1)) {
+    if (ctx->needs_input_grad(1) || (eager_cuda(g) && accum_wanted(w))) {
       if (eager_cuda(g) && eager_cuda(a)) {
         GradTarget t = grad_target(w, true);
         chan_reduce_into(g, a, bias, mult, chan_dim, t.buf);
@@ -600,9 +607,10 @@ struct LokrConv2dFn : public torch::autograd::Function<LokrConv2dFn> {
     const bool nx = ctx->needs_input_grad(0), n1 = ctx->needs_input_grad(1), n2 = ctx->needs_input_grad(2);
     Tensor f1 = f32c(w1), w2p = f32c(w2.detach().permute({0, 2, 3, 1}));
     const int code = dtype_code(rows.scalar_type());
-    Tensor dx_rows = (nx || n1) ? at::empty({B * H * W, C}, rows.options()) : Tensor();
-    GradTarget t1 = grad_target(w1, n1);
-    GradTarget t2 = cl_grad_target(w2, n2, {c, gv[0], gv[1], d});
+    Tensor dx_rows = (nx || n1 || accum_wanted(w1)) ? at::empty({B * H * W, C}, rows.options()) : Tensor();
+    const bool a1 = n1 || accum_wanted(w1), a2 = n2 || accum_wanted(w2);
+    GradTarget t1 = grad_target(w1, a1);
+    GradTarget t2 = cl_grad_target(w2, a2, {c, gv[0], gv[1], d});
     Tensor ws;
     if (t1.buf.defined()) {
       const int64_t nb = lyc_lokr_conv2d_bwd_workspace_bytes(B, H, W, (int)a, (int)b, (int)d);
@@ -668,8 +676,8 @@ struct LoconConv2dFn : public torch::autograd::Function<LoconConv2dFn> {
     Tensor down_p = f32c(down.detach().permute({0, 2, 3, 1})), up2 = f32c(up.detach().reshape({O, r}));
     Tensor dt = at::empty({B * Ho * Wo, r}, rows.options().dtype(at::kFloat));
     Tensor dx_rows = nx ? at::empty({B * H * W, C}, rows.options()) : Tensor();
-    GradTarget td = cl_grad_target(down, nd, {r, gv[0], gv[1], C});
-    GradTarget tu = grad_target(up, nu);
+    GradTarget td = cl_grad_target(down, nd || accum_wanted(down), {r, gv[0], gv[1], C});
+    GradTarget tu = grad_target(up, nu || accum_wanted(up));
     check_rc(lyc_locon_conv2d_bwd(cptr(g_rows), cptr(rows), cfp(down_p), cfp(up2), cfp(t), mfp(dt), mptr(dx_rows), mfp(td.buf),
                                   mfp(tu.buf), B, H, W, (int)C, (int)O, (int)r, (int)gv[0], (int)gv[1], (int)gv[2], (int)gv[3],
                                   (int)gv[4], (int)gv[5], (int)gv[6], (int)gv[7], (float)alpha, dtype_code(rows.scalar_type()),

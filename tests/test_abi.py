@@ -92,3 +92,13 @@ def test_cpu_tensors_are_rejected_by_the_custom_op_path():
         ops.lokr_linear(torch.randn(4, 64), torch.randn(8, 8), torch.randn(8, 8), 1.0)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.chan_affine(torch.randn(4, 64), torch.randn(64))
+
+
+def test_loading_the_custom_op_extension_first_does_not_deadlock():
+    """round-2 regression: load_torch_ops() took the loader lock and then called load(), which takes it again"""
+    import subprocess
+    import sys
+    code = "from lycoris_amd import _native as N; N.load_torch_ops(); print('ok', N.load().lyc_abi_version())"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-500:]
