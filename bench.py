@@ -220,8 +220,9 @@ def forward_all(insts):
 def backward_range(outs, lo, hi):
     """backward of outs[lo:hi] in reverse order.  autograd.grad instead of .backward(): dx is produced and dropped (a
     real UNet hands it to the previous layer); the factor gradients go straight into the arena (fused accumulation)."""
-    for y, it in reversed(outs[lo:hi]):
-        torch.autograd.grad(y, [it.x], it.g)
+    seg = outs[lo:hi][::-1]
+    if seg:  # ONE engine invocation for the whole segment, as loss.backward() is one for a real network
+        torch.autograd.grad([y for y, _ in seg], [it.x for _, it in seg], [it.g for _, it in seg])
 
 
 def lib_sha():
@@ -356,6 +357,7 @@ def main():
         },
     }
     extra = rank == 0 and world == 1 and not args.eager
+    sync._sync_enabled = False  # the measurement legs below repeat passes without finish(): no bucket bookkeeping there
     if extra and not args.no_roofline:
         result["roofline"] = roofline(insts, args, dtype, dev)
     if extra and not args.no_reference and args.algo in ("lokr", "locon", "loha"):
@@ -510,9 +512,8 @@ def reference_leg(insts, sync, native_graph_ms):
     PyTorch-ROCm on this GPU over the same layer instances, like for like: eager vs eager (Python-driven, what an
     sd-scripts user gets without whole-step capture) and hipGraph vs hipGraph (kernel time)."""
     def ref_pass():
-        outs = [(it.reference_forward(), it) for it in insts]
-        for y, it in reversed(outs):
-            torch.autograd.grad(y, [it.x] + it.params, it.g)
+        outs = [(it.reference_forward(), it) for it in insts][::-1]
+        torch.autograd.grad([y for y, _ in outs], [t for _, it in outs for t in [it.x] + it.params], [it.g for _, it in outs])
 
     def nat_pass():
         backward_range(forward_all(insts), 0, len(insts))

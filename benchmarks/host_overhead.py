@@ -37,8 +37,7 @@ def layers(algo):
 def native(algo, ls):
     fn = ops.lokr_linear if algo == "lokr" else ops.locon_linear
     ys = [fn(x, fs[0], fs[1], 1.0) for x, g, fs, W in ls]
-    for y, (x, g, fs, W) in zip(reversed(ys), reversed(ls)):
-        torch.autograd.grad(y, [x] + fs, g)
+    torch.autograd.grad(ys, [t for x, g, fs, W in ls for t in [x] + fs], [g for x, g, fs, W in ls])  # one engine call
 
 
 def reference(algo, ls):
@@ -46,8 +45,7 @@ def reference(algo, ls):
     for x, g, fs, W in ls:
         dW = torch.kron(fs[0], fs[1]) if algo == "lokr" else fs[1] @ fs[0]
         ys.append(F.linear(x, (W + dW.to(W.dtype)) - W))
-    for y, (x, g, fs, W) in zip(reversed(ys), reversed(ls)):
-        torch.autograd.grad(y, [x] + fs, g)
+    torch.autograd.grad(ys, [t for x, g, fs, W in ls for t in [x] + fs], [g for x, g, fs, W in ls])
 
 
 def wall(fn):

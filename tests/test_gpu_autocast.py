@@ -72,7 +72,7 @@ def test_module_under_autocast(algo, conv, amp, layer_dtype):
     # IA3's delta goes through the frozen layer's autocast GEMM (W rounded to 16 bits there, output rounded once more)
     bound = (8e-3 if amp == torch.bfloat16 else 2e-3) if algo == "ia3" else 1e-3
     if algo == "loha" and amp == torch.bfloat16:
-        bound = 3e-3  # dW rounded once to bf16 before the contraction, as the reference does (gpu_util.TOL["loha_store"])
+        bound = 4e-3  # dW rounded once to bf16 before the contraction, as the reference does (gpu_util.TOL["loha_store"])
     check(f"autocast[{algo},{conv},{amp},{ldt}]",
           {"delta": err(delta, want, amp), "dx": err(grads[0], dx_want, amp)},
           {"delta": bound, "dx": bound})

@@ -6,6 +6,7 @@ grad-sync callback work from the C++ backward, (c) an adapted layer traces under
 backward split into dispatcher ops) -- the reference exercises torch.compile in test/compile.py."""
 import pytest
 import torch
+import torch._dynamo
 import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
@@ -115,7 +116,6 @@ def test_adapted_linear_layer_under_torch_compile(algo):
         return [y.detach()] + list(torch.autograd.grad(y.float().pow(2).sum(), [x] + params))
 
     eager = run(layer)
-    import torch._dynamo
     torch._dynamo.reset()
     compiled = torch.compile(layer, backend="aot_eager", fullgraph=True)
     got = run(compiled)
