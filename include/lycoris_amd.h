@@ -31,7 +31,7 @@ enum { LYC_F32 = 0, LYC_F16 = 1, LYC_BF16 = 2 };
 enum { LYC_F32_ROWS = 0x100 };
 enum { LYC_OK = 0, LYC_ERR_ARG = 1, LYC_ERR_UNSUPPORTED = 2, LYC_ERR_LAUNCH = 3 };
 
-#define LYC_ABI_VERSION 4
+#define LYC_ABI_VERSION 5
 int lyc_abi_version(void);
 const char* lyc_last_error(void);
 
@@ -168,6 +168,17 @@ int lyc_loha_wgrad(const float* gw, const float* w1a, const float* w1b, const fl
                    float* d_w1b, float* d_w2a, float* d_w2b, int64_t O, int64_t J, int r, float alpha, void* stream);
 int lyc_lokr_wgrad(const float* gw, const float* w1, const float* w2, float* d_w1, float* d_w2, int a, int b, int c,
                    int64_t dk, float alpha, void* stream);
+
+/* ---- Tucker / conv-CP forms ------------------------------------------------------------------------------------
+ * rebuild_tucker (lycoris/functional/general.py:9-11): W[p, q, k] = sum_ij t[i, j, k] wa[i, p] wb[j, q].  Every Tucker
+ * form of the reference (lora_mid, modules/locon.py:85-90; hada_t1 / hada_t2 with HadaWeightTucker, functional/loha.py:
+ * 33-75; lokr_t2, modules/lokr.py:121-128) is the non-Tucker form of the same algorithm with the k x k core folded into
+ * the input-side factor:  B[i, (q, k)] = sum_j t[i, j, k] wb[j, q]   (t [r1, r2, kk], wb [r2, Q], B [r1, Q * kk] = the
+ * layout of a flattened conv factor [r, I, kh, kw]); the adapter kernels then run unchanged on (wa^T, B).
+ * fwd writes B; bwd writes d_t [r1, r2, kk] and d_wb [r2, Q] (either may be NULL) from dB.  Not accumulated. */
+int lyc_tucker_core_fwd(const float* t, const float* wb, float* out, int r1, int r2, int64_t Q, int kk, void* stream);
+int lyc_tucker_core_bwd(const float* dout, const float* t, const float* wb, float* d_t, float* d_wb, int r1, int r2, int64_t Q,
+                        int kk, void* stream);
 
 /* ---- Conv2d lowering (NCHW, groups = 1) --------------------------------------------------------
  * The Conv2d form of every adapter (F.conv2d in lycoris/functional/general.py:6, kw_dict of

@@ -12,10 +12,10 @@
 #include "kron3.h"
 #include "kron_dw2s.h"
 #include "loha_mfma.h"
-#include "loha16.h"
 #include "lokr_kernels.h"
 #include "lowrank.h"
 #include "skinny_kernels.h"
+#include "tucker.h"
 #include "wspace.h"
 
 using namespace lyc;
@@ -1028,40 +1028,12 @@ rocblas_datatype rb_type(int dtype) {
 
 // HadaWeight.backward on a dense fp32 gradient G [O, I] (functional/loha.py:18-30): shared by the activation path
 // (G = g^T x) and the weight-space path (DoRA's norm gradient).
-// fast16: rank <= 32 on the 16-bit matrix cores (loha16.h: hi/lo bf16 operands -- bf16 keeps fp32's exponent range for
-// the gradient values --, three MFMAs per product, ~3e-5 relative); otherwise the exact-fp32 matrix core (loha_mfma.h).
 void launch_loha_factor_grad(const float* gw, const float* w1a, const float* w1b, const float* w2a, const float* w2b,
                              float* d_w1a, float* d_w1b, float* d_w2a, float* d_w2b, long O, long I, int r, float alpha,
-                             hipStream_t st, bool fast16 = false) {
+                             hipStream_t st) {
   LohaArgs la{};
   la.w1a = w1a; la.w1b = w1b; la.w2a = w2a; la.w2b = w2b; la.O = O; la.I = I; la.R = r; la.scale = alpha;
   la.G = gw; la.d_w1a = d_w1a; la.d_w1b = d_w1b; la.d_w2a = d_w2a; la.d_w2b = d_w2b;
-  if (fast16 && r <= L16_R) {
-    const long to = cdiv(O, L16_T), tj = cdiv(I, L16_T);
-    long per = (to * tj) / 512;  // keep >= ~512 workgroups (one per CU: 112 KiB of LDS each)
-    int no = 1;
-    LohaGradGeom gm{1};
-    if (per >= 2) {
-      no = per >= 8 ? 4 : 2;
-      if (no > to) no = to >= 2 ? 2 : 1;
-      gm.nt = (int)(per / no);
-      if (gm.nt < 1) gm.nt = 1;
-      if (gm.nt > tj) gm.nt = (int)tj;
-    }
-    const dim3 fg((unsigned)cdiv(to, no), (unsigned)cdiv(tj, gm.nt));
-    constexpr int lds = loha16_grad_lds_bytes();
-    static const hipError_t once[3] = {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&loha_factor_grad16_kernel<__bf16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&loha_factor_grad16_kernel<__bf16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&loha_factor_grad16_kernel<__bf16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)};
-    (void)once;
-    switch (no) {
-      case 4: hipLaunchKernelGGL((loha_factor_grad16_kernel<__bf16, 4>), fg, dim3(NTHREADS), lds, st, la, gm); break;
-      case 2: hipLaunchKernelGGL((loha_factor_grad16_kernel<__bf16, 2>), fg, dim3(NTHREADS), lds, st, la, gm); break;
-      default: hipLaunchKernelGGL((loha_factor_grad16_kernel<__bf16, 1>), fg, dim3(NTHREADS), lds, st, la, gm); break;
-    }
-    return;
-  }
   // NO x nt tiles per workgroup (fewer atomics: the a-side gradients stay in registers over nt column tiles, the
   // b-side over NO row tiles) as long as ~512 workgroups remain; ranks > 32 go tile by tile, chunk by chunk
   const long tiles_o = cdiv(O, LOHA_T), tiles_j = cdiv(I, LOHA_T);
@@ -1103,16 +1075,9 @@ int lyc_loha_linear_fwd(const void* x, const float* w1a, const float* w1b, const
   la.w1a = w1a; la.w1b = w1b; la.w2a = w2a; la.w2b = w2b; la.O = O; la.I = I; la.R = r; la.scale = alpha;
   la.Wn_h = pl.nh; la.Wn_l = pl.nl; la.Wt_h = pl.th; la.Wt_l = pl.tl; la.ldn = pl.ldn; la.ldt = pl.ldt;
   dim3 rg((unsigned)cdiv(O, LOHA_T), (unsigned)cdiv(I, LOHA_T));
-  const bool r16 = r <= L16_R && (pl.ldn % 8) == 0;  // 16-bit matrix cores (hi/lo operands): loha16.h
   switch (dtype & 0xff) {  // the transposed planes are only read by the fp32-activation GEMM kernels
-    case LYC_BF16:
-      if (r16) hipLaunchKernelGGL((loha_rebuild16_kernel<__bf16>), rg, dim3(NTHREADS), 0, st, la);
-      else hipLaunchKernelGGL((loha_rebuild_mfma_kernel<__bf16, false>), rg, dim3(NTHREADS), 0, st, la);
-      break;
-    case LYC_F16:
-      if (r16) hipLaunchKernelGGL((loha_rebuild16_kernel<_Float16>), rg, dim3(NTHREADS), 0, st, la);
-      else hipLaunchKernelGGL((loha_rebuild_mfma_kernel<_Float16, false>), rg, dim3(NTHREADS), 0, st, la);
-      break;
+    case LYC_BF16: hipLaunchKernelGGL((loha_rebuild_mfma_kernel<__bf16, false>), rg, dim3(NTHREADS), 0, st, la); break;
+    case LYC_F16: hipLaunchKernelGGL((loha_rebuild_mfma_kernel<_Float16, false>), rg, dim3(NTHREADS), 0, st, la); break;
     case LYC_F32: hipLaunchKernelGGL((loha_rebuild_mfma_kernel<float, true>), rg, dim3(NTHREADS), 0, st, la); break;
     default: return fail(LYC_ERR_ARG, "unknown dtype %d", dtype);
   }
@@ -1169,7 +1134,7 @@ int lyc_loha_linear_bwd(const void* g, const void* x, const float* w1a, const fl
       dim3 gg((unsigned)cdiv(O, 128), (unsigned)cdiv(I, 128), 1);
       DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_tn_kernel<T>), gg, dim3(NTHREADS), 0, st, ga));
     }
-    launch_loha_factor_grad(gw, w1a, w1b, w2a, w2b, d_w1a, d_w1b, d_w2a, d_w2b, O, I, r, alpha, st, /*fast16=*/lib);
+    launch_loha_factor_grad(gw, w1a, w1b, w2a, w2b, d_w1a, d_w1b, d_w2a, d_w2b, O, I, r, alpha, st);
   }
   return check_launch("loha_linear_bwd");
 }
@@ -1247,6 +1212,33 @@ int lyc_lokr_wgrad(const float* gw, const float* w1, const float* w2, float* d_w
   hipLaunchKernelGGL(kron_wgrad_kernel, dim3((unsigned)c, (unsigned)cdiv(dk, NTHREADS)), dim3(NTHREADS), 0,
                      (hipStream_t)stream, k);
   return check_launch("lokr_wgrad");
+}
+
+
+// ---- Tucker / conv-CP core fold (tucker.h) ---------------------------------------------------------------------------
+int lyc_tucker_core_fwd(const float* t, const float* wb, float* out, int r1, int r2, int64_t Q, int kk, void* stream) {
+  if (r1 < 1 || r2 < 1 || Q < 1 || kk < 1 || !t || !wb || !out) return fail(LYC_ERR_ARG, "tucker_core_fwd: bad arguments");
+  TuckerArgs a{};
+  a.t = t; a.wb = wb; a.B = out; a.r1 = r1; a.r2 = r2; a.Q = Q; a.kk = kk;
+  long blocks = cdiv((long)r1 * Q * kk, NTHREADS);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(tucker_core_fwd_kernel, dim3((unsigned)blocks), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+  return check_launch("tucker_core_fwd");
+}
+
+int lyc_tucker_core_bwd(const float* dout, const float* t, const float* wb, float* d_t, float* d_wb, int r1, int r2, int64_t Q,
+                        int kk, void* stream) {
+  if (r1 < 1 || r2 < 1 || Q < 1 || kk < 1 || !dout || !t || !wb) return fail(LYC_ERR_ARG, "tucker_core_bwd: bad arguments");
+  TuckerArgs a{};
+  a.t = t; a.wb = wb; a.dB = dout; a.d_t = d_t; a.d_wb = d_wb; a.r1 = r1; a.r2 = r2; a.Q = Q; a.kk = kk;
+  hipStream_t st = (hipStream_t)stream;
+  if (d_t) hipLaunchKernelGGL(tucker_core_dt_kernel, dim3((unsigned)(r1 * r2)), dim3(NTHREADS), 0, st, a);
+  if (d_wb) {
+    long blocks = cdiv((long)r2 * Q, NTHREADS);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(tucker_core_dwb_kernel, dim3((unsigned)blocks), dim3(NTHREADS), 0, st, a);
+  }
+  return check_launch("tucker_core_bwd");
 }
 
 // ---- Conv2d lowering -------------------------------------------------------------------------------

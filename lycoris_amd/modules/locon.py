@@ -40,10 +40,13 @@ class LoConModule(LycorisBaseModule):
         if self.module_type == "conv2d":
             self.isconv = True
             k = org_module.kernel_size
-            if use_tucker and any(i != 1 for i in k):
-                raise _unsupported("use_tucker (lora_mid) for k>1 convolutions")
-            self.lora_down = nn.Conv2d(org_module.in_channels, lora_dim, k, org_module.stride, org_module.padding,
-                                       bias=False)
+            self.tucker = bool(use_tucker) and any(i != 1 for i in k)
+            if self.tucker:  # conv-CP form (locon.py:85-90): 1x1 down, k x k core r -> r, 1x1 up
+                self.lora_down = nn.Conv2d(org_module.in_channels, lora_dim, 1, bias=False)
+                self.lora_mid = nn.Conv2d(lora_dim, lora_dim, k, org_module.stride, org_module.padding, bias=False)
+            else:
+                self.lora_down = nn.Conv2d(org_module.in_channels, lora_dim, k, org_module.stride, org_module.padding,
+                                           bias=False)
             self.lora_up = nn.Conv2d(lora_dim, org_module.out_channels, 1, bias=False)
         else:
             self.isconv = False
@@ -55,6 +58,8 @@ class LoConModule(LycorisBaseModule):
             nn.init.kaiming_uniform_(self.lora_up.weight, a=math.sqrt(5))
         else:
             nn.init.zeros_(self.lora_up.weight)
+        if self.tucker:
+            nn.init.kaiming_uniform_(self.lora_mid.weight, a=math.sqrt(5))
 
     @classmethod
     def make_module_from_state_dict(cls, lora_name, orig_module, up, down, mid, alpha, dora_scale):
@@ -63,6 +68,8 @@ class LoConModule(LycorisBaseModule):
                   weight_decompose=dora_scale is not None, wd_on_out=wd_on_out)
         mod.lora_up.weight.data.copy_(up)
         mod.lora_down.weight.data.copy_(down)
+        if mid is not None:
+            mod.lora_mid.weight.data.copy_(mid)
         if dora_scale is not None:
             mod.dora_scale.data.copy_(dora_scale.reshape(mod.dora_scale.shape))
         return mod
@@ -72,15 +79,26 @@ class LoConModule(LycorisBaseModule):
               "lora_down.weight": self.lora_down.weight}
         if self.wd:
             sd["dora_scale"] = self.dora_scale
+        if self.tucker:
+            sd["lora_mid.weight"] = self.lora_mid.weight
         return sd
 
+    def _down_eff(self):
+        """the input-side factor as the kernels take it, [r, I, kh, kw]: lora_down itself, or with use_tucker the k x k
+        core folded into the 1x1 down-projection (up(mid(down(x))) == up(conv(x, mid o down)): csrc/tucker.h)"""
+        if not self.tucker:
+            return self.lora_down.weight
+        if self.lora_mid.weight.is_cuda:
+            return ops.tucker_core(self.lora_mid.weight, self.lora_down.weight)
+        return torch.einsum("ijhw,jq->iqhw", self.lora_mid.weight, self.lora_down.weight.flatten(1))  # offline / CPU
+
     def _ws_factors(self, gated=True):
-        return (self.lora_down.weight, self._gate(self.lora_up.weight) if gated else self.lora_up.weight)
+        return (self._down_eff(), self._gate(self.lora_up.weight) if gated else self.lora_up.weight)
 
     # ---- dW materialisation (merge / export / max-norm only) -----------------------------------------------------
     def make_weight(self, device=None):
         up = self.lora_up.weight.to(device)
-        down = self.lora_down.weight.to(device)
+        down = self._down_eff().to(device)
         w = up.reshape(up.size(0), -1) @ down.reshape(down.size(0), -1)
         return w.reshape(self.shape) * self.scalar.to(device)
 
@@ -127,4 +145,4 @@ class LoConModule(LycorisBaseModule):
         if not self.isconv:
             return ops.locon_linear(x, self.lora_down.weight, up, alpha)
         stride, padding, dilation = conv_args(self.kw_dict)
-        return ops.locon_conv2d(x, self.lora_down.weight, up, alpha, stride, padding, dilation)
+        return ops.locon_conv2d(x, self._down_eff(), up, alpha, stride, padding, dilation)

@@ -34,13 +34,22 @@ class LohaModule(LycorisBaseModule):
         out_dim, in_flat = self.shape[0], self.shape[1]
         if self.module_type == "conv2d":
             k = org_module.kernel_size
-            if use_tucker and any(i != 1 for i in k):
-                raise _unsupported("use_tucker (hada_t1/t2) for k>1 convolutions")
+            self.tucker = bool(use_tucker) and any(i != 1 for i in k)
             in_flat = self.shape[1] * k[0] * k[1]  # non-Tucker conv factors are [r, I*kh*kw] (loha.py:76)
-        self.hada_w1_a = nn.Parameter(torch.empty(out_dim, lora_dim))
-        self.hada_w1_b = nn.Parameter(torch.empty(lora_dim, in_flat))
-        self.hada_w2_a = nn.Parameter(torch.empty(out_dim, lora_dim))
-        self.hada_w2_b = nn.Parameter(torch.empty(lora_dim, in_flat))
+        if self.tucker:  # loha.py:78-93: cores [r, r, kh, kw], a-side [r, O] ("1-mode"), b-side [r, I] ("2-mode")
+            self.hada_t1 = nn.Parameter(torch.empty(lora_dim, lora_dim, *self.shape[2:]))
+            self.hada_w1_a = nn.Parameter(torch.empty(lora_dim, out_dim))
+            self.hada_w1_b = nn.Parameter(torch.empty(lora_dim, self.shape[1]))
+            self.hada_t2 = nn.Parameter(torch.empty(lora_dim, lora_dim, *self.shape[2:]))
+            self.hada_w2_a = nn.Parameter(torch.empty(lora_dim, out_dim))
+            self.hada_w2_b = nn.Parameter(torch.empty(lora_dim, self.shape[1]))
+            nn.init.normal_(self.hada_t1, std=0.1)
+            nn.init.normal_(self.hada_t2, std=0.1)
+        else:
+            self.hada_w1_a = nn.Parameter(torch.empty(out_dim, lora_dim))
+            self.hada_w1_b = nn.Parameter(torch.empty(lora_dim, in_flat))
+            self.hada_w2_a = nn.Parameter(torch.empty(out_dim, lora_dim))
+            self.hada_w2_b = nn.Parameter(torch.empty(lora_dim, in_flat))
         self._init_scale(lora_dim, alpha, rs_lora, use_scalar)
         nn.init.normal_(self.hada_w1_b, std=1)
         nn.init.normal_(self.hada_w1_a, std=0.1)
@@ -57,6 +66,9 @@ class LohaModule(LycorisBaseModule):
                   weight_decompose=dora_scale is not None, wd_on_out=wd_on_out)
         for p, v in ((mod.hada_w1_a, w1a), (mod.hada_w1_b, w1b), (mod.hada_w2_a, w2a), (mod.hada_w2_b, w2b)):
             p.data.copy_(v)
+        if t1 is not None:
+            mod.hada_t1.data.copy_(t1)
+            mod.hada_t2.data.copy_(t2)
         if dora_scale is not None:
             mod.dora_scale.data.copy_(dora_scale.reshape(mod.dora_scale.shape))
         return mod
@@ -66,14 +78,28 @@ class LohaModule(LycorisBaseModule):
               "hada_w2_a": self.hada_w2_a, "hada_w2_b": self.hada_w2_b}
         if self.wd:
             sd["dora_scale"] = self.dora_scale
+        if self.tucker:
+            sd["hada_t1"] = self.hada_t1
+            sd["hada_t2"] = self.hada_t2
         return sd
 
+    def _fold(self, t, wb):
+        if t.is_cuda:
+            return ops.tucker_core(t, wb).flatten(1)
+        return torch.einsum("ijhw,jq->iqhw", t, wb).flatten(1)  # offline / CPU
+
     def _ws_factors(self, gated=True):
-        return (self._gate(self.hada_w1_a) if gated else self.hada_w1_a, self.hada_w1_b, self.hada_w2_a, self.hada_w2_b)
+        """(w1a [O, r], w1b [r, I*kh*kw], w2a, w2b) as the kernels take them.  Tucker (HadaWeightTucker, functional/loha.py:
+        33-75): rebuild_k = w_k_a^T @ fold(t_k, w_k_b), i.e. the plain form on the transposed a-side and the folded b-side."""
+        a1 = self._gate(self.hada_w1_a) if gated else self.hada_w1_a
+        if not self.tucker:
+            return (a1, self.hada_w1_b, self.hada_w2_a, self.hada_w2_b)
+        return (a1.t(), self._fold(self.hada_t1, self.hada_w1_b), self.hada_w2_a.t(), self._fold(self.hada_t2, self.hada_w2_b))
 
     # ---- dW materialisation (merge / export / max-norm only) -----------------------------------------------------
     def get_weight(self, shape):
-        w = (self.hada_w1_a @ self.hada_w1_b) * (self.hada_w2_a @ self.hada_w2_b) * self.scale
+        a1, b1, a2, b2 = self._ws_factors(gated=False)
+        w = (a1 @ b1) * (a2 @ b2) * self.scale
         return w if shape is None else w.reshape(shape)
 
     def get_diff_weight(self, multiplier=1, shape=None, device=None):
@@ -115,9 +141,8 @@ class LohaModule(LycorisBaseModule):
     def bypass_forward_diff(self, x, scale=1):
         """delta = op(x, ((w1a w1b) * (w2a w2b)) * alpha/r * scalar * scale)  (loha.py:294-299 and :301-322)."""
         alpha = self.scale * scale
-        w1a = self._gate(self.hada_w1_a)
+        w1a, w1b, w2a, w2b = self._ws_factors()
         if self.module_type == "linear":
-            return ops.loha_linear(x, w1a, self.hada_w1_b, self.hada_w2_a, self.hada_w2_b, alpha)
+            return ops.loha_linear(x, w1a, w1b, w2a, w2b, alpha)
         stride, padding, dilation = conv_args(self.kw_dict)
-        return ops.loha_conv2d(x, w1a, self.hada_w1_b, self.hada_w2_a, self.hada_w2_b, alpha, tuple(self.shape),
-                               stride, padding, dilation)
+        return ops.loha_conv2d(x, w1a, w1b, w2a, w2b, alpha, tuple(self.shape), stride, padding, dilation)

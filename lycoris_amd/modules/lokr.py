@@ -60,8 +60,7 @@ class LokrModule(LycorisBaseModule):
         out_l, out_k = factorization(out_dim, factor)
         if unbalanced_factorization:
             out_l, out_k = out_k, out_l
-        if is_conv and use_tucker and any(i != 1 for i in ksize):
-            raise _unsupported("use_tucker (lokr_t2) for k>1 convolutions")
+        self.tucker = bool(use_tucker) and is_conv and any(i != 1 for i in ksize)
 
         # small factor w1: [out_l, in_m] (optionally rank-decomposed)
         self.use_w1 = not (decompose_both and lora_dim < max(out_l, in_m) / 2 and not full_matrix)
@@ -77,6 +76,10 @@ class LokrModule(LycorisBaseModule):
             if not full_matrix:
                 _warn_full_matrix(lora_dim, max(in_dim, out_dim), factor)
             self.lokr_w2 = nn.Parameter(torch.empty(out_k, in_n, *ksize))
+        elif self.tucker:  # lokr.py:121-128: core [r, r, kh, kw], "1-mode" [r, out_k], "2-mode" [r, in_n]
+            self.lokr_t2 = nn.Parameter(torch.empty(lora_dim, lora_dim, *ksize))
+            self.lokr_w2_a = nn.Parameter(torch.empty(lora_dim, out_k))
+            self.lokr_w2_b = nn.Parameter(torch.empty(lora_dim, in_n))
         else:
             kprod = 1
             for i in ksize:
@@ -92,6 +95,8 @@ class LokrModule(LycorisBaseModule):
             else:
                 nn.init.zeros_(self.lokr_w2)
         else:
+            if self.tucker and not self.use_w2:
+                nn.init.kaiming_uniform_(self.lokr_t2, a=math.sqrt(5))
             nn.init.kaiming_uniform_(self.lokr_w2_a, a=math.sqrt(5))
             if use_scalar:
                 nn.init.kaiming_uniform_(self.lokr_w2_b, a=math.sqrt(5))
@@ -107,12 +112,13 @@ class LokrModule(LycorisBaseModule):
     def make_module_from_state_dict(cls, lora_name, orig_module, w1, w1a, w1b, w2, w2a, w2b, _, t2, alpha,
                                     dora_scale):
         """Rebuild a module from checkpoint tensors: find the ``factor`` that reproduces the stored factor shapes."""
-        if t2 is not None:
-            raise _unsupported("LoKr checkpoints with lokr_t2")
         full_matrix = w1a is None and w2a is None
-        lora_dim = w1a.size(1) if w1a is not None else (w2a.size(1) if w2a is not None else 1)
+        if t2 is not None:  # Tucker: w2_a is [r, out_k]
+            lora_dim = t2.size(0)
+        else:
+            lora_dim = w1a.size(1) if w1a is not None else (w2a.size(1) if w2a is not None else 1)
         a, b = (w1.shape if w1 is not None else (w1a.size(0), w1b.size(1)))
-        c = w2.size(0) if w2 is not None else w2a.size(0)
+        c = w2.size(0) if w2 is not None else (w2a.size(1) if t2 is not None else w2a.size(0))
         probe = cls.__new__(cls)  # only to read the wrapped layer's dims through the base bookkeeping
         nn.Module.__init__(probe)
         LycorisBaseModule.__init__(probe, lora_name, orig_module)
@@ -129,13 +135,13 @@ class LokrModule(LycorisBaseModule):
         if factor is None:
             raise ValueError(f"cannot infer LoKr factor for {lora_name}: w1 {a}x{b}, layer {out_dim}x{in_dim}")
         mod = cls(lora_name, orig_module, 1, lora_dim, float(alpha), decompose_both=w1 is None and w2 is None,
-                  factor=factor, full_matrix=full_matrix, weight_decompose=dora_scale is not None,
+                  factor=factor, full_matrix=full_matrix, use_tucker=t2 is not None, weight_decompose=dora_scale is not None,
                   wd_on_out=dora_scale is None or dora_scale.shape[0] == out_dim)
         if dora_scale is not None:
             mod.dora_scale.data.copy_(dora_scale.reshape(mod.dora_scale.shape))
         with torch.no_grad():
             for name, val in (("lokr_w1", w1), ("lokr_w1_a", w1a), ("lokr_w1_b", w1b), ("lokr_w2", w2),
-                              ("lokr_w2_a", w2a), ("lokr_w2_b", w2b)):
+                              ("lokr_w2_a", w2a), ("lokr_w2_b", w2b), ("lokr_t2", t2)):
                 if val is not None:
                     getattr(mod, name).copy_(val)
         return mod
@@ -154,6 +160,8 @@ class LokrModule(LycorisBaseModule):
         else:
             sd["lokr_w2_a"] = self.lokr_w2_a
             sd["lokr_w2_b"] = self.lokr_w2_b
+            if self.tucker:
+                sd["lokr_t2"] = self.lokr_t2
         return sd
 
     # ---- factors -------------------------------------------------------------------------------------------------
@@ -164,6 +172,12 @@ class LokrModule(LycorisBaseModule):
         if self.use_w2:
             return self.lokr_w2
         out_k, in_n = self._kron_dims[2], self._kron_dims[3]
+        if self.tucker:  # rebuild_tucker(t2, w2_a, w2_b) = w2_a^T @ fold(t2, w2_b)   (general.py:9-11, csrc/tucker.h)
+            if self.lokr_t2.is_cuda:
+                fold = ops.tucker_core(self.lokr_t2, self.lokr_w2_b)
+            else:
+                fold = torch.einsum("ijhw,jq->iqhw", self.lokr_t2, self.lokr_w2_b)  # offline / CPU
+            return (self.lokr_w2_a.t() @ fold.flatten(1)).reshape(out_k, in_n, *self.shape[2:])
         return (self.lokr_w2_a @ self.lokr_w2_b).reshape(out_k, in_n, *self.shape[2:])
 
     def _ws_factors(self, gated=True):

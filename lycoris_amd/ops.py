@@ -754,3 +754,49 @@ class _WeightNorm2(torch.autograd.Function):
 def weight_norm2(algo, W, factors, alpha=1.0, chan_mode=CH_ROW):
     """differentiable (w.r.t. the factors) squared norms of W + alpha * dW per output row / per input channel"""
     return _WeightNorm2.apply(algo, W, alpha, chan_mode, *factors)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Tucker / conv-CP forms: fold the k x k core into the input-side factor (lyc_tucker_core_*; csrc/tucker.h)
+# ---------------------------------------------------------------------------------------------------------------
+class _TuckerCore(torch.autograd.Function):
+    """B[i, q, *k] = sum_j t[i, j, *k] wb[j, q]:  t [r1, r2, kh, kw], wb [r2, Q]  ->  [r1, Q, kh, kw].
+    rebuild_tucker(t, wa, wb) (functional/general.py:9-11) == wa^T @ B, so a Tucker adapter is the plain adapter on
+    (wa^T, B) and all its activation-path kernels are reused."""
+
+    @staticmethod
+    def forward(ctx, t, wb):
+        N.require_device(t, "Tucker core")
+        tf, wf = _f32c(t), _f32c(wb.reshape(wb.shape[0], -1))
+        r1, r2 = tf.shape[0], tf.shape[1]
+        kk = 1
+        for s in tf.shape[2:]:
+            kk *= s
+        Q = wf.shape[1]
+        if wf.shape[0] != r2:
+            raise ValueError(f"tucker_core: core is {tuple(t.shape)}, factor is {tuple(wb.shape)}")
+        out = torch.empty((r1, Q, *tf.shape[2:]), dtype=torch.float32, device=t.device)
+        N.call("lyc_tucker_core_fwd", N.ptr(tf), N.ptr(wf), N.ptr(out), r1, r2, Q, kk, N.stream_ptr(t.device))
+        ctx.save_for_backward(t, wb)
+        return out.to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        t, wb = ctx.saved_tensors
+        tf, wf = _f32c(t), _f32c(wb.reshape(wb.shape[0], -1))
+        r1, r2 = tf.shape[0], tf.shape[1]
+        kk = 1
+        for s in tf.shape[2:]:
+            kk *= s
+        Q = wf.shape[1]
+        gf = _f32c(g)
+        dt = torch.empty_like(tf) if ctx.needs_input_grad[0] else None
+        dwb = torch.empty_like(wf) if ctx.needs_input_grad[1] else None
+        N.call("lyc_tucker_core_bwd", N.ptr(gf), N.ptr(tf), N.ptr(wf), N.ptr(dt), N.ptr(dwb), r1, r2, Q, kk,
+               N.stream_ptr(t.device))
+        return (None if dt is None else dt.to(t.dtype)), (None if dwb is None else dwb.reshape(wb.shape).to(wb.dtype))
+
+
+def tucker_core(t, wb):
+    """t [r1, r2, kh, kw] (the Tucker core / lora_mid.weight), wb [r2, Q(,1,1)] -> [r1, Q, kh, kw]"""
+    return _TuckerCore.apply(t, wb)

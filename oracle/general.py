@@ -115,6 +115,30 @@ def dense_backward(x, w, g, conv_args=None):
     return dx, dw
 
 
+def tucker_core(t, wb):
+    """Fold the Tucker core into the input-side factor: B[i, q, ...] = sum_j t[i, j, ...] wb[j, q].
+    rebuild_tucker(t, wa, wb) (general.py:9-11: einsum "i j ..., i p, j r -> p r ...") == wa^T @ B."""
+    t = np.asarray(t, dtype=np.float64)
+    wb = np.asarray(wb, dtype=np.float64).reshape(t.shape[1], -1)
+    return np.einsum("ij...,jq->iq...", t, wb)
+
+
+def tucker_core_grads(dB, t, wb):
+    """(d_t, d_wb) of sum(dB * tucker_core(t, wb))"""
+    t = np.asarray(t, dtype=np.float64)
+    wb2 = np.asarray(wb, dtype=np.float64).reshape(t.shape[1], -1)
+    t3 = t.reshape(t.shape[0], t.shape[1], -1)
+    dB3 = np.asarray(dB, dtype=np.float64).reshape(t.shape[0], wb2.shape[1], -1)
+    d_t = np.einsum("iqk,jq->ijk", dB3, wb2).reshape(t.shape)
+    d_wb = np.einsum("ijk,iqk->jq", t3, dB3)
+    return d_t, d_wb.reshape(np.asarray(wb).shape)
+
+
+def rebuild_tucker(t, wa, wb):
+    """W[p, q, ...] = sum_ij t[i, j, ...] wa[i, p] wb[j, q]   (functional/general.py:9-11)"""
+    return np.einsum("ij...,ip,jq->pq...", np.asarray(t, np.float64), np.asarray(wa, np.float64), np.asarray(wb, np.float64))
+
+
 def rel_err(a, b):
     """Norm-wise relative error ||a-b|| / ||b|| (the metric of SURVEY 8d)."""
     a = np.asarray(a, dtype=np.float64)

@@ -71,6 +71,19 @@ def numeric_case(name, algo, layer_kw, mod_kw, xshape, seed, multiplier=0.7):
     for (n, p), gr in zip(params, grads[1:]):
         rec["p." + n] = p.detach()
         rec["g." + n] = gr
+    if algo == "loha" and getattr(mod, "tucker", False):
+        # Reference defect D10: HadaWeightTucker.backward (functional/loha.py:49-56, 66-73) contracts grad_w with the fold of
+        # the OTHER branch (`temp` is built from t2 / w2d and then used for grad_w1u, and vice versa), so its gradients of
+        # hada_w1_a / hada_w2_a are not the derivative of its own forward.  The same forward through plain autograd (the
+        # reference's rebuild_tucker einsum, functional/general.py:9-11) gives the true a-side gradients: stored as gtrue.*.
+        from lycoris.functional.general import rebuild_tucker
+        ps = dict(params)
+        dw = (rebuild_tucker(ps["hada_t1"], ps["hada_w1_a"], ps["hada_w1_b"])
+              * rebuild_tucker(ps["hada_t2"], ps["hada_w2_a"], ps["hada_w2_b"]) * mod.scale * multiplier)
+        y2 = torch.nn.functional.conv2d(x, dw, None, layer.stride, layer.padding, layer.dilation)
+        assert torch.allclose(y2, (out - base).detach(), atol=1e-10)
+        ga, gb = torch.autograd.grad((y2 * g).sum(), [ps["hada_w1_a"], ps["hada_w2_a"]])
+        rec["gtrue.hada_w1_a"], rec["gtrue.hada_w2_a"] = ga, gb
     meta = {
         "algo": algo, "layer": layer_kw, "mod": mod_kw, "multiplier": multiplier,
         "scale": float(getattr(mod, "scale", 1.0)),
@@ -136,6 +149,14 @@ def main():
         numeric_case("dora_lokr_linear_out", "lokr", lin, dict(lora_dim=10000, alpha=1, factor=4, weight_decompose=True, wd_on_out=True), xl3, 48),
         numeric_case("dora_lokr_linear_in_lowrank", "lokr", lin, dict(lora_dim=2, alpha=1, factor=2, weight_decompose=True, wd_on_out=False), xl, 49),
         numeric_case("dora_lokr_conv3_out", "lokr", c3, dict(lora_dim=10000, alpha=1, factor=4, weight_decompose=True, wd_on_out=True), xc, 50),
+        # Tucker / conv-CP forms (use_tucker on k > 1 convolutions): lora_mid, HadaWeightTucker, lokr_t2
+        numeric_case("tucker_locon_conv3", "locon", c3, dict(lora_dim=4, alpha=1, use_tucker=True), xc, 61),
+        numeric_case("tucker_locon_conv3_s2", "locon", c3s2, dict(lora_dim=2, alpha=2, use_tucker=True, use_scalar=True), (2, 16, 7, 6), 62),
+        numeric_case("tucker_loha_conv3", "loha", c3, dict(lora_dim=4, alpha=1, use_tucker=True), xc, 63),
+        numeric_case("tucker_lokr_conv3", "lokr", dict(kind="conv2d", cin=16, cout=32, k=3, stride=1, padding=1),
+                     dict(lora_dim=2, alpha=1, factor=2, use_tucker=True), (2, 16, 5, 6), 64),
+        numeric_case("tucker_lokr_conv3_d2", "lokr", dict(kind="conv2d", cin=16, cout=16, k=3, stride=1, padding=2, dilation=2),
+                     dict(lora_dim=2, alpha=2, factor=4, use_tucker=True), (1, 16, 9, 8), 65),
         numeric_case("ia3_linear_out", "ia3", lin, dict(), xl3, 31),
         numeric_case("ia3_linear_in", "ia3", lin, dict(train_on_input=True), xl3, 32),
         numeric_case("ia3_linear_out_nobias", "ia3", lin_nb, dict(), (7, 32), 33),

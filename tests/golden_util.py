@@ -23,16 +23,46 @@ def oracle_eval(meta, a):
         return _oracle_eval_dora(meta, a, scalar, ca)
     if algo == "locon":
         down, up = a["p.lora_down.weight"], a["p.lora_up.weight"]
+        mid = a.get("p.lora_mid.weight")
+        if mid is not None:  # use_tucker: up(mid(down(x))) = the plain form on the folded input-side factor
+            down_raw, down = down, oracle.general.tucker_core(mid, down)
         delta = oracle.locon.forward(x, down, up, eff, ca)
         dx, dd, du = oracle.locon.backward(x, g, down, up, eff, ca)
         out = {"dx": dx, "g.lora_down.weight": dd, "g.lora_up.weight": du}
+        if mid is not None:
+            out["g.lora_mid.weight"], out["g.lora_down.weight"] = oracle.general.tucker_core_grads(dd, mid, down_raw)
         dscalar = (du * up).sum() / scalar if "p.scalar" in a else None
     elif algo == "loha":
         ws = [a["p.hada_w1_a"], a["p.hada_w1_b"], a["p.hada_w2_a"], a["p.hada_w2_b"]]
+        t1, t2 = a.get("p.hada_t1"), a.get("p.hada_t2")
+        raw = list(ws)
+        if t1 is not None:  # HadaWeightTucker: rebuild_k = w_k_a^T @ fold(t_k, w_k_b)
+            r = t1.shape[0]
+            ws = [raw[0].T, oracle.general.tucker_core(t1, raw[1]).reshape(r, -1),
+                  raw[2].T, oracle.general.tucker_core(t2, raw[3]).reshape(r, -1)]
         delta = oracle.loha.forward(x, *ws, eff, W.shape, ca)
         dx, g1a, g1b, g2a, g2b = oracle.loha.backward(x, g, *ws, eff, W.shape, ca)
+        if t1 is not None:
+            gt1, g1b = oracle.general.tucker_core_grads(g1b, t1, raw[1])
+            gt2, g2b = oracle.general.tucker_core_grads(g2b, t2, raw[3])
+            g1a, g2a = g1a.T, g2a.T
         out = {"dx": dx, "g.hada_w1_a": g1a, "g.hada_w1_b": g1b, "g.hada_w2_a": g2a, "g.hada_w2_b": g2b}
-        dscalar = (g1a * ws[0]).sum() / scalar if "p.scalar" in a else None
+        if t1 is not None:
+            out["g.hada_t1"], out["g.hada_t2"] = gt1, gt2
+        dscalar = (g1a * raw[0]).sum() / scalar if "p.scalar" in a else None
+    elif algo == "lokr" and "p.lokr_t2" in a:
+        t2, w2a, w2b, w1 = a["p.lokr_t2"], a["p.lokr_w2_a"], a["p.lokr_w2_b"], a["p.lokr_w1"]
+        r = t2.shape[0]
+        fold = oracle.general.tucker_core(t2, w2b)                       # [r, d, kh, kw]
+        f2 = (w2a.T @ fold.reshape(r, -1)).reshape(w2a.shape[1], w2b.shape[1], *t2.shape[2:])
+        args = dict(w1=w1, w2=f2, scale=eff, kshape=tuple(W.shape[2:]), conv_args=ca)
+        delta = oracle.lokr.forward(x, **args)
+        gr = oracle.lokr.backward(x, g, **args)
+        d2 = gr["w2"].reshape(f2.shape[0], -1)                             # [c, d*kk]
+        gt2, gw2b = oracle.general.tucker_core_grads(w2a @ d2, t2, w2b)
+        out = {"dx": gr["dx"], "g.lokr_w1": gr["w1"], "g.lokr_w2_a": fold.reshape(r, -1) @ d2.T, "g.lokr_w2_b": gw2b,
+               "g.lokr_t2": gt2}
+        dscalar = (gr["w1"] * w1).sum() / scalar if "p.scalar" in a else None
     elif algo == "lokr":
         kw = {k: a.get("p.lokr_" + k) for k in ("w1", "w1_a", "w1_b", "w2", "w2_a", "w2_b")}
         args = dict(w1=kw["w1"], w1a=kw["w1_a"], w1b=kw["w1_b"], w2=kw["w2"], w2a=kw["w2_a"], w2b=kw["w2_b"],

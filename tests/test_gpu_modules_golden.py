@@ -51,7 +51,8 @@ def test_module_matches_reference_golden(name, golden_cases):
     torch.cuda.synchronize()
     errs = {"delta": err(out - base, a["delta"]), "dx": err(grads[0] - dx_base, a["dx"])}
     for (n, _), gr in zip(params, grads[1:]):
-        errs["g." + n] = err(gr, a["g." + n])
+        # (gtrue.*: the reference's HadaWeightTucker.backward is wrong for the a-side factors -- defect D10, make_golden.py)
+        errs["g." + n] = err(gr, a.get("gtrue." + n, a["g." + n]))
     # fp32 end to end; delta/dx are differences of fp32 tensors dominated by `base`, hence the looser bound there
     bounds = {k: (2e-4 if k in ("delta", "dx") else 5e-5) for k in errs}
     check(f"module_golden[{name}]", errs, bounds)

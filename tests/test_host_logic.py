@@ -185,8 +185,12 @@ def test_no_cpu_fallback_and_unsupported_features_fail_loudly():
     m = LoConModule("m", nn.Linear(8, 8), 1.0, 2, 1, dropout=0.1, rank_dropout=0.2, module_dropout=0.3,
                     rank_dropout_scale=True)
     assert (m.dropout, m.rank_dropout, m.module_dropout, m.rank_dropout_scale) == (0.1, 0.2, 0.3, True)
-    with pytest.raises(NotImplementedError):
-        LokrModule("m", nn.Conv2d(8, 8, 3), 1.0, 2, 1, use_tucker=True, factor=2)
+    # Tucker / conv-CP forms are on the native path (core folded into the input-side factor, csrc/tucker.h)
+    m = LokrModule("m", nn.Conv2d(8, 8, 3), 1.0, 1, 1, use_tucker=True, factor=2)
+    assert m.tucker and tuple(m.lokr_t2.shape) == (1, 1, 3, 3) and "lokr_t2" in m.state_dict()
+    m = LoConModule("m", nn.Conv2d(8, 8, 3), 1.0, 2, 1, use_tucker=True)
+    assert m.tucker and tuple(m.lora_mid.weight.shape) == (2, 2, 3, 3) and tuple(m.lora_down.weight.shape) == (2, 8, 1, 1)
+    assert not LoConModule("m", nn.Conv2d(8, 8, 1), 1.0, 2, 1, use_tucker=True).tucker      # 1x1: nothing to factor
     with pytest.raises(NotImplementedError):
         LohaModule("m", nn.Conv1d(8, 8, 3), 1.0, 2, 1)
     with pytest.raises(ValueError):

@@ -22,6 +22,10 @@ def test_oracle_matches_reference_module(name, golden_cases):
     for k, v in a.items():
         if k.startswith("g.") and k != "g":
             assert k in grads, (name, k)
+            if "gtrue." + k[2:] in a:
+                # reference defect D10 (HadaWeightTucker.backward mixes up the two branches for the a-side factors): the
+                # oracle follows the derivative of the reference's own FORWARD, pinned by the plain-autograd vectors
+                v = a["gtrue." + k[2:]]
             assert oracle.general.rel_err(np.asarray(grads[k]).reshape(v.shape), v) < 1e-11, (name, k)
             checked += 1
     assert checked >= 1
