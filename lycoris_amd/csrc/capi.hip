@@ -201,39 +201,6 @@ void launch_dw2s(KronDw2sArgs da, hipStream_t st) {
   else launch_dw2s_inst<T, 2, 2, 4>(da, da.tiles_i, da.tiles_j, st);
 }
 
-// ---- fused backward launch (kron_bwd_fused_kernel): dx + dW1 partials and dW2 as two roles of one grid ------------------
-template <typename T, int NI, int GM, int MI, int NJ, int U>
-void launch_bwd_fused_inst(const KronArgs& ka, const KronDw2sArgs& da, hipStream_t st) {
-  const int nbx = (int)cdiv(ka.M, K3_RT / ka.Gin), nby = (int)cdiv(ka.N, 16 * NI);
-  const int n_dw2 = (int)round_up((long)da.tiles_i * da.tiles_j * da.nsplit, 8);
-  const long nseg = cdiv(ka.K, kron3_kc(NI));
-  const int k3 = kron3_lds_bytes(NI, nseg > 1 ? 2 : 1) + (GM == 3 ? kron3_xs_bytes() : 0);
-  constexpr int d2 = kron_dw2s_lds_bytes<MI, NJ>();
-  const int lds = k3 > d2 ? k3 : d2;
-  constexpr int lds_max = (kron3_lds_bytes(NI, 2) + kron3_xs_bytes()) > d2 ? (kron3_lds_bytes(NI, 2) + kron3_xs_bytes()) : d2;
-  static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&kron_bwd_fused_kernel<T, NI, GM, MI, NJ, U>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-  (void)once;
-  hipLaunchKernelGGL((kron_bwd_fused_kernel<T, NI, GM, MI, NJ, U>), dim3((unsigned)(n_dw2 + nbx * nby)), dim3(NTHREADS), lds, st,
-                     ka, da, n_dw2, nbx);
-}
-
-// false: not taken (the 64 x 64 dW2 tile needs > 256 registers next to the dx role: one workgroup per CU, nothing to overlap)
-template <typename T>
-bool launch_bwd_fused(const KronArgs& ka, KronDw2sArgs da, hipStream_t st) {
-  if (plan_dw2s(da)) return false;
-  const int ni = kron3_pick_ni(ka);
-  const bool xs = (ka.K % 32) == 0;  // x through the per-wave LDS stage (see launch_kron3_inst)
-  if (ni == 4) {
-    if (xs) launch_bwd_fused_inst<T, 4, 3, 2, 2, 4>(ka, da, st);
-    else launch_bwd_fused_inst<T, 4, 0, 2, 2, 4>(ka, da, st);
-  } else {
-    if (xs) launch_bwd_fused_inst<T, 2, 3, 2, 2, 4>(ka, da, st);
-    else launch_bwd_fused_inst<T, 2, 0, 2, 2, 4>(ka, da, st);
-  }
-  return true;
-}
-
 template <typename T>
 void launch_kron_dw2(KronDw2Args da, hipStream_t st) {
   const long rows_total = da.M * da.Gs;
@@ -510,12 +477,6 @@ struct ForkCtx {
 };
 thread_local ForkCtx g_fork[16];
 
-// LYC_FUSED_BWD=0 switches the one-launch backward off (A/B measurements)
-bool fused_bwd_enabled() {
-  static const int v = lr_env("LYC_FUSED_BWD", 1);
-  return v != 0;
-}
-
 int fork_mode() {
   static const int v = lr_env("LYC_FORK_BWD", 0);
   return v;
@@ -586,31 +547,6 @@ int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const flo
       else launch_dw2s<_Float16>(da, s2);
       if (int rc = check_launch("lokr_linear_bwd(dw2, forked)")) return rc;
       dw2_done = true;
-    }
-  }
-  if (dx && dw1 && ws && dw2s_ok && !dw2_done && fused_bwd_enabled()) {
-    // ONE launch: dx + dW1 partials and dW2 as two roles of one grid (kron_bwd_fused_kernel), then the tiny fixed-order
-    // reduction of the dW1 partials
-    KronArgs ka{};
-    ka.x = g; ka.y = dx; ka.w1 = w1; ka.w2 = w2; ka.dw1 = dw1; ka.xref = x; ka.dw1_ws = static_cast<float*>(ws);
-    ka.M = M; ka.Gin = a; ka.K = c; ka.Gout = b; ka.N = d;
-    ka.s1o = 1; ka.s1i = b; ka.s2n = 1; ka.s2k = d; ka.alpha = alpha; ka.out_f32 = (dtype & LYC_F32_ROWS) ? 1 : 0;
-    KronDw2sArgs da{};
-    da.Q = g; da.P = x; da.W = w1; da.out = dw2; da.M = M; da.G = a; da.I = c; da.J = d;
-    da.ws = b; da.wt = 1; da.os = d; da.alpha = alpha;
-    bool ok16 = false;
-    if ((dtype & 0xff) == LYC_BF16) ok16 = kron_fast_ok<__bf16>(ka) && launch_bwd_fused<__bf16>(ka, da, st);
-    else ok16 = kron_fast_ok<_Float16>(ka) && launch_bwd_fused<_Float16>(ka, da, st);
-    if (ok16) {
-      if (int rc = check_launch("lokr_linear_bwd(fused)")) return rc;
-      KronDw2sArgs ra{};
-      const int ni = kron3_pick_ni(ka);
-      ra.dw1_ws = static_cast<const float*>(ws); ra.dw1 = dw1; ra.dw1_n = a * b;
-      ra.dw1_nblk = (int)(cdiv(M, K3_RT / a) * cdiv(d, 16 * ni));
-      long r = ra.dw1_nblk / 64;
-      ra.dw1_red = (int)(r > 16 ? 16 : r < 1 ? 1 : r);
-      hipLaunchKernelGGL(kron_dw1_reduce_kernel, dim3((unsigned)ra.dw1_red), dim3(NTHREADS), 0, st, ra);
-      return check_launch("lokr_linear_bwd(dw1 reduce)");
     }
   }
   if (dx || dw1) {

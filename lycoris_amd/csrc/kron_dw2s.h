@@ -75,8 +75,11 @@ __device__ __forceinline__ void dw1_reduce_role(const KronDw2sArgs& a, int r, fl
 
 // U = 32-row steps per prefetch group: the loads of two groups (2 * U * NB * 4 x 16 bytes per lane) are in flight while a
 // group is processed -- with ~1 wave per SIMD (small problems) only instruction-level parallelism hides the HBM latency.
-// The body is a device function so that the fused backward launch (kron_bwd_fused_kernel, below) can run it as one role.
-// `b_`: index of this workgroup among the dW2 workgroups; `smem`: kron_dw2s_lds_bytes<MI, NJ>() bytes, 16-byte aligned.
+// `b_`: index of this workgroup in the launch; `smem`: kron_dw2s_lds_bytes<MI, NJ>() bytes, 16-byte aligned.
+// (A device function: round 2 ran it and kron3_body as two roles of ONE grid -- the whole LoKr backward of a layer in a
+// single launch.  Measured on the SDXL step: 19.3 ms against 17.5 ms for the two launches back to back, twice, A/B in one
+// process (profiles/r02_fused_bwd_ab.txt): the two kernels are not idle-latency-bound but share the per-CU load path, and
+// the merged kernel runs at the register count of the larger role.  Removed again; the split stays for such experiments.)
 template <typename T, int MI, int NJ, int U, bool GATHER>
 __device__ __forceinline__ void kron_dw2s_body(const KronDw2sArgs& a, char* smem, const int b_) {
   constexpr int TI = 16 * MI, TJ = 16 * NJ, NC = TI + TJ;
@@ -386,26 +389,6 @@ template <typename T, int MI, int NJ, int U, bool GATHER>
 __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[kron_dw2s_lds_bytes<MI, NJ>()];
   kron_dw2s_body<T, MI, NJ, U, GATHER>(a, smem, (int)blockIdx.x);
-}
-
-// ---- the whole LoKr backward of a plain-row layer in ONE launch ------------------------------------------------------
-// dx (+ dW1 partials) and dW2 are independent and both latency-bound at about one workgroup per CU (7.7 - 19 us each on
-// the SDXL shapes, profiles/r01_v7_bench_lokr_kernel_stats.csv): as two launches they run back to back with a kernel
-// boundary in between; as two ROLES of one grid their workgroups are resident together and fill each other's stalls.
-// (Round 1 tried the same overlap with fork / join branches inside the hipGraph: 46.7 vs 36.5 ms per step -- a fork / join
-// pair costs more than it hides.  One grid has no such cost.)  Workgroups [0, n_dw2) take the dW2 role -- they keep
-// their own XCD-aware mapping, which only depends on the block index -- the rest the dx role (tile d % nbx, d / nbx).
-// The dW1 partials of the dx role are summed by kron_dw1_reduce_kernel afterwards (fixed order).
-template <typename T, int NI, int GM, int MI, int NJ, int U>
-__global__ __launch_bounds__(NTHREADS) void kron_bwd_fused_kernel(KronArgs ka, KronDw2sArgs da, int n_dw2, int nbx) {
-  extern __shared__ __attribute__((aligned(16))) char kf_smem[];
-  const int b = (int)blockIdx.x;
-  if (b < n_dw2) {
-    kron_dw2s_body<T, MI, NJ, U, false>(da, kf_smem, b);
-    return;
-  }
-  const int d = b - n_dw2;
-  kron3_body<T, NI, true, GM>(ka, kf_smem, d % nbx, d / nbx, nbx);
 }
 
 // stand-alone reduction of the w1-gradient partials (used when the caller asks for dw1 but not dw2)
