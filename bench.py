@@ -142,9 +142,14 @@ class Inst:
             self.bias = torch.randn(O, **f32) * 0.1 if spec.get("side", "out") == "out" else None
         self.params = [torch.nn.Parameter(p) for p in ps]
 
-    def forward(self):
+    def forward(self, base=None):
+        """the adapter delta; with `base` (the frozen layer's output) base + delta, fused where the kernels can"""
         ops, s, p = self.ops, self.spec, self.params
         lin = s["kind"] == "linear"
+        if base is not None:
+            if lin and self.algo == "lokr":
+                return ops.lokr_linear(self.x, p[0], p[1], 1.0, base=base)
+            return base + self.forward()
         if self.algo == "ia3":
             chan = -1 if lin else 1
             if s.get("side", "out") == "out":  # y = base * (1 + w) - bias * w   (rebuild semantics, no GEMM)
@@ -491,19 +496,44 @@ def roofline(insts, args, dtype, dev):
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "algorithmic_flops_per_layer": int(flops / n_l)})
         return out
-    fam = {"lokr": "lokr_linear", "locon": "locon_linear", "ia3": "ia3"}[lin[0].algo]
+    fam = {"lokr": "lokr_kron3", "locon": "locon_linear", "ia3": "ia3"}[lin[0].algo]
     nbytes = b_fwd + b_bwd
-    ach = nbytes / (t_ms * 1e-3) / 1e9
+    hot = nbytes / (t_ms * 1e-3) / 1e9
     traffic, src = pmc_traffic(fam)
-    out.update({"bound": "hbm",
-                "kernel": {"lokr": "lyc::kron3_kernel (forward, backward dx + dW1) + lyc::kron_dw2s_kernel (dW2): the LoKr "
-                                   "launches of the Linear layers",
-                           "locon": "lyc::bneck_kernel (forward, backward-dx) + lyc::lowrank_tn_kernel (factor gradients)",
-                           "ia3": "lyc::chan_scale_kernel / lyc::chan_reduce_kernel"}[lin[0].algo],
-                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": src,
-                "algorithmic_bytes_per_launch": int(nbytes / (launches * n_l)),
+    out.update({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic, "traffic_source": src,
+                "hot_path_gbs": round(hot, 1), "hot_path_frac": round(hot / HBM_PEAK_GBS, 4),
                 "forward_gbs": round(b_fwd / (t_fwd * 1e-3) / 1e9, 1), "backward_gbs": round(b_bwd / (t_bwd * 1e-3) / 1e9, 1)})
+    if lin[0].algo == "lokr":
+        # the dominant KERNEL: lyc::kron3_kernel runs the forward and the backward dx (+ dW1) launch; lyc::kron_dw2s_kernel the
+        # dW2 launch, which re-reads g and x.  A third graph with only the dW2 launches separates the two families.
+        from lycoris_amd import _native as N
+        code = N.dtype_code(dtype)
+
+        def only_dw2():
+            for it, rows, g, fs, bufs in calls:
+                (a, b), (c, d) = fs[0].shape, fs[1].shape
+                N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), None, None, N.ptr(bufs[1]), None,
+                       rows.shape[0], a, b, c, d, 1.0, code, N.stream_ptr(dev))
+
+        t_dw2 = _graph_ms(only_dw2)
+        t_dx = max(t_bwd - t_dw2, 0.0)
+        b_dw2 = sum(esz * (it.spec["M"] * (it.spec["I"] + it.spec["O"])) + 4 * sum(p.numel() for p in it.params) for it in lin)
+        b_dx = b_bwd  # g + x (dW1) + dx + factors: the SURVEY 8d backward bytes belong to this launch
+        k3_ms, k3_bytes = t_fwd + t_dx, b_fwd + b_dx
+        ach = k3_bytes / (k3_ms * 1e-3) / 1e9
+        out["families_ms"] = {"kron3_forward": round(t_fwd, 3), "kron3_backward_dx_dw1": round(t_dx, 3), "kron_dw2s": round(t_dw2, 3)}
+        out.update({"kernel": "lyc::kron3_kernel (LoKr forward + backward dx / dW1 launches of the Linear layers); "
+                              "lyc::kron_dw2s_kernel (dW2, re-reads g and x) under families_ms",
+                    "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "avg_launch_us": round(k3_ms * 1e3 / (2 * n_l), 2), "launches_per_layer": 2,
+                    "algorithmic_bytes_per_launch": int(k3_bytes / (2 * n_l)),
+                    "dw2s_gbs": round(b_dw2 / (t_dw2 * 1e-3) / 1e9, 1)})
+        return out
+    out.update({"kernel": {"locon": "lyc::bneck_kernel (forward, backward-dx) + lyc::lowrank_tn_kernel (factor gradients): the three "
+                                    "launches of a LoCon Linear layer (comparable cost each)",
+                           "ia3": "lyc::chan_scale_kernel / lyc::chan_reduce_kernel"}[lin[0].algo],
+                "achieved": round(hot, 1), "frac": round(hot / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_launch": int(nbytes / (launches * n_l))})
     return out
 
 
@@ -546,7 +576,7 @@ def base_leg(insts, sync):
             torch.autograd.grad(y, [it.x], it.g)
 
     def both_pass():
-        outs = [(it.base_forward() + it.forward(), it) for it in insts]
+        outs = [(it.forward(base=it.base_forward()), it) for it in insts]
         for y, it in reversed(outs):
             torch.autograd.grad(y, [it.x], it.g)
 

@@ -193,7 +193,7 @@ int main(int argc, char** argv) {
     const int nl = nsets * 2 > 32 ? nsets * 2 : 32;
     const float t_f = bench(st, nl, 3, [&](int i) {
       const Set& q = sets[i % nsets];
-      LYC(lyc_lokr_linear_fwd(q.x, q.w1, q.w2, q.y, s.M, a, b, c, d, 1.0f, LYC_BF16, st));
+      LYC(lyc_lokr_linear_fwd(q.x, q.w1, q.w2, nullptr, q.y, s.M, a, b, c, d, 1.0f, LYC_BF16, st));
     });
     float t_b = bench(st, nl, 3, [&](int i) {
       const Set& q = sets[i % nsets];

@@ -33,9 +33,11 @@ def short(name):
 
 
 # kernel families of bench.py's roofline legs: every launch the Linear layers of one algorithm make
-FAMILIES = {
-    "lokr_linear": ("kron3_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "kron_kernel", "kron_dw2_kernel", "kron_bwd"),
-    "locon_linear": ("bneck_kernel", "lowrank_tn_kernel", "skinny_", "expand_nt"),
+FAMILIES = {  # family -> (algo whose pass is used, kernel-name substrings)
+    "lokr_kron3": ("lokr", ("kron3_kernel",)),
+    "lokr_dw2s": ("lokr", ("kron_dw2s_kernel",)),
+    "lokr_linear": ("lokr", ("kron3_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "kron_kernel", "kron_dw2_kernel")),
+    "locon_linear": ("locon", ("bneck_kernel", "lowrank_tn_kernel", "skinny_", "expand_nt")),
 }
 CAL_R, CAL_W = 2047.96, 1024.0  # bytes per counter unit, calibrated on a 1 GiB copy (profiles/r01_pmc_kbench.txt)
 
@@ -51,15 +53,17 @@ def family_json(out_path, triples):
            "source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
                      "`bench.py --algo A --pmc-pass 1 --layers linear` (benchmarks/pmc_traffic.sh); read 2048 B/unit "
                      "(the gfx950 1/2 correction of FETCH_SIZE), write 1024 B/unit, calibrated on a 1 GiB copy"}
-    for algo, fdir, wdir in triples:
-        fetch, write = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
-        keys = FAMILIES[algo + "_linear"]
+    passes = {algo: (load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")) for algo, fdir, wdir in triples}
+    for fam, (algo, keys) in FAMILIES.items():
+        if algo not in passes:
+            continue
+        fetch, write = passes[algo]
         fs = [v for k, vs in fetch.items() if any(x in k for x in keys) for v in vs]
         ws_ = [v for k, vs in write.items() if any(x in k for x in keys) for v in vs]
         if not fs or not ws_:
             continue
         n = max(len(fs), len(ws_))
-        rec["families"][algo + "_linear"] = {
+        rec["families"][fam] = {
             "launches": n, "read_bytes": sum(fs) * CAL_R, "write_bytes": sum(ws_) * CAL_W,
             "bytes_per_launch": (sum(fs) * CAL_R + sum(ws_) * CAL_W) / n,
             "kernels": sorted({short(k) for k in list(fetch) + list(write) if any(x in k for x in keys)})}

@@ -31,7 +31,7 @@ enum { LYC_F32 = 0, LYC_F16 = 1, LYC_BF16 = 2 };
 enum { LYC_F32_ROWS = 0x100 };
 enum { LYC_OK = 0, LYC_ERR_ARG = 1, LYC_ERR_UNSUPPORTED = 2, LYC_ERR_LAUNCH = 3 };
 
-#define LYC_ABI_VERSION 5
+#define LYC_ABI_VERSION 6
 int lyc_abi_version(void);
 const char* lyc_last_error(void);
 
@@ -41,11 +41,14 @@ const char* lyc_last_error(void);
  *   w1:[a,b]  w2:[c,d]  x:[M, b*d]  y:[M, a*c]
  *   y[m, p*c+q] = alpha * sum_u w1[p,u] * sum_v w2[q,v] * x[m, u*d+v]          (== x @ (kron(w1,w2)*alpha)^T)
  * bwd: dx = g @ (kron(w1,w2)*alpha);  dw1 += , dw2 +=  (gradients of sum(g*y) w.r.t. w1, w2)
+ * `base`: optional [M, a*c] output of the frozen layer (same dtype): with it y = base + delta is formed in the kernel's
+ *       epilogue (fp32 add, one rounding) -- the reference's `return base + delta` (modules/lokr.py:566) without the extra
+ *       elementwise launch and its 3 * M * O elements of traffic.  16-bit fast path only (LYC_ERR_UNSUPPORTED otherwise).
  * `ws`: optional device scratch of lyc_lokr_bwd_workspace_bytes(...) bytes (no need to clear).  With it the w1
  *       gradient is reduced from per-workgroup partials in a fixed order (deterministic, and ~10 us faster per call
  *       than the same-address fp32 atomics used when ws == NULL).                                          */
-int lyc_lokr_linear_fwd(const void* x, const float* w1, const float* w2, void* y, int64_t M, int a, int b, int c,
-                        int d, float alpha, int dtype, void* stream);
+int lyc_lokr_linear_fwd(const void* x, const float* w1, const float* w2, const void* base, void* y, int64_t M, int a, int b,
+                        int c, int d, float alpha, int dtype, void* stream);
 int64_t lyc_lokr_bwd_workspace_bytes(int64_t M, int a, int b, int c, int d, int dtype);
 int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const float* w2, void* dx, float* dw1,
                         float* dw2, void* ws, int64_t M, int a, int b, int c, int d, float alpha, int dtype,

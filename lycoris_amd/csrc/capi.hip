@@ -442,13 +442,20 @@ extern "C" {
 int lyc_abi_version(void) { return LYC_ABI_VERSION; }
 const char* lyc_last_error(void) { return g_err; }
 
-int lyc_lokr_linear_fwd(const void* x, const float* w1, const float* w2, void* y, int64_t M, int a, int b, int c,
-                        int d, float alpha, int dtype, void* stream) {
+int lyc_lokr_linear_fwd(const void* x, const float* w1, const float* w2, const void* base, void* y, int64_t M, int a, int b,
+                        int c, int d, float alpha, int dtype, void* stream) {
   if (int rc = check_kron_dims(M, a, b, c, d)) return rc;
   if (!x || !w1 || !w2 || !y) return fail(LYC_ERR_ARG, "lokr_linear_fwd: null pointer");
   if (M == 0) return LYC_OK;
   KronArgs ka{};
-  ka.x = x; ka.y = y; ka.w1 = w1; ka.w2 = w2; ka.dw1 = nullptr; ka.xref = nullptr;
+  ka.x = x; ka.y = y; ka.w1 = w1; ka.w2 = w2; ka.dw1 = nullptr; ka.xref = nullptr; ka.base = base;
+  if (base) {  // fused `y = base + delta` lives in the epilogue of the 16-bit kron3 kernel only
+    ka.M = M; ka.Gin = b; ka.K = d; ka.Gout = a; ka.N = c;
+    const bool fast = ((dtype & 0xff) == LYC_BF16 && kron_fast_ok<__bf16>(ka)) || ((dtype & 0xff) == LYC_F16 && kron_fast_ok<_Float16>(ka));
+    if (!fast)
+      return fail(LYC_ERR_UNSUPPORTED, "lokr_linear_fwd: the fused base + delta epilogue needs the 16-bit fast path "
+                                       "(a == b dividing 16, d %% 8 == 0, aligned x); add `base` on the caller's side");
+  }
   ka.M = M; ka.Gin = b; ka.K = d; ka.Gout = a; ka.N = c;
   ka.s1o = b; ka.s1i = 1; ka.s2n = d; ka.s2k = 1; ka.alpha = alpha;
   DISPATCH_DTYPE(dtype, launch_kron<T>(ka, (hipStream_t)stream));
@@ -958,12 +965,15 @@ int lyc_chan_reduce(const void* a, const void* b, const float* bias, float* dw, 
   ca.mult = mult;
   dim3 grid;
   if (inner == 1) {
-    const long ct = cdiv(C, 64);
-    long slabs = cdiv(1024, ct);
+    const int vec = (dtype & 0xff) == LYC_F32 ? 4 : 8;  // elements per 16-byte load
+    const bool vec_ok = (C % vec) == 0 && (reinterpret_cast<uintptr_t>(a) & 15u) == 0 && (reinterpret_cast<uintptr_t>(b) & 15u) == 0;
+    const long ct = cdiv(C, vec_ok ? 64 * vec : 64);
+    long slabs = cdiv(vec_ok ? 768 : 1024, ct);
     const long max_slabs = cdiv(outer, 16);
     if (slabs > max_slabs) slabs = max_slabs;
     if (slabs < 1) slabs = 1;
     grid = dim3((unsigned)ct, (unsigned)slabs);
+    ca.vec = vec_ok ? 1 : 0;
   } else {
     if (outer > 65535) return fail(LYC_ERR_UNSUPPORTED, "chan_reduce: outer=%ld too large for the conv layout", (long)outer);
     grid = dim3((unsigned)C, (unsigned)outer);

@@ -23,6 +23,7 @@ struct ChanArgs {
   long C;
   long inner;
   float s0, mult;
+  int vec;             // chan_reduce, inner == 1: the host verified C % VEC == 0 and 16-byte alignment (vector layout)
 };
 
 // out[o, c, i] = a[o, c, i] * (s0 + w[c] * mult) - bias[c] * w[c] * mult
@@ -35,27 +36,41 @@ __global__ __launch_bounds__(NTHREADS) void chan_scale_kernel(ChanArgs a) {
   const bool vec_ok = ((a.inner == 1 ? a.C : a.inner) % VEC == 0) && vec_aligned<T>(in, VEC) && vec_aligned<T>(out, VEC);
   const long stride = (long)gridDim.x * NTHREADS;
   if (vec_ok) {
+    // UNR independent 16-byte loads per lane in flight before the first use: at 5 MB per launch the kernel lives on
+    // memory-level parallelism, not on occupancy (a launch is one or two rounds of workgroups)
+    constexpr int UNR = 4;
     const long nvec = total / VEC;
-    for (long v = (long)blockIdx.x * NTHREADS + threadIdx.x; v < nvec; v += stride) {
-      const long e0 = v * VEC;
-      T iv[VEC], ov[VEC];
-      *reinterpret_cast<u32x4*>(iv) = *reinterpret_cast<const u32x4*>(in + e0);
-      if (a.inner == 1) {
-        const long c0 = e0 % a.C;
+    for (long v0 = (long)blockIdx.x * NTHREADS + threadIdx.x; v0 < nvec; v0 += stride * UNR) {
+      u32x4 raw[UNR];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          const float wm = a.w[c0 + e] * a.mult;
-          const float b = a.bias ? a.bias[c0 + e] : 0.f;
-          ov[e] = TT<T>::from_f(TT<T>::to_f(iv[e]) * (a.s0 + wm) - b * wm);
-        }
-      } else {
-        const long c = (e0 / a.inner) % a.C;
-        const float wm = a.w[c] * a.mult;
-        const float b = a.bias ? a.bias[c] : 0.f;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) ov[e] = TT<T>::from_f(TT<T>::to_f(iv[e]) * (a.s0 + wm) - b * wm);
+      for (int u = 0; u < UNR; ++u) {
+        const long v = v0 + u * stride;
+        raw[u] = *reinterpret_cast<const u32x4*>(in + (v < nvec ? v : v0) * VEC);
       }
-      *reinterpret_cast<u32x4*>(out + e0) = *reinterpret_cast<u32x4*>(ov);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long v = v0 + u * stride;
+        if (v >= nvec) break;
+        const long e0 = v * VEC;
+        T iv[VEC], ov[VEC];
+        *reinterpret_cast<u32x4*>(iv) = raw[u];
+        if (a.inner == 1) {
+          const long c0 = e0 % a.C;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float wm = a.w[c0 + e] * a.mult;
+            const float b = a.bias ? a.bias[c0 + e] : 0.f;
+            ov[e] = TT<T>::from_f(TT<T>::to_f(iv[e]) * (a.s0 + wm) - b * wm);
+          }
+        } else {
+          const long c = (e0 / a.inner) % a.C;
+          const float wm = a.w[c] * a.mult;
+          const float b = a.bias ? a.bias[c] : 0.f;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) ov[e] = TT<T>::from_f(TT<T>::to_f(iv[e]) * (a.s0 + wm) - b * wm);
+        }
+        *reinterpret_cast<u32x4*>(out + e0) = *reinterpret_cast<u32x4*>(ov);
+      }
     }
   } else {
     for (long e = (long)blockIdx.x * NTHREADS + threadIdx.x; e < total; e += stride) {
@@ -77,7 +92,48 @@ __global__ __launch_bounds__(NTHREADS) void chan_reduce_kernel(ChanArgs a) {
   const T* B = static_cast<const T*>(a.b_in);
   __shared__ float red[NTHREADS];
   const int tid = threadIdx.x;
-  if (a.inner == 1) {
+  if (a.inner == 1 && a.vec) {
+    // vector layout (host: C % VEC == 0, aligned): a lane owns VEC consecutive channels (16-byte loads), a wave 64 * VEC,
+    // the 4 waves take interleaved rows of the slab; LDS sum over the waves, one atomic per channel.
+    constexpr int VEC = TT<T>::VEC;
+    __shared__ float redv[NWAVES][64 * VEC];
+    const int lane = tid & 63, wave = tid >> 6;
+    const long c0 = ((long)blockIdx.x * 64 + lane) * VEC;
+    const long rows_per = (a.outer + gridDim.y - 1) / gridDim.y;
+    const long rbeg = (long)blockIdx.y * rows_per;
+    long rend = rbeg + rows_per;
+    if (rend > a.outer) rend = a.outer;
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+    if (c0 < a.C) {
+      float bv[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) bv[e] = a.bias ? a.bias[c0 + e] : 0.f;
+      for (long r = rbeg + wave; r < rend; r += 2 * NWAVES) {  // two rows per iteration: four loads in flight
+        const bool two = r + NWAVES < rend;
+        T av[2][VEC], gv[2][VEC];
+        *reinterpret_cast<u32x4*>(av[0]) = *reinterpret_cast<const u32x4*>(A + r * a.C + c0);
+        *reinterpret_cast<u32x4*>(gv[0]) = *reinterpret_cast<const u32x4*>(B + r * a.C + c0);
+        *reinterpret_cast<u32x4*>(av[1]) = *reinterpret_cast<const u32x4*>(A + (two ? r + NWAVES : r) * a.C + c0);
+        *reinterpret_cast<u32x4*>(gv[1]) = *reinterpret_cast<const u32x4*>(B + (two ? r + NWAVES : r) * a.C + c0);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          s[e] = fmaf(TT<T>::to_f(av[0][e]), TT<T>::to_f(gv[0][e]) - bv[e], s[e]);
+          if (two) s[e] = fmaf(TT<T>::to_f(av[1][e]), TT<T>::to_f(gv[1][e]) - bv[e], s[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) redv[wave][lane * VEC + e] = s[e];
+    __syncthreads();
+    for (int i = tid; i < 64 * VEC; i += NTHREADS) {
+      const long c = (long)blockIdx.x * 64 * VEC + i;
+      if (c < a.C)
+        __hip_atomic_fetch_add(a.dw + c, a.mult * (redv[0][i] + redv[1][i] + redv[2][i] + redv[3][i]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if (a.inner == 1) {
     const long c = (long)blockIdx.x * 64 + (tid & 63);
     const long rows_per = (a.outer + gridDim.y - 1) / gridDim.y;
     const long rbeg = (long)blockIdx.y * rows_per;

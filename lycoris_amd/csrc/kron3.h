@@ -515,10 +515,16 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
 
   // backward: the xref fragments of the w1 gradient (B[k = n][j = row li], 8 bytes per (mi, ni)) are fetched while stage 1
   // runs instead of inside the epilogue (they were ~1 us of exposed latency there); masked at use
-  // (plain-row kernels only: the gather variants have no registers to spare -- 2 -> 1 waves per SIMD with it)
-  constexpr bool XPRE = WITH_DW1 && (GM == 0 || GM == 3);
+  // (plain-row kernels only: the gather variants have no registers to spare -- 2 -> 1 waves per SIMD with it).
+  // forward: the same registers prefetch the frozen layer's output when the caller wants `base + delta` fused (a.base);
+  // without it the loads still go out (one broadcast address, ignored): a conditional load would make the registers a PHI
+  // of loaded / undefined, which the compiler resolves with a vmcnt(0) in front of stage 1 (see k3_load_w2).
+  constexpr bool XPRE = GM == 0 || GM == 3;
   u32x2 xrv[MI][NI];
-  const bool xr_vec = WITH_DW1 && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.xref) & 7u) == 0);
+  const T* pre = WITH_DW1 ? static_cast<const T*>(a.xref) : static_cast<const T*>(a.base);
+  const bool have_pre = pre != nullptr;
+  if (!have_pre) pre = static_cast<const T*>(a.x);
+  const bool xr_vec = have_pre && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(pre) & 7u) == 0);
   auto prefetch_xref = [&]() {
     if constexpr (XPRE) {
 #pragma unroll
@@ -529,7 +535,7 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
         for (int ni = 0; ni < NI; ++ni) {
           const long gn = n0 + 16 * ni + 4 * g;
           const bool ok = xr_vec && R < rows_end && gn < N;
-          xrv[mi][ni] = *reinterpret_cast<const u32x2*>(static_cast<const T*>(a.xref) + (ok ? rofs + gn : 0));
+          xrv[mi][ni] = *reinterpret_cast<const u32x2*>(pre + (ok ? rofs + gn : 0));
         }
       }
     }
@@ -586,8 +592,24 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
         } else {
           T* dst = static_cast<T*>(a.y) + rofs + gn;
           T o[4];
+          float bb[4] = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (!WITH_DW1) {
+            if (a.base != nullptr) {  // fused `base + delta`: fp32 add, one rounding
+              const T* bp = static_cast<const T*>(a.base) + rofs + gn;
+              if (XPRE && xr_vec) {  // prefetched; gn + 4 <= N here (N % 4 == 0)
+                T bt[4];
+                *reinterpret_cast<u32x2*>(bt) = xrv[mi][ni];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = TT<T>::from_f(a.alpha * yv[e]);
+                for (int e = 0; e < 4; ++e) bb[e] = TT<T>::to_f(bt[e]);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (gn + e < N) bb[e] = TT<T>::to_f(bp[e]);
+              }
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = TT<T>::from_f(a.alpha * yv[e] + bb[e]);
           if (y_vec && gn + 4 <= N) {
             *reinterpret_cast<u32x2*>(dst) = *reinterpret_cast<u32x2*>(o);
           } else {

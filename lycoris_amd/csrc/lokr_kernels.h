@@ -43,6 +43,7 @@ struct KronArgs {
   float* dw1;        // optional, same addressing as w1 (accumulated atomically)
   float* dw1_ws;     // optional (kron3 only): per-workgroup dw1 partials [grid.y * grid.x][G * G] instead of atomics
   const void* xref;  // optional [M, Gout * N] (needed iff dw1 != nullptr)
+  const void* base;  // optional [M, Gout * N] (kron3 plain-row forward only): y = base + alpha * (...), rounded once
   long M;
   int Gin, K, Gout, N;
   long s1o, s1i, s2n, s2k;

@@ -129,7 +129,7 @@ Tensor amp(const Tensor& x) {
 // =====================================================================================================================
 // LoKr on nn.Linear
 // =====================================================================================================================
-Tensor lokr_linear_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha) {
+Tensor lokr_linear_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, const c10::optional<Tensor>& base) {
   require_device(x, "input");
   const c10::DeviceGuard guard(x.device());
   TORCH_CHECK(w1.dim() == 2 && w2.dim() == 2, "lokr_linear: w1 [a, b], w2 [c, d]");
@@ -139,7 +139,13 @@ Tensor lokr_linear_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2, doub
   auto oshape = x.sizes().vec();
   oshape.back() = a * c;
   Tensor y = at::empty({rows.size(0), a * c}, x.options());
-  check_rc(lyc_lokr_linear_fwd(cptr(rows), cfp(f1), cfp(f2), mptr(y), rows.size(0), (int)a, (int)b, (int)c, (int)d,
+  Tensor bs;
+  if (base.has_value() && base->defined()) {
+    TORCH_CHECK(base->scalar_type() == x.scalar_type() && base->numel() == y.numel() && base->is_contiguous(),
+                "lokr_linear: `base` must be the frozen layer's contiguous output in the activation dtype");
+    bs = *base;
+  }
+  check_rc(lyc_lokr_linear_fwd(cptr(rows), cfp(f1), cfp(f2), cptr(bs), mptr(y), rows.size(0), (int)a, (int)b, (int)c, (int)d,
                                (float)alpha, dtype_code(x.scalar_type()), stream_of(x)), "lyc_lokr_linear_fwd");
   return y.view(oshape);
 }
@@ -173,13 +179,15 @@ std::tuple<Tensor, Tensor, Tensor> lokr_linear_bwd(const Tensor& g, const Tensor
 }
 
 struct LokrLinearFn : public torch::autograd::Function<LokrLinearFn> {
-  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha) {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha,
+                        const c10::optional<Tensor>& base) {
     at::AutoDispatchBelowADInplaceOrView guard;
     static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::lokr_linear", "")
-                         .typed<Tensor(const Tensor&, const Tensor&, const Tensor&, double)>();
-    Tensor y = op.call(x, w1, w2, alpha);
+                         .typed<Tensor(const Tensor&, const Tensor&, const Tensor&, double, const c10::optional<Tensor>&)>();
+    Tensor y = op.call(x, w1, w2, alpha, base);
     ctx->save_for_backward({x, w1, w2});
     ctx->saved_data["alpha"] = alpha;
+    ctx->saved_data["has_base"] = base.has_value() && base->defined();
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
@@ -187,25 +195,27 @@ struct LokrLinearFn : public torch::autograd::Function<LokrLinearFn> {
     const Tensor &x = saved[0], &w1 = saved[1], &w2 = saved[2];
     const double alpha = ctx->saved_data["alpha"].toDouble();
     const bool nx = ctx->needs_input_grad(0), n1 = ctx->needs_input_grad(1), n2 = ctx->needs_input_grad(2);
+    // needs_input_grad indexes the VARIABLE inputs (x, w1, w2[, base]); the float `alpha` has no edge
+    const bool nb = ctx->saved_data["has_base"].toBool() && ctx->needs_input_grad(3);
     Tensor g = grads[0];
     if (eager_cuda(g) && eager_cuda(x)) {  // eager: accumulate straight into .grad where possible
       GradTarget t1 = grad_target(w1, n1 || accum_wanted(w1)), t2 = grad_target(w2, n2 || accum_wanted(w2));
       Tensor dx = lokr_linear_bwd_into(g, x, w1, w2, alpha, nx, t1.buf, t2.buf);
-      return {dx, finish_grad(w1, t1), finish_grad(w2, t2), Tensor()};
+      return {dx, finish_grad(w1, t1), finish_grad(w2, t2), Tensor(), nb ? g : Tensor()};  // d(base + delta)/d base = 1
     }
     static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_lokr_linear_backward", "")
                          .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&,
                                                                    double, bool, bool, bool)>();
     auto [dx, d1, d2] = op.call(g, x, w1, w2, alpha, nx, n1, n2);
-    return {nx ? dx : Tensor(), n1 ? d1 : Tensor(), n2 ? d2 : Tensor(), Tensor()};
+    return {nx ? dx : Tensor(), n1 ? d1 : Tensor(), n2 ? d2 : Tensor(), Tensor(), nb ? g : Tensor()};
   }
 };
 
-Tensor lokr_linear_autograd(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha) {
-  return LokrLinearFn::apply(amp(x), w1, w2, alpha);
+Tensor lokr_linear_autograd(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, const c10::optional<Tensor>& base) {
+  return LokrLinearFn::apply(amp(x), w1, w2, alpha, base);
 }
 
-Tensor lokr_linear_meta(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha) {
+Tensor lokr_linear_meta(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, const c10::optional<Tensor>& base) {
   auto oshape = x.sym_sizes().vec();
   oshape.back() = w1.sym_size(0) * w2.sym_size(0);
   return x.new_empty_symint(oshape);
@@ -726,7 +736,7 @@ Tensor locon_conv2d_meta(const Tensor& x, const Tensor& down, const Tensor& up, 
 
 TORCH_LIBRARY(lycoris_amd, m) {
   // public ops: what lycoris_amd.ops / the modules call (autograd-aware)
-  m.def("lokr_linear(Tensor x, Tensor w1, Tensor w2, float alpha) -> Tensor");
+  m.def("lokr_linear(Tensor x, Tensor w1, Tensor w2, float alpha, Tensor? base=None) -> Tensor");
   m.def("locon_linear(Tensor x, Tensor down, Tensor up, float alpha) -> Tensor");
   m.def("loha_linear(Tensor x, Tensor w1a, Tensor w1b, Tensor w2a, Tensor w2b, float alpha) -> Tensor");
   m.def("chan_affine(Tensor a, Tensor w, Tensor? bias, float s0, float mult, int chan_dim) -> Tensor");

@@ -388,6 +388,11 @@ class LycorisBaseModule(nn.Module):
         if getattr(self, "wd", False):
             return self._forward_dora(x, *args, **kwargs)
         base = self.org_forward(x, *args, **kwargs)
+        plain = not (self.training and (self.rank_dropout or (self.bypass_mode and self.dropout)))
+        if plain:
+            fused = self._forward_fused(x, base)  # `base + delta` formed in the adapter kernel's epilogue, where it can be
+            if fused is not None:
+                return fused
         delta = self.bypass_forward_diff(x, scale=self.multiplier)
         if self.rank_dropout and self.training:
             from .. import ops
@@ -396,6 +401,11 @@ class LycorisBaseModule(nn.Module):
         if self.bypass_mode and self.training and self.name in ("locon", "lora"):
             delta = self.drop(delta)
         return base + delta
+
+    def _forward_fused(self, x, base):
+        """Algorithms whose kernels can add the frozen layer's output in their epilogue return `base + delta` here
+        (modules/lokr.py:566 `return base + delta` without the separate elementwise pass); None = not available."""
+        return None
 
     # ---- helpers for subclasses --------------------------------------------------------------------------------
     def _conv_geometry(self):

@@ -222,6 +222,14 @@ class LokrModule(LycorisBaseModule):
         return scaled, orig_norm * ratio.to(orig_norm.device)
 
     # ---- hot path --------------------------------------------------------------------------------------------------
+    def _forward_fused(self, x, base):
+        if self.module_type != "linear":
+            return None
+        w1, w2 = self._gate(self._w1_full()), self._w2_full()
+        if not ops.lokr_linear_fusable(x, w1, w2, base):
+            return None
+        return ops.lokr_linear(x, w1, w2, self.scale * self.multiplier, base=base)
+
     def bypass_forward_diff(self, h, scale=1):
         """delta = (w1 (x) w2) h * alpha/r * scalar * scale, Kronecker-factored.
 

@@ -118,7 +118,7 @@ class _LokrCore:
     def fwd(rows, fs, alpha):
         (a, b), (c, d) = fs[0].shape, fs[1].shape
         y = torch.empty((rows.shape[0], a * c), dtype=rows.dtype, device=rows.device)
-        N.call("lyc_lokr_linear_fwd", N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(y), rows.shape[0], a, b, c, d,
+        N.call("lyc_lokr_linear_fwd", N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), None, N.ptr(y), rows.shape[0], a, b, c, d,
                alpha, N.dtype_code(rows.dtype), N.stream_ptr(rows.device))
         return y, ()
 
@@ -560,11 +560,24 @@ class _ChanAffine(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------------------
 # public functional entry points
 # ---------------------------------------------------------------------------------------------------------------
-def lokr_linear(x, w1, w2, alpha=1.0):
-    """w1:[a,b]  w2:[c,d]  x:[..., b*d] -> [..., a*c]"""
+def lokr_linear_fusable(x, w1, w2, base):
+    """can `base + delta` be formed in the kernel's epilogue?  (the 16-bit fast path of kron3_kernel, same dtype / shape)"""
+    a, b = w1.shape
+    return (base is not None and base.dtype in (torch.bfloat16, torch.float16) and base.is_contiguous()
+            and (x.dtype == base.dtype or (x.dtype == torch.float32 and torch.is_autocast_enabled("cuda")
+                                           and torch.get_autocast_dtype("cuda") == base.dtype))
+            and a == b and 16 % a == 0 and w2.shape[1] % 8 == 0 and w2.shape[0] % 4 == 0
+            and tuple(base.shape) == (*x.shape[:-1], a * w2.shape[0]) and _DISPATCH["mode"] == "cpp")
+
+
+def lokr_linear(x, w1, w2, alpha=1.0, base=None):
+    """w1:[a,b]  w2:[c,d]  x:[..., b*d] -> [..., a*c];  with `base` (the frozen layer's output): base + delta, fused into the
+    kernel's epilogue when lokr_linear_fusable(...), a separate add otherwise"""
     N.require_device(x, "input")
+    if base is not None and not lokr_linear_fusable(x, w1, w2, base):
+        return base + lokr_linear(x, w1, w2, alpha)
     if _cpp():
-        return torch.ops.lycoris_amd.lokr_linear(x, w1, w2, float(alpha))
+        return torch.ops.lycoris_amd.lokr_linear(x, w1, w2, float(alpha), base)
     return _AdapterLinear.apply(_LokrCore, alpha, _amp(x), w1, w2)
 
 

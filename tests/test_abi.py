@@ -46,7 +46,7 @@ def test_argument_errors_are_reported_not_crashed():
     """Argument checks run before any launch, so they work on the CPU-only build box."""
     from lycoris_amd import _native as N
     with pytest.raises(RuntimeError, match="128x128"):
-        N.call("lyc_lokr_linear_fwd", None, None, None, None, 4, 200, 8, 4, 4, 1.0, N.LYC_BF16, None)
+        N.call("lyc_lokr_linear_fwd", None, None, None, None, None, 4, 200, 8, 4, 4, 1.0, N.LYC_BF16, None)
     with pytest.raises(RuntimeError, match="null pointer"):
         N.call("lyc_locon_linear_fwd", None, None, None, None, None, 4, 8, 8, 2, 1.0, N.LYC_BF16, None)
     with pytest.raises(RuntimeError, match="bad dims"):
@@ -74,6 +74,10 @@ def test_torch_custom_ops_are_registered_with_meta_kernels():
     assert y.shape == (3, 5, 128) and y.dtype == torch.bfloat16
     gx, g1, g2 = torch.autograd.grad(y, [x, w1, w2], torch.empty_like(y))
     assert gx.shape == x.shape and g1.shape == w1.shape and g2.shape == w2.shape
+    base = torch.empty(3, 5, 128, dtype=torch.bfloat16, requires_grad=True, **m)   # fused `base + delta` form
+    yb = ns.lokr_linear(x, w1, w2, 1.0, base)
+    gb, g1b = torch.autograd.grad(yb, [base, w1], torch.empty_like(yb))
+    assert yb.shape == base.shape and gb.shape == base.shape and g1b.shape == w1.shape
     down, up = torch.empty(4, 64, **m), torch.empty(32, 4, **m)
     y, t = ns._locon_linear_forward(x, down, up, 1.0)
     assert y.shape == (3, 5, 32) and t.shape == (15, 4) and t.dtype == torch.float32

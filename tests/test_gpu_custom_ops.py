@@ -122,3 +122,62 @@ def test_adapted_linear_layer_under_torch_compile(algo):
     mod.restore()
     for i, (u, v) in enumerate(zip(got, eager)):
         assert torch.allclose(u.float(), v.float(), rtol=2e-2 if i < 2 else 1e-3, atol=1e-3), (algo, i)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(64, 8, 32, 32), (300, 8, 160, 160), (77, 8, 160, 256), (33, 4, 20, 24), (1024, 8, 1280, 160)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_lokr_fused_base_plus_delta(shape, dtype):
+    """y = base + delta in the kron3 epilogue (fp32 add, ONE rounding) vs the oracle; gradients: d base = g, the rest as
+    without the fusion.  (33, 4, 20, 24): c % 4 == 0 but ragged tiles; the module-level use is LokrModule.forward."""
+    import numpy as np
+    import oracle
+    from gpu_util import TOL, check, err, rnd
+    from lycoris_amd import ops
+    M, G, c, d = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    x, x64 = rnd((M, G * d), dtype, gen)
+    base, b64 = rnd((M, G * c), dtype, gen)
+    g, g64 = rnd((M, G * c), dtype, gen, 1.0 / np.sqrt(G * c))
+    w1, n1 = rnd((G, G), torch.float32, gen, 0.3)
+    w2, n2 = rnd((c, d), torch.float32, gen, 0.1)
+    for t in (x, base, w1, w2):
+        t.requires_grad_(True)
+    assert ops.lokr_linear_fusable(x, w1, w2, base)
+    y = ops.lokr_linear(x, w1, w2, 0.75, base=base)
+    dx, db, dw1, dw2 = torch.autograd.grad(y, [x, base, w1, w2], g)
+    y_ref = b64 + oracle.lokr.forward(x64, w1=n1, w2=n2, scale=0.75)
+    gr = oracle.lokr.backward(x64, g64, w1=n1, w2=n2, scale=0.75)
+    assert torch.equal(db, g)
+    # unfused: round(base + round(delta)); fused: round(base + delta) -- the fused value is the closer one to the oracle
+    unfused = (base + ops.lokr_linear(x, w1, w2, 0.75)).detach()
+    e_f, e_u = err(y, y_ref, dtype), err(unfused, y_ref, dtype)
+    assert e_f <= e_u * 1.05 + 1e-6, (e_f, e_u)
+    check(f"lokr_fused_base[{shape},{dtype}]",
+          {"y": e_f, "dx": err(dx, gr["dx"], dtype), "dw1": err(dw1, gr["w1"]), "dw2": err(dw2, gr["w2"])},
+          {"y": TOL["store_out"][dtype], "dx": TOL["store_out"][dtype], "dw1": TOL["f32_out"][dtype], "dw2": TOL["f32_out"][dtype]})
+
+
+def test_lokr_module_forward_uses_the_fused_epilogue():
+    from lycoris_amd import ops
+    from lycoris_amd.modules import LokrModule
+    torch.manual_seed(1)
+    layer = nn.Linear(64, 128).to(DEV, torch.bfloat16).requires_grad_(False)
+    mod = LokrModule("m", layer, 0.7, lora_dim=100000, alpha=1, factor=8).to(DEV)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(torch.randn_like(p) * 0.2)
+    x = torch.randn(5, 7, 64, device=DEV, dtype=torch.bfloat16)
+    base = layer(x)
+    want = base.float() + mod.bypass_forward_diff(x, scale=mod.multiplier).float()
+    calls = []
+    orig = ops.lokr_linear
+    ops.lokr_linear = lambda *a, **k: (calls.append(k.get("base") is not None), orig(*a, **k))[1]
+    try:
+        mod.apply_to()
+        out = layer(x)
+        mod.restore()
+    finally:
+        ops.lokr_linear = orig
+    assert calls == [True]  # one call, with base
+    assert torch.allclose(out.float(), want, rtol=2e-2, atol=2e-2)
