@@ -59,29 +59,30 @@ bool kron_fast_ok(const KronArgs& ka) {
   }
 }
 
-// development override of the tile heuristics: LYC_K3_NI = 2 | 4
-int k3_ni_override() {
-  static const int v = [] { const char* e = getenv("LYC_K3_NI"); return e ? atoi(e) : 0; }();
-  return v;
-}
-
-template <typename T, int NI, bool DW1, int GATHER>
+template <typename T, int NI, bool DW1, int GATHER, bool BASE = false>
 void launch_kron3_inst2(const KronArgs& ka, dim3 grid, hipStream_t st) {
   const long nseg = GATHER == 2 ? cdiv((long)ka.gat.taps * ka.K, kron3_kc(NI))
                                 : (ka.gat.mode ? ka.gat.taps : 1) * cdiv(ka.K, kron3_kc(NI));
   const int xs = GATHER == 3 ? kron3_xs_bytes() : 0;  // per-wave x tiles behind the w2 tiles
   const int lds = kron3_lds_bytes(NI, nseg > 1 ? 2 : 1) + xs;
   if (lds > 64 * 1024) {  // more than the default dynamic-LDS window: opt in once per instantiation
-    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&kron3_kernel<T, NI, DW1, GATHER>),
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&kron3_kernel<T, NI, DW1, GATHER, BASE>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kron3_lds_bytes(NI, 2) + xs);
     (void)once;
   }
-  hipLaunchKernelGGL((kron3_kernel<T, NI, DW1, GATHER>), grid, dim3(NTHREADS), lds, st, ka);
+  hipLaunchKernelGGL((kron3_kernel<T, NI, DW1, GATHER, BASE>), grid, dim3(NTHREADS), lds, st, ka);
 }
 
 template <typename T, int NI, bool DW1>
 void launch_kron3_inst(const KronArgs& ka, dim3 grid, hipStream_t st) {
-  static const int use_xs = [] { const char* e = getenv("LYC_K3_XS"); return e ? atoi(e) : 2; }();
+  constexpr int use_xs = 2;  // 0 = never, 1 = only the launches without dW1, 2 = every plain-row launch (measured best)
+  if constexpr (!DW1) {
+    if (ka.base != nullptr && !ka.gat.mode) {  // forward with the fused `base + delta` epilogue (plain rows only)
+      if (use_xs && (ka.K % 32) == 0) launch_kron3_inst2<T, NI, false, 3, true>(ka, grid, st);
+      else launch_kron3_inst2<T, NI, false, 0, true>(ka, grid, st);
+      return;
+    }
+  }
   if (ka.gat.mode && ka.gat.flat) launch_kron3_inst2<T, NI, DW1, 2>(ka, grid, st);
   else if (ka.gat.mode) launch_kron3_inst2<T, NI, DW1, 1>(ka, grid, st);
   // x through the per-wave LDS stage (quad-coalesced loads): -3 % on the forward launches, -2 % on the backward ones
@@ -93,7 +94,6 @@ void launch_kron3_inst(const KronArgs& ka, dim3 grid, hipStream_t st) {
 // 64-column tiles halve the x re-reads and the per-column w2 conversions; 32-column tiles double the workgroup count.
 // Small problems (fewer 64-wide tiles than ~1.5 per CU) are latency-bound and take the narrow tile.
 inline int kron3_pick_ni(const KronArgs& ka) {
-  if (int o = k3_ni_override()) return o;
   const long mt = cdiv(ka.M, K3_RT / ka.Gin);
   return (mt * cdiv(ka.N, 64) >= 384 && ka.N > 32) ? 4 : 2;
 }
@@ -141,16 +141,10 @@ void launch_dw2s_inst(KronDw2sArgs da, long tiles_i, long tiles_j, hipStream_t s
     hipLaunchKernelGGL((kron_dw2s_kernel<T, MI, NJ, U, false>), grid, dim3(NTHREADS), 0, st, da);
 }
 
-int dw2s_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 // fills rows_per_block / nsplit / dw1_red / tiles of `da`; returns true for the 64 x 64 tile, false for 32 x 32
 bool plan_dw2s(KronDw2sArgs& da) {
-  static const int target_blocks = dw2s_env("LYC_DW2_BLOCKS", 512);       // development overrides
-  static const int atomic_budget = dw2s_env("LYC_DW2_ATOMICS", 620000);   // fp32 atomics per launch (~300 / ns)
-  static const int force_big = dw2s_env("LYC_DW2_BIG", -1);
+  constexpr int target_blocks = 512;       // one resident round: 2 workgroups per CU
+  constexpr int atomic_budget = 620000;    // fp32 atomics per launch (~300 / ns)
   const long rows_total = da.M * da.G;
   auto plan = [&](int mi, int nj, long& tiles, long& split) {
     tiles = cdiv(da.I, 16 * mi) * cdiv(da.J, 16 * nj);
@@ -170,7 +164,6 @@ bool plan_dw2s(KronDw2sArgs& da) {
   // the padding of I, J to multiples of 64 does not waste more than half of the tile.
   const double eff44 = (double)da.I * da.J / ((double)round_up(da.I, 64) * round_up(da.J, 64));
   bool big = rows_total >= 16384 && eff44 >= 0.5;
-  if (force_big >= 0) big = force_big != 0;
   long split = big ? s44 : s22;
   const long tiles = big ? t44 : t22;
   while (split > 1 && tiles * split > target_blocks) --split;  // one resident round: 2 workgroups per CU
@@ -275,11 +268,6 @@ void launch_skinny_tn(SkinnyArgs sa, hipStream_t st) {
 }
 // ------------------------------------------------------------------------------------------------
 // rank-r (LoCon) fast path: lowrank.h
-int lr_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 bool bneck_ok(const BneckArgs& b, int dtype) {
   const int dt = dtype & 0xff;
   if (dt != LYC_BF16 && dt != LYC_F16) return false;
@@ -291,13 +279,11 @@ void launch_bneck_v(BneckArgs b, bool vec, hipStream_t st) {
   // few row tiles (M = 1024 gives 64): also split the output columns over gridDim.y so that every CU gets a share of
   // the expand stage; each slice repeats the reduce stage (its operands come from L2).  Measured best on the SDXL shapes
   // (benchmarks/kt_lowrank.sh): as many slices as keep the grid within one round of 256 workgroups, at most 8.
-  static const int force_ns = lr_env("LYC_BN_NS", 0);
   const long rows = cdiv(b.M, 16 * MI);
   long ns = b.out != nullptr ? 256 / rows : 1;
   if (ns > cdiv(b.N2, 16 * NW)) ns = cdiv(b.N2, 16 * NW);
   if (ns > 8) ns = 8;
   if (ns < 1) ns = 1;
-  if (force_ns) ns = force_ns;
   b.nsplit = (int)ns;
   const dim3 grid((unsigned)rows, (unsigned)ns);
   if constexpr (RT == 1) {
@@ -307,8 +293,7 @@ void launch_bneck_v(BneckArgs b, bool vec, hipStream_t st) {
     }
   }
   if constexpr (NW == 4 && RT <= 2 && MI * RT <= 2) {  // coalesced operand loads through the per-wave LDS stage (<= 64 KiB)
-    static const int use_stg = lr_env("LYC_BN_STG", 1);
-    if (vec && use_stg) {
+    if (vec) {
       hipLaunchKernelGGL((bneck_kernel<T, NW, MI, RT, true, true, false, true>), grid, dim3(NW * 64), 0, st, b);
       return;
     }
@@ -321,13 +306,10 @@ void launch_bneck_v(BneckArgs b, bool vec, hipStream_t st) {
 
 template <typename T, int RT>
 void launch_bneck_rt(const BneckArgs& b, hipStream_t st) {
-  static const int force_nw = lr_env("LYC_BN_NW", 0), force_mi = lr_env("LYC_BN_MI", 0);
   const bool vec = b.f1k == 1 && (b.f1n % 4) == 0 && (reinterpret_cast<uintptr_t>(b.F1) & 15u) == 0 && b.f2k == 1 &&
                    (b.f2n % 4) == 0 && (b.R % 4) == 0 && (reinterpret_cast<uintptr_t>(b.F2) & 15u) == 0;
   int mi = b.M >= 8192 ? 2 : 1;
-  if (force_mi) mi = force_mi;
   int nw = (mi == 1 && b.K1 >= 8192) ? 8 : 4;  // 8 waves only pay when the reduce stage is very long
-  if (force_nw && mi == 1) nw = force_nw;
   if (mi == 2)
     launch_bneck_v<T, 4, 2, RT>(b, vec, st);
   else if (nw == 8)
@@ -385,8 +367,7 @@ void launch_tn_rt(LowrankTnArgs& a, int cv, hipStream_t st) {
 
 // both factor gradients of a rank-r layer in one launch; false = shapes the fast kernel does not take
 bool launch_lowrank_tn(LowrankTnArgs a, int dtype, hipStream_t st) {
-  static const int atomic_budget = lr_env("LYC_TN_ATOMICS", 800000), wave_target = lr_env("LYC_TN_WAVES", 1400);
-  static const int force_cv = lr_env("LYC_TN_CV", 0), force_split = lr_env("LYC_TN_SPLIT", 0);
+  constexpr int atomic_budget = 800000, wave_target = 1400;  // measured (profiles/r01_ktrace_lowrank.log)
   const int dt = dtype & 0xff;
   if ((dt != LYC_BF16 && dt != LYC_F16) || a.R > 64) return false;
   long csum = 0;
@@ -403,7 +384,6 @@ bool launch_lowrank_tn(LowrankTnArgs a, int dtype, hipStream_t st) {
   if (split > cap) split = cap;
   if (split < 2 && a.M >= 64) split = 2;
   if (split < 1) split = 1;
-  if (force_split) split = force_split;
   a.rows_per_slab = round_up(cdiv(a.M, split), 4);
   a.nsplit = (int)cdiv(a.M, a.rows_per_slab);
   // columns per lane: 1 (most waves) unless the layer is so wide that 2 still gives thousands of waves
@@ -421,7 +401,6 @@ bool launch_lowrank_tn(LowrankTnArgs a, int dtype, hipStream_t st) {
       break;
     }
   }
-  if (force_cv) cv = force_cv;
   const int rt = a.R <= 16 ? 1 : a.R <= 32 ? 2 : 4;
   if (dt == LYC_BF16) {
     if (rt == 1) launch_tn_rt<__bf16, 1>(a, cv, st);
@@ -469,68 +448,6 @@ int64_t lyc_lokr_bwd_workspace_bytes(int64_t M, int a, int b, int c, int d, int 
   return (int64_t)cdiv(M, K3_RT / a) * cdiv(d, 32) * a * b * (int64_t)sizeof(float);
 }
 
-// ---- fork / join of independent launches --------------------------------------------------------------------------
-// The two LoKr backward launches of a layer (dx + dW1 partials | dW2) are independent and both latency-bound with about
-// one workgroup per CU, so they were put on separate branches of the captured hipGraph (dW2 on a library-owned side
-// stream between an event fork and an event join).  MEASURED (MI355X, ROCm 7.2, SDXL step): 46.7 ms/step against 36.5
-// ms on a single branch -- every fork / join pair costs more in the graph than the overlap hides.  The code stays as an
-// experiment switch, OFF by default: LYC_FORK_BWD=1 forks while `stream` is being captured, =2 always.
-extern "C++" {
-namespace {
-struct ForkCtx {
-  hipStream_t side = nullptr;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  bool tried = false, ok = false;
-};
-thread_local ForkCtx g_fork[16];
-
-int fork_mode() {
-  static const int v = lr_env("LYC_FORK_BWD", 0);
-  return v;
-}
-
-ForkCtx* fork_ctx(bool may_create) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  ForkCtx& f = g_fork[dev];
-  if (!f.tried && may_create) {
-    f.tried = true;
-    f.ok = hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess &&
-           hipEventCreateWithFlags(&f.e0, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&f.e1, hipEventDisableTiming) == hipSuccess;
-    (void)hipGetLastError();
-  }
-  return f.ok ? &f : nullptr;
-}
-
-// returns the stream for the forked launch (the side stream), or `st` itself when not forking
-hipStream_t fork_begin(hipStream_t st, ForkCtx*& ctx) {
-  ctx = nullptr;
-  const int mode = fork_mode();
-  if (mode == 0) return st;
-  bool capturing = false;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) == hipSuccess) capturing = cs == hipStreamCaptureStatusActive;
-  (void)hipGetLastError();
-  ForkCtx* f = fork_ctx(!capturing);  // the side stream / events are created on an eager call (never inside a capture)
-  if (!f || (mode == 1 && !capturing)) return st;
-  if (hipEventRecord(f->e0, st) != hipSuccess || hipStreamWaitEvent(f->side, f->e0, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    return st;
-  }
-  ctx = f;
-  return f->side;
-}
-
-int fork_join(hipStream_t st, ForkCtx* ctx) {
-  if (!ctx) return LYC_OK;
-  if (hipEventRecord(ctx->e1, ctx->side) != hipSuccess || hipStreamWaitEvent(st, ctx->e1, 0) != hipSuccess)
-    return fail(LYC_ERR_LAUNCH, "fork_join: %s", hipGetErrorString(hipGetLastError()));
-  return LYC_OK;
-}
-}  // namespace
-}  // extern "C++"
-
 int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const float* w2, void* dx, float* dw1,
                         float* dw2, void* ws, int64_t M, int a, int b, int c, int d, float alpha, int dtype,
                         void* stream) {
@@ -542,20 +459,6 @@ int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const flo
   long dw1_partials = 0;  // > 0: the dx launch left that many [a*b] partials in ws
   const bool dw2s_ok = dw2 && is16 && a == b && (16 % a) == 0 && (c % 8) == 0 && (d % 8) == 0 &&
                        (reinterpret_cast<uintptr_t>(g) & 15u) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
-  ForkCtx* fk = nullptr;
-  bool dw2_done = false;
-  if (dw2s_ok && dx) {  // both launches: try to put the dW2 one on a parallel branch (it then cannot carry the dW1 reduction)
-    hipStream_t s2 = fork_begin(st, fk);
-    if (fk) {
-      KronDw2sArgs da{};
-      da.Q = g; da.P = x; da.W = w1; da.out = dw2; da.M = M; da.G = a; da.I = c; da.J = d;
-      da.ws = b; da.wt = 1; da.os = d; da.alpha = alpha;
-      if ((dtype & 0xff) == LYC_BF16) launch_dw2s<__bf16>(da, s2);
-      else launch_dw2s<_Float16>(da, s2);
-      if (int rc = check_launch("lokr_linear_bwd(dw2, forked)")) return rc;
-      dw2_done = true;
-    }
-  }
   if (dx || dw1) {
     // dx[m, u*d+v] = alpha * sum_p w1[p,u] * sum_q w2[q,v] * g[m, p*c+q]: the same kernel on (w1^T, w2^T),
     // with the w1 gradient taken from its stage-1 result (GZ) against x.
@@ -576,8 +479,7 @@ int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const flo
     ra.dw1_red = 1;
   }
   bool reduced = dw1_partials == 0;
-  if (int rc = fork_join(st, fk)) return rc;
-  if (dw2 && !dw2_done) {
+  if (dw2) {
     bool done = false;
     if (dw2s_ok) {
       // rows of the tile run over q (exact operand g), the w1 mix is applied to x on the matrix cores; the output
@@ -694,21 +596,6 @@ int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1,
   hipStream_t st = (hipStream_t)stream;
   const bool bf = (dtype & 0xff) == LYC_BF16;
   long dw1_partials = 0;
-  ForkCtx* fk = nullptr;
-  bool dw2_done = false;
-  if (dx_rows && dw2p) {  // dW2 on a parallel branch of a captured graph (see fork_begin)
-    hipStream_t s2 = fork_begin(st, fk);
-    if (fk) {
-      KronDw2sArgs da{};
-      da.Q = g_rows; da.P = x_rows; da.W = w1; da.out = dw2p; da.M = B * cd.Ho * cd.Wo; da.G = a; da.I = c;
-      da.J = cd.taps * d; da.Jt = d; da.ws = b; da.wt = 1; da.os = (long)cd.taps * d; da.alpha = alpha;
-      da.gat = make_gather(1, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
-      if (bf) launch_dw2s<__bf16>(da, s2);
-      else launch_dw2s<_Float16>(da, s2);
-      if (int rc = check_launch("lokr_conv2d_bwd(dw2, forked)")) return rc;
-      dw2_done = true;
-    }
-  }
   if (dx_rows) {
     // transposed convolution: destination rows are INPUT pixels, the operand rows come from g (output pixels)
     KronArgs ka{};
@@ -731,8 +618,7 @@ int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1,
     ra.dw1_ws = static_cast<const float*>(ws); ra.dw1 = dw1; ra.dw1_nblk = (int)dw1_partials; ra.dw1_n = a * b;
     ra.dw1_red = 1;
   }
-  if (int rc = fork_join(st, fk)) return rc;
-  if (dw2p && !dw2_done) {
+  if (dw2p) {
     KronDw2sArgs da = ra;
     da.Q = g_rows; da.P = x_rows; da.W = w1; da.out = dw2p; da.M = B * cd.Ho * cd.Wo; da.G = a; da.I = c;
     da.J = cd.taps * d; da.Jt = d; da.ws = b; da.wt = 1; da.os = (long)cd.taps * d; da.alpha = alpha;
@@ -1054,7 +940,7 @@ void launch_loha_factor_grad(const float* gw, const float* w1a, const float* w1b
   // NO x nt tiles per workgroup (fewer atomics: the a-side gradients stay in registers over nt column tiles, the
   // b-side over NO row tiles) as long as ~512 workgroups remain; ranks > 32 go tile by tile, chunk by chunk
   const long tiles_o = cdiv(O, LOHA_T), tiles_j = cdiv(I, LOHA_T);
-  static const int lh_wgs = lr_env("LYC_LOHA_WGS", 512);
+  constexpr int lh_wgs = 512;
   long per = (tiles_o * tiles_j) / lh_wgs;
   int no = 1;
   LohaGradGeom gm{1};

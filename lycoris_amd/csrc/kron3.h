@@ -485,8 +485,9 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
 
 // The body is a device function so that the fused backward launch (kron_bwd_fused_kernel) can run it as one role.
 // `bx`, `by`: tile coordinates (M tile, N tile).  `smem`: kron3_lds_bytes(NI, K > K3_KC ? 2 : 1) bytes, 16-byte aligned.
-template <typename T, int NI, bool WITH_DW1, int GM>
+template <typename T, int NI, bool WITH_DW1, int GM, bool BASE = false>
 __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx, int by, int nbx) {
+  static_assert(!(WITH_DW1 && BASE), "base + delta is a forward epilogue");
   constexpr int MI = 2, TQ = 16 * NI;
   using F4 = typename Mma16<T>::frag;
 
@@ -516,15 +517,13 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
   // backward: the xref fragments of the w1 gradient (B[k = n][j = row li], 8 bytes per (mi, ni)) are fetched while stage 1
   // runs instead of inside the epilogue (they were ~1 us of exposed latency there); masked at use
   // (plain-row kernels only: the gather variants have no registers to spare -- 2 -> 1 waves per SIMD with it).
-  // forward: the same registers prefetch the frozen layer's output when the caller wants `base + delta` fused (a.base);
-  // without it the loads still go out (one broadcast address, ignored): a conditional load would make the registers a PHI
-  // of loaded / undefined, which the compiler resolves with a vmcnt(0) in front of stage 1 (see k3_load_w2).
-  constexpr bool XPRE = GM == 0 || GM == 3;
+  // forward, BASE instantiation: the same registers prefetch the frozen layer's output for the fused `base + delta`
+  // epilogue (a template parameter, not a runtime test: unconditional dummy loads in the plain forward cost 5 %, measured;
+  // a conditional load makes the registers a PHI of loaded / undefined and the compiler waits vmcnt(0) before stage 1).
+  constexpr bool XPRE = (WITH_DW1 || BASE) && (GM == 0 || GM == 3);
   u32x2 xrv[MI][NI];
   const T* pre = WITH_DW1 ? static_cast<const T*>(a.xref) : static_cast<const T*>(a.base);
-  const bool have_pre = pre != nullptr;
-  if (!have_pre) pre = static_cast<const T*>(a.x);
-  const bool xr_vec = have_pre && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(pre) & 7u) == 0);
+  const bool xr_vec = (WITH_DW1 || BASE) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(pre) & 7u) == 0);
   auto prefetch_xref = [&]() {
     if constexpr (XPRE) {
 #pragma unroll
@@ -593,8 +592,8 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
           T* dst = static_cast<T*>(a.y) + rofs + gn;
           T o[4];
           float bb[4] = {0.f, 0.f, 0.f, 0.f};
-          if constexpr (!WITH_DW1) {
-            if (a.base != nullptr) {  // fused `base + delta`: fp32 add, one rounding
+          if constexpr (BASE) {
+            {  // fused `base + delta`: fp32 add, one rounding
               const T* bp = static_cast<const T*>(a.base) + rofs + gn;
               if (XPRE && xr_vec) {  // prefetched; gn + 4 <= N here (N % 4 == 0)
                 T bt[4];
@@ -678,10 +677,10 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
   }
 }
 
-template <typename T, int NI, bool WITH_DW1, int GM>
+template <typename T, int NI, bool WITH_DW1, int GM, bool BASE = false>
 __global__ __launch_bounds__(NTHREADS) void kron3_kernel(KronArgs a) {
   extern __shared__ __attribute__((aligned(16))) char k3_smem[];
-  kron3_body<T, NI, WITH_DW1, GM>(a, k3_smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+  kron3_body<T, NI, WITH_DW1, GM, BASE>(a, k3_smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
 }  // namespace lyc
