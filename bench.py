@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="time the step without hipGraph capture (Python-driven)")
     ap.add_argument("--segments", type=int, default=8, help="backward graph segments (N > 1: collectives in between)")
     ap.add_argument("--layers", default="all", help="'all', 'linear' or 'conv' (development)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="development: 'gloo' lets N ranks share ONE GPU (rank % device_count) to exercise the N > 1 control flow "
+                         "on a single-GPU box; the driver's runs use nccl (= RCCL), one GPU per rank")
     ap.add_argument("--pmc-pass", type=int, default=0,
                     help="run N eager compute passes and exit (for rocprofv3 --pmc, which cannot sample inside graph replays)")
     a = ap.parse_args()
@@ -245,10 +248,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
 

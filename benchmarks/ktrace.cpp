@@ -34,14 +34,29 @@ int main(int argc, char** argv) {
       if (!bw) { ka.x = x; ka.y = y; ka.w1 = w1; ka.w2 = w2; ka.M = M; ka.Gin = G; ka.K = d; ka.Gout = G; ka.N = c; ka.s1o = G; ka.s1i = 1; ka.s2n = d; ka.s2k = 1; }
       else { ka.x = g; ka.y = dx; ka.w1 = w1; ka.w2 = w2; ka.dw1 = dw1; ka.xref = x; ka.M = M; ka.Gin = G; ka.K = c; ka.Gout = G; ka.N = d; ka.s1o = 1; ka.s1i = G; ka.s2n = 1; ka.s2k = d; }
       ka.alpha = 1.f;
-      const int ni = getenv("LYC_K3_NI") ? atoi(getenv("LYC_K3_NI")) : 4;
+      const int ni = getenv("KT_NI") ? atoi(getenv("KT_NI")) : 2;   // production picks 2 for the 1280-wide layers
+      const int gm = getenv("KT_GM") ? atoi(getenv("KT_GM")) : 3;   // 3 = x through the per-wave LDS stage (production)
       dim3 grid((unsigned)cdiv(M, K3_RT / G), (unsigned)cdiv(ka.N, 16 * ni));
-      if (ni == 4) {
-        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 4, true, 0>), grid, dim3(NTHREADS), kron3_lds_bytes(4, 2), 0, ka);
-        else hipLaunchKernelGGL((kron3_kernel<__bf16, 4, false, 0>), grid, dim3(NTHREADS), kron3_lds_bytes(4, 2), 0, ka);
+      const int lds4 = kron3_lds_bytes(4, 2) + kron3_xs_bytes(), lds2 = kron3_lds_bytes(2, 2) + kron3_xs_bytes();
+      const int lds1 = kron3_lds_bytes(1, 2) + kron3_xs_bytes();
+      if (ni == 1 && gm == 3) {
+        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 1, true, 3>), grid, dim3(NTHREADS), lds1, 0, ka);
+        else hipLaunchKernelGGL((kron3_kernel<__bf16, 1, false, 3>), grid, dim3(NTHREADS), lds1, 0, ka);
+      } else if (ni == 1) {
+        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 1, true, 0>), grid, dim3(NTHREADS), lds1, 0, ka);
+        else hipLaunchKernelGGL((kron3_kernel<__bf16, 1, false, 0>), grid, dim3(NTHREADS), lds1, 0, ka);
+      } else if (ni == 4 && gm == 3) {
+        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 4, true, 3>), grid, dim3(NTHREADS), lds4, 0, ka);
+        else hipLaunchKernelGGL((kron3_kernel<__bf16, 4, false, 3>), grid, dim3(NTHREADS), lds4, 0, ka);
+      } else if (ni == 4) {
+        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 4, true, 0>), grid, dim3(NTHREADS), lds4, 0, ka);
+        else hipLaunchKernelGGL((kron3_kernel<__bf16, 4, false, 0>), grid, dim3(NTHREADS), lds4, 0, ka);
+      } else if (gm == 3) {
+        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 2, true, 3>), grid, dim3(NTHREADS), lds2, 0, ka);
+        else hipLaunchKernelGGL((kron3_kernel<__bf16, 2, false, 3>), grid, dim3(NTHREADS), lds2, 0, ka);
       } else {
-        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 2, true, 0>), grid, dim3(NTHREADS), kron3_lds_bytes(2, 2), 0, ka);
-        else hipLaunchKernelGGL((kron3_kernel<__bf16, 2, false, 0>), grid, dim3(NTHREADS), kron3_lds_bytes(2, 2), 0, ka);
+        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 2, true, 0>), grid, dim3(NTHREADS), lds2, 0, ka);
+        else hipLaunchKernelGGL((kron3_kernel<__bf16, 2, false, 0>), grid, dim3(NTHREADS), lds2, 0, ka);
       }
       if (rep == 0) printf("grid %u x %u\n", grid.x, grid.y);
     }

@@ -56,7 +56,7 @@ constexpr int K3_RT = 128;          // stage-1 rows per workgroup (4 waves x 32)
 //       fit in one chunk, so most launches have a single segment and a single barrier);
 //    96 for the wide tile (NI = 4, throughput-bound problems: fewer live registers -> 3-4 waves per SIMD).
 // LDS row pitch of the w2 tiles = KC + 16 elements (8 mod 16 dwords: conflict-free ds_read_b128 fragments).
-__host__ __device__ constexpr int kron3_kc(int NI) { return NI == 2 ? 160 : 96; }
+__host__ __device__ constexpr int kron3_kc(int NI) { return NI <= 2 ? 160 : 96; }
 
 // one hi/lo tile pair per buffer; a second buffer only when there is more than one segment
 __host__ __device__ constexpr int kron3_lds_bytes(int NI, int nbuf) {
@@ -375,8 +375,11 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = zero4();
 
+  LYC_STAMP_DIRECT(1);  // all loads of the first chunk issued
   k3_store_w2<T, TQ, K3_KC>(Bbase, Bbase + PLANE, raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, Kloop);
+  LYC_STAMP_DIRECT(2);  // w2 data arrived, converted, written to LDS
   __syncthreads();
+  LYC_STAMP_DIRECT(3);  // first barrier passed
 
   // one chunk: NKS k-steps of MFMAs from (af, LDS tile); with MORE the fragment registers of each k-step are re-loaded
   // for the next chunk as soon as they are free.  Straight-line code (no per-k-step branches), so the compiler hoists the

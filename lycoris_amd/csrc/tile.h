@@ -40,11 +40,20 @@ __device__ unsigned long long lyc_trace_buf[32];
 #define LYC_TRACE_FLUSH()                                                                                      \
   do {                                                                                                         \
     if (threadIdx.x == 0 && blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y == LYC_TRACE_BLOCK) \
-      _Pragma("unroll") for (int i_ = 0; i_ < 32; ++i_) lyc_trace_buf[i_] = lyc_t[i_];                         \
+      _Pragma("unroll") for (int i_ = 0; i_ < 32; ++i_) if (lyc_t[i_]) lyc_trace_buf[i_] = lyc_t[i_];          \
+  } while (0)
+// stamp from a helper function that has no LYC_TRACE_DECL in scope: written straight to memory (perturbs a little)
+#define LYC_STAMP_DIRECT(i)                                                                                    \
+  do {                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y == LYC_TRACE_BLOCK) \
+      lyc_trace_buf[i] = __builtin_readcyclecounter();                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
   } while (0)
 #else
 #define LYC_TRACE_DECL do {} while (0)
 #define LYC_STAMP(i) do {} while (0)
+#define LYC_STAMP_DIRECT(i) do {} while (0)
 #define LYC_TRACE_FLUSH() do {} while (0)
 #endif
 
