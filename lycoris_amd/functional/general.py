@@ -29,7 +29,12 @@ def factorization(dimension: int, factor: int = -1) -> tuple[int, int]:
 
 
 def rebuild_tucker(t: torch.Tensor, wa: torch.Tensor, wb: torch.Tensor) -> torch.Tensor:
-    """W[p, q, ...] = sum_ij t[i, j, ...] wa[i, p] wb[j, q]  (functional/general.py:9-11).  Offline helper."""
+    """W[p, q, ...] = sum_ij t[i, j, ...] wa[i, p] wb[j, q]  (functional/general.py:9-11) = wa^T @ fold(t, wb): on the device the
+    fold is the tucker_core kernel (csrc/tucker.h, differentiable); CPU tensors (offline tools) take the einsum."""
+    if t.is_cuda and t.dim() == 4:
+        from .. import ops
+        fold = ops.tucker_core(t, wb)
+        return (wa.t() @ fold.flatten(1)).reshape(wa.shape[1], wb.shape[1], *t.shape[2:])
     return torch.einsum("ij...,ip,jq->pq...", t, wa, wb)
 
 

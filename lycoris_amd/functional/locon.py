@@ -43,8 +43,8 @@ def diff_weight(*weights, gamma=1.0):
 def bypass_forward_diff(x, org_out, *weights, gamma=1.0, extra_args={}):
     """delta = up(down(x)) * gamma on the HIP path (functional/locon.py:64-85).  ``org_out`` is unused, as upstream."""
     down, up, mid = weights
-    if mid is not None:
-        raise NotImplementedError("lycoris_amd: Tucker (lora_mid) LoCon is not on the native path yet")
+    if mid is not None:  # conv-CP form: fold the k x k core into the 1x1 down-projection (csrc/tucker.h), then the plain path
+        down = ops.tucker_core(mid, down)
     if down.dim() == 2:
         return ops.locon_linear(x, down, up, gamma)
     if down.dim() == 4:

@@ -39,8 +39,12 @@ def weight_gen(org_weight, rank, tucker=True, factor=-1, decompose_both=False, f
     if full_w2:
         w2 = torch.zeros(out_k, in_n, *k)
     else:
-        if k and tucker and any(i != 1 for i in k):
-            raise NotImplementedError("lycoris_amd: Tucker LoKr is not on the native path yet; pass tucker=False")
+        if k and tucker and any(i != 1 for i in k):  # functional/lokr.py:88-101: core [r, r, *k], [r, out_k], [r, in_n]
+            t2 = torch.empty(rank, rank, *k)
+            w2a, w2b = torch.empty(rank, out_k), torch.zeros(rank, in_n)
+            nn.init.kaiming_uniform_(t2, a=math.sqrt(5))
+            nn.init.kaiming_uniform_(w2a, a=math.sqrt(5))
+            return w1, w1a, w1b, w2, w2a, w2b, t2
         w2a = torch.empty(out_k, rank)
         w2b = torch.zeros(rank, in_n, *k)
         nn.init.kaiming_uniform_(w2a, a=math.sqrt(5))
@@ -49,10 +53,10 @@ def weight_gen(org_weight, rank, tucker=True, factor=-1, decompose_both=False, f
 
 def _resolve(weights, gamma):
     w1, w1a, w1b, w2, w2a, w2b, t = weights
-    if t is not None:
-        raise NotImplementedError("lycoris_amd: Tucker LoKr is not supported")
     if w1a is not None:
         rank = w1a.shape[1]
+    elif t is not None:
+        rank = t.shape[0]
     elif w2a is not None:
         rank = w2a.shape[1]
     else:
@@ -61,6 +65,9 @@ def _resolve(weights, gamma):
     f1 = w1 if w1 is not None else w1a @ w1b
     if w2 is not None:
         f2 = w2
+    elif t is not None:  # rebuild_tucker(t, w2a, w2b) = w2a^T @ fold(t, w2b)   (functional/general.py:9-11, csrc/tucker.h)
+        fold = ops.tucker_core(t, w2b) if t.is_cuda else torch.einsum("ijhw,jq->iqhw", t, w2b)
+        f2 = (w2a.t() @ fold.flatten(1)).reshape(w2a.shape[1], w2b.shape[1], *t.shape[2:])
     else:
         f2 = (w2a @ w2b.reshape(w2b.shape[0], -1)).reshape(w2a.shape[0], *w2b.shape[1:])
     return f1, f2, scale

@@ -147,3 +147,36 @@ def test_lokr_functional_gamma_is_alpha(dtype, form, conv):
             errs["d_" + key] = err(grads[id(t)], gr[key].reshape(t.shape))
             bd["d_" + key] = TOL["f32_out"][dtype]
     check(f"lokr_functional[{name},{dtype},{conv}]", errs, bd)
+
+
+@pytest.mark.parametrize("algo", ["locon", "loha", "lokr"])
+def test_tucker_forms_through_the_functional_api(algo):
+    """weights tuples with a Tucker core (mid / t1, t2 / t2): bypass_forward_diff == op(x, diff_weight) with diff_weight from the
+    reference's rebuild_tucker semantics (functional/general.py:9-11), restated by oracle.general.rebuild_tucker"""
+    from lycoris_amd import functional as F
+    gen = torch.Generator().manual_seed(9)
+    r, I, O, dtype = 4, 16, 32, torch.float32
+    x, x64 = rnd((2, I, 7, 6), dtype, gen)
+    ea = {"stride": 1, "padding": 1, "dilation": 1, "groups": 1}
+    ca = {"stride": 1, "padding": 1, "dilation": 1}
+    core = lambda: rnd((r, r, 3, 3), torch.float32, gen, 0.3)
+    if algo == "locon":
+        (down, d64), (up, u64), (mid, m64) = rnd((r, I, 1, 1), torch.float32, gen, 0.3), rnd((O, r, 1, 1), torch.float32, gen, 0.3), core()
+        y = F.locon.bypass_forward_diff(x, None, down, up, mid, gamma=0.5, extra_args=ea)
+        dw = oracle.general.rebuild_tucker(m64, u64.reshape(O, r).T, d64.reshape(r, I)) * 0.5
+    elif algo == "loha":
+        (w1d, a), (w1u, b), (w2d, c), (w2u, d) = (rnd((r, I), torch.float32, gen, 0.7), rnd((r, O), torch.float32, gen, 0.3),
+                                                  rnd((r, I), torch.float32, gen, 0.7), rnd((r, O), torch.float32, gen, 0.3))
+        (t1, t1n), (t2, t2n) = core(), core()
+        y = F.loha.bypass_forward_diff(x, None, w1d, w1u, w2d, w2u, t1, t2, gamma=torch.tensor(0.5), extra_args=ea)
+        dw = oracle.general.rebuild_tucker(t1n, b, a) * oracle.general.rebuild_tucker(t2n, d, c) * 0.5
+        got_dw = F.loha.diff_weight(w1d, w1u, w2d, w2u, t1, t2, gamma=0.5)
+        assert err(got_dw, dw) < 1e-5
+    else:
+        (w1, n1), (w2a, na), (w2b, nb), (t2, tn) = (rnd((4, 4), torch.float32, gen, 0.3), rnd((r, O // 4), torch.float32, gen, 0.5),
+                                                    rnd((r, I // 4), torch.float32, gen, 0.5), core())
+        y = F.lokr.bypass_forward_diff(x, None, w1, None, None, None, w2a, w2b, t2, gamma=2.0, extra_args=ea)
+        f2 = oracle.general.rebuild_tucker(tn, na, nb)
+        dw = oracle.lokr.diff_weight(w1=n1, w2=f2, scale=2.0 / r, kshape=(3, 3)).reshape(O, I, 3, 3)
+    want = oracle.general.dense_forward(x64, dw, ca)
+    check(f"tucker_functional[{algo}]", {"y": err(y, want)}, {"y": 2e-5})
