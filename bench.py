@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-defer", action="store_true",
+                    help="A/B: one LoKr weight-gradient launch per layer instead of the grouped launches")
     ap.add_argument("--no-reference", action="store_true", help="skip the PyTorch-ROCm eager comparator leg")
     ap.add_argument("--no-base", action="store_true", help="skip the base+adapter leg")
     ap.add_argument("--shared-inputs", action="store_true",
@@ -265,6 +267,9 @@ def main():
     all_params = [p for it in insts for p in it.params]
     sync = AdapterGradSync(all_params, bucket_bytes=32 << 20)
     sync.attach_fused()  # kernels accumulate into the arena and report to the bucket counters (eager: overlap by hooks)
+    if args.no_defer:  # A/B: one weight-gradient launch per layer instead of the grouped launches
+        from lycoris_amd import ops as _ops
+        _ops.deferred_weight_gradients(False)
     opt = torch.optim.AdamW(all_params, lr=1e-4, fused=True)
     n_layers = len(insts)
     act_bytes = sum(t.numel() * t.element_size() for it in insts for t in {id(it.x): it.x, id(it.g): it.g}.values())
@@ -511,30 +516,61 @@ def roofline(insts, args, dtype, dev):
                 "hot_path_gbs": round(hot, 1), "hot_path_frac": round(hot / HBM_PEAK_GBS, 4),
                 "forward_gbs": round(b_fwd / (t_fwd * 1e-3) / 1e9, 1), "backward_gbs": round(b_bwd / (t_bwd * 1e-3) / 1e9, 1)})
     if lin[0].algo == "lokr":
-        # the dominant KERNEL: lyc::kron3_kernel runs the forward and the backward dx (+ dW1) launch; lyc::kron_dw2s_kernel the
-        # dW2 launch, which re-reads g and x.  A third graph with only the dW2 launches separates the two families.
+        # the dominant KERNEL: lyc::kron3_kernel runs the forward and the backward dx (+ dW1 partials) launch of every layer;
+        # the weight gradients (dW2, dW1 reduction) of ALL layers run in grouped launches (lyc::kron_dw2s_group_kernel,
+        # lyc_lokr_wgrad_group: 24 layers per launch), which re-read g and x.  Three graphs, no subtraction:
+        #   forward | backward dx with LYC_DEFER_WGRAD | one lyc_lokr_wgrad_group call over all layers
+        import ctypes
         from lycoris_amd import _native as N
         code = N.dtype_code(dtype)
+        items = (N.WgradItem * len(calls))()
+        wss, dxs = [], []
+        for k, (it, rows, g, fs, bufs) in enumerate(calls):
+            (a, b), (c, d) = fs[0].shape, fs[1].shape
+            nb = max(int(N.load().lyc_lokr_bwd_workspace_bytes(rows.shape[0], a, b, c, d, code)), 16)
+            wss.append(torch.empty(nb, dtype=torch.uint8, device=dev))
+            dxs.append(torch.empty_like(rows))
+            assert N.load().lyc_lokr_wgrad_deferrable(N.ptr(g), N.ptr(rows), rows.shape[0], a, b, c, d, code) == 1
+            items[k] = N.WgradItem(N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(bufs[0]), N.ptr(bufs[1]), N.ptr(wss[k]),
+                                   rows.shape[0], a, b, c, d, 1.0)
+        _KEEP.extend([items, wss, dxs])
 
-        def only_dw2():
+        def only_dx():
+            for k, (it, rows, g, fs, bufs) in enumerate(calls):
+                (a, b), (c, d) = fs[0].shape, fs[1].shape
+                N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(dxs[k]), N.ptr(bufs[0]),
+                       None, N.ptr(wss[k]), rows.shape[0], a, b, c, d, 1.0, code | 0x200, N.stream_ptr(dev))
+
+        def grouped_wgrad():
+            N.call("lyc_lokr_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(calls), code, N.stream_ptr(dev))
+
+        def per_layer_dw2():
             for it, rows, g, fs, bufs in calls:
                 (a, b), (c, d) = fs[0].shape, fs[1].shape
                 N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), None, None, N.ptr(bufs[1]), None,
                        rows.shape[0], a, b, c, d, 1.0, code, N.stream_ptr(dev))
 
-        t_dw2 = _graph_ms(only_dw2)
-        t_dx = max(t_bwd - t_dw2, 0.0)
+        t_dx = _graph_ms(only_dx)
+        t_wg = _graph_ms(grouped_wgrad)
+        t_dw2 = _graph_ms(per_layer_dw2)
         b_dw2 = sum(esz * (it.spec["M"] * (it.spec["I"] + it.spec["O"])) + 4 * sum(p.numel() for p in it.params) for it in lin)
         b_dx = b_bwd  # g + x (dW1) + dx + factors: the SURVEY 8d backward bytes belong to this launch
         k3_ms, k3_bytes = t_fwd + t_dx, b_fwd + b_dx
         ach = k3_bytes / (k3_ms * 1e-3) / 1e9
-        out["families_ms"] = {"kron3_forward": round(t_fwd, 3), "kron3_backward_dx_dw1": round(t_dx, 3), "kron_dw2s": round(t_dw2, 3)}
-        out.update({"kernel": "lyc::kron3_kernel (LoKr forward + backward dx / dW1 launches of the Linear layers); "
-                              "lyc::kron_dw2s_kernel (dW2, re-reads g and x) under families_ms",
+        hot = nbytes / ((t_fwd + t_dx + t_wg) * 1e-3) / 1e9
+        out["families_ms"] = {"kron3_forward": round(t_fwd, 3), "kron3_backward_dx_dw1": round(t_dx, 3),
+                              "kron_dw2s_grouped": round(t_wg, 3), "kron_dw2s_one_launch_per_layer": round(t_dw2, 3),
+                              "backward_one_call_per_layer": round(t_bwd, 3)}
+        out.update({"kernel": "lyc::kron3_kernel (LoKr forward + backward dx / dW1 launches of the Linear layers); the weight "
+                              "gradients run grouped (lyc::kron_dw2s_group_kernel, 24 layers per launch, re-reads g and x): "
+                              "families_ms",
                     "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
                     "avg_launch_us": round(k3_ms * 1e3 / (2 * n_l), 2), "launches_per_layer": 2,
                     "algorithmic_bytes_per_launch": int(k3_bytes / (2 * n_l)),
-                    "dw2s_gbs": round(b_dw2 / (t_dw2 * 1e-3) / 1e9, 1)})
+                    "hot_path_gbs": round(hot, 1), "hot_path_frac": round(hot / HBM_PEAK_GBS, 4),
+                    "backward_gbs": round(b_bwd / ((t_dx + t_wg) * 1e-3) / 1e9, 1),
+                    "dw2s_grouped_gbs": round(b_dw2 / (t_wg * 1e-3) / 1e9, 1),
+                    "dw2s_per_layer_gbs": round(b_dw2 / (t_dw2 * 1e-3) / 1e9, 1)})
         return out
     out.update({"kernel": {"locon": "lyc::bneck_kernel (forward, backward-dx) + lyc::lowrank_tn_kernel (factor gradients): the three "
                                     "launches of a LoCon Linear layer (comparable cost each)",

@@ -35,8 +35,8 @@ def short(name):
 # kernel families of bench.py's roofline legs: every launch the Linear layers of one algorithm make
 FAMILIES = {  # family -> (algo whose pass is used, kernel-name substrings)
     "lokr_kron3": ("lokr", ("kron3_kernel",)),
-    "lokr_dw2s": ("lokr", ("kron_dw2s_kernel",)),
-    "lokr_linear": ("lokr", ("kron3_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "kron_kernel", "kron_dw2_kernel")),
+    "lokr_dw2s": ("lokr", ("kron_dw2s_kernel", "kron_dw2s_group_kernel")),
+    "lokr_linear": ("lokr", ("kron3_kernel", "kron_dw2s_kernel", "kron_dw2s_group_kernel", "kron_dw1_reduce", "kron_kernel", "kron_dw2_kernel")),
     "locon_linear": ("locon", ("bneck_kernel", "lowrank_tn_kernel", "skinny_", "expand_nt")),
 }
 CAL_R, CAL_W = 2047.96, 1024.0  # bytes per counter unit, calibrated on a 1 GiB copy (profiles/r01_pmc_kbench.txt)

@@ -28,10 +28,10 @@ extern "C" {
 enum { LYC_F32 = 0, LYC_F16 = 1, LYC_BF16 = 2 };
 /* OR-able into `dtype`: the row-matrix side of the call (dx of the *_linear_bwd entry points, dcols of lyc_col2im)
  * is fp32 instead of `dtype`.  Used by the Conv2d lowering so that col2im sums un-rounded rows and rounds once. */
-enum { LYC_F32_ROWS = 0x100 };
+enum { LYC_F32_ROWS = 0x100, LYC_DEFER_WGRAD = 0x200 };
 enum { LYC_OK = 0, LYC_ERR_ARG = 1, LYC_ERR_UNSUPPORTED = 2, LYC_ERR_LAUNCH = 3 };
 
-#define LYC_ABI_VERSION 6
+#define LYC_ABI_VERSION 7
 int lyc_abi_version(void);
 const char* lyc_last_error(void);
 
@@ -53,6 +53,28 @@ int64_t lyc_lokr_bwd_workspace_bytes(int64_t M, int a, int b, int c, int d, int 
 int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const float* w2, void* dx, float* dw1,
                         float* dw2, void* ws, int64_t M, int a, int b, int c, int d, float alpha, int dtype,
                         void* stream);
+
+/* ---- deferred, grouped LoKr weight gradients ---------------------------------------------------------
+ * The factor gradients are consumed by the optimizer only, so the backward pass of a network does not have to wait for
+ * them layer by layer: call lyc_lokr_linear_bwd with `dtype | LYC_DEFER_WGRAD`, dw1 != NULL, dw2 == NULL and a `ws` --
+ * it runs the dx launch only and leaves the w1-gradient partials in `ws` -- keep (g, x, ws) of the layer alive, and hand
+ * batches of layers to lyc_lokr_wgrad_group, which finishes dw1 and accumulates dw2 for ALL of them in
+ * ceil(n / 24) launches per tile configuration (reference: the same autograd products of modules/lokr.py:543-566, just
+ * scheduled together).  Items must satisfy lyc_lokr_wgrad_deferrable (16-bit activations, a == b dividing 16, c and d
+ * multiples of 8, 16-byte aligned g and x); `dw1` may be NULL (only dw2 wanted).  A parameter may appear in several items. */
+typedef struct LycLokrWgradItem {
+  const void* g;    /* [M, a*c] upstream gradient            */
+  const void* x;    /* [M, b*d] layer input                  */
+  const float* w1;  /* [a, b]                                */
+  float* dw1;       /* [a, b]  += (NULL: skip)               */
+  float* dw2;       /* [c, d]  +=                            */
+  void* ws;         /* the scratch the layer's dx launch used */
+  int64_t M;
+  int a, b, c, d;
+  float alpha;
+} LycLokrWgradItem;
+int lyc_lokr_wgrad_deferrable(const void* g, const void* x, int64_t M, int a, int b, int c, int d, int dtype);
+int lyc_lokr_wgrad_group(const LycLokrWgradItem* items, int n, int dtype, void* stream);
 
 /* ---- LoKr on nn.Conv2d (groups = 1): implicit GEMM, no im2col -------------------------------------
  * replaces lycoris/modules/lokr.py:543-566 with F.conv2d (functional/general.py:6) and the grouped-conv bypass

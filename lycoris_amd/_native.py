@@ -13,7 +13,7 @@ import torch
 
 _LIB_NAME = "liblycoris_amd.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 LYC_F32, LYC_F16, LYC_BF16 = 0, 1, 2
 _DTYPE_CODE = {torch.float32: LYC_F32, torch.float16: LYC_F16, torch.bfloat16: LYC_BF16}
@@ -24,6 +24,7 @@ _vp, _fp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, c
 SIGNATURES = {
     "lyc_lokr_linear_fwd": [_vp, _fp, _fp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_lokr_linear_bwd": [_vp, _vp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    "lyc_lokr_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of WgradItem
     "lyc_lokr_conv2d_fwd": [_vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_lokr_conv2d_bwd": [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_locon_linear_fwd": [_vp, _fp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
@@ -52,7 +53,14 @@ VALUE_SIGNATURES = {
     "lyc_loha_workspace_bytes": ([_i32, _i32, _i32], ctypes.c_int64),
     "lyc_lokr_bwd_workspace_bytes": ([_i64, _i32, _i32, _i32, _i32, _i32], ctypes.c_int64),
     "lyc_lokr_conv2d_bwd_workspace_bytes": ([_i64, _i64, _i64, _i32, _i32, _i32], ctypes.c_int64),
+    "lyc_lokr_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32], ctypes.c_int),  # 1 / 0, not an error code
 }
+
+
+class WgradItem(ctypes.Structure):
+    """LycLokrWgradItem (include/lycoris_amd.h)"""
+    _fields_ = [("g", _vp), ("x", _vp), ("w1", _vp), ("dw1", _vp), ("dw2", _vp), ("ws", _vp), ("M", _i64),
+                ("a", _i32), ("b", _i32), ("c", _i32), ("d", _i32), ("alpha", _f32)]
 
 _lock = threading.RLock()  # re-entrant: load_torch_ops() calls load() while holding it
 _lib = None

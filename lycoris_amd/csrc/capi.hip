@@ -142,8 +142,10 @@ void launch_dw2s_inst(KronDw2sArgs da, long tiles_i, long tiles_j, hipStream_t s
 }
 
 // fills rows_per_block / nsplit / dw1_red / tiles of `da`; returns true for the 64 x 64 tile, false for 32 x 32
-bool plan_dw2s(KronDw2sArgs& da) {
-  constexpr int target_blocks = 512;       // one resident round: 2 workgroups per CU
+// `grouped`: the problem is one of many in a launch (kron_dw2s_group_kernel): parallelism comes from the other problems, so
+// fewer, longer row slabs (less atomic traffic, the set-up of a workgroup amortised over more rows)
+bool plan_dw2s(KronDw2sArgs& da, bool grouped = false) {
+  const int target_blocks = grouped ? 128 : 512;  // single launch: one resident round, 2 workgroups per CU
   constexpr int atomic_budget = 620000;    // fp32 atomics per launch (~300 / ns)
   const long rows_total = da.M * da.G;
   auto plan = [&](int mi, int nj, long& tiles, long& split) {
@@ -167,6 +169,11 @@ bool plan_dw2s(KronDw2sArgs& da) {
   long split = big ? s44 : s22;
   const long tiles = big ? t44 : t22;
   while (split > 1 && tiles * split > target_blocks) --split;  // one resident round: 2 workgroups per CU
+  if (grouped) {  // ... but no slab longer than 4096 rows (the tail of the launch), atomic budget permitting
+    long smax = atomic_budget / ((long)da.I * da.J);
+    if (smax < 1) smax = 1;
+    while (split < smax && cdiv(rows_total, split) > 4096) ++split;
+  }
   if (split > 8) {
     // the work items are dealt to the 8 XCDs in contiguous eighths of the slab-major order (kernel block mapping): with a
     // multiple of 8 slabs no slab straddles two XCDs (measured: 41 slabs run 1.7x slower than 40).  Round up when the
@@ -513,11 +520,95 @@ int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const flo
       if (int rc = check_launch("lokr_linear_bwd(dw2)")) return rc;
     }
   }
+  if (!reduced && (dtype & LYC_DEFER_WGRAD)) {
+    if (dw2) return fail(LYC_ERR_ARG, "lokr_linear_bwd: LYC_DEFER_WGRAD leaves dw2 to lyc_lokr_wgrad_group (pass dw2 = NULL)");
+    return LYC_OK;  // the partials stay in ws; lyc_lokr_wgrad_group reduces them
+  }
   if (!reduced) {  // partials were written but no dW2 launch carried the reduction
     long r = dw1_partials / 64;
     ra.dw1_red = (int)(r > 16 ? 16 : r < 1 ? 1 : r);
     hipLaunchKernelGGL(kron_dw1_reduce_kernel, dim3((unsigned)ra.dw1_red), dim3(NTHREADS), 0, st, ra);
     if (int rc = check_launch("lokr_linear_bwd(dw1 reduce)")) return rc;
+  }
+  return LYC_OK;
+}
+
+// ---- deferred, grouped weight gradients (kron_dw2s_group_kernel) ------------------------------------------------
+extern "C++" {
+namespace {
+bool lokr_wgrad_fast(const void* g, const void* x, int64_t M, int a, int b, int c, int d, int dtype) {
+  const int dt = dtype & 0xff;
+  return M > 0 && (dt == LYC_BF16 || dt == LYC_F16) && a == b && a >= 1 && (16 % a) == 0 && (c % 8) == 0 && (d % 8) == 0 &&
+         (reinterpret_cast<uintptr_t>(g) & 15u) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+}
+template <typename T, int MI, int NJ, int U>
+void launch_dw2s_group(const KronDw2sGroupArgs& ga, hipStream_t st) {
+  hipLaunchKernelGGL((kron_dw2s_group_kernel<T, MI, NJ, U>), dim3((unsigned)ga.wg_end[ga.n - 1]), dim3(NTHREADS), 0, st, ga);
+}
+}  // namespace
+}  // extern "C++"
+
+int lyc_lokr_wgrad_deferrable(const void* g, const void* x, int64_t M, int a, int b, int c, int d, int dtype) {
+  return lokr_wgrad_fast(g, x, M, a, b, c, d, dtype) ? 1 : 0;
+}
+
+int lyc_lokr_wgrad_group(const LycLokrWgradItem* items, int n, int dtype, void* stream) {
+  if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "lokr_wgrad_group: bad item list");
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = dtype & 0xff;
+  // two tile configurations (plan_dw2s): each gets its own sequence of launches, items keep their order
+  for (int big = 0; big < 2; ++big) {
+    KronDw2sGroupArgs ga{};
+    auto flush = [&]() -> int {
+      if (ga.n == 0) return LYC_OK;
+      for (int i = 0; i < ga.n; ++i)  // a parameter that appears twice in one grid (shared module) must be added atomically
+        for (int j = 0; j < i; ++j)
+          if (ga.p[i].out == ga.p[j].out || (ga.p[i].dw1 && ga.p[i].dw1 == ga.p[j].dw1))
+            ga.p[i].force_atomic = ga.p[j].force_atomic = 1;
+      if (dt == LYC_BF16) {
+        if (big) launch_dw2s_group<__bf16, 4, 4, 1>(ga, st);
+        else launch_dw2s_group<__bf16, 2, 2, 4>(ga, st);
+      } else {
+        if (big) launch_dw2s_group<_Float16, 4, 4, 1>(ga, st);
+        else launch_dw2s_group<_Float16, 2, 2, 4>(ga, st);
+      }
+      ga = KronDw2sGroupArgs{};
+      return check_launch("lokr_wgrad_group");
+    };
+    for (int k = 0; k < n; ++k) {
+      const LycLokrWgradItem& it = items[k];
+      if (big == 0) {  // validate once
+        if (int rc = check_kron_dims(it.M, it.a, it.b, it.c, it.d)) return rc;
+        if (!it.g || !it.x || !it.w1 || !it.dw2) return fail(LYC_ERR_ARG, "lokr_wgrad_group: item %d: null pointer", k);
+        if (!lokr_wgrad_fast(it.g, it.x, it.M, it.a, it.b, it.c, it.d, dtype))
+          return fail(LYC_ERR_UNSUPPORTED, "lokr_wgrad_group: item %d is not on the 16-bit fast path (see lyc_lokr_wgrad_deferrable)", k);
+        if (it.dw1 && !it.ws) return fail(LYC_ERR_ARG, "lokr_wgrad_group: item %d: dw1 needs the ws its dx launch wrote", k);
+      }
+      KronDw2sArgs da{};
+      da.Q = it.g; da.P = it.x; da.W = it.w1; da.out = it.dw2; da.M = it.M; da.G = it.a; da.I = it.c; da.J = it.d;
+      da.ws = it.b; da.wt = 1; da.os = it.d; da.alpha = it.alpha;
+      if (it.dw1) {  // partials of the dx launch: one [a*b] block per workgroup of launch_kron3's grid
+        KronArgs ka{};
+        ka.M = it.M; ka.Gin = it.a; ka.K = it.c; ka.Gout = it.b; ka.N = it.d;
+        const int ni = kron3_pick_ni(ka);
+        da.dw1_ws = static_cast<const float*>(it.ws); da.dw1 = it.dw1; da.dw1_n = it.a * it.b;
+        da.dw1_nblk = (int)(cdiv(it.M, K3_RT / it.a) * cdiv(it.d, 16 * ni));
+        da.dw1_red = 1;
+      }
+      if ((plan_dw2s(da, true) ? 1 : 0) != big) continue;
+      const long wgs = round_up((long)da.tiles_i * da.tiles_j * da.nsplit, 8) + round_up(da.dw1_ws ? da.dw1_red : 0, 8);
+      const long before = ga.n ? ga.wg_end[ga.n - 1] : 0;
+      if (ga.n == DW2G_MAX || before + wgs > (1L << 30))
+        if (int rc = flush()) return rc;
+      KronDw2sItem& q = ga.p[ga.n];
+      q.Q = da.Q; q.P = da.P; q.W = da.W; q.out = da.out; q.dw1_ws = da.dw1_ws; q.dw1 = da.dw1; q.M = da.M;
+      q.rows_per_block = da.rows_per_block; q.G = da.G; q.I = da.I; q.J = da.J; q.nsplit = da.nsplit;
+      q.tiles_i = da.tiles_i; q.tiles_j = da.tiles_j; q.dw1_nblk = da.dw1_nblk; q.dw1_n = da.dw1_n; q.dw1_red = da.dw1_red;
+      q.ws = (int)da.ws; q.wt = (int)da.wt; q.os = (int)da.os; q.alpha = da.alpha; q.force_atomic = 0;
+      ga.wg_end[ga.n] = (int)((ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs);
+      ++ga.n;
+    }
+    if (int rc = flush()) return rc;
   }
   return LYC_OK;
 }

@@ -32,6 +32,7 @@ struct KronDw2sArgs {
   int nsplit;           // row slabs
   int tiles_i, tiles_j; // output tiles; the grid is 1-D: round_up(tiles_i * tiles_j * nsplit, 8) (+ dw1_red reducers)
   float alpha;
+  int force_atomic;     // != 0: `out` / `dw1` may be shared with another problem of the same launch (grouped launches)
   // w1-gradient partial reduction (runs in grid slice z == nsplit; nullptr = nothing to do)
   const float* dw1_ws;  // [dw1_nblk][dw1_n] partials, already in dw1 memory order
   float* dw1;
@@ -66,7 +67,7 @@ __device__ __forceinline__ void dw1_reduce_role(const KronDw2sArgs& a, int r, fl
   if (tid < n) {
     float t = 0.f;
     for (int p = 0; p < nparts; ++p) t += lds[p * n + tid];
-    if (a.dw1_red == 1)
+    if (a.dw1_red == 1 && !a.force_atomic)
       a.dw1[tid] += t;
     else
       __hip_atomic_fetch_add(a.dw1 + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -349,7 +350,7 @@ __device__ __forceinline__ void kron_dw2s_body(const KronDw2sArgs& a, char* smem
   // cross-wave reduction through LDS: every wave publishes its tiles, wave w sums and stores tiles t = w (mod 4)
   float* red = reinterpret_cast<float*>(smem);
   constexpr int NT = MI * NJ, TB = NT < 8 ? NT : 8;  // tiles per batch (LDS budget)
-  const bool plain = a.nsplit == 1;
+  const bool plain = a.nsplit == 1 && !a.force_atomic;
   LYC_STAMP(4);
 #pragma unroll
   for (int t0 = 0; t0 < NT; t0 += TB) {
@@ -389,6 +390,52 @@ template <typename T, int MI, int NJ, int U, bool GATHER>
 __global__ __launch_bounds__(NTHREADS) void kron_dw2s_kernel(KronDw2sArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[kron_dw2s_lds_bytes<MI, NJ>()];
   kron_dw2s_body<T, MI, NJ, U, GATHER>(a, smem, (int)blockIdx.x);
+}
+
+// ---- grouped launch: the weight gradients of up to DW2G_MAX layers in ONE grid -----------------------------------------
+// dW1 / dW2 of a layer are consumed by the optimizer only, so nothing in the backward pass waits for them: the host keeps
+// (g, x) of the finished layers alive (288 GB of HBM: a few hundred MB) and hands a batch of them to this kernel.  A single
+// layer's launch is ~500 workgroups of ~10 k cycles each -- one resident round whose time is the serial chain of one
+// workgroup plus the launch overhead; a batch is thousands of workgroups, so the chains of co-resident workgroups overlap,
+// the split-K factor per problem (and with it the atomic traffic) drops, and 24 launches become one.
+// The problem descriptors travel by value in the kernel arguments (no device-side table to keep coherent, legal inside
+// hipGraph capture).  Every problem's workgroup count is a multiple of 8, so `index % 8` is still the XCD.
+constexpr int DW2G_MAX = 24;
+struct KronDw2sItem {
+  const void* Q;
+  const void* P;
+  const float* W;
+  float* out;
+  const float* dw1_ws;
+  float* dw1;
+  long M;
+  long rows_per_block;
+  int G, I, J, nsplit, tiles_i, tiles_j, dw1_nblk, dw1_n, dw1_red;
+  int ws, wt, os;
+  float alpha;
+  int force_atomic;
+};
+struct KronDw2sGroupArgs {
+  int n;
+  int wg_end[DW2G_MAX];  // exclusive prefix of the workgroup counts
+  KronDw2sItem p[DW2G_MAX];
+};
+static_assert(sizeof(KronDw2sGroupArgs) <= 3584, "kernel arguments are limited to 4 KiB");
+
+template <typename T, int MI, int NJ, int U>
+__global__ __launch_bounds__(NTHREADS) void kron_dw2s_group_kernel(KronDw2sGroupArgs ga) {
+  __shared__ __attribute__((aligned(16))) char smem[kron_dw2s_lds_bytes<MI, NJ>()];
+  const int b = (int)blockIdx.x;
+  int p = 0;
+  while (p + 1 < ga.n && b >= ga.wg_end[p]) ++p;  // uniform: scalar loads from the kernel-argument segment
+  const int b0 = p ? ga.wg_end[p - 1] : 0;
+  const KronDw2sItem& it = ga.p[p];
+  KronDw2sArgs a{};
+  a.Q = it.Q; a.P = it.P; a.W = it.W; a.out = it.out; a.M = it.M; a.G = it.G; a.I = it.I; a.J = it.J;
+  a.ws = it.ws; a.wt = it.wt; a.os = it.os; a.rows_per_block = it.rows_per_block; a.nsplit = it.nsplit;
+  a.tiles_i = it.tiles_i; a.tiles_j = it.tiles_j; a.alpha = it.alpha; a.force_atomic = it.force_atomic;
+  a.dw1_ws = it.dw1_ws; a.dw1 = it.dw1; a.dw1_nblk = it.dw1_nblk; a.dw1_n = it.dw1_n; a.dw1_red = it.dw1_red;
+  kron_dw2s_body<T, MI, NJ, U, false>(a, smem, b - b0);
 }
 
 // stand-alone reduction of the w1-gradient partials (used when the caller asks for dw1 but not dw2)

@@ -16,7 +16,7 @@
 
 namespace lyc {
 
-constexpr int LH_AP = LOHA_RC + 1;  // pitch of the a-factor tiles [64 o][32 r]
+constexpr int LH_AP = LOHA_RC + 4;  // pitch of the a-factor tiles [64 o][32 r]  (multiple of 4: 16-byte LDS writes)
 constexpr int LH_BP = LOHA_T + 4;   // pitch of the b-factor tiles [32 r][64 i]
 constexpr int LH_TP = LOHA_T + 4;   // pitch of the T tiles [64 o][64 i]
 
@@ -25,26 +25,112 @@ __device__ __forceinline__ float lh_mma(float a, float b, f32x4& c) {
   return 0.f;
 }
 
-// a-factor rows o0 .. o0+63, rank chunk r0 .. r0+31 -> [64][LH_AP]   (zero outside)
-__device__ __forceinline__ void lh_stage_a(const LohaArgs& a, long o0, int r0, float* sA1, float* sA2) {
-  for (int e = threadIdx.x; e < LOHA_T * LOHA_RC; e += NTHREADS) {
+// Factor staging.  Every load of a tile is ISSUED before the first LDS write: the first version looped "load one element,
+// wait, write" -- 16 dependent L2 round trips per tile, which was most of the time of a tile (profiles/r01_v7: the rebuild
+// of a 640 x 640 layer took 10 us).  Whole float4s when the rows allow it (R % 4 == 0 / I % 4 == 0, 16-byte aligned base).
+__device__ __forceinline__ bool lh_vec_ok(const LohaArgs& a) {
+  return (a.R % 4 == 0) && (a.I % 4 == 0) &&
+         (((reinterpret_cast<uintptr_t>(a.w1a) | reinterpret_cast<uintptr_t>(a.w2a) | reinterpret_cast<uintptr_t>(a.w1b) |
+            reinterpret_cast<uintptr_t>(a.w2b)) & 15u) == 0);
+}
+
+struct LhRaw {
+  f32x4 a1[2], a2[2], b1[2], b2[2];
+};
+
+// issue: a-factor rows o0 .. o0+63 x rank chunk r0 .. r0+31 (512 float4, two per thread and factor), b-factor rank chunk x
+// columns i0 .. i0+63 (512 float4)
+__device__ __forceinline__ void lh_load_vec(const LohaArgs& a, long o0, long i0, int r0, LhRaw& w) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = threadIdx.x + NTHREADS * it;
+    const int o = e >> 3, c4 = (e & 7) * 4;
+    const bool ok = (o0 + o < a.O) && (r0 + c4 < a.R);
+    const long idx = ok ? (o0 + o) * a.R + r0 + c4 : 0;
+    w.a1[it] = *reinterpret_cast<const f32x4*>(a.w1a + idx);
+    w.a2[it] = *reinterpret_cast<const f32x4*>(a.w2a + idx);
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = threadIdx.x + NTHREADS * it;
+    const int rb = e >> 4, c4 = (e & 15) * 4;
+    const bool ok = (r0 + rb < a.R) && (i0 + c4 < a.I);
+    const long idx = ok ? (long)(r0 + rb) * a.I + i0 + c4 : 0;
+    w.b1[it] = *reinterpret_cast<const f32x4*>(a.w1b + idx);
+    w.b2[it] = *reinterpret_cast<const f32x4*>(a.w2b + idx);
+  }
+}
+__device__ __forceinline__ void lh_store_vec(const LohaArgs& a, long o0, long i0, int r0, const LhRaw& w, float* sA1,
+                                             float* sA2, float* sB1, float* sB2) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = threadIdx.x + NTHREADS * it;
+    const int o = e >> 3, c4 = (e & 7) * 4;
+    const bool ok = (o0 + o < a.O) && (r0 + c4 < a.R);
+    *reinterpret_cast<f32x4*>(sA1 + o * LH_AP + c4) = ok ? w.a1[it] : z;
+    *reinterpret_cast<f32x4*>(sA2 + o * LH_AP + c4) = ok ? w.a2[it] : z;
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = threadIdx.x + NTHREADS * it;
+    const int rb = e >> 4, c4 = (e & 15) * 4;
+    const bool ok = (r0 + rb < a.R) && (i0 + c4 < a.I);
+    *reinterpret_cast<f32x4*>(sB1 + rb * LH_BP + c4) = ok ? w.b1[it] : z;
+    *reinterpret_cast<f32x4*>(sB2 + rb * LH_BP + c4) = ok ? w.b2[it] : z;
+  }
+}
+
+// element-wise form (odd ranks / widths / alignment); also with all loads of a factor pair in flight before the writes
+__device__ __forceinline__ void lh_stage_scalar(const LohaArgs& a, long o0, long i0, int r0, float* sA1, float* sA2,
+                                                float* sB1, float* sB2) {
+  constexpr int N = LOHA_T * LOHA_RC / NTHREADS;  // 8 elements per thread and tile
+  float v1[N], v2[N];
+#pragma unroll
+  for (int it = 0; it < N; ++it) {
+    const int e = threadIdx.x + NTHREADS * it;
     const int o = e / LOHA_RC, rr = e % LOHA_RC;
     const bool ok = (o0 + o < a.O) && (r0 + rr < a.R);
     const long idx = ok ? (o0 + o) * a.R + r0 + rr : 0;
-    const float v1 = a.w1a[idx], v2 = a.w2a[idx];
-    sA1[o * LH_AP + rr] = ok ? v1 : 0.f;
-    sA2[o * LH_AP + rr] = ok ? v2 : 0.f;
+    v1[it] = a.w1a[idx];
+    v2[it] = a.w2a[idx];
   }
-}
-// b-factor columns i0 .. i0+63, rank chunk -> [32][LH_BP]
-__device__ __forceinline__ void lh_stage_b(const LohaArgs& a, long i0, int r0, float* sB1, float* sB2) {
-  for (int e = threadIdx.x; e < LOHA_RC * LOHA_T; e += NTHREADS) {
+#pragma unroll
+  for (int it = 0; it < N; ++it) {
+    const int e = threadIdx.x + NTHREADS * it;
+    const int o = e / LOHA_RC, rr = e % LOHA_RC;
+    const bool ok = (o0 + o < a.O) && (r0 + rr < a.R);
+    sA1[o * LH_AP + rr] = ok ? v1[it] : 0.f;
+    sA2[o * LH_AP + rr] = ok ? v2[it] : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < N; ++it) {
+    const int e = threadIdx.x + NTHREADS * it;
     const int rb = e / LOHA_T, i = e % LOHA_T;
     const bool ok = (r0 + rb < a.R) && (i0 + i < a.I);
     const long idx = ok ? (long)(r0 + rb) * a.I + i0 + i : 0;
-    const float v1 = a.w1b[idx], v2 = a.w2b[idx];
-    sB1[rb * LH_BP + i] = ok ? v1 : 0.f;
-    sB2[rb * LH_BP + i] = ok ? v2 : 0.f;
+    v1[it] = a.w1b[idx];
+    v2[it] = a.w2b[idx];
+  }
+#pragma unroll
+  for (int it = 0; it < N; ++it) {
+    const int e = threadIdx.x + NTHREADS * it;
+    const int rb = e / LOHA_T, i = e % LOHA_T;
+    const bool ok = (r0 + rb < a.R) && (i0 + i < a.I);
+    sB1[rb * LH_BP + i] = ok ? v1[it] : 0.f;
+    sB2[rb * LH_BP + i] = ok ? v2[it] : 0.f;
+  }
+}
+
+// both factor pairs of tile (o0, i0), rank chunk r0 -> LDS
+__device__ __forceinline__ void lh_stage(const LohaArgs& a, bool vec, long o0, long i0, int r0, float* sA1, float* sA2,
+                                         float* sB1, float* sB2) {
+  if (vec) {
+    LhRaw w;
+    lh_load_vec(a, o0, i0, r0, w);
+    lh_store_vec(a, o0, i0, r0, w, sA1, sA2, sB1, sB2);
+  } else {
+    lh_stage_scalar(a, o0, i0, r0, sA1, sA2, sB1, sB2);
   }
 }
 
@@ -64,10 +150,10 @@ __global__ __launch_bounds__(NTHREADS) void loha_rebuild_mfma_kernel(LohaArgs a)
   f32x4 p1[4], p2[4];  // [ti]: rows i = 16 ti + 4 g + q, column o = 16 wave + li
 #pragma unroll
   for (int t = 0; t < 4; ++t) p1[t] = p2[t] = zero4();
+  const bool vec_in = lh_vec_ok(a);
   for (int r0 = 0; r0 < a.R; r0 += LOHA_RC) {
     if (r0) __syncthreads();
-    lh_stage_a(a, o0, r0, sA1, sA2);
-    lh_stage_b(a, i0, r0, sB1, sB2);
+    lh_stage(a, vec_in, o0, i0, r0, sA1, sA2, sB1, sB2);
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < LOHA_RC / 4; ++ks) {
@@ -145,6 +231,7 @@ __global__ __launch_bounds__(NTHREADS) void loha_factor_grad_mfma_kernel(LohaArg
   const long jb = (long)blockIdx.y * gm.nt;
   const long tiles_j = (a.I + LOHA_T - 1) / LOHA_T;
   const int nchunk = (a.R + LOHA_RC - 1) / LOHA_RC;
+  const bool vec_in = lh_vec_ok(a);
 
   f32x4 da1[NO][2], da2[NO][2];  // d_w*a of row tile os: rows o = 16 wave + 4 g + q, column r = 16 rt + li
 #pragma unroll
@@ -181,8 +268,7 @@ __global__ __launch_bounds__(NTHREADS) void loha_factor_grad_mfma_kernel(LohaArg
       for (int c = 0; c < 4; ++c) p1[c] = p2[c] = zero4();
       for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();  // previous users of the factor tiles / T tiles are done
-        lh_stage_a(a, o0, ch * LOHA_RC, sA1, sA2);
-        lh_stage_b(a, i0, ch * LOHA_RC, sB1, sB2);
+        lh_stage(a, vec_in, o0, i0, ch * LOHA_RC, sA1, sA2, sB1, sB2);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < LOHA_RC / 4; ++ks) {
@@ -210,8 +296,7 @@ __global__ __launch_bounds__(NTHREADS) void loha_factor_grad_mfma_kernel(LohaArg
       for (int ch = nchunk - 1; ch >= 0; --ch) {
         if (ch != nchunk - 1) {
           __syncthreads();
-          lh_stage_a(a, o0, ch * LOHA_RC, sA1, sA2);
-          lh_stage_b(a, i0, ch * LOHA_RC, sB1, sB2);
+          lh_stage(a, vec_in, o0, i0, ch * LOHA_RC, sA1, sA2, sB1, sB2);
         }
         __syncthreads();  // T tiles (and re-staged factors) visible
         if (os == 0 || nchunk > 1) {

@@ -16,7 +16,11 @@
 #include <torch/extension.h>
 #include <torch/library.h>
 
+#include <hip/hip_runtime_api.h>
+#include <torch/csrc/autograd/engine.h>
+
 #include <mutex>
+#include <vector>
 
 #include "../../include/lycoris_amd.h"
 
@@ -126,6 +130,80 @@ Tensor amp(const Tensor& x) {
   return x;
 }
 
+// ---- deferred, grouped weight gradients (lyc_lokr_wgrad_group) --------------------------------------------------------------
+// A factor gradient that is accumulated straight into `.grad` is invisible to autograd, so nothing in the backward pass waits
+// for it.  The backward node of such a layer runs only its dx launch, parks (g, x, ws) here, and the engine's end-of-backward
+// callback (or a full batch) hands all parked layers to ONE grouped launch per 24 layers: the per-layer launches were bound by
+// the latency chain of a single resident round of workgroups, a batch is throughput-bound.  MI355X has the memory for it:
+// the parked tensors of a whole SDXL backward are a few GB of 288.
+struct DeferredLokr {
+  Tensor g, x, f1, w1, w2, dw1, dw2, ws;
+  int64_t M;
+  int a, b, c, d, code;
+  float alpha;
+  void* stream;
+  c10::DeviceIndex device;
+};
+struct Deferred {
+  bool enabled = true;
+  size_t flush_at = 48;
+  std::mutex mu;
+  std::vector<DeferredLokr> lokr;
+  bool callback_queued = false;
+} g_defer;
+
+void flush_deferred() {
+  std::vector<DeferredLokr> items;
+  {
+    std::lock_guard<std::mutex> lock(g_defer.mu);
+    items.swap(g_defer.lokr);
+    g_defer.callback_queued = false;
+  }
+  if (items.empty()) return;
+  // one call per (device, stream, dtype) run of items, in arrival order
+  size_t lo = 0;
+  while (lo < items.size()) {
+    size_t hi = lo + 1;
+    while (hi < items.size() && items[hi].device == items[lo].device && items[hi].stream == items[lo].stream &&
+           items[hi].code == items[lo].code)
+      ++hi;
+    std::vector<LycLokrWgradItem> raw(hi - lo);
+    for (size_t i = lo; i < hi; ++i) {
+      const DeferredLokr& it = items[i];
+      raw[i - lo] = LycLokrWgradItem{cptr(it.g), cptr(it.x), cfp(it.f1), mfp(it.dw1), mfp(it.dw2), mptr(it.ws), it.M,
+                                     it.a, it.b, it.c, it.d, it.alpha};
+    }
+    const c10::DeviceGuard guard(c10::Device(c10::kCUDA, items[lo].device));
+    check_rc(lyc_lokr_wgrad_group(raw.data(), (int)raw.size(), items[lo].code, items[lo].stream), "lyc_lokr_wgrad_group");
+    void* cur = c10::hip::getCurrentHIPStream(items[lo].device).stream();
+    if (cur != items[lo].stream) {  // whoever consumes .grad on the ambient stream must see the late launches
+      hipEvent_t ev;
+      TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+      (void)hipEventRecord(ev, (hipStream_t)items[lo].stream);
+      (void)hipStreamWaitEvent((hipStream_t)cur, ev, 0);
+      (void)hipEventDestroy(ev);
+    }
+    lo = hi;
+  }
+  for (const DeferredLokr& it : items) {  // the gradients are enqueued: tell the DP sync (no lock held: this takes the GIL)
+    if (it.dw1.defined()) notify(it.w1);
+    notify(it.w2);
+  }
+}
+
+// called from a backward node (the engine has a current graph task: final callbacks may be installed)
+void park_deferred(DeferredLokr&& item) {
+  bool queue = false, full = false;
+  {
+    std::lock_guard<std::mutex> lock(g_defer.mu);
+    g_defer.lokr.push_back(std::move(item));
+    if (!g_defer.callback_queued) g_defer.callback_queued = queue = true;
+    full = g_defer.lokr.size() >= g_defer.flush_at;
+  }
+  if (queue) torch::autograd::Engine::get_default_engine().queue_callback([]() { flush_deferred(); });
+  if (full) flush_deferred();
+}
+
 // =====================================================================================================================
 // LoKr on nn.Linear
 // =====================================================================================================================
@@ -169,6 +247,33 @@ Tensor lokr_linear_bwd_into(const Tensor& g, const Tensor& x, const Tensor& w1, 
   return need_dx ? dx.view(x.sizes()) : Tensor();
 }
 
+// dx now, dw1 / dw2 later (park_deferred): returns false when the layer is not on the grouped fast path
+bool lokr_linear_bwd_deferred(const Tensor& g, const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, bool need_dx,
+                              const Tensor& dw1, const Tensor& dw2, Tensor& dx_out) {
+  const c10::DeviceGuard guard(x.device());
+  const int64_t a = w1.size(0), b = w1.size(1), c = w2.size(0), d = w2.size(1);
+  Tensor rows = rows_of(x, b * d), g2 = rows_of(g, a * c);
+  const int code = dtype_code(x.scalar_type());
+  if (!lyc_lokr_wgrad_deferrable(cptr(g2), cptr(rows), rows.size(0), (int)a, (int)b, (int)c, (int)d, code)) return false;
+  Tensor f1 = f32c(w1), f2 = f32c(w2), dx, ws;
+  const bool want_dx = need_dx || dw1.defined();
+  if (want_dx) {
+    dx = at::empty(rows.sizes(), x.options());
+    if (dw1.defined()) {
+      const int64_t nbytes = lyc_lokr_bwd_workspace_bytes(rows.size(0), (int)a, (int)b, (int)c, (int)d, code);
+      TORCH_CHECK(nbytes > 0, "lycoris_amd: deferrable layer without a dw1 workspace");
+      ws = at::empty({nbytes}, x.options().dtype(at::kByte));
+    }
+    check_rc(lyc_lokr_linear_bwd(cptr(g2), cptr(rows), cfp(f1), cfp(f2), mptr(dx), mfp(dw1), nullptr, mptr(ws), rows.size(0),
+                                 (int)a, (int)b, (int)c, (int)d, (float)alpha, code | LYC_DEFER_WGRAD, stream_of(x)),
+             "lyc_lokr_linear_bwd(dx)");
+  }
+  park_deferred(DeferredLokr{g2, rows, f1, w1, w2, dw1, dw2, ws, rows.size(0), (int)a, (int)b, (int)c, (int)d, code,
+                             (float)alpha, stream_of(x), x.device().index()});
+  dx_out = need_dx ? dx.view(x.sizes()) : Tensor();
+  return true;
+}
+
 std::tuple<Tensor, Tensor, Tensor> lokr_linear_bwd(const Tensor& g, const Tensor& x, const Tensor& w1, const Tensor& w2,
                                                    double alpha, bool need_dx, bool need_dw1, bool need_dw2) {
   Tensor dw1 = need_dw1 ? at::zeros(w1.sizes(), w1.options().dtype(at::kFloat)) : Tensor();
@@ -200,6 +305,11 @@ struct LokrLinearFn : public torch::autograd::Function<LokrLinearFn> {
     Tensor g = grads[0];
     if (eager_cuda(g) && eager_cuda(x)) {  // eager: accumulate straight into .grad where possible
       GradTarget t1 = grad_target(w1, n1 || accum_wanted(w1)), t2 = grad_target(w2, n2 || accum_wanted(w2));
+      if (g_defer.enabled && t2.buf.defined() && !t2.hand_back && !(t1.buf.defined() && t1.hand_back)) {
+        Tensor dx;
+        if (lokr_linear_bwd_deferred(g, x, w1, w2, alpha, nx, t1.buf, t2.buf, dx))
+          return {dx, Tensor(), Tensor(), Tensor(), nb ? g : Tensor()};
+      }
       Tensor dx = lokr_linear_bwd_into(g, x, w1, w2, alpha, nx, t1.buf, t2.buf);
       return {dx, finish_grad(w1, t1), finish_grad(w2, t2), Tensor(), nb ? g : Tensor()};  // d(base + delta)/d base = 1
     }
@@ -802,5 +912,26 @@ PYBIND11_MODULE(_lyc_torch, m) {
     *g_accum.callback = std::move(callback);
   });
   m.def("accum_enabled", []() { return g_accum.enabled; });
+  m.def("set_defer", [](bool enabled, int flush_at) {
+    std::lock_guard<std::mutex> lk(g_defer.mu);
+    g_defer.enabled = enabled;
+    if (flush_at > 0) g_defer.flush_at = (size_t)flush_at;
+  }, py::arg("enabled"), py::arg("flush_at") = 0);
+  m.def("defer_enabled", []() { return g_defer.enabled; });
+  m.def("deferred_pending", []() {
+    std::lock_guard<std::mutex> lk(g_defer.mu);
+    return g_defer.lokr.size();
+  });
+  m.def("flush_deferred", []() {
+    py::gil_scoped_release nogil;  // flush_deferred() notifies through a callback that takes the GIL itself
+    flush_deferred();
+  });
+  m.def("discard_deferred", []() {  // after a failed backward: drop parked layers instead of adding them to the next step
+    std::vector<DeferredLokr> items;
+    std::lock_guard<std::mutex> lk(g_defer.mu);
+    items.swap(g_defer.lokr);
+    g_defer.callback_queued = false;
+    return items.size();
+  });
   m.def("abi_version", []() { return lyc_abi_version(); });
 }

@@ -54,6 +54,27 @@ def fused_grad_accumulation(enabled: bool = True, callback=None):
         _DISPATCH["ext"].set_accum(bool(enabled), callback)
 
 
+def deferred_weight_gradients(enabled: bool = True, flush_at: int = 48):
+    """LoKr layers whose factor gradients are accumulated straight into `.grad` (fused_grad_accumulation) run only their
+    dx launch inside the backward pass; dW1 / dW2 of up to `flush_at` parked layers are then computed by ONE grouped launch
+    per 24 layers (lyc_lokr_wgrad_group) -- at the latest when the autograd engine finishes the pass, so `.grad` is complete
+    when `backward()` returns.  On by default; `enabled=False` restores one weight-gradient launch per layer."""
+    if not _cpp():
+        raise RuntimeError("deferred weight gradients live in the C++ dispatch (ops.set_dispatch('cpp'))")
+    _DISPATCH["ext"].set_defer(bool(enabled), int(flush_at))
+
+
+def flush_deferred():
+    """Enqueue the weight gradients of every parked layer now (the engine does this by itself at the end of a backward pass)."""
+    if _DISPATCH["ext"] is not None:
+        _DISPATCH["ext"].flush_deferred()
+
+
+def discard_deferred() -> int:
+    """After a backward pass that raised: drop the parked layers so that they are not added to the next step."""
+    return _DISPATCH["ext"].discard_deferred() if _DISPATCH["ext"] is not None else 0
+
+
 def _grad_targets(factors, needs):
     """Per factor: the tensor the kernel should accumulate into (existing .grad or a fresh zero buffer) and whether
     the result has to be handed back to autograd."""

@@ -1,0 +1,192 @@
+"""GPU: deferred, grouped LoKr weight gradients (lyc_lokr_linear_bwd | LYC_DEFER_WGRAD + lyc_lokr_wgrad_group,
+csrc/kron_dw2s.h: kron_dw2s_group_kernel; host side csrc/torch_ops.cpp: park_deferred / flush_deferred).
+
+The grouped launch computes the same autograd products as the per-layer launches (reference: the factor gradients of
+lycoris/modules/lokr.py:543-566), only scheduled together, so the checks are: (a) C ABI: a batch of layers of every tile
+configuration, more than one launch's worth of them, a parameter that appears twice, against the oracle and against the
+per-layer entry point; (b) custom ops: `.grad` is complete when backward() returns, with any flush threshold, and the
+grad-sync callback hears about every parameter exactly once per backward."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import oracle
+from gpu_util import TOL, err, rnd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+DEFER = 0x200  # LYC_DEFER_WGRAD
+
+# (M, a = b, c, d): SDXL attention (32x32 tiles, 20 slabs when launched alone), the 77-token context, a 640-wide layer,
+# a problem on the 64x64 tile configuration (M * a >= 16 k rows), ragged rows / tiny factors, a single row
+SHAPES = [(1024, 8, 160, 160), (77, 8, 160, 256), (4096, 8, 80, 80), (4096, 8, 128, 128), (50, 4, 16, 8), (1, 8, 40, 160),
+          (333, 16, 24, 40)]
+
+
+def _problem(gen, M, a, c, d, dtype):
+    """device tensors (g, x, w1, w2) and the float64 numpy arrays of the same (already rounded) values"""
+    x, x64 = rnd((M, a * d), dtype, gen)
+    g, g64 = rnd((M, a * c), dtype, gen, 0.1)
+    w1, w164 = rnd((a, a), torch.float32, gen, 0.3)
+    w2, w264 = rnd((c, d), torch.float32, gen, 0.1)
+    return (g, x, w1, w2), (g64, x64, w164, w264)
+
+
+def _oracle(h, alpha):
+    g64, x64, w1, w2 = h
+    gr = oracle.lokr.backward(x64, g64, w1=w1, w2=w2, scale=alpha)
+    return gr["w1"], gr["w2"]
+
+
+def _per_layer(N, g, x, w1, w2, alpha, code):  # (g, x, w1, w2): device tensors
+    M, (a, b), (c, d) = x.shape[0], w1.shape, w2.shape
+    dx = torch.empty_like(x)
+    dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
+    ws = torch.empty(max(int(N.load().lyc_lokr_bwd_workspace_bytes(M, a, b, c, d, code)), 16), dtype=torch.uint8, device=DEV)
+    N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(x), N.ptr(w1), N.ptr(w2), N.ptr(dx), N.ptr(dw1), N.ptr(dw2), N.ptr(ws),
+           M, a, b, c, d, alpha, code, N.stream_ptr(x.device))
+    return dx, dw1, dw2
+
+
+def _deferred(N, probs, alpha, code, shared=()):
+    """dx launches with LYC_DEFER_WGRAD, then ONE lyc_lokr_wgrad_group call over all problems.  `shared`: pairs (i, j) of
+    problems whose dw1 / dw2 are the SAME buffers (a module applied twice)."""
+    items = (N.WgradItem * len(probs))()
+    keep, outs = [], []
+    alias = dict(shared)
+    for k, (g, x, w1, w2) in enumerate(probs):
+        M, (a, b), (c, d) = x.shape[0], w1.shape, w2.shape
+        dx = torch.empty_like(x)
+        if k in alias:
+            dw1, dw2 = outs[alias[k]][1], outs[alias[k]][2]
+        else:
+            dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
+        ws = torch.empty(max(int(N.load().lyc_lokr_bwd_workspace_bytes(M, a, b, c, d, code)), 16), dtype=torch.uint8, device=DEV)
+        assert N.load().lyc_lokr_wgrad_deferrable(N.ptr(g), N.ptr(x), M, a, b, c, d, code) == 1
+        N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(x), N.ptr(w1), N.ptr(w2), N.ptr(dx), N.ptr(dw1), None, N.ptr(ws),
+               M, a, b, c, d, alpha, code | DEFER, N.stream_ptr(x.device))
+        items[k] = N.WgradItem(N.ptr(g), N.ptr(x), N.ptr(w1), N.ptr(dw1), N.ptr(dw2), N.ptr(ws), M, a, b, c, d, alpha)
+        keep.append(ws)
+        outs.append((dx, dw1, dw2))
+    N.call("lyc_lokr_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(probs), code, N.stream_ptr(probs[0][1].device))
+    torch.cuda.synchronize()
+    return outs
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_grouped_weight_gradients_match_the_oracle_and_the_per_layer_path(dtype):
+    from lycoris_amd import _native as N
+    gen = torch.Generator().manual_seed(11)
+    code = N.dtype_code(dtype)
+    alpha = 0.7
+    both = [_problem(gen, *s, dtype) for s in SHAPES]
+    both += [_problem(gen, 64, 8, 16, 16, dtype) for _ in range(30)]  # > 24 items of one configuration: two launches
+    probs, host = [b[0] for b in both], [b[1] for b in both]
+    got = _deferred(N, probs, alpha, code)
+    bound = TOL["f32_out"][dtype]
+    for k, (h, (dx, dw1, dw2)) in enumerate(zip(host, got)):
+        r1, r2 = _oracle(h, alpha)
+        assert err(dw1, r1) <= bound, (k, "dw1", err(dw1, r1))
+        assert err(dw2, r2) <= bound, (k, "dw2", err(dw2, r2))
+        if k < len(SHAPES):  # dx is the same launch with or without the flag
+            px, p1, p2 = _per_layer(N, *probs[k], alpha, code)
+            assert torch.equal(dx, px), k
+            assert err(dw1, p1.double().cpu().numpy()) <= 1e-5 and err(dw2, p2.double().cpu().numpy()) <= 1e-5, k
+
+
+def test_a_parameter_that_appears_twice_in_one_group_is_added_atomically():
+    from lycoris_amd import _native as N
+    gen = torch.Generator().manual_seed(12)
+    dtype, alpha = torch.bfloat16, 1.0
+    code = N.dtype_code(dtype)
+    (ga, xa, w1, w2), ha = _problem(gen, 256, 8, 32, 32, dtype)   # one slab each: the plain (non-atomic) store path when alone
+    (gb, xb, _, _), hb = _problem(gen, 256, 8, 32, 32, dtype)
+    hb = (hb[0], hb[1], ha[2], ha[3])
+    got = _deferred(N, [(ga, xa, w1, w2), (gb, xb, w1, w2)], alpha, code, shared=[(1, 0)])
+    a1, a2 = _oracle(ha, alpha)
+    b1, b2 = _oracle(hb, alpha)
+    assert got[0][1].data_ptr() == got[1][1].data_ptr()
+    bound = TOL["f32_out"][dtype]
+    assert err(got[0][1], a1 + b1) <= bound and err(got[0][2], a2 + b2) <= bound
+
+
+def test_group_call_rejects_what_it_cannot_run():
+    from lycoris_amd import _native as N
+    x = torch.zeros(8, 24, device=DEV, dtype=torch.float32)
+    assert N.load().lyc_lokr_wgrad_deferrable(N.ptr(x), N.ptr(x), 8, 4, 4, 6, 6, N.LYC_F32) == 0   # fp32 activations
+    assert N.load().lyc_lokr_wgrad_deferrable(N.ptr(x), N.ptr(x), 8, 4, 4, 6, 6, N.LYC_BF16) == 0  # c, d not multiples of 8
+    items = (N.WgradItem * 1)()
+    items[0] = N.WgradItem(N.ptr(x), N.ptr(x), N.ptr(x), None, N.ptr(x), None, 8, 4, 4, 6, 6, 1.0)
+    with pytest.raises(RuntimeError, match="fast path"):
+        N.call("lyc_lokr_wgrad_group", ctypes.cast(items, ctypes.c_void_p), 1, N.LYC_BF16, None)
+    N.call("lyc_lokr_wgrad_group", None, 0, N.LYC_BF16, None)  # an empty batch is fine
+
+
+class _Stack(nn.Module):
+    """a few LoKr-adapted layers in sequence, one of them applied twice (weight sharing inside one backward)"""
+
+    def __init__(self, n=5, a=8, c=16, d=16):
+        super().__init__()
+        self.w1 = nn.ParameterList([nn.Parameter(torch.randn(a, a, device=DEV) * 0.3) for _ in range(n)])
+        self.w2 = nn.ParameterList([nn.Parameter(torch.randn(c, d, device=DEV) * 0.1) for _ in range(n)])
+
+    def forward(self, x):
+        from lycoris_amd import ops
+        order = list(range(len(self.w1))) + [1]
+        for i in order:
+            x = x + ops.lokr_linear(x, self.w1[i], self.w2[i], 0.5)
+        return x
+
+
+@pytest.mark.parametrize("flush_at", [48, 2], ids=["end_of_backward", "every_2_layers"])
+def test_grads_are_complete_when_backward_returns_and_every_parameter_is_reported(flush_at):
+    from lycoris_amd import ops
+    torch.manual_seed(5)
+    net = _Stack()
+    x = (torch.randn(96, 128, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    gy = (torch.randn(96, 128, device=DEV) * 0.1).to(torch.bfloat16)
+    params = list(net.parameters())
+
+    def run(defer):
+        seen = []
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        x.grad = None
+        ops.fused_grad_accumulation(True, callback=lambda p: seen.append(id(p)))
+        ops.deferred_weight_gradients(defer, flush_at)
+        try:
+            net(x).backward(gy)
+            assert ops._DISPATCH["ext"].deferred_pending() == 0  # nothing parked once backward() has returned
+            torch.cuda.synchronize()
+            return x.grad.clone(), [p.grad.clone() for p in params], seen
+        finally:
+            ops.fused_grad_accumulation(False, None)
+            ops.deferred_weight_gradients(True, 48)
+
+    dx0, g0, seen0 = run(False)
+    dx1, g1, seen1 = run(True)
+    assert torch.equal(dx0, dx1)
+    for p, u, v in zip(params, g0, g1):
+        assert float(u.abs().max()) > 0
+        assert torch.allclose(u, v, rtol=2e-4, atol=1e-6), float((u - v).abs().max())
+    # 6 layer calls, two parameters each -- the shared layer is reported once per call, in both modes
+    assert sorted(seen0) == sorted(seen1) and len(seen1) == 12
+
+
+def test_parameters_without_a_grad_buffer_are_not_deferred():
+    """plain autograd (gradients handed back to the engine) keeps the per-layer launches"""
+    from lycoris_amd import ops
+    net = _Stack(n=2)
+    x = (torch.randn(32, 128, device=DEV)).to(torch.bfloat16).requires_grad_(True)
+    ops.fused_grad_accumulation(True, None)
+    try:
+        y = net(x)
+        grads = torch.autograd.grad(y, list(net.parameters()), torch.ones_like(y) * 0.01)
+        assert all(g is not None and float(g.abs().max()) > 0 for g in grads)
+        assert ops._DISPATCH["ext"].deferred_pending() == 0
+    finally:
+        ops.fused_grad_accumulation(False, None)
