@@ -1,0 +1,92 @@
+// wgbench.cpp -- timing of the grouped LoKr weight-gradient launches (lyc_lokr_wgrad_group) over the SDXL layer mix, with the
+// library source compiled IN (so that the LYC_WG_* plan constants of capi.hip can be varied per binary):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ilycoris_amd/csrc -DLYC_WG_TARGET=64 benchmarks/wgbench.cpp -o wgbench_t64 -lrocblas
+// Prints ms per call and algorithmic GB/s (g + x read once) per shape class and for the whole SDXL Linear mix.
+#include "../lycoris_amd/csrc/capi.hip"
+
+#include <cstdio>
+#include <random>
+#include <vector>
+
+struct Shape {
+  long M;
+  int a, c, d, count;
+  const char* tag;
+};
+
+#define CK(x)                                                              \
+  do {                                                                     \
+    hipError_t e_ = (x);                                                   \
+    if (e_ != hipSuccess) {                                                \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));              \
+      return 1;                                                            \
+    }                                                                      \
+  } while (0)
+
+int main() {
+  const std::vector<Shape> sdxl = {{1024, 8, 160, 160, 372, "attn/proj @1280"}, {1024, 8, 1280, 160, 60, "ff.net.0 @1280"},
+                                   {1024, 8, 160, 640, 60, "ff.net.2 @1280"},  {4096, 8, 80, 80, 70, "attn/proj @640"},
+                                   {4096, 8, 640, 80, 10, "ff.net.0 @640"},    {4096, 8, 80, 320, 10, "ff.net.2 @640"},
+                                   {77, 8, 160, 256, 120, "attn2 k/v @1280"},  {77, 8, 80, 256, 20, "attn2 k/v @640"}};
+  std::vector<LycLokrWgradItem> all;
+  std::vector<std::pair<size_t, size_t>> range;  // items of each shape class
+  std::mt19937 rng(7);
+  std::vector<unsigned short> host;
+  double total_bytes = 0;
+  std::vector<double> class_bytes;
+  for (const Shape& s : sdxl) {
+    const size_t lo = all.size();
+    const size_t ng = (size_t)s.M * s.a * s.c, nx = (size_t)s.M * s.a * s.d;
+    for (int k = 0; k < s.count; ++k) {
+      void *g, *x;
+      float *w1, *dw2;
+      CK(hipMalloc(&g, ng * 2));
+      CK(hipMalloc(&x, nx * 2));
+      CK(hipMalloc((void**)&w1, 64 * 4));
+      CK(hipMalloc((void**)&dw2, (size_t)s.c * s.d * 4));
+      host.resize(ng > nx ? ng : nx);
+      for (auto& v : host) v = (unsigned short)(0x3c00 + (rng() & 0x1ff));  // bf16 values around 0.01
+      CK(hipMemcpy(g, host.data(), ng * 2, hipMemcpyHostToDevice));
+      CK(hipMemcpy(x, host.data(), nx * 2, hipMemcpyHostToDevice));
+      CK(hipMemset(w1, 0, 64 * 4));
+      CK(hipMemset(dw2, 0, (size_t)s.c * s.d * 4));
+      all.push_back(LycLokrWgradItem{g, x, w1, nullptr, dw2, nullptr, s.M, s.a, s.a, s.c, s.d, 1.0f});
+    }
+    range.push_back({lo, all.size()});
+    class_bytes.push_back((double)s.count * 2.0 * (ng + nx));
+    total_bytes += class_bytes.back();
+  }
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  auto time_call = [&](const LycLokrWgradItem* it, int n, float& ms) -> int {
+    const int reps = 5;
+    if (lyc_lokr_wgrad_group(it, n, LYC_BF16, st)) { fprintf(stderr, "%s\n", lyc_last_error()); return 1; }
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r) lyc_lokr_wgrad_group(it, n, LYC_BF16, st);
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    return 0;
+  };
+  printf("plan: target %d  maxrows %d  big_rows %d  U %d  wide %d\n", LYC_WG_TARGET, LYC_WG_MAXROWS, LYC_WG_BIG_ROWS, LYC_WG_U,
+         LYC_WG_WIDE);
+  for (size_t c = 0; c < sdxl.size(); ++c) {
+    float ms = 0;
+    if (time_call(all.data() + range[c].first, (int)(range[c].second - range[c].first), ms)) return 1;
+    KronDw2sArgs da{};
+    da.M = sdxl[c].M; da.G = sdxl[c].a; da.I = sdxl[c].c; da.J = sdxl[c].d;
+    const int cfg = plan_dw2s(da, true);
+    printf("%-18s M %5ld c %4d d %4d x%3d : %8.3f ms  %6.2f us/problem  %7.1f GB/s   tile %s  slabs %d  rows/slab %ld\n", sdxl[c].tag,
+           sdxl[c].M, sdxl[c].c, sdxl[c].d, sdxl[c].count, ms, ms * 1e3 / sdxl[c].count, class_bytes[c] / (ms * 1e-3) / 1e9,
+           cfg == DW2_T44 ? "64x64" : cfg == DW2_T52 ? "80x32" : "32x32", da.nsplit, da.rows_per_block);
+  }
+  float ms = 0;
+  if (time_call(all.data(), (int)all.size(), ms)) return 1;
+  printf("SDXL Linear mix, %zu problems in one call: %8.3f ms  %7.1f GB/s\n", all.size(), ms, total_bytes / (ms * 1e-3) / 1e9);
+  return 0;
+}

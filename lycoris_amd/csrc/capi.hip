@@ -144,8 +144,26 @@ void launch_dw2s_inst(KronDw2sArgs da, long tiles_i, long tiles_j, hipStream_t s
 // fills rows_per_block / nsplit / dw1_red / tiles of `da`; returns true for the 64 x 64 tile, false for 32 x 32
 // `grouped`: the problem is one of many in a launch (kron_dw2s_group_kernel): parallelism comes from the other problems, so
 // fewer, longer row slabs (less atomic traffic, the set-up of a workgroup amortised over more rows)
-bool plan_dw2s(KronDw2sArgs& da, bool grouped = false) {
-  const int target_blocks = grouped ? 128 : 512;  // single launch: one resident round, 2 workgroups per CU
+// (the LYC_WG_* macros exist for benchmarks/wgbench.cpp, which compiles this file with other values)
+#ifndef LYC_WG_TARGET
+#define LYC_WG_TARGET 128
+#endif
+#ifndef LYC_WG_MAXROWS
+#define LYC_WG_MAXROWS 4096
+#endif
+#ifndef LYC_WG_BIG_ROWS
+#define LYC_WG_BIG_ROWS 16384
+#endif
+#ifndef LYC_WG_U
+#define LYC_WG_U 2
+#endif
+#ifndef LYC_WG_WIDE
+#define LYC_WG_WIDE 2
+#endif
+// tile configurations of kron_dw2s_kernel: (MI, NJ, U)
+enum { DW2_T22 = 0, DW2_T44 = 1, DW2_T52 = 2, DW2_NCFG = 3 };
+int plan_dw2s(KronDw2sArgs& da, bool grouped = false) {
+  const int target_blocks = grouped ? LYC_WG_TARGET : 512;  // single launch: one resident round, 2 workgroups per CU
   constexpr int atomic_budget = 620000;    // fp32 atomics per launch (~300 / ns)
   const long rows_total = da.M * da.G;
   auto plan = [&](int mi, int nj, long& tiles, long& split) {
@@ -165,14 +183,23 @@ bool plan_dw2s(KronDw2sArgs& da, bool grouped = false) {
   // do 4x the matrix work per loaded byte: they win whenever there are enough rows to split (measured: M*G >= 16k) and
   // the padding of I, J to multiples of 64 does not waste more than half of the tile.
   const double eff44 = (double)da.I * da.J / ((double)round_up(da.I, 64) * round_up(da.J, 64));
-  bool big = rows_total >= 16384 && eff44 >= 0.5;
-  long split = big ? s44 : s22;
-  const long tiles = big ? t44 : t22;
+  bool big = rows_total >= (grouped ? LYC_WG_BIG_ROWS : 16384) && eff44 >= 0.5;
+  // grouped launches are instruction-bound (benchmarks/wgbench.cpp, profiles/r02_wgbench_sweep*.log), and most of a step's
+  // instructions belong to the MIXED operand (G x G mix on the matrix cores + hi/lo split of its result), whose cost goes with
+  // the tile's J extent only: an 80 x 32 tile does 2.5x the output per mixed column (SDXL mix: 4.65 -> 3.62 ms; it also beats
+  // the 64 x 64 tile, which runs at one wave per SIMD).  Every SDXL / SD1.5 w2 has c = O / 8 a multiple of 80 or 40.
+  const bool wide = grouped && LYC_WG_WIDE && (LYC_WG_WIDE == 2 || !big) && da.I >= 80 &&
+                    (double)da.I / (double)round_up(da.I, 80) >= 0.8;
+  if (wide) big = false;
+  long t52 = 0, s52 = 0;
+  if (wide) plan(5, 2, t52, s52);
+  long split = wide ? s52 : big ? s44 : s22;
+  const long tiles = wide ? t52 : big ? t44 : t22;
   while (split > 1 && tiles * split > target_blocks) --split;  // one resident round: 2 workgroups per CU
   if (grouped) {  // ... but no slab longer than 4096 rows (the tail of the launch), atomic budget permitting
     long smax = atomic_budget / ((long)da.I * da.J);
     if (smax < 1) smax = 1;
-    while (split < smax && cdiv(rows_total, split) > 4096) ++split;
+    while (split < smax && cdiv(rows_total, split) > LYC_WG_MAXROWS) ++split;
   }
   if (split > 8) {
     // the work items are dealt to the 8 XCDs in contiguous eighths of the slab-major order (kernel block mapping): with a
@@ -190,14 +217,14 @@ bool plan_dw2s(KronDw2sArgs& da, bool grouped = false) {
     if (r < 1) r = 1;
     da.dw1_red = (int)r;
   }
-  da.tiles_i = (int)cdiv(da.I, big ? 64 : 32);
+  da.tiles_i = (int)cdiv(da.I, wide ? 80 : big ? 64 : 32);
   da.tiles_j = (int)cdiv(da.J, big ? 64 : 32);
-  return big;
+  return wide ? DW2_T52 : big ? DW2_T44 : DW2_T22;
 }
 
 template <typename T>
 void launch_dw2s(KronDw2sArgs da, hipStream_t st) {
-  if (plan_dw2s(da)) launch_dw2s_inst<T, 4, 4, 1>(da, da.tiles_i, da.tiles_j, st);
+  if (plan_dw2s(da) == DW2_T44) launch_dw2s_inst<T, 4, 4, 1>(da, da.tiles_i, da.tiles_j, st);
   else launch_dw2s_inst<T, 2, 2, 4>(da, da.tiles_i, da.tiles_j, st);
 }
 
@@ -556,8 +583,8 @@ int lyc_lokr_wgrad_group(const LycLokrWgradItem* items, int n, int dtype, void* 
   if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "lokr_wgrad_group: bad item list");
   hipStream_t st = (hipStream_t)stream;
   const int dt = dtype & 0xff;
-  // two tile configurations (plan_dw2s): each gets its own sequence of launches, items keep their order
-  for (int big = 0; big < 2; ++big) {
+  // one sequence of launches per tile configuration (plan_dw2s), items keep their order
+  for (int cfg = 0; cfg < DW2_NCFG; ++cfg) {
     KronDw2sGroupArgs ga{};
     auto flush = [&]() -> int {
       if (ga.n == 0) return LYC_OK;
@@ -566,18 +593,20 @@ int lyc_lokr_wgrad_group(const LycLokrWgradItem* items, int n, int dtype, void* 
           if (ga.p[i].out == ga.p[j].out || (ga.p[i].dw1 && ga.p[i].dw1 == ga.p[j].dw1))
             ga.p[i].force_atomic = ga.p[j].force_atomic = 1;
       if (dt == LYC_BF16) {
-        if (big) launch_dw2s_group<__bf16, 4, 4, 1>(ga, st);
-        else launch_dw2s_group<__bf16, 2, 2, 4>(ga, st);
+        if (cfg == DW2_T44) launch_dw2s_group<__bf16, 4, 4, 1>(ga, st);
+        else if (cfg == DW2_T52) launch_dw2s_group<__bf16, 5, 2, 1>(ga, st);
+        else launch_dw2s_group<__bf16, 2, 2, LYC_WG_U>(ga, st);
       } else {
-        if (big) launch_dw2s_group<_Float16, 4, 4, 1>(ga, st);
-        else launch_dw2s_group<_Float16, 2, 2, 4>(ga, st);
+        if (cfg == DW2_T44) launch_dw2s_group<_Float16, 4, 4, 1>(ga, st);
+        else if (cfg == DW2_T52) launch_dw2s_group<_Float16, 5, 2, 1>(ga, st);
+        else launch_dw2s_group<_Float16, 2, 2, LYC_WG_U>(ga, st);
       }
       ga = KronDw2sGroupArgs{};
       return check_launch("lokr_wgrad_group");
     };
     for (int k = 0; k < n; ++k) {
       const LycLokrWgradItem& it = items[k];
-      if (big == 0) {  // validate once
+      if (cfg == 0) {  // validate once
         if (int rc = check_kron_dims(it.M, it.a, it.b, it.c, it.d)) return rc;
         if (!it.g || !it.x || !it.w1 || !it.dw2) return fail(LYC_ERR_ARG, "lokr_wgrad_group: item %d: null pointer", k);
         if (!lokr_wgrad_fast(it.g, it.x, it.M, it.a, it.b, it.c, it.d, dtype))
@@ -595,7 +624,7 @@ int lyc_lokr_wgrad_group(const LycLokrWgradItem* items, int n, int dtype, void* 
         da.dw1_nblk = (int)(cdiv(it.M, K3_RT / it.a) * cdiv(it.d, 16 * ni));
         da.dw1_red = 1;
       }
-      if ((plan_dw2s(da, true) ? 1 : 0) != big) continue;
+      if (plan_dw2s(da, true) != cfg) continue;
       const long wgs = round_up((long)da.tiles_i * da.tiles_j * da.nsplit, 8) + round_up(da.dw1_ws ? da.dw1_red : 0, 8);
       const long before = ga.n ? ga.wg_end[ga.n - 1] : 0;
       if (ga.n == DW2G_MAX || before + wgs > (1L << 30))

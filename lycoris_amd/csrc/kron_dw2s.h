@@ -349,7 +349,7 @@ __device__ __forceinline__ void kron_dw2s_body(const KronDw2sArgs& a, char* smem
 
   // cross-wave reduction through LDS: every wave publishes its tiles, wave w sums and stores tiles t = w (mod 4)
   float* red = reinterpret_cast<float*>(smem);
-  constexpr int NT = MI * NJ, TB = NT < 8 ? NT : 8;  // tiles per batch (LDS budget)
+  constexpr int NT = MI * NJ, TB = NT < 8 ? NT : 8;  // tiles per batch (LDS budget); NT need not be a multiple of TB
   const bool plain = a.nsplit == 1 && !a.force_atomic;
   LYC_STAMP(4);
 #pragma unroll
@@ -357,13 +357,16 @@ __device__ __forceinline__ void kron_dw2s_body(const KronDw2sArgs& a, char* smem
     __syncthreads();  // the staging tiles (or the previous batch) are dead
 #pragma unroll
     for (int t = 0; t < TB; ++t) {
-      const int mi = (t0 + t) / NJ, nj = (t0 + t) % NJ;
-      *reinterpret_cast<f32x4*>(red + (wave * TB + t) * 256 + lane * 4) = acc[mi][nj];
+      if (t0 + t < NT) {
+        const int mi = (t0 + t) / NJ, nj = (t0 + t) % NJ;
+        *reinterpret_cast<f32x4*>(red + (wave * TB + t) * 256 + lane * 4) = acc[mi][nj];
+      }
     }
     __syncthreads();
 #pragma unroll
-    for (int tt = 0; tt < TB / NWAVES; ++tt) {
+    for (int tt = 0; tt < (TB + NWAVES - 1) / NWAVES; ++tt) {
       const int t = tt * NWAVES + wave;  // this wave's tile of the batch
+      if (t >= TB || t0 + t >= NT) continue;
       const int mi = (t0 + t) / NJ, nj = (t0 + t) % NJ;
       f32x4 s = zero4();
 #pragma unroll
