@@ -37,27 +37,19 @@ int main(int argc, char** argv) {
       const int ni = getenv("KT_NI") ? atoi(getenv("KT_NI")) : 2;   // production picks 2 for the 1280-wide layers
       const int gm = getenv("KT_GM") ? atoi(getenv("KT_GM")) : 3;   // 3 = x through the per-wave LDS stage (production)
       dim3 grid((unsigned)cdiv(M, K3_RT / G), (unsigned)cdiv(ka.N, 16 * ni));
-      const int lds4 = kron3_lds_bytes(4, 2) + kron3_xs_bytes(), lds2 = kron3_lds_bytes(2, 2) + kron3_xs_bytes();
-      const int lds1 = kron3_lds_bytes(1, 2) + kron3_xs_bytes();
-      if (ni == 1 && gm == 3) {
-        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 1, true, 3>), grid, dim3(NTHREADS), lds1, 0, ka);
-        else hipLaunchKernelGGL((kron3_kernel<__bf16, 1, false, 3>), grid, dim3(NTHREADS), lds1, 0, ka);
-      } else if (ni == 1) {
-        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 1, true, 0>), grid, dim3(NTHREADS), lds1, 0, ka);
-        else hipLaunchKernelGGL((kron3_kernel<__bf16, 1, false, 0>), grid, dim3(NTHREADS), lds1, 0, ka);
-      } else if (ni == 4 && gm == 3) {
-        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 4, true, 3>), grid, dim3(NTHREADS), lds4, 0, ka);
-        else hipLaunchKernelGGL((kron3_kernel<__bf16, 4, false, 3>), grid, dim3(NTHREADS), lds4, 0, ka);
-      } else if (ni == 4) {
-        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 4, true, 0>), grid, dim3(NTHREADS), lds4, 0, ka);
-        else hipLaunchKernelGGL((kron3_kernel<__bf16, 4, false, 0>), grid, dim3(NTHREADS), lds4, 0, ka);
-      } else if (gm == 3) {
-        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 2, true, 3>), grid, dim3(NTHREADS), lds2, 0, ka);
-        else hipLaunchKernelGGL((kron3_kernel<__bf16, 2, false, 3>), grid, dim3(NTHREADS), lds2, 0, ka);
-      } else {
-        if (bw) hipLaunchKernelGGL((kron3_kernel<__bf16, 2, true, 0>), grid, dim3(NTHREADS), lds2, 0, ka);
-        else hipLaunchKernelGGL((kron3_kernel<__bf16, 2, false, 0>), grid, dim3(NTHREADS), lds2, 0, ka);
-      }
+      const long nseg = cdiv(ka.K, kron3_kc(ni));
+      const int lds = kron3_lds_bytes(ni, nseg > 1 ? 2 : 1) + (gm == 3 ? kron3_xs_bytes() : 0);
+      auto go = [&](auto kern) {
+        if (rep == 0) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, 0, ka);
+        CK(hipGetLastError());
+      };
+      if (ni == 1 && gm == 3) { if (bw) go(kron3_kernel<__bf16, 1, true, 3>); else go(kron3_kernel<__bf16, 1, false, 3>); }
+      else if (ni == 1) { if (bw) go(kron3_kernel<__bf16, 1, true, 0>); else go(kron3_kernel<__bf16, 1, false, 0>); }
+      else if (ni == 4 && gm == 3) { if (bw) go(kron3_kernel<__bf16, 4, true, 3>); else go(kron3_kernel<__bf16, 4, false, 3>); }
+      else if (ni == 4) { if (bw) go(kron3_kernel<__bf16, 4, true, 0>); else go(kron3_kernel<__bf16, 4, false, 0>); }
+      else if (gm == 3) { if (bw) go(kron3_kernel<__bf16, 2, true, 3>); else go(kron3_kernel<__bf16, 2, false, 3>); }
+      else { if (bw) go(kron3_kernel<__bf16, 2, true, 0>); else go(kron3_kernel<__bf16, 2, false, 0>); }
       if (rep == 0) printf("grid %u x %u\n", grid.x, grid.y);
     }
     if (!strcmp(mode, "dw2")) {

@@ -76,6 +76,23 @@ typedef struct LycLokrWgradItem {
 int lyc_lokr_wgrad_deferrable(const void* g, const void* x, int64_t M, int a, int b, int c, int d, int dtype);
 int lyc_lokr_wgrad_group(const LycLokrWgradItem* items, int n, int dtype, void* stream);
 
+/* The same for LoCon on nn.Linear: call lyc_locon_linear_bwd with d_down == d_up == NULL (dx launch only; `dt` is still
+ * written), keep (g, x, t, dt) alive, and hand batches to lyc_locon_wgrad_group: d_up += alpha * g^T t, d_down += dt^T x for
+ * ALL layers in ceil(n / 18) launches per kernel configuration (reference: the autograd products of modules/locon.py:309-332). */
+typedef struct LycLoconWgradItem {
+  const void* g;    /* [M, O] upstream gradient                          */
+  const void* x;    /* [M, I] layer input                                */
+  const float* t;   /* [M, r] forward intermediate (needed for d_up)     */
+  const float* dt;  /* [M, r] written by the layer's lyc_locon_linear_bwd */
+  float* d_down;    /* [r, I] += (NULL: skip)                            */
+  float* d_up;      /* [O, r] += (NULL: skip)                            */
+  int64_t M;
+  int I, O, r;
+  float alpha;
+} LycLoconWgradItem;
+int lyc_locon_wgrad_deferrable(const void* g, const void* x, int64_t M, int I, int O, int r, int dtype);
+int lyc_locon_wgrad_group(const LycLoconWgradItem* items, int n, int dtype, void* stream);
+
 /* ---- LoKr on nn.Conv2d (groups = 1): implicit GEMM, no im2col -------------------------------------
  * replaces lycoris/modules/lokr.py:543-566 with F.conv2d (functional/general.py:6) and the grouped-conv bypass
  * lycoris/functional/lokr.py:195-247.  Activations are NHWC ROW matrices (channels contiguous):

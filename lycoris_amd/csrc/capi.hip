@@ -399,30 +399,38 @@ void launch_tn_rt(LowrankTnArgs& a, int cv, hipStream_t st) {
   }
 }
 
-// both factor gradients of a rank-r layer in one launch; false = shapes the fast kernel does not take
-bool launch_lowrank_tn(LowrankTnArgs a, int dtype, hipStream_t st) {
+// Launch parameters of lowrank_tn_kernel for the (up to two) problems of `a`: fills rows_per_slab / nsplit / tiles and
+// returns the columns per lane (0 = shapes the fast kernel does not take).  `grouped`: the layer is one of many in a launch
+// (lowrank_tn_group_kernel): long slabs (few atomics) and the widest column vector, parallelism comes from the other layers.
+#ifndef LYC_TNG_ROWS
+#define LYC_TNG_ROWS 512
+#endif
+#ifndef LYC_TNG_CVMAX
+#define LYC_TNG_CVMAX 8
+#endif
+int plan_lowrank_tn(LowrankTnArgs& a, int dtype, bool grouped = false) {
   constexpr int atomic_budget = 800000, wave_target = 1400;  // measured (profiles/r01_ktrace_lowrank.log)
   const int dt = dtype & 0xff;
-  if ((dt != LYC_BF16 && dt != LYC_F16) || a.R > 64) return false;
+  if ((dt != LYC_BF16 && dt != LYC_F16) || a.R > 64) return 0;
   long csum = 0;
   for (int i = 0; i < 2; ++i)
     if (a.p[i].act) {
-      if (!tn_cv_ok(a.p[i], 1, (i == 1 && a.gat.mode) ? a.Ct : 0)) return false;
+      if (!tn_cv_ok(a.p[i], 1, (i == 1 && a.gat.mode) ? a.Ct : 0)) return 0;
       csum += a.p[i].C;
     }
-  if (csum == 0) return true;
+  if (csum == 0) return 1;
   // Row slabs: ~160-256 rows per wave measured best (benchmarks/kt_lowrank.sh) -- shorter slabs multiply the atomics,
   // longer ones leave the wave a long serial chain; bounded by the atomic budget.
-  long split = a.M / 160;
+  long split = a.M / (grouped ? LYC_TNG_ROWS : 160);
   const long cap = atomic_budget / ((long)a.R * csum);
   if (split > cap) split = cap;
-  if (split < 2 && a.M >= 64) split = 2;
+  if (!grouped && split < 2 && a.M >= 64) split = 2;
   if (split < 1) split = 1;
   a.rows_per_slab = round_up(cdiv(a.M, split), 4);
   a.nsplit = (int)cdiv(a.M, a.rows_per_slab);
   // columns per lane: 1 (most waves) unless the layer is so wide that 2 still gives thousands of waves
   int cv = 1;
-  for (int c = 8; c >= 2; c >>= 1) {
+  for (int c = grouped ? LYC_TNG_CVMAX : 8; c >= 2; c >>= 1) {
     bool ok = true;
     long tiles = 0;
     for (int i = 0; i < 2; ++i)
@@ -430,13 +438,22 @@ bool launch_lowrank_tn(LowrankTnArgs a, int dtype, hipStream_t st) {
         ok = ok && tn_cv_ok(a.p[i], c, (i == 1 && a.gat.mode) ? a.Ct : 0);
         tiles += cdiv(a.p[i].C, 16 * c);
       }
-    if (ok && tiles * a.nsplit >= wave_target) {
+    if (ok && (grouped || tiles * a.nsplit >= wave_target)) {
       cv = c;
       break;
     }
   }
+  for (int i = 0; i < 2; ++i) a.p[i].tiles = a.p[i].act ? (int)cdiv(a.p[i].C, 16 * cv) : 0;
+  return cv;
+}
+
+// both factor gradients of a rank-r layer in one launch; false = shapes the fast kernel does not take
+bool launch_lowrank_tn(LowrankTnArgs a, int dtype, hipStream_t st) {
+  const int cv = plan_lowrank_tn(a, dtype);
+  if (cv == 0) return false;
+  if (!a.p[0].act && !a.p[1].act) return true;
   const int rt = a.R <= 16 ? 1 : a.R <= 32 ? 2 : 4;
-  if (dt == LYC_BF16) {
+  if ((dtype & 0xff) == LYC_BF16) {
     if (rt == 1) launch_tn_rt<__bf16, 1>(a, cv, st);
     else if (rt == 2) launch_tn_rt<__bf16, 2>(a, cv, st);
     else launch_tn_rt<__bf16, 4>(a, cv, st);
@@ -446,6 +463,32 @@ bool launch_lowrank_tn(LowrankTnArgs a, int dtype, hipStream_t st) {
     else launch_tn_rt<_Float16, 4>(a, cv, st);
   }
   return true;
+}
+
+template <typename T, int RT>
+void launch_tn_group_rt(const LowrankTnGroupArgs& ga, int cv, hipStream_t st) {
+  const dim3 grid((unsigned)ga.wg_end[ga.n - 1]);
+  switch (cv) {
+    case 8: hipLaunchKernelGGL((lowrank_tn_group_kernel<T, RT, 8>), grid, dim3(NTHREADS), 0, st, ga); break;
+    case 4: hipLaunchKernelGGL((lowrank_tn_group_kernel<T, RT, 4>), grid, dim3(NTHREADS), 0, st, ga); break;
+    case 2: hipLaunchKernelGGL((lowrank_tn_group_kernel<T, RT, 2>), grid, dim3(NTHREADS), 0, st, ga); break;
+    default: hipLaunchKernelGGL((lowrank_tn_group_kernel<T, RT, 1>), grid, dim3(NTHREADS), 0, st, ga); break;
+  }
+}
+
+// the two factor-gradient problems of one rank-r Linear layer (what lyc_locon_linear_bwd launches per layer)
+void locon_tn_problems(LowrankTnArgs& ta, const void* g, const void* x, const float* t, const float* dt, float* d_down,
+                       float* d_up, int64_t M, int I, int O, int r, float alpha) {
+  ta.M = M; ta.R = r;
+  int np = 0;
+  if (d_up) {
+    LowrankTnProb& p = ta.p[np++];
+    p.act = g; p.ld = O; p.C = O; p.mid = t; p.out = d_up; p.os = r; p.oj = 1; p.alpha = alpha;
+  }
+  if (d_down) {
+    LowrankTnProb& p = ta.p[np++];
+    p.act = x; p.ld = I; p.C = I; p.mid = dt; p.out = d_down; p.os = 1; p.oj = I; p.alpha = 1.0f; p.swap = 1;
+  }
 }
 
 }  // namespace
@@ -805,17 +848,8 @@ int lyc_locon_linear_bwd(const void* g, const void* x, const float* down, const 
   }
   if (fast_rows) {  // both factor gradients in one launch
     LowrankTnArgs ta{};
-    ta.M = M; ta.R = r;
-    int np = 0;
-    if (d_up) {
-      LowrankTnProb& p = ta.p[np++];
-      p.act = g; p.ld = O; p.C = O; p.mid = t; p.out = d_up; p.os = r; p.oj = 1; p.alpha = alpha;
-    }
-    if (d_down) {
-      LowrankTnProb& p = ta.p[np++];
-      p.act = x; p.ld = I; p.C = I; p.mid = dt; p.out = d_down; p.os = 1; p.oj = I; p.alpha = 1.0f; p.swap = 1;
-    }
-    if (np == 0) return LYC_OK;
+    if (!d_up && !d_down) return LYC_OK;  // dx only: the caller defers the factor gradients (lyc_locon_wgrad_group)
+    locon_tn_problems(ta, g, x, t, dt, d_down, d_up, M, I, O, r, alpha);
     if (launch_lowrank_tn(ta, dtype, st)) return check_launch("locon_linear_bwd(factor gradients)");
   } else if (hipMemsetAsync(dt, 0, (size_t)M * r * sizeof(float), st) != hipSuccess) {
     return check_launch("locon_linear_bwd(memset)");
@@ -845,6 +879,72 @@ int lyc_locon_linear_bwd(const void* g, const void* x, const float* down, const 
     DISPATCH_DTYPE(dtype, launch_skinny_tn<T>(s, st));
   }
   return check_launch("locon_linear_bwd");
+}
+
+// ---- deferred, grouped LoCon factor gradients (lowrank_tn_group_kernel) -------------------------------------------------
+int lyc_locon_wgrad_deferrable(const void* g, const void* x, int64_t M, int I, int O, int r, int dtype) {
+  const int dt = dtype & 0xff;
+  if (M < 1 || (dt != LYC_BF16 && dt != LYC_F16) || r < 1 || r > 64) return 0;
+  // the same conditions under which lyc_locon_linear_bwd runs its fused dx launch (bneck_ok) and the wave kernel
+  return (O % 8) == 0 && (reinterpret_cast<uintptr_t>(g) & 15u) == 0 && (reinterpret_cast<uintptr_t>(x) & 1u) == 0 ? 1 : 0;
+}
+
+int lyc_locon_wgrad_group(const LycLoconWgradItem* items, int n, int dtype, void* stream) {
+  if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "locon_wgrad_group: bad item list");
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = dtype & 0xff;
+  // one sequence of launches per kernel instantiation (rank tiles 1 / 2 / 4 x columns per lane 1 / 2 / 4 / 8)
+  for (int rt = 1; rt <= 4; rt <<= 1)
+    for (int cvw = 1; cvw <= 8; cvw <<= 1) {
+      LowrankTnGroupArgs ga{};
+      auto flush = [&]() -> int {
+        if (ga.n == 0) return LYC_OK;
+        for (int i = 0; i < ga.n; ++i)  // a parameter that appears twice in one grid must be added atomically
+          for (int j = 0; j < i; ++j)
+            for (int u = 0; u < 2; ++u)
+              for (int v = 0; v < 2; ++v)
+                if (ga.p[i].p[u].out && ga.p[i].p[u].out == ga.p[j].p[v].out) ga.p[i].force_atomic = ga.p[j].force_atomic = 1;
+        if (dt == LYC_BF16) {
+          if (rt == 1) launch_tn_group_rt<__bf16, 1>(ga, cvw, st);
+          else if (rt == 2) launch_tn_group_rt<__bf16, 2>(ga, cvw, st);
+          else launch_tn_group_rt<__bf16, 4>(ga, cvw, st);
+        } else {
+          if (rt == 1) launch_tn_group_rt<_Float16, 1>(ga, cvw, st);
+          else if (rt == 2) launch_tn_group_rt<_Float16, 2>(ga, cvw, st);
+          else launch_tn_group_rt<_Float16, 4>(ga, cvw, st);
+        }
+        ga = LowrankTnGroupArgs{};
+        return check_launch("locon_wgrad_group");
+      };
+      for (int k = 0; k < n; ++k) {
+        const LycLoconWgradItem& it = items[k];
+        if (rt == 1 && cvw == 1) {  // validate once
+          if (it.M < 1 || it.I < 1 || it.O < 1 || it.r < 1) return fail(LYC_ERR_ARG, "locon_wgrad_group: item %d: bad dims", k);
+          if (!it.g || !it.x || !it.dt || (it.d_up && !it.t))
+            return fail(LYC_ERR_ARG, "locon_wgrad_group: item %d: null pointer (d_up needs t from the forward call)", k);
+          if (!lyc_locon_wgrad_deferrable(it.g, it.x, it.M, it.I, it.O, it.r, dtype))
+            return fail(LYC_ERR_UNSUPPORTED, "locon_wgrad_group: item %d is not on the 16-bit fast path (see lyc_locon_wgrad_deferrable)", k);
+        }
+        if (!it.d_up && !it.d_down) continue;
+        if ((it.r <= 16 ? 1 : it.r <= 32 ? 2 : 4) != rt) continue;
+        LowrankTnArgs ta{};
+        locon_tn_problems(ta, it.g, it.x, it.t, it.dt, it.d_down, it.d_up, it.M, it.I, it.O, it.r, it.alpha);
+        const int cv = plan_lowrank_tn(ta, dtype, true);
+        if (cv == 0) return fail(LYC_ERR_UNSUPPORTED, "locon_wgrad_group: item %d: unaligned activations", k);
+        if (cv != cvw) continue;
+        const long wgs = cdiv((long)(ta.p[0].tiles + ta.p[1].tiles) * ta.nsplit, NWAVES);
+        const long before = ga.n ? ga.wg_end[ga.n - 1] : 0;
+        if (ga.n == TNG_MAX || before + wgs > (1L << 30))
+          if (int rc = flush()) return rc;
+        LowrankTnItem& q = ga.p[ga.n];
+        q.p[0] = ta.p[0]; q.p[1] = ta.p[1]; q.M = ta.M; q.rows_per_slab = ta.rows_per_slab; q.R = ta.R; q.nsplit = ta.nsplit;
+        q.force_atomic = 0;
+        ga.wg_end[ga.n] = (int)((ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs);
+        ++ga.n;
+      }
+      if (int rc = flush()) return rc;
+    }
+  return LYC_OK;
 }
 
 // ---- LoCon on Conv2d without im2col (reference: modules/locon.py:286-332 with F.conv2d; lora_down is the kh x kw conv,

@@ -517,6 +517,7 @@ struct LowrankTnArgs {
   int R;
   int nsplit;          // row slabs
   long rows_per_slab;  // multiple of 4
+  int force_atomic;    // != 0: an output may be shared with another problem of the same (grouped) launch
   // implicit Conv2d (GAT kernels), problem p[1] only: its act holds the NHWC input pixel rows [B * Hs * Ws, Ct], its C
   // columns are the flat (tap, channel) index (C = taps * Ct, Ct % (16 CV) == 0) and the Act row of output pixel m and tap
   // t is the source pixel given by gat (mode 1), zero outside the image
@@ -536,14 +537,13 @@ template <typename T>
 struct LrVec<T, 1> { typedef uint16_t type; };
 
 // One wave per (column tile of 16 CV, row slab).  CV in {1, 2, 4, 8} columns per lane (C % CV == 0, ld % CV == 0, aligned).
-template <typename T, int RT, int CV, bool GAT = false>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 4))) void lowrank_tn_kernel(LowrankTnArgs a) {
+// `w`: index of this wave among the problem's (tiles x slabs) work items
+template <typename T, int RT, int CV, bool GAT>
+__device__ __forceinline__ void lowrank_tn_body(const LowrankTnArgs& a, const long w) {
   constexpr int D = CV * RT <= 4 ? 16 : 8;  // 4-row steps in flight
   using V = typename LrVec<T, CV>::type;
   const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tiles_total = a.p[0].tiles + a.p[1].tiles;
-  const long w = (long)blockIdx.x * NWAVES + wave;
   if (w >= (long)tiles_total * a.nsplit) return;
   const int slab = (int)(w / tiles_total);
   int tile = (int)(w - (long)slab * tiles_total);
@@ -671,11 +671,52 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 4))
         if (n >= R || c >= C) continue;
         float* o = out + (long)c * os + (long)n * oj;
         const float v = acc[j][rt][q] * alpha;
-        if (a.nsplit == 1)
+        if (a.nsplit == 1 && !a.force_atomic)
           *o += v;
         else
           __hip_atomic_fetch_add(o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+}
+
+template <typename T, int RT, int CV, bool GAT = false>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 4))) void lowrank_tn_kernel(LowrankTnArgs a) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  lowrank_tn_body<T, RT, CV, GAT>(a, (long)blockIdx.x * NWAVES + wave);
+}
+
+// ---- grouped launch: the factor gradients of up to TNG_MAX rank-r layers in ONE grid -------------------------------------
+// Like kron_dw2s_group_kernel (kron_dw2s.h): d_down / d_up feed the optimizer only, the host parks (g, x, t, dt) of the
+// finished layers and hands batches to this kernel.  A work item here is one WAVE (a 16 CV column tile x a row slab) with no
+// cross-wave cooperation, so a batch is simply more independent waves per launch: the single-layer launch is a few hundred
+// waves whose time is one wave's serial chain plus the launch; a batch keeps 4 waves per SIMD busy and can afford the widest
+// column vector (16-byte loads) and long slabs (few atomics), because its parallelism comes from the other layers.
+constexpr int TNG_MAX = 18;
+struct LowrankTnItem {
+  LowrankTnProb p[2];
+  long M;
+  long rows_per_slab;
+  int R, nsplit, force_atomic;
+};
+struct LowrankTnGroupArgs {
+  int n;
+  int wg_end[TNG_MAX];  // exclusive prefix of the workgroup counts (a workgroup = NWAVES work items of ONE problem)
+  LowrankTnItem p[TNG_MAX];
+};
+static_assert(sizeof(LowrankTnGroupArgs) <= 3584, "kernel arguments are limited to 4 KiB");
+
+template <typename T, int RT, int CV>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 4))) void lowrank_tn_group_kernel(LowrankTnGroupArgs ga) {
+  const int b = (int)blockIdx.x;
+  int q = 0;
+  while (q + 1 < ga.n && b >= ga.wg_end[q]) ++q;
+  const int b0 = q ? ga.wg_end[q - 1] : 0;
+  const LowrankTnItem& it = ga.p[q];
+  LowrankTnArgs a{};
+  a.p[0] = it.p[0];
+  a.p[1] = it.p[1];
+  a.M = it.M; a.R = it.R; a.nsplit = it.nsplit; a.rows_per_slab = it.rows_per_slab; a.force_atomic = it.force_atomic;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  lowrank_tn_body<T, RT, CV, false>(a, (long)(b - b0) * NWAVES + wave);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

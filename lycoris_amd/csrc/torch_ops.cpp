@@ -144,25 +144,45 @@ struct DeferredLokr {
   void* stream;
   c10::DeviceIndex device;
 };
+struct DeferredLocon {
+  Tensor g, x, t, dt, down, up, dd, du;  // dd / du: the .grad targets (either may be undefined)
+  int64_t M;
+  int I, O, r, code;
+  float alpha;
+  void* stream;
+  c10::DeviceIndex device;
+};
 struct Deferred {
   bool enabled = true;
   size_t flush_at = 48;
   std::mutex mu;
   std::vector<DeferredLokr> lokr;
+  std::vector<DeferredLocon> locon;
   bool callback_queued = false;
 } g_defer;
 
+// after launches on `stream`: whoever consumes .grad on the ambient stream must see them
+void join_ambient(c10::DeviceIndex device, void* stream) {
+  void* cur = c10::hip::getCurrentHIPStream(device).stream();
+  if (cur == stream) return;
+  hipEvent_t ev;
+  TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+  (void)hipEventRecord(ev, (hipStream_t)stream);
+  (void)hipStreamWaitEvent((hipStream_t)cur, ev, 0);
+  (void)hipEventDestroy(ev);
+}
+
 void flush_deferred() {
   std::vector<DeferredLokr> items;
+  std::vector<DeferredLocon> litems;
   {
     std::lock_guard<std::mutex> lock(g_defer.mu);
     items.swap(g_defer.lokr);
+    litems.swap(g_defer.locon);
     g_defer.callback_queued = false;
   }
-  if (items.empty()) return;
   // one call per (device, stream, dtype) run of items, in arrival order
-  size_t lo = 0;
-  while (lo < items.size()) {
+  for (size_t lo = 0; lo < items.size();) {
     size_t hi = lo + 1;
     while (hi < items.size() && items[hi].device == items[lo].device && items[hi].stream == items[lo].stream &&
            items[hi].code == items[lo].code)
@@ -175,34 +195,51 @@ void flush_deferred() {
     }
     const c10::DeviceGuard guard(c10::Device(c10::kCUDA, items[lo].device));
     check_rc(lyc_lokr_wgrad_group(raw.data(), (int)raw.size(), items[lo].code, items[lo].stream), "lyc_lokr_wgrad_group");
-    void* cur = c10::hip::getCurrentHIPStream(items[lo].device).stream();
-    if (cur != items[lo].stream) {  // whoever consumes .grad on the ambient stream must see the late launches
-      hipEvent_t ev;
-      TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
-      (void)hipEventRecord(ev, (hipStream_t)items[lo].stream);
-      (void)hipStreamWaitEvent((hipStream_t)cur, ev, 0);
-      (void)hipEventDestroy(ev);
-    }
+    join_ambient(items[lo].device, items[lo].stream);
     lo = hi;
   }
-  for (const DeferredLokr& it : items) {  // the gradients are enqueued: tell the DP sync (no lock held: this takes the GIL)
+  for (size_t lo = 0; lo < litems.size();) {
+    size_t hi = lo + 1;
+    while (hi < litems.size() && litems[hi].device == litems[lo].device && litems[hi].stream == litems[lo].stream &&
+           litems[hi].code == litems[lo].code)
+      ++hi;
+    std::vector<LycLoconWgradItem> raw(hi - lo);
+    for (size_t i = lo; i < hi; ++i) {
+      const DeferredLocon& it = litems[i];
+      raw[i - lo] = LycLoconWgradItem{cptr(it.g), cptr(it.x), cfp(it.t), cfp(it.dt), mfp(it.dd), mfp(it.du), it.M,
+                                      it.I, it.O, it.r, it.alpha};
+    }
+    const c10::DeviceGuard guard(c10::Device(c10::kCUDA, litems[lo].device));
+    check_rc(lyc_locon_wgrad_group(raw.data(), (int)raw.size(), litems[lo].code, litems[lo].stream), "lyc_locon_wgrad_group");
+    join_ambient(litems[lo].device, litems[lo].stream);
+    lo = hi;
+  }
+  // the gradients are enqueued: tell the DP sync (no lock held: this takes the GIL)
+  for (const DeferredLokr& it : items) {
     if (it.dw1.defined()) notify(it.w1);
     notify(it.w2);
+  }
+  for (const DeferredLocon& it : litems) {
+    if (it.dd.defined()) notify(it.down);
+    if (it.du.defined()) notify(it.up);
   }
 }
 
 // called from a backward node (the engine has a current graph task: final callbacks may be installed)
-void park_deferred(DeferredLokr&& item) {
+template <typename Item>
+void park_deferred_in(std::vector<Item> Deferred::*list, Item&& item) {
   bool queue = false, full = false;
   {
     std::lock_guard<std::mutex> lock(g_defer.mu);
-    g_defer.lokr.push_back(std::move(item));
+    (g_defer.*list).push_back(std::move(item));
     if (!g_defer.callback_queued) g_defer.callback_queued = queue = true;
-    full = g_defer.lokr.size() >= g_defer.flush_at;
+    full = g_defer.lokr.size() + g_defer.locon.size() >= g_defer.flush_at;
   }
   if (queue) torch::autograd::Engine::get_default_engine().queue_callback([]() { flush_deferred(); });
   if (full) flush_deferred();
 }
+void park_deferred(DeferredLokr&& item) { park_deferred_in(&Deferred::lokr, std::move(item)); }
+void park_deferred(DeferredLocon&& item) { park_deferred_in(&Deferred::locon, std::move(item)); }
 
 // =====================================================================================================================
 // LoKr on nn.Linear
@@ -369,6 +406,26 @@ Tensor locon_linear_bwd_into(const Tensor& g, const Tensor& x, const Tensor& dow
   return need_dx ? dx.view(x.sizes()) : Tensor();
 }
 
+// dx now (the launch also writes dt), d_down / d_up later (park_deferred); false = not on the grouped fast path
+bool locon_linear_bwd_deferred(const Tensor& g, const Tensor& x, const Tensor& down, const Tensor& up, const Tensor& t, double alpha,
+                               bool need_dx, const Tensor& dd, const Tensor& du, Tensor& dx_out) {
+  const c10::DeviceGuard guard(x.device());
+  const int64_t r = down.size(0), I = down.size(1), O = up.size(0);
+  Tensor rows = rows_of(x, I), g2 = rows_of(g, O);
+  const int64_t M = rows.size(0);
+  const int code = dtype_code(x.scalar_type());
+  if (!lyc_locon_wgrad_deferrable(cptr(g2), cptr(rows), M, (int)I, (int)O, (int)r, code)) return false;
+  Tensor fd = f32c(down), fu = f32c(up);
+  Tensor dt = at::empty({M, r}, x.options().dtype(at::kFloat));
+  Tensor dx = need_dx ? at::empty(rows.sizes(), x.options()) : Tensor();
+  check_rc(lyc_locon_linear_bwd(cptr(g2), cptr(rows), cfp(fd), cfp(fu), cfp(t), mfp(dt), mptr(dx), nullptr, nullptr, M, (int)I,
+                                (int)O, (int)r, (float)alpha, code, stream_of(x)), "lyc_locon_linear_bwd(dx)");
+  park_deferred(DeferredLocon{g2, rows, t, dt, down, up, dd, du, M, (int)I, (int)O, (int)r, code, (float)alpha, stream_of(x),
+                              x.device().index()});
+  dx_out = need_dx ? dx.view(x.sizes()) : Tensor();
+  return true;
+}
+
 std::tuple<Tensor, Tensor, Tensor> locon_linear_bwd(const Tensor& g, const Tensor& x, const Tensor& down, const Tensor& up,
                                                     const Tensor& t, double alpha, bool need_dx, bool need_dd, bool need_du) {
   Tensor dd = need_dd ? at::zeros(down.sizes(), down.options().dtype(at::kFloat)) : Tensor();
@@ -396,6 +453,11 @@ struct LoconLinearFn : public torch::autograd::Function<LoconLinearFn> {
     Tensor g = grads[0];
     if (eager_cuda(g) && eager_cuda(x)) {
       GradTarget td = grad_target(down, nd || accum_wanted(down)), tu = grad_target(up, nu || accum_wanted(up));
+      const bool any = td.buf.defined() || tu.buf.defined(), handed = (td.buf.defined() && td.hand_back) || (tu.buf.defined() && tu.hand_back);
+      if (g_defer.enabled && any && !handed) {  // both factor gradients go straight into .grad: dx now, the rest grouped
+        Tensor dx;
+        if (locon_linear_bwd_deferred(g, x, down, up, t, alpha, nx, td.buf, tu.buf, dx)) return {dx, Tensor(), Tensor(), Tensor()};
+      }
       Tensor dx = locon_linear_bwd_into(g, x, down, up, t, alpha, nx, td.buf, tu.buf);
       return {dx, finish_grad(down, td), finish_grad(up, tu), Tensor()};
     }
@@ -920,7 +982,7 @@ PYBIND11_MODULE(_lyc_torch, m) {
   m.def("defer_enabled", []() { return g_defer.enabled; });
   m.def("deferred_pending", []() {
     std::lock_guard<std::mutex> lk(g_defer.mu);
-    return g_defer.lokr.size();
+    return g_defer.lokr.size() + g_defer.locon.size();
   });
   m.def("flush_deferred", []() {
     py::gil_scoped_release nogil;  // flush_deferred() notifies through a callback that takes the GIL itself
@@ -928,10 +990,12 @@ PYBIND11_MODULE(_lyc_torch, m) {
   });
   m.def("discard_deferred", []() {  // after a failed backward: drop parked layers instead of adding them to the next step
     std::vector<DeferredLokr> items;
+    std::vector<DeferredLocon> litems;
     std::lock_guard<std::mutex> lk(g_defer.mu);
     items.swap(g_defer.lokr);
+    litems.swap(g_defer.locon);
     g_defer.callback_queued = false;
-    return items.size();
+    return items.size() + litems.size();
   });
   m.def("abi_version", []() { return lyc_abi_version(); });
 }

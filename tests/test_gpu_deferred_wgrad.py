@@ -8,7 +8,6 @@ per-layer entry point; (b) custom ops: `.grad` is complete when backward() retur
 grad-sync callback hears about every parameter exactly once per backward."""
 import ctypes
 
-import numpy as np
 import pytest
 import torch
 import torch.nn as nn
@@ -190,3 +189,116 @@ def test_parameters_without_a_grad_buffer_are_not_deferred():
         assert ops._DISPATCH["ext"].deferred_pending() == 0
     finally:
         ops.fused_grad_accumulation(False, None)
+
+
+# ---- LoCon: lyc_locon_linear_bwd with d_down = d_up = NULL, then lyc_locon_wgrad_group --------------------------------------
+LOCON_SHAPES = [(1024, 1280, 1280, 16), (77, 2048, 640, 16), (4096, 640, 640, 8), (50, 72, 40, 4), (1, 1280, 320, 16),
+                (300, 96, 136, 24), (128, 64, 64, 40)]  # (M, I, O, r): ranks on all three rank tiles, odd widths
+
+
+def _locon_problem(gen, M, I, O, r, dtype):
+    x, x64 = rnd((M, I), dtype, gen)
+    g, g64 = rnd((M, O), dtype, gen, 0.1)
+    down, d64 = rnd((r, I), torch.float32, gen, 0.1)
+    up, u64 = rnd((O, r), torch.float32, gen, 0.1)
+    return (g, x, down, up), (g64, x64, d64, u64)
+
+
+def _locon_deferred(N, probs, alpha, code, shared=()):
+    items = (N.LoconWgradItem * len(probs))()
+    outs, keep = [], []
+    alias = dict(shared)
+    for k, (g, x, down, up) in enumerate(probs):
+        M, I, O, r = x.shape[0], x.shape[1], g.shape[1], down.shape[0]
+        t = torch.empty(M, r, device=DEV)
+        y = torch.empty_like(g)
+        N.call("lyc_locon_linear_fwd", N.ptr(x), N.ptr(down), N.ptr(up), N.ptr(t), N.ptr(y), M, I, O, r, alpha, code, N.stream_ptr(x.device))
+        dt, dx = torch.empty(M, r, device=DEV), torch.empty_like(x)
+        dd, du = (outs[alias[k]][1], outs[alias[k]][2]) if k in alias else (torch.zeros_like(down), torch.zeros_like(up))
+        assert N.load().lyc_locon_wgrad_deferrable(N.ptr(g), N.ptr(x), M, I, O, r, code) == 1
+        N.call("lyc_locon_linear_bwd", N.ptr(g), N.ptr(x), N.ptr(down), N.ptr(up), N.ptr(t), N.ptr(dt), N.ptr(dx), None, None,
+               M, I, O, r, alpha, code, N.stream_ptr(x.device))
+        items[k] = N.LoconWgradItem(N.ptr(g), N.ptr(x), N.ptr(t), N.ptr(dt), N.ptr(dd), N.ptr(du), M, I, O, r, alpha)
+        keep += [t, dt]
+        outs.append((dx, dd, du))
+    N.call("lyc_locon_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(probs), code, N.stream_ptr(probs[0][1].device))
+    torch.cuda.synchronize()
+    return outs
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_grouped_locon_factor_gradients_match_the_oracle(dtype):
+    from lycoris_amd import _native as N
+    gen = torch.Generator().manual_seed(21)
+    code = N.dtype_code(dtype)
+    alpha = 0.7
+    both = [_locon_problem(gen, *s, dtype) for s in LOCON_SHAPES]
+    both += [_locon_problem(gen, 64, 128, 128, 16, dtype) for _ in range(22)]  # > 18 items of one configuration: two launches
+    probs, host = [b[0] for b in both], [b[1] for b in both]
+    got = _locon_deferred(N, probs, alpha, code)
+    bound = TOL["f32_out"][dtype]
+    for k, ((g64, x64, d64, u64), (dx, dd, du)) in enumerate(zip(host, got)):
+        rx, rd, ru = oracle.locon.backward(x64, g64, d64, u64, scale=alpha)
+        assert err(dd, rd) <= bound, (k, "d_down", err(dd, rd))
+        assert err(du, ru) <= bound, (k, "d_up", err(du, ru))
+        assert err(dx, rx, dtype) <= TOL["store_out"][dtype], (k, "dx")
+
+
+def test_a_shared_locon_layer_in_one_group_is_added_atomically():
+    from lycoris_amd import _native as N
+    gen = torch.Generator().manual_seed(22)
+    dtype, alpha = torch.bfloat16, 1.0
+    code = N.dtype_code(dtype)
+    (ga, xa, down, up), ha = _locon_problem(gen, 96, 128, 64, 8, dtype)  # one slab each: plain stores when alone
+    (gb, xb, _, _), hb = _locon_problem(gen, 96, 128, 64, 8, dtype)
+    got = _locon_deferred(N, [(ga, xa, down, up), (gb, xb, down, up)], alpha, code, shared=[(1, 0)])
+    _, ad, au = oracle.locon.backward(ha[1], ha[0], ha[2], ha[3], scale=alpha)
+    _, bd, bu = oracle.locon.backward(hb[1], hb[0], ha[2], ha[3], scale=alpha)
+    bound = TOL["f32_out"][dtype]
+    assert err(got[0][1], ad + bd) <= bound and err(got[0][2], au + bu) <= bound
+
+
+class _LoconStack(nn.Module):
+    def __init__(self, n=4, width=128, r=16):
+        super().__init__()
+        self.down = nn.ParameterList([nn.Parameter(torch.randn(r, width, device=DEV) * 0.1) for _ in range(n)])
+        self.up = nn.ParameterList([nn.Parameter(torch.randn(width, r, device=DEV) * 0.1) for _ in range(n)])
+
+    def forward(self, x):
+        from lycoris_amd import ops
+        for i in list(range(len(self.down))) + [0]:
+            x = x + ops.locon_linear(x, self.down[i], self.up[i], 0.5)
+        return x
+
+
+@pytest.mark.parametrize("flush_at", [48, 3], ids=["end_of_backward", "every_3_layers"])
+def test_locon_grads_are_complete_when_backward_returns(flush_at):
+    from lycoris_amd import ops
+    torch.manual_seed(6)
+    net = _LoconStack()
+    x = (torch.randn(80, 128, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    gy = (torch.randn(80, 128, device=DEV) * 0.1).to(torch.bfloat16)
+    params = list(net.parameters())
+
+    def run(defer):
+        seen = []
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        x.grad = None
+        ops.fused_grad_accumulation(True, callback=lambda p: seen.append(id(p)))
+        ops.deferred_weight_gradients(defer, flush_at)
+        try:
+            net(x).backward(gy)
+            assert ops._DISPATCH["ext"].deferred_pending() == 0
+            torch.cuda.synchronize()
+            return x.grad.clone(), [p.grad.clone() for p in params], seen
+        finally:
+            ops.fused_grad_accumulation(False, None)
+            ops.deferred_weight_gradients(True, 48)
+
+    dx0, g0, seen0 = run(False)
+    dx1, g1, seen1 = run(True)
+    assert torch.equal(dx0, dx1)
+    for u, v in zip(g0, g1):
+        assert float(u.abs().max()) > 0 and torch.allclose(u, v, rtol=2e-4, atol=1e-6), float((u - v).abs().max())
+    assert sorted(seen0) == sorted(seen1) and len(seen1) == 10
