@@ -572,9 +572,49 @@ def roofline(insts, args, dtype, dev):
                     "dw2s_grouped_gbs": round(b_dw2 / (t_wg * 1e-3) / 1e9, 1),
                     "dw2s_per_layer_gbs": round(b_dw2 / (t_dw2 * 1e-3) / 1e9, 1)})
         return out
-    out.update({"kernel": {"locon": "lyc::bneck_kernel (forward, backward-dx) + lyc::lowrank_tn_kernel (factor gradients): the three "
-                                    "launches of a LoCon Linear layer (comparable cost each)",
-                           "ia3": "lyc::chan_scale_kernel / lyc::chan_reduce_kernel"}[lin[0].algo],
+    if lin[0].algo == "locon":
+        # production backward: the fused dx launch per layer (lyc::bneck_kernel, also writes dt) + the factor gradients of ALL
+        # layers in grouped launches (lyc::lowrank_tn_group_kernel, lyc_locon_wgrad_group: 18 layers per launch)
+        import ctypes
+        from lycoris_amd import _native as N
+        code = N.dtype_code(dtype)
+        items = (N.LoconWgradItem * len(calls))()
+        dts, dxs = [], []
+        for k, (it, rows, g, fs, bufs) in enumerate(calls):
+            r, I = fs[0].shape
+            O = fs[1].shape[0]
+            dts.append(torch.empty(rows.shape[0], r, device=dev))
+            dxs.append(torch.empty_like(rows))
+            assert N.load().lyc_locon_wgrad_deferrable(N.ptr(g), N.ptr(rows), rows.shape[0], I, O, r, code) == 1
+            items[k] = N.LoconWgradItem(N.ptr(g), N.ptr(rows), N.ptr(saved[id(it)][1][0]), N.ptr(dts[k]), N.ptr(bufs[0]), N.ptr(bufs[1]),
+                                        rows.shape[0], I, O, r, 1.0)
+        _KEEP.extend([items, dts, dxs])
+
+        def only_dx():
+            for k, (it, rows, g, fs, bufs) in enumerate(calls):
+                r, I = fs[0].shape
+                N.call("lyc_locon_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(saved[id(it)][1][0]), N.ptr(dts[k]),
+                       N.ptr(dxs[k]), None, None, rows.shape[0], I, fs[1].shape[0], r, 1.0, code, N.stream_ptr(dev))
+
+        def grouped_wgrad():
+            N.call("lyc_locon_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(calls), code, N.stream_ptr(dev))
+
+        t_dx = _graph_ms(only_dx)
+        t_wg = _graph_ms(grouped_wgrad)
+        hot = nbytes / ((t_fwd + t_dx + t_wg) * 1e-3) / 1e9
+        b2 = b_fwd + b_bwd  # the two bneck launches of a layer read x / g and write y / dx: the SURVEY 8d bytes of the layer
+        k_ms = t_fwd + t_dx
+        ach = b2 / (k_ms * 1e-3) / 1e9
+        out["families_ms"] = {"bneck_forward": round(t_fwd, 3), "bneck_backward_dx": round(t_dx, 3), "lowrank_tn_grouped": round(t_wg, 3),
+                              "backward_one_call_per_layer": round(t_bwd, 3)}
+        out.update({"kernel": "lyc::bneck_kernel (LoCon forward + backward-dx launches of the Linear layers); the factor gradients run "
+                              "grouped (lyc::lowrank_tn_group_kernel, 18 layers per launch, re-reads g and x): families_ms",
+                    "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "launches_per_layer": 2,
+                    "avg_launch_us": round(k_ms * 1e3 / (2 * n_l), 2), "algorithmic_bytes_per_launch": int(b2 / (2 * n_l)),
+                    "hot_path_gbs": round(hot, 1), "hot_path_frac": round(hot / HBM_PEAK_GBS, 4),
+                    "backward_gbs": round(b_bwd / ((t_dx + t_wg) * 1e-3) / 1e9, 1)})
+        return out
+    out.update({"kernel": "lyc::chan_scale_kernel / lyc::chan_reduce_kernel",
                 "achieved": round(hot, 1), "frac": round(hot / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_launch": int(nbytes / (launches * n_l))})
     return out

@@ -88,5 +88,47 @@ int main() {
   float ms = 0;
   if (time_call(all.data(), (int)all.size(), ms)) return 1;
   printf("SDXL Linear mix, %zu problems in one call: %8.3f ms  %7.1f GB/s\n", all.size(), ms, total_bytes / (ms * 1e-3) / 1e9);
+
+  // ---- LoCon (rank 16): the same layers as [M, I] x / [M, O] g with I = 8 d, O = 8 c ------------------------------------------
+  printf("locon plan: rows/slab %d  cvmax %d\n", LYC_TNG_ROWS, LYC_TNG_CVMAX);
+  std::vector<LycLoconWgradItem> lall;
+  std::vector<std::pair<size_t, size_t>> lrange;
+  for (size_t c = 0; c < sdxl.size(); ++c) {
+    const Shape& s = sdxl[c];
+    const size_t lo = lall.size();
+    const int I = s.a * s.d, O = s.a * s.c, r = 16;
+    for (size_t k = range[c].first; k < range[c].second; ++k) {
+      float *t, *dt, *dd, *du;
+      CK(hipMalloc((void**)&t, (size_t)s.M * r * 4));
+      CK(hipMalloc((void**)&dt, (size_t)s.M * r * 4));
+      CK(hipMalloc((void**)&dd, (size_t)r * I * 4));
+      CK(hipMalloc((void**)&du, (size_t)r * O * 4));
+      CK(hipMemset(t, 0, (size_t)s.M * r * 4));
+      CK(hipMemset(dt, 0, (size_t)s.M * r * 4));
+      CK(hipMemset(dd, 0, (size_t)r * I * 4));
+      CK(hipMemset(du, 0, (size_t)r * O * 4));
+      lall.push_back(LycLoconWgradItem{all[k].g, all[k].x, t, dt, dd, du, s.M, I, O, r, 1.0f});
+    }
+    lrange.push_back({lo, lall.size()});
+  }
+  auto time_locon = [&](const LycLoconWgradItem* it, int n, float& ms_) -> int {
+    const int reps = 5;
+    if (lyc_locon_wgrad_group(it, n, LYC_BF16, st)) { fprintf(stderr, "%s\n", lyc_last_error()); return 1; }
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r) lyc_locon_wgrad_group(it, n, LYC_BF16, st);
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms_, e0, e1));
+    ms_ /= reps;
+    return 0;
+  };
+  for (size_t c = 0; c < sdxl.size(); ++c) {
+    if (time_locon(lall.data() + lrange[c].first, (int)(lrange[c].second - lrange[c].first), ms)) return 1;
+    printf("locon %-18s x%3d : %8.3f ms  %6.2f us/problem  %7.1f GB/s\n", sdxl[c].tag, sdxl[c].count, ms, ms * 1e3 / sdxl[c].count,
+           class_bytes[c] / (ms * 1e-3) / 1e9);
+  }
+  if (time_locon(lall.data(), (int)lall.size(), ms)) return 1;
+  printf("locon SDXL Linear mix, %zu problems in one call: %8.3f ms  %7.1f GB/s\n", lall.size(), ms, total_bytes / (ms * 1e-3) / 1e9);
   return 0;
 }

@@ -401,12 +401,14 @@ void launch_tn_rt(LowrankTnArgs& a, int cv, hipStream_t st) {
 
 // Launch parameters of lowrank_tn_kernel for the (up to two) problems of `a`: fills rows_per_slab / nsplit / tiles and
 // returns the columns per lane (0 = shapes the fast kernel does not take).  `grouped`: the layer is one of many in a launch
-// (lowrank_tn_group_kernel): long slabs (few atomics) and the widest column vector, parallelism comes from the other layers.
+// (lowrank_tn_group_kernel): longer slabs (fewer atomics); measured on the SDXL mix (benchmarks/wgbench.cpp,
+// profiles/r02_wgbench_sweep3_locon.log): 512-row slabs and 2 columns per lane (2.06 ms for 722 layers; 8 columns: 2.88 ms --
+// more, narrower waves keep 4 waves per SIMD in flight; 256 / 1024-row slabs: 3.5 / 3.4 ms).
 #ifndef LYC_TNG_ROWS
 #define LYC_TNG_ROWS 512
 #endif
 #ifndef LYC_TNG_CVMAX
-#define LYC_TNG_CVMAX 8
+#define LYC_TNG_CVMAX 2
 #endif
 int plan_lowrank_tn(LowrankTnArgs& a, int dtype, bool grouped = false) {
   constexpr int atomic_budget = 800000, wave_target = 1400;  // measured (profiles/r01_ktrace_lowrank.log)
