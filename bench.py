@@ -501,6 +501,36 @@ def roofline(insts, args, dtype, dev):
     out = {"families_ms": {"forward": round(t_fwd, 3), "backward": round(t_bwd, 3)}, "layers": n_l,
            "launches_per_layer": launches, "avg_launch_us": round(t_ms * 1e3 / (launches * n_l), 2)}
     if lin[0].algo == "loha":
+        # production backward: dx = g dW per layer + G = g^T x and HadaWeight.backward of ALL layers in one lyc_loha_wgrad_group
+        # call (library GEMM per layer, grouped factor-gradient launches)
+        import ctypes
+        from lycoris_amd import _native as N
+        code = N.dtype_code(dtype)
+        items = (N.LohaWgradItem * len(calls))()
+        gws, dxs = [], []
+        for k, (it, rows, g, fs, bufs) in enumerate(calls):
+            O, r = fs[0].shape
+            I = fs[1].shape[1]
+            gws.append(torch.empty(O, I, device=dev))
+            dxs.append(torch.empty_like(rows))
+            items[k] = N.LohaWgradItem(N.ptr(g), N.ptr(rows), *[N.ptr(f) for f in fs], *[N.ptr(b) for b in bufs], N.ptr(gws[k]),
+                                       rows.shape[0], I, O, r, 1.0)
+        _KEEP.extend([items, gws, dxs])
+
+        def only_dx():
+            for k, (it, rows, g, fs, bufs) in enumerate(calls):
+                O, r = fs[0].shape
+                N.call("lyc_loha_linear_bwd", N.ptr(g), N.ptr(rows), *[N.ptr(f) for f in fs], N.ptr(saved[id(it)][1][0]), None, N.ptr(dxs[k]),
+                       None, None, None, None, rows.shape[0], fs[1].shape[1], O, r, 1.0, code, N.stream_ptr(dev))
+
+        def grouped_wgrad():
+            N.call("lyc_loha_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(calls), code, N.stream_ptr(dev))
+
+        t_dx = _graph_ms(only_dx)
+        t_wg = _graph_ms(grouped_wgrad)
+        out["families_ms"] = {"forward": round(t_fwd, 3), "backward_dx": round(t_dx, 3), "G_gemm_and_grouped_factor_gradients": round(t_wg, 3),
+                              "backward_one_call_per_layer": round(t_bwd, 3)}
+        t_ms = t_fwd + t_dx + t_wg
         ach = flops / (t_ms * 1e-3) / 1e12
         out.update({"bound": "mfma", "kernel": "LoHa dense contractions y = x dW^T, dx = g dW, G = g^T x of the Linear layers "
                                               "(+ dW rebuild and Hadamard chain rule)",

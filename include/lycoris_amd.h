@@ -93,6 +93,23 @@ typedef struct LycLoconWgradItem {
 int lyc_locon_wgrad_deferrable(const void* g, const void* x, int64_t M, int I, int O, int r, int dtype);
 int lyc_locon_wgrad_group(const LycLoconWgradItem* items, int n, int dtype, void* stream);
 
+/* And for LoHa on nn.Linear: lyc_loha_linear_bwd with the four gradient pointers NULL runs only dx = g dW; lyc_loha_wgrad_group
+ * then computes G = g^T x per layer (library GEMM into the item's `gw` scratch, [O, I] fp32) and HadaWeight.backward
+ * (functional/loha.py:18-30) for up to 24 layers per launch with blocks of tiles per workgroup: 1/nt + 1/NO fp32 atomics per
+ * element of G instead of 2.  The gradients always accumulate with atomics here, so a parameter may appear in several items. */
+typedef struct LycLohaWgradItem {
+  const void* g;    /* [M, O] */
+  const void* x;    /* [M, I] */
+  const float *w1a, *w1b, *w2a, *w2b;     /* w*a:[O, r]  w*b:[r, I] */
+  float *d_w1a, *d_w1b, *d_w2a, *d_w2b;   /* +=, all four           */
+  float* gw;        /* [O, I] fp32 scratch */
+  int64_t M;
+  int I, O, r;
+  float alpha;
+} LycLohaWgradItem;
+int lyc_loha_wgrad_deferrable(const void* g, const void* x, int64_t M, int I, int O, int r, int dtype);
+int lyc_loha_wgrad_group(const LycLohaWgradItem* items, int n, int dtype, void* stream);
+
 /* ---- LoKr on nn.Conv2d (groups = 1): implicit GEMM, no im2col -------------------------------------
  * replaces lycoris/modules/lokr.py:543-566 with F.conv2d (functional/general.py:6) and the grouped-conv bypass
  * lycoris/functional/lokr.py:195-247.  Activations are NHWC ROW matrices (channels contiguous):

@@ -26,6 +26,7 @@ SIGNATURES = {
     "lyc_lokr_linear_bwd": [_vp, _vp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_lokr_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of WgradItem
     "lyc_locon_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LoconWgradItem
+    "lyc_loha_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LohaWgradItem
     "lyc_lokr_conv2d_fwd": [_vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_lokr_conv2d_bwd": [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_locon_linear_fwd": [_vp, _fp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
@@ -56,7 +57,14 @@ VALUE_SIGNATURES = {
     "lyc_lokr_conv2d_bwd_workspace_bytes": ([_i64, _i64, _i64, _i32, _i32, _i32], ctypes.c_int64),
     "lyc_lokr_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32], ctypes.c_int),  # 1 / 0, not an error code
     "lyc_locon_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32], ctypes.c_int),
+    "lyc_loha_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32], ctypes.c_int),
 }
+
+
+class LohaWgradItem(ctypes.Structure):
+    """LycLohaWgradItem (include/lycoris_amd.h)"""
+    _fields_ = [("g", _vp), ("x", _vp), ("w1a", _vp), ("w1b", _vp), ("w2a", _vp), ("w2b", _vp), ("d_w1a", _vp), ("d_w1b", _vp),
+                ("d_w2a", _vp), ("d_w2b", _vp), ("gw", _vp), ("M", _i64), ("I", _i32), ("O", _i32), ("r", _i32), ("alpha", _f32)]
 
 
 class LoconWgradItem(ctypes.Structure):

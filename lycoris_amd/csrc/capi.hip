@@ -1153,26 +1153,40 @@ rocblas_datatype rb_type(int dtype) {
 
 // HadaWeight.backward on a dense fp32 gradient G [O, I] (functional/loha.py:18-30): shared by the activation path
 // (G = g^T x) and the weight-space path (DoRA's norm gradient).
+// NO x nt tiles per workgroup (fewer atomics: the a-side gradients stay in registers over nt column tiles, the b-side over
+// NO row tiles).  One layer per launch: as long as ~512 workgroups remain.  `grouped` (loha_factor_grad_group_kernel): the
+// other layers of the batch supply the parallelism, ~32 workgroups per layer are enough.  Ranks > 32 go tile by tile.
+#ifndef LYC_LHG_TARGET
+#define LYC_LHG_TARGET 32
+#endif
+#ifndef LYC_LHG_NTMAX
+#define LYC_LHG_NTMAX 8
+#endif
+void plan_loha_grad(long O, long I, int r, bool grouped, int& no, int& nt) {
+  const long tiles_o = cdiv(O, LOHA_T), tiles_j = cdiv(I, LOHA_T);
+  const long per = (tiles_o * tiles_j) / (grouped ? LYC_LHG_TARGET : 512);
+  no = 1;
+  nt = 1;
+  if (r <= LOHA_RC && per >= 2) {
+    no = per >= 8 ? 4 : 2;
+    if (no > tiles_o) no = tiles_o >= 2 ? 2 : 1;
+    nt = (int)(per / no);
+    if (nt < 1) nt = 1;
+    if (grouped && nt > LYC_LHG_NTMAX) nt = LYC_LHG_NTMAX;
+    if (nt > tiles_j) nt = (int)tiles_j;
+  }
+}
+
 void launch_loha_factor_grad(const float* gw, const float* w1a, const float* w1b, const float* w2a, const float* w2b,
                              float* d_w1a, float* d_w1b, float* d_w2a, float* d_w2b, long O, long I, int r, float alpha,
                              hipStream_t st) {
   LohaArgs la{};
   la.w1a = w1a; la.w1b = w1b; la.w2a = w2a; la.w2b = w2b; la.O = O; la.I = I; la.R = r; la.scale = alpha;
   la.G = gw; la.d_w1a = d_w1a; la.d_w1b = d_w1b; la.d_w2a = d_w2a; la.d_w2b = d_w2b;
-  // NO x nt tiles per workgroup (fewer atomics: the a-side gradients stay in registers over nt column tiles, the
-  // b-side over NO row tiles) as long as ~512 workgroups remain; ranks > 32 go tile by tile, chunk by chunk
-  const long tiles_o = cdiv(O, LOHA_T), tiles_j = cdiv(I, LOHA_T);
-  constexpr int lh_wgs = 512;
-  long per = (tiles_o * tiles_j) / lh_wgs;
   int no = 1;
   LohaGradGeom gm{1};
-  if (r <= LOHA_RC && per >= 2) {
-    no = per >= 8 ? 4 : 2;
-    if (no > tiles_o) no = tiles_o >= 2 ? 2 : 1;
-    gm.nt = (int)(per / no);
-    if (gm.nt < 1) gm.nt = 1;
-    if (gm.nt > tiles_j) gm.nt = (int)tiles_j;
-  }
+  plan_loha_grad(O, I, r, false, no, gm.nt);
+  const long tiles_o = cdiv(O, LOHA_T), tiles_j = cdiv(I, LOHA_T);
   dim3 fg((unsigned)cdiv(tiles_o, no), (unsigned)cdiv(tiles_j, gm.nt));
   switch (no) {
     case 4: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<4>), fg, dim3(NTHREADS), 0, st, la, gm); break;
@@ -1264,6 +1278,61 @@ int lyc_loha_linear_bwd(const void* g, const void* x, const float* w1a, const fl
   return check_launch("loha_linear_bwd");
 }
 
+
+// ---- deferred, grouped LoHa factor gradients (loha_factor_grad_group_kernel) ---------------------------------------------
+int lyc_loha_wgrad_deferrable(const void* g, const void* x, int64_t M, int I, int O, int r, int dtype) {
+  const int dt = dtype & 0xff;
+  (void)g; (void)x;
+  return (M >= 1 && (dt == LYC_BF16 || dt == LYC_F16) && r >= 1 && O < (1 << 30) && I < (1 << 30)) ? 1 : 0;
+}
+
+int lyc_loha_wgrad_group(const LycLohaWgradItem* items, int n, int dtype, void* stream) {
+  if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "loha_wgrad_group: bad item list");
+  hipStream_t st = (hipStream_t)stream;
+  for (int k = 0; k < n; ++k) {  // G_k = g_k^T x_k (fp32, [O, I]): one library GEMM per layer, back to back
+    const LycLohaWgradItem& it = items[k];
+    if (it.M < 1 || it.I < 1 || it.O < 1 || it.r < 1) return fail(LYC_ERR_ARG, "loha_wgrad_group: item %d: bad dims", k);
+    if (!it.g || !it.x || !it.w1a || !it.w1b || !it.w2a || !it.w2b || !it.gw || !it.d_w1a || !it.d_w1b || !it.d_w2a || !it.d_w2b)
+      return fail(LYC_ERR_ARG, "loha_wgrad_group: item %d: null pointer (the four gradients come as a set and need the gw scratch)", k);
+    if (!lyc_loha_wgrad_deferrable(it.g, it.x, it.M, it.I, it.O, it.r, dtype))
+      return fail(LYC_ERR_UNSUPPORTED, "loha_wgrad_group: item %d needs 16-bit activations", k);
+    if (int rc = rb_gemm(st, true, false, it.O, it.I, it.M, it.g, it.O, it.x, it.I, it.gw, it.I, rb_type(dtype),
+                         rocblas_datatype_f32_r, 1.0f, 0.0f, "loha_wgrad_group(G)"))
+      return rc;
+  }
+  for (int no = 1; no <= 4; no <<= 1) {  // one sequence of launches per row-block instantiation
+    LohaGradGroupArgs ga{};
+    auto flush = [&]() -> int {
+      if (ga.n == 0) return LYC_OK;
+      const dim3 grid((unsigned)ga.wg_end[ga.n - 1]);
+      switch (no) {
+        case 4: hipLaunchKernelGGL((loha_factor_grad_group_kernel<4>), grid, dim3(NTHREADS), 0, st, ga); break;
+        case 2: hipLaunchKernelGGL((loha_factor_grad_group_kernel<2>), grid, dim3(NTHREADS), 0, st, ga); break;
+        default: hipLaunchKernelGGL((loha_factor_grad_group_kernel<1>), grid, dim3(NTHREADS), 0, st, ga); break;
+      }
+      ga = LohaGradGroupArgs{};
+      return check_launch("loha_wgrad_group");
+    };
+    for (int k = 0; k < n; ++k) {
+      const LycLohaWgradItem& it = items[k];
+      int pno = 1, nt = 1;
+      plan_loha_grad(it.O, it.I, it.r, true, pno, nt);
+      if (pno != no) continue;
+      const long gx = cdiv(cdiv(it.O, LOHA_T), no), gy = cdiv(cdiv(it.I, LOHA_T), nt);
+      const long before = ga.n ? ga.wg_end[ga.n - 1] : 0;
+      if (ga.n == LHG_MAX || before + gx * gy > (1L << 30))
+        if (int rc = flush()) return rc;
+      LohaGradItem& q = ga.p[ga.n];
+      q.w1a = it.w1a; q.w1b = it.w1b; q.w2a = it.w2a; q.w2b = it.w2b; q.G = it.gw;
+      q.d_w1a = it.d_w1a; q.d_w1b = it.d_w1b; q.d_w2a = it.d_w2a; q.d_w2b = it.d_w2b;
+      q.O = it.O; q.I = it.I; q.R = it.r; q.nt = nt; q.gx = (int)gx; q.scale = it.alpha;
+      ga.wg_end[ga.n] = (int)((ga.n ? ga.wg_end[ga.n - 1] : 0) + gx * gy);
+      ++ga.n;
+    }
+    if (int rc = flush()) return rc;
+  }
+  return LYC_OK;
+}
 
 // ---- weight space: merge / diff weight / max-norm / DoRA (wspace.h) ------------------------------------------------
 int lyc_wspace(int algo, const float* f0, const float* f1, const float* f2, const float* f3, int64_t O, int64_t J, int r,

@@ -217,9 +217,12 @@ struct LohaGradGeom {
 
 // One workgroup: row tiles ob*NO .. +NO-1, column tiles jb*nt .. +nt-1 (R <= 32: a single rank chunk stays resident;
 // larger ranks run with NO = nt = 1 and loop over the chunks).
+constexpr int loha_grad_lds_floats() { return 2 * LOHA_T * LH_AP + 2 * LOHA_RC * LH_BP + 2 * LOHA_T * LH_TP; }
+
+// `bx`, `by`: this workgroup's block of row tiles / column tiles; `sm`: loha_grad_lds_floats() floats
 template <int NO>
-__global__ __launch_bounds__(NTHREADS) void loha_factor_grad_mfma_kernel(LohaArgs a, LohaGradGeom gm) {
-  __shared__ __attribute__((aligned(16))) float sm[2 * LOHA_T * LH_AP + 2 * LOHA_RC * LH_BP + 2 * LOHA_T * LH_TP];
+__device__ __forceinline__ void loha_factor_grad_body(const LohaArgs& a, const LohaGradGeom& gm, float* sm, const int bx,
+                                                      const int by) {
   float* sA1 = sm;
   float* sA2 = sA1 + LOHA_T * LH_AP;
   float* sB1 = sA2 + LOHA_T * LH_AP;
@@ -227,8 +230,8 @@ __global__ __launch_bounds__(NTHREADS) void loha_factor_grad_mfma_kernel(LohaArg
   float* sT1 = sB2 + LOHA_RC * LH_BP;
   float* sT2 = sT1 + LOHA_T * LH_TP;
   const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
-  const long ob = (long)blockIdx.x * NO;  // first row tile
-  const long jb = (long)blockIdx.y * gm.nt;
+  const long ob = (long)bx * NO;  // first row tile
+  const long jb = (long)by * gm.nt;
   const long tiles_j = (a.I + LOHA_T - 1) / LOHA_T;
   const int nchunk = (a.R + LOHA_RC - 1) / LOHA_RC;
   const bool vec_in = lh_vec_ok(a);
@@ -351,6 +354,48 @@ __global__ __launch_bounds__(NTHREADS) void loha_factor_grad_mfma_kernel(LohaArg
 #pragma unroll
     for (int os = 0; os < NO; ++os) emit_a(os, 0);
   }
+}
+
+template <int NO>
+__global__ __launch_bounds__(NTHREADS) void loha_factor_grad_mfma_kernel(LohaArgs a, LohaGradGeom gm) {
+  __shared__ __attribute__((aligned(16))) float sm[loha_grad_lds_floats()];
+  loha_factor_grad_body<NO>(a, gm, sm, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ---- grouped launch: HadaWeight.backward of up to LHG_MAX layers in ONE grid ---------------------------------------------
+// The per-layer launch needs ~400+ workgroups for parallelism, i.e. one 64 x 64 tile each, and then pays 2 fp32 atomics per
+// element of G (the a-side gradients of a tile are shared with the other column tiles, the b-side with the other row tiles):
+// 4.4 G atomics per SDXL step, ~15 ms at the measured 300 G/s.  With the factor gradients deferred (they feed the optimizer
+// only) a batch of layers supplies the parallelism, so a workgroup can own an NO x nt BLOCK of tiles and keep the a-side sums in
+// registers over nt column tiles and the b-side sums over NO row tiles: 1/nt + 1/NO atomics per element instead of 2.
+constexpr int LHG_MAX = 24;
+struct LohaGradItem {
+  const float *w1a, *w1b, *w2a, *w2b, *G;
+  float *d_w1a, *d_w1b, *d_w2a, *d_w2b;
+  int O, I, R, nt, gx;  // gx: workgroups along the row-tile axis (block index = by * gx + bx)
+  float scale;
+};
+struct LohaGradGroupArgs {
+  int n;
+  int wg_end[LHG_MAX];
+  LohaGradItem p[LHG_MAX];
+};
+static_assert(sizeof(LohaGradGroupArgs) <= 3584, "kernel arguments are limited to 4 KiB");
+
+template <int NO>
+__global__ __launch_bounds__(NTHREADS) void loha_factor_grad_group_kernel(LohaGradGroupArgs ga) {
+  __shared__ __attribute__((aligned(16))) float sm[loha_grad_lds_floats()];
+  const int b = (int)blockIdx.x;
+  int q = 0;
+  while (q + 1 < ga.n && b >= ga.wg_end[q]) ++q;
+  const int bl = b - (q ? ga.wg_end[q - 1] : 0);
+  const LohaGradItem& it = ga.p[q];
+  LohaArgs a{};
+  a.w1a = it.w1a; a.w1b = it.w1b; a.w2a = it.w2a; a.w2b = it.w2b; a.G = it.G;
+  a.d_w1a = it.d_w1a; a.d_w1b = it.d_w1b; a.d_w2a = it.d_w2a; a.d_w2b = it.d_w2b;
+  a.O = it.O; a.I = it.I; a.R = it.R; a.scale = it.scale;
+  LohaGradGeom gm{it.nt};
+  loha_factor_grad_body<NO>(a, gm, sm, bl % it.gx, bl / it.gx);
 }
 
 }  // namespace lyc

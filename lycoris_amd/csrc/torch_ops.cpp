@@ -11,6 +11,7 @@
 #include <ATen/ATen.h>
 #include <ATen/autocast_mode.h>
 #include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/extension.h>
@@ -152,12 +153,21 @@ struct DeferredLocon {
   void* stream;
   c10::DeviceIndex device;
 };
+struct DeferredLoha {
+  Tensor g, x, f[4], p[4], d[4];  // f: fp32 contiguous factors, p: the parameters (for the sync callback), d: .grad targets
+  int64_t M;
+  int I, O, r, code;
+  float alpha;
+  void* stream;
+  c10::DeviceIndex device;
+};
 struct Deferred {
   bool enabled = true;
   size_t flush_at = 48;
   std::mutex mu;
   std::vector<DeferredLokr> lokr;
   std::vector<DeferredLocon> locon;
+  std::vector<DeferredLoha> loha;
   bool callback_queued = false;
 } g_defer;
 
@@ -175,10 +185,12 @@ void join_ambient(c10::DeviceIndex device, void* stream) {
 void flush_deferred() {
   std::vector<DeferredLokr> items;
   std::vector<DeferredLocon> litems;
+  std::vector<DeferredLoha> hitems;
   {
     std::lock_guard<std::mutex> lock(g_defer.mu);
     items.swap(g_defer.lokr);
     litems.swap(g_defer.locon);
+    hitems.swap(g_defer.loha);
     g_defer.callback_queued = false;
   }
   // one call per (device, stream, dtype) run of items, in arrival order
@@ -214,7 +226,30 @@ void flush_deferred() {
     join_ambient(litems[lo].device, litems[lo].stream);
     lo = hi;
   }
+  for (size_t lo = 0; lo < hitems.size();) {
+    size_t hi = lo + 1;
+    while (hi < hitems.size() && hitems[hi].device == hitems[lo].device && hitems[hi].stream == hitems[lo].stream &&
+           hitems[hi].code == hitems[lo].code)
+      ++hi;
+    const c10::DeviceGuard guard(c10::Device(c10::kCUDA, hitems[lo].device));
+    const c10::hip::HIPStreamGuard sguard(c10::hip::getStreamFromExternal((hipStream_t)hitems[lo].stream, hitems[lo].device));
+    std::vector<LycLohaWgradItem> raw(hi - lo);
+    std::vector<Tensor> gws(hi - lo);  // G = g^T x of every layer of the batch: [O, I] fp32 each (HBM is not the constraint here)
+    for (size_t i = lo; i < hi; ++i) {
+      const DeferredLoha& it = hitems[i];
+      gws[i - lo] = at::empty({it.O, it.I}, it.x.options().dtype(at::kFloat));
+      raw[i - lo] = LycLohaWgradItem{cptr(it.g), cptr(it.x), cfp(it.f[0]), cfp(it.f[1]), cfp(it.f[2]), cfp(it.f[3]),
+                                     mfp(it.d[0]), mfp(it.d[1]), mfp(it.d[2]), mfp(it.d[3]), mfp(gws[i - lo]), it.M,
+                                     it.I, it.O, it.r, it.alpha};
+    }
+    check_rc(lyc_loha_wgrad_group(raw.data(), (int)raw.size(), hitems[lo].code, hitems[lo].stream), "lyc_loha_wgrad_group");
+    lo = hi;
+  }
+  for (size_t lo = 0; lo < hitems.size(); ++lo)
+    if (lo + 1 == hitems.size() || hitems[lo + 1].stream != hitems[lo].stream) join_ambient(hitems[lo].device, hitems[lo].stream);
   // the gradients are enqueued: tell the DP sync (no lock held: this takes the GIL)
+  for (const DeferredLoha& it : hitems)
+    for (int i = 0; i < 4; ++i) notify(it.p[i]);
   for (const DeferredLokr& it : items) {
     if (it.dw1.defined()) notify(it.w1);
     notify(it.w2);
@@ -233,13 +268,14 @@ void park_deferred_in(std::vector<Item> Deferred::*list, Item&& item) {
     std::lock_guard<std::mutex> lock(g_defer.mu);
     (g_defer.*list).push_back(std::move(item));
     if (!g_defer.callback_queued) g_defer.callback_queued = queue = true;
-    full = g_defer.lokr.size() + g_defer.locon.size() >= g_defer.flush_at;
+    full = g_defer.lokr.size() + g_defer.locon.size() + g_defer.loha.size() >= g_defer.flush_at;
   }
   if (queue) torch::autograd::Engine::get_default_engine().queue_callback([]() { flush_deferred(); });
   if (full) flush_deferred();
 }
 void park_deferred(DeferredLokr&& item) { park_deferred_in(&Deferred::lokr, std::move(item)); }
 void park_deferred(DeferredLocon&& item) { park_deferred_in(&Deferred::locon, std::move(item)); }
+void park_deferred(DeferredLoha&& item) { park_deferred_in(&Deferred::loha, std::move(item)); }
 
 // =====================================================================================================================
 // LoKr on nn.Linear
@@ -527,6 +563,28 @@ Tensor loha_linear_bwd_into(const Tensor& g, const Tensor& x, const Tensor& w1a,
   return need_dx ? dx.view(x.sizes()) : Tensor();
 }
 
+// dx = g dW now, G = g^T x and HadaWeight.backward later (park_deferred); false = not on the grouped path
+bool loha_linear_bwd_deferred(const Tensor& g, const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a,
+                              const Tensor& w2b, const Tensor& ws, double alpha, bool need_dx, Tensor (&d)[4], Tensor& dx_out) {
+  const c10::DeviceGuard guard(x.device());
+  const int64_t O = w1a.size(0), r = w1a.size(1), I = w1b.size(1);
+  Tensor rows = rows_of(x, I), g2 = rows_of(g, O);
+  const int code = dtype_code(x.scalar_type());
+  if (!lyc_loha_wgrad_deferrable(cptr(g2), cptr(rows), rows.size(0), (int)I, (int)O, (int)r, code)) return false;
+  Tensor a1 = f32c(w1a), b1 = f32c(w1b), a2 = f32c(w2a), b2 = f32c(w2b);
+  Tensor dx;
+  if (need_dx) {
+    dx = at::empty(rows.sizes(), x.options());
+    check_rc(lyc_loha_linear_bwd(cptr(g2), cptr(rows), cfp(a1), cfp(b1), cfp(a2), cfp(b2), cptr(ws), nullptr, mptr(dx), nullptr,
+                                 nullptr, nullptr, nullptr, rows.size(0), (int)I, (int)O, (int)r, (float)alpha, code, stream_of(x)),
+             "lyc_loha_linear_bwd(dx)");
+  }
+  park_deferred(DeferredLoha{g2, rows, {a1, b1, a2, b2}, {w1a, w1b, w2a, w2b}, {d[0], d[1], d[2], d[3]}, rows.size(0), (int)I,
+                             (int)O, (int)r, code, (float)alpha, stream_of(x), x.device().index()});
+  dx_out = need_dx ? dx.view(x.sizes()) : Tensor();
+  return true;
+}
+
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> loha_linear_bwd(const Tensor& g, const Tensor& x, const Tensor& w1a,
                                                                    const Tensor& w1b, const Tensor& w2a, const Tensor& w2b,
                                                                    const Tensor& ws, double alpha, bool need_dx, bool need_f) {
@@ -564,6 +622,13 @@ struct LohaLinearFn : public torch::autograd::Function<LohaLinearFn> {
       for (int i = 0; i < 4; ++i) {
         t[i] = grad_target(s[1 + i], nf[i] || accum_wanted(s[1 + i]));
         d[i] = t[i].buf;
+      }
+      bool all_accum = g_defer.enabled;  // all four factor gradients go straight into .grad: dx now, the rest grouped
+      for (int i = 0; i < 4; ++i) all_accum = all_accum && d[i].defined() && !t[i].hand_back;
+      if (all_accum) {
+        Tensor dx;
+        if (loha_linear_bwd_deferred(g, s[0], s[1], s[2], s[3], s[4], s[5], alpha, nx, d, dx))
+          return {dx, Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
       }
       Tensor dx = loha_linear_bwd_into(g, s[0], s[1], s[2], s[3], s[4], s[5], alpha, nx, d);
       return {dx, finish_grad(s[1], t[0]), finish_grad(s[2], t[1]), finish_grad(s[3], t[2]), finish_grad(s[4], t[3]), Tensor()};
@@ -982,7 +1047,7 @@ PYBIND11_MODULE(_lyc_torch, m) {
   m.def("defer_enabled", []() { return g_defer.enabled; });
   m.def("deferred_pending", []() {
     std::lock_guard<std::mutex> lk(g_defer.mu);
-    return g_defer.lokr.size() + g_defer.locon.size();
+    return g_defer.lokr.size() + g_defer.locon.size() + g_defer.loha.size();
   });
   m.def("flush_deferred", []() {
     py::gil_scoped_release nogil;  // flush_deferred() notifies through a callback that takes the GIL itself
@@ -991,11 +1056,13 @@ PYBIND11_MODULE(_lyc_torch, m) {
   m.def("discard_deferred", []() {  // after a failed backward: drop parked layers instead of adding them to the next step
     std::vector<DeferredLokr> items;
     std::vector<DeferredLocon> litems;
+    std::vector<DeferredLoha> hitems;
     std::lock_guard<std::mutex> lk(g_defer.mu);
     items.swap(g_defer.lokr);
     litems.swap(g_defer.locon);
+    hitems.swap(g_defer.loha);
     g_defer.callback_queued = false;
-    return items.size() + litems.size();
+    return items.size() + litems.size() + hitems.size();
   });
   m.def("abi_version", []() { return lyc_abi_version(); });
 }

@@ -302,3 +302,92 @@ def test_locon_grads_are_complete_when_backward_returns(flush_at):
     for u, v in zip(g0, g1):
         assert float(u.abs().max()) > 0 and torch.allclose(u, v, rtol=2e-4, atol=1e-6), float((u - v).abs().max())
     assert sorted(seen0) == sorted(seen1) and len(seen1) == 10
+
+
+# ---- LoHa: lyc_loha_linear_bwd with NULL gradient pointers (dx only), then lyc_loha_wgrad_group -----------------------------
+LOHA_SHAPES = [(256, 1280, 1280, 32), (77, 2048, 640, 32), (300, 640, 2560, 16), (50, 72, 40, 4), (1, 320, 1280, 32),
+               (128, 200, 136, 40)]  # (M, I, O, r): blocks of 4 x n, 2 x n and single tiles, ragged edges, a rank > 32
+
+
+def _loha_problem(gen, M, I, O, r, dtype):
+    x, x64 = rnd((M, I), dtype, gen)
+    g, g64 = rnd((M, O), dtype, gen, 0.1)
+    fs = [rnd((O, r), torch.float32, gen, 0.3), rnd((r, I), torch.float32, gen, 0.3), rnd((O, r), torch.float32, gen, 0.3),
+          rnd((r, I), torch.float32, gen, 0.3)]
+    return (g, x, [f[0] for f in fs]), (g64, x64, [f[1] for f in fs])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_grouped_loha_factor_gradients_match_the_oracle(dtype):
+    from lycoris_amd import _native as N
+    gen = torch.Generator().manual_seed(31)
+    code = N.dtype_code(dtype)
+    alpha = 0.7
+    both = [_loha_problem(gen, *s, dtype) for s in LOHA_SHAPES]
+    both += [_loha_problem(gen, 64, 128, 128, 8, dtype) for _ in range(26)]  # > 24 items of one configuration
+    items = (N.LohaWgradItem * len(both))()
+    outs, keep = [], []
+    for k, ((g, x, fs), _) in enumerate(both):
+        M, I, O, r = x.shape[0], x.shape[1], g.shape[1], fs[0].shape[1]
+        ws = torch.empty(int(N.load().lyc_loha_workspace_bytes(O, I, code)), dtype=torch.uint8, device=DEV)
+        y, dx = torch.empty_like(g), torch.empty_like(x)
+        N.call("lyc_loha_linear_fwd", N.ptr(x), *[N.ptr(f) for f in fs], N.ptr(ws), N.ptr(y), M, I, O, r, alpha, code, N.stream_ptr(x.device))
+        N.call("lyc_loha_linear_bwd", N.ptr(g), N.ptr(x), *[N.ptr(f) for f in fs], N.ptr(ws), None, N.ptr(dx), None, None, None, None,
+               M, I, O, r, alpha, code, N.stream_ptr(x.device))
+        ds = [torch.zeros_like(f) for f in fs]
+        gw = torch.empty(O, I, device=DEV)
+        items[k] = N.LohaWgradItem(N.ptr(g), N.ptr(x), *[N.ptr(f) for f in fs], *[N.ptr(d) for d in ds], N.ptr(gw), M, I, O, r, alpha)
+        keep += [ws, gw]
+        outs.append((dx, ds))
+    N.call("lyc_loha_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(both), code, N.stream_ptr(both[0][0][1].device))
+    torch.cuda.synchronize()
+    for k, ((_, (g64, x64, f64)), (dx, ds)) in enumerate(zip(both, outs)):
+        rx, *rf = oracle.loha.backward(x64, g64, *f64, scale=alpha)
+        for name, d, want in zip(("w1a", "w1b", "w2a", "w2b"), ds, rf):
+            assert err(d, want) <= TOL["f32_out"][dtype], (k, name, err(d, want))
+        assert err(dx, rx, dtype) <= TOL["loha_store"][dtype], (k, "dx")
+
+
+class _LohaStack(nn.Module):
+    def __init__(self, n=3, width=128, r=8):
+        super().__init__()
+        mk = lambda *s: nn.Parameter(torch.randn(*s, device=DEV) * 0.3)
+        self.f = nn.ModuleList([nn.ParameterList([mk(width, r), mk(r, width), mk(width, r), mk(r, width)]) for _ in range(n)])
+
+    def forward(self, x):
+        from lycoris_amd import ops
+        for i in list(range(len(self.f))) + [0]:
+            x = x + ops.loha_linear(x, *self.f[i], 0.5)
+        return x
+
+
+def test_loha_grads_are_complete_when_backward_returns():
+    from lycoris_amd import ops
+    torch.manual_seed(7)
+    net = _LohaStack()
+    x = (torch.randn(80, 128, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    gy = (torch.randn(80, 128, device=DEV) * 0.1).to(torch.bfloat16)
+    params = list(net.parameters())
+
+    def run(defer):
+        seen = []
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        x.grad = None
+        ops.fused_grad_accumulation(True, callback=lambda p: seen.append(id(p)))
+        ops.deferred_weight_gradients(defer, 48)
+        try:
+            net(x).backward(gy)
+            assert ops._DISPATCH["ext"].deferred_pending() == 0
+            torch.cuda.synchronize()
+            return x.grad.clone(), [p.grad.clone() for p in params], seen
+        finally:
+            ops.fused_grad_accumulation(False, None)
+            ops.deferred_weight_gradients(True, 48)
+
+    dx0, g0, seen0 = run(False)
+    dx1, g1, seen1 = run(True)
+    assert torch.equal(dx0, dx1)
+    for u, v in zip(g0, g1):
+        assert float(u.abs().max()) > 0 and torch.allclose(u, v, rtol=2e-4, atol=1e-6), float((u - v).abs().max())
+    assert sorted(seen0) == sorted(seen1) and len(seen1) == 16
