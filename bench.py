@@ -683,15 +683,15 @@ def reference_leg(insts, sync, native_graph_ms):
 def base_leg(insts, sync):
     """the step with the frozen layers' own ops in it (rocBLAS / MIOpen forward + dx-only backward), next to
     the adapter-only number: base alone, and base + adapter (out = base + delta, one autograd.grad for both)."""
+    def one_backward(outs):  # ONE engine invocation for all layers, as loss.backward() is one for a real network
+        outs = outs[::-1]
+        torch.autograd.grad([y for y, _ in outs], [it.x for _, it in outs], [it.g for _, it in outs])
+
     def base_pass():
-        outs = [(it.base_forward(), it) for it in insts]
-        for y, it in reversed(outs):
-            torch.autograd.grad(y, [it.x], it.g)
+        one_backward([(it.base_forward(), it) for it in insts])
 
     def both_pass():
-        outs = [(it.forward(base=it.base_forward()), it) for it in insts]
-        for y, it in reversed(outs):
-            torch.autograd.grad(y, [it.x], it.g)
+        one_backward([(it.forward(base=it.base_forward()), it) for it in insts])
 
     sync._sync_enabled = False
     try:

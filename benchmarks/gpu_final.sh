@@ -22,6 +22,7 @@ run locon $Q --algo locon
 run locon_nodefer $Q --algo locon --no-defer --no-reference --no-base --no-roofline
 run sd15_locon $Q --algo locon --model sd15
 run loha --steps 5 --warmup 2 --no-cpu-baseline --algo loha
+run loha_nodefer --steps 5 --warmup 2 --no-cpu-baseline --algo loha --no-defer --no-reference --no-base --no-roofline
 run ia3 $Q --algo ia3
 run mixed_fp16 $Q --preset mixed --dtype fp16
 timeout 200 python benchmarks/host_overhead.py > $O/${TAG}_host_overhead.log 2>&1; echo "host rc=$?"; cp $O/host_overhead.json $O/${TAG}_host_overhead.json 2>/dev/null

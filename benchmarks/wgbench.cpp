@@ -130,5 +130,49 @@ int main() {
   }
   if (time_locon(lall.data(), (int)lall.size(), ms)) return 1;
   printf("locon SDXL Linear mix, %zu problems in one call: %8.3f ms  %7.1f GB/s\n", lall.size(), ms, total_bytes / (ms * 1e-3) / 1e9);
+
+  // ---- LoHa (rank 32): G = g^T x per layer (library GEMM) + grouped HadaWeight.backward ----------------------------------------
+  printf("loha plan: target %d  ntmax %d\n", LYC_LHG_TARGET, LYC_LHG_NTMAX);
+  std::vector<LycLohaWgradItem> hall;
+  std::vector<std::pair<size_t, size_t>> hrange;
+  for (size_t c = 0; c < sdxl.size(); ++c) {
+    const Shape& s = sdxl[c];
+    const size_t lo = hall.size();
+    const int I = s.a * s.d, O = s.a * s.c, r = 32;
+    for (size_t k = range[c].first; k < range[c].second; ++k) {
+      float *f[4], *d[4], *gw;
+      const size_t na = (size_t)O * r, nb = (size_t)r * I;
+      for (int j = 0; j < 4; ++j) {
+        const size_t nf = (j & 1) ? nb : na;
+        CK(hipMalloc((void**)&f[j], nf * 4));
+        CK(hipMalloc((void**)&d[j], nf * 4));
+        CK(hipMemset(f[j], 0, nf * 4));
+        CK(hipMemset(d[j], 0, nf * 4));
+      }
+      CK(hipMalloc((void**)&gw, (size_t)O * I * 4));
+      hall.push_back(LycLohaWgradItem{all[k].g, all[k].x, f[0], f[1], f[2], f[3], d[0], d[1], d[2], d[3], gw, s.M, I, O, r, 1.0f});
+    }
+    hrange.push_back({lo, hall.size()});
+  }
+  auto time_loha = [&](const LycLohaWgradItem* it, int n, float& ms_) -> int {
+    const int reps = 3;
+    if (lyc_loha_wgrad_group(it, n, LYC_BF16, st)) { fprintf(stderr, "%s\n", lyc_last_error()); return 1; }
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r) lyc_loha_wgrad_group(it, n, LYC_BF16, st);
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms_, e0, e1));
+    ms_ /= reps;
+    return 0;
+  };
+  for (size_t c = 0; c < sdxl.size(); ++c) {
+    if (time_loha(hall.data() + hrange[c].first, (int)(hrange[c].second - hrange[c].first), ms)) return 1;
+    int no = 1, nt = 1;
+    plan_loha_grad(sdxl[c].a * sdxl[c].c, sdxl[c].a * sdxl[c].d, 32, true, no, nt);
+    printf("loha %-18s x%3d : %8.3f ms  %6.2f us/problem   block %d x %d\n", sdxl[c].tag, sdxl[c].count, ms, ms * 1e3 / sdxl[c].count, no, nt);
+  }
+  if (time_loha(hall.data(), (int)hall.size(), ms)) return 1;
+  printf("loha SDXL Linear mix, %zu problems in one call (G GEMMs + factor gradients): %8.3f ms\n", hall.size(), ms);
   return 0;
 }

@@ -157,6 +157,9 @@ void launch_dw2s_inst(KronDw2sArgs da, long tiles_i, long tiles_j, hipStream_t s
 #ifndef LYC_WG_U
 #define LYC_WG_U 2
 #endif
+#ifndef LYC_GROUP_MIN
+#define LYC_GROUP_MIN 8  // layers in a lyc_*_wgrad_group call from which on the batch plans are used
+#endif
 #ifndef LYC_WG_WIDE
 #define LYC_WG_WIDE 2
 #endif
@@ -628,6 +631,9 @@ int lyc_lokr_wgrad_group(const LycLokrWgradItem* items, int n, int dtype, void* 
   if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "lokr_wgrad_group: bad item list");
   hipStream_t st = (hipStream_t)stream;
   const int dt = dtype & 0xff;
+  // The batch plans (fewer, longer slabs; 80 x 32 tiles) assume that the other layers of the call supply the parallelism: a
+  // call with a handful of layers (a backward pass over one or two modules) is planned like single launches.
+  const bool batch = n >= LYC_GROUP_MIN;
   // one sequence of launches per tile configuration (plan_dw2s), items keep their order
   for (int cfg = 0; cfg < DW2_NCFG; ++cfg) {
     KronDw2sGroupArgs ga{};
@@ -669,7 +675,7 @@ int lyc_lokr_wgrad_group(const LycLokrWgradItem* items, int n, int dtype, void* 
         da.dw1_nblk = (int)(cdiv(it.M, K3_RT / it.a) * cdiv(it.d, 16 * ni));
         da.dw1_red = 1;
       }
-      if (plan_dw2s(da, true) != cfg) continue;
+      if (plan_dw2s(da, batch) != cfg) continue;
       const long wgs = round_up((long)da.tiles_i * da.tiles_j * da.nsplit, 8) + round_up(da.dw1_ws ? da.dw1_red : 0, 8);
       const long before = ga.n ? ga.wg_end[ga.n - 1] : 0;
       if (ga.n == DW2G_MAX || before + wgs > (1L << 30))
@@ -931,7 +937,7 @@ int lyc_locon_wgrad_group(const LycLoconWgradItem* items, int n, int dtype, void
         if ((it.r <= 16 ? 1 : it.r <= 32 ? 2 : 4) != rt) continue;
         LowrankTnArgs ta{};
         locon_tn_problems(ta, it.g, it.x, it.t, it.dt, it.d_down, it.d_up, it.M, it.I, it.O, it.r, it.alpha);
-        const int cv = plan_lowrank_tn(ta, dtype, true);
+        const int cv = plan_lowrank_tn(ta, dtype, n >= LYC_GROUP_MIN);
         if (cv == 0) return fail(LYC_ERR_UNSUPPORTED, "locon_wgrad_group: item %d: unaligned activations", k);
         if (cv != cvw) continue;
         const long wgs = cdiv((long)(ta.p[0].tiles + ta.p[1].tiles) * ta.nsplit, NWAVES);
@@ -1162,14 +1168,21 @@ rocblas_datatype rb_type(int dtype) {
 #ifndef LYC_LHG_NTMAX
 #define LYC_LHG_NTMAX 8
 #endif
+// one rank chunk and float4 staging (the conditions of lh_vec_ok): the lean instantiation of the factor-gradient kernels
+bool loha_grad_fast(const float* w1a, const float* w1b, const float* w2a, const float* w2b, long I, int r) {
+  return r <= LOHA_RC && (r % 4) == 0 && (I % 4) == 0 &&
+         (((reinterpret_cast<uintptr_t>(w1a) | reinterpret_cast<uintptr_t>(w2a) | reinterpret_cast<uintptr_t>(w1b) |
+            reinterpret_cast<uintptr_t>(w2b)) & 15u) == 0);
+}
+
 void plan_loha_grad(long O, long I, int r, bool grouped, int& no, int& nt) {
   const long tiles_o = cdiv(O, LOHA_T), tiles_j = cdiv(I, LOHA_T);
   const long per = (tiles_o * tiles_j) / (grouped ? LYC_LHG_TARGET : 512);
   no = 1;
   nt = 1;
   if (r <= LOHA_RC && per >= 2) {
-    no = per >= 8 ? 4 : 2;
-    if (no > tiles_o) no = tiles_o >= 2 ? 2 : 1;
+    no = 2;  // (4 row tiles per workgroup need > 256 registers: one wave per SIMD, measured slower than 2 x nt)
+    if (no > tiles_o) no = 1;
     nt = (int)(per / no);
     if (nt < 1) nt = 1;
     if (grouped && nt > LYC_LHG_NTMAX) nt = LYC_LHG_NTMAX;
@@ -1188,6 +1201,14 @@ void launch_loha_factor_grad(const float* gw, const float* w1a, const float* w1b
   plan_loha_grad(O, I, r, false, no, gm.nt);
   const long tiles_o = cdiv(O, LOHA_T), tiles_j = cdiv(I, LOHA_T);
   dim3 fg((unsigned)cdiv(tiles_o, no), (unsigned)cdiv(tiles_j, gm.nt));
+  if (loha_grad_fast(w1a, w1b, w2a, w2b, I, r)) {
+    switch (no) {
+      case 4: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<4, true>), fg, dim3(NTHREADS), 0, st, la, gm); break;
+      case 2: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<2, true>), fg, dim3(NTHREADS), 0, st, la, gm); break;
+      default: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<1, true>), fg, dim3(NTHREADS), 0, st, la, gm); break;
+    }
+    return;
+  }
   switch (no) {
     case 4: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<4>), fg, dim3(NTHREADS), 0, st, la, gm); break;
     case 2: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<2>), fg, dim3(NTHREADS), 0, st, la, gm); break;
@@ -1300,15 +1321,24 @@ int lyc_loha_wgrad_group(const LycLohaWgradItem* items, int n, int dtype, void* 
                          rocblas_datatype_f32_r, 1.0f, 0.0f, "loha_wgrad_group(G)"))
       return rc;
   }
-  for (int no = 1; no <= 4; no <<= 1) {  // one sequence of launches per row-block instantiation
+  for (int fast = 0; fast < 2; ++fast)
+  for (int no = 1; no <= 4; no <<= 1) {  // one sequence of launches per kernel instantiation
     LohaGradGroupArgs ga{};
     auto flush = [&]() -> int {
       if (ga.n == 0) return LYC_OK;
       const dim3 grid((unsigned)ga.wg_end[ga.n - 1]);
-      switch (no) {
-        case 4: hipLaunchKernelGGL((loha_factor_grad_group_kernel<4>), grid, dim3(NTHREADS), 0, st, ga); break;
-        case 2: hipLaunchKernelGGL((loha_factor_grad_group_kernel<2>), grid, dim3(NTHREADS), 0, st, ga); break;
-        default: hipLaunchKernelGGL((loha_factor_grad_group_kernel<1>), grid, dim3(NTHREADS), 0, st, ga); break;
+      if (fast) {
+        switch (no) {
+          case 4: hipLaunchKernelGGL((loha_factor_grad_group_kernel<4, true>), grid, dim3(NTHREADS), 0, st, ga); break;
+          case 2: hipLaunchKernelGGL((loha_factor_grad_group_kernel<2, true>), grid, dim3(NTHREADS), 0, st, ga); break;
+          default: hipLaunchKernelGGL((loha_factor_grad_group_kernel<1, true>), grid, dim3(NTHREADS), 0, st, ga); break;
+        }
+      } else {
+        switch (no) {
+          case 4: hipLaunchKernelGGL((loha_factor_grad_group_kernel<4>), grid, dim3(NTHREADS), 0, st, ga); break;
+          case 2: hipLaunchKernelGGL((loha_factor_grad_group_kernel<2>), grid, dim3(NTHREADS), 0, st, ga); break;
+          default: hipLaunchKernelGGL((loha_factor_grad_group_kernel<1>), grid, dim3(NTHREADS), 0, st, ga); break;
+        }
       }
       ga = LohaGradGroupArgs{};
       return check_launch("loha_wgrad_group");
@@ -1316,8 +1346,8 @@ int lyc_loha_wgrad_group(const LycLohaWgradItem* items, int n, int dtype, void* 
     for (int k = 0; k < n; ++k) {
       const LycLohaWgradItem& it = items[k];
       int pno = 1, nt = 1;
-      plan_loha_grad(it.O, it.I, it.r, true, pno, nt);
-      if (pno != no) continue;
+      plan_loha_grad(it.O, it.I, it.r, n >= LYC_GROUP_MIN, pno, nt);
+      if (pno != no || (loha_grad_fast(it.w1a, it.w1b, it.w2a, it.w2b, it.I, it.r) ? 1 : 0) != fast) continue;
       const long gx = cdiv(cdiv(it.O, LOHA_T), no), gy = cdiv(cdiv(it.I, LOHA_T), nt);
       const long before = ga.n ? ga.wg_end[ga.n - 1] : 0;
       if (ga.n == LHG_MAX || before + gx * gy > (1L << 30))

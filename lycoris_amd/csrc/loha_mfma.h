@@ -220,7 +220,9 @@ struct LohaGradGeom {
 constexpr int loha_grad_lds_floats() { return 2 * LOHA_T * LH_AP + 2 * LOHA_RC * LH_BP + 2 * LOHA_T * LH_TP; }
 
 // `bx`, `by`: this workgroup's block of row tiles / column tiles; `sm`: loha_grad_lds_floats() floats
-template <int NO>
+// FAST: rank <= 32 (one chunk) and float4 staging (lh_vec_ok) are guaranteed by the host: the chunk loops and the element-wise
+// staging path disappear at compile time, and with them ~60 live registers (280 -> 2 waves per SIMD without spills).
+template <int NO, bool FAST>
 __device__ __forceinline__ void loha_factor_grad_body(const LohaArgs& a, const LohaGradGeom& gm, float* sm, const int bx,
                                                       const int by) {
   float* sA1 = sm;
@@ -233,8 +235,8 @@ __device__ __forceinline__ void loha_factor_grad_body(const LohaArgs& a, const L
   const long ob = (long)bx * NO;  // first row tile
   const long jb = (long)by * gm.nt;
   const long tiles_j = (a.I + LOHA_T - 1) / LOHA_T;
-  const int nchunk = (a.R + LOHA_RC - 1) / LOHA_RC;
-  const bool vec_in = lh_vec_ok(a);
+  const int nchunk = FAST ? 1 : (a.R + LOHA_RC - 1) / LOHA_RC;
+  const bool vec_in = FAST ? true : lh_vec_ok(a);
 
   f32x4 da1[NO][2], da2[NO][2];  // d_w*a of row tile os: rows o = 16 wave + 4 g + q, column r = 16 rt + li
 #pragma unroll
@@ -356,10 +358,14 @@ __device__ __forceinline__ void loha_factor_grad_body(const LohaArgs& a, const L
   }
 }
 
-template <int NO>
-__global__ __launch_bounds__(NTHREADS) void loha_factor_grad_mfma_kernel(LohaArgs a, LohaGradGeom gm) {
+// Two waves per SIMD (<= 256 registers) for the lean instantiations with one or two row tiles per workgroup: the general form
+// needs 280 - 512 registers (the NO = 4 block even spills), and with one wave per SIMD nothing hides the LDS / global round
+// trips between the MFMA bursts of a tile -- measured: every instantiation ran at ~1/5 of its MFMA bound.
+#define LYC_LH_OCC(NO, FAST) __attribute__((amdgpu_waves_per_eu(((FAST) && (NO) <= 2) ? 2 : 1, 2)))
+template <int NO, bool FAST = false>
+__global__ __launch_bounds__(NTHREADS) LYC_LH_OCC(NO, FAST) void loha_factor_grad_mfma_kernel(LohaArgs a, LohaGradGeom gm) {
   __shared__ __attribute__((aligned(16))) float sm[loha_grad_lds_floats()];
-  loha_factor_grad_body<NO>(a, gm, sm, (int)blockIdx.x, (int)blockIdx.y);
+  loha_factor_grad_body<NO, FAST>(a, gm, sm, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ---- grouped launch: HadaWeight.backward of up to LHG_MAX layers in ONE grid ---------------------------------------------
@@ -382,8 +388,8 @@ struct LohaGradGroupArgs {
 };
 static_assert(sizeof(LohaGradGroupArgs) <= 3584, "kernel arguments are limited to 4 KiB");
 
-template <int NO>
-__global__ __launch_bounds__(NTHREADS) void loha_factor_grad_group_kernel(LohaGradGroupArgs ga) {
+template <int NO, bool FAST = false>
+__global__ __launch_bounds__(NTHREADS) LYC_LH_OCC(NO, FAST) void loha_factor_grad_group_kernel(LohaGradGroupArgs ga) {
   __shared__ __attribute__((aligned(16))) float sm[loha_grad_lds_floats()];
   const int b = (int)blockIdx.x;
   int q = 0;
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(NTHREADS) void loha_factor_grad_group_kernel(LohaGr
   a.d_w1a = it.d_w1a; a.d_w1b = it.d_w1b; a.d_w2a = it.d_w2a; a.d_w2b = it.d_w2b;
   a.O = it.O; a.I = it.I; a.R = it.R; a.scale = it.scale;
   LohaGradGeom gm{it.nt};
-  loha_factor_grad_body<NO>(a, gm, sm, bl % it.gx, bl / it.gx);
+  loha_factor_grad_body<NO, FAST>(a, gm, sm, bl % it.gx, bl / it.gx);
 }
 
 }  // namespace lyc

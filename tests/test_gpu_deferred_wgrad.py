@@ -391,3 +391,21 @@ def test_loha_grads_are_complete_when_backward_returns():
     for u, v in zip(g0, g1):
         assert float(u.abs().max()) > 0 and torch.allclose(u, v, rtol=2e-4, atol=1e-6), float((u - v).abs().max())
     assert sorted(seen0) == sorted(seen1) and len(seen1) == 16
+
+
+def test_small_batches_take_the_single_launch_plans():
+    """fewer than 8 layers in a call: planned like per-layer launches (the batch plans would starve the chip)"""
+    from lycoris_amd import _native as N
+    gen = torch.Generator().manual_seed(41)
+    dtype, alpha = torch.bfloat16, 0.7
+    code = N.dtype_code(dtype)
+    both = [_problem(gen, *s, dtype) for s in SHAPES[:3]]
+    got = _deferred(N, [b[0] for b in both], alpha, code)
+    for k, ((_, h), (dx, dw1, dw2)) in enumerate(zip(both, got)):
+        r1, r2 = _oracle(h, alpha)
+        assert err(dw1, r1) <= TOL["f32_out"][dtype] and err(dw2, r2) <= TOL["f32_out"][dtype], k
+    lboth = [_locon_problem(gen, *s, dtype) for s in LOCON_SHAPES[:3]]
+    lgot = _locon_deferred(N, [b[0] for b in lboth], alpha, code)
+    for k, ((_, (g64, x64, d64, u64)), (dx, dd, du)) in enumerate(zip(lboth, lgot)):
+        _, rd, ru = oracle.locon.backward(x64, g64, d64, u64, scale=alpha)
+        assert err(dd, rd) <= TOL["f32_out"][dtype] and err(du, ru) <= TOL["f32_out"][dtype], k
