@@ -1203,14 +1203,12 @@ void launch_loha_factor_grad(const float* gw, const float* w1a, const float* w1b
   dim3 fg((unsigned)cdiv(tiles_o, no), (unsigned)cdiv(tiles_j, gm.nt));
   if (loha_grad_fast(w1a, w1b, w2a, w2b, I, r)) {
     switch (no) {
-      case 4: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<4, true>), fg, dim3(NTHREADS), 0, st, la, gm); break;
       case 2: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<2, true>), fg, dim3(NTHREADS), 0, st, la, gm); break;
       default: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<1, true>), fg, dim3(NTHREADS), 0, st, la, gm); break;
     }
     return;
   }
   switch (no) {
-    case 4: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<4>), fg, dim3(NTHREADS), 0, st, la, gm); break;
     case 2: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<2>), fg, dim3(NTHREADS), 0, st, la, gm); break;
     default: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<1>), fg, dim3(NTHREADS), 0, st, la, gm); break;
   }
@@ -1322,20 +1320,18 @@ int lyc_loha_wgrad_group(const LycLohaWgradItem* items, int n, int dtype, void* 
       return rc;
   }
   for (int fast = 0; fast < 2; ++fast)
-  for (int no = 1; no <= 4; no <<= 1) {  // one sequence of launches per kernel instantiation
+  for (int no = 1; no <= 2; no <<= 1) {  // one sequence of launches per kernel instantiation
     LohaGradGroupArgs ga{};
     auto flush = [&]() -> int {
       if (ga.n == 0) return LYC_OK;
       const dim3 grid((unsigned)ga.wg_end[ga.n - 1]);
       if (fast) {
         switch (no) {
-          case 4: hipLaunchKernelGGL((loha_factor_grad_group_kernel<4, true>), grid, dim3(NTHREADS), 0, st, ga); break;
           case 2: hipLaunchKernelGGL((loha_factor_grad_group_kernel<2, true>), grid, dim3(NTHREADS), 0, st, ga); break;
           default: hipLaunchKernelGGL((loha_factor_grad_group_kernel<1, true>), grid, dim3(NTHREADS), 0, st, ga); break;
         }
       } else {
         switch (no) {
-          case 4: hipLaunchKernelGGL((loha_factor_grad_group_kernel<4>), grid, dim3(NTHREADS), 0, st, ga); break;
           case 2: hipLaunchKernelGGL((loha_factor_grad_group_kernel<2>), grid, dim3(NTHREADS), 0, st, ga); break;
           default: hipLaunchKernelGGL((loha_factor_grad_group_kernel<1>), grid, dim3(NTHREADS), 0, st, ga); break;
         }

@@ -169,6 +169,7 @@ struct Deferred {
   std::vector<DeferredLocon> locon;
   std::vector<DeferredLoha> loha;
   bool callback_queued = false;
+  int queued_task = -1;  // graph task the pending end-of-backward callback belongs to
 } g_defer;
 
 // after launches on `stream`: whoever consumes .grad on the ambient stream must see them
@@ -264,10 +265,16 @@ void flush_deferred() {
 template <typename Item>
 void park_deferred_in(std::vector<Item> Deferred::*list, Item&& item) {
   bool queue = false, full = false;
+  // one final callback per backward pass (graph task) that parks something: a pass that died with an exception never runs
+  // its callback, so "a callback is queued" must not be remembered across passes
+  const int task = torch::autograd::get_current_graph_task_id();
   {
     std::lock_guard<std::mutex> lock(g_defer.mu);
     (g_defer.*list).push_back(std::move(item));
-    if (!g_defer.callback_queued) g_defer.callback_queued = queue = true;
+    if (!g_defer.callback_queued || g_defer.queued_task != task) {
+      g_defer.callback_queued = queue = true;
+      g_defer.queued_task = task;
+    }
     full = g_defer.lokr.size() + g_defer.locon.size() + g_defer.loha.size() >= g_defer.flush_at;
   }
   if (queue) torch::autograd::Engine::get_default_engine().queue_callback([]() { flush_deferred(); });

@@ -409,3 +409,72 @@ def test_small_batches_take_the_single_launch_plans():
     for k, ((_, (g64, x64, d64, u64)), (dx, dd, du)) in enumerate(zip(lboth, lgot)):
         _, rd, ru = oracle.locon.backward(x64, g64, d64, u64, scale=alpha)
         assert err(dd, rd) <= TOL["f32_out"][dtype] and err(du, ru) <= TOL["f32_out"][dtype], k
+
+
+def test_deferred_gradients_under_activation_checkpointing():
+    """torch.utils.checkpoint re-runs the forward inside the backward pass: the parked layers of the re-run segment are flushed
+    by the same end-of-backward callback"""
+    from torch.utils.checkpoint import checkpoint
+    from lycoris_amd import ops
+    torch.manual_seed(8)
+    net = _Stack(n=3)
+    x = (torch.randn(64, 128, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    gy = (torch.randn(64, 128, device=DEV) * 0.1).to(torch.bfloat16)
+    params = list(net.parameters())
+
+    def run(ckpt):
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        x.grad = None
+        ops.fused_grad_accumulation(True, None)
+        try:
+            y = checkpoint(net, x, use_reentrant=False) if ckpt else net(x)
+            y.backward(gy)
+            assert ops._DISPATCH["ext"].deferred_pending() == 0
+            torch.cuda.synchronize()
+            return x.grad.clone(), [p.grad.clone() for p in params]
+        finally:
+            ops.fused_grad_accumulation(False, None)
+
+    dx0, g0 = run(False)
+    dx1, g1 = run(True)
+    assert torch.equal(dx0, dx1)
+    for u, v in zip(g0, g1):
+        assert torch.allclose(u, v, rtol=2e-4, atol=1e-6)
+
+
+def test_parked_layers_of_a_failed_backward_can_be_discarded():
+    from lycoris_amd import ops
+    net = _Stack(n=2)
+    x = (torch.randn(32, 128, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    ops.fused_grad_accumulation(True, None)
+    try:
+        y = net(x)
+
+        def boom(g):
+            raise RuntimeError("boom")
+
+        x.register_hook(boom)  # the last thing the backward pass does: both layers are parked by then
+        with pytest.raises(RuntimeError, match="boom"):
+            y.backward(torch.ones_like(y))
+        ops.discard_deferred()  # (whether the engine ran its final callbacks after the error is an implementation detail)
+        assert ops._DISPATCH["ext"].deferred_pending() == 0
+        # the next pass is complete again: its own end-of-backward callback is installed although the failed pass never ran its
+        x2 = x.detach().clone().requires_grad_(True)
+        want = []
+        for defer in (False, True):
+            ops.deferred_weight_gradients(defer)
+            for p in net.parameters():
+                p.grad = torch.zeros_like(p)
+            net(x2).backward(torch.ones_like(y) * 0.01)
+            assert ops._DISPATCH["ext"].deferred_pending() == 0
+            torch.cuda.synchronize()
+            want.append([p.grad.clone() for p in net.parameters()])
+        for u, v in zip(*want):
+            assert float(u.abs().max()) > 0 and torch.allclose(u, v, rtol=2e-4, atol=1e-6)
+    finally:
+        ops.deferred_weight_gradients(True)
+        ops.fused_grad_accumulation(False, None)
+        ops.discard_deferred()
