@@ -163,6 +163,12 @@ void launch_dw2s_inst(KronDw2sArgs da, long tiles_i, long tiles_j, hipStream_t s
 #ifndef LYC_WG_WIDE
 #define LYC_WG_WIDE 2
 #endif
+#ifndef LYC_CONV_WIDE
+#define LYC_CONV_WIDE 0  // measured on the 49 conv layers of SDXL: 9.98 vs 9.83 ms per step -- not worth it
+#endif
+#ifndef LYC_CONV_BIG
+#define LYC_CONV_BIG 1   // 64 x 64 dW2 tiles for the convs (32 x 32: 10.12 vs 9.82 ms per step over the 49 conv layers)
+#endif
 // tile configurations of kron_dw2s_kernel: (MI, NJ, U)
 enum { DW2_T22 = 0, DW2_T44 = 1, DW2_T52 = 2, DW2_NCFG = 3 };
 int plan_dw2s(KronDw2sArgs& da, bool grouped = false) {
@@ -186,12 +192,13 @@ int plan_dw2s(KronDw2sArgs& da, bool grouped = false) {
   // do 4x the matrix work per loaded byte: they win whenever there are enough rows to split (measured: M*G >= 16k) and
   // the padding of I, J to multiples of 64 does not waste more than half of the tile.
   const double eff44 = (double)da.I * da.J / ((double)round_up(da.I, 64) * round_up(da.J, 64));
-  bool big = rows_total >= (grouped ? LYC_WG_BIG_ROWS : 16384) && eff44 >= 0.5;
+  bool big = rows_total >= (grouped ? LYC_WG_BIG_ROWS : 16384) && eff44 >= 0.5 && (LYC_CONV_BIG || da.gat.mode == 0);
   // grouped launches are instruction-bound (benchmarks/wgbench.cpp, profiles/r02_wgbench_sweep*.log), and most of a step's
   // instructions belong to the MIXED operand (G x G mix on the matrix cores + hi/lo split of its result), whose cost goes with
   // the tile's J extent only: an 80 x 32 tile does 2.5x the output per mixed column (SDXL mix: 4.65 -> 3.62 ms; it also beats
   // the 64 x 64 tile, which runs at one wave per SIMD).  Every SDXL / SD1.5 w2 has c = O / 8 a multiple of 80 or 40.
-  const bool wide = grouped && LYC_WG_WIDE && (LYC_WG_WIDE == 2 || !big) && da.I >= 80 &&
+  // (also for the single-layer launches of the implicit Conv2d: its 64 x 64 tile needs 340 registers, one wave per SIMD)
+  const bool wide = (grouped || (LYC_CONV_WIDE && da.gat.mode != 0)) && LYC_WG_WIDE && (LYC_WG_WIDE == 2 || !big) && da.I >= 80 &&
                     (double)da.I / (double)round_up(da.I, 80) >= 0.8;
   if (wide) big = false;
   long t52 = 0, s52 = 0;
@@ -227,7 +234,9 @@ int plan_dw2s(KronDw2sArgs& da, bool grouped = false) {
 
 template <typename T>
 void launch_dw2s(KronDw2sArgs da, hipStream_t st) {
-  if (plan_dw2s(da) == DW2_T44) launch_dw2s_inst<T, 4, 4, 1>(da, da.tiles_i, da.tiles_j, st);
+  const int cfg = plan_dw2s(da);
+  if (cfg == DW2_T44) launch_dw2s_inst<T, 4, 4, 1>(da, da.tiles_i, da.tiles_j, st);
+  else if (cfg == DW2_T52) launch_dw2s_inst<T, 5, 2, 1>(da, da.tiles_i, da.tiles_j, st);
   else launch_dw2s_inst<T, 2, 2, 4>(da, da.tiles_i, da.tiles_j, st);
 }
 
