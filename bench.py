@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--channels-last", action="store_true",
+                    help="Conv2d activations in torch.channels_last memory (what `unet.to(memory_format=torch.channels_last)` gives): "
+                         "the NHWC row matrices are then free views, no transposes")
     ap.add_argument("--no-defer", action="store_true",
                     help="A/B: one LoKr weight-gradient launch per layer instead of the grouped launches")
     ap.add_argument("--no-reference", action="store_true", help="skip the PyTorch-ROCm eager comparator leg")
@@ -125,6 +128,11 @@ class Inst:
                 self.x = torch.randn(*xs, device=dev, dtype=dtype, generator=gen).requires_grad_(True)
             gshape = xs if (algo == "ia3" and spec.get("side") == "in") else gs
             self.g = torch.randn(*gshape, device=dev, dtype=dtype, generator=gen) / math.sqrt(O)
+            if not lin and CHANNELS_LAST:
+                self.x = self.x.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+                self.g = self.g.contiguous(memory_format=torch.channels_last)
+                if self.base is not None:
+                    self.base = self.x
         f32 = dict(device=dev, dtype=torch.float32, generator=gen)
         if algo == "lokr":  # factor 8, full-matrix w2 (lora_dim >= 10000): w1 [8,8], w2 [O/8, I/8(,k,k)]
             w2 = torch.randn(O // FACTOR, cin // FACTOR, *ksz, **f32) * 0.05
@@ -207,7 +215,12 @@ class Inst:
         return F.conv2d(self.x, delta_w, None, s["stride"], s["pad"])
 
 
+CHANNELS_LAST = False
+
+
 def build_instances(args, dtype, dev):
+    global CHANNELS_LAST
+    CHANNELS_LAST = bool(args.channels_last)
     gen = torch.Generator(device=dev).manual_seed(1234)
     insts = []
     for spec, algo, count in layer_specs(args.model, args.algo):
@@ -369,6 +382,7 @@ def main():
             "graph": "eager (no capture)" if args.eager else
                      f"hipGraph replay: 1 forward graph + {len(graphs)} backward segment(s)"
                      + (", bucket all-reduces issued between segments on a side stream" if world > 1 else ""),
+            "conv_memory_format": "channels_last" if args.channels_last else "contiguous (NCHW)",
             "inputs": "shared per shape (cache-resident)" if args.shared_inputs else
                       f"distinct x / g per layer instance: {act_bytes / 1e9:.2f} GB read per step",
         },
