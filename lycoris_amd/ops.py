@@ -322,32 +322,41 @@ class _AdapterConv2d(torch.autograd.Function):
         N.require_device(x, "input")
         if x.dim() != 4:
             raise ValueError(f"Conv2d adapter expects NCHW input, got shape {tuple(x.shape)}")
-        x = x.contiguous()
         fs = [_f32c(t) for t in factors]
         k, s, p, d = geom
         B, C, H, W = x.shape
         I, O = core.dims(fs)
         if I != C * k[0] * k[1]:
             raise ValueError(f"adapter expects {I} = C*kh*kw im2col features, input has C={C}, kernel={k}")
-        rows = _to_rows(x) if _is_pointwise(geom) else _im2col(x, geom)
+        x_cl = False
+        if _is_pointwise(geom):  # a 1x1 conv IS the row op on the NHWC pixel rows: free for a channels_last tensor
+            rows, copied = _rows_view(x)
+            x_cl = not copied
+        else:
+            rows = _im2col(x.contiguous(), geom)
         y_rows, saved = core.fwd(rows, fs, float(alpha))
         ctx.save_for_backward(rows, *factors, *saved)
-        ctx.meta = (core, float(alpha), geom, x.shape, len(factors))
-        return _from_rows(y_rows, B, _conv_out(H, W, k, s, p, d))
+        ctx.meta = (core, float(alpha), geom, x.shape, len(factors), x_cl)
+        sp = _conv_out(H, W, k, s, p, d)
+        if x_cl:  # keep the caller's memory format: the row matrix is the channels_last tensor
+            return y_rows.view(B, sp[0], sp[1], O).permute(0, 3, 1, 2)
+        return _from_rows(y_rows, B, sp)
 
     @staticmethod
     def backward(ctx, g):
-        core, alpha, geom, xshape, nf = ctx.meta
+        core, alpha, geom, xshape, nf, x_cl = ctx.meta
         rows, factors, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + nf], ctx.saved_tensors[1 + nf:]
         fs = [_f32c(t) for t in factors]
-        g_rows = _to_rows(g.contiguous())
+        g_rows, _ = _rows_view(g)
         need_x, need_f = ctx.needs_input_grad[3], list(ctx.needs_input_grad[4:])
         pointwise = _is_pointwise(geom)
         # k > 1: col2im sums up to kh*kw row entries per pixel -> keep them in fp32 and round once
         bufs, hand_back = _grad_targets(factors, need_f)
         dx_rows = core.bwd(g_rows, rows, fs, saved, alpha, need_x, need_f, not pointwise, bufs)
         dx = None
-        if need_x:
+        if need_x and pointwise and x_cl:
+            dx = dx_rows.view(xshape[0], xshape[2], xshape[3], xshape[1]).permute(0, 3, 1, 2)
+        elif need_x:
             dx = _from_rows(dx_rows, xshape[0], xshape[2:]) if pointwise else _col2im(dx_rows, xshape, rows.dtype, geom)
         return (None, None, None, dx, *_finish_grads(factors, bufs, hand_back))
 

@@ -181,3 +181,33 @@ def test_lokr_module_forward_uses_the_fused_epilogue():
         ops.lokr_linear = orig
     assert calls == [True]  # one call, with base
     assert torch.allclose(out.float(), want, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("algo", ["locon", "loha"])
+def test_pointwise_conv_on_a_channels_last_tensor_is_copy_free_and_equal(algo):
+    """a 1x1 conv is the row op on the NHWC pixel rows: a channels_last activation is used as it is and the output keeps the
+    memory format (reference: F.conv2d preserves channels_last, functional/general.py:6)"""
+    from lycoris_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(2, 64, 6, 5, device=DEV, generator=g).to(torch.bfloat16)
+    gy = (torch.randn(2, 48, 6, 5, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    if algo == "locon":
+        fs = [torch.randn(8, 64, 1, 1, device=DEV, generator=g) * 0.1, torch.randn(48, 8, 1, 1, device=DEV, generator=g) * 0.1]
+        f = lambda t: ops.locon_conv2d(t, *fs, 0.7, (1, 1), (0, 0), (1, 1))
+    else:
+        fs = [torch.randn(48, 4, device=DEV, generator=g) * 0.3, torch.randn(4, 64, device=DEV, generator=g),
+              torch.randn(48, 4, device=DEV, generator=g) * 0.3, torch.randn(4, 64, device=DEV, generator=g)]
+        f = lambda t: ops.loha_conv2d(t, *fs, 0.7, (48, 64, 1, 1), (1, 1), (0, 0), (1, 1))
+    for t in fs:
+        t.requires_grad_(True)
+    outs = []
+    for cl in (False, True):
+        xi = (x.contiguous(memory_format=torch.channels_last) if cl else x.clone()).requires_grad_(True)
+        gi = gy.contiguous(memory_format=torch.channels_last) if cl else gy
+        y = f(xi)
+        assert y.is_contiguous(memory_format=torch.channels_last) == cl
+        grads = torch.autograd.grad(y, [xi] + fs, gi)
+        assert grads[0].is_contiguous(memory_format=torch.channels_last) == cl
+        outs.append([y.detach().float()] + [t.float() for t in grads])
+    for u, v in zip(*outs):
+        assert torch.allclose(u, v, rtol=1e-4, atol=1e-6), float((u - v).abs().max())
