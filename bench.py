@@ -3,8 +3,8 @@
 
 One "step" = one pass of the adapter hot path over every adapted layer of the UNet (synthetic activations of the real
 shapes: benchmarks/sdxl_shapes.py = 788 layers at 1024x1024, benchmarks/sd15_shapes.py = 278 layers at 512x512 bs 4):
-adapter forward (delta) and backward (dx + factor gradients accumulated straight into the flat gradient arena) of every
-layer, the arena zero-fill, the data-parallel mean all-reduce of the adapter gradients (N > 1: RCCL, launched bucket by
+adapter forward (delta) and backward (dx per layer; the factor gradients of the Linear layers in grouped launches of 18-24
+layers each, accumulated straight into the flat gradient arena -- DESIGN.md 1) of every layer, the arena zero-fill, the data-parallel mean all-reduce of the adapter gradients (N > 1: RCCL, launched bucket by
 bucket between the backward segments so it overlaps the rest of the backward) and a fused AdamW update.  EVERY layer
 instance owns its activation buffers (x and the upstream gradient g): a step reads the ~6 GB a real step reads, from
 HBM, not from the 256 MB Infinity Cache.  The compute of a step is captured in hipGraphs and replayed.
