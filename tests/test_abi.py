@@ -106,3 +106,35 @@ def test_loading_the_custom_op_extension_first_does_not_deadlock():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-500:]
+
+
+def test_ctypes_item_structs_match_the_header_layout(tmp_path):
+    """LycLokrWgradItem / LycLoconWgradItem / LycLohaWgradItem are passed as host arrays: the ctypes mirrors must have the C
+    compiler's size and field offsets (gcc compiles a probe against include/lycoris_amd.h)."""
+    import shutil
+    import subprocess
+    from lycoris_amd import _native as N
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    mirrors = {"LycLokrWgradItem": N.WgradItem, "LycLoconWgradItem": N.LoconWgradItem, "LycLohaWgradItem": N.LohaWgradItem}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{HEADER}"', "int main(void) {"]
+    for cname, cls in mirrors.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-std=c99", str(src), "-o", str(exe)], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    seen = 0
+    for line in out:
+        if not line.strip():
+            continue
+        cname, what, val = line.split()
+        cls = mirrors[cname]
+        want = ctypes.sizeof(cls) if what == "size" else getattr(cls, what).offset
+        assert int(val) == want, (cname, what, val, want)
+        seen += 1
+    assert seen == sum(1 + len(c._fields_) for c in mirrors.values())

@@ -232,3 +232,17 @@ def test_conv_dispatch_predicates():
     assert not ops._lokr_conv_implicit_ok(x, torch.zeros(8, 4), torch.zeros(40, 80, 3, 3))        # a != b
     assert not ops._lokr_conv_implicit_ok(x, torch.zeros(2, 2), torch.zeros(160, 160, 3, 3))      # factor 2
     assert not ops._lokr_conv_implicit_ok(x.float(), w1, w2)
+
+
+def test_deferred_weight_gradient_controls_need_the_cpp_dispatch():
+    """the park / flush machinery lives in the C++ custom-op layer: asking for it under the Python dispatch is an error, not a
+    silent no-op; flush / discard without a loaded extension are harmless"""
+    from lycoris_amd import ops
+    ops.set_dispatch("python")
+    try:
+        with pytest.raises(RuntimeError, match="C\\+\\+ dispatch"):
+            ops.deferred_weight_gradients(True)
+    finally:
+        ops.set_dispatch("cpp")
+    ops.flush_deferred()                 # nothing parked: no-op (and no GPU needed)
+    assert ops.discard_deferred() == 0
