@@ -53,6 +53,7 @@ void require_device(const Tensor& t, const char* what) {
 
 // fp32 contiguous, detached view of a (small) factor
 Tensor f32c(const Tensor& t) {
+  if (t.scalar_type() == at::kFloat && t.is_contiguous()) return t;  // the usual case: no new TensorImpl (host time per layer)
   Tensor f = t.detach();
   if (f.scalar_type() != at::kFloat) f = f.to(at::kFloat);
   return f.contiguous();
@@ -64,6 +65,7 @@ const float* cfp(const Tensor& t) { return t.defined() ? t.const_data_ptr<float>
 float* mfp(const Tensor& t) { return t.defined() ? t.mutable_data_ptr<float>() : nullptr; }
 
 Tensor rows_of(const Tensor& x, int64_t feat) {
+  if (x.dim() == 2 && x.size(1) == feat && x.is_contiguous()) return x;
   Tensor r = x.reshape({-1, feat});
   return r.is_contiguous() ? r : r.contiguous();
 }
