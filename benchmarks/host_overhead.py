@@ -40,6 +40,14 @@ def native(algo, ls):
     torch.autograd.grad(ys, [t for x, g, fs, W in ls for t in [x] + fs], [g for x, g, fs, W in ls])  # one engine call
 
 
+def native_training(algo, ls):
+    """the training configuration: .grad buffers exist, the kernels accumulate straight into them and the weight gradients of
+    all layers run in grouped launches (ops.fused_grad_accumulation + the default deferral): only dx comes back from autograd"""
+    fn = ops.lokr_linear if algo == "lokr" else ops.locon_linear
+    ys = [fn(x, fs[0], fs[1], 1.0) for x, g, fs, W in ls]
+    torch.autograd.grad(ys, [x for x, g, fs, W in ls], [g for x, g, fs, W in ls])  # one engine call
+
+
 def reference(algo, ls):
     ys = []
     for x, g, fs, W in ls:
@@ -68,9 +76,22 @@ for algo in ("lokr", "locon"):
         ops.set_dispatch(mode)
         row[f"native_{mode}_us"] = round(wall(lambda: native(algo, ls)), 1)
     ops.set_dispatch("cpp")
+    for x, g, fs, W in ls:
+        for f in fs:
+            f.grad = torch.zeros_like(f)
+    ops.fused_grad_accumulation(True, None)
+    try:
+        row["native_cpp_training_config_us"] = round(wall(lambda: native_training(algo, ls)), 1)
+    finally:
+        ops.fused_grad_accumulation(False, None)
+        for x, g, fs, W in ls:
+            for f in fs:
+                f.grad = None
     row["reference_torch_us"] = round(wall(lambda: reference(algo, ls)), 1)
     res[algo] = row
     print(algo, row, flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump({"what": "host microseconds per adapted layer, fwd + bwd, M = 16 rows (GPU time negligible)", "per_layer": res},
+json.dump({"what": "host microseconds per adapted layer, fwd + bwd, M = 16 rows (GPU time negligible); native_cpp / native_python / "
+                   "reference: plain autograd (factor gradients handed back to the engine); native_cpp_training_config: gradients "
+                   "accumulated into existing .grad buffers, weight gradients in grouped launches", "per_layer": res},
           open("gpurun_out/host_overhead.json", "w"), indent=1)
