@@ -783,10 +783,14 @@ Geom geom_of(at::IntArrayRef ksize, at::IntArrayRef s, at::IntArrayRef p, at::In
   return g;
 }
 
+// a channels_last tensor already IS the NHWC row matrix (degenerate shapes are ambiguous: treated as NCHW)
+bool rows_are_free(const Tensor& t) {
+  return t.is_contiguous(at::MemoryFormat::ChannelsLast) && !(t.size(1) == 1 || t.size(2) * t.size(3) == 1);
+}
 // [B, C, H, W] -> [B*H*W, C] NHWC rows; *copied = false when the tensor already is such a matrix (channels_last)
 Tensor rows_view(const Tensor& t, bool* copied) {
   const int64_t B = t.size(0), C = t.size(1), H = t.size(2), W = t.size(3);
-  if (t.is_contiguous(at::MemoryFormat::ChannelsLast) && !(C == 1 || H * W == 1)) {
+  if (rows_are_free(t)) {
     *copied = false;
     return t.permute({0, 2, 3, 1}).reshape({B * H * W, C});
   }
@@ -825,6 +829,187 @@ Tensor cl_finish(const Tensor& p, const GradTarget& g) {
   notify(p);
   return Tensor();
 }
+
+Tensor conv2d_meta(const Tensor& x, const Tensor& f0, const Tensor& f1, double alpha, at::IntArrayRef stride, at::IntArrayRef padding,
+                   at::IntArrayRef dilation, bool lokr);
+
+// ---- the Conv2d ops as functional forward / backward dispatcher ops (what torch.compile traces: FakeTensors see the Meta
+// kernels, the compiled graph calls the CUDA kernels below).  The eager autograd Functions above keep the NHWC row matrix of
+// x between forward and backward; these recompute it (one transpose for an NCHW tensor, nothing for channels_last).
+Tensor lokr_conv2d_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, at::IntArrayRef stride,
+                       at::IntArrayRef padding, at::IntArrayRef dilation) {
+  require_device(x, "input");
+  const c10::DeviceGuard dg(x.device());
+  TORCH_CHECK(x.dim() == 4 && w2.dim() == 4, "lokr_conv2d: NCHW input, w2 [c, d, kh, kw]");
+  const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+  const int64_t a = w1.size(0), b = w1.size(1), c = w2.size(0), d = w2.size(1);
+  TORCH_CHECK(C == b * d, "adapter expects ", b * d, " input channels, got ", x.sizes());
+  Geom gm = geom_of({w2.size(2), w2.size(3)}, stride, padding, dilation, H, W);
+  bool copied;
+  Tensor rows = rows_view(x, &copied), f1 = f32c(w1), w2p = f32c(w2.detach().permute({0, 2, 3, 1}));
+  Tensor y = at::empty({B * gm.Ho * gm.Wo, a * c}, x.options());
+  check_rc(lyc_lokr_conv2d_fwd(cptr(rows), cfp(f1), cfp(w2p), mptr(y), B, H, W, (int)a, (int)b, (int)c, (int)d, gm.kh, gm.kw, gm.sh,
+                               gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, (float)alpha, dtype_code(x.scalar_type()), stream_of(x)),
+           "lyc_lokr_conv2d_fwd");
+  return from_rows(y, B, gm.Ho, gm.Wo, !copied);
+}
+
+std::tuple<Tensor, Tensor, Tensor> lokr_conv2d_bwd(const Tensor& g, const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha,
+                                                   at::IntArrayRef stride, at::IntArrayRef padding, at::IntArrayRef dilation,
+                                                   bool need_dx, bool need_dw1, bool need_dw2) {
+  require_device(x, "input");
+  const c10::DeviceGuard dg(x.device());
+  const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+  const int64_t a = w1.size(0), b = w1.size(1), c = w2.size(0), d = w2.size(1), kh = w2.size(2), kw = w2.size(3);
+  bool xc, gc;
+  Tensor rows = rows_view(x, &xc), g_rows = rows_view(g, &gc);
+  Tensor f1 = f32c(w1), w2p = f32c(w2.detach().permute({0, 2, 3, 1}));
+  const int code = dtype_code(x.scalar_type());
+  const bool want_dx = need_dx || need_dw1;  // the w1 gradient shares the pass that produces dx
+  Tensor dx_rows = want_dx ? at::empty({B * H * W, C}, rows.options()) : Tensor();
+  Tensor dw1 = need_dw1 ? at::zeros({a, b}, w1.options().dtype(at::kFloat)) : Tensor();
+  Tensor dw2p = need_dw2 ? at::zeros({c, kh, kw, d}, w2.options().dtype(at::kFloat)) : Tensor();
+  Tensor ws, w2t;
+  if (dw1.defined()) {
+    const int64_t nb = lyc_lokr_conv2d_bwd_workspace_bytes(B, H, W, (int)a, (int)b, (int)d);
+    if (nb > 0) ws = at::empty({nb}, rows.options().dtype(at::kByte));
+  }
+  if (dx_rows.defined() && stride[0] == 1 && stride[1] == 1) w2t = w2.detach().to(at::kFloat).permute({2, 3, 0, 1}).contiguous();
+  check_rc(lyc_lokr_conv2d_bwd(cptr(g_rows), cptr(rows), cfp(f1), cfp(w2p), cfp(w2t), mptr(dx_rows), mfp(dw1), mfp(dw2p), mptr(ws), B,
+                               H, W, (int)a, (int)b, (int)c, (int)d, (int)kh, (int)kw, (int)stride[0], (int)stride[1],
+                               (int)padding[0], (int)padding[1], (int)dilation[0], (int)dilation[1], (float)alpha, code, stream_of(x)),
+           "lyc_lokr_conv2d_bwd");
+  Tensor dx = need_dx ? from_rows(dx_rows, B, H, W, !xc) : at::empty({0}, x.options());
+  Tensor dw2;
+  if (need_dw2) {  // in w2's own layout (what the Meta kernel promises: empty_like)
+    dw2 = at::empty_like(w2);
+    dw2.copy_(dw2p.permute({0, 3, 1, 2}));
+  }
+  return {dx, need_dw1 ? dw1.to(w1.scalar_type()) : at::empty({0}, w1.options()), need_dw2 ? dw2 : at::empty({0}, w2.options())};
+}
+std::tuple<Tensor, Tensor, Tensor> lokr_conv2d_bwd_meta(const Tensor& g, const Tensor& x, const Tensor& w1, const Tensor& w2,
+                                                        double alpha, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef, bool nx,
+                                                        bool n1, bool n2) {
+  return {nx ? at::empty_like(x) : x.new_empty({0}), n1 ? at::empty_like(w1) : w1.new_empty({0}),
+          n2 ? at::empty_like(w2) : w2.new_empty({0})};
+}
+
+std::tuple<Tensor, Tensor> locon_conv2d_fwd(const Tensor& x, const Tensor& down, const Tensor& up, double alpha,
+                                            at::IntArrayRef stride, at::IntArrayRef padding, at::IntArrayRef dilation) {
+  require_device(x, "input");
+  const c10::DeviceGuard dg(x.device());
+  TORCH_CHECK(x.dim() == 4 && down.dim() == 4, "locon_conv2d: NCHW input, lora_down [r, C, kh, kw]");
+  const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+  const int64_t r = down.size(0), O = up.size(0);
+  TORCH_CHECK(C == down.size(1), "adapter expects ", down.size(1), " input channels, got ", x.sizes());
+  Geom gm = geom_of({down.size(2), down.size(3)}, stride, padding, dilation, H, W);
+  bool copied;
+  Tensor rows = rows_view(x, &copied), down_p = f32c(down.detach().permute({0, 2, 3, 1})), up2 = f32c(up.detach().reshape({O, r}));
+  Tensor t = at::empty({B * gm.Ho * gm.Wo, r}, x.options().dtype(at::kFloat));
+  Tensor y = at::empty({B * gm.Ho * gm.Wo, O}, x.options());
+  check_rc(lyc_locon_conv2d_fwd(cptr(rows), cfp(down_p), cfp(up2), mfp(t), mptr(y), B, H, W, (int)C, (int)O, (int)r, gm.kh, gm.kw,
+                                gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, (float)alpha, dtype_code(x.scalar_type()), stream_of(x)),
+           "lyc_locon_conv2d_fwd");
+  return {from_rows(y, B, gm.Ho, gm.Wo, !copied), t};
+}
+std::tuple<Tensor, Tensor> locon_conv2d_fwd_meta(const Tensor& x, const Tensor& down, const Tensor& up, double alpha,
+                                                 at::IntArrayRef stride, at::IntArrayRef padding, at::IntArrayRef dilation) {
+  Tensor y = conv2d_meta(x, down, up, alpha, stride, padding, dilation, false);
+  return {y, x.new_empty({y.size(0) * y.size(2) * y.size(3), down.size(0)}, x.options().dtype(at::kFloat))};
+}
+
+std::tuple<Tensor, Tensor, Tensor> locon_conv2d_bwd(const Tensor& g, const Tensor& x, const Tensor& down, const Tensor& up,
+                                                    const Tensor& t, double alpha, at::IntArrayRef stride, at::IntArrayRef padding,
+                                                    at::IntArrayRef dilation, bool need_dx, bool need_dd, bool need_du) {
+  require_device(x, "input");
+  const c10::DeviceGuard dg(x.device());
+  const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+  const int64_t r = down.size(0), O = up.size(0), kh = down.size(2), kw = down.size(3);
+  Geom gm = geom_of({kh, kw}, stride, padding, dilation, H, W);
+  bool xc, gc;
+  Tensor rows = rows_view(x, &xc), g_rows = rows_view(g, &gc);
+  Tensor down_p = f32c(down.detach().permute({0, 2, 3, 1})), up2 = f32c(up.detach().reshape({O, r}));
+  Tensor dt = at::empty({B * gm.Ho * gm.Wo, r}, rows.options().dtype(at::kFloat));
+  Tensor dx_rows = need_dx ? at::empty({B * H * W, C}, rows.options()) : Tensor();
+  Tensor ddp = need_dd ? at::zeros({r, kh, kw, C}, down.options().dtype(at::kFloat)) : Tensor();
+  Tensor du = need_du ? at::zeros({O, r}, up.options().dtype(at::kFloat)) : Tensor();
+  check_rc(lyc_locon_conv2d_bwd(cptr(g_rows), cptr(rows), cfp(down_p), cfp(up2), cfp(t), mfp(dt), mptr(dx_rows), mfp(ddp), mfp(du), B,
+                                H, W, (int)C, (int)O, (int)r, (int)kh, (int)kw, (int)stride[0], (int)stride[1], (int)padding[0],
+                                (int)padding[1], (int)dilation[0], (int)dilation[1], (float)alpha, dtype_code(x.scalar_type()),
+                                stream_of(x)), "lyc_locon_conv2d_bwd");
+  Tensor dx = need_dx ? from_rows(dx_rows, B, H, W, !xc) : at::empty({0}, x.options());
+  Tensor dd, duo;
+  if (need_dd) {
+    dd = at::empty_like(down);
+    dd.copy_(ddp.permute({0, 3, 1, 2}));
+  }
+  if (need_du) {
+    duo = at::empty_like(up);
+    duo.copy_(du.reshape(up.sizes()));
+  }
+  return {dx, need_dd ? dd : at::empty({0}, down.options()), need_du ? duo : at::empty({0}, up.options())};
+}
+std::tuple<Tensor, Tensor, Tensor> locon_conv2d_bwd_meta(const Tensor& g, const Tensor& x, const Tensor& down, const Tensor& up,
+                                                         const Tensor& t, double alpha, at::IntArrayRef, at::IntArrayRef,
+                                                         at::IntArrayRef, bool nx, bool nd, bool nu) {
+  return {nx ? at::empty_like(x) : x.new_empty({0}), nd ? at::empty_like(down) : down.new_empty({0}),
+          nu ? at::empty_like(up) : up.new_empty({0})};
+}
+
+// autograd for traced (non-eager) tensors: forward = the public op below autograd, backward = the functional backward op
+struct LokrConv2dTraceFn : public torch::autograd::Function<LokrConv2dTraceFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha,
+                        std::vector<int64_t> stride, std::vector<int64_t> padding, std::vector<int64_t> dilation) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::lokr_conv2d", "")
+                         .typed<Tensor(const Tensor&, const Tensor&, const Tensor&, double, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef)>();
+    Tensor y = op.call(x, w1, w2, alpha, stride, padding, dilation);
+    ctx->save_for_backward({x, w1, w2});
+    ctx->saved_data["alpha"] = alpha;
+    ctx->saved_data["stride"] = stride;
+    ctx->saved_data["padding"] = padding;
+    ctx->saved_data["dilation"] = dilation;
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const bool nx = ctx->needs_input_grad(0), n1 = ctx->needs_input_grad(1), n2 = ctx->needs_input_grad(2);
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_lokr_conv2d_backward", "")
+                         .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, double,
+                                                                   at::IntArrayRef, at::IntArrayRef, at::IntArrayRef, bool, bool, bool)>();
+    auto [dx, d1, d2] = op.call(grads[0], s[0], s[1], s[2], ctx->saved_data["alpha"].toDouble(), ctx->saved_data["stride"].toIntVector(),
+                                ctx->saved_data["padding"].toIntVector(), ctx->saved_data["dilation"].toIntVector(), nx, n1, n2);
+    return {nx ? dx : Tensor(), n1 ? d1 : Tensor(), n2 ? d2 : Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+struct LoconConv2dTraceFn : public torch::autograd::Function<LoconConv2dTraceFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& down, const Tensor& up, double alpha,
+                        std::vector<int64_t> stride, std::vector<int64_t> padding, std::vector<int64_t> dilation) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_locon_conv2d_forward", "")
+                         .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, double, at::IntArrayRef,
+                                                           at::IntArrayRef, at::IntArrayRef)>();
+    auto [y, t] = op.call(x, down, up, alpha, stride, padding, dilation);
+    ctx->save_for_backward({x, down, up, t});
+    ctx->saved_data["alpha"] = alpha;
+    ctx->saved_data["stride"] = stride;
+    ctx->saved_data["padding"] = padding;
+    ctx->saved_data["dilation"] = dilation;
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const bool nx = ctx->needs_input_grad(0), nd = ctx->needs_input_grad(1), nu = ctx->needs_input_grad(2);
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_locon_conv2d_backward", "")
+                         .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&,
+                                                                   double, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef, bool, bool,
+                                                                   bool)>();
+    auto [dx, dd, du] = op.call(grads[0], s[0], s[1], s[2], s[3], ctx->saved_data["alpha"].toDouble(),
+                                ctx->saved_data["stride"].toIntVector(), ctx->saved_data["padding"].toIntVector(),
+                                ctx->saved_data["dilation"].toIntVector(), nx, nd, nu);
+    return {nx ? dx : Tensor(), nd ? dd : Tensor(), nu ? du : Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
 
 struct LokrConv2dFn : public torch::autograd::Function<LokrConv2dFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha,
@@ -884,12 +1069,8 @@ struct LokrConv2dFn : public torch::autograd::Function<LokrConv2dFn> {
 };
 Tensor lokr_conv2d_implicit(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, at::IntArrayRef stride,
                             at::IntArrayRef padding, at::IntArrayRef dilation) {
-  if (!x.is_cuda() || !eager_cuda(x)) {  // shape propagation only (Meta kernel); the conv ops are not differentiable under tracing
-    at::AutoDispatchBelowADInplaceOrView guard;
-    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::lokr_conv2d", "")
-                         .typed<Tensor(const Tensor&, const Tensor&, const Tensor&, double, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef)>();
-    return op.call(x, w1, w2, alpha, stride, padding, dilation);
-  }
+  if (!x.is_cuda() || !eager_cuda(x))  // FakeTensor / meta: differentiable through the functional forward / backward ops
+    return LokrConv2dTraceFn::apply(amp(x), w1, w2, alpha, stride.vec(), padding.vec(), dilation.vec());
   return LokrConv2dFn::apply(amp(x), w1, w2, alpha, stride.vec(), padding.vec(), dilation.vec());
 }
 
@@ -944,22 +1125,18 @@ struct LoconConv2dFn : public torch::autograd::Function<LoconConv2dFn> {
 };
 Tensor locon_conv2d_implicit(const Tensor& x, const Tensor& down, const Tensor& up, double alpha, at::IntArrayRef stride,
                              at::IntArrayRef padding, at::IntArrayRef dilation) {
-  if (!x.is_cuda() || !eager_cuda(x)) {
-    at::AutoDispatchBelowADInplaceOrView guard;
-    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::locon_conv2d", "")
-                         .typed<Tensor(const Tensor&, const Tensor&, const Tensor&, double, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef)>();
-    return op.call(x, down, up, alpha, stride, padding, dilation);
-  }
+  if (!x.is_cuda() || !eager_cuda(x))
+    return LoconConv2dTraceFn::apply(amp(x), down, up, alpha, stride.vec(), padding.vec(), dilation.vec());
   return LoconConv2dFn::apply(amp(x), down, up, alpha, stride.vec(), padding.vec(), dilation.vec());
 }
 
 Tensor lokr_conv2d_eager(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, at::IntArrayRef stride,
                          at::IntArrayRef padding, at::IntArrayRef dilation) {
-  return LokrConv2dFn::apply(x, w1, w2, alpha, stride.vec(), padding.vec(), dilation.vec());
+  return lokr_conv2d_fwd(x, w1, w2, alpha, stride, padding, dilation);  // below autograd: inference_mode / a compiled graph
 }
 Tensor locon_conv2d_eager(const Tensor& x, const Tensor& down, const Tensor& up, double alpha, at::IntArrayRef stride,
                           at::IntArrayRef padding, at::IntArrayRef dilation) {
-  return LoconConv2dFn::apply(x, down, up, alpha, stride.vec(), padding.vec(), dilation.vec());
+  return std::get<0>(locon_conv2d_fwd(x, down, up, alpha, stride, padding, dilation));
 }
 
 Tensor conv2d_meta(const Tensor& x, const Tensor& f0, const Tensor& f1, double alpha, at::IntArrayRef stride, at::IntArrayRef padding,
@@ -967,7 +1144,9 @@ Tensor conv2d_meta(const Tensor& x, const Tensor& f0, const Tensor& f1, double a
   const int64_t kh = lokr ? f1.size(2) : f0.size(2), kw = lokr ? f1.size(3) : f0.size(3);
   const int64_t O = lokr ? f0.size(0) * f1.size(0) : f1.size(0);
   Geom gm = geom_of({kh, kw}, stride, padding, dilation, x.size(2), x.size(3));
-  return x.new_empty({x.size(0), O, gm.Ho, gm.Wo});
+  // the kernels return the row matrix as a channels_last tensor when x came as one (rows_view / from_rows)
+  return at::empty({x.size(0), O, gm.Ho, gm.Wo},
+                   x.options().memory_format(rows_are_free(x) ? at::MemoryFormat::ChannelsLast : at::MemoryFormat::Contiguous));
 }
 Tensor lokr_conv2d_meta(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, at::IntArrayRef s, at::IntArrayRef p,
                         at::IntArrayRef d) {
@@ -998,6 +1177,12 @@ TORCH_LIBRARY(lycoris_amd, m) {
   m.def("_loha_linear_backward(Tensor g, Tensor x, Tensor w1a, Tensor w1b, Tensor w2a, Tensor w2b, Tensor ws, float alpha, "
         "bool need_dx, bool need_f) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("_chan_reduce(Tensor g, Tensor a, Tensor? bias, Tensor w_like, float mult, int chan_dim) -> Tensor");
+  m.def("_lokr_conv2d_backward(Tensor g, Tensor x, Tensor w1, Tensor w2, float alpha, int[2] stride, int[2] padding, int[2] dilation, "
+        "bool need_dx, bool need_dw1, bool need_dw2) -> (Tensor, Tensor, Tensor)");
+  m.def("_locon_conv2d_forward(Tensor x, Tensor down, Tensor up, float alpha, int[2] stride, int[2] padding, int[2] dilation) "
+        "-> (Tensor, Tensor)");
+  m.def("_locon_conv2d_backward(Tensor g, Tensor x, Tensor down, Tensor up, Tensor t, float alpha, int[2] stride, int[2] padding, "
+        "int[2] dilation, bool need_dx, bool need_dd, bool need_du) -> (Tensor, Tensor, Tensor)");
 }
 
 TORCH_LIBRARY_IMPL(lycoris_amd, CUDA, m) {
@@ -1013,6 +1198,9 @@ TORCH_LIBRARY_IMPL(lycoris_amd, CUDA, m) {
   m.impl("_chan_reduce", chan_reduce);
   m.impl("lokr_conv2d", lokr_conv2d_eager);    // inference_mode skips the Autograd key
   m.impl("locon_conv2d", locon_conv2d_eager);
+  m.impl("_lokr_conv2d_backward", lokr_conv2d_bwd);
+  m.impl("_locon_conv2d_forward", locon_conv2d_fwd);
+  m.impl("_locon_conv2d_backward", locon_conv2d_bwd);
 }
 
 TORCH_LIBRARY_IMPL(lycoris_amd, Meta, m) {
@@ -1028,6 +1216,9 @@ TORCH_LIBRARY_IMPL(lycoris_amd, Meta, m) {
   m.impl("_chan_reduce", chan_reduce_meta);
   m.impl("lokr_conv2d", lokr_conv2d_meta);
   m.impl("locon_conv2d", locon_conv2d_meta);
+  m.impl("_lokr_conv2d_backward", lokr_conv2d_bwd_meta);
+  m.impl("_locon_conv2d_forward", locon_conv2d_fwd_meta);
+  m.impl("_locon_conv2d_backward", locon_conv2d_bwd_meta);
 }
 
 TORCH_LIBRARY_IMPL(lycoris_amd, Autograd, m) {

@@ -87,6 +87,18 @@ def test_torch_custom_ops_are_registered_with_meta_kernels():
     xc = torch.empty(2, 64, 9, 7, dtype=torch.float16, **m)
     assert ns.lokr_conv2d(xc, torch.empty(8, 8, **m), torch.empty(4, 8, 3, 3, **m), 1.0, [2, 2], [1, 1], [1, 1]).shape == (2, 32, 5, 4)
     assert ns.locon_conv2d(xc, torch.empty(4, 64, 3, 3, **m), torch.empty(24, 4, 1, 1, **m), 1.0, [1, 1], [1, 1], [1, 1]).shape == (2, 24, 9, 7)
+    # the Conv2d ops are differentiable under tracing: C++ autograd through the functional backward ops
+    xg = torch.empty(2, 64, 9, 7, dtype=torch.bfloat16, requires_grad=True, **m)
+    cw1, cw2 = torch.empty(8, 8, requires_grad=True, **m), torch.empty(4, 8, 3, 3, requires_grad=True, **m)
+    yc = ns.lokr_conv2d(xg, cw1, cw2, 1.0, [1, 1], [1, 1], [1, 1])
+    gs = torch.autograd.grad(yc, [xg, cw1, cw2], torch.empty_like(yc))
+    assert [g.shape for g in gs] == [xg.shape, cw1.shape, cw2.shape]
+    cd, cu = torch.empty(4, 64, 3, 3, requires_grad=True, **m), torch.empty(24, 4, 1, 1, requires_grad=True, **m)
+    yc = ns.locon_conv2d(xg, cd, cu, 1.0, [2, 2], [1, 1], [1, 1])
+    gs = torch.autograd.grad(yc, [xg, cd, cu], torch.empty_like(yc))
+    assert yc.shape == (2, 24, 5, 4) and [g.shape for g in gs] == [xg.shape, cd.shape, cu.shape]
+    for name in ("_lokr_conv2d_backward", "_locon_conv2d_forward", "_locon_conv2d_backward"):
+        assert hasattr(ns, name), name
 
 
 def test_cpu_tensors_are_rejected_by_the_custom_op_path():

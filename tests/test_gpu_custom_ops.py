@@ -124,6 +124,36 @@ def test_adapted_linear_layer_under_torch_compile(algo):
         assert torch.allclose(u.float(), v.float(), rtol=2e-2 if i < 2 else 1e-3, atol=1e-3), (algo, i)
 
 
+@pytest.mark.parametrize("algo", ["lokr", "locon"])
+def test_adapted_conv2d_layer_under_torch_compile(algo):
+    """the Conv2d ops trace too: forward = the public op, backward = lycoris_amd::_{lokr,locon}_conv2d_backward, both with Meta
+    kernels (reference: test/compile.py compiles a model with conv layers)"""
+    from lycoris_amd.modules import LoConModule, LokrModule
+    torch.manual_seed(0)
+    layer = nn.Conv2d(64, 128, 3, padding=1).to(DEV, torch.bfloat16).requires_grad_(False)
+    cls, kw = {"lokr": (LokrModule, dict(lora_dim=100000, alpha=1, factor=8)), "locon": (LoConModule, dict(lora_dim=8, alpha=4))}[algo]
+    mod = cls("m", layer, 1.0, **kw).to(DEV)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(torch.randn_like(p) * 0.2)
+    mod.apply_to()
+    x = torch.randn(2, 64, 9, 8, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    params = list(mod.parameters())
+
+    def run(fn):
+        y = fn(x)
+        return [y.detach()] + list(torch.autograd.grad(y.float().pow(2).sum(), [x] + params))
+
+    eager = run(layer)
+    torch._dynamo.reset()
+    compiled = torch.compile(layer, backend="aot_eager", fullgraph=True)
+    got = run(compiled)
+    mod.restore()
+    for i, (u, v) in enumerate(zip(got, eager)):
+        assert u.shape == v.shape, (algo, i)
+        assert torch.allclose(u.float(), v.float(), rtol=2e-2 if i < 2 else 1e-3, atol=2e-3), (algo, i, float((u.float() - v.float()).abs().max()))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape", [(64, 8, 32, 32), (300, 8, 160, 160), (77, 8, 160, 256), (33, 4, 20, 24), (1024, 8, 1280, 160)],
                          ids=lambda s: "x".join(map(str, s)))
