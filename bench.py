@@ -447,16 +447,22 @@ def _wall_ms(fn, reps=2):
 def pmc_traffic(family):
     """HBM bytes per launch of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate runs, gfx950 corrections per MI355X_MICROARCH.md; benchmarks/pmc_summary.py --json writes the file).  Only
-    trusted when it was collected on THIS build of the library (sha of liblycoris_amd.so recorded in the file)."""
+    trusted when it was collected on THIS build of the library (sha of liblycoris_amd.so recorded in the file) or on a build
+    the file itself declares traffic-equivalent, in which case `traffic_source` carries that statement."""
     try:
         with open(PMC_FILE) as f:
             rec = json.load(f)
     except (OSError, ValueError):
         return None, "no profiles/pmc_traffic.json"
+    src = rec.get("source", "profiles/pmc_traffic.json")
     if rec.get("lib_sha16") != lib_sha():
-        return None, f"profiles/pmc_traffic.json was collected on build {rec.get('lib_sha16')}, this is {lib_sha()}"
+        # a later build may be DECLARED traffic-equivalent in the file (with the reason); the line then says so
+        why = rec.get("equivalent_builds", {}).get(lib_sha())
+        if why is None:
+            return None, f"profiles/pmc_traffic.json was collected on build {rec.get('lib_sha16')}, this is {lib_sha()}"
+        src = f"{src}: collected on build {rec.get('lib_sha16')}, not on the running build {lib_sha()} ({why})"
     fam = rec.get("families", {}).get(family)
-    return (int(fam["bytes_per_launch"]) if fam else None), rec.get("source", "profiles/pmc_traffic.json")
+    return (int(fam["bytes_per_launch"]) if fam else None), src
 
 
 def roofline(insts, args, dtype, dev):

@@ -285,13 +285,14 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
     const u32x4 o = ok ? v : z;
     return *reinterpret_cast<const F8*>(&o);
   };
-  // row base pointer (+ 8g) and validity of lane row r for tap t
+  // row base pointer (WITHOUT the lane's 8g column offset: load_frag_x adds it only where the fragment lies inside the row)
+  // and validity of lane row r for tap t
   auto row_src = [&](int r, int t, const T*& p, bool& ok) {
     const long gr = r ? gr1 : gr0;
     const bool rok = r ? ok1 : ok0;
     if constexpr (!GATHER) {
       ok = rok;
-      p = x + (rok ? gr : row0) * K + 8 * g;
+      p = x + (rok ? gr : row0) * K;
       return;
     }
     const int i = t / a.gat.kw, j = t - i * a.gat.kw;
@@ -309,11 +310,15 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
     }
     ok = rok && v;
     const long spix = ok ? ((long)pb[r] * a.gat.Hs + hs) * a.gat.Ws + ws : 0;
-    p = x + ((spix << lg) + (gr & (G - 1))) * K + 8 * g;
+    p = x + ((spix << lg) + (gr & (G - 1))) * K;
   };
+  // The load is unconditional (masked afterwards), so its address must be valid for EVERY lane: a lane whose fragment lies
+  // beyond the row (kk + 8g >= K) reads the row's first 16 bytes.  (Until the end of round 2 it read `row + 8g`, which for
+  // K < 32 is past the row and, on the matrix's last rows, up to 48 bytes past the END of the activation tensor: a rare
+  // memory access fault when the tensor filled its allocation exactly -- found by benchmarks/stress_grouped.py.)
   auto load_frag_x = [&](bool ok, const T* p, long kk) -> F8 {
     const bool k_ok = kk + 8 * g < K;  // K % 8 == 0: a fragment is all in or all out
-    const u32x4 v = *reinterpret_cast<const u32x4*>(p + (k_ok ? kk : 0));
+    const u32x4 v = *reinterpret_cast<const u32x4*>(p + (k_ok ? kk + 8 * g : 0));
     const u32x4 z = {0u, 0u, 0u, 0u};
     const u32x4 r = (ok && k_ok) ? v : z;
     return *reinterpret_cast<const F8*>(&r);
