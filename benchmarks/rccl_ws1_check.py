@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""The data-parallel gradient path through RCCL on ONE GPU (missing #5 / next #8).
+
+No 8-GPU node is available to the builder, so until the driver's first N = 8 run `AdapterGradSync`'s collectives had only ever
+run through gloo.  This script initialises the `nccl` (= RCCL) backend at world_size 1 and drives the SAME code the N > 1 bench
+step runs -- in-place `all_reduce(ReduceOp.AVG)` of each bucket on the side stream, launched from the kernels' fused-accumulation
+callback (eager) and by `launch_ready()` between the replays of the backward segment graphs (captured), `finish()` joining the
+side stream before the optimizer -- and checks that the gradients equal the ones of a plain single-process backward.
+
+    MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 RANK=0 WORLD_SIZE=1 python benchmarks/rccl_ws1_check.py
+
+Also checks a module shared by two layer calls through the sync (its bucket used to be reduced early).
+Prints "rccl-ws1 ok" and exits 0.  Run by tests/test_gpu_grad_sync.py in a child process.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+
+from lycoris_amd import ops
+from lycoris_amd.grad_sync import AdapterGradSync
+
+DEV = torch.device("cuda:0")
+
+
+class Layer:
+    def __init__(self, algo, M, I, O, gen, params=None):
+        self.algo = algo
+        self.x = torch.randn(M, I, device=DEV, dtype=torch.bfloat16, generator=gen).requires_grad_(True)
+        self.g = torch.randn(M, O, device=DEV, dtype=torch.bfloat16, generator=gen) / O ** 0.5
+        f32 = dict(device=DEV, dtype=torch.float32, generator=gen)
+        if params is not None:
+            self.params = params
+        elif algo == "lokr":
+            self.params = [torch.nn.Parameter(torch.randn(8, 8, **f32) * 0.3), torch.nn.Parameter(torch.randn(O // 8, I // 8, **f32) * 0.05)]
+        else:
+            self.params = [torch.nn.Parameter(torch.randn(16, I, **f32) * 0.05), torch.nn.Parameter(torch.randn(O, 16, **f32) * 0.05)]
+
+    def forward(self):
+        if self.algo == "lokr":
+            return ops.lokr_linear(self.x, self.params[0], self.params[1], 1.0)
+        return ops.locon_linear(self.x, self.params[0], self.params[1], 1.0)
+
+
+def backward_range(outs, lo, hi):
+    seg = outs[lo:hi][::-1]
+    torch.autograd.grad([y for y, _ in seg], [l.x for _, l in seg], [l.g for _, l in seg])
+
+
+def main():
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=DEV)
+    assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    shapes = [("lokr", 256, 640, 640), ("locon", 256, 640, 1280), ("lokr", 64, 1280, 640), ("locon", 77, 2048, 640)] * 6
+    layers = [Layer(a, M, I, O, gen) for a, M, I, O in shapes]
+    shared = Layer("lokr", 128, 640, 640, gen)
+    layers.insert(5, shared)
+    layers.append(Layer("lokr", 32, 640, 640, gen, params=shared.params))  # the same parameters in a second layer call
+    params, seen = [], set()
+    for l in layers:
+        for p in l.params:
+            if id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+
+    # ---- truth: plain autograd, gradients handed back ------------------------------------------------------------------
+    outs = [(l.forward(), l) for l in layers]
+    want = torch.autograd.grad([y for y, _ in outs], params, [l.g for _, l in outs])
+    want = [w.clone() for w in want]
+    torch.cuda.synchronize()
+
+    def check(tag):
+        torch.cuda.synchronize()
+        worst = 0.0
+        for p, w in zip(params, want):
+            e = float((p.grad - w).norm() / (w.norm() + 1e-30))
+            worst = max(worst, e)
+        assert worst < 1e-5, f"{tag}: gradient mismatch {worst:.3e}"
+        return worst
+
+    # ---- eager: collectives launched from inside the backward by the fused-accumulation callback -------------------------
+    sync = AdapterGradSync(params, bucket_bytes=256 << 10, always_reduce=True)  # several buckets
+    assert len(sync.buckets) >= 3, len(sync.buckets)
+    sync.attach_fused()
+    try:
+        for rep in range(2):
+            sync.zero_grad()
+            outs = [(l.forward(), l) for l in layers]
+            backward_range(outs, 0, len(layers))
+            launched_in_backward = len(sync.launch_log)
+            sync.finish()
+            e = check(f"eager step {rep}")
+        assert launched_in_backward == len(sync.buckets), (launched_in_backward, len(sync.buckets))
+        print(f"eager: {len(sync.buckets)} buckets all-reduced (AVG, side stream) from inside the backward, rel-err {e:.1e}")
+
+        # ---- captured: forward graph + backward segment graphs, launch_ready() between the replays (bench.py's N > 1 step) ---
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        sync._sync_enabled = False
+        with torch.cuda.stream(side):
+            pool = torch.cuda.graph_pool_handle()
+            g_fwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fwd, pool=pool):
+                for arena in sync.arenas.values():
+                    arena.zero_()
+                outs = [(l.forward(), l) for l in layers]
+            n, nseg = len(layers), 4
+            edges = [round(i * n / nseg) for i in range(nseg + 1)]
+            graphs, bounds = [], []
+            for s in range(nseg, 0, -1):
+                lo, hi = edges[s - 1], edges[s]
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph, pool=pool):
+                    backward_range(outs, lo, hi)
+                graphs.append(gph)
+                bounds.append(layers[lo - 1].params[-1] if lo > 0 else None)
+        torch.cuda.current_stream().wait_stream(side)
+        sync._sync_enabled = True
+        for rep in range(3):
+            sync._reset_pending()
+            g_fwd.replay()
+            for gph, upto in zip(graphs, bounds):
+                gph.replay()
+                sync.launch_ready(upto)
+            sync.finish()
+            e = check(f"graph step {rep}")
+        print(f"captured: 1 forward graph + {nseg} backward segments, bucket all-reduces between the replays, rel-err {e:.1e}")
+    finally:
+        sync.attach_fused(False)
+        sync.remove()
+    dist.destroy_process_group()
+    print("rccl-ws1 ok")
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,9 @@
 #include <hip/hip_runtime_api.h>
 #include <torch/csrc/autograd/engine.h>
 
+#include <atomic>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/lycoris_amd.h"
@@ -77,11 +79,44 @@ Tensor rows_of(const Tensor& x, int64_t feat) {
 struct Accum {
   bool enabled = false;
   py::object* callback = nullptr;  // leaked on purpose: must not be destroyed after the interpreter has shut down
+  bool has_callback = false;       // callback set and not None (readable without the GIL)
   std::mutex mu;
+  // A parameter used by several layer calls of one forward pass (a shared module) gets one accumulation per call, but the
+  // callback's contract is the autograd hook's: ONE report per parameter, after its LAST accumulation (the DP sync
+  // counted a shared parameter twice and all-reduced its bucket early).  `expect()` counts the backward nodes created for a
+  // parameter (forward, grad mode on); `notify()` reports when the count returns to zero.  A forward whose backward never runs
+  // leaves a stale count: the report is then skipped, AdapterGradSync.finish() launches such buckets, and
+  // reset_use_counts() (called by AdapterGradSync.zero_grad() / finish()) clears the map once per step.
+  std::unordered_map<const void*, int> uses;
 } g_accum;
 
+// true when the backward node of a layer call on activation `x` will accumulate into factor.grad and notify() for it
+// (the condition of grad_target() / finish_grad() below)
+bool will_report(const Tensor& factor, const Tensor& x, bool cl = false) {
+  if (!g_accum.enabled || !g_accum.has_callback || !factor.defined() || !factor.is_leaf() || !factor.requires_grad()) return false;
+  if (!c10::GradMode::is_enabled() || !x.is_cuda()) return false;
+  const c10::DispatchKeySet ks = x.key_set();
+  if (ks.has(c10::DispatchKey::Python) || ks.has(c10::DispatchKey::Meta) || ks.has(c10::DispatchKey::Functionalize)) return false;
+  const Tensor& gr = factor.grad();
+  if (!gr.defined() || gr.scalar_type() != at::kFloat || gr.device() != factor.device()) return false;
+  return cl ? gr.permute({0, 2, 3, 1}).is_contiguous() : gr.is_contiguous();  // cl: cl_grad_target()'s condition
+}
+void expect(const Tensor& param, const Tensor& x, bool cl = false) {
+  if (!will_report(param, x, cl)) return;
+  std::lock_guard<std::mutex> lk(g_accum.mu);
+  ++g_accum.uses[param.unsafeGetTensorImpl()];
+}
+
 void notify(const Tensor& param) {
-  if (g_accum.callback == nullptr) return;
+  if (g_accum.callback == nullptr || !param.defined()) return;
+  {
+    std::lock_guard<std::mutex> lk(g_accum.mu);
+    auto it = g_accum.uses.find(param.unsafeGetTensorImpl());
+    if (it != g_accum.uses.end()) {
+      if (--it->second > 0) return;  // another layer call of this pass still has to accumulate into the same .grad
+      g_accum.uses.erase(it);
+    }
+  }
   py::gil_scoped_acquire gil;
   if (!g_accum.callback->is_none()) (*g_accum.callback)(param);
 }
@@ -163,16 +198,27 @@ struct DeferredLoha {
   void* stream;
   c10::DeviceIndex device;
 };
-struct Deferred {
-  bool enabled = true;
-  size_t flush_at = 48;
+// One park list per DEVICE (a process that drives two GPUs has one autograd worker thread per device; they
+// must not share a list, a lock or the "callback queued" state).  `enabled` / `flush_at` are process-wide settings.
+struct DeferredLists {
   std::mutex mu;
   std::vector<DeferredLokr> lokr;
   std::vector<DeferredLocon> locon;
   std::vector<DeferredLoha> loha;
   bool callback_queued = false;
   int queued_task = -1;  // graph task the pending end-of-backward callback belongs to
+  size_t size() const { return lokr.size() + locon.size() + loha.size(); }
+};
+constexpr int kMaxDevices = 64;
+struct Deferred {
+  std::atomic<bool> enabled{true};
+  std::atomic<size_t> flush_at{48};
+  DeferredLists dev[kMaxDevices];
 } g_defer;
+DeferredLists& lists_of(c10::DeviceIndex device) {
+  TORCH_CHECK(device >= 0 && device < kMaxDevices, "lycoris_amd: device index ", (int)device, " out of range");
+  return g_defer.dev[device];
+}
 
 // after launches on `stream`: whoever consumes .grad on the ambient stream must see them
 void join_ambient(c10::DeviceIndex device, void* stream) {
@@ -185,17 +231,19 @@ void join_ambient(c10::DeviceIndex device, void* stream) {
   (void)hipEventDestroy(ev);
 }
 
-void flush_deferred() {
+void flush_deferred(c10::DeviceIndex device) {
   std::vector<DeferredLokr> items;
   std::vector<DeferredLocon> litems;
   std::vector<DeferredLoha> hitems;
   {
-    std::lock_guard<std::mutex> lock(g_defer.mu);
-    items.swap(g_defer.lokr);
-    litems.swap(g_defer.locon);
-    hitems.swap(g_defer.loha);
-    g_defer.callback_queued = false;
+    DeferredLists& L = lists_of(device);
+    std::lock_guard<std::mutex> lock(L.mu);
+    items.swap(L.lokr);
+    litems.swap(L.locon);
+    hitems.swap(L.loha);
+    L.callback_queued = false;
   }
+  if (items.empty() && litems.empty() && hitems.empty()) return;
   // one call per (device, stream, dtype) run of items, in arrival order
   for (size_t lo = 0; lo < items.size();) {
     size_t hi = lo + 1;
@@ -265,26 +313,28 @@ void flush_deferred() {
 
 // called from a backward node (the engine has a current graph task: final callbacks may be installed)
 template <typename Item>
-void park_deferred_in(std::vector<Item> Deferred::*list, Item&& item) {
+void park_deferred_in(std::vector<Item> DeferredLists::*list, Item&& item) {
   bool queue = false, full = false;
   // one final callback per backward pass (graph task) that parks something: a pass that died with an exception never runs
   // its callback, so "a callback is queued" must not be remembered across passes
   const int task = torch::autograd::get_current_graph_task_id();
+  const c10::DeviceIndex device = item.device;
   {
-    std::lock_guard<std::mutex> lock(g_defer.mu);
-    (g_defer.*list).push_back(std::move(item));
-    if (!g_defer.callback_queued || g_defer.queued_task != task) {
-      g_defer.callback_queued = queue = true;
-      g_defer.queued_task = task;
+    DeferredLists& L = lists_of(device);
+    std::lock_guard<std::mutex> lock(L.mu);
+    (L.*list).push_back(std::move(item));
+    if (!L.callback_queued || L.queued_task != task) {
+      L.callback_queued = queue = true;
+      L.queued_task = task;
     }
-    full = g_defer.lokr.size() + g_defer.locon.size() + g_defer.loha.size() >= g_defer.flush_at;
+    full = L.size() >= g_defer.flush_at.load();
   }
-  if (queue) torch::autograd::Engine::get_default_engine().queue_callback([]() { flush_deferred(); });
-  if (full) flush_deferred();
+  if (queue) torch::autograd::Engine::get_default_engine().queue_callback([device]() { flush_deferred(device); });
+  if (full) flush_deferred(device);
 }
-void park_deferred(DeferredLokr&& item) { park_deferred_in(&Deferred::lokr, std::move(item)); }
-void park_deferred(DeferredLocon&& item) { park_deferred_in(&Deferred::locon, std::move(item)); }
-void park_deferred(DeferredLoha&& item) { park_deferred_in(&Deferred::loha, std::move(item)); }
+void park_deferred(DeferredLokr&& item) { park_deferred_in(&DeferredLists::lokr, std::move(item)); }
+void park_deferred(DeferredLocon&& item) { park_deferred_in(&DeferredLists::locon, std::move(item)); }
+void park_deferred(DeferredLoha&& item) { park_deferred_in(&DeferredLists::loha, std::move(item)); }
 
 // =====================================================================================================================
 // LoKr on nn.Linear
@@ -372,6 +422,8 @@ struct LokrLinearFn : public torch::autograd::Function<LokrLinearFn> {
     static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::lokr_linear", "")
                          .typed<Tensor(const Tensor&, const Tensor&, const Tensor&, double, const c10::optional<Tensor>&)>();
     Tensor y = op.call(x, w1, w2, alpha, base);
+    expect(w1, x);
+    expect(w2, x);
     ctx->save_for_backward({x, w1, w2});
     ctx->saved_data["alpha"] = alpha;
     ctx->saved_data["has_base"] = base.has_value() && base->defined();
@@ -486,6 +538,8 @@ struct LoconLinearFn : public torch::autograd::Function<LoconLinearFn> {
     static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_locon_linear_forward", "")
                          .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, double)>();
     auto [y, t] = op.call(x, down, up, alpha);
+    expect(down, x);
+    expect(up, x);
     ctx->save_for_backward({x, down, up, t});
     ctx->saved_data["alpha"] = alpha;
     return y;
@@ -614,6 +668,7 @@ struct LohaLinearFn : public torch::autograd::Function<LohaLinearFn> {
                          .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&,
                                                            double)>();
     auto [y, ws] = op.call(x, w1a, w1b, w2a, w2b, alpha);
+    for (const Tensor* f : {&w1a, &w1b, &w2a, &w2b}) expect(*f, x);
     ctx->save_for_backward({x, w1a, w1b, w2a, w2b, ws});
     ctx->saved_data["alpha"] = alpha;
     return y;
@@ -727,6 +782,7 @@ struct ChanAffineFn : public torch::autograd::Function<ChanAffineFn> {
     static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::chan_affine", "")
                          .typed<Tensor(const Tensor&, const Tensor&, const c10::optional<Tensor>&, double, double, int64_t)>();
     Tensor out = op.call(a, w, bias, s0, mult, chan_dim);
+    expect(w, a);
     ctx->save_for_backward({a, w, bias.has_value() ? *bias : Tensor()});
     ctx->saved_data["s0"] = s0;
     ctx->saved_data["mult"] = mult;
@@ -1029,6 +1085,8 @@ struct LokrConv2dFn : public torch::autograd::Function<LokrConv2dFn> {
     check_rc(lyc_lokr_conv2d_fwd(cptr(rows), cfp(f1), cfp(w2p), mptr(y), B, H, W, (int)a, (int)b, (int)c, (int)d, gm.kh, gm.kw, gm.sh,
                                  gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, (float)alpha, dtype_code(x.scalar_type()), stream_of(x)),
              "lyc_lokr_conv2d_fwd");
+    expect(w1, x);
+    expect(w2, x, /*cl=*/true);
     ctx->save_for_backward({rows, w1, w2});
     ctx->saved_data["alpha"] = alpha;
     ctx->saved_data["geom"] = std::vector<int64_t>{gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, gm.Ho, gm.Wo, B, C, H, W, !copied};
@@ -1093,6 +1151,8 @@ struct LoconConv2dFn : public torch::autograd::Function<LoconConv2dFn> {
     check_rc(lyc_locon_conv2d_fwd(cptr(rows), cfp(down_p), cfp(up2), mfp(t), mptr(y), B, H, W, (int)C, (int)O, (int)r, gm.kh, gm.kw,
                                   gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, (float)alpha, dtype_code(x.scalar_type()), stream_of(x)),
              "lyc_locon_conv2d_fwd");
+    expect(down, x, /*cl=*/true);
+    expect(up, x);
     ctx->save_for_backward({rows, down, up, t});
     ctx->saved_data["alpha"] = alpha;
     ctx->saved_data["geom"] = std::vector<int64_t>{gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, gm.Ho, gm.Wo, B, C, H, W, !copied};
@@ -1236,33 +1296,48 @@ PYBIND11_MODULE(_lyc_torch, m) {
     std::lock_guard<std::mutex> lk(g_accum.mu);
     g_accum.enabled = enabled;
     if (g_accum.callback == nullptr) g_accum.callback = new py::object();
+    g_accum.has_callback = !callback.is_none();
     *g_accum.callback = std::move(callback);
+    g_accum.uses.clear();
+  });
+  m.def("reset_use_counts", []() {  // once per optimizer step (AdapterGradSync.zero_grad / finish): drop counts of forwards
+    std::lock_guard<std::mutex> lk(g_accum.mu);  // whose backward never ran
+    g_accum.uses.clear();
   });
   m.def("accum_enabled", []() { return g_accum.enabled; });
   m.def("set_defer", [](bool enabled, int flush_at) {
-    std::lock_guard<std::mutex> lk(g_defer.mu);
     g_defer.enabled = enabled;
     if (flush_at > 0) g_defer.flush_at = (size_t)flush_at;
   }, py::arg("enabled"), py::arg("flush_at") = 0);
-  m.def("defer_enabled", []() { return g_defer.enabled; });
+  m.def("defer_enabled", []() { return g_defer.enabled.load(); });
   m.def("deferred_pending", []() {
-    std::lock_guard<std::mutex> lk(g_defer.mu);
-    return g_defer.lokr.size() + g_defer.locon.size() + g_defer.loha.size();
+    size_t n = 0;
+    for (DeferredLists& L : g_defer.dev) {
+      std::lock_guard<std::mutex> lk(L.mu);
+      n += L.size();
+    }
+    return n;
   });
   m.def("flush_deferred", []() {
     py::gil_scoped_release nogil;  // flush_deferred() notifies through a callback that takes the GIL itself
-    flush_deferred();
+    for (int d = 0; d < kMaxDevices; ++d) flush_deferred((c10::DeviceIndex)d);
   });
   m.def("discard_deferred", []() {  // after a failed backward: drop parked layers instead of adding them to the next step
-    std::vector<DeferredLokr> items;
-    std::vector<DeferredLocon> litems;
-    std::vector<DeferredLoha> hitems;
-    std::lock_guard<std::mutex> lk(g_defer.mu);
-    items.swap(g_defer.lokr);
-    litems.swap(g_defer.locon);
-    hitems.swap(g_defer.loha);
-    g_defer.callback_queued = false;
-    return items.size() + litems.size() + hitems.size();
+    size_t n = 0;
+    for (DeferredLists& L : g_defer.dev) {
+      std::vector<DeferredLokr> items;
+      std::vector<DeferredLocon> litems;
+      std::vector<DeferredLoha> hitems;
+      {
+        std::lock_guard<std::mutex> lk(L.mu);
+        items.swap(L.lokr);
+        litems.swap(L.locon);
+        hitems.swap(L.loha);
+        L.callback_queued = false;
+      }
+      n += items.size() + litems.size() + hitems.size();  // the tensors are released outside the lock
+    }
+    return n;
   });
   m.def("abi_version", []() { return lyc_abi_version(); });
 }

@@ -63,6 +63,7 @@ class AdapterGradSync:
         self._bucket_of = {}
         self._handles = []
         self._sync_enabled = True
+        self._fused = False
         self.launch_log: List[int] = []  # bucket indices in launch order of the current step (tests / diagnostics)
         # reverse registration order: the last layers' gradients are ready first during backward
         by_dtype = {}
@@ -114,6 +115,7 @@ class AdapterGradSync:
     def zero_grad(self):
         """One memset per arena.  Use this instead of optimizer.zero_grad(set_to_none=True), which would detach the
         gradient views from the arena."""
+        self._forget_pass()
         for arena in self.arenas.values():
             arena.zero_()
         for p in self.params:  # re-attach if somebody replaced / dropped a .grad
@@ -122,6 +124,14 @@ class AdapterGradSync:
                 self._reattach()
                 break
         self._reset_pending()
+
+    def _forget_pass(self):
+        """Step boundary of the fused path: layers parked by a backward pass that raised are dropped (they would otherwise be
+        added to the next step's gradients) and stale pending-accumulation counts are cleared."""
+        if self.device.type == "cuda" and self._fused:
+            from . import ops
+            ops.discard_deferred()
+            ops.reset_use_counts()
 
     def _reattach(self):
         for dtype, arena in self.arenas.items():
@@ -148,9 +158,12 @@ class AdapterGradSync:
 
     def attach_fused(self, enabled: bool = True):
         """Let the kernels accumulate factor gradients straight into the arena (``ops.fused_grad_accumulation``) and
-        report each finished parameter to the bucket counters, exactly like the autograd hook would."""
+        report each finished parameter to the bucket counters, exactly like the autograd hook would: ONE report per parameter
+        and backward pass, after its last accumulation -- a parameter shared by several layer calls is counted in the forward
+        pass (csrc/torch_ops.cpp `expect()`) and reported when the last of its backward nodes has run."""
         from . import ops
         ops.fused_grad_accumulation(enabled, callback=self._on_grad_ready if enabled else None)
+        self._fused = bool(enabled)
 
     def _on_grad_ready(self, p):
         if not self._sync_enabled:
@@ -224,6 +237,9 @@ class AdapterGradSync:
         if self.side_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
         self._reset_pending()
+        if self.device.type == "cuda" and self._fused:
+            from . import ops
+            ops.reset_use_counts()
 
     def remove(self):
         for h in self._handles:

@@ -385,7 +385,9 @@ class LycorisBaseModule(nn.Module):
         ignores it on the rebuild path and for LoHa / LoKr)."""
         if self.module_dropout and self.training and float(torch.rand(1)) < self.module_dropout:
             return self.org_forward(x, *args, **kwargs)
-        if getattr(self, "wd", False):
+        # upstream consults bypass_mode first (modules/lokr.py:548-549, locon.py / loha.py alike): in bypass mode -- forced for
+        # quantised base layers -- weight_decompose is ignored and the base weight is never read
+        if getattr(self, "wd", False) and not self.bypass_mode:
             return self._forward_dora(x, *args, **kwargs)
         base = self.org_forward(x, *args, **kwargs)
         plain = not (self.training and (self.rank_dropout or (self.bypass_mode and self.dropout)))

@@ -81,6 +81,14 @@ def discard_deferred() -> int:
     return _DISPATCH["ext"].discard_deferred() if _DISPATCH["ext"] is not None else 0
 
 
+def reset_use_counts():
+    """Forget the per-parameter count of pending accumulations (csrc/torch_ops.cpp `expect()` / `notify()`): a forward pass whose
+    backward never ran leaves a count behind, which would swallow that parameter's next report.  AdapterGradSync calls this once
+    per optimizer step (zero_grad / finish)."""
+    if _DISPATCH["ext"] is not None:
+        _DISPATCH["ext"].reset_use_counts()
+
+
 def _grad_targets(factors, needs):
     """Per factor: the tensor the kernel should accumulate into (existing .grad or a fresh zero buffer) and whether
     the result has to be handed back to autograd."""

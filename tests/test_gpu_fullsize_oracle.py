@@ -40,11 +40,14 @@ def _bounds(dtype, names_store, names_f32, store="store_out"):
     return b
 
 
+DT16 = pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+
+
+@DT16
 @pytest.mark.parametrize("shape", LINEAR, ids=IDS)
-def test_lokr_linear_fullsize(shape):
+def test_lokr_linear_fullsize(shape, dtype):
     from lycoris_amd import ops
     M, I, O = shape
-    dtype = torch.bfloat16
     a = b = 8
     c, d = O // 8, I // 8
     gen = torch.Generator().manual_seed(M + I + O)
@@ -60,7 +63,7 @@ def test_lokr_linear_fullsize(shape):
     y_ref = oracle.lokr.forward(x64, w1=w1_64, w2=w2_64, scale=1.0)
     gr = oracle.lokr.backward(x64, g64, w1=w1_64, w2=w2_64, scale=1.0)
     errs = {"y": err(y, y_ref, dtype), "dx": err(dx, gr["dx"], dtype), "dw1": err(dw1, gr["w1"]), "dw2": err(dw2, gr["w2"])}
-    check(f"lokr_linear_full[{shape}]", errs, _bounds(dtype, ["y", "dx"], ["dw1", "dw2"]))
+    check(f"lokr_linear_full[{shape},{dtype}]", errs, _bounds(dtype, ["y", "dx"], ["dw1", "dw2"]))
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
@@ -85,11 +88,12 @@ def test_locon_linear_fullsize(shape, dtype):
     check(f"locon_linear_full[{shape},{dtype}]", errs, _bounds(dtype, ["y", "dx"], ["d_down", "d_up"]))
 
 
+@DT16
 @pytest.mark.parametrize("shape", LINEAR, ids=IDS)
-def test_loha_linear_fullsize(shape):
+def test_loha_linear_fullsize(shape, dtype):
     from lycoris_amd import ops
     M, I, O = shape
-    r, dtype = 32, torch.bfloat16
+    r = 32
     gen = torch.Generator().manual_seed(M + I + O + 2)
     x, x64 = rnd((M, I), dtype, gen)
     g, g64 = rnd((M, O), dtype, gen, 1.0 / np.sqrt(O))
@@ -109,11 +113,14 @@ def test_loha_linear_fullsize(shape):
     errs = {"y": err(y, y_ref, dtype), "dx": err(grads[0], ref[0], dtype)}
     for n, gr, rf in zip(names[1:], grads[1:], ref[1:]):
         errs[n] = err(gr, rf)
-    check(f"loha_linear_full[{shape}]", errs, _bounds(dtype, ["y", "dx"], names[1:], "loha_store"))
+    check(f"loha_linear_full[{shape},{dtype}]", errs, _bounds(dtype, ["y", "dx"], names[1:], "loha_store"))
 
 
 # ---- Conv2d at full size ------------------------------------------------------------------------------------------
-# (B, C, H, O, k, stride): SDXL resnet conv @128, @32, downsample, 1x1 shortcut; SD1.5 1x1 proj_in, resnet conv bs 4
+# (B, C, H, O, k, stride): SDXL resnet conv @128, @32, downsample, 1x1 shortcut; SD1.5 1x1 proj_in, resnet conv bs 4;
+# then the rest of the distinct SDXL 3x3 shapes: the up-block convs with C = 960 / 1920 / 2560
+# (d = 120 / 240 / 320: other K-chunk / LDS-patch plans), the channel-changing resnet convs, both upsample convs and the
+# second downsample conv
 CONV = [
     (1, 320, 128, 320, 3, 1),
     (1, 1280, 32, 1280, 3, 1),
@@ -121,6 +128,17 @@ CONV = [
     (1, 960, 128, 320, 1, 1),
     (4, 320, 64, 320, 1, 1),
     (4, 320, 64, 320, 3, 1),
+    (1, 960, 128, 320, 3, 1),
+    (1, 640, 128, 320, 3, 1),
+    (1, 1920, 64, 640, 3, 1),
+    (1, 960, 64, 640, 3, 1),
+    (1, 320, 64, 640, 3, 1),
+    (1, 2560, 32, 1280, 3, 1),
+    (1, 1920, 32, 1280, 3, 1),
+    (1, 640, 32, 1280, 3, 1),
+    (1, 640, 128, 640, 3, 1),
+    (1, 1280, 64, 1280, 3, 1),
+    (1, 640, 64, 640, 3, 2),
 ]
 CIDS = [f"B{b}_{c}x{h}to{o}_k{k}s{s}" for b, c, h, o, k, s in CONV]
 
@@ -129,11 +147,13 @@ def _ca(k, s):
     return {"stride": s, "padding": k // 2, "dilation": 1}
 
 
+@DT16
 @pytest.mark.parametrize("shape", CONV, ids=CIDS)
-def test_lokr_conv2d_fullsize(shape):
+def test_lokr_conv2d_fullsize(shape, dtype):
     from lycoris_amd import ops
     B, C, H, O, k, s = shape
-    dtype = torch.bfloat16
+    if dtype == torch.float16 and shape not in (CONV[0], CONV[1], CONV[2], CONV[8], CONV[11]):
+        pytest.skip("fp16: one shape per kernel plan")
     gen = torch.Generator().manual_seed(B + C + H + O + k)
     x, x64 = rnd((B, C, H, H), dtype, gen)
     Ho = (H + 2 * (k // 2) - k) // s + 1
@@ -149,10 +169,10 @@ def test_lokr_conv2d_fullsize(shape):
     y_ref = oracle.lokr.forward(x64, w1=w1_64, w2=w2_64, scale=1.0, kshape=(k, k), conv_args=ca)
     gr = oracle.lokr.backward(x64, g64, w1=w1_64, w2=w2_64, scale=1.0, kshape=(k, k), conv_args=ca)
     errs = {"y": err(y, y_ref, dtype), "dx": err(dx, gr["dx"], dtype), "dw1": err(dw1, gr["w1"]), "dw2": err(dw2, gr["w2"])}
-    check(f"lokr_conv_full[{shape}]", errs, _bounds(dtype, ["y", "dx"], ["dw1", "dw2"]))
+    check(f"lokr_conv_full[{shape},{dtype}]", errs, _bounds(dtype, ["y", "dx"], ["dw1", "dw2"]))
 
 
-@pytest.mark.parametrize("shape", CONV, ids=CIDS)
+@pytest.mark.parametrize("shape", CONV[:6] + [CONV[8], CONV[11]], ids=CIDS[:6] + [CIDS[8], CIDS[11]])
 def test_locon_conv2d_fullsize(shape):
     from lycoris_amd import ops
     B, C, H, O, k, s = shape
@@ -203,3 +223,49 @@ def test_loha_conv2d_fullsize(shape):
     for n, gr, rf in zip(names[1:], grads[1:], ref[1:]):
         errs[n] = err(gr, rf)
     check(f"loha_conv_full[{shape}]", errs, _bounds(dtype, ["y", "dx"], names[1:], "loha_store"))
+
+
+# ---- low-rank LoKr (BASELINE configs[3] "(low)": dim 16, and decompose_both) at full size -------------------------
+LOWRANK = [(1024, 1280, 1280), (1024, 1280, 10240), (1024, 5120, 1280), (4096, 640, 640), (4096, 640, 5120), (77, 2048, 1280)]
+
+
+@DT16
+@pytest.mark.parametrize("both", [False, True], ids=["w2lowrank", "decompose_both"])
+@pytest.mark.parametrize("shape", LOWRANK, ids=[f"M{m}_{i}to{o}" for m, i, o in LOWRANK])
+def test_lokr_lowrank_module_fullsize(shape, both, dtype):
+    """LokrModule(lora_dim = 16, alpha = 8, factor = 8[, decompose_both with rank 2 on the 8 x 8 factor]) on a full-size Linear:
+    w2 = w2a @ w2b (and w1 = w1a @ w1b) are products of trained factors -- reference modules/lokr.py:358-381."""
+    import torch.nn as nn
+    from lycoris_amd.modules import LokrModule
+    M, I, O = shape
+    rank = 2 if both else 16
+    torch.manual_seed(M + I + O + 7)
+    lin = nn.Linear(I, O, bias=False).to(dev(), dtype)
+    mod = LokrModule("t", lin, 1.0, rank, rank / 2, factor=8, decompose_both=both).to(dev())
+    gen = torch.Generator().manual_seed(M + I + O + 8)
+    names = [n for n in ("lokr_w1", "lokr_w1_a", "lokr_w1_b", "lokr_w2", "lokr_w2_a", "lokr_w2_b") if hasattr(mod, n)]
+    if both:
+        assert "lokr_w1_a" in names
+    assert "lokr_w2_a" in names, names
+    f64 = {}
+    for n in names:
+        p = getattr(mod, n)
+        t, t64 = rnd(tuple(p.shape), torch.float32, gen, 0.3 if "w1" in n else 0.1)
+        p.data.copy_(t)
+        f64[n] = t64
+    x, x64 = rnd((M, I), dtype, gen)
+    g, g64 = rnd((M, O), dtype, gen, 1.0 / np.sqrt(O))
+    x.requires_grad_(True)
+    delta = mod.bypass_forward_diff(x) if hasattr(mod, "bypass_forward_diff") else None
+    params = [getattr(mod, n) for n in names]
+    grads = torch.autograd.grad(delta, [x] + params, g)
+    torch.cuda.synchronize()
+    kw = {"w1": f64.get("lokr_w1"), "w1a": f64.get("lokr_w1_a"), "w1b": f64.get("lokr_w1_b"),
+          "w2": f64.get("lokr_w2"), "w2a": f64.get("lokr_w2_a"), "w2b": f64.get("lokr_w2_b")}
+    scale = float(mod.scale)
+    y_ref = oracle.lokr.forward(x64, scale=scale, **kw)
+    gr = oracle.lokr.backward(x64, g64, scale=scale, **kw)
+    errs = {"y": err(delta, y_ref, dtype), "dx": err(grads[0], gr["dx"], dtype)}
+    for n, gv in zip(names, grads[1:]):
+        errs[n] = err(gv, gr[n.replace("lokr_", "").replace("_a", "a").replace("_b", "b")])
+    check(f"lokr_lowrank_full[{shape},{both},{dtype}]", errs, _bounds(dtype, ["y", "dx"], names))
