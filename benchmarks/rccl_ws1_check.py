@@ -12,9 +12,12 @@ side stream before the optimizer -- and checks that the gradients equal the ones
 Also checks a module shared by two layer calls through the sync (its bucket used to be reduced early).
 Prints "rccl-ws1 ok" and exits 0.  Run by tests/test_gpu_grad_sync.py in a child process.
 """
+import faulthandler
 import os
 import sys
+import time
 
+faulthandler.enable()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist
@@ -53,6 +56,7 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", device_id=DEV)
     assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
+    print("nccl process group up", flush=True)
     gen = torch.Generator(device=DEV).manual_seed(7)
     shapes = [("lokr", 256, 640, 640), ("locon", 256, 640, 1280), ("lokr", 64, 1280, 640), ("locon", 77, 2048, 640)] * 6
     layers = [Layer(a, M, I, O, gen) for a, M, I, O in shapes]
@@ -71,6 +75,7 @@ def main():
     want = torch.autograd.grad([y for y, _ in outs], params, [l.g for _, l in outs])
     want = [w.clone() for w in want]
     torch.cuda.synchronize()
+    print("truth computed", flush=True)
 
     def check(tag):
         torch.cuda.synchronize()
@@ -84,6 +89,7 @@ def main():
     # ---- eager: collectives launched from inside the backward by the fused-accumulation callback -------------------------
     sync = AdapterGradSync(params, bucket_bytes=256 << 10, always_reduce=True)  # several buckets
     assert len(sync.buckets) >= 3, len(sync.buckets)
+    print(f"{len(sync.buckets)} buckets", flush=True)
     sync.attach_fused()
     try:
         for rep in range(2):
@@ -94,9 +100,11 @@ def main():
             sync.finish()
             e = check(f"eager step {rep}")
         assert launched_in_backward == len(sync.buckets), (launched_in_backward, len(sync.buckets))
-        print(f"eager: {len(sync.buckets)} buckets all-reduced (AVG, side stream) from inside the backward, rel-err {e:.1e}")
+        print(f"eager: {len(sync.buckets)} buckets all-reduced (AVG, side stream) from inside the backward, rel-err {e:.1e}", flush=True)
 
         # ---- captured: forward graph + backward segment graphs, launch_ready() between the replays (bench.py's N > 1 step) ---
+        torch.cuda.synchronize()
+        time.sleep(1.0)  # every collective of the eager steps has been retired by RCCL's watchdog thread before the capture starts
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         sync._sync_enabled = False
@@ -127,7 +135,7 @@ def main():
                 sync.launch_ready(upto)
             sync.finish()
             e = check(f"graph step {rep}")
-        print(f"captured: 1 forward graph + {nseg} backward segments, bucket all-reduces between the replays, rel-err {e:.1e}")
+        print(f"captured: 1 forward graph + {nseg} backward segments, bucket all-reduces between the replays, rel-err {e:.1e}", flush=True)
     finally:
         sync.attach_fused(False)
         sync.remove()

@@ -31,7 +31,7 @@ enum { LYC_F32 = 0, LYC_F16 = 1, LYC_BF16 = 2 };
 enum { LYC_F32_ROWS = 0x100, LYC_DEFER_WGRAD = 0x200 };
 enum { LYC_OK = 0, LYC_ERR_ARG = 1, LYC_ERR_UNSUPPORTED = 2, LYC_ERR_LAUNCH = 3 };
 
-#define LYC_ABI_VERSION 7
+#define LYC_ABI_VERSION 8
 int lyc_abi_version(void);
 const char* lyc_last_error(void);
 
@@ -133,6 +133,55 @@ int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1,
                         void* dx_rows, float* dw1, float* dw2p, void* ws, int64_t B, int64_t H, int64_t W, int a, int b, int c, int d,
                         int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float alpha, int dtype,
                         void* stream);
+
+/* ---- LoKr: pre-packed operand planes + the LDS-patch Conv2d kernels (ABI v8, csrc/kron_conv.h) ------------------------
+ * w2 (lokr_w2, or lokr_w2_a @ lokr_w2_b: reference lycoris/modules/lokr.py:358-381 get_weight / functional/lokr.py:124-151)
+ * is a PARAMETER: it changes once per optimizer step.  lyc_lokr_pack_w2 writes it once as hi + lo planes in the activation
+ * dtype, in MFMA-fragment order, for the two contractions that use it: `planes_fwd` (n = q, k = (tap, v): y = ... w2 x) and
+ * `planes_bwd` (n = v, k = (tap, q): dx = ... w2^T g); either may be NULL.  lyc_lokr_planes_bytes gives their sizes.
+ *   full matrix : w2 element (q, v, tap) at w2[q*sq + v*sv + tap*st]            (w2a == w2b == NULL)
+ *                 [c, d, kh, kw] contiguous: sq = d*kh*kw, sv = kh*kw, st = 1; channels_last / [c, kh*kw, d]: sq = kh*kw*d, sv = 1, st = d
+ *   low rank    : w2 == NULL; w2[q, v, tap] = sum_r w2a[q*a_sq + r*a_sr] * w2b[r*b_sr + v*b_sv + tap*b_st]   (the product is
+ *                 formed inside the pack kernel: no [c, d] tensor, no library GEMM)
+ * The *_planes Conv2d entry points are lyc_lokr_conv2d_fwd / _bwd with the stage-1 operand taken from the planes and the
+ * kh x kw window applied from a source patch held in LDS (each source pixel is loaded once per workgroup instead of once
+ * per tap).  lyc_lokr_conv2d_planes_ok(..., backward) tells whether a geometry is covered (16-bit activations, a == b in
+ * {4, 8, 16}, c % 8 == d % 8 == 0, the patch + operand ring within 160 KiB of LDS; backward: stride 1); a refused call
+ * returns LYC_ERR_UNSUPPORTED and does nothing.  In lyc_lokr_conv2d_bwd_planes `w2p` may be NULL when the geometry is
+ * covered (it is only the fallback operand); dw2p is computed as by lyc_lokr_conv2d_bwd. */
+int64_t lyc_lokr_planes_bytes(int c, int d, int taps, int backward);
+int lyc_lokr_pack_w2(const float* w2, int64_t sq, int64_t sv, int64_t st, const float* w2a, int64_t a_sq, int64_t a_sr,
+                     const float* w2b, int64_t b_sr, int64_t b_sv, int64_t b_st, int rank, int c, int d, int taps,
+                     void* planes_fwd, void* planes_bwd, int dtype, void* stream);
+int lyc_lokr_conv2d_planes_ok(int64_t B, int64_t H, int64_t W, int a, int b, int c, int d, int kh, int kw, int sh, int sw, int ph,
+                              int pw, int dh, int dw, int dtype, int backward);
+int lyc_lokr_conv2d_fwd_planes(const void* x_rows, const float* w1, const void* planes_fwd, void* y_rows, int64_t B, int64_t H,
+                               int64_t W, int a, int b, int c, int d, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                               int dw, float alpha, int dtype, void* stream);
+/* Deferred, grouped weight gradients of the Conv2d form (as lyc_lokr_wgrad_group for nn.Linear): call lyc_lokr_conv2d_bwd[_planes]
+ * with dw2p == NULL and dtype | LYC_DEFER_WGRAD (dx launch only; the dw1 partials stay in `ws`), keep (g_rows, x_rows, ws) alive,
+ * and hand batches of layers to lyc_lokr_conv_wgrad_group: dw2p += for up to 14 layers per launch, dw1 += reduced from the
+ * partials.  `dw1_blocks` = lyc_lokr_conv2d_dx_blocks(..., with_planes) for the dx call that wrote `ws` (with_planes: it was
+ * lyc_lokr_conv2d_bwd_planes on a geometry lyc_lokr_conv2d_planes_ok(backward = 1) covers). */
+typedef struct LycLokrConvWgradItem {
+  const void* g_rows;  /* [B*Ho*Wo, a*c] */
+  const void* x_rows;  /* [B*H*W, b*d]   */
+  const float* w1;     /* [a, b]         */
+  float* dw1;          /* [a, b] += (NULL: skip) */
+  float* dw2p;         /* [c, kh*kw, d] +=       */
+  void* ws;            /* the scratch the layer's dx launch used */
+  int64_t B, H, W;
+  int64_t dw1_blocks;
+  int a, b, c, d, kh, kw, sh, sw, ph, pw, dh, dw;
+  float alpha;
+} LycLokrConvWgradItem;
+int64_t lyc_lokr_conv2d_dx_blocks(int64_t B, int64_t H, int64_t W, int a, int b, int c, int d, int kh, int kw, int sh, int sw, int ph,
+                                  int pw, int dh, int dw, int dtype, int with_planes);
+int lyc_lokr_conv_wgrad_group(const LycLokrConvWgradItem* items, int n, int dtype, void* stream);
+int lyc_lokr_conv2d_bwd_planes(const void* g_rows, const void* x_rows, const float* w1, const float* w2p, const void* planes_bwd,
+                               void* dx_rows, float* dw1, float* dw2p, void* ws, int64_t B, int64_t H, int64_t W, int a, int b,
+                               int c, int d, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float alpha, int dtype,
+                               void* stream);
 
 /* ---- LoCon on nn.Linear ------------------------------------------------------------------------
  * replaces lycoris/modules/locon.py:309-332 (forward: make_weight + dense F.linear) and the bypass

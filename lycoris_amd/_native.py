@@ -13,7 +13,7 @@ import torch
 
 _LIB_NAME = "liblycoris_amd.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 LYC_F32, LYC_F16, LYC_BF16 = 0, 1, 2
 _DTYPE_CODE = {torch.float32: LYC_F32, torch.float16: LYC_F16, torch.bfloat16: LYC_BF16}
@@ -29,6 +29,10 @@ SIGNATURES = {
     "lyc_loha_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LohaWgradItem
     "lyc_lokr_conv2d_fwd": [_vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_lokr_conv2d_bwd": [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
+    "lyc_lokr_conv_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LokrConvWgradItem
+    "lyc_lokr_pack_w2": [_fp, _i64, _i64, _i64, _fp, _i64, _i64, _fp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
+    "lyc_lokr_conv2d_fwd_planes": [_vp, _fp, _vp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
+    "lyc_lokr_conv2d_bwd_planes": [_vp, _vp, _fp, _fp, _vp, _vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_locon_linear_fwd": [_vp, _fp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_locon_linear_bwd": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _fp, _fp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_locon_conv2d_fwd": [_vp, _fp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 11 + [_f32, _i32, _vp],
@@ -55,6 +59,9 @@ VALUE_SIGNATURES = {
     "lyc_loha_workspace_bytes": ([_i32, _i32, _i32], ctypes.c_int64),
     "lyc_lokr_bwd_workspace_bytes": ([_i64, _i32, _i32, _i32, _i32, _i32], ctypes.c_int64),
     "lyc_lokr_conv2d_bwd_workspace_bytes": ([_i64, _i64, _i64, _i32, _i32, _i32], ctypes.c_int64),
+    "lyc_lokr_planes_bytes": ([_i32, _i32, _i32, _i32], ctypes.c_int64),
+    "lyc_lokr_conv2d_dx_blocks": ([_i64, _i64, _i64] + [_i32] * 14, ctypes.c_int64),
+    "lyc_lokr_conv2d_planes_ok": ([_i64, _i64, _i64] + [_i32] * 14, ctypes.c_int),
     "lyc_lokr_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32], ctypes.c_int),  # 1 / 0, not an error code
     "lyc_locon_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32], ctypes.c_int),
     "lyc_loha_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32], ctypes.c_int),
@@ -71,6 +78,13 @@ class LoconWgradItem(ctypes.Structure):
     """LycLoconWgradItem (include/lycoris_amd.h)"""
     _fields_ = [("g", _vp), ("x", _vp), ("t", _vp), ("dt", _vp), ("d_down", _vp), ("d_up", _vp), ("M", _i64),
                 ("I", _i32), ("O", _i32), ("r", _i32), ("alpha", _f32)]
+
+
+class LokrConvWgradItem(ctypes.Structure):
+    """LycLokrConvWgradItem (include/lycoris_amd.h)"""
+    _fields_ = [("g_rows", _vp), ("x_rows", _vp), ("w1", _vp), ("dw1", _vp), ("dw2p", _vp), ("ws", _vp), ("B", _i64), ("H", _i64),
+                ("W", _i64), ("dw1_blocks", _i64)] + [(n, _i32) for n in ("a", "b", "c", "d", "kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw")] + [
+                    ("alpha", _f32)]
 
 
 class WgradItem(ctypes.Structure):

@@ -1,6 +1,7 @@
 // capi.hip -- C ABI launchers (include/lycoris_amd.h).  gfx950 only.
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
+#include <cstdlib>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -11,6 +12,7 @@
 #include "ia3_kernels.h"
 #include "kron3.h"
 #include "kron_dw2s.h"
+#include "kron_conv.h"
 #include "loha_mfma.h"
 #include "lokr_kernels.h"
 #include "lowrank.h"
@@ -761,14 +763,220 @@ int lyc_lokr_conv2d_fwd(const void* x_rows, const float* w1, const float* w2p, v
 
 int64_t lyc_lokr_conv2d_bwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int a, int b, int d) {
   if (B <= 0 || H < 1 || W < 1 || a < 1 || a != b || a > 16 || d < 1) return 0;
-  return (int64_t)cdiv(B * H * W, K3_RT / a) * cdiv(d, 32) * a * b * (int64_t)sizeof(float);
+  // one [a*b] partial per workgroup of the dx launch: the row kernel tiles 128 / a consecutive pixels, the patch kernel
+  // (kron_conv.h) TH x TW pixel tiles per image; both take column tiles of >= 32
+  const int tmp = K3_RT / a;  // the patch kernel's smallest tile (MI = 2: 128 rows) has the most workgroups
+  int lt = 0;
+  while ((2 << lt) <= tmp) ++lt;
+  const int th = 1 << (lt / 2), tw = tmp / th;
+  const long flat = cdiv(B * H * W, tmp), tiled = B * cdiv(H, th) * cdiv(W, tw), strip = B * H * cdiv(W, tmp);  // strip: 1 x 1 windows
+  long most = flat > tiled ? flat : tiled;
+  if (strip > most) most = strip;
+  return (int64_t)most * cdiv(d, 32) * a * b * (int64_t)sizeof(float);
+}
+
+extern "C++" {
+namespace {
+// ---- the patch kernel (kron_conv.h): plan, launch ---------------------------------------------------------------------
+// `ka` carries the problem as for kron3 (x = source rows, M = destination pixels, K per tap, N, gat with mode 1 / 2).
+// Tile of 64 mi / G destination pixels for one MI; false when the patch + operand ring do not fit the LDS.
+bool plan_kconv_mi(const KronArgs& ka, int mi, KconvGeom& gm, int ni, int ksteps) {
+  const KronGather& gt = ka.gat;
+  const int G = ka.Gin, kh = gt.taps / gt.kw;
+  const int tmp = 64 * mi / G;
+  if (tmp < 2) return false;
+  int lt = 0;
+  while ((2 << lt) <= tmp) ++lt;       // log2(tmp)
+  gm.TH = 1 << (lt / 2);
+  gm.TW = tmp / gm.TH;
+  if (gt.taps == 1) { gm.TH = 1; gm.TW = tmp; }  // 1 x 1 window: no halo, a strip of consecutive pixels
+  if (gt.mode == 1) {
+    gm.sy = gt.sh; gm.sx = gt.sw; gm.oy0 = -gt.ph; gm.ox0 = -gt.pw;
+    gm.PH = (gm.TH - 1) * gt.sh + (kh - 1) * gt.dh + 1;
+    gm.PW = (gm.TW - 1) * gt.sw + (gt.kw - 1) * gt.dw + 1;
+  } else {
+    gm.sy = gm.sx = 1; gm.oy0 = gt.ph - (kh - 1) * gt.dh; gm.ox0 = gt.pw - (gt.kw - 1) * gt.dw;
+    gm.PH = gm.TH + (kh - 1) * gt.dh;
+    gm.PW = gm.TW + (gt.kw - 1) * gt.dw;
+  }
+  gm.tiles_h = (int)cdiv(gt.Hd, gm.TH);
+  gm.tiles_w = (int)cdiv(gt.Wd, gm.TW);
+  gm.GP = ka.K + (((ka.K / 8) % 2 == 0) ? 8 : 0);  // an odd number of 16-byte slots per group segment
+  gm.CP = G * gm.GP;
+  const long pbytes = round_up((long)gm.PH * gm.PW * gm.CP * 2, 1024);
+  if (pbytes > 140 * 1024) return false;
+  gm.patch_bytes = (int)pbytes;
+  gm.kss = ksteps < 4 ? ksteps : 4;
+  while (gm.kss > 1 && kconv_lds_bytes(ni, gm) > 160 * 1024) gm.kss >>= 1;
+  return kconv_lds_bytes(ni, gm) <= 160 * 1024;
+}
+
+bool plan_kconv(const KronArgs& ka, int64_t B, KconvGeom& gm, int& mi, int& ni, int& ksteps) {
+  const KronGather& gt = ka.gat;
+  const int G = ka.Gin;
+  if (G != ka.Gout || (G != 4 && G != 8 && G != 16) || (ka.K % 8) != 0 || (ka.N % 8) != 0 || gt.taps < 1 || gt.taps > 64) return false;
+  if (gt.mode == 2 && (gt.sh != 1 || gt.sw != 1)) return false;  // the transposed convolution of a strided layer: row kernel
+  if ((long)gt.Hs * gt.Ws * G * ka.K >= (1L << 30)) return false;  // buffer descriptor offsets are 32-bit
+  ksteps = (int)kron_plane_ksteps(gt.taps, ka.K);
+  // column tile: the widest of 64 / 48 / 32 that pads N by <= 25 %, else the one that pads least
+  ni = 0;
+  long best = 1L << 40;
+  for (int cand = 4; cand >= 2; --cand) {
+    const long padded = round_up(ka.N, 16 * cand);
+    if (padded * 4 <= (long)ka.N * 5) { ni = cand; break; }
+    if (padded < best) { best = padded; ni = cand; }
+  }
+  // row tile: every workgroup streams the operand planes of its column tile once, so their traffic goes with 1 / MI -- take the
+  // largest pixel tile that fits the LDS and still leaves about one workgroup per CU; else the smallest (most workgroups)
+  const long ctiles = cdiv(ka.N, 16 * ni);
+  KconvGeom g2{};
+  bool have = false;
+  const char* force = getenv("LYC_KCONV_MI");  // tests: pin the row tile (2 / 4 / 8) so that small problems reach every instantiation
+  const int only = force ? atoi(force) : 0;
+  for (int cand = 8; cand >= 2; cand >>= 1) {
+    if (only && cand != only) continue;
+    KconvGeom t{};
+    if (!plan_kconv_mi(ka, cand, t, ni, ksteps)) continue;
+    g2 = t; mi = cand; have = true;
+    if (B * t.tiles_h * t.tiles_w * ctiles >= 200) break;
+  }
+  if (!have) return false;
+  gm = g2;
+  return true;
+}
+
+template <typename T, int MI, int NI, bool DW1>
+void launch_kconv_inst(const KconvArgs& ca, dim3 grid, int lds, hipStream_t st) {
+  static bool attr_set = false;  // dynamic LDS above 64 KiB needs the opt-in (per instantiation)
+  if (lds > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kconv_kernel<T, MI, NI, DW1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((kconv_kernel<T, MI, NI, DW1>), grid, dim3(NTHREADS), lds, st, ca);
+}
+template <typename T, int MI, bool DW1>
+void launch_kconv_ni(int ni, const KconvArgs& ca, dim3 grid, int lds, hipStream_t st) {
+  switch (ni) {
+    case 2: launch_kconv_inst<T, MI, 2, DW1>(ca, grid, lds, st); break;
+    case 3: launch_kconv_inst<T, MI, 3, DW1>(ca, grid, lds, st); break;
+    default: launch_kconv_inst<T, MI, 4, DW1>(ca, grid, lds, st); break;
+  }
+}
+
+// returns the number of workgroups, or -1 when the problem is not plannable
+template <typename T>
+long launch_kconv(const KronArgs& ka, const void* planes, int64_t B, hipStream_t st) {
+  KconvArgs ca{};
+  int mi = 0, ni = 0, ksteps = 0;
+  if (!plan_kconv(ka, B, ca.gm, mi, ni, ksteps)) return -1;
+  ca.k = ka;
+  ca.planes = planes;
+  ca.ksteps = ksteps;
+  dim3 grid((unsigned)(B * ca.gm.tiles_h * ca.gm.tiles_w), (unsigned)cdiv(ka.N, 16 * ni));
+  const int lds = kconv_lds_bytes(ni, ca.gm);
+  const bool dw1 = ka.dw1 != nullptr || ka.dw1_ws != nullptr;
+  switch (mi) {
+    case 8: dw1 ? launch_kconv_ni<T, 8, true>(ni, ca, grid, lds, st) : launch_kconv_ni<T, 8, false>(ni, ca, grid, lds, st); break;
+    case 4: dw1 ? launch_kconv_ni<T, 4, true>(ni, ca, grid, lds, st) : launch_kconv_ni<T, 4, false>(ni, ca, grid, lds, st); break;
+    default: dw1 ? launch_kconv_ni<T, 2, true>(ni, ca, grid, lds, st) : launch_kconv_ni<T, 2, false>(ni, ca, grid, lds, st); break;
+  }
+  return (long)grid.x * grid.y;
+}
+
+int lokr_conv2d_bwd_impl(const void* g_rows, const void* x_rows, const float* w1, const float* w2p, const float* w2t,
+                         const void* planes_bwd, void* dx_rows, float* dw1, float* dw2p, void* ws, int64_t B, int64_t H, int64_t W,
+                         int a, int b, int c, int d, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float alpha,
+                         int dtype, void* stream);
+}  // namespace
+}  // extern "C++"
+
+int64_t lyc_lokr_planes_bytes(int c, int d, int taps, int backward) {
+  if (c < 1 || d < 1 || taps < 1) return 0;
+  return backward ? kron_plane_bytes(d, taps, c) : kron_plane_bytes(c, taps, d);
+}
+
+int lyc_lokr_pack_w2(const float* w2, int64_t sq, int64_t sv, int64_t st, const float* w2a, int64_t a_sq, int64_t a_sr,
+                     const float* w2b, int64_t b_sr, int64_t b_sv, int64_t b_st, int rank, int c, int d, int taps,
+                     void* planes_fwd, void* planes_bwd, int dtype, void* stream) {
+  if (c < 1 || d < 1 || taps < 1 || (c % 8) != 0 || (d % 8) != 0) return fail(LYC_ERR_ARG, "lokr_pack_w2: c, d must be positive multiples of 8");
+  if (!w2 && !(w2a && w2b && rank >= 1)) return fail(LYC_ERR_ARG, "lokr_pack_w2: pass w2 or the low-rank pair (w2a, w2b, rank)");
+  if (!planes_fwd && !planes_bwd) return LYC_OK;
+  KronPackArgs pa{};
+  pa.w2 = w2; pa.sq = sq; pa.sv = sv; pa.st = st;
+  pa.w2a = w2a; pa.w2b = w2b; pa.a_sq = a_sq; pa.a_sr = a_sr; pa.b_sr = b_sr; pa.b_sv = b_sv; pa.b_st = b_st; pa.rank = rank;
+  pa.c = c; pa.d = d; pa.taps = taps; pa.fwd = planes_fwd; pa.bwd = planes_bwd;
+  pa.units_fwd = kron_plane_bytes(c, taps, d) / 2048;
+  const long units = pa.units_fwd + kron_plane_bytes(d, taps, c) / 2048;
+  const dim3 grid((unsigned)cdiv(units, NWAVES));
+  switch (dtype & 0xff) {
+    case LYC_BF16: hipLaunchKernelGGL((kron_pack_kernel<__bf16>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, pa); break;
+    case LYC_F16: hipLaunchKernelGGL((kron_pack_kernel<_Float16>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, pa); break;
+    default: return fail(LYC_ERR_UNSUPPORTED, "lokr_pack_w2: operand planes exist for 16-bit activations only");
+  }
+  return check_launch("lokr_pack_w2");
+}
+
+int lyc_lokr_conv2d_planes_ok(int64_t B, int64_t H, int64_t W, int a, int b, int c, int d, int kh, int kw, int sh, int sw, int ph,
+                              int pw, int dh, int dw, int dtype, int backward) {
+  ConvDims cd{};
+  if (B < 1 || (dtype & 0xff) == LYC_F32 || a != b) return 0;
+  if (H < 1 || W < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0 || dh < 1 || dw < 1) return 0;
+  cd.Ho = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1;
+  cd.Wo = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
+  cd.taps = kh * kw;
+  if (cd.Ho < 1 || cd.Wo < 1) return 0;
+  KronArgs ka{};
+  if (!backward) { ka.Gin = b; ka.K = d; ka.Gout = a; ka.N = c; }
+  else { ka.Gin = a; ka.K = c; ka.Gout = b; ka.N = d; }
+  ka.gat = make_gather(backward ? 2 : 1, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
+  KconvGeom gm{};
+  int mi, ni, ks;
+  return plan_kconv(ka, B, gm, mi, ni, ks) ? mi : 0;  // != 0: covered; the value is the row tile (64 * value stage-1 rows per workgroup)
+}
+
+int lyc_lokr_conv2d_fwd_planes(const void* x_rows, const float* w1, const void* planes_fwd, void* y_rows, int64_t B, int64_t H,
+                               int64_t W, int a, int b, int c, int d, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                               int dw, float alpha, int dtype, void* stream) {
+  if (!x_rows || !w1 || !planes_fwd || !y_rows) return fail(LYC_ERR_ARG, "lokr_conv2d_fwd_planes: null pointer");
+  ConvDims cd{};
+  if (int rc = lokr_conv_check(cd, B, H, W, a, b, c, d, kh, kw, sh, sw, ph, pw, dh, dw, dtype, x_rows, y_rows)) return rc;
+  if (B == 0) return LYC_OK;
+  KronArgs ka{};
+  ka.x = x_rows; ka.y = y_rows; ka.w1 = w1;
+  ka.M = B * cd.Ho * cd.Wo; ka.Gin = b; ka.K = d; ka.Gout = a; ka.N = c;
+  ka.s1o = b; ka.s1i = 1; ka.alpha = alpha;
+  ka.gat = make_gather(1, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
+  const long n = (dtype & 0xff) == LYC_BF16 ? launch_kconv<__bf16>(ka, planes_fwd, B, (hipStream_t)stream)
+                                            : launch_kconv<_Float16>(ka, planes_fwd, B, (hipStream_t)stream);
+  if (n < 0) return fail(LYC_ERR_UNSUPPORTED, "lokr_conv2d_fwd_planes: geometry outside the patch kernel (see lyc_lokr_conv2d_planes_ok)");
+  return check_launch("lokr_conv2d_fwd_planes");
+}
+
+int lyc_lokr_conv2d_bwd_planes(const void* g_rows, const void* x_rows, const float* w1, const float* w2p, const void* planes_bwd,
+                               void* dx_rows, float* dw1, float* dw2p, void* ws, int64_t B, int64_t H, int64_t W, int a, int b,
+                               int c, int d, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float alpha, int dtype,
+                               void* stream) {
+  if (!planes_bwd) return fail(LYC_ERR_ARG, "lokr_conv2d_bwd_planes: null planes");
+  return lokr_conv2d_bwd_impl(g_rows, x_rows, w1, w2p, nullptr, planes_bwd, dx_rows, dw1, dw2p, ws, B, H, W, a, b, c, d, kh, kw, sh, sw,
+                              ph, pw, dh, dw, alpha, dtype, stream);
 }
 
 int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1, const float* w2p, const float* w2t,
                         void* dx_rows, float* dw1, float* dw2p, void* ws, int64_t B, int64_t H, int64_t W, int a, int b, int c, int d,
                         int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float alpha, int dtype,
                         void* stream) {
-  if (!g_rows || !x_rows || !w1 || !w2p) return fail(LYC_ERR_ARG, "lokr_conv2d_bwd: null pointer");
+  return lokr_conv2d_bwd_impl(g_rows, x_rows, w1, w2p, w2t, nullptr, dx_rows, dw1, dw2p, ws, B, H, W, a, b, c, d, kh, kw, sh, sw, ph,
+                              pw, dh, dw, alpha, dtype, stream);
+}
+
+extern "C++" {
+namespace {
+int lokr_conv2d_bwd_impl(const void* g_rows, const void* x_rows, const float* w1, const float* w2p, const float* w2t,
+                         const void* planes_bwd, void* dx_rows, float* dw1, float* dw2p, void* ws, int64_t B, int64_t H, int64_t W,
+                         int a, int b, int c, int d, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, float alpha,
+                         int dtype, void* stream) {
+  if (!g_rows || !x_rows || !w1 || (!w2p && !planes_bwd)) return fail(LYC_ERR_ARG, "lokr_conv2d_bwd: null pointer");
   ConvDims cd{};
   if (int rc = lokr_conv_check(cd, B, H, W, a, b, c, d, kh, kw, sh, sw, ph, pw, dh, dw, dtype, x_rows, g_rows)) return rc;
   if (dw1 && !dx_rows) return fail(LYC_ERR_ARG, "lokr_conv2d_bwd: dw1 requires dx (they share one pass over g)");
@@ -784,12 +992,20 @@ int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1,
     ka.M = B * H * W; ka.Gin = a; ka.K = c; ka.Gout = b; ka.N = d;
     ka.s1o = 1; ka.s1i = b; ka.s2n = 1; ka.s2k = (long)cd.taps * d; ka.alpha = alpha;
     ka.gat = make_gather(2, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
-    if (w2t && sh == 1 && sw == 1 && cd.taps <= 64) {
-      // stride 1: the source pixel of tap t is base - offset[t], so K can run over the flat (tap, q) index with full
-      // segments; that needs the factor as [taps, c, d]: element (n = v, k = t*c + q) at w2t[k * d + v]
-      ka.w2 = w2t; ka.s2n = 1; ka.s2k = d; ka.gat.flat = 1;
+    long nblk = -1;
+    if (planes_bwd) {  // LDS source patch + pre-packed operand planes (kron_conv.h)
+      nblk = bf ? launch_kconv<__bf16>(ka, planes_bwd, B, st) : launch_kconv<_Float16>(ka, planes_bwd, B, st);
+      if (nblk < 0 && !w2p)
+        return fail(LYC_ERR_UNSUPPORTED, "lokr_conv2d_bwd_planes: geometry outside the patch kernel (see lyc_lokr_conv2d_planes_ok)");
     }
-    const long nblk = bf ? launch_kron3<__bf16>(ka, st) : launch_kron3<_Float16>(ka, st);
+    if (nblk < 0) {
+      if (w2t && sh == 1 && sw == 1 && cd.taps <= 64) {
+        // stride 1: the source pixel of tap t is base - offset[t], so K can run over the flat (tap, q) index with full
+        // segments; that needs the factor as [taps, c, d]: element (n = v, k = t*c + q) at w2t[k * d + v]
+        ka.w2 = w2t; ka.s2n = 1; ka.s2k = d; ka.gat.flat = 1;
+      }
+      nblk = bf ? launch_kron3<__bf16>(ka, st) : launch_kron3<_Float16>(ka, st);
+    }
     if (int rc = check_launch("lokr_conv2d_bwd(dx)")) return rc;
     if (ka.dw1_ws) dw1_partials = nblk;
   }
@@ -806,11 +1022,108 @@ int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1,
     if (bf) launch_dw2s<__bf16>(da, st);
     else launch_dw2s<_Float16>(da, st);
     if (int rc = check_launch("lokr_conv2d_bwd(dw2)")) return rc;
-  } else if (dw1_partials > 0) {
+  } else if (dw1_partials > 0 && !(dtype & LYC_DEFER_WGRAD)) {  // deferred: lyc_lokr_conv_wgrad_group reduces the partials
     long r = dw1_partials / 64;
     ra.dw1_red = (int)(r > 16 ? 16 : r < 1 ? 1 : r);
     hipLaunchKernelGGL(kron_dw1_reduce_kernel, dim3((unsigned)ra.dw1_red), dim3(NTHREADS), 0, st, ra);
     if (int rc = check_launch("lokr_conv2d_bwd(dw1 reduce)")) return rc;
+  }
+  return LYC_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+// ---- deferred, grouped weight gradients of the implicit Conv2d form (kron_dw2s_conv_group_kernel) ---------------------------
+extern "C++" {
+namespace {
+template <typename T, int MI, int NJ, int U>
+void launch_dw2s_conv_group(const KronDw2sConvGroupArgs& ga, hipStream_t st) {
+  hipLaunchKernelGGL((kron_dw2s_conv_group_kernel<T, MI, NJ, U>), dim3((unsigned)ga.wg_end[ga.n - 1]), dim3(NTHREADS), 0, st, ga);
+}
+}  // namespace
+}  // extern "C++"
+
+int64_t lyc_lokr_conv2d_dx_blocks(int64_t B, int64_t H, int64_t W, int a, int b, int c, int d, int kh, int kw, int sh, int sw, int ph,
+                                  int pw, int dh, int dw, int dtype, int with_planes) {
+  // number of [a*b] dw1 partials the dx launch of lyc_lokr_conv2d_bwd / _bwd_planes leaves in `ws` (its workgroup count)
+  ConvDims cd{};
+  if (B < 1 || a != b || a < 1) return 0;
+  cd.Ho = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1;
+  cd.Wo = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
+  cd.taps = kh * kw;
+  KronArgs ka{};
+  ka.M = B * H * W; ka.Gin = a; ka.K = c; ka.Gout = b; ka.N = d;
+  ka.gat = make_gather(2, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
+  if (with_planes) {
+    KconvGeom gm{};
+    int mi, ni, ks;
+    if (plan_kconv(ka, B, gm, mi, ni, ks)) return (int64_t)B * gm.tiles_h * gm.tiles_w * cdiv(ka.N, 16 * ni);
+  }
+  (void)dtype;
+  return (int64_t)cdiv(ka.M, K3_RT / ka.Gin) * cdiv(ka.N, 16 * kron3_pick_ni(ka));
+}
+
+int lyc_lokr_conv_wgrad_group(const LycLokrConvWgradItem* items, int n, int dtype, void* stream) {
+  if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "lokr_conv_wgrad_group: bad item list");
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = dtype & 0xff;
+  if (n > 0 && dt != LYC_BF16 && dt != LYC_F16) return fail(LYC_ERR_UNSUPPORTED, "lokr_conv_wgrad_group: 16-bit activations only");
+  const bool batch = n >= 4;  // a few conv layers already fill the chip (their row counts are 8 x those of the Linear layers)
+  for (int cfg = 0; cfg < DW2_NCFG; ++cfg) {
+    KronDw2sConvGroupArgs ga{};
+    auto flush = [&]() -> int {
+      if (ga.n == 0) return LYC_OK;
+      for (int i = 0; i < ga.n; ++i)
+        for (int j = 0; j < i; ++j)
+          if (ga.p[i].it.out == ga.p[j].it.out || (ga.p[i].it.dw1 && ga.p[i].it.dw1 == ga.p[j].it.dw1))
+            ga.p[i].it.force_atomic = ga.p[j].it.force_atomic = 1;
+      if (dt == LYC_BF16) {
+        if (cfg == DW2_T44) launch_dw2s_conv_group<__bf16, 4, 4, 1>(ga, st);
+        else if (cfg == DW2_T52) launch_dw2s_conv_group<__bf16, 5, 2, 1>(ga, st);
+        else launch_dw2s_conv_group<__bf16, 2, 2, LYC_WG_U>(ga, st);
+      } else {
+        if (cfg == DW2_T44) launch_dw2s_conv_group<_Float16, 4, 4, 1>(ga, st);
+        else if (cfg == DW2_T52) launch_dw2s_conv_group<_Float16, 5, 2, 1>(ga, st);
+        else launch_dw2s_conv_group<_Float16, 2, 2, LYC_WG_U>(ga, st);
+      }
+      ga = KronDw2sConvGroupArgs{};
+      return check_launch("lokr_conv_wgrad_group");
+    };
+    for (int k = 0; k < n; ++k) {
+      const LycLokrConvWgradItem& it = items[k];
+      ConvDims cd{};
+      if (cfg == 0) {
+        if (!it.g_rows || !it.x_rows || !it.w1 || !it.dw2p) return fail(LYC_ERR_ARG, "lokr_conv_wgrad_group: item %d: null pointer", k);
+        if (it.dw1 && (!it.ws || it.dw1_blocks < 1)) return fail(LYC_ERR_ARG, "lokr_conv_wgrad_group: item %d: dw1 needs ws and dw1_blocks", k);
+      }
+      if (int rc = lokr_conv_check(cd, it.B, it.H, it.W, it.a, it.b, it.c, it.d, it.kh, it.kw, it.sh, it.sw, it.ph, it.pw, it.dh, it.dw, dtype,
+                                   it.x_rows, it.g_rows))
+        return rc;
+      KronDw2sArgs da{};
+      da.Q = it.g_rows; da.P = it.x_rows; da.W = it.w1; da.out = it.dw2p; da.M = it.B * cd.Ho * cd.Wo; da.G = it.a; da.I = it.c;
+      da.J = cd.taps * it.d; da.Jt = it.d; da.ws = it.b; da.wt = 1; da.os = (long)cd.taps * it.d; da.alpha = it.alpha;
+      da.gat = make_gather(1, cd, it.H, it.W, it.kw, it.sh, it.sw, it.ph, it.pw, it.dh, it.dw, it.d);
+      if (it.dw1) {
+        da.dw1_ws = static_cast<const float*>(it.ws); da.dw1 = it.dw1; da.dw1_n = it.a * it.b; da.dw1_nblk = (int)it.dw1_blocks;
+        da.dw1_red = 1;
+      }
+      if (plan_dw2s(da, batch) != cfg) continue;
+      const long wgs = round_up((long)da.tiles_i * da.tiles_j * da.nsplit, 8) + round_up(da.dw1_ws ? da.dw1_red : 0, 8);
+      const long before = ga.n ? ga.wg_end[ga.n - 1] : 0;
+      if (ga.n == DW2GC_MAX || before + wgs > (1L << 30))
+        if (int rc = flush()) return rc;
+      KronDw2sConvItem& ci = ga.p[ga.n];
+      KronDw2sItem& q = ci.it;
+      q.Q = da.Q; q.P = da.P; q.W = da.W; q.out = da.out; q.dw1_ws = da.dw1_ws; q.dw1 = da.dw1; q.M = da.M;
+      q.rows_per_block = da.rows_per_block; q.G = da.G; q.I = da.I; q.J = da.J; q.nsplit = da.nsplit;
+      q.tiles_i = da.tiles_i; q.tiles_j = da.tiles_j; q.dw1_nblk = da.dw1_nblk; q.dw1_n = da.dw1_n; q.dw1_red = da.dw1_red;
+      q.ws = (int)da.ws; q.wt = (int)da.wt; q.os = (int)da.os; q.alpha = da.alpha; q.force_atomic = 0;
+      ci.gat = da.gat;
+      ci.Jt = da.Jt;
+      ga.wg_end[ga.n] = (int)((ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs);
+      ++ga.n;
+    }
+    if (int rc = flush()) return rc;
   }
   return LYC_OK;
 }

@@ -1,0 +1,406 @@
+// kron_conv.h -- LoKr on nn.Conv2d, activation path (forward and backward-dx / dW1), gfx950.  Round 3.
+//
+// The round-2 implicit-GEMM kernels (kron3.h, GM = 1 / 2) fetched every MFMA A fragment straight from HBM / L2: each
+// source pixel row was read once per tap (9x for a 3x3 window) as 16-byte pieces of 16 different pixel rows per
+// instruction, and every workgroup converted its fp32 w2 tile to hi/lo 16-bit planes by itself (49 conv layers = 31 % of the
+// SDXL LoKr step at 2.4 % of the HBM roofline).  This kernel changes both ends:
+//
+//   * SOURCE PATCH IN LDS.  A workgroup owns a TH x TW tile of destination pixels (64 MI stage-1 rows = pixels x groups, MI = 2 /
+//     4 / 8 chosen by the host: the operand planes are re-streamed per workgroup, so their traffic goes with 1 / MI) and
+//     loads the (TH-1)*s + (kh-1)*dil + 1 rows of source pixels it touches ONCE, with full 16-byte coalesced loads along
+//     the NHWC channel dimension, into LDS (zero-filled outside the image: no masks in the main loop).  The A fragment of
+//     (pixel, group u, tap, k) is then one ds_read_b128 at  patch[(py + tap_dy) * PW + px + tap_dx][u][k].
+//     Layout: [patch pixel][group u][K + pad]: the pad makes the group pitch an ODD number of 16-byte slots, so the 16 rows
+//     of a fragment (2 pixels x 8 groups for factor 8) fall into 16 different slots of the 256-byte bank row.
+//   * PRE-PACKED OPERAND PLANES.  w2 is a parameter: it changes once per optimizer step, not per workgroup.  A small pack
+//     kernel (kron_pack_kernel below) writes it as hi + lo planes in the activation dtype in FRAGMENT-MAJOR order
+//     [n tile][k step][hi | lo][lane][8]: the B fragment of a k step is 1 KiB of contiguous memory.  The conv kernel
+//     streams those units into a two-stage LDS ring with global_load_lds (LDS-DMA: no registers, no conversion
+//     instructions, no ds_write) and reads them back conflict-free as lane-linear ds_read_b128.
+//
+// Stage 2 (the G x G mix with w1), the fused dW1 partials and the stores are kron3.h's register epilogue.
+// Reference math: lycoris/functional/lokr.py:195-247 (conv branch of bypass_forward_diff), modules/lokr.py:358-381.
+#pragma once
+#include "kron3.h"
+
+namespace lyc {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Packed operand planes
+// ---------------------------------------------------------------------------------------------------------------------
+// One "role" = the B operand of one stage-1 contraction:  B[n][k],  n < N,  k = tap * Kt + kk  (kk < Kt, Kt % 8 == 0)
+//   forward role : n = q (w2 rows, N = c),    kk = v (Kt = d)      B = w2[q, v, tap]
+//   backward role: n = v (w2 columns, N = d), kk = q (Kt = c)      B = w2[q, v, tap]
+// stored as units of 2 KiB: unit (nt, ks) = {hi[64 lanes][8], lo[64 lanes][8]}, lane (li, g) element e <-> n = 16 nt + li,
+// k = 32 ks + 8 g + e; zero outside [N) x [taps * Kt).  Units are ordered ks-major inside an n tile.
+__host__ __device__ inline long kron_plane_ksteps(int taps, int Kt) { return ((long)taps * Kt + 31) / 32; }
+__host__ __device__ inline long kron_plane_bytes(int N, int taps, int Kt) {
+  return (long)((N + 15) / 16) * kron_plane_ksteps(taps, Kt) * 2048;
+}
+
+struct KronPackArgs {
+  const float* w2;      // full matrix: element (q, v, tap) at q * sq + v * sv + tap * st      (nullptr: low-rank product)
+  long sq, sv, st;
+  const float* w2a;     // low-rank: w2[q, v, tap] = sum_r w2a[q * a_sq + r * a_sr] * w2b[r * b_sr + v * b_sv + tap * b_st]
+  const float* w2b;
+  long a_sq, a_sr, b_sr, b_sv, b_st;
+  int rank;
+  int c, d, taps;
+  void* fwd;            // kron_plane_bytes(c, taps, d) bytes, or nullptr
+  void* bwd;            // kron_plane_bytes(d, taps, c) bytes, or nullptr
+  long units_fwd;       // units of the forward role (the grid covers units_fwd + units_bwd units, 4 per workgroup)
+};
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void kron_pack_kernel(KronPackArgs a) {
+  const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
+  long unit = (long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
+  const bool fwd = unit < a.units_fwd;
+  if (!fwd) unit -= a.units_fwd;
+  char* plane = static_cast<char*>(fwd ? a.fwd : a.bwd);
+  if (plane == nullptr) return;
+  const int N = fwd ? a.c : a.d, Kt = fwd ? a.d : a.c;
+  const long KS = kron_plane_ksteps(a.taps, Kt);
+  const long nunits = (long)((N + 15) / 16) * KS;
+  if (unit >= nunits) return;
+  const int nt = (int)(unit / KS), ks = (int)(unit - (long)nt * KS);
+  const int n = 16 * nt + li;
+  const long k0 = 32L * ks + 8 * g;  // the 8 elements share one tap (Kt % 8 == 0)
+  const int tap = (int)(k0 / Kt);
+  const int kk0 = (int)(k0 - (long)tap * Kt);
+  T h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = 0.f;
+    if (n < N && tap < a.taps) {
+      const int q = fwd ? n : kk0 + e, vv = fwd ? kk0 + e : n;
+      if (a.w2 != nullptr) {
+        v = a.w2[q * a.sq + vv * a.sv + tap * a.st];
+      } else {
+        for (int r = 0; r < a.rank; ++r)
+          v = fmaf(a.w2a[q * a.a_sq + r * a.a_sr], a.w2b[r * a.b_sr + vv * a.b_sv + tap * a.b_st], v);
+      }
+    }
+    split_f<T>(v, h[e], l[e]);
+  }
+  *reinterpret_cast<u32x4*>(plane + unit * 2048 + lane * 16) = *reinterpret_cast<u32x4*>(h);
+  *reinterpret_cast<u32x4*>(plane + unit * 2048 + 1024 + lane * 16) = *reinterpret_cast<u32x4*>(l);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Conv kernel
+// ---------------------------------------------------------------------------------------------------------------------
+struct KconvGeom {      // host-computed (capi.hip: plan_kconv)
+  int TH, TW;           // destination tile (TH * TW * G == 64 MI rows)
+  int PH, PW;           // source patch
+  int tiles_h, tiles_w; // tiles per image
+  int GP, CP;           // LDS pitch (elements) of a group segment / a patch pixel
+  int sy, sx;           // destination -> patch step (stride for the forward, 1 for the backward)
+  int oy0, ox0;         // patch origin = tile origin * s + o0 (source coordinates)
+  int kss;              // k steps per LDS stage of the B ring
+  int patch_bytes;      // PH * PW * CP * 2, rounded up to 1 KiB
+};
+
+constexpr int KC_ZERO_BYTES = 16;  // a 16-byte slot of zeros behind the patch (fragments of the K padding read it)
+
+__host__ __device__ inline int kconv_stage_bytes(int NI, int kss) { return NI * kss * 2048; }
+__host__ __device__ inline int kconv_lds_bytes(int NI, const KconvGeom& gm) {
+  const int ring = 2 * kconv_stage_bytes(NI, gm.kss);
+  return gm.patch_bytes + 1024 + (ring > 4096 ? ring : 4096);
+}
+
+// kron3.h's register epilogue for a caller that supplies the row bookkeeping: stage 2 on the matrix cores, optional fused
+// `base + delta`, optional dW1 partial (per-workgroup block of a.dw1_ws, or atomics).
+//   row_ok[mi], rofs[mi]: validity and element offset (into y / xref / base) of this lane's output row 16 mi + li of the wave
+//   (MI 16-row tiles per wave: the workgroup owns 64 MI stage-1 rows)
+template <typename T, int MI, int NI, bool WITH_DW1>
+__device__ __forceinline__ void k3_epilogue_rows(const KronArgs& a, char* red_smem, f32x4 (&acc)[MI][NI], const float (&w1raw)[4],
+                                                 const bool (&row_ok)[MI], const long (&rofs)[MI], long n0, long wg_index) {
+  using F4 = typename Mma16<T>::frag;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int G = a.Gin, N = a.N;
+  const int lg = 31 - __builtin_clz((unsigned)G);
+  F4 a2h, a2l;
+  {
+    T h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_f<T>(w1raw[j], h[j], l[j]);
+    a2h = *reinterpret_cast<F4*>(h);
+    a2l = *reinterpret_cast<F4*>(l);
+  }
+  F4 ident;
+  {
+    T idv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) idv[e] = TT<T>::from_f((4 * g + e) == li ? 1.f : 0.f);
+    ident = *reinterpret_cast<F4*>(idv);
+  }
+  const bool y_vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 7u) == 0);
+  const bool xr_vec = WITH_DW1 && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.xref) & 7u) == 0);
+  f32x4 cdw = zero4();
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const long gn = n0 + 16 * ni + 4 * g;
+      T h[4], l[4];
+      k3_split4<T>(acc[mi][ni], h, l);
+      const F4 sh = *reinterpret_cast<F4*>(h), sl = *reinterpret_cast<F4*>(l);
+      f32x4 yv = zero4();
+      yv = Mma16<T>::mma(sh, a2h, yv);
+      yv = Mma16<T>::mma(sl, a2h, yv);
+      yv = Mma16<T>::mma(sh, a2l, yv);
+      if (row_ok[mi] && gn < N) {
+        T* dst = static_cast<T*>(a.y) + rofs[mi] + gn;
+        T o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = TT<T>::from_f(a.alpha * yv[e]);
+        if (y_vec && gn + 4 <= N) {
+          *reinterpret_cast<u32x2*>(dst) = *reinterpret_cast<u32x2*>(o);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gn + e < N) dst[e] = o[e];
+        }
+      }
+      if constexpr (WITH_DW1) {
+        const f32x4 th = Mma16<T>::mma(sh, ident, zero4());
+        const f32x4 tl = Mma16<T>::mma(sl, ident, zero4());
+        T thv[4], tlv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          thv[e] = TT<T>::from_f(th[e]);
+          tlv[e] = TT<T>::from_f(tl[e]);
+        }
+        const T* xr = static_cast<const T*>(a.xref) + rofs[mi] + gn;
+        T bv[4];
+        if (xr_vec) {
+          const bool ok = row_ok[mi] && gn < N;  // gn + 4 <= N or gn >= N
+          const u32x2 z = {0u, 0u};
+          const u32x2 v = *reinterpret_cast<const u32x2*>(ok ? xr : static_cast<const T*>(a.xref));
+          *reinterpret_cast<u32x2*>(bv) = ok ? v : z;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[e] = (row_ok[mi] && gn + e < N) ? xr[e] : TT<T>::from_f(0.f);
+        }
+        const F4 bf = *reinterpret_cast<F4*>(bv);
+        cdw = Mma16<T>::mma(*reinterpret_cast<F4*>(thv), bf, cdw);
+        cdw = Mma16<T>::mma(*reinterpret_cast<F4*>(tlv), bf, cdw);
+      }
+    }
+  }
+  if constexpr (WITH_DW1) {
+    float* red = reinterpret_cast<float*>(red_smem);
+    __syncthreads();  // other waves may still read the last B stage
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * g + r) * 16 + li] = cdw[r];
+    __syncthreads();
+    if (tid < G * G) {
+      const int u = tid >> lg, po = tid & (G - 1);
+      float s = 0.f;
+      for (int b = 0; b < (16 >> lg); ++b) {
+        const int e = ((b << lg) + u) * 16 + (b << lg) + po;
+        s += red[e] + red[256 + e] + red[512 + e] + red[768 + e];
+      }
+      const long e = (long)po * a.s1o + (long)u * a.s1i;
+      if (a.dw1_ws != nullptr)
+        a.dw1_ws[wg_index * (G * G) + e] = a.alpha * s;
+      else
+        __hip_atomic_fetch_add(a.dw1 + e, a.alpha * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+struct KconvArgs {
+  KronArgs k;          // x = source rows [B * Hs * Ws, G * K], y = destination rows [B * Hd * Wd, G * N]; w2 unused
+  const void* planes;  // packed role planes: ceil(N / 16) n tiles x ksteps units
+  KconvGeom gm;
+  int ksteps;          // k steps of 32 over the flat (tap, k) index
+};
+
+template <typename T, int MI, int NI, bool WITH_DW1>
+__global__ __launch_bounds__(NTHREADS) void kconv_kernel(KconvArgs ca) {
+  extern __shared__ __attribute__((aligned(1024))) char kc_smem[];
+  const KronArgs& a = ca.k;
+  const KconvGeom& gm = ca.gm;
+  using F8 = typename TT<T>::frag;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int G = a.Gin, K = a.K, N = a.N;
+  const int lg = 31 - __builtin_clz((unsigned)G);
+  const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+  const long n0 = (long)by * (16 * NI);
+
+  // ---- tile -> (image, tile row, tile column) -------------------------------------------------------------------------
+  const int tpi = gm.tiles_h * gm.tiles_w;
+  const int img = bx / tpi;
+  const int trem = bx - img * tpi;
+  const int th = trem / gm.tiles_w, tw = trem - th * gm.tiles_w;
+  const int hd0 = th * gm.TH, wd0 = tw * gm.TW;          // destination tile origin
+  const int hs0 = hd0 * gm.sy + gm.oy0, ws0 = wd0 * gm.sx + gm.ox0;  // patch origin in the source image (may be negative)
+
+  char* zero_slot = kc_smem + gm.patch_bytes;
+  char* ring = kc_smem + gm.patch_bytes + 1024;
+  const int stage_bytes = kconv_stage_bytes(NI, gm.kss);
+
+  // ---- B ring: stage s = k steps [s * kss, (s + 1) * kss) of the NI n tiles, unit (ni, kk) at ((ni * kss + kk) * 2048) ------
+  const char* planes = static_cast<const char*>(ca.planes);
+  const int nstage = (ca.ksteps + gm.kss - 1) / gm.kss;
+  const int ntiles_n = (N + 15) / 16;
+  auto issue_stage = [&](int s, char* buf) {
+    // NI * kss units of 2 KiB = 2 * NI * kss pieces of 1 KiB; piece p -> wave p % 4 (wave-uniform loop)
+    const int npiece = 2 * NI * gm.kss;
+    for (int p = wave; p < npiece; p += NWAVES) {
+      const int unit = p >> 1, half = p & 1;
+      const int ni = unit / gm.kss, kk = unit - ni * gm.kss;
+      const int ks = s * gm.kss + kk;
+      long nt = n0 / 16 + ni;
+      if (nt >= ntiles_n) nt = ntiles_n - 1;  // column tile beyond N: a valid duplicate (its results are never stored; finite
+                                              // values keep the dW1 partial, which multiplies them by zeros, finite)
+      if (ks < ca.ksteps) {
+        const char* src = planes + ((nt * ca.ksteps + ks) * 2 + half) * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(buf + p * 1024), 16, 0, 0);
+      }
+    }
+  };
+  issue_stage(0, ring);
+
+  // ---- w1 block operand and tap table -------------------------------------------------------------------------------------
+  float w1raw[4];
+  {
+    const int mi_ = li >> lg, po = li & (G - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kk = 4 * g + j;
+      const float v = a.w1[po * a.s1o + (kk & (G - 1)) * a.s1i];
+      w1raw[j] = ((kk >> lg) == mi_) ? v : 0.f;
+    }
+  }
+  // (inside the one dynamic LDS array: a second __shared__ object makes hipcc wait vmcnt(0) before every ds_read that follows
+  // an LDS-DMA, i.e. it would serialise the ring -- cdna_hip_programming.md 5, trap 4a)
+  int* kc_tapoff = reinterpret_cast<int*>(zero_slot + 64);
+  if (tid < a.gat.taps) {
+    const int kh = a.gat.taps / a.gat.kw;
+    const int i = tid / a.gat.kw, j = tid - i * a.gat.kw;
+    // forward: the source of tap (i, j) is patch (py + i dh, px + j dw); backward (stride 1): (py + (kh-1-i) dh, px + (kw-1-j) dw)
+    const int oi = a.gat.mode == 1 ? i * a.gat.dh : (kh - 1 - i) * a.gat.dh;
+    const int oj = a.gat.mode == 1 ? j * a.gat.dw : (a.gat.kw - 1 - j) * a.gat.dw;
+    kc_tapoff[tid] = (oi * gm.PW + oj) * gm.CP * (int)sizeof(T);
+  }
+  if (tid < 4) reinterpret_cast<uint32_t*>(zero_slot)[tid] = 0u;
+
+  // ---- source patch: HBM -> LDS by LDS-DMA (buffer_load ... lds), every piece in flight at once ---------------------------------
+  // One wave instruction fills 1 KiB of the patch image: lane l supplies the global address of the 16 bytes that belong at
+  // (piece base + 16 l) -- a slot of [patch pixel][group u][GP] -- through a buffer descriptor of THIS image, so slots outside
+  // the image (zero padding), in the group-pitch padding or beyond the patch get an out-of-range offset and the hardware
+  // writes zeros.  No staging registers, no ds_write, and -- what the first version of this kernel lacked (38 us per launch
+  // with 4 loads in flight per wave) -- the whole patch is requested before anything waits.
+  {
+    const T* x = static_cast<const T*>(a.x);
+    const int vpp = (G * K) / 8;            // 16-byte vectors of real data per pixel
+    const int kv = K / 8;                    // ... per group segment
+    const int spg = gm.GP / 8;               // 16-byte slots per group segment (kv, or kv + 1 with the pad)
+    const int spp = G * spg;                 // slots per patch pixel
+    const int npix = gm.PH * gm.PW;
+    const long img_elems = (long)a.gat.Hs * a.gat.Ws * G * K;  // < 2^30 elements (host check)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x + (long)img * img_elems), 0,
+                                                                        (int)(img_elems * (long)sizeof(T)), 0x00020000);
+    const float inv_spp = 1.0f / (float)spp, inv_spg = 1.0f / (float)spg, inv_pw = 1.0f / (float)gm.PW;
+    const int OOR = 0x7ffffff0;
+    const int npiece = gm.patch_bytes >> 10;
+    for (int pc = wave; pc < npiece; pc += NWAVES) {
+      const int sl = pc * 64 + lane;  // slot index in the patch image
+      int pp = (int)(((float)sl + 0.5f) * inv_spp);
+      int q = sl - pp * spp;
+      if (q < 0) { q += spp; --pp; }
+      if (q >= spp) { q -= spp; ++pp; }
+      int u = (int)(((float)q + 0.5f) * inv_spg);
+      int kq = q - u * spg;
+      if (kq < 0) { kq += spg; --u; }
+      if (kq >= spg) { kq -= spg; ++u; }
+      int py = (int)(((float)pp + 0.5f) * inv_pw);
+      int px = pp - py * gm.PW;
+      if (px < 0) { px += gm.PW; --py; }
+      if (px >= gm.PW) { px -= gm.PW; ++py; }
+      const int hs = hs0 + py, ws = ws0 + px;
+      const bool ok = pp < npix && kq < kv && hs >= 0 && hs < a.gat.Hs && ws >= 0 && ws < a.gat.Ws;
+      const int off = ok ? ((hs * a.gat.Ws + ws) * vpp + u * kv + kq) * 16 : OOR;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(kc_smem + pc * 1024), 16, off, 0, 0, 0);
+    }
+  }
+
+  // ---- this lane's two stage-1 rows: local pixel (ly, lx), group u; byte offset of (pixel, u) in the patch ----------------
+  int rowbase[MI];
+  bool row_ok[MI];
+  long rofs[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int r = wave * (16 * MI) + mi * 16 + li;  // local stage-1 row
+    const int lp = r >> lg, u = r & (G - 1);
+    const int ly = lp / gm.TW, lx = lp - ly * gm.TW;
+    rowbase[mi] = ((ly * gm.sy * gm.PW + lx * gm.sx) * gm.CP + u * gm.GP) * (int)sizeof(T);
+    const int hd = hd0 + ly, wd = wd0 + lx;
+    row_ok[mi] = hd < a.gat.Hd && wd < a.gat.Wd;
+    const long dpix = ((long)img * a.gat.Hd + hd) * a.gat.Wd + wd;
+    rofs[mi] = dpix * ((long)G * N) + (long)u * N;
+  }
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = zero4();
+
+  const int Kflat = a.gat.taps * K;
+  const float inv_k = 1.0f / (float)K;
+  const int zero_ofs = gm.patch_bytes;  // byte offset of the zero slot from the patch base
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage 0 has landed (LDS-DMA counts on vmcnt)
+  __syncthreads();  // patch, tap table, zero slot, stage 0
+
+  for (int s = 0; s < nstage; ++s) {
+    char* buf = ring + (s & 1) * stage_bytes;
+    if (s + 1 < nstage) issue_stage(s + 1, ring + ((s + 1) & 1) * stage_bytes);
+    const int ks_lo = s * gm.kss;
+    const int nk = (ca.ksteps - ks_lo) < gm.kss ? (ca.ksteps - ks_lo) : gm.kss;
+    // one k step: A fragments from the patch, B fragments from the ring, 4 NI MFMAs
+    auto kstep = [&](int kk, int kss_) {
+      const int k = 32 * (ks_lo + kk) + 8 * g;  // this lane's 8 flat k (one tap: K % 8 == 0)
+      int tap = (int)(((float)k + 0.5f) * inv_k);
+      int v = k - tap * K;
+      if (v < 0) { v += K; --tap; }
+      if (v >= K) { v -= K; ++tap; }
+      const bool kok = k < Kflat;
+      const int toff = kc_tapoff[kok ? tap : 0] + v * (int)sizeof(T);
+      F8 af[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const F8*>(kc_smem + (kok ? rowbase[mi] + toff : zero_ofs));
+      F8 bh[NI], bl[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const char* up = buf + (ni * kss_ + kk) * 2048 + lane * 16;
+        bh[ni] = *reinterpret_cast<const F8*>(up);
+        bl[ni] = *reinterpret_cast<const F8*>(up + 1024);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT<T>::mma(af[mi], bh[ni], acc[mi][ni]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT<T>::mma(af[mi], bl[ni], acc[mi][ni]);
+    };
+    if (gm.kss == 4 && nk == 4) {  // the common case, straight-line: the fragment reads of step kk + 1 issue under the MFMAs of kk
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) kstep(kk, 4);
+    } else {
+      for (int kk = 0; kk < nk; ++kk) kstep(kk, gm.kss);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage s + 1 has landed
+    __syncthreads();  // ... everybody's has, and nobody still reads stage s's buffer
+  }
+
+  k3_epilogue_rows<T, MI, NI, WITH_DW1>(a, ring, acc, w1raw, row_ok, rofs, n0, (long)by * gridDim.x + bx);
+}
+
+}  // namespace lyc

@@ -425,6 +425,39 @@ struct KronDw2sGroupArgs {
 };
 static_assert(sizeof(KronDw2sGroupArgs) <= 3584, "kernel arguments are limited to 4 KiB");
 
+// The same for the implicit Conv2d form (GATHER kernels): the item also carries the window geometry, so fewer fit into the
+// 4 KiB of kernel arguments.  Round 3: the 38 3x3 convs of an SDXL step used to run one ~70-100 us launch each.
+constexpr int DW2GC_MAX = 14;
+struct KronDw2sConvItem {
+  KronDw2sItem it;
+  KronGather gat;
+  int Jt;
+};
+struct KronDw2sConvGroupArgs {
+  int n;
+  int wg_end[DW2GC_MAX];
+  KronDw2sConvItem p[DW2GC_MAX];
+};
+static_assert(sizeof(KronDw2sConvGroupArgs) <= 3584, "kernel arguments are limited to 4 KiB");
+
+template <typename T, int MI, int NJ, int U>
+__global__ __launch_bounds__(NTHREADS) void kron_dw2s_conv_group_kernel(KronDw2sConvGroupArgs ga) {
+  __shared__ __attribute__((aligned(16))) char smem[kron_dw2s_lds_bytes<MI, NJ>()];
+  const int b = (int)blockIdx.x;
+  int p = 0;
+  while (p + 1 < ga.n && b >= ga.wg_end[p]) ++p;
+  const int b0 = p ? ga.wg_end[p - 1] : 0;
+  const KronDw2sItem& it = ga.p[p].it;
+  KronDw2sArgs a{};
+  a.Q = it.Q; a.P = it.P; a.W = it.W; a.out = it.out; a.M = it.M; a.G = it.G; a.I = it.I; a.J = it.J;
+  a.ws = it.ws; a.wt = it.wt; a.os = it.os; a.rows_per_block = it.rows_per_block; a.nsplit = it.nsplit;
+  a.tiles_i = it.tiles_i; a.tiles_j = it.tiles_j; a.alpha = it.alpha; a.force_atomic = it.force_atomic;
+  a.dw1_ws = it.dw1_ws; a.dw1 = it.dw1; a.dw1_nblk = it.dw1_nblk; a.dw1_n = it.dw1_n; a.dw1_red = it.dw1_red;
+  a.gat = ga.p[p].gat;
+  a.Jt = ga.p[p].Jt;
+  kron_dw2s_body<T, MI, NJ, U, true>(a, smem, b - b0);
+}
+
 template <typename T, int MI, int NJ, int U>
 __global__ __launch_bounds__(NTHREADS) void kron_dw2s_group_kernel(KronDw2sGroupArgs ga) {
   __shared__ __attribute__((aligned(16))) char smem[kron_dw2s_lds_bytes<MI, NJ>()];

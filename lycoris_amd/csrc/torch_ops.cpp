@@ -90,11 +90,18 @@ struct Accum {
   std::unordered_map<const void*, int> uses;
 } g_accum;
 
+// torch::autograd::Function::apply runs forward() with grad mode OFF: whether a backward node is being built is only visible to
+// the wrapper that calls apply().  Every such wrapper records it here first (thread-local: apply() runs on the calling thread).
+thread_local bool tl_grad_at_apply = false;
+struct GradAtApply {
+  GradAtApply() { tl_grad_at_apply = c10::GradMode::is_enabled(); }
+};
+
 // true when the backward node of a layer call on activation `x` will accumulate into factor.grad and notify() for it
 // (the condition of grad_target() / finish_grad() below)
 bool will_report(const Tensor& factor, const Tensor& x, bool cl = false) {
   if (!g_accum.enabled || !g_accum.has_callback || !factor.defined() || !factor.is_leaf() || !factor.requires_grad()) return false;
-  if (!c10::GradMode::is_enabled() || !x.is_cuda()) return false;
+  if (!tl_grad_at_apply || !x.is_cuda()) return false;
   const c10::DispatchKeySet ks = x.key_set();
   if (ks.has(c10::DispatchKey::Python) || ks.has(c10::DispatchKey::Meta) || ks.has(c10::DispatchKey::Functionalize)) return false;
   const Tensor& gr = factor.grad();
@@ -190,6 +197,14 @@ struct DeferredLocon {
   void* stream;
   c10::DeviceIndex device;
 };
+struct DeferredLokrConv {
+  Tensor g_rows, x_rows, f1, w1, w2, dw1, dw2p, ws;  // dw2p: the window-major view of w2.grad
+  int64_t B, H, W, dw1_blocks;
+  int a, b, c, d, geom[8], code;
+  float alpha;
+  void* stream;
+  c10::DeviceIndex device;
+};
 struct DeferredLoha {
   Tensor g, x, f[4], p[4], d[4];  // f: fp32 contiguous factors, p: the parameters (for the sync callback), d: .grad targets
   int64_t M;
@@ -205,9 +220,10 @@ struct DeferredLists {
   std::vector<DeferredLokr> lokr;
   std::vector<DeferredLocon> locon;
   std::vector<DeferredLoha> loha;
+  std::vector<DeferredLokrConv> lokr_conv;
   bool callback_queued = false;
   int queued_task = -1;  // graph task the pending end-of-backward callback belongs to
-  size_t size() const { return lokr.size() + locon.size() + loha.size(); }
+  size_t size() const { return lokr.size() + locon.size() + loha.size() + lokr_conv.size(); }
 };
 constexpr int kMaxDevices = 64;
 struct Deferred {
@@ -235,15 +251,32 @@ void flush_deferred(c10::DeviceIndex device) {
   std::vector<DeferredLokr> items;
   std::vector<DeferredLocon> litems;
   std::vector<DeferredLoha> hitems;
+  std::vector<DeferredLokrConv> citems;
   {
     DeferredLists& L = lists_of(device);
     std::lock_guard<std::mutex> lock(L.mu);
     items.swap(L.lokr);
     litems.swap(L.locon);
     hitems.swap(L.loha);
+    citems.swap(L.lokr_conv);
     L.callback_queued = false;
   }
-  if (items.empty() && litems.empty() && hitems.empty()) return;
+  if (items.empty() && litems.empty() && hitems.empty() && citems.empty()) return;
+  for (size_t lo = 0; lo < citems.size();) {  // Conv2d LoKr layers: one call per (stream, dtype) run
+    size_t hi = lo + 1;
+    while (hi < citems.size() && citems[hi].stream == citems[lo].stream && citems[hi].code == citems[lo].code) ++hi;
+    std::vector<LycLokrConvWgradItem> raw(hi - lo);
+    for (size_t i = lo; i < hi; ++i) {
+      const DeferredLokrConv& it = citems[i];
+      raw[i - lo] = LycLokrConvWgradItem{cptr(it.g_rows), cptr(it.x_rows), cfp(it.f1), mfp(it.dw1), mfp(it.dw2p), mptr(it.ws), it.B, it.H,
+                                         it.W, it.dw1_blocks, it.a, it.b, it.c, it.d, it.geom[0], it.geom[1], it.geom[2], it.geom[3],
+                                         it.geom[4], it.geom[5], it.geom[6], it.geom[7], it.alpha};
+    }
+    const c10::DeviceGuard guard(c10::Device(c10::kCUDA, citems[lo].device));
+    check_rc(lyc_lokr_conv_wgrad_group(raw.data(), (int)raw.size(), citems[lo].code, citems[lo].stream), "lyc_lokr_conv_wgrad_group");
+    join_ambient(citems[lo].device, citems[lo].stream);
+    lo = hi;
+  }
   // one call per (device, stream, dtype) run of items, in arrival order
   for (size_t lo = 0; lo < items.size();) {
     size_t hi = lo + 1;
@@ -309,6 +342,10 @@ void flush_deferred(c10::DeviceIndex device) {
     if (it.dd.defined()) notify(it.down);
     if (it.du.defined()) notify(it.up);
   }
+  for (const DeferredLokrConv& it : citems) {
+    if (it.dw1.defined()) notify(it.w1);
+    notify(it.w2);
+  }
 }
 
 // called from a backward node (the engine has a current graph task: final callbacks may be installed)
@@ -335,6 +372,7 @@ void park_deferred_in(std::vector<Item> DeferredLists::*list, Item&& item) {
 void park_deferred(DeferredLokr&& item) { park_deferred_in(&DeferredLists::lokr, std::move(item)); }
 void park_deferred(DeferredLocon&& item) { park_deferred_in(&DeferredLists::locon, std::move(item)); }
 void park_deferred(DeferredLoha&& item) { park_deferred_in(&DeferredLists::loha, std::move(item)); }
+void park_deferred(DeferredLokrConv&& item) { park_deferred_in(&DeferredLists::lokr_conv, std::move(item)); }
 
 // =====================================================================================================================
 // LoKr on nn.Linear
@@ -456,6 +494,7 @@ struct LokrLinearFn : public torch::autograd::Function<LokrLinearFn> {
 };
 
 Tensor lokr_linear_autograd(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, const c10::optional<Tensor>& base) {
+  const GradAtApply ga_;
   return LokrLinearFn::apply(amp(x), w1, w2, alpha, base);
 }
 
@@ -568,6 +607,7 @@ struct LoconLinearFn : public torch::autograd::Function<LoconLinearFn> {
   }
 };
 Tensor locon_linear_autograd(const Tensor& x, const Tensor& down, const Tensor& up, double alpha) {
+  const GradAtApply ga_;
   return LoconLinearFn::apply(amp(x), down, up, alpha);
 }
 Tensor locon_linear_cuda(const Tensor& x, const Tensor& down, const Tensor& up, double alpha) {
@@ -707,6 +747,7 @@ struct LohaLinearFn : public torch::autograd::Function<LohaLinearFn> {
 };
 Tensor loha_linear_autograd(const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a, const Tensor& w2b,
                             double alpha) {
+  const GradAtApply ga_;
   return LohaLinearFn::apply(amp(x), w1a, w1b, w2a, w2b, alpha);
 }
 Tensor loha_linear_cuda(const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a, const Tensor& w2b, double alpha) {
@@ -815,6 +856,7 @@ struct ChanAffineFn : public torch::autograd::Function<ChanAffineFn> {
 };
 Tensor chan_affine_autograd(const Tensor& a, const Tensor& w, const c10::optional<Tensor>& bias, double s0, double mult,
                             int64_t chan_dim) {
+  const GradAtApply ga_;
   return ChanAffineFn::apply(amp(a), w, bias, s0, mult, chan_dim);
 }
 Tensor chan_affine_meta(const Tensor& a, const Tensor& w, const c10::optional<Tensor>& bias, double s0, double mult, int64_t chan_dim) {
@@ -1080,14 +1122,41 @@ struct LokrConv2dFn : public torch::autograd::Function<LokrConv2dFn> {
     TORCH_CHECK(C == b * d, "adapter expects ", b * d, " input channels, got ", x.sizes());
     Geom gm = geom_of({w2.size(2), w2.size(3)}, stride, padding, dilation, H, W);
     bool copied;
-    Tensor rows = rows_view(x, &copied), f1 = f32c(w1), w2p = f32c(w2.detach().permute({0, 2, 3, 1}));
+    Tensor rows = rows_view(x, &copied), f1 = f32c(w1);
     Tensor y = at::empty({B * gm.Ho * gm.Wo, a * c}, x.options());
-    check_rc(lyc_lokr_conv2d_fwd(cptr(rows), cfp(f1), cfp(w2p), mptr(y), B, H, W, (int)a, (int)b, (int)c, (int)d, gm.kh, gm.kw, gm.sh,
-                                 gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, (float)alpha, dtype_code(x.scalar_type()), stream_of(x)),
-             "lyc_lokr_conv2d_fwd");
+    const int code = dtype_code(x.scalar_type());
+    // Pre-packed operand planes + LDS source patch (csrc/kron_conv.h) where the geometry allows: ONE small pack launch writes
+    // w2 as hi / lo planes for the forward contraction and for the transposed one of the backward pass (kept for it), straight
+    // from the parameter's own memory layout -- no permuted fp32 copies of w2.
+    const bool pf = lyc_lokr_conv2d_planes_ok(B, H, W, (int)a, (int)b, (int)c, (int)d, gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh,
+                                              gm.dw, code, 0) != 0;
+    const bool pb = tl_grad_at_apply && (x.requires_grad() || w1.requires_grad() || w2.requires_grad()) &&
+                    lyc_lokr_conv2d_planes_ok(B, H, W, (int)a, (int)b, (int)c, (int)d, gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh,
+                                              gm.dw, code, 1) != 0;
+    Tensor planes_f, planes_b;
+    if (pf || pb) {
+      Tensor w2f = w2.detach();
+      if (w2f.scalar_type() != at::kFloat) w2f = w2f.to(at::kFloat);
+      if (w2f.stride(2) != gm.kw * w2f.stride(3) && gm.kh > 1) w2f = w2f.contiguous();  // one tap stride: (i, j) -> i * kw + j
+      const int taps = gm.kh * gm.kw;
+      if (pf) planes_f = at::empty({lyc_lokr_planes_bytes((int)c, (int)d, taps, 0)}, x.options().dtype(at::kByte));
+      if (pb) planes_b = at::empty({lyc_lokr_planes_bytes((int)c, (int)d, taps, 1)}, x.options().dtype(at::kByte));
+      check_rc(lyc_lokr_pack_w2(cfp(w2f), w2f.stride(0), w2f.stride(1), w2f.stride(3), nullptr, 0, 0, nullptr, 0, 0, 0, 0, (int)c, (int)d,
+                                taps, mptr(planes_f), mptr(planes_b), code, stream_of(x)), "lyc_lokr_pack_w2");
+    }
+    if (pf) {
+      check_rc(lyc_lokr_conv2d_fwd_planes(cptr(rows), cfp(f1), cptr(planes_f), mptr(y), B, H, W, (int)a, (int)b, (int)c, (int)d, gm.kh,
+                                          gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, (float)alpha, code, stream_of(x)),
+               "lyc_lokr_conv2d_fwd_planes");
+    } else {
+      Tensor w2p = f32c(w2.detach().permute({0, 2, 3, 1}));
+      check_rc(lyc_lokr_conv2d_fwd(cptr(rows), cfp(f1), cfp(w2p), mptr(y), B, H, W, (int)a, (int)b, (int)c, (int)d, gm.kh, gm.kw, gm.sh,
+                                   gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, (float)alpha, code, stream_of(x)),
+               "lyc_lokr_conv2d_fwd");
+    }
     expect(w1, x);
     expect(w2, x, /*cl=*/true);
-    ctx->save_for_backward({rows, w1, w2});
+    ctx->save_for_backward({rows, w1, w2, planes_b});
     ctx->saved_data["alpha"] = alpha;
     ctx->saved_data["geom"] = std::vector<int64_t>{gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, gm.Ho, gm.Wo, B, C, H, W, !copied};
     return from_rows(y, B, gm.Ho, gm.Wo, !copied);
@@ -1104,7 +1173,9 @@ struct LokrConv2dFn : public torch::autograd::Function<LokrConv2dFn> {
     bool cp;
     Tensor g_rows = rows_view(grads[0], &cp);
     const bool nx = ctx->needs_input_grad(0), n1 = ctx->needs_input_grad(1), n2 = ctx->needs_input_grad(2);
-    Tensor f1 = f32c(w1), w2p = f32c(w2.detach().permute({0, 2, 3, 1}));
+    const Tensor& planes_b = s[3];  // defined: the transposed convolution runs the patch kernel on pre-packed planes
+    Tensor f1 = f32c(w1), w2p;
+    if (!planes_b.defined()) w2p = f32c(w2.detach().permute({0, 2, 3, 1}));
     const int code = dtype_code(rows.scalar_type());
     Tensor dx_rows = (nx || n1 || accum_wanted(w1)) ? at::empty({B * H * W, C}, rows.options()) : Tensor();
     const bool a1 = n1 || accum_wanted(w1), a2 = n2 || accum_wanted(w2);
@@ -1115,12 +1186,37 @@ struct LokrConv2dFn : public torch::autograd::Function<LokrConv2dFn> {
       const int64_t nb = lyc_lokr_conv2d_bwd_workspace_bytes(B, H, W, (int)a, (int)b, (int)d);
       if (nb > 0) ws = at::empty({nb}, rows.options().dtype(at::kByte));
     }
-    Tensor w2t;  // stride 1: a [kh, kw, c, d] copy lets the transposed convolution use full K segments
-    if (dx_rows.defined() && gv[2] == 1 && gv[3] == 1) w2t = w2.detach().to(at::kFloat).permute({2, 3, 0, 1}).contiguous();
-    check_rc(lyc_lokr_conv2d_bwd(cptr(g_rows), cptr(rows), cfp(f1), cfp(w2p), cfp(w2t), mptr(dx_rows), mfp(t1.buf), mfp(t2.buf),
-                                 mptr(ws), B, H, W, (int)a, (int)b, (int)c, (int)d, (int)gv[0], (int)gv[1], (int)gv[2], (int)gv[3],
-                                 (int)gv[4], (int)gv[5], (int)gv[6], (int)gv[7], (float)alpha, code, stream_of(rows)),
-             "lyc_lokr_conv2d_bwd");
+    // both factor gradients go straight into .grad (fused accumulation): only the dx launch runs now, the weight gradients of
+    // all parked Conv2d layers run in grouped launches at the end of the backward pass (as for nn.Linear)
+    const bool defer = g_defer.enabled && planes_b.defined() && t2.buf.defined() && !t2.hand_back && t1.buf.defined() && !t1.hand_back &&
+                       ws.defined() && dx_rows.defined();
+    if (defer) {
+      check_rc(lyc_lokr_conv2d_bwd_planes(cptr(g_rows), cptr(rows), cfp(f1), nullptr, cptr(planes_b), mptr(dx_rows), mfp(t1.buf),
+                                          nullptr, mptr(ws), B, H, W, (int)a, (int)b, (int)c, (int)d, (int)gv[0], (int)gv[1],
+                                          (int)gv[2], (int)gv[3], (int)gv[4], (int)gv[5], (int)gv[6], (int)gv[7], (float)alpha,
+                                          code | LYC_DEFER_WGRAD, stream_of(rows)), "lyc_lokr_conv2d_bwd_planes(dx)");
+      DeferredLokrConv item{g_rows, rows, f1, w1, w2, t1.buf, t2.buf, ws, B, H, W,
+                            lyc_lokr_conv2d_dx_blocks(B, H, W, (int)a, (int)b, (int)c, (int)d, (int)gv[0], (int)gv[1], (int)gv[2], (int)gv[3],
+                                                      (int)gv[4], (int)gv[5], (int)gv[6], (int)gv[7], code, 1),
+                            (int)a, (int)b, (int)c, (int)d, {(int)gv[0], (int)gv[1], (int)gv[2], (int)gv[3], (int)gv[4], (int)gv[5], (int)gv[6],
+                            (int)gv[7]}, code, (float)alpha, stream_of(rows), rows.device().index()};
+      park_deferred(std::move(item));
+      Tensor dxd = nx ? from_rows(dx_rows, B, H, W, x_cl) : Tensor();
+      return {dxd, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+    if (planes_b.defined()) {
+      check_rc(lyc_lokr_conv2d_bwd_planes(cptr(g_rows), cptr(rows), cfp(f1), nullptr, cptr(planes_b), mptr(dx_rows), mfp(t1.buf),
+                                          mfp(t2.buf), mptr(ws), B, H, W, (int)a, (int)b, (int)c, (int)d, (int)gv[0], (int)gv[1],
+                                          (int)gv[2], (int)gv[3], (int)gv[4], (int)gv[5], (int)gv[6], (int)gv[7], (float)alpha, code,
+                                          stream_of(rows)), "lyc_lokr_conv2d_bwd_planes");
+    } else {
+      Tensor w2t;  // stride 1: a [kh, kw, c, d] copy lets the transposed convolution use full K segments
+      if (dx_rows.defined() && gv[2] == 1 && gv[3] == 1) w2t = w2.detach().to(at::kFloat).permute({2, 3, 0, 1}).contiguous();
+      check_rc(lyc_lokr_conv2d_bwd(cptr(g_rows), cptr(rows), cfp(f1), cfp(w2p), cfp(w2t), mptr(dx_rows), mfp(t1.buf), mfp(t2.buf),
+                                   mptr(ws), B, H, W, (int)a, (int)b, (int)c, (int)d, (int)gv[0], (int)gv[1], (int)gv[2], (int)gv[3],
+                                   (int)gv[4], (int)gv[5], (int)gv[6], (int)gv[7], (float)alpha, code, stream_of(rows)),
+               "lyc_lokr_conv2d_bwd");
+    }
     Tensor dx = nx ? from_rows(dx_rows, B, H, W, x_cl) : Tensor();
     return {dx, finish_grad(w1, t1), cl_finish(w2, t2), Tensor(), Tensor(), Tensor(), Tensor()};
   }
@@ -1129,6 +1225,7 @@ Tensor lokr_conv2d_implicit(const Tensor& x, const Tensor& w1, const Tensor& w2,
                             at::IntArrayRef padding, at::IntArrayRef dilation) {
   if (!x.is_cuda() || !eager_cuda(x))  // FakeTensor / meta: differentiable through the functional forward / backward ops
     return LokrConv2dTraceFn::apply(amp(x), w1, w2, alpha, stride.vec(), padding.vec(), dilation.vec());
+  const GradAtApply ga_;
   return LokrConv2dFn::apply(amp(x), w1, w2, alpha, stride.vec(), padding.vec(), dilation.vec());
 }
 
@@ -1187,6 +1284,7 @@ Tensor locon_conv2d_implicit(const Tensor& x, const Tensor& down, const Tensor& 
                              at::IntArrayRef padding, at::IntArrayRef dilation) {
   if (!x.is_cuda() || !eager_cuda(x))
     return LoconConv2dTraceFn::apply(amp(x), down, up, alpha, stride.vec(), padding.vec(), dilation.vec());
+  const GradAtApply ga_;
   return LoconConv2dFn::apply(amp(x), down, up, alpha, stride.vec(), padding.vec(), dilation.vec());
 }
 
@@ -1328,14 +1426,16 @@ PYBIND11_MODULE(_lyc_torch, m) {
       std::vector<DeferredLokr> items;
       std::vector<DeferredLocon> litems;
       std::vector<DeferredLoha> hitems;
+      std::vector<DeferredLokrConv> citems;
       {
         std::lock_guard<std::mutex> lk(L.mu);
         items.swap(L.lokr);
         litems.swap(L.locon);
         hitems.swap(L.loha);
+        citems.swap(L.lokr_conv);
         L.callback_queued = false;
       }
-      n += items.size() + litems.size() + hitems.size();  // the tensors are released outside the lock
+      n += items.size() + litems.size() + hitems.size() + citems.size();  // the tensors are released outside the lock
     }
     return n;
   });

@@ -46,13 +46,16 @@ class _Bucket:
 
 class AdapterGradSync:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20,
-                 process_group=None, average: bool = True):
+                 process_group=None, average: bool = True, always_reduce: bool = False):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("AdapterGradSync: no trainable parameters")
         self.group = process_group
         self.average = average
         self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # `always_reduce`: issue the collectives even at world_size 1 (a process group must be initialised) -- lets ONE GPU drive
+        # the RCCL path end to end (benchmarks/rccl_ws1_check.py); a no-op all-reduce is otherwise skipped
+        self._reduce = self.world_size > 1 or (always_reduce and dist.is_available() and dist.is_initialized())
         dev = self.params[0].device
         if any(p.device != dev for p in self.params):
             raise ValueError("AdapterGradSync: all adapter parameters must live on one device")
@@ -183,7 +186,7 @@ class AdapterGradSync:
     def _launch(self, b: _Bucket):
         b.launched = True
         self.launch_log.append(b.index)
-        if self.world_size == 1:
+        if not self._reduce:
             return
         if self.side_stream is not None:
             # the bucket's gradients were produced on the compute stream: order the collective after them

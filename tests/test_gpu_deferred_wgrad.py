@@ -172,8 +172,9 @@ def test_grads_are_complete_when_backward_returns_and_every_parameter_is_reporte
     for p, u, v in zip(params, g0, g1):
         assert float(u.abs().max()) > 0
         assert torch.allclose(u, v, rtol=2e-4, atol=1e-6), float((u - v).abs().max())
-    # 6 layer calls, two parameters each -- the shared layer is reported once per call, in both modes
-    assert sorted(seen0) == sorted(seen1) and len(seen1) == 12
+    # 6 layer calls on 5 layers: every parameter is reported ONCE per backward pass, after its last accumulation -- the shared
+    # layer's pair too (the contract of an autograd post-accumulate hook; round 3), in both modes
+    assert sorted(seen0) == sorted(seen1) == sorted(id(p) for p in params) and len(seen1) == 10
 
 
 def test_parameters_without_a_grad_buffer_are_not_deferred():
@@ -301,7 +302,7 @@ def test_locon_grads_are_complete_when_backward_returns(flush_at):
     assert torch.equal(dx0, dx1)
     for u, v in zip(g0, g1):
         assert float(u.abs().max()) > 0 and torch.allclose(u, v, rtol=2e-4, atol=1e-6), float((u - v).abs().max())
-    assert sorted(seen0) == sorted(seen1) and len(seen1) == 10
+    assert sorted(seen0) == sorted(seen1) == sorted(id(p) for p in params) and len(seen1) == 8  # once per parameter
 
 
 # ---- LoHa: lyc_loha_linear_bwd with NULL gradient pointers (dx only), then lyc_loha_wgrad_group -----------------------------
@@ -390,7 +391,7 @@ def test_loha_grads_are_complete_when_backward_returns():
     assert torch.equal(dx0, dx1)
     for u, v in zip(g0, g1):
         assert float(u.abs().max()) > 0 and torch.allclose(u, v, rtol=2e-4, atol=1e-6), float((u - v).abs().max())
-    assert sorted(seen0) == sorted(seen1) and len(seen1) == 16
+    assert sorted(seen0) == sorted(seen1) == sorted(id(p) for p in params) and len(seen1) == 12  # once per parameter
 
 
 def test_small_batches_take_the_single_launch_plans():

@@ -1,0 +1,194 @@
+"""GPU: pre-packed LoKr operand planes (lyc_lokr_pack_w2) and the LDS-patch Conv2d kernels that consume them
+(csrc/kron_conv.h, lyc_lokr_conv2d_{fwd,bwd}_planes), through the C ABI, against the float64 oracle.
+
+The pack kernel is checked BIT-EXACTLY: a plane element is hi = round_T(w), lo = round_T(w - hi) of the fp32 value at a
+known (n, k) position, so the expected byte image can be built with torch on the host.  The conv kernels are checked against
+oracle.lokr (reference semantics: lycoris/functional/lokr.py:195-247, modules/lokr.py:358-381) on geometries chosen to hit
+every plan branch: ragged images (tiles partly outside), batch > 1, stride 2 (forward only), dilation, 5x5 windows, factor 4 /
+8 / 16, group widths with and without LDS padding (K / 8 even / odd), column counts that need 2 / 3 / 4 n tiles and padding.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gpu_util import TOL, check, dev, err, rnd
+from lycoris_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected_planes(w2, c, d, taps, backward, dtype):
+    """byte image of one role: units [nt][ks] of {hi[64][8], lo[64][8]}; w2: fp32 [c, d, taps] (cpu)"""
+    Nn, Kt = (d, c) if backward else (c, d)
+    ks_n = (taps * Kt + 31) // 32
+    nt_n = (Nn + 15) // 16
+    B = torch.zeros(nt_n * 16, ks_n * 32, dtype=torch.float32)
+    src = w2.permute(1, 2, 0).reshape(d, taps * c) if backward else w2.permute(0, 2, 1).reshape(c, taps * d)  # [n, (tap, kk)]
+    B[:Nn, :taps * Kt] = src
+    hi = B.to(dtype)
+    lo = (B - hi.float()).to(dtype)
+    # unit (nt, ks): lane = li + 16 g holds n = 16 nt + li, k = 32 ks + 8 g + e
+    def units(t):
+        t = t.view(nt_n, 16, ks_n, 4, 8)            # nt, li, ks, g, e
+        return t.permute(0, 2, 3, 1, 4).contiguous()  # nt, ks, g, li, e  -> lane = g * 16 + li
+    img = torch.stack([units(hi), units(lo)], dim=2)  # nt, ks, {hi, lo}, g, li, e
+    return img.contiguous().view(torch.uint8).flatten()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("c,d,kh,layout", [(40, 40, 3, "nchw"), (160, 80, 3, "cl"), (24, 56, 1, "nchw"), (8, 8, 5, "cl"), (48, 120, 3, "nchw")])
+def test_pack_full_matrix_bit_exact(c, d, kh, layout, dtype):
+    taps = kh * kh
+    gen = torch.Generator().manual_seed(c * d + kh)
+    w2 = torch.randn(c, d, kh, kh, generator=gen) * 0.1
+    wd = w2.to(dev())
+    if layout == "cl":
+        wd = wd.contiguous(memory_format=torch.channels_last)
+    lib = N.load()
+    code = N.dtype_code(dtype)
+    pf = torch.full((int(lib.lyc_lokr_planes_bytes(c, d, taps, 0)),), 0xCD, dtype=torch.uint8, device=dev())
+    pb = torch.full((int(lib.lyc_lokr_planes_bytes(c, d, taps, 1)),), 0xCD, dtype=torch.uint8, device=dev())
+    N.call("lyc_lokr_pack_w2", N.ptr(wd), wd.stride(0), wd.stride(1), wd.stride(3), None, 0, 0, None, 0, 0, 0, 0, c, d, taps,
+           N.ptr(pf), N.ptr(pb), code, N.stream_ptr(dev()))
+    torch.cuda.synchronize()
+    w3 = w2.reshape(c, d, taps)
+    assert torch.equal(pf.cpu(), _expected_planes(w3, c, d, taps, False, dtype))
+    assert torch.equal(pb.cpu(), _expected_planes(w3, c, d, taps, True, dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_pack_low_rank_product(dtype):
+    """w2 = w2a @ w2b formed inside the pack kernel (reference modules/lokr.py:131-136, 370: lokr_w2_a [c, r], lokr_w2_b [r, d*k*k])"""
+    c, d, kh, r = 80, 40, 3, 16
+    taps = kh * kh
+    gen = torch.Generator().manual_seed(5)
+    w2a, w2b = torch.randn(c, r, generator=gen) * 0.3, torch.randn(r, d * taps, generator=gen) * 0.3
+    lib = N.load()
+    code = N.dtype_code(dtype)
+    pf = torch.zeros(int(lib.lyc_lokr_planes_bytes(c, d, taps, 0)), dtype=torch.uint8, device=dev())
+    pb = torch.zeros(int(lib.lyc_lokr_planes_bytes(c, d, taps, 1)), dtype=torch.uint8, device=dev())
+    ad, bd = w2a.to(dev()), w2b.to(dev())
+    N.call("lyc_lokr_pack_w2", None, 0, 0, 0, N.ptr(ad), r, 1, N.ptr(bd), d * taps, taps, 1, r, c, d, taps, N.ptr(pf), N.ptr(pb), code,
+           N.stream_ptr(dev()))
+    torch.cuda.synchronize()
+    w2 = (w2a.double() @ w2b.double()).reshape(c, d, taps)
+
+    def unpack(img, Nn, Kt):  # -> hi + lo as float64 [Nn, taps * Kt]
+        ks_n, nt_n = (taps * Kt + 31) // 32, (Nn + 15) // 16
+        t = img.cpu().view(dtype).view(nt_n, ks_n, 2, 4, 16, 8).double()
+        t = t[:, :, 0] + t[:, :, 1]                        # nt, ks, g, li, e
+        return t.permute(0, 3, 1, 2, 4).reshape(nt_n * 16, ks_n * 32)[:Nn, :taps * Kt]
+
+    got_f = unpack(pf, c, d)
+    got_b = unpack(pb, d, c)
+    want_f = w2.permute(0, 2, 1).reshape(c, taps * d)
+    want_b = w2.permute(1, 2, 0).reshape(d, taps * c)
+    # hi + lo of a T pair resolves 2 * mantissa bits: 2^-16 (bf16) / 2^-22 (fp16) relative; the product itself is an fp32 fma chain
+    tol = 1e-4 if dtype == torch.bfloat16 else 1e-5
+    assert float((got_f - want_f).norm() / want_f.norm()) < tol
+    assert float((got_b - want_b).norm() / want_b.norm()) < tol
+
+
+# (B, H, W, a, c, d, k, stride, pad, dil)
+GEOMS = [
+    (1, 16, 16, 8, 40, 40, 3, 1, 1, 1),     # SDXL 320-channel conv in small: K / 8 odd (no LDS pad), 3 n tiles of 16 (N = 40 -> 48)
+    (2, 9, 13, 8, 80, 80, 3, 1, 1, 1),      # ragged image, batch 2, K / 8 even (padded group pitch)
+    (1, 12, 12, 8, 160, 16, 3, 1, 1, 1),    # wide N (4 n tiles x 3 column tiles), tiny K
+    (1, 11, 7, 8, 24, 120, 3, 1, 1, 1),     # K = 120 (the C = 960 convs), N = 24
+    (1, 17, 17, 8, 40, 40, 3, 2, 1, 1),     # stride 2: planes forward, row kernel backward
+    (1, 10, 10, 8, 16, 24, 3, 1, 2, 2),     # dilation 2
+    (1, 9, 9, 8, 16, 16, 5, 1, 2, 1),       # 5x5 window: 25 taps
+    (1, 8, 12, 4, 32, 48, 3, 1, 1, 1),      # factor 4: 4 x 8 pixel tiles
+    (1, 8, 8, 16, 8, 8, 3, 1, 1, 1),        # factor 16: 2 x 4 pixel tiles
+    (1, 6, 6, 8, 40, 40, 3, 1, 0, 1),       # no padding: output smaller than the input
+    (3, 5, 5, 8, 8, 8, 1, 1, 0, 1),         # 1x1 window through the conv entry points
+]
+
+
+@pytest.fixture
+def row_tile(request, monkeypatch):
+    """pin the patch kernel's row tile (64 * MI stage-1 rows per workgroup): the host otherwise picks the smallest one for these
+    small problems (csrc/capi.hip plan_kconv reads LYC_KCONV_MI at every call)"""
+    mi = getattr(request, "param", 0)
+    if mi:
+        monkeypatch.setenv("LYC_KCONV_MI", str(mi))
+    else:
+        monkeypatch.delenv("LYC_KCONV_MI", raising=False)
+    return mi
+
+
+@pytest.mark.parametrize("row_tile", [0, 4, 8], ids=["mi_auto", "mi4", "mi8"], indirect=True)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("geom", GEOMS, ids=[f"B{g[0]}_{g[1]}x{g[2]}_a{g[3]}_c{g[4]}_d{g[5]}_k{g[6]}s{g[7]}p{g[8]}d{g[9]}" for g in GEOMS])
+def test_conv_planes_vs_oracle(geom, dtype, row_tile):
+    B, H, W, a, c, d, k, s, p, dl = geom
+    if row_tile and dtype == torch.float16 and geom not in (GEOMS[0], GEOMS[1], GEOMS[4]):
+        pytest.skip("fp16 with a pinned row tile: three geometries")
+    lib = N.load()
+    code = N.dtype_code(dtype)
+    taps = k * k
+    Ho, Wo = (H + 2 * p - dl * (k - 1) - 1) // s + 1, (W + 2 * p - dl * (k - 1) - 1) // s + 1
+    gen = torch.Generator().manual_seed(sum(geom))
+    x, x64 = rnd((B, a * d, H, W), dtype, gen)
+    g, g64 = rnd((B, a * c, Ho, Wo), dtype, gen, 1.0 / np.sqrt(a * c))
+    w1, w1_64 = rnd((a, a), torch.float32, gen, 0.3)
+    w2, w2_64 = rnd((c, d, k, k), torch.float32, gen, 0.1)
+    geo = (B, H, W, a, a, c, d, k, k, s, s, p, p, dl, dl)
+    fwd_ok = lib.lyc_lokr_conv2d_planes_ok(*geo, code, 0) != 0
+    bwd_ok = lib.lyc_lokr_conv2d_planes_ok(*geo, code, 1) != 0
+    if row_tile:  # a pinned tile may not fit the LDS for this geometry (the host then refuses it: nothing to test)
+        if not fwd_ok:
+            pytest.skip(f"row tile {row_tile} does not fit the LDS for this geometry")
+        assert lib.lyc_lokr_conv2d_planes_ok(*geo, code, 0) == row_tile
+        assert not bwd_ok or s == 1
+    else:
+        assert fwd_ok, "every geometry of this list fits the forward patch kernel"
+        assert bwd_ok == (s == 1)
+    x_rows = x.permute(0, 2, 3, 1).reshape(B * H * W, a * d).contiguous()
+    g_rows = g.permute(0, 2, 3, 1).reshape(B * Ho * Wo, a * c).contiguous()
+    pf = torch.empty(int(lib.lyc_lokr_planes_bytes(c, d, taps, 0)), dtype=torch.uint8, device=dev())
+    pb = torch.empty(int(lib.lyc_lokr_planes_bytes(c, d, taps, 1)), dtype=torch.uint8, device=dev())
+    N.call("lyc_lokr_pack_w2", N.ptr(w2), w2.stride(0), w2.stride(1), w2.stride(3), None, 0, 0, None, 0, 0, 0, 0, c, d, taps, N.ptr(pf),
+           N.ptr(pb), code, N.stream_ptr(dev()))
+    y_rows = torch.full((B * Ho * Wo, a * c), float("nan"), dtype=dtype, device=dev())
+    N.call("lyc_lokr_conv2d_fwd_planes", N.ptr(x_rows), N.ptr(w1), N.ptr(pf), N.ptr(y_rows), *geo, 0.5, code, N.stream_ptr(dev()))
+    ca = {"stride": s, "padding": p, "dilation": dl}
+    y_ref = oracle.lokr.forward(x64, w1=w1_64, w2=w2_64, scale=0.5, kshape=(k, k), conv_args=ca)
+    y = y_rows.view(B, Ho, Wo, a * c).permute(0, 3, 1, 2)
+    errs = {"y": err(y, y_ref, dtype)}
+    bounds = {"y": TOL["store_out"][dtype]}
+    if bwd_ok:
+        dx_rows = torch.full((B * H * W, a * d), float("nan"), dtype=dtype, device=dev())
+        dw1 = torch.zeros(a, a, device=dev())
+        dw2p = torch.zeros(c, taps, d, device=dev())
+        ws = torch.empty(max(int(lib.lyc_lokr_conv2d_bwd_workspace_bytes(B, H, W, a, a, d)), 16), dtype=torch.uint8, device=dev())
+        N.call("lyc_lokr_conv2d_bwd_planes", N.ptr(g_rows), N.ptr(x_rows), N.ptr(w1), None, N.ptr(pb), N.ptr(dx_rows), N.ptr(dw1),
+               N.ptr(dw2p), N.ptr(ws), *geo, 0.5, code, N.stream_ptr(dev()))
+        gr = oracle.lokr.backward(x64, g64, w1=w1_64, w2=w2_64, scale=0.5, kshape=(k, k), conv_args=ca)
+        dx = dx_rows.view(B, H, W, a * d).permute(0, 3, 1, 2)
+        errs.update({"dx": err(dx, gr["dx"], dtype), "dw1": err(dw1, gr["w1"]),
+                     "dw2": err(dw2p.view(c, k, k, d).permute(0, 3, 1, 2), gr["w2"])})
+        bounds.update({"dx": TOL["store_out"][dtype], "dw1": TOL["f32_out"][dtype], "dw2": TOL["f32_out"][dtype]})
+    torch.cuda.synchronize()
+    check(f"conv_planes[{geom},{dtype}]", errs, bounds)
+
+
+def test_every_sdxl_conv_takes_the_patch_kernel_where_lds_allows():
+    """which SDXL / SD1.5 Conv2d layers run on the patch kernel: all 3x3 forward passes with C_in <= 1280 and every stride-1
+    backward pass (the transposed convolution's operand rows are the OUTPUT channels, <= 1280)"""
+    from benchmarks.sdxl_shapes import sdxl_unet_layers
+    lib = N.load()
+    code = N.dtype_code(torch.bfloat16)
+    n_f = n_b = n = 0
+    for l in sdxl_unet_layers(1):
+        if l["kind"] != "conv" or l["k"] == 1:
+            continue
+        geo = (l["B"], l["H"], l["W"], 8, 8, l["O"] // 8, l["C"] // 8, l["k"], l["k"], l["stride"], l["stride"], l["pad"], l["pad"], 1, 1)
+        f, b = lib.lyc_lokr_conv2d_planes_ok(*geo, code, 0), lib.lyc_lokr_conv2d_planes_ok(*geo, code, 1)
+        assert (f != 0) == (l["C"] <= 1920), l
+        assert (b != 0) == (l["stride"] == 1), l
+        n += l["count"]
+        n_f += (f != 0) * l["count"]
+        n_b += (b != 0) * l["count"]
+    assert n_f >= n - 6 and n_b >= n - 2, (n, n_f, n_b)
