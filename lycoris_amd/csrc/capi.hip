@@ -1,7 +1,7 @@
 // capi.hip -- C ABI launchers (include/lycoris_amd.h).  gfx950 only.
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
 #include <cstdlib>
+#include <vector>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -13,7 +13,9 @@
 #include "kron3.h"
 #include "kron_dw2s.h"
 #include "kron_conv.h"
+#include "kron_conv_dw2.h"
 #include "loha_mfma.h"
+#include "gemm16.h"
 #include "lokr_kernels.h"
 #include "lowrank.h"
 #include "skinny_kernels.h"
@@ -1063,11 +1065,109 @@ int64_t lyc_lokr_conv2d_dx_blocks(int64_t B, int64_t H, int64_t W, int a, int b,
   return (int64_t)cdiv(ka.M, K3_RT / ka.Gin) * cdiv(ka.N, 16 * kron3_pick_ni(ka));
 }
 
-int lyc_lokr_conv_wgrad_group(const LycLokrConvWgradItem* items, int n, int dtype, void* stream) {
-  if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "lokr_conv_wgrad_group: bad item list");
+extern "C++" {
+namespace {
+// plan of the patch kernel (kron_conv_dw2.h) for one layer; false: the row-gather kernel takes it
+bool plan_kd(const LycLokrConvWgradItem& it, const ConvDims& cd, KdItem& k) {
+  const int G = it.a;
+  if (it.a != it.b || (G != 4 && G != 8 && G != 16) || (it.c % 8) != 0 || (it.d % 8) != 0) return false;
+  if (getenv("LYC_CONV_DW2_ROWS")) return false;  // tests / A-B: force the row-gather kernel
+  k = KdItem{};
+  k.g = it.g_rows; k.x = it.x_rows; k.w1 = it.w1; k.out = it.dw2p;
+  k.B = (int)it.B; k.G = G; k.I = it.c; k.J = it.d;
+  k.Hs = (int)it.H; k.Ws = (int)it.W; k.Hd = (int)cd.Ho; k.Wd = (int)cd.Wo;
+  k.taps = cd.taps; k.kw = it.kw; k.sh = it.sh; k.sw = it.sw; k.ph = it.ph; k.pw = it.pw; k.dh = it.dh; k.dw = it.dw;
+  const int tmp = K3_RT / G;
+  int lt = 0;
+  while ((2 << lt) <= tmp) ++lt;
+  k.TH = 1 << (lt / 2);
+  k.TW = tmp / k.TH;
+  const int pv = 16 / G;
+  if (k.TH % pv != 0) return false;
+  k.PH = (k.TH - 1) * it.sh + (it.kh - 1) * it.dh + 1;
+  k.PW = (k.TW - 1) * it.sw + (it.kw - 1) * it.dw + 1;
+  k.tiles_h = (int)cdiv(cd.Ho, k.TH);
+  k.tiles_w = (int)cdiv(cd.Wo, k.TW);
+  k.nq = (int)cdiv(it.c, KD_WIN); k.KQ = (int)round_up(cdiv(it.c, k.nq), 8);
+  k.nv = (int)cdiv(it.d, KD_WIN); k.KV = (int)round_up(cdiv(it.d, k.nv), 8);
+  k.nq = (int)cdiv(it.c, k.KQ);
+  k.nv = (int)cdiv(it.d, k.KV);
+  if (cd.taps * cdiv(k.KQ, 16) * cdiv(k.KV, 16) > 4 * KD_MAXC) return false;
+  if ((long)it.H * it.W * G * it.d >= (1L << 30) || cd.Ho * cd.Wo * G * it.c >= (1L << 30)) return false;
+  if (kd_lds(k).total() > 160 * 1024) return false;
+  const long ntile = it.B * k.tiles_h * k.tiles_w;
+  // split over pixel-tile slabs: ~1 M fp32 atomics per layer at most (each slab adds its whole [c, taps, d] block once)
+  long slabs = 1000000 / ((long)it.c * cd.taps * it.d);
+  if (slabs < 1) slabs = 1;
+  if (slabs > ntile) slabs = ntile;
+  k.tiles_per_slab = (int)cdiv(ntile, slabs);
+  k.slabs = (int)cdiv(ntile, k.tiles_per_slab);
+  k.ws = it.b; k.wt = 1; k.os = cd.taps * it.d; k.alpha = it.alpha;
+  return true;
+}
+}  // namespace
+}  // extern "C++"
+
+int lyc_lokr_conv_wgrad_group(const LycLokrConvWgradItem* items_in, int n, int dtype, void* stream) {
+  if (n < 0 || (n > 0 && !items_in)) return fail(LYC_ERR_ARG, "lokr_conv_wgrad_group: bad item list");
   hipStream_t st = (hipStream_t)stream;
   const int dt = dtype & 0xff;
   if (n > 0 && dt != LYC_BF16 && dt != LYC_F16) return fail(LYC_ERR_UNSUPPORTED, "lokr_conv_wgrad_group: 16-bit activations only");
+  // ---- layers the patch kernel covers (stride-1 / small-patch geometries): kconv_dw2_group_kernel, 12 layers per launch ------
+  std::vector<LycLokrConvWgradItem> rest;
+  {
+    KdGroupArgs ga{};
+    int lds = 0;
+    auto flush = [&]() -> int {
+      if (ga.n == 0) return LYC_OK;
+      for (int i = 0; i < ga.n; ++i)
+        for (int j = 0; j < i; ++j)
+          if (ga.p[i].out == ga.p[j].out || (ga.p[i].dw1 && ga.p[i].dw1 == ga.p[j].dw1)) ga.p[i].force_atomic = ga.p[j].force_atomic = 1;
+      const dim3 grid((unsigned)ga.wg_end[ga.n - 1]);
+      if (dt == LYC_BF16) {
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kconv_dw2_group_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+        hipLaunchKernelGGL((kconv_dw2_group_kernel<__bf16>), grid, dim3(NTHREADS), lds, st, ga);
+      } else {
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kconv_dw2_group_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+        hipLaunchKernelGGL((kconv_dw2_group_kernel<_Float16>), grid, dim3(NTHREADS), lds, st, ga);
+      }
+      ga = KdGroupArgs{};
+      lds = 0;
+      return check_launch("lokr_conv_wgrad_group(patch)");
+    };
+    for (int k = 0; k < n; ++k) {
+      const LycLokrConvWgradItem& it = items_in[k];
+      if (!it.g_rows || !it.x_rows || !it.w1 || !it.dw2p) return fail(LYC_ERR_ARG, "lokr_conv_wgrad_group: item %d: null pointer", k);
+      if (it.dw1 && (!it.ws || it.dw1_blocks < 1)) return fail(LYC_ERR_ARG, "lokr_conv_wgrad_group: item %d: dw1 needs ws and dw1_blocks", k);
+      ConvDims cd{};
+      if (int rc = lokr_conv_check(cd, it.B, it.H, it.W, it.a, it.b, it.c, it.d, it.kh, it.kw, it.sh, it.sw, it.ph, it.pw, it.dh, it.dw, dtype,
+                                   it.x_rows, it.g_rows))
+        return rc;
+      KdItem kd{};
+      if (it.B < 1 || !plan_kd(it, cd, kd)) {
+        rest.push_back(it);
+        continue;
+      }
+      if (it.dw1) {
+        kd.dw1_ws = static_cast<const float*>(it.ws); kd.dw1 = it.dw1; kd.dw1_n = it.a * it.b; kd.dw1_nblk = (int)it.dw1_blocks;
+        long r = it.dw1_blocks / 64;
+        kd.dw1_red = (int)(r > 16 ? 16 : r < 1 ? 1 : r);
+      }
+      if (ga.n == KD_MAX_ITEMS)
+        if (int rc = flush()) return rc;
+      const int wgs = kd.slabs * kd.nq * kd.nv + (kd.dw1_ws ? kd.dw1_red : 0);
+      ga.p[ga.n] = kd;
+      ga.wg_end[ga.n] = (ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs;
+      const int need = kd_lds(kd).total();
+      if (need > lds) lds = need;
+      ++ga.n;
+    }
+    if (int rc = flush()) return rc;
+  }
+  const LycLokrConvWgradItem* items = rest.data();
+  n = (int)rest.size();
   const bool batch = n >= 4;  // a few conv layers already fill the chip (their row counts are 8 x those of the Linear layers)
   for (int cfg = 0; cfg < DW2_NCFG; ++cfg) {
     KronDw2sConvGroupArgs ga{};
@@ -1426,57 +1526,53 @@ struct LohaPlanes {
   char *nh, *nl, *th, *tl;
   long ldn, ldt;
 };
+// 16-bit activations with O % 8 == I % 8 == 0 (every real layer): one plane; the three contractions run on gemm16.h.
+// Other 16-bit dims and fp32 activations: the plane and its transpose for the generic NT / TN kernels of dense_kernels.h.
+bool loha_dims_fast(long O, long I) { return (O % 8) == 0 && (I % 8) == 0; }
 LohaPlanes loha_planes(void* base, int O, int I, size_t esz) {
   LohaPlanes p;
   p.ldn = round_up(I, 16 / (long)esz);
   p.ldt = round_up(O, 16 / (long)esz);
   char* b = static_cast<char*>(base);
   const size_t n = (size_t)O * p.ldn * esz;
-  // 16-bit activations: one plane (dW rounded to the activation type, the library GEMMs transpose by flag);
-  // fp32 activations: the plane and its transpose for the two NT kernels (no hi/lo split in fp32)
-  p.nh = b; p.nl = nullptr; p.th = esz == 4 ? b + n : nullptr; p.tl = nullptr;
+  const bool transposed = esz == 4 || !loha_dims_fast(O, I);
+  p.nh = b; p.nl = nullptr; p.th = transposed ? b + n : nullptr; p.tl = nullptr;
   return p;
 }
 size_t esize(int dtype) { return (dtype & 0xff) == LYC_F32 ? 4 : 2; }
 
-// LoHa's Hadamard product of two rank-r matrices is full rank: once the dW operand planes exist, the three contractions
-// (y = x dW^T, dx = g dW, G = g^T x) are PLAIN dense GEMMs -- the one place where the vendor library is the right tool
-// (hand-written kernels are for the fused / factored ops).  Row-major C[m, n] = op(A) op(B) is issued as the
-// column-major product C^T = op(B)^T op(A)^T.  One handle per host thread; calls only enqueue on `st`.
-rocblas_handle rb_handle(hipStream_t st) {
-  thread_local rocblas_handle handles[16] = {nullptr};  // one per (host thread, device): a handle is bound to its device
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  rocblas_handle& h = handles[dev];
-  if (!h) {
-    if (rocblas_create_handle(&h) != rocblas_status_success) {
-      h = nullptr;
-      return nullptr;
-    }
-    rocblas_set_pointer_mode(h, rocblas_pointer_mode_host);
+// LoHa's Hadamard product of two rank-r matrices is full rank: once the dW operand plane exists, the three contractions
+// (y = x dW^T, dx = g dW, G = g^T x) are plain dense GEMMs -- gemm16.h (rounds 1-2 called rocBLAS here).
+// 128 x 128 tiles, or 64 x 128 when that leaves fewer than ~200 workgroups (M = 1024 x N = 1280: 80 -> 160).
+template <typename T, bool A_KS, bool B_KS>
+void launch_gemm16_group(const Gemm16Group& ga, int tm, hipStream_t st) {
+  const dim3 grid((unsigned)ga.wg_end[ga.n - 1]);
+  if (tm == 128) {
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<T, 128, A_KS, B_KS>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm16_lds_bytes<128>()); once = true; }
+    hipLaunchKernelGGL((gemm16_kernel<T, 128, A_KS, B_KS>), grid, dim3(NTHREADS), gemm16_lds_bytes<128>(), st, ga);
+  } else {
+    hipLaunchKernelGGL((gemm16_kernel<T, 64, A_KS, B_KS>), grid, dim3(NTHREADS), gemm16_lds_bytes<64>(), st, ga);
   }
-  if (rocblas_set_stream(h, st) != rocblas_status_success) return nullptr;
-  return h;
 }
-// C[M, N] (ldc) = alpha * A' * B' + beta * C, all row-major.
-//   a_t == false: A is [M, K] (lda)      a_t == true: A is [K, M] (lda)
-//   b_t == false: B is [K, N] (ldb)      b_t == true: B is [N, K] (ldb)
-int rb_gemm(hipStream_t st, bool a_t, bool b_t, long M, long N, long K, const void* A, long lda, const void* B, long ldb,
-            void* C, long ldc, rocblas_datatype in_t, rocblas_datatype out_t, float alpha, float beta, const char* what) {
-  rocblas_handle h = rb_handle(st);
-  if (!h) return fail(LYC_ERR_LAUNCH, "%s: rocBLAS handle unavailable", what);
-  // column-major view: C^T [N x M] = op(B) [N x K] * op(A) [K x M]
-  const rocblas_operation opB = b_t ? rocblas_operation_transpose : rocblas_operation_none;   // B row-major [N,K] = cm [K,N]
-  const rocblas_operation opA = a_t ? rocblas_operation_transpose : rocblas_operation_none;   // A row-major [K,M] = cm [M,K]
-  const rocblas_status rs =
-      rocblas_gemm_ex(h, opB, opA, (rocblas_int)N, (rocblas_int)M, (rocblas_int)K, &alpha, B, in_t, (rocblas_int)ldb, A, in_t,
-                      (rocblas_int)lda, &beta, C, out_t, (rocblas_int)ldc, C, out_t, (rocblas_int)ldc,
-                      rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
-  if (rs != rocblas_status_success) return fail(LYC_ERR_LAUNCH, "%s: rocblas_gemm_ex failed (%d)", what, (int)rs);
-  return LYC_OK;
+inline int gemm16_pick_tm(long M, long N) { return cdiv(M, 128) * cdiv(N, 128) >= 200 ? 128 : 64; }
+inline bool gemm16_ok(const Gemm16Prob& p, bool a_ks, bool b_ks) {
+  const bool al = ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15u) == 0 && (p.lda % 8) == 0 && (p.ldb % 8) == 0;
+  const bool kc = (a_ks && b_ks) || (p.K % 8) == 0;  // a K-contiguous operand is read in 16-byte vectors along K
+  const bool ks = (!a_ks || (p.M % 8) == 0) && (!b_ks || (p.N % 8) == 0);
+  const long ae = a_ks ? (long)p.K * p.lda : (long)p.M * p.lda, be = b_ks ? (long)p.K * p.ldb : (long)p.N * p.ldb;
+  return al && kc && ks && ae < (1L << 30) && be < (1L << 30);
 }
-rocblas_datatype rb_type(int dtype) {
-  return (dtype & 0xff) == LYC_BF16 ? rocblas_datatype_bf16_r : rocblas_datatype_f16_r;
+// one problem; mode: 0 = NT, 1 = NN (B K-strided), 2 = TN (both K-strided)
+template <typename T>
+void launch_gemm16(const Gemm16Prob& p, int mode, int out_f32, hipStream_t st) {
+  Gemm16Group ga{};
+  ga.n = 1; ga.out_f32 = out_f32; ga.p[0] = p;
+  const int tm = gemm16_pick_tm(p.M, p.N);
+  ga.wg_end[0] = (int)(cdiv(p.M, tm) * cdiv(p.N, 128));
+  if (mode == 0) launch_gemm16_group<T, false, false>(ga, tm, st);
+  else if (mode == 1) launch_gemm16_group<T, false, true>(ga, tm, st);
+  else launch_gemm16_group<T, true, true>(ga, tm, st);
 }
 
 // HadaWeight.backward on a dense fp32 gradient G [O, I] (functional/loha.py:18-30): shared by the activation path
@@ -1541,7 +1637,7 @@ void launch_loha_factor_grad(const float* gw, const float* w1a, const float* w1b
 int64_t lyc_loha_workspace_bytes(int O, int I, int dtype) {
   const long esz = (long)esize(dtype);
   const int64_t n = (int64_t)O * round_up(I, 16 / esz) * esz;
-  return esz == 4 ? n + (int64_t)I * round_up(O, 16 / esz) * esz : n;
+  return (esz == 4 || !loha_dims_fast(O, I)) ? n + (int64_t)I * round_up(O, 16 / esz) * esz : n;
 }
 
 int lyc_loha_linear_fwd(const void* x, const float* w1a, const float* w1b, const float* w2a, const float* w2b,
@@ -1555,18 +1651,36 @@ int lyc_loha_linear_fwd(const void* x, const float* w1a, const float* w1b, const
   la.w1a = w1a; la.w1b = w1b; la.w2a = w2a; la.w2b = w2b; la.O = O; la.I = I; la.R = r; la.scale = alpha;
   la.Wn_h = pl.nh; la.Wn_l = pl.nl; la.Wt_h = pl.th; la.Wt_l = pl.tl; la.ldn = pl.ldn; la.ldt = pl.ldt;
   dim3 rg((unsigned)cdiv(O, LOHA_T), (unsigned)cdiv(I, LOHA_T));
-  switch (dtype & 0xff) {  // the transposed planes are only read by the fp32-activation GEMM kernels
-    case LYC_BF16: hipLaunchKernelGGL((loha_rebuild_mfma_kernel<__bf16, false>), rg, dim3(NTHREADS), 0, st, la); break;
-    case LYC_F16: hipLaunchKernelGGL((loha_rebuild_mfma_kernel<_Float16, false>), rg, dim3(NTHREADS), 0, st, la); break;
+  const bool wt16 = pl.th != nullptr;  // the transposed plane is read by the generic dx kernels only
+  switch (dtype & 0xff) {
+    case LYC_BF16:
+      if (wt16) hipLaunchKernelGGL((loha_rebuild_mfma_kernel<__bf16, true>), rg, dim3(NTHREADS), 0, st, la);
+      else hipLaunchKernelGGL((loha_rebuild_mfma_kernel<__bf16, false>), rg, dim3(NTHREADS), 0, st, la);
+      break;
+    case LYC_F16:
+      if (wt16) hipLaunchKernelGGL((loha_rebuild_mfma_kernel<_Float16, true>), rg, dim3(NTHREADS), 0, st, la);
+      else hipLaunchKernelGGL((loha_rebuild_mfma_kernel<_Float16, false>), rg, dim3(NTHREADS), 0, st, la);
+      break;
     case LYC_F32: hipLaunchKernelGGL((loha_rebuild_mfma_kernel<float, true>), rg, dim3(NTHREADS), 0, st, la); break;
     default: return fail(LYC_ERR_ARG, "unknown dtype %d", dtype);
   }
   if (int rc = check_launch("loha_linear_fwd(rebuild)")) return rc;
   if (M > 0 && (dtype & 0xff) != LYC_F32) {
     // y = x dW^T with dW in the activation type (one plane, one pass: the reference's own semantics)
-    const rocblas_datatype t = rb_type(dtype);
-    if (int rc = rb_gemm(st, false, true, M, O, I, x, I, pl.nh, pl.ldn, y, O, t, t, 1.0f, 0.0f, "loha_linear_fwd")) return rc;
-    return LYC_OK;
+    Gemm16Prob gp{};
+    gp.A = x; gp.B = pl.nh; gp.C = y; gp.M = (int)M; gp.N = O; gp.K = I; gp.lda = I; gp.ldb = (int)pl.ldn; gp.ldc = O; gp.alpha = 1.0f;
+    if (!wt16 && gemm16_ok(gp, false, false)) {
+      if ((dtype & 0xff) == LYC_BF16) launch_gemm16<__bf16>(gp, 0, 0, st);
+      else launch_gemm16<_Float16>(gp, 0, 0, st);
+    } else {  // odd dims / unaligned rows: the generic NT kernel on the single plane
+      GemmArgs ga{};
+      ga.A = x; ga.Bh = pl.nh; ga.Bl = pl.nh; ga.out = y; ga.M = M; ga.N = O; ga.K = I;
+      ga.lda = I; ga.ldb = pl.ldn; ga.ldo = O; ga.alpha = 1.0f;
+      dim3 gg((unsigned)cdiv(M, 128), (unsigned)cdiv(O, 128));
+      if ((dtype & 0xff) == LYC_BF16) hipLaunchKernelGGL((gemm_nt_kernel<__bf16, false>), gg, dim3(NTHREADS), 0, st, ga);
+      else hipLaunchKernelGGL((gemm_nt_kernel<_Float16, false>), gg, dim3(NTHREADS), 0, st, ga);
+    }
+    return check_launch("loha_linear_fwd");
   }
   if (M > 0) {  // fp32 activations: exact fp32 MFMA kernel
     GemmArgs ga{};
@@ -1591,10 +1705,23 @@ int lyc_loha_linear_bwd(const void* g, const void* x, const float* w1a, const fl
   hipStream_t st = (hipStream_t)stream;
   LohaPlanes pl = loha_planes(const_cast<void*>(wplanes), O, I, esize(dtype));
   const bool lib = (dtype & 0xff) != LYC_F32;
-  if (dx && lib) {  // dx = g dW: [M,O] x [O,I] on the same plane
-    const rocblas_datatype t = rb_type(dtype);
-    const rocblas_datatype to = (dtype & LYC_F32_ROWS) ? rocblas_datatype_f32_r : t;
-    if (int rc = rb_gemm(st, false, false, M, I, O, g, O, pl.nh, pl.ldn, dx, I, t, to, 1.0f, 0.0f, "loha_linear_bwd(dx)")) return rc;
+  const bool bf = (dtype & 0xff) == LYC_BF16;
+  if (dx && lib) {  // dx = g dW: [M,O] x [O,I] on the same plane (B operand K-strided)
+    Gemm16Prob gp{};
+    gp.A = g; gp.B = pl.nh; gp.C = dx; gp.M = (int)M; gp.N = I; gp.K = O; gp.lda = O; gp.ldb = (int)pl.ldn; gp.ldc = I; gp.alpha = 1.0f;
+    const int of32 = (dtype & LYC_F32_ROWS) ? 1 : 0;
+    if (pl.th == nullptr && gemm16_ok(gp, false, true)) {
+      if (bf) launch_gemm16<__bf16>(gp, 1, of32, st);
+      else launch_gemm16<_Float16>(gp, 1, of32, st);
+    } else {
+      if (pl.th == nullptr) return fail(LYC_ERR_UNSUPPORTED, "loha_linear_bwd: unaligned activations need the transposed plane (odd dims)");
+      GemmArgs ga{};
+      ga.A = g; ga.Bh = pl.th; ga.Bl = pl.th; ga.out = dx; ga.M = M; ga.N = I; ga.K = O;
+      ga.lda = O; ga.ldb = pl.ldt; ga.ldo = I; ga.alpha = 1.0f; ga.out_f32 = of32;
+      dim3 gg((unsigned)cdiv(M, 128), (unsigned)cdiv(I, 128));
+      if (bf) hipLaunchKernelGGL((gemm_nt_kernel<__bf16, false>), gg, dim3(NTHREADS), 0, st, ga);
+      else hipLaunchKernelGGL((gemm_nt_kernel<_Float16, false>), gg, dim3(NTHREADS), 0, st, ga);
+    }
   } else if (dx) {  // dx = g @ dW : B operand rows = i, K = o  -> the transposed planes
     GemmArgs ga{};
     ga.A = g; ga.Bh = pl.th; ga.Bl = pl.tl; ga.out = dx; ga.M = M; ga.N = I; ga.K = O;
@@ -1603,10 +1730,11 @@ int lyc_loha_linear_bwd(const void* g, const void* x, const float* w1a, const fl
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_nt_kernel<T>), gg, dim3(NTHREADS), 0, st, ga));
   }
   if (want_factors) {  // G = g^T x (fp32, [O, I]), then the Hadamard chain rule on the factors
-    if (lib) {
-      if (int rc = rb_gemm(st, true, false, O, I, M, g, O, x, I, gw, I, rb_type(dtype), rocblas_datatype_f32_r, 1.0f, 0.0f,
-                           "loha_linear_bwd(G)"))
-        return rc;
+    Gemm16Prob gp{};
+    gp.A = g; gp.B = x; gp.C = gw; gp.M = O; gp.N = I; gp.K = (int)M; gp.lda = O; gp.ldb = I; gp.ldc = I; gp.alpha = 1.0f;
+    if (lib && gemm16_ok(gp, true, true)) {
+      if (bf) launch_gemm16<__bf16>(gp, 2, 1, st);
+      else launch_gemm16<_Float16>(gp, 2, 1, st);
     } else {
       GemmArgs ga{};
       ga.A = g; ga.Bh = x; ga.out = gw; ga.M = O; ga.N = I; ga.K = M;
@@ -1637,9 +1765,41 @@ int lyc_loha_wgrad_group(const LycLohaWgradItem* items, int n, int dtype, void* 
       return fail(LYC_ERR_ARG, "loha_wgrad_group: item %d: null pointer (the four gradients come as a set and need the gw scratch)", k);
     if (!lyc_loha_wgrad_deferrable(it.g, it.x, it.M, it.I, it.O, it.r, dtype))
       return fail(LYC_ERR_UNSUPPORTED, "loha_wgrad_group: item %d needs 16-bit activations", k);
-    if (int rc = rb_gemm(st, true, false, it.O, it.I, it.M, it.g, it.O, it.x, it.I, it.gw, it.I, rb_type(dtype),
-                         rocblas_datatype_f32_r, 1.0f, 0.0f, "loha_wgrad_group(G)"))
-      return rc;
+  }
+  {  // G_k = g_k^T x_k (fp32, [O, I]) of ALL layers: gemm16 TN, up to 24 layers per launch (128 x 128 tiles: thousands of workgroups)
+    const bool bf = (dtype & 0xff) == LYC_BF16;
+    Gemm16Group ga{};
+    ga.out_f32 = 1;
+    auto flush = [&]() -> int {
+      if (ga.n == 0) return LYC_OK;
+      if (bf) launch_gemm16_group<__bf16, true, true>(ga, 128, st);
+      else launch_gemm16_group<_Float16, true, true>(ga, 128, st);
+      ga = Gemm16Group{};
+      ga.out_f32 = 1;
+      return check_launch("loha_wgrad_group(G)");
+    };
+    for (int k = 0; k < n; ++k) {
+      const LycLohaWgradItem& it = items[k];
+      Gemm16Prob gp{};
+      gp.A = it.g; gp.B = it.x; gp.C = it.gw; gp.M = it.O; gp.N = it.I; gp.K = (int)it.M; gp.lda = it.O; gp.ldb = it.I; gp.ldc = it.I;
+      gp.alpha = 1.0f;
+      if (!gemm16_ok(gp, true, true)) {  // odd dims: the generic TN kernel, one launch
+        GemmArgs ta{};
+        ta.A = it.g; ta.Bh = it.x; ta.out = it.gw; ta.M = it.O; ta.N = it.I; ta.K = it.M;
+        ta.lda = it.O; ta.ldb = it.I; ta.ldo = it.I; ta.alpha = 1.0f; ta.atomic = 0; ta.chunk = it.M;
+        dim3 gg((unsigned)cdiv(it.O, 128), (unsigned)cdiv(it.I, 128), 1);
+        if (bf) hipLaunchKernelGGL((gemm_tn_kernel<__bf16>), gg, dim3(NTHREADS), 0, st, ta);
+        else hipLaunchKernelGGL((gemm_tn_kernel<_Float16>), gg, dim3(NTHREADS), 0, st, ta);
+        continue;
+      }
+      const long wgs = cdiv(it.O, 128) * cdiv(it.I, 128);
+      if (ga.n == G16_MAX || (ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs > (1L << 30))
+        if (int rc = flush()) return rc;
+      ga.p[ga.n] = gp;
+      ga.wg_end[ga.n] = (int)((ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs);
+      ++ga.n;
+    }
+    if (int rc = flush()) return rc;
   }
   for (int fast = 0; fast < 2; ++fast)
   for (int no = 1; no <= 2; no <<= 1) {  // one sequence of launches per kernel instantiation

@@ -22,7 +22,8 @@ struct GemmArgs {
   int out_f32;      // gemm_nt: write fp32 rows instead of T (LYC_F32_ROWS)
 };
 
-template <typename T>
+// BSPLIT = false: B is ONE plane of T (LoHa's dW in the activation type): no lo tile, one MFMA per pair
+template <typename T, bool BSPLIT = true>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs a) {
   constexpr int BK = (sizeof(T) == 2) ? 32 : 16;
   constexpr int TM = 128, TN = 128;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs a) {
   const int wr = wave >> 1, wc = wave & 1;
   const long m0 = (long)blockIdx.x * TM, n0 = (long)blockIdx.y * TN;
   const bool a_vec = vec_aligned<T>(A, a.lda);
-  const bool b_vec = vec_aligned<T>(gBh, a.ldb) && (!TT<T>::SPLIT || vec_aligned<T>(gBl, a.ldb));
+  const bool b_vec = vec_aligned<T>(gBh, a.ldb) && (!(TT<T>::SPLIT && BSPLIT) || vec_aligned<T>(gBl, a.ldb));
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -52,9 +53,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs a) {
   for (long k0 = 0; k0 < a.K; k0 += BK) {
     stage_rows<T, TM, BK>(As, A, a.lda, m0, a.M, k0, a.K, a_vec);
     stage_rows<T, TN, BK>(Bh, gBh, a.ldb, n0, a.N, k0, a.K, b_vec);
-    if constexpr (TT<T>::SPLIT) stage_rows<T, TN, BK>(Bl, gBl, a.ldb, n0, a.N, k0, a.K, b_vec);
+    if constexpr (TT<T>::SPLIT && BSPLIT) stage_rows<T, TN, BK>(Bl, gBl, a.ldb, n0, a.N, k0, a.K, b_vec);
     __syncthreads();
-    mma_tile<T, BK, 4, 4, true>(acc, As, wr * 64, Bh, Bl, wc * 64);
+    mma_tile<T, BK, 4, 4, BSPLIT>(acc, As, wr * 64, Bh, Bl, wc * 64);
     __syncthreads();
   }
   if (a.out_f32) {  // un-rounded rows straight from the accumulators (conv backward path)

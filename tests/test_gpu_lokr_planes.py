@@ -192,3 +192,101 @@ def test_every_sdxl_conv_takes_the_patch_kernel_where_lds_allows():
         n_f += (f != 0) * l["count"]
         n_b += (b != 0) * l["count"]
     assert n_f >= n - 6 and n_b >= n - 2, (n, n_f, n_b)
+
+
+@pytest.mark.parametrize("kernel", ["patch", "rows"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_conv_wgrad_group_vs_oracle(dtype, kernel, monkeypatch):
+    """lyc_lokr_conv_wgrad_group over ALL geometries of the list in one call (the deferred form: dx launches with LYC_DEFER_WGRAD
+    leave the dw1 partials in `ws`, the grouped launch computes dw2p and reduces dw1).  `patch`: the LDS-patch kernel
+    (kron_conv_dw2.h) where its plan covers the layer; `rows`: the row-gather kernel for every layer (LYC_CONV_DW2_ROWS)."""
+    import ctypes
+    if kernel == "rows":
+        monkeypatch.setenv("LYC_CONV_DW2_ROWS", "1")
+    else:
+        monkeypatch.delenv("LYC_CONV_DW2_ROWS", raising=False)
+    lib = N.load()
+    code = N.dtype_code(dtype)
+    geoms = GEOMS + [GEOMS[0]]  # one layer twice: two items on different tensors
+    items = (N.LokrConvWgradItem * len(geoms))()
+    keep, want = [], []
+    for k, geom in enumerate(geoms):
+        B, H, W, a, c, d, kk, s, p, dl = geom
+        taps = kk * kk
+        Ho, Wo = (H + 2 * p - dl * (kk - 1) - 1) // s + 1, (W + 2 * p - dl * (kk - 1) - 1) // s + 1
+        gen = torch.Generator().manual_seed(sum(geom) + 31 * k)
+        x, x64 = rnd((B, a * d, H, W), dtype, gen)
+        g, g64 = rnd((B, a * c, Ho, Wo), dtype, gen, 1.0 / np.sqrt(a * c))
+        w1, w1_64 = rnd((a, a), torch.float32, gen, 0.3)
+        w2, w2_64 = rnd((c, d, kk, kk), torch.float32, gen, 0.1)
+        geo = (B, H, W, a, a, c, d, kk, kk, s, s, p, p, dl, dl)
+        x_rows = x.permute(0, 2, 3, 1).reshape(B * H * W, a * d).contiguous()
+        g_rows = g.permute(0, 2, 3, 1).reshape(B * Ho * Wo, a * c).contiguous()
+        dx_rows = torch.empty_like(x_rows)
+        dw1 = torch.zeros(a, a, device=dev())
+        dw2p = torch.zeros(c, taps, d, device=dev())
+        ws = torch.empty(max(int(lib.lyc_lokr_conv2d_bwd_workspace_bytes(B, H, W, a, a, d)), 16), dtype=torch.uint8, device=dev())
+        with_planes = int(lib.lyc_lokr_conv2d_planes_ok(*geo, code, 1) != 0)
+        if with_planes:
+            pb = torch.empty(int(lib.lyc_lokr_planes_bytes(c, d, taps, 1)), dtype=torch.uint8, device=dev())
+            N.call("lyc_lokr_pack_w2", N.ptr(w2), w2.stride(0), w2.stride(1), w2.stride(3), None, 0, 0, None, 0, 0, 0, 0, c, d, taps, None,
+                   N.ptr(pb), code, N.stream_ptr(dev()))
+            N.call("lyc_lokr_conv2d_bwd_planes", N.ptr(g_rows), N.ptr(x_rows), N.ptr(w1), None, N.ptr(pb), N.ptr(dx_rows), N.ptr(dw1), None,
+                   N.ptr(ws), *geo, 0.5, code | 0x200, N.stream_ptr(dev()))
+            keep.append(pb)
+        else:
+            w2p = w2.permute(0, 2, 3, 1).contiguous()
+            N.call("lyc_lokr_conv2d_bwd", N.ptr(g_rows), N.ptr(x_rows), N.ptr(w1), N.ptr(w2p), None, N.ptr(dx_rows), N.ptr(dw1), None,
+                   N.ptr(ws), *geo, 0.5, code | 0x200, N.stream_ptr(dev()))
+            keep.append(w2p)
+        blocks = int(lib.lyc_lokr_conv2d_dx_blocks(*geo, code, with_planes))
+        items[k] = N.LokrConvWgradItem(N.ptr(g_rows), N.ptr(x_rows), N.ptr(w1), N.ptr(dw1), N.ptr(dw2p), N.ptr(ws), B, H, W, blocks,
+                                       a, a, c, d, kk, kk, s, s, p, p, dl, dl, 0.5)
+        keep += [x_rows, g_rows, dx_rows, ws, w1]
+        gr = oracle.lokr.backward(x64, g64, w1=w1_64, w2=w2_64, scale=0.5, kshape=(kk, kk), conv_args={"stride": s, "padding": p, "dilation": dl})
+        want.append((geom, dw1, dw2p, gr, (c, kk, d)))
+    N.call("lyc_lokr_conv_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(geoms), code, N.stream_ptr(dev()))
+    torch.cuda.synchronize()
+    for k, (geom, dw1, dw2p, gr, (c, kk, d)) in enumerate(want):
+        errs = {"dw1": err(dw1, gr["w1"]), "dw2": err(dw2p.view(c, kk, kk, d).permute(0, 3, 1, 2), gr["w2"])}
+        check(f"conv_wgrad_group[{k},{geom},{dtype},{kernel}]", errs, {"dw1": TOL["f32_out"][dtype], "dw2": TOL["f32_out"][dtype]})
+
+
+def test_conv_module_grads_complete_when_backward_returns():
+    """Conv2d LoKr layers in the training configuration (.grad buffers exist, fused accumulation): the dx launch runs inside the
+    backward pass, the weight gradients of all parked conv layers in the grouped launch at its end -- .grad must be complete and
+    equal to the per-layer path when backward() returns; every parameter is reported once."""
+    import torch.nn as nn
+    from lycoris_amd import ops
+    torch.manual_seed(11)
+    w1s = [nn.Parameter(torch.randn(8, 8, device=dev()) * 0.3) for _ in range(3)]
+    w2s = [nn.Parameter((torch.randn(16, 16, 3, 3, device=dev()) * 0.1).contiguous(memory_format=torch.channels_last)) for _ in range(3)]
+    params = w1s + w2s
+    x = (torch.randn(2, 128, 12, 12, device=dev()) * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = (torch.randn(2, 128, 12, 12, device=dev()) * 0.1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def run(defer):
+        seen = []
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        x.grad = None
+        ops.fused_grad_accumulation(True, callback=lambda p: seen.append(id(p)))
+        ops.deferred_weight_gradients(defer, 48)
+        try:
+            h = x
+            for w1, w2 in zip(w1s, w2s):
+                h = h + ops.lokr_conv2d(h, w1, w2, 0.5, (1, 1), (1, 1), (1, 1))
+            h.backward(gy)
+            assert ops._DISPATCH["ext"].deferred_pending() == 0
+            torch.cuda.synchronize()
+            return x.grad.clone(), [p.grad.clone() for p in params], seen
+        finally:
+            ops.fused_grad_accumulation(False, None)
+            ops.deferred_weight_gradients(True, 48)
+
+    dx0, g0, seen0 = run(False)
+    dx1, g1, seen1 = run(True)
+    assert torch.equal(dx0, dx1)
+    for u, v in zip(g0, g1):
+        assert float(u.abs().max()) > 0 and torch.allclose(u, v, rtol=3e-4, atol=1e-6), float((u - v).abs().max())
+    assert sorted(seen0) == sorted(seen1) == sorted(id(p) for p in params)
