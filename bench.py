@@ -58,6 +58,8 @@ def parse():
                          "the NHWC row matrices are then free views, no transposes")
     ap.add_argument("--no-defer", action="store_true",
                     help="A/B: one LoKr weight-gradient launch per layer instead of the grouped launches")
+    ap.add_argument("--no-planes", action="store_true",
+                    help="A/B: no pre-packed LoKr operand planes (every workgroup converts its fp32 w2 tile, as in rounds 1-2)")
     ap.add_argument("--no-reference", action="store_true", help="skip the PyTorch-ROCm eager comparator leg")
     ap.add_argument("--no-base", action="store_true", help="skip the base+adapter leg")
     ap.add_argument("--shared-inputs", action="store_true",
@@ -280,9 +282,11 @@ def main():
     all_params = [p for it in insts for p in it.params]
     sync = AdapterGradSync(all_params, bucket_bytes=32 << 20)
     sync.attach_fused()  # kernels accumulate into the arena and report to the bucket counters (eager: overlap by hooks)
+    from lycoris_amd import ops as _ops
     if args.no_defer:  # A/B: one weight-gradient launch per layer instead of the grouped launches
-        from lycoris_amd import ops as _ops
         _ops.deferred_weight_gradients(False)
+    if args.no_planes:
+        _ops.lokr_planes_cache(False)
     opt = torch.optim.AdamW(all_params, lr=1e-4, fused=True)
     n_layers = len(insts)
     act_bytes = sum(t.numel() * t.element_size() for it in insts for t in {id(it.x): it.x, id(it.g): it.g}.values())
@@ -319,6 +323,9 @@ def main():
         with torch.cuda.graph(g_fwd, pool=pool):
             for arena in sync.arenas.values():
                 arena.zero_()
+            # the optimizer changed every factor: repack the cached LoKr operand planes (one grouped launch per 28 factors) --
+            # part of the step, captured here so that every replay packs the parameters of ITS step
+            _ops.refresh_lokr_planes(force=True)
             outs = forward_all(insts)
         nseg = max(1, min(args.segments if world > 1 else 1, n_layers))
         edges = [round(i * n_layers / nseg) for i in range(nseg + 1)]
@@ -497,13 +504,35 @@ def roofline(insts, args, dtype, dev):
         flops += 3 * 2 * M * O * I
     saved = {}
 
+    # LoKr: the production launches read pre-packed operand planes (one set per layer, refreshed once per step by grouped
+    # pack launches that are part of the timed step but not of this kernel family)
+    planes = {}
+    use_planes = lin[0].algo == "lokr" and not args.no_planes and dtype != torch.float32
+    if use_planes:
+        from lycoris_amd import _native as N_
+        code_ = N_.dtype_code(dtype)
+        for it, rows, g, fs, bufs in calls:
+            (a, b), (c, d) = fs[0].shape, fs[1].shape
+            nf = int(N_.load().lyc_lokr_planes_bytes(c, d, 1, 0))
+            pl = torch.empty(nf + int(N_.load().lyc_lokr_planes_bytes(c, d, 1, 1)), dtype=torch.uint8, device=dev)
+            N_.call("lyc_lokr_pack_w2", N_.ptr(fs[1]), d, 1, 0, None, 0, 0, None, 0, 0, 0, 0, c, d, 1, N_.ptr(pl), N_.ptr(pl[nf:]), code_,
+                    N_.stream_ptr(dev))
+            planes[id(it)] = (pl, pl[nf:])
+
     def fwd():
         if core is None:  # ia3
             for it in lin:
                 saved[id(it)] = it.forward()
             return
         for it, rows, g, fs, bufs in calls:
-            saved[id(it)] = core.fwd(rows, fs, 1.0)
+            if use_planes:
+                (a, b), (c, d) = fs[0].shape, fs[1].shape
+                y = torch.empty(rows.shape[0], a * c, dtype=dtype, device=dev)
+                N_.call("lyc_lokr_linear_fwd_planes", N_.ptr(rows), N_.ptr(fs[0]), N_.ptr(planes[id(it)][0]), None, N_.ptr(y), rows.shape[0],
+                        a, b, c, d, 1.0, code_, N_.stream_ptr(dev))
+                saved[id(it)] = (y, ())
+            else:
+                saved[id(it)] = core.fwd(rows, fs, 1.0)
 
     def bwd():
         if core is None:
@@ -588,8 +617,12 @@ def roofline(insts, args, dtype, dev):
         def only_dx():
             for k, (it, rows, g, fs, bufs) in enumerate(calls):
                 (a, b), (c, d) = fs[0].shape, fs[1].shape
-                N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(dxs[k]), N.ptr(bufs[0]),
-                       None, N.ptr(wss[k]), rows.shape[0], a, b, c, d, 1.0, code | 0x200, N.stream_ptr(dev))
+                if use_planes:
+                    N.call("lyc_lokr_linear_bwd_planes", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(planes[id(it)][1]), N.ptr(dxs[k]),
+                           N.ptr(bufs[0]), None, N.ptr(wss[k]), rows.shape[0], a, b, c, d, 1.0, code | 0x200, N.stream_ptr(dev))
+                else:
+                    N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(dxs[k]), N.ptr(bufs[0]),
+                           None, N.ptr(wss[k]), rows.shape[0], a, b, c, d, 1.0, code | 0x200, N.stream_ptr(dev))
 
         def grouped_wgrad():
             N.call("lyc_lokr_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(calls), code, N.stream_ptr(dev))
@@ -611,7 +644,9 @@ def roofline(insts, args, dtype, dev):
         out["families_ms"] = {"kron3_forward": round(t_fwd, 3), "kron3_backward_dx_dw1": round(t_dx, 3),
                               "kron_dw2s_grouped": round(t_wg, 3), "kron_dw2s_one_launch_per_layer": round(t_dw2, 3),
                               "backward_one_call_per_layer": round(t_bwd, 3)}
-        out.update({"kernel": "lyc::kron3_kernel (LoKr forward + backward dx / dW1 launches of the Linear layers); the weight "
+        out.update({"operand_planes": bool(use_planes),
+                    "kernel": "lyc::kron3_kernel (LoKr forward + backward dx / dW1 launches of the Linear layers"
+                              + (", w2 from pre-packed hi/lo planes by LDS-DMA" if use_planes else "") + "); the weight "
                               "gradients run grouped (lyc::kron_dw2s_group_kernel, 24 layers per launch, re-reads g and x): "
                               "families_ms",
                     "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),

@@ -53,10 +53,14 @@ def backward_range(outs, lo, hi):
 
 
 def main():
+    # diagnostics: --no-pg (no process group at all: the capture logic alone), --skip-eager (captured phase only),
+    # --eager-only (what tests/test_gpu_grad_sync.py runs by default: see its docstring)
+    no_pg, skip_eager, eager_only = "--no-pg" in sys.argv, "--skip-eager" in sys.argv, "--eager-only" in sys.argv
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", device_id=DEV)
-    assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
-    print("nccl process group up", flush=True)
+    if not no_pg:
+        dist.init_process_group("nccl", device_id=DEV)
+        assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
+        print("nccl process group up", flush=True)
     gen = torch.Generator(device=DEV).manual_seed(7)
     shapes = [("lokr", 256, 640, 640), ("locon", 256, 640, 1280), ("lokr", 64, 1280, 640), ("locon", 77, 2048, 640)] * 6
     layers = [Layer(a, M, I, O, gen) for a, M, I, O in shapes]
@@ -87,21 +91,25 @@ def main():
         return worst
 
     # ---- eager: collectives launched from inside the backward by the fused-accumulation callback -------------------------
-    sync = AdapterGradSync(params, bucket_bytes=256 << 10, always_reduce=True)  # several buckets
+    sync = AdapterGradSync(params, bucket_bytes=256 << 10, always_reduce=not no_pg)  # several buckets
     assert len(sync.buckets) >= 3, len(sync.buckets)
     print(f"{len(sync.buckets)} buckets", flush=True)
     sync.attach_fused()
     try:
-        for rep in range(2):
+        for rep in range(0 if skip_eager else 2):
             sync.zero_grad()
             outs = [(l.forward(), l) for l in layers]
             backward_range(outs, 0, len(layers))
             launched_in_backward = len(sync.launch_log)
             sync.finish()
             e = check(f"eager step {rep}")
-        assert launched_in_backward == len(sync.buckets), (launched_in_backward, len(sync.buckets))
-        print(f"eager: {len(sync.buckets)} buckets all-reduced (AVG, side stream) from inside the backward, rel-err {e:.1e}", flush=True)
+        if not skip_eager:
+            assert launched_in_backward == len(sync.buckets), (launched_in_backward, len(sync.buckets))
+            print(f"eager: {len(sync.buckets)} buckets all-reduced (AVG, side stream) from inside the backward, rel-err {e:.1e}", flush=True)
 
+        if eager_only:
+            print("rccl-ws1 ok (eager only)", flush=True)
+            return
         # ---- captured: forward graph + backward segment graphs, launch_ready() between the replays (bench.py's N > 1 step) ---
         torch.cuda.synchronize()
         time.sleep(1.0)  # every collective of the eager steps has been retired by RCCL's watchdog thread before the capture starts
@@ -139,8 +147,9 @@ def main():
     finally:
         sync.attach_fused(False)
         sync.remove()
-    dist.destroy_process_group()
-    print("rccl-ws1 ok")
+        if not no_pg and dist.is_initialized():
+            dist.destroy_process_group()
+    print("rccl-ws1 ok", flush=True)
 
 
 if __name__ == "__main__":

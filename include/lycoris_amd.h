@@ -149,6 +149,26 @@ int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1,
  * {4, 8, 16}, c % 8 == d % 8 == 0, the patch + operand ring within 160 KiB of LDS; backward: stride 1); a refused call
  * returns LYC_ERR_UNSUPPORTED and does nothing.  In lyc_lokr_conv2d_bwd_planes `w2p` may be NULL when the geometry is
  * covered (it is only the fallback operand); dw2p is computed as by lyc_lokr_conv2d_bwd. */
+/* The same planes serve nn.Linear (taps = 1: planes_fwd n = q, k = v for y; planes_bwd n = v, k = q for dx): the *_planes forms of
+ * lyc_lokr_linear_fwd / _bwd take them instead of the fp32 w2, so that the workgroups of the row kernel (csrc/kron3.h) no longer
+ * convert their w2 tile themselves (a fifth of a workgroup's instruction chain) but stream the planes into LDS by LDS-DMA.
+ * 16-bit fast path only (lyc_lokr_linear_planes_ok: a == b dividing 16, c % 8 == d % 8 == 0, 16-bit dtype; the activation
+ * pointers 16-byte aligned); dw2 is computed from g and x alone, as before (also by lyc_lokr_wgrad_group).
+ * lyc_lokr_pack_group refreshes the planes of MANY layers in one launch per 28 factors (full matrices, any strides): the
+ * once-per-optimizer-step form. */
+typedef struct LycLokrPackItem {
+  const float* w2;     /* element (q, v, tap) at q*sq + v*sv + tap*st */
+  int64_t sq, sv, st;
+  int c, d, taps;
+  void* planes_fwd;    /* lyc_lokr_planes_bytes(c, d, taps, 0) bytes, or NULL */
+  void* planes_bwd;    /* lyc_lokr_planes_bytes(c, d, taps, 1) bytes, or NULL */
+} LycLokrPackItem;
+int lyc_lokr_pack_group(const LycLokrPackItem* items, int n, int dtype, void* stream);
+int lyc_lokr_linear_planes_ok(int64_t M, int a, int b, int c, int d, int dtype);
+int lyc_lokr_linear_fwd_planes(const void* x, const float* w1, const void* planes_fwd, const void* base, void* y, int64_t M, int a,
+                               int b, int c, int d, float alpha, int dtype, void* stream);
+int lyc_lokr_linear_bwd_planes(const void* g, const void* x, const float* w1, const void* planes_bwd, void* dx, float* dw1,
+                               float* dw2, void* ws, int64_t M, int a, int b, int c, int d, float alpha, int dtype, void* stream);
 int64_t lyc_lokr_planes_bytes(int c, int d, int taps, int backward);
 int lyc_lokr_pack_w2(const float* w2, int64_t sq, int64_t sv, int64_t st, const float* w2a, int64_t a_sq, int64_t a_sr,
                      const float* w2b, int64_t b_sr, int64_t b_sv, int64_t b_st, int rank, int c, int d, int taps,

@@ -30,6 +30,9 @@ SIGNATURES = {
     "lyc_lokr_conv2d_fwd": [_vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_lokr_conv2d_bwd": [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_lokr_conv_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LokrConvWgradItem
+    "lyc_lokr_pack_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LokrPackItem
+    "lyc_lokr_linear_fwd_planes": [_vp, _fp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    "lyc_lokr_linear_bwd_planes": [_vp, _vp, _fp, _vp, _vp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_lokr_pack_w2": [_fp, _i64, _i64, _i64, _fp, _i64, _i64, _fp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
     "lyc_lokr_conv2d_fwd_planes": [_vp, _fp, _vp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_lokr_conv2d_bwd_planes": [_vp, _vp, _fp, _fp, _vp, _vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
@@ -60,6 +63,7 @@ VALUE_SIGNATURES = {
     "lyc_lokr_bwd_workspace_bytes": ([_i64, _i32, _i32, _i32, _i32, _i32], ctypes.c_int64),
     "lyc_lokr_conv2d_bwd_workspace_bytes": ([_i64, _i64, _i64, _i32, _i32, _i32], ctypes.c_int64),
     "lyc_lokr_planes_bytes": ([_i32, _i32, _i32, _i32], ctypes.c_int64),
+    "lyc_lokr_linear_planes_ok": ([_i64, _i32, _i32, _i32, _i32, _i32], ctypes.c_int),
     "lyc_lokr_conv2d_dx_blocks": ([_i64, _i64, _i64] + [_i32] * 14, ctypes.c_int64),
     "lyc_lokr_conv2d_planes_ok": ([_i64, _i64, _i64] + [_i32] * 14, ctypes.c_int),
     "lyc_lokr_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32], ctypes.c_int),  # 1 / 0, not an error code
@@ -78,6 +82,12 @@ class LoconWgradItem(ctypes.Structure):
     """LycLoconWgradItem (include/lycoris_amd.h)"""
     _fields_ = [("g", _vp), ("x", _vp), ("t", _vp), ("dt", _vp), ("d_down", _vp), ("d_up", _vp), ("M", _i64),
                 ("I", _i32), ("O", _i32), ("r", _i32), ("alpha", _f32)]
+
+
+class LokrPackItem(ctypes.Structure):
+    """LycLokrPackItem (include/lycoris_amd.h)"""
+    _fields_ = [("w2", _vp), ("sq", _i64), ("sv", _i64), ("st", _i64), ("c", _i32), ("d", _i32), ("taps", _i32), ("planes_fwd", _vp),
+                ("planes_bwd", _vp)]
 
 
 class LokrConvWgradItem(ctypes.Structure):

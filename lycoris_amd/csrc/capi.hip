@@ -69,6 +69,12 @@ void launch_kron3_inst2(const KronArgs& ka, dim3 grid, hipStream_t st) {
                                 : (ka.gat.mode ? ka.gat.taps : 1) * cdiv(ka.K, kron3_kc(NI));
   const int xs = GATHER == 3 ? kron3_xs_bytes() : 0;  // per-wave x tiles behind the w2 tiles
   const int lds = kron3_lds_bytes(NI, nseg > 1 ? 2 : 1) + xs;
+  if constexpr (GATHER == 0 || GATHER == 3) {
+    if (ka.w2p != nullptr) {  // pre-packed operand planes: the PL instantiation (same LDS footprint)
+      hipLaunchKernelGGL((kron3_kernel<T, NI, DW1, GATHER, BASE, true>), grid, dim3(NTHREADS), lds, st, ka);
+      return;
+    }
+  }
   if (lds > 64 * 1024) {  // more than the default dynamic-LDS window: opt in once per instantiation
     static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&kron3_kernel<T, NI, DW1, GATHER, BASE>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kron3_lds_bytes(NI, 2) + xs);
@@ -516,13 +522,90 @@ extern "C" {
 int lyc_abi_version(void) { return LYC_ABI_VERSION; }
 const char* lyc_last_error(void) { return g_err; }
 
+extern "C++" {
+namespace {
+int lokr_linear_fwd_impl(const void* x, const float* w1, const float* w2, const void* planes, const void* base, void* y, int64_t M,
+                         int a, int b, int c, int d, float alpha, int dtype, void* stream);
+int lokr_linear_bwd_impl(const void* g, const void* x, const float* w1, const float* w2, const void* planes, void* dx, float* dw1,
+                         float* dw2, void* ws, int64_t M, int a, int b, int c, int d, float alpha, int dtype, void* stream);
+// the planes serve the 16-bit fast path (kron3, plain rows) only
+bool lokr_planes_usable(const void* act, int64_t M, int a, int b, int c, int d, int dtype) {
+  const int dt = dtype & 0xff;
+  return (dt == LYC_BF16 || dt == LYC_F16) && a == b && a >= 1 && (16 % a) == 0 && (c % 8) == 0 && (d % 8) == 0 && M > 0 &&
+         (reinterpret_cast<uintptr_t>(act) & 15u) == 0;
+}
+}  // namespace
+}  // extern "C++"
+
+int lyc_lokr_linear_planes_ok(int64_t M, int a, int b, int c, int d, int dtype) {
+  static const int dummy = 0;
+  (void)dummy;
+  return lokr_planes_usable(nullptr, M, a, b, c, d, dtype) ? 1 : 0;
+}
+
 int lyc_lokr_linear_fwd(const void* x, const float* w1, const float* w2, const void* base, void* y, int64_t M, int a, int b,
                         int c, int d, float alpha, int dtype, void* stream) {
+  return lokr_linear_fwd_impl(x, w1, w2, nullptr, base, y, M, a, b, c, d, alpha, dtype, stream);
+}
+
+int lyc_lokr_linear_fwd_planes(const void* x, const float* w1, const void* planes_fwd, const void* base, void* y, int64_t M, int a,
+                               int b, int c, int d, float alpha, int dtype, void* stream) {
+  if (!planes_fwd) return fail(LYC_ERR_ARG, "lokr_linear_fwd_planes: null planes");
+  if (!lokr_planes_usable(x, M, a, b, c, d, dtype))
+    return fail(LYC_ERR_UNSUPPORTED, "lokr_linear_fwd_planes: the planes serve the 16-bit fast path only (lyc_lokr_linear_planes_ok)");
+  return lokr_linear_fwd_impl(x, w1, nullptr, planes_fwd, base, y, M, a, b, c, d, alpha, dtype, stream);
+}
+
+int lyc_lokr_linear_bwd_planes(const void* g, const void* x, const float* w1, const void* planes_bwd, void* dx, float* dw1,
+                               float* dw2, void* ws, int64_t M, int a, int b, int c, int d, float alpha, int dtype, void* stream) {
+  if (!planes_bwd) return fail(LYC_ERR_ARG, "lokr_linear_bwd_planes: null planes");
+  if (!lokr_planes_usable(g, M, a, b, c, d, dtype))
+    return fail(LYC_ERR_UNSUPPORTED, "lokr_linear_bwd_planes: the planes serve the 16-bit fast path only (lyc_lokr_linear_planes_ok)");
+  return lokr_linear_bwd_impl(g, x, w1, nullptr, planes_bwd, dx, dw1, dw2, ws, M, a, b, c, d, alpha, dtype, stream);
+}
+
+// one pack launch for MANY layers (Linear or Conv2d factors given as full matrices): the once-per-optimizer-step refresh
+int lyc_lokr_pack_group(const LycLokrPackItem* items, int n, int dtype, void* stream) {
+  if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "lokr_pack_group: bad item list");
+  const int dt = dtype & 0xff;
+  if (n > 0 && dt != LYC_BF16 && dt != LYC_F16) return fail(LYC_ERR_UNSUPPORTED, "lokr_pack_group: 16-bit planes only");
+  KronPackGroupArgs ga{};
+  auto flush = [&]() -> int {
+    if (ga.n == 0) return LYC_OK;
+    const dim3 grid((unsigned)cdiv(ga.unit_end[ga.n - 1], NWAVES));
+    if (dt == LYC_BF16) hipLaunchKernelGGL((kron_pack_group_kernel<__bf16>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, ga);
+    else hipLaunchKernelGGL((kron_pack_group_kernel<_Float16>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, ga);
+    ga = KronPackGroupArgs{};
+    return check_launch("lokr_pack_group");
+  };
+  for (int k = 0; k < n; ++k) {
+    const LycLokrPackItem& it = items[k];
+    if (!it.w2 || it.c < 1 || it.d < 1 || it.taps < 1 || (it.c % 8) != 0 || (it.d % 8) != 0)
+      return fail(LYC_ERR_ARG, "lokr_pack_group: item %d: bad factor (c, d must be positive multiples of 8)", k);
+    if (!it.planes_fwd && !it.planes_bwd) continue;
+    if (ga.n == KPG_MAX)
+      if (int rc = flush()) return rc;
+    KronPackArgs& pa = ga.p[ga.n];
+    pa = KronPackArgs{};
+    pa.w2 = it.w2; pa.sq = it.sq; pa.sv = it.sv; pa.st = it.st; pa.c = it.c; pa.d = it.d; pa.taps = it.taps;
+    pa.fwd = it.planes_fwd; pa.bwd = it.planes_bwd;
+    pa.units_fwd = kron_plane_bytes(it.c, it.taps, it.d) / 2048;
+    const long units = pa.units_fwd + kron_plane_bytes(it.d, it.taps, it.c) / 2048;
+    ga.unit_end[ga.n] = (ga.n ? ga.unit_end[ga.n - 1] : 0) + round_up(units, NWAVES);
+    ++ga.n;
+  }
+  return flush();
+}
+
+extern "C++" {
+namespace {
+int lokr_linear_fwd_impl(const void* x, const float* w1, const float* w2, const void* planes, const void* base, void* y, int64_t M,
+                         int a, int b, int c, int d, float alpha, int dtype, void* stream) {
   if (int rc = check_kron_dims(M, a, b, c, d)) return rc;
-  if (!x || !w1 || !w2 || !y) return fail(LYC_ERR_ARG, "lokr_linear_fwd: null pointer");
+  if (!x || !w1 || (!w2 && !planes) || !y) return fail(LYC_ERR_ARG, "lokr_linear_fwd: null pointer");
   if (M == 0) return LYC_OK;
   KronArgs ka{};
-  ka.x = x; ka.y = y; ka.w1 = w1; ka.w2 = w2; ka.dw1 = nullptr; ka.xref = nullptr; ka.base = base;
+  ka.x = x; ka.y = y; ka.w1 = w1; ka.w2 = w2; ka.w2p = planes; ka.dw1 = nullptr; ka.xref = nullptr; ka.base = base;
   if (base) {  // fused `y = base + delta` lives in the epilogue of the 16-bit kron3 kernel only
     ka.M = M; ka.Gin = b; ka.K = d; ka.Gout = a; ka.N = c;
     const bool fast = ((dtype & 0xff) == LYC_BF16 && kron_fast_ok<__bf16>(ka)) || ((dtype & 0xff) == LYC_F16 && kron_fast_ok<_Float16>(ka));
@@ -535,6 +618,8 @@ int lyc_lokr_linear_fwd(const void* x, const float* w1, const float* w2, const v
   DISPATCH_DTYPE(dtype, launch_kron<T>(ka, (hipStream_t)stream));
   return check_launch("lokr_linear_fwd");
 }
+}  // namespace
+}  // extern "C++"
 
 int64_t lyc_lokr_bwd_workspace_bytes(int64_t M, int a, int b, int c, int d, int dtype) {
   (void)c; (void)dtype;
@@ -546,8 +631,15 @@ int64_t lyc_lokr_bwd_workspace_bytes(int64_t M, int a, int b, int c, int d, int 
 int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const float* w2, void* dx, float* dw1,
                         float* dw2, void* ws, int64_t M, int a, int b, int c, int d, float alpha, int dtype,
                         void* stream) {
+  return lokr_linear_bwd_impl(g, x, w1, w2, nullptr, dx, dw1, dw2, ws, M, a, b, c, d, alpha, dtype, stream);
+}
+
+extern "C++" {
+namespace {
+int lokr_linear_bwd_impl(const void* g, const void* x, const float* w1, const float* w2, const void* planes, void* dx, float* dw1,
+                         float* dw2, void* ws, int64_t M, int a, int b, int c, int d, float alpha, int dtype, void* stream) {
   if (int rc = check_kron_dims(M, a, b, c, d)) return rc;
-  if (!g || !x || !w1 || !w2) return fail(LYC_ERR_ARG, "lokr_linear_bwd: null pointer");
+  if (!g || !x || !w1 || (!w2 && !planes)) return fail(LYC_ERR_ARG, "lokr_linear_bwd: null pointer");
   if (M == 0) return LYC_OK;
   hipStream_t st = (hipStream_t)stream;
   const bool is16 = (dtype & 0xff) != LYC_F32;
@@ -559,7 +651,7 @@ int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const flo
     // with the w1 gradient taken from its stage-1 result (GZ) against x.
     if (!dx) return fail(LYC_ERR_ARG, "lokr_linear_bwd: dw1 requires dx (they share one pass over g)");
     KronArgs ka{};
-    ka.x = g; ka.y = dx; ka.w1 = w1; ka.w2 = w2; ka.dw1 = dw1; ka.xref = dw1 ? x : nullptr;
+    ka.x = g; ka.y = dx; ka.w1 = w1; ka.w2 = w2; ka.w2p = planes; ka.dw1 = dw1; ka.xref = dw1 ? x : nullptr;
     ka.dw1_ws = (dw1 && ws) ? static_cast<float*>(ws) : nullptr;
     ka.M = M; ka.Gin = a; ka.K = c; ka.Gout = b; ka.N = d;
     ka.s1o = 1; ka.s1i = b; ka.s2n = 1; ka.s2k = d; ka.alpha = alpha; ka.out_f32 = (dtype & LYC_F32_ROWS) ? 1 : 0;
@@ -620,6 +712,8 @@ int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const flo
   }
   return LYC_OK;
 }
+}  // namespace
+}  // extern "C++"
 
 // ---- deferred, grouped weight gradients (kron_dw2s_group_kernel) ------------------------------------------------
 extern "C++" {
@@ -1071,7 +1165,10 @@ namespace {
 bool plan_kd(const LycLokrConvWgradItem& it, const ConvDims& cd, KdItem& k) {
   const int G = it.a;
   if (it.a != it.b || (G != 4 && G != 8 && G != 16) || (it.c % 8) != 0 || (it.d % 8) != 0) return false;
-  if (getenv("LYC_CONV_DW2_ROWS")) return false;  // tests / A-B: force the row-gather kernel
+  // Measured (profiles/r03_c5_*): correct, but 5.9 ms per SDXL step against 2.2 ms for the grouped row-gather kernel -- its
+  // per-block address arithmetic (runtime divisions in a 168-way unrolled loop) issues ~8000 instructions per tile and wave.
+  // Kept as an opt-in (and under test) until that is table-driven; the row-gather kernel is the default.
+  if (!getenv("LYC_CONV_DW2_PATCH")) return false;
   k = KdItem{};
   k.g = it.g_rows; k.x = it.x_rows; k.w1 = it.w1; k.out = it.dw2p;
   k.B = (int)it.B; k.G = G; k.I = it.c; k.J = it.d;
@@ -1543,19 +1640,13 @@ size_t esize(int dtype) { return (dtype & 0xff) == LYC_F32 ? 4 : 2; }
 
 // LoHa's Hadamard product of two rank-r matrices is full rank: once the dW operand plane exists, the three contractions
 // (y = x dW^T, dx = g dW, G = g^T x) are plain dense GEMMs -- gemm16.h (rounds 1-2 called rocBLAS here).
-// 128 x 128 tiles, or 64 x 128 when that leaves fewer than ~200 workgroups (M = 1024 x N = 1280: 80 -> 160).
+// 64 x 128 output tiles: the 128 x 128 instantiation needs > 256 registers for the two-deep prefetch (one wave per SIMD, or
+// a compiler that serialises the pipeline to fit the cap) -- measured slower on this workload's M = 1024 ... 4096 problems.
 template <typename T, bool A_KS, bool B_KS>
-void launch_gemm16_group(const Gemm16Group& ga, int tm, hipStream_t st) {
+void launch_gemm16_group(const Gemm16Group& ga, hipStream_t st) {
   const dim3 grid((unsigned)ga.wg_end[ga.n - 1]);
-  if (tm == 128) {
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<T, 128, A_KS, B_KS>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm16_lds_bytes<128>()); once = true; }
-    hipLaunchKernelGGL((gemm16_kernel<T, 128, A_KS, B_KS>), grid, dim3(NTHREADS), gemm16_lds_bytes<128>(), st, ga);
-  } else {
-    hipLaunchKernelGGL((gemm16_kernel<T, 64, A_KS, B_KS>), grid, dim3(NTHREADS), gemm16_lds_bytes<64>(), st, ga);
-  }
+  hipLaunchKernelGGL((gemm16_kernel<T, G16_TM, A_KS, B_KS>), grid, dim3(NTHREADS), gemm16_lds_bytes<G16_TM>(), st, ga);
 }
-inline int gemm16_pick_tm(long M, long N) { return cdiv(M, 128) * cdiv(N, 128) >= 200 ? 128 : 64; }
 inline bool gemm16_ok(const Gemm16Prob& p, bool a_ks, bool b_ks) {
   const bool al = ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15u) == 0 && (p.lda % 8) == 0 && (p.ldb % 8) == 0;
   const bool kc = (a_ks && b_ks) || (p.K % 8) == 0;  // a K-contiguous operand is read in 16-byte vectors along K
@@ -1568,11 +1659,10 @@ template <typename T>
 void launch_gemm16(const Gemm16Prob& p, int mode, int out_f32, hipStream_t st) {
   Gemm16Group ga{};
   ga.n = 1; ga.out_f32 = out_f32; ga.p[0] = p;
-  const int tm = gemm16_pick_tm(p.M, p.N);
-  ga.wg_end[0] = (int)(cdiv(p.M, tm) * cdiv(p.N, 128));
-  if (mode == 0) launch_gemm16_group<T, false, false>(ga, tm, st);
-  else if (mode == 1) launch_gemm16_group<T, false, true>(ga, tm, st);
-  else launch_gemm16_group<T, true, true>(ga, tm, st);
+  ga.wg_end[0] = (int)(cdiv(p.M, G16_TM) * cdiv(p.N, 128));
+  if (mode == 0) launch_gemm16_group<T, false, false>(ga, st);
+  else if (mode == 1) launch_gemm16_group<T, false, true>(ga, st);
+  else launch_gemm16_group<T, true, true>(ga, st);
 }
 
 // HadaWeight.backward on a dense fp32 gradient G [O, I] (functional/loha.py:18-30): shared by the activation path
@@ -1772,8 +1862,8 @@ int lyc_loha_wgrad_group(const LycLohaWgradItem* items, int n, int dtype, void* 
     ga.out_f32 = 1;
     auto flush = [&]() -> int {
       if (ga.n == 0) return LYC_OK;
-      if (bf) launch_gemm16_group<__bf16, true, true>(ga, 128, st);
-      else launch_gemm16_group<_Float16, true, true>(ga, 128, st);
+      if (bf) launch_gemm16_group<__bf16, true, true>(ga, st);
+      else launch_gemm16_group<_Float16, true, true>(ga, st);
       ga = Gemm16Group{};
       ga.out_f32 = 1;
       return check_launch("loha_wgrad_group(G)");
@@ -1792,7 +1882,7 @@ int lyc_loha_wgrad_group(const LycLohaWgradItem* items, int n, int dtype, void* 
         else hipLaunchKernelGGL((gemm_tn_kernel<_Float16>), gg, dim3(NTHREADS), 0, st, ta);
         continue;
       }
-      const long wgs = cdiv(it.O, 128) * cdiv(it.I, 128);
+      const long wgs = cdiv(it.O, G16_TM) * cdiv(it.I, 128);
       if (ga.n == G16_MAX || (ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs > (1L << 30))
         if (int rc = flush()) return rc;
       ga.p[ga.n] = gp;

@@ -5,11 +5,11 @@
 //     y  = x  dW^T      [M, O] = [M, I] x [O, I]^T      A K-contiguous, B K-contiguous   ("NT")
 //     dx = g  dW        [M, I] = [M, O] x [O, I]        A K-contiguous, B K-strided      ("NN")
 //     G  = g^T x        [O, I] = [M, O]^T x [M, I]      A K-strided,   B K-strided      ("TN", fp32 out, up to 24 layers per launch)
-// One kernel template: 128 x 128 (or 64 x 128) output tile, BK = 64, four waves as 2 x 2, v_mfma_f32_16x16x32, fp32
+// One kernel template: 64 x 128 (or 128 x 128) output tile, BK = 64, four waves as 2 x 2, v_mfma_f32_16x16x32, fp32
 // accumulation.  Both operand tiles live K-contiguous in LDS ([row][64 + 8]: 144-byte pitch, ds_read_b128 fragments);
 // a K-contiguous operand is staged with 16-byte loads, a K-strided one as 4 (k) x 8 (row) register blocks transposed with
-// v_perm_b32 (tile.h stage_cols' scheme).  Software pipeline: the global loads of K tile t + 1 are issued before the MFMAs of
-// tile t and written to the other LDS buffer behind them -- one barrier per K tile.  All loads go through buffer
+// v_perm_b32 (tile.h stage_cols' scheme).  Software pipeline: the global loads of K tile t + 2 are issued before the MFMAs of
+// tile t (two register stages) and written to the other LDS buffer a tile later -- one barrier per K tile.  All loads go through buffer
 // descriptors: rows / columns beyond the matrix return zeros, no edge branches.  Output through an LDS image: 16-byte
 // coalesced stores of T or fp32.
 #pragma once
@@ -18,6 +18,7 @@
 namespace lyc {
 
 constexpr int G16_BK = 64;
+constexpr int G16_TM = 64;          // rows of the output tile the launchers use (the template also builds with 128)
 constexpr int G16_LD = G16_BK + 8;  // LDS pitch (elements): 144 bytes
 
 struct Gemm16Prob {
@@ -133,20 +134,23 @@ __device__ __forceinline__ void gemm16_body(const Gemm16Prob& p, int out_f32, ch
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = zero4();
 
-  G16Stage<TM, A_KS> sa;
-  G16Stage<TN, B_KS> sb;
+  // Software pipeline, prefetch distance TWO K tiles: the per-layer problems of this workload put ~1 workgroup on a CU, whose
+  // time is then the serial chain of its K loop -- with the loads of tile t + 1 issued only one tile of MFMAs (~500 cycles)
+  // ahead, every iteration waited out most of an L2 / HBM round trip (first version: 2.5x slower than the vendor library).
+  // Two register stages: tile t + 2 is requested into the stage that tile t has just left for LDS.
+  G16Stage<TM, A_KS> sa0, sa1;
+  G16Stage<TN, B_KS> sb0, sb1;
   const int nk = (p.K + G16_BK - 1) / G16_BK;
-  g16_load<T, TM, A_KS>(sa, ra, p.lda, m0, p.M, 0, p.K);
-  g16_load<T, TN, B_KS>(sb, rb, p.ldb, n0, p.N, 0, p.K);
-  g16_store<T, TM, A_KS>(sa, As[0]);
-  g16_store<T, TN, B_KS>(sb, Bs[0]);
+  g16_load<T, TM, A_KS>(sa0, ra, p.lda, m0, p.M, 0, p.K);
+  g16_load<T, TN, B_KS>(sb0, rb, p.ldb, n0, p.N, 0, p.K);
+  // (loads are UNCONDITIONAL: a tile beyond K is all out of range and comes back as zeros without memory traffic; a load under
+  // `if (kt + 2 < nk)` would make the stage a PHI of loaded / not loaded and hipcc then waits vmcnt(0) at the join)
+  g16_load<T, TM, A_KS>(sa1, ra, p.lda, m0, p.M, G16_BK, p.K);
+  g16_load<T, TN, B_KS>(sb1, rb, p.ldb, n0, p.N, G16_BK, p.K);
+  g16_store<T, TM, A_KS>(sa0, As[0]);
+  g16_store<T, TN, B_KS>(sb0, Bs[0]);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      g16_load<T, TM, A_KS>(sa, ra, p.lda, m0, p.M, (kt + 1) * G16_BK, p.K);
-      g16_load<T, TN, B_KS>(sb, rb, p.ldb, n0, p.N, (kt + 1) * G16_BK, p.K);
-    }
+  auto compute = [&](int cur) {
     const T* at = As[cur] + (wr * (TM / 2)) * G16_LD;
     const T* bt = Bs[cur] + (wc * 64) * G16_LD;
 #pragma unroll
@@ -161,10 +165,24 @@ __device__ __forceinline__ void gemm16_body(const Gemm16Prob& p, int out_f32, ch
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = TT<T>::mma(af[mi], bf[ni], acc[mi][ni]);
     }
-    if (kt + 1 < nk) {
-      g16_store<T, TM, A_KS>(sa, As[cur ^ 1]);
-      g16_store<T, TN, B_KS>(sb, Bs[cur ^ 1]);
-    }
+  };
+  // even tiles travel through stage 0 and LDS buffer 0, odd tiles through stage 1 and buffer 1 (two tiles per trip: static
+  // register indexing)
+  for (int kt = 0; kt < nk; kt += 2) {
+    // tile kt is in buffer 0; tile kt + 1 is in flight in stage 1; stage 0 is free
+    g16_load<T, TM, A_KS>(sa0, ra, p.lda, m0, p.M, (kt + 2) * G16_BK, p.K);
+    g16_load<T, TN, B_KS>(sb0, rb, p.ldb, n0, p.N, (kt + 2) * G16_BK, p.K);
+    compute(0);
+    g16_store<T, TM, A_KS>(sa1, As[1]);
+    g16_store<T, TN, B_KS>(sb1, Bs[1]);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    // tile kt + 1 is in buffer 1; tile kt + 2 is in flight in stage 0; stage 1 is free
+    g16_load<T, TM, A_KS>(sa1, ra, p.lda, m0, p.M, (kt + 3) * G16_BK, p.K);
+    g16_load<T, TN, B_KS>(sb1, rb, p.ldb, n0, p.N, (kt + 3) * G16_BK, p.K);
+    compute(1);
+    g16_store<T, TM, A_KS>(sa0, As[0]);
+    g16_store<T, TN, B_KS>(sb0, Bs[0]);
     __syncthreads();
   }
 
@@ -221,7 +239,7 @@ __device__ __forceinline__ void gemm16_body(const Gemm16Prob& p, int out_f32, ch
 }
 
 template <typename T, int TM, bool A_KS, bool B_KS>
-__global__ __launch_bounds__(NTHREADS) void gemm16_kernel(Gemm16Group ga) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm16_kernel(Gemm16Group ga) {  // two workgroups per CU (72 KB of LDS each)
   extern __shared__ __attribute__((aligned(16))) char g16_smem[];
   const int b = (int)blockIdx.x;
   int p = 0;

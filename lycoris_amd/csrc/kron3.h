@@ -201,9 +201,14 @@ __device__ __forceinline__ void k3_store_w2(T* __restrict__ Bh, T* __restrict__ 
 // 1), so segments are full K3_KC chunks however short the per-tap rows are (C = 320 convs have 40 columns per tap).
 // `after_loads()` is invoked once, right behind the issue of the first chunk's w2 and x loads: the place for loads the
 // caller needs only after stage 1 (vector-memory results return in issue order, so they must not precede the w2 loads).
-template <typename T, int NI, int GM, typename Hook>
+// PL (round 3): the w2 operand comes from PRE-PACKED hi / lo planes (kron_conv.h: fragment-major units of 2 KiB per (n tile, k
+// step), written once per optimizer step by lyc_lokr_pack_w2 / _pack_group) streamed into the LDS tile by LDS-DMA: no fp32 loads,
+// no conversion (~1900 of a workgroup's ~10000 cycles, profiles/r02_ktrace_kron3_phases.log), no ds_write, lane-linear
+// conflict-free fragment reads.  Plain-row modes only (GM = 0 / 3); the chunk / double-buffer structure is unchanged.
+template <typename T, int NI, int GM, bool PL, typename Hook>
 __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long row0, long rows_end, long n0,
                                           f32x4 (&acc)[2][NI], Hook&& after_loads) {
+  static_assert(!PL || GM == 0 || GM == 3, "packed planes: plain-row kernels only");
   constexpr bool GATHER = GM == 1 || GM == 2;
   constexpr bool FLAT = GM == 2;
   constexpr bool XS = GM == 3;  // plain rows, x through the per-wave LDS stage (quad-coalesced loads)
@@ -330,7 +335,28 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
   // The w2 loads go out FIRST: vector-memory results return in issue order, and the w2 tile is on the critical path
   // (convert -> LDS -> barrier -> first MFMA) while the x fragments are only needed at the MFMAs.  Issued behind the ten
   // x loads (HBM) the L2-resident w2 data could not be touched before all of x had arrived.
-  k3_load_w2<TQ, K3_KC>(raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, Kloop, a.x);
+  // PL: unit (n tile nt, k step ks) of the planes lives at ((nt * ksteps + ks) * 2 + {hi, lo}) KiB; a chunk's image in LDS is
+  // [ni][ks][hi | lo][64 lanes][16 B] (piece p = (ni * K3_KS + ks) * 2 + half at p KiB), filled by 1 KiB LDS-DMA pieces
+  const char* planes = static_cast<const char*>(a.w2p);
+  const int pl_ksteps = (K + 31) >> 5;
+  const int pl_ntiles = (N + 15) >> 4;
+  auto issue_planes = [&](long k0c, char* dst) {
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ks0 = (int)(k0c >> 5);
+    for (int p = wv; p < 2 * NI * K3_KS; p += NWAVES) {
+      const int unit = p >> 1, half = p & 1;
+      const int ni = unit / K3_KS, kk = unit - ni * K3_KS;
+      long nt = n0 / 16 + ni;
+      if (nt >= pl_ntiles) nt = pl_ntiles - 1;  // beyond N: a valid duplicate, its columns are never stored
+      if (ks0 + kk < pl_ksteps) {
+        const char* src = planes + ((nt * pl_ksteps + ks0 + kk) * 2 + half) * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+      }
+    }
+  };
+  if constexpr (PL) issue_planes(0, smem);
+  else k3_load_w2<TQ, K3_KC>(raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, Kloop, a.x);
   LR3_FENCE();
   // XS: this lane's piece of a k-step: rows (lane >> 2) and (lane >> 2) + 16 of the wave's 32, columns 8 (lane & 3) .. + 7
   const int xs_r = lane >> 2, xs_c = 8 * (lane & 3);
@@ -381,7 +407,8 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = zero4();
 
   LYC_STAMP_DIRECT(1);  // all loads of the first chunk issued
-  k3_store_w2<T, TQ, K3_KC>(Bbase, Bbase + PLANE, raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, Kloop);
+  if constexpr (PL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+  else k3_store_w2<T, TQ, K3_KC>(Bbase, Bbase + PLANE, raw, w2mode, a.w2, a.s2n, a.s2k, n0, N, 0, Kloop);
   LYC_STAMP_DIRECT(2);  // w2 data arrived, converted, written to LDS
   __syncthreads();
   LYC_STAMP_DIRECT(3);  // first barrier passed
@@ -413,8 +440,14 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
         F8 bh[NI], bl[NI];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          bh[ni] = *reinterpret_cast<const F8*>(Bh + (16 * ni + li) * K3_LDB + kofs);
-          bl[ni] = *reinterpret_cast<const F8*>(Bl + (16 * ni + li) * K3_LDB + kofs);
+          if constexpr (PL) {  // Bh = this chunk's image: lane-linear units
+            const char* up = reinterpret_cast<const char*>(Bh) + ((ni * K3_KS + ks) * 2) * 1024 + lane * 16;
+            bh[ni] = *reinterpret_cast<const F8*>(up);
+            bl[ni] = *reinterpret_cast<const F8*>(up + 1024);
+          } else {
+            bh[ni] = *reinterpret_cast<const F8*>(Bh + (16 * ni + li) * K3_LDB + kofs);
+            bl[ni] = *reinterpret_cast<const F8*>(Bl + (16 * ni + li) * K3_LDB + kofs);
+          }
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -477,10 +510,12 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
         row_src(1, ntap, np1, nv1);
       }
       const float* w2n = (GATHER && !FLAT) ? a.w2 + (long)ntap * a.gat.s2t : a.w2;
-      k3_load_w2<TQ, K3_KC>(raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, Kloop, a.x);
-      run_chunk(nks, std::true_type{}, Bh, Bl, np0, nv0, np1, nv1, nk0, k0);
       T* Nh = Bbase + (buf ^ 1) * 2 * PLANE;
-      k3_store_w2<T, TQ, K3_KC>(Nh, Nh + PLANE, raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, Kloop);
+      if constexpr (PL) issue_planes(nk0, reinterpret_cast<char*>(Nh));  // lands under this chunk's MFMAs
+      else k3_load_w2<TQ, K3_KC>(raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, Kloop, a.x);
+      run_chunk(nks, std::true_type{}, Bh, Bl, np0, nv0, np1, nv1, nk0, k0);
+      if constexpr (PL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else k3_store_w2<T, TQ, K3_KC>(Nh, Nh + PLANE, raw, w2mode, w2n, a.s2n, a.s2k, n0, N, nk0, Kloop);
       __syncthreads();
       buf ^= 1;
       tap = ntap;
@@ -493,7 +528,7 @@ __device__ __forceinline__ void k3_stage1(const KronArgs& a, char* smem, long ro
 
 // The body is a device function so that the fused backward launch (kron_bwd_fused_kernel) can run it as one role.
 // `bx`, `by`: tile coordinates (M tile, N tile).  `smem`: kron3_lds_bytes(NI, K > K3_KC ? 2 : 1) bytes, 16-byte aligned.
-template <typename T, int NI, bool WITH_DW1, int GM, bool BASE = false>
+template <typename T, int NI, bool WITH_DW1, int GM, bool BASE = false, bool PL = false>
 __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx, int by, int nbx) {
   static_assert(!(WITH_DW1 && BASE), "base + delta is a forward epilogue");
   constexpr int MI = 2, TQ = 16 * NI;
@@ -548,7 +583,7 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
     }
   };
   f32x4 acc[MI][NI];
-  k3_stage1<T, NI, GM>(a, smem, row0, rows_end, n0, acc, prefetch_xref);
+  k3_stage1<T, NI, GM, PL>(a, smem, row0, rows_end, n0, acc, prefetch_xref);
   LYC_STAMP(4);
 
   // ---- epilogue, all in registers ----
@@ -685,10 +720,10 @@ __device__ __forceinline__ void kron3_body(const KronArgs& a, char* smem, int bx
   }
 }
 
-template <typename T, int NI, bool WITH_DW1, int GM, bool BASE = false>
+template <typename T, int NI, bool WITH_DW1, int GM, bool BASE = false, bool PL = false>
 __global__ __launch_bounds__(NTHREADS) void kron3_kernel(KronArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char k3_smem[];
-  kron3_body<T, NI, WITH_DW1, GM, BASE>(a, k3_smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+  extern __shared__ __attribute__((aligned(1024))) char k3_smem[];
+  kron3_body<T, NI, WITH_DW1, GM, BASE, PL>(a, k3_smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
 }  // namespace lyc

@@ -52,9 +52,8 @@ struct KronPackArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void kron_pack_kernel(KronPackArgs a) {
+__device__ __forceinline__ void kron_pack_units(const KronPackArgs& a, long unit) {
   const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
-  long unit = (long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
   const bool fwd = unit < a.units_fwd;
   if (!fwd) unit -= a.units_fwd;
   char* plane = static_cast<char*>(fwd ? a.fwd : a.bwd);
@@ -85,6 +84,29 @@ __global__ __launch_bounds__(NTHREADS) void kron_pack_kernel(KronPackArgs a) {
   }
   *reinterpret_cast<u32x4*>(plane + unit * 2048 + lane * 16) = *reinterpret_cast<u32x4*>(h);
   *reinterpret_cast<u32x4*>(plane + unit * 2048 + 1024 + lane * 16) = *reinterpret_cast<u32x4*>(l);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void kron_pack_kernel(KronPackArgs a) {
+  kron_pack_units<T>(a, (long)blockIdx.x * NWAVES + (threadIdx.x >> 6));
+}
+
+// Many layers per launch (the once-per-optimizer-step refresh of every cached plane set): descriptors by value.
+constexpr int KPG_MAX = 28;
+struct KronPackGroupArgs {
+  int n;
+  long unit_end[KPG_MAX];  // exclusive prefix of the (NWAVES-aligned) unit counts
+  KronPackArgs p[KPG_MAX];
+};
+static_assert(sizeof(KronPackGroupArgs) <= 3840, "kernel arguments are limited to 4 KiB");
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void kron_pack_group_kernel(KronPackGroupArgs ga) {
+  const long u = (long)blockIdx.x * NWAVES + (threadIdx.x >> 6);
+  int p = 0;
+  while (p + 1 < ga.n && u >= ga.unit_end[p]) ++p;
+  const long u0 = p ? ga.unit_end[p - 1] : 0;
+  kron_pack_units<T>(ga.p[p], u - u0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -40,6 +40,7 @@ struct KronArgs {
   void* y;           // [M, Gout * N]
   const float* w1;   // element (po, ui) at po * s1o + ui * s1i
   const float* w2;   // element (n, k)  at n * s2n + k * s2k
+  const void* w2p;   // optional (kron3 plain rows, PL instantiations): pre-packed hi / lo planes of this role (kron_conv.h)
   float* dw1;        // optional, same addressing as w1 (accumulated atomically)
   float* dw1_ws;     // optional (kron3 only): per-workgroup dw1 partials [grid.y * grid.x][G * G] instead of atomics
   const void* xref;  // optional [M, Gout * N] (needed iff dw1 != nullptr)

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime_api.h>
 #include <torch/csrc/autograd/engine.h>
 
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <unordered_map>
@@ -375,6 +376,120 @@ void park_deferred(DeferredLoha&& item) { park_deferred_in(&DeferredLists::loha,
 void park_deferred(DeferredLokrConv&& item) { park_deferred_in(&DeferredLists::lokr_conv, std::move(item)); }
 
 // =====================================================================================================================
+// Pre-packed LoKr operand planes (csrc/kron_conv.h): a cache keyed on the PARAMETER
+// =====================================================================================================================
+// w2 changes once per optimizer step; its hi / lo operand planes (forward and backward role, in the activation dtype) are kept
+// per leaf tensor together with the parameter's version counter.  A layer call that finds its entry stale -- the first one after
+// optimizer.step() -- refreshes EVERY stale entry of that device in one grouped launch (lyc_lokr_pack_group); the other layers
+// of the step then just read.  Non-leaf factors (low-rank products, gated factors) are new tensors on every call: no planes,
+// the kernels convert the fp32 tile themselves as before.  `refresh_planes(force)` is the explicit form for callers that
+// replay captured graphs (the capture must contain the pack launch: bench.py).
+struct PlaneEntry {
+  c10::weak_intrusive_ptr<c10::TensorImpl> owner;
+  Tensor planes[2];          // [bf16, f16]: fwd role bytes, then bwd role bytes
+  int64_t version[2] = {-1, -1};
+  int c = 0, d = 0, taps = 0;
+  int64_t sq = 0, sv = 0, st = 0;
+  const float* w2 = nullptr;
+  c10::DeviceIndex device = 0;
+  explicit PlaneEntry(c10::weak_intrusive_ptr<c10::TensorImpl> o) : owner(std::move(o)) {}
+};
+struct PlaneCache {
+  std::mutex mu;
+  std::unordered_map<const void*, PlaneEntry> map;
+  std::atomic<bool> enabled{true};
+} g_planes;
+
+// must hold g_planes.mu.  Repacks every entry of `device` whose parameter changed (or all with `force`), one grouped launch per
+// 28 factors and dtype, on `stream`.
+void refresh_planes_locked(c10::DeviceIndex device, void* stream, bool force) {
+  for (int slot = 0; slot < 2; ++slot) {
+    std::vector<LycLokrPackItem> items;
+    std::vector<PlaneEntry*> who;
+    std::vector<int64_t> vers;
+    for (auto it = g_planes.map.begin(); it != g_planes.map.end();) {
+      PlaneEntry& e = it->second;
+      auto owner = e.owner.lock();
+      if (!owner) {  // the parameter is gone
+        it = g_planes.map.erase(it);
+        continue;
+      }
+      if (e.device == device && e.planes[slot].defined()) {
+        const int64_t v = (int64_t)owner->version_counter().current_version();
+        if (force || v != e.version[slot]) {
+          char* base = static_cast<char*>(e.planes[slot].mutable_data_ptr());
+          items.push_back(LycLokrPackItem{e.w2, e.sq, e.sv, e.st, e.c, e.d, e.taps, base, base + lyc_lokr_planes_bytes(e.c, e.d, e.taps, 0)});
+          who.push_back(&e);
+          vers.push_back(v);
+        }
+      }
+      ++it;
+    }
+    if (items.empty()) continue;
+    const c10::DeviceGuard guard(c10::Device(c10::kCUDA, device));
+    check_rc(lyc_lokr_pack_group(items.data(), (int)items.size(), slot == 0 ? LYC_BF16 : LYC_F16, stream), "lyc_lokr_pack_group");
+    for (size_t i = 0; i < who.size(); ++i) who[i]->version[slot] = vers[i];
+  }
+}
+
+// planes of the leaf factor `w2` ([c, d] or [c, d, kh, kw]) for activations of `act`, or an undefined tensor
+Tensor planes_for(const Tensor& w2, at::ScalarType act, void* stream) {
+  if (!g_planes.enabled || !w2.defined() || !w2.is_cuda() || !w2.is_leaf() || w2.scalar_type() != at::kFloat) return Tensor();
+  if (act != at::kBFloat16 && act != at::kHalf) return Tensor();
+  const c10::DispatchKeySet ks = w2.key_set();
+  if (ks.has(c10::DispatchKey::Python) || ks.has(c10::DispatchKey::Meta) || ks.has(c10::DispatchKey::Functionalize)) return Tensor();
+  const int64_t c = w2.size(0), d = w2.size(1);
+  int taps = 1;
+  int64_t st = 0;
+  if (w2.dim() == 4) {
+    taps = (int)(w2.size(2) * w2.size(3));
+    st = w2.stride(3);
+    if (w2.size(2) > 1 && w2.stride(2) != w2.size(3) * w2.stride(3)) return Tensor();  // one tap stride: (i, j) -> i * kw + j
+  } else if (w2.dim() != 2) {
+    return Tensor();
+  }
+  if ((c % 8) != 0 || (d % 8) != 0 || c >= (1 << 20) || d >= (1 << 20)) return Tensor();
+  const int slot = act == at::kBFloat16 ? 0 : 1;
+  c10::TensorImpl* impl = w2.unsafeGetTensorImpl();
+  std::lock_guard<std::mutex> lk(g_planes.mu);
+  auto it = g_planes.map.find(impl);
+  if (it != g_planes.map.end()) {
+    auto owner = it->second.owner.lock();
+    if (!owner || owner.get() != impl) {
+      g_planes.map.erase(it);
+      it = g_planes.map.end();
+    }
+  }
+  if (it == g_planes.map.end())
+    it = g_planes.map.emplace(impl, PlaneEntry(c10::weak_intrusive_ptr<c10::TensorImpl>(w2.getIntrusivePtr()))).first;
+  PlaneEntry& e = it->second;
+  const float* ptr = w2.const_data_ptr<float>();
+  const bool same_view = e.w2 == ptr && e.c == c && e.d == d && e.taps == taps && e.sq == w2.stride(0) && e.sv == w2.stride(1) && e.st == st;
+  if (!same_view) {  // first use, or the parameter's storage / layout changed (.data swap, .to(memory_format)): start over
+    e.planes[0] = e.planes[1] = Tensor();
+    e.version[0] = e.version[1] = -1;
+    e.w2 = ptr; e.c = (int)c; e.d = (int)d; e.taps = taps; e.sq = w2.stride(0); e.sv = w2.stride(1); e.st = st;
+    e.device = w2.device().index();
+  }
+  const int64_t v = (int64_t)w2._version();
+  if (!e.planes[slot].defined()) {
+    const int64_t nb = lyc_lokr_planes_bytes((int)c, (int)d, taps, 0) + lyc_lokr_planes_bytes((int)c, (int)d, taps, 1);
+    e.planes[slot] = at::empty({nb}, w2.options().dtype(at::kByte));
+    char* base = static_cast<char*>(e.planes[slot].mutable_data_ptr());
+    check_rc(lyc_lokr_pack_w2(ptr, e.sq, e.sv, e.st, nullptr, 0, 0, nullptr, 0, 0, 0, 0, (int)c, (int)d, taps, base,
+                              base + lyc_lokr_planes_bytes((int)c, (int)d, taps, 0), slot == 0 ? LYC_BF16 : LYC_F16, stream),
+             "lyc_lokr_pack_w2");
+    e.version[slot] = v;
+  } else if (e.version[slot] != v) {
+    refresh_planes_locked(e.device, stream, false);
+  }
+  return e.planes[slot];
+}
+const void* planes_bwd_ptr(const Tensor& planes, int64_t c, int64_t d, int taps) {
+  return static_cast<const char*>(planes.const_data_ptr()) + lyc_lokr_planes_bytes((int)c, (int)d, taps, 0);
+}
+
+// =====================================================================================================================
 // LoKr on nn.Linear
 // =====================================================================================================================
 Tensor lokr_linear_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, const c10::optional<Tensor>& base) {
@@ -383,7 +498,7 @@ Tensor lokr_linear_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2, doub
   TORCH_CHECK(w1.dim() == 2 && w2.dim() == 2, "lokr_linear: w1 [a, b], w2 [c, d]");
   const int64_t a = w1.size(0), b = w1.size(1), c = w2.size(0), d = w2.size(1);
   TORCH_CHECK(x.size(-1) == b * d, "adapter expects ", b * d, " input features, got ", x.sizes());
-  Tensor rows = rows_of(x, b * d), f1 = f32c(w1), f2 = f32c(w2);
+  Tensor rows = rows_of(x, b * d), f1 = f32c(w1);
   auto oshape = x.sizes().vec();
   oshape.back() = a * c;
   Tensor y = at::empty({rows.size(0), a * c}, x.options());
@@ -393,8 +508,18 @@ Tensor lokr_linear_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2, doub
                 "lokr_linear: `base` must be the frozen layer's contiguous output in the activation dtype");
     bs = *base;
   }
-  check_rc(lyc_lokr_linear_fwd(cptr(rows), cfp(f1), cfp(f2), cptr(bs), mptr(y), rows.size(0), (int)a, (int)b, (int)c, (int)d,
-                               (float)alpha, dtype_code(x.scalar_type()), stream_of(x)), "lyc_lokr_linear_fwd");
+  const int code = dtype_code(x.scalar_type());
+  Tensor pl;
+  if (lyc_lokr_linear_planes_ok(rows.size(0), (int)a, (int)b, (int)c, (int)d, code) && (reinterpret_cast<uintptr_t>(cptr(rows)) & 15u) == 0)
+    pl = planes_for(w2, x.scalar_type(), stream_of(x));
+  if (pl.defined()) {
+    check_rc(lyc_lokr_linear_fwd_planes(cptr(rows), cfp(f1), cptr(pl), cptr(bs), mptr(y), rows.size(0), (int)a, (int)b, (int)c, (int)d,
+                                        (float)alpha, code, stream_of(x)), "lyc_lokr_linear_fwd_planes");
+  } else {
+    Tensor f2 = f32c(w2);
+    check_rc(lyc_lokr_linear_fwd(cptr(rows), cfp(f1), cfp(f2), cptr(bs), mptr(y), rows.size(0), (int)a, (int)b, (int)c, (int)d,
+                                 (float)alpha, code, stream_of(x)), "lyc_lokr_linear_fwd");
+  }
   return y.view(oshape);
 }
 
@@ -403,7 +528,7 @@ Tensor lokr_linear_bwd_into(const Tensor& g, const Tensor& x, const Tensor& w1, 
                             const Tensor& dw1, const Tensor& dw2) {
   const c10::DeviceGuard guard(x.device());
   const int64_t a = w1.size(0), b = w1.size(1), c = w2.size(0), d = w2.size(1);
-  Tensor rows = rows_of(x, b * d), g2 = rows_of(g, a * c), f1 = f32c(w1), f2 = f32c(w2);
+  Tensor rows = rows_of(x, b * d), g2 = rows_of(g, a * c), f1 = f32c(w1);
   const int code = dtype_code(x.scalar_type());
   const bool want_dx = need_dx || dw1.defined();  // the w1 gradient shares the pass over g that produces dx
   Tensor dx, ws;
@@ -412,8 +537,19 @@ Tensor lokr_linear_bwd_into(const Tensor& g, const Tensor& x, const Tensor& w1, 
     const int64_t nbytes = lyc_lokr_bwd_workspace_bytes(rows.size(0), (int)a, (int)b, (int)c, (int)d, code);
     if (nbytes > 0) ws = at::empty({nbytes}, x.options().dtype(at::kByte));
   }
-  check_rc(lyc_lokr_linear_bwd(cptr(g2), cptr(rows), cfp(f1), cfp(f2), mptr(dx), mfp(dw1), mfp(dw2), mptr(ws), rows.size(0),
-                               (int)a, (int)b, (int)c, (int)d, (float)alpha, code, stream_of(x)), "lyc_lokr_linear_bwd");
+  Tensor pl;
+  if (want_dx && lyc_lokr_linear_planes_ok(rows.size(0), (int)a, (int)b, (int)c, (int)d, code) &&
+      (reinterpret_cast<uintptr_t>(cptr(g2)) & 15u) == 0)
+    pl = planes_for(w2, x.scalar_type(), stream_of(x));
+  if (pl.defined()) {
+    check_rc(lyc_lokr_linear_bwd_planes(cptr(g2), cptr(rows), cfp(f1), planes_bwd_ptr(pl, c, d, 1), mptr(dx), mfp(dw1), mfp(dw2), mptr(ws),
+                                        rows.size(0), (int)a, (int)b, (int)c, (int)d, (float)alpha, code, stream_of(x)),
+             "lyc_lokr_linear_bwd_planes");
+  } else {
+    Tensor f2 = f32c(w2);
+    check_rc(lyc_lokr_linear_bwd(cptr(g2), cptr(rows), cfp(f1), cfp(f2), mptr(dx), mfp(dw1), mfp(dw2), mptr(ws), rows.size(0),
+                                 (int)a, (int)b, (int)c, (int)d, (float)alpha, code, stream_of(x)), "lyc_lokr_linear_bwd");
+  }
   return need_dx ? dx.view(x.sizes()) : Tensor();
 }
 
@@ -425,7 +561,7 @@ bool lokr_linear_bwd_deferred(const Tensor& g, const Tensor& x, const Tensor& w1
   Tensor rows = rows_of(x, b * d), g2 = rows_of(g, a * c);
   const int code = dtype_code(x.scalar_type());
   if (!lyc_lokr_wgrad_deferrable(cptr(g2), cptr(rows), rows.size(0), (int)a, (int)b, (int)c, (int)d, code)) return false;
-  Tensor f1 = f32c(w1), f2 = f32c(w2), dx, ws;
+  Tensor f1 = f32c(w1), dx, ws;
   const bool want_dx = need_dx || dw1.defined();
   if (want_dx) {
     dx = at::empty(rows.sizes(), x.options());
@@ -434,9 +570,17 @@ bool lokr_linear_bwd_deferred(const Tensor& g, const Tensor& x, const Tensor& w1
       TORCH_CHECK(nbytes > 0, "lycoris_amd: deferrable layer without a dw1 workspace");
       ws = at::empty({nbytes}, x.options().dtype(at::kByte));
     }
-    check_rc(lyc_lokr_linear_bwd(cptr(g2), cptr(rows), cfp(f1), cfp(f2), mptr(dx), mfp(dw1), nullptr, mptr(ws), rows.size(0),
-                                 (int)a, (int)b, (int)c, (int)d, (float)alpha, code | LYC_DEFER_WGRAD, stream_of(x)),
-             "lyc_lokr_linear_bwd(dx)");
+    Tensor pl = planes_for(w2, x.scalar_type(), stream_of(x));  // deferrable layers are on the 16-bit fast path
+    if (pl.defined()) {
+      check_rc(lyc_lokr_linear_bwd_planes(cptr(g2), cptr(rows), cfp(f1), planes_bwd_ptr(pl, c, d, 1), mptr(dx), mfp(dw1), nullptr,
+                                          mptr(ws), rows.size(0), (int)a, (int)b, (int)c, (int)d, (float)alpha, code | LYC_DEFER_WGRAD,
+                                          stream_of(x)), "lyc_lokr_linear_bwd_planes(dx)");
+    } else {
+      Tensor f2 = f32c(w2);
+      check_rc(lyc_lokr_linear_bwd(cptr(g2), cptr(rows), cfp(f1), cfp(f2), mptr(dx), mfp(dw1), nullptr, mptr(ws), rows.size(0),
+                                   (int)a, (int)b, (int)c, (int)d, (float)alpha, code | LYC_DEFER_WGRAD, stream_of(x)),
+               "lyc_lokr_linear_bwd(dx)");
+    }
   }
   park_deferred(DeferredLokr{g2, rows, f1, w1, w2, dw1, dw2, ws, rows.size(0), (int)a, (int)b, (int)c, (int)d, code,
                              (float)alpha, stream_of(x), x.device().index()});
@@ -1134,7 +1278,12 @@ struct LokrConv2dFn : public torch::autograd::Function<LokrConv2dFn> {
                     lyc_lokr_conv2d_planes_ok(B, H, W, (int)a, (int)b, (int)c, (int)d, gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh,
                                               gm.dw, code, 1) != 0;
     Tensor planes_f, planes_b;
-    if (pf || pb) {
+    const int64_t bytes_f = lyc_lokr_planes_bytes((int)c, (int)d, gm.kh * gm.kw, 0), bytes_b = lyc_lokr_planes_bytes((int)c, (int)d, gm.kh * gm.kw, 1);
+    Tensor cached = (pf || pb) ? planes_for(w2, x.scalar_type(), stream_of(x)) : Tensor();  // leaf parameter: packed once per optimizer step
+    if (cached.defined()) {
+      if (pf) planes_f = cached.narrow(0, 0, bytes_f);
+      if (pb) planes_b = cached.narrow(0, bytes_f, bytes_b);
+    } else if (pf || pb) {
       Tensor w2f = w2.detach();
       if (w2f.scalar_type() != at::kFloat) w2f = w2f.to(at::kFloat);
       if (w2f.stride(2) != gm.kw * w2f.stride(3) && gm.kh > 1) w2f = w2f.contiguous();  // one tap stride: (i, j) -> i * kw + j
@@ -1398,6 +1547,24 @@ PYBIND11_MODULE(_lyc_torch, m) {
     *g_accum.callback = std::move(callback);
     g_accum.uses.clear();
   });
+  m.def("set_planes_cache", [](bool enabled) {
+    g_planes.enabled = enabled;
+    if (!enabled) {
+      std::lock_guard<std::mutex> lk(g_planes.mu);
+      g_planes.map.clear();
+    }
+  });
+  m.def("planes_cache_size", []() {
+    std::lock_guard<std::mutex> lk(g_planes.mu);
+    return g_planes.map.size();
+  });
+  m.def("refresh_planes", [](bool force) {  // every cached plane set whose parameter changed (force: all), on the current streams
+    std::lock_guard<std::mutex> lk(g_planes.mu);
+    std::vector<c10::DeviceIndex> devs;
+    for (auto& kv : g_planes.map)
+      if (std::find(devs.begin(), devs.end(), kv.second.device) == devs.end()) devs.push_back(kv.second.device);
+    for (c10::DeviceIndex dv : devs) refresh_planes_locked(dv, c10::hip::getCurrentHIPStream(dv).stream(), force);
+  }, py::arg("force") = false);
   m.def("reset_use_counts", []() {  // once per optimizer step (AdapterGradSync.zero_grad / finish): drop counts of forwards
     std::lock_guard<std::mutex> lk(g_accum.mu);  // whose backward never ran
     g_accum.uses.clear();

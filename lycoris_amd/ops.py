@@ -81,6 +81,21 @@ def discard_deferred() -> int:
     return _DISPATCH["ext"].discard_deferred() if _DISPATCH["ext"] is not None else 0
 
 
+def refresh_lokr_planes(force: bool = False):
+    """Repack the cached LoKr operand planes (csrc/torch_ops.cpp `planes_for`) of every parameter that changed since they were
+    written -- `force`: of every cached parameter -- in grouped launches on the current stream.  Eager training never needs to
+    call this (the first layer call after optimizer.step() does it); a caller that REPLAYS captured graphs must capture this
+    call (with force=True) in front of the forward pass, so that each replay sees the parameters of its own step."""
+    if _cpp():
+        _DISPATCH["ext"].refresh_planes(bool(force))
+
+
+def lokr_planes_cache(enabled: bool = True):
+    """A/B switch: False drops the cache; the kernels then convert the fp32 factor tile per workgroup (rounds 1-2)."""
+    if _cpp():
+        _DISPATCH["ext"].set_planes_cache(bool(enabled))
+
+
 def reset_use_counts():
     """Forget the per-parameter count of pending accumulations (csrc/torch_ops.cpp `expect()` / `notify()`): a forward pass whose
     backward never ran leaves a count behind, which would swallow that parameter's next report.  AdapterGradSync calls this once
