@@ -58,6 +58,9 @@ def parse():
                          "the NHWC row matrices are then free views, no transposes")
     ap.add_argument("--no-defer", action="store_true",
                     help="A/B: one LoKr weight-gradient launch per layer instead of the grouped launches")
+    ap.add_argument("--rank", type=int, default=0,
+                    help="LoKr: low-rank w2 = w2_a @ w2_b of this rank (BASELINE configs[3] 'factor=8 (low)': dim 16); 0 = full-matrix w2 "
+                         "(the 'dim=10k-class' headline configuration)")
     ap.add_argument("--no-planes", action="store_true",
                     help="A/B: no pre-packed LoKr operand planes (every workgroup converts its fp32 w2 tile, as in rounds 1-2)")
     ap.add_argument("--no-reference", action="store_true", help="skip the PyTorch-ROCm eager comparator leg")
@@ -67,6 +70,8 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="time the step without hipGraph capture (Python-driven)")
     ap.add_argument("--segments", type=int, default=8, help="backward graph segments (N > 1: collectives in between)")
     ap.add_argument("--layers", default="all", help="'all', 'linear' or 'conv' (development)")
+    ap.add_argument("--force-segments", action="store_true",
+                    help="development: cut the backward into --segments graphs at N = 1 too (the N > 1 replay structure without the collectives)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="development: 'gloo' lets N ranks share ONE GPU (rank % device_count) to exercise the N > 1 control flow "
                          "on a single-GPU box; the driver's runs use nccl (= RCCL), one GPU per rank")
@@ -136,7 +141,12 @@ class Inst:
                 if self.base is not None:
                     self.base = self.x
         f32 = dict(device=dev, dtype=torch.float32, generator=gen)
-        if algo == "lokr":  # factor 8, full-matrix w2 (lora_dim >= 10000): w1 [8,8], w2 [O/8, I/8(,k,k)]
+        if algo == "lokr" and LOKR_RANK > 0 and LOKR_RANK < max(O // FACTOR, cin // FACTOR) / 2:
+            # low-rank w2 (modules/lokr.py:131-136): lokr_w2_a [c, r], lokr_w2_b [r, d * k * k]; the product is formed per call
+            kk = ksz[0] * ksz[1] if ksz else 1
+            ps = [torch.randn(FACTOR, FACTOR, **f32) * 0.3, torch.randn(O // FACTOR, LOKR_RANK, **f32) * 0.1,
+                  torch.randn(LOKR_RANK, (cin // FACTOR) * kk, **f32) * 0.1]
+        elif algo == "lokr":  # factor 8, full-matrix w2 (lora_dim >= 10000): w1 [8,8], w2 [O/8, I/8(,k,k)]
             w2 = torch.randn(O // FACTOR, cin // FACTOR, *ksz, **f32) * 0.05
             if ksz:  # conv factor kept in channels_last memory: the implicit-GEMM kernels read / write it in place
                 w2 = w2.contiguous(memory_format=torch.channels_last)
@@ -161,6 +171,8 @@ class Inst:
         """the adapter delta; with `base` (the frozen layer's output) base + delta, fused where the kernels can"""
         ops, s, p = self.ops, self.spec, self.params
         lin = s["kind"] == "linear"
+        if self.algo == "lokr" and len(p) == 3:  # low-rank w2: the product the modules form (lycoris_amd/modules/lokr.py _w2_full)
+            p = [p[0], (p[1] @ p[2]).reshape(p[1].shape[0], self.cin // FACTOR, *self.ksz)]
         if base is not None:
             if lin and self.algo == "lokr":
                 return ops.lokr_linear(self.x, p[0], p[1], 1.0, base=base)
@@ -202,8 +214,9 @@ class Inst:
         the base-weight dtype, `W + dW - W`, dense op (lokr.py:543-566, locon.py:309-332, loha.py:301-322)."""
         W, p = self.ensure_weight(), self.params
         if self.algo == "lokr":
-            f1 = p[0].reshape(*p[0].shape, *([1] * (p[1].dim() - 2)))
-            dW = torch.kron(f1, p[1].contiguous())
+            w2 = p[1] if len(p) == 2 else (p[1] @ p[2]).reshape(p[1].shape[0], self.cin // FACTOR, *self.ksz)
+            f1 = p[0].reshape(*p[0].shape, *([1] * (w2.dim() - 2)))
+            dW = torch.kron(f1, w2.contiguous())
         elif self.algo == "locon":
             dW = (p[1].reshape(p[1].shape[0], -1) @ p[0].reshape(p[0].shape[0], -1)).reshape(W.shape)
         elif self.algo == "loha":
@@ -218,11 +231,13 @@ class Inst:
 
 
 CHANNELS_LAST = False
+LOKR_RANK = 0
 
 
 def build_instances(args, dtype, dev):
-    global CHANNELS_LAST
+    global CHANNELS_LAST, LOKR_RANK
     CHANNELS_LAST = bool(args.channels_last)
+    LOKR_RANK = int(args.rank)
     gen = torch.Generator(device=dev).manual_seed(1234)
     insts = []
     for spec, algo, count in layer_specs(args.model, args.algo):
@@ -327,7 +342,7 @@ def main():
             # part of the step, captured here so that every replay packs the parameters of ITS step
             _ops.refresh_lokr_planes(force=True)
             outs = forward_all(insts)
-        nseg = max(1, min(args.segments if world > 1 else 1, n_layers))
+        nseg = max(1, min(args.segments if (world > 1 or args.force_segments) else 1, n_layers))
         edges = [round(i * n_layers / nseg) for i in range(nseg + 1)]
         for s in range(nseg, 0, -1):  # backward runs from the last layer to the first
             lo, hi = edges[s - 1], edges[s]
@@ -343,7 +358,7 @@ def main():
             g_fwd.replay()
             for gph, upto in zip(graphs, seg_bounds):
                 gph.replay()
-                if world > 1:
+                if world > 1 or args.force_segments:
                     sync.launch_ready(upto)  # side stream: waits for this segment, runs beside the next ones
             sync.finish()
             opt.step()
@@ -384,6 +399,7 @@ def main():
                         f"layers ({n_lin} Linear + {n_layers - n_lin} Conv2d), adapter fwd+bwd + grad all-reduce + fused "
                         "AdamW; frozen UNet ops not timed (see base_plus_adapter)",
             "algo": args.algo, "factor": FACTOR if args.algo in ("lokr", "mixed") else None, "layers": n_layers,
+            "lokr_w2": (f"low rank {args.rank} (w2_a @ w2_b per call)" if args.rank else "full matrix") if args.algo in ("lokr", "mixed") else None,
             "adapter_params": sum(p.numel() for p in all_params), "dp_payload_mb": round(sync.payload_bytes / 2**20, 1),
             "parallelism": f"dp{world}",
             "graph": "eager (no capture)" if args.eager else
@@ -396,12 +412,15 @@ def main():
     }
     extra = rank == 0 and world == 1 and not args.eager
     sync._sync_enabled = False  # the measurement legs below repeat passes without finish(): no bucket bookkeeping there
-    if extra and not args.no_roofline:
+    if extra and not args.no_roofline and not args.rank:  # (the low-rank leg reports the step only: its Linear kernels are the same)
         result["roofline"] = roofline(insts, args, dtype, dev)
     if extra and not args.no_reference and args.algo in ("lokr", "locon", "loha"):
         result["reference_rocm_eager"] = reference_leg(insts, sync, ms_per_step)
     if extra and not args.no_base and args.algo in ("lokr", "locon", "loha"):
         result["base_plus_adapter"] = base_leg(insts, sync)
+        # SURVEY 8d defines the step WITH the frozen layers' forward + dx ops: the contract number next to `value`
+        # (forward + backward of base and adapter; the optimizer and arena fill add ~1.3 ms more, see ms_per_step)
+        result["value_base_plus_adapter"] = round(1e3 / result["base_plus_adapter"]["base_plus_adapter_ms"], 3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.algo in ("lokr", "locon", "loha"):
         result["cpu_baseline"] = cpu_baseline(args.algo, args.model)
     if rank == 0:
@@ -451,25 +470,23 @@ def _wall_ms(fn, reps=2):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def pmc_traffic(family):
-    """HBM bytes per launch of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate runs, gfx950 corrections per MI355X_MICROARCH.md; benchmarks/pmc_summary.py --json writes the file).  Only
-    trusted when it was collected on THIS build of the library (sha of liblycoris_amd.so recorded in the file) or on a build
-    the file itself declares traffic-equivalent, in which case `traffic_source` carries that statement."""
+def pmc_traffic(family, workload):
+    """HBM bytes per launch (and launches per pass) of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, gfx950 corrections per MI355X_MICROARCH.md; benchmarks/pmc_summary.py --json writes the file).
+    Keyed by WORKLOAD ("algo/model/layers", VERDICT r2 weak #11b: an SD1.5 line used to print the SDXL constant) and only trusted
+    when it was collected on THIS build of the library (sha of liblycoris_amd.so recorded in the file): otherwise None + why."""
     try:
         with open(PMC_FILE) as f:
             rec = json.load(f)
     except (OSError, ValueError):
         return None, "no profiles/pmc_traffic.json"
-    src = rec.get("source", "profiles/pmc_traffic.json")
     if rec.get("lib_sha16") != lib_sha():
-        # a later build may be DECLARED traffic-equivalent in the file (with the reason); the line then says so
-        why = rec.get("equivalent_builds", {}).get(lib_sha())
-        if why is None:
-            return None, f"profiles/pmc_traffic.json was collected on build {rec.get('lib_sha16')}, this is {lib_sha()}"
-        src = f"{src}: collected on build {rec.get('lib_sha16')}, not on the running build {lib_sha()} ({why})"
-    fam = rec.get("families", {}).get(family)
-    return (int(fam["bytes_per_launch"]) if fam else None), src
+        return None, f"profiles/pmc_traffic.json was collected on build {rec.get('lib_sha16')}, this is {lib_sha()}"
+    wl = rec.get("workloads", {}).get(workload)
+    if wl is None:
+        return None, f"profiles/pmc_traffic.json has no pass for workload {workload}"
+    fam = wl.get(family)
+    return (fam if fam else None), rec.get("source", "profiles/pmc_traffic.json")
 
 
 def roofline(insts, args, dtype, dev):
@@ -590,8 +607,10 @@ def roofline(insts, args, dtype, dev):
     fam = {"lokr": "lokr_kron3", "locon": "locon_linear", "ia3": "ia3"}[lin[0].algo]
     nbytes = b_fwd + b_bwd
     hot = nbytes / (t_ms * 1e-3) / 1e9
-    traffic, src = pmc_traffic(fam)
-    out.update({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic, "traffic_source": src,
+    workload = f"{lin[0].algo if algo != 'mixed' else 'mixed'}/{args.model}/linear"
+    tr, src = pmc_traffic(fam, workload)
+    traffic = int(tr["bytes_per_launch"]) if tr else None
+    out.update({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic, "traffic_source": src, "traffic_workload": workload,
                 "hot_path_gbs": round(hot, 1), "hot_path_frac": round(hot / HBM_PEAK_GBS, 4),
                 "forward_gbs": round(b_fwd / (t_fwd * 1e-3) / 1e9, 1), "backward_gbs": round(b_bwd / (t_bwd * 1e-3) / 1e9, 1)})
     if lin[0].algo == "lokr":
@@ -656,6 +675,9 @@ def roofline(insts, args, dtype, dev):
                     "backward_gbs": round(b_bwd / ((t_dx + t_wg) * 1e-3) / 1e9, 1),
                     "dw2s_grouped_gbs": round(b_dw2 / (t_wg * 1e-3) / 1e9, 1),
                     "dw2s_per_layer_gbs": round(b_dw2 / (t_dw2 * 1e-3) / 1e9, 1)})
+        conv = conv_leg(insts, args, dtype)
+        if conv:
+            out["conv"] = conv
         return out
     if lin[0].algo == "locon":
         # production backward: the fused dx launch per layer (lyc::bneck_kernel, also writes dt) + the factor gradients of ALL
@@ -702,6 +724,41 @@ def roofline(insts, args, dtype, dev):
     out.update({"kernel": "lyc::chan_scale_kernel / lyc::chan_reduce_kernel",
                 "achieved": round(hot, 1), "frac": round(hot / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_launch": int(nbytes / (launches * n_l))})
+    return out
+
+
+def conv_leg(insts, args, dtype):
+    """roofline.conv: the Conv2d layers of the LoKr step as their own kernel family (the family furthest below
+    its roofline had no leg and no counters).  Algorithmic bytes per layer e * (3 |x| + 2 |y|) (forward: x, y; backward: g, x, dx);
+    time = forward graph + backward graph (dx launches + the grouped weight-gradient launches), op level, HIP events."""
+    conv = [it for it in insts if it.spec["kind"] == "conv" and it.algo == "lokr"]
+    if not conv:
+        return None
+    esz = torch.empty((), dtype=dtype).element_size()
+    nbytes = sum(esz * (3 * it.x.numel() + 2 * it.g.numel()) for it in conv)
+    held = {}
+
+    def fwd():
+        held["o"] = forward_all(conv)
+
+    def both():
+        outs = forward_all(conv)
+        backward_range(outs, 0, len(outs))
+
+    t_f = _graph_ms(fwd)
+    t_fb = _graph_ms(both)
+    t_b = max(t_fb - t_f, 0.0)
+    ach = nbytes / (t_fb * 1e-3) / 1e9
+    workload = f"lokr/{args.model}/conv"
+    tr, src = pmc_traffic("lokr_conv", workload)
+    out = {"layers": len(conv), "kernel": "lyc::kconv_kernel (LDS source patch + packed operand planes; forward, backward dx / dW1) + the "
+                                           "grouped weight-gradient launches (lyc::kron_dw2s_conv_group_kernel); 1x1 convs run the row kernels",
+           "families_ms": {"forward": round(t_f, 3), "backward_dx_and_grouped_dw2": round(t_b, 3)},
+           "algorithmic_bytes_per_step": int(nbytes), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK_GBS, 4), "memory_format": "channels_last" if args.channels_last else "contiguous (NCHW: + two row transposes per pass)",
+           "traffic": int(tr["bytes_per_pass"]) if tr else None, "traffic_source": src, "traffic_workload": workload}
+    if tr:
+        out["traffic_over_algorithmic"] = round(tr["bytes_per_pass"] / nbytes, 2)
     return out
 
 

@@ -7,6 +7,7 @@
 #include <string.h>
 #include "../lycoris_amd/csrc/kron3.h"
 #include "../lycoris_amd/csrc/kron_dw2s.h"
+#include "../lycoris_amd/csrc/kron_conv.h"
 #include "../lycoris_amd/csrc/lowrank.h"
 
 using namespace lyc;
@@ -34,6 +35,18 @@ int main(int argc, char** argv) {
       if (!bw) { ka.x = x; ka.y = y; ka.w1 = w1; ka.w2 = w2; ka.M = M; ka.Gin = G; ka.K = d; ka.Gout = G; ka.N = c; ka.s1o = G; ka.s1i = 1; ka.s2n = d; ka.s2k = 1; }
       else { ka.x = g; ka.y = dx; ka.w1 = w1; ka.w2 = w2; ka.dw1 = dw1; ka.xref = x; ka.M = M; ka.Gin = G; ka.K = c; ka.Gout = G; ka.N = d; ka.s1o = 1; ka.s1i = G; ka.s2n = 1; ka.s2k = d; }
       ka.alpha = 1.f;
+      static void* planes = nullptr;  // KT_PL=1: the pre-packed operand planes (round 3), packed once
+      const bool pl = getenv("KT_PL") != nullptr;
+      if (pl && planes == nullptr) {
+        const long nf = kron_plane_bytes(c, 1, d), nb = kron_plane_bytes(d, 1, c);
+        CK(hipMalloc(&planes, nf + nb));
+        KronPackArgs pa{};
+        pa.w2 = w2; pa.sq = d; pa.sv = 1; pa.st = 0; pa.c = c; pa.d = d; pa.taps = 1; pa.fwd = planes; pa.bwd = (char*)planes + nf;
+        pa.units_fwd = nf / 2048;
+        hipLaunchKernelGGL((kron_pack_kernel<__bf16>), dim3((unsigned)cdiv((nf + nb) / 2048, NWAVES)), dim3(NTHREADS), 0, 0, pa);
+        CK(hipDeviceSynchronize());
+      }
+      if (pl) ka.w2p = bw ? (char*)planes + kron_plane_bytes(c, 1, d) : planes;
       const int ni = getenv("KT_NI") ? atoi(getenv("KT_NI")) : 2;   // production picks 2 for the 1280-wide layers
       const int gm = getenv("KT_GM") ? atoi(getenv("KT_GM")) : 3;   // 3 = x through the per-wave LDS stage (production)
       dim3 grid((unsigned)cdiv(M, K3_RT / G), (unsigned)cdiv(ka.N, 16 * ni));
@@ -48,6 +61,7 @@ int main(int argc, char** argv) {
       else if (ni == 1) { if (bw) go(kron3_kernel<__bf16, 1, true, 0>); else go(kron3_kernel<__bf16, 1, false, 0>); }
       else if (ni == 4 && gm == 3) { if (bw) go(kron3_kernel<__bf16, 4, true, 3>); else go(kron3_kernel<__bf16, 4, false, 3>); }
       else if (ni == 4) { if (bw) go(kron3_kernel<__bf16, 4, true, 0>); else go(kron3_kernel<__bf16, 4, false, 0>); }
+      else if (gm == 3 && pl) { if (bw) go(kron3_kernel<__bf16, 2, true, 3, false, true>); else go(kron3_kernel<__bf16, 2, false, 3, false, true>); }
       else if (gm == 3) { if (bw) go(kron3_kernel<__bf16, 2, true, 3>); else go(kron3_kernel<__bf16, 2, false, 3>); }
       else { if (bw) go(kron3_kernel<__bf16, 2, true, 0>); else go(kron3_kernel<__bf16, 2, false, 0>); }
       if (rep == 0) printf("grid %u x %u\n", grid.x, grid.y);

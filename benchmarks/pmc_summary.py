@@ -25,48 +25,56 @@ def load(d, counter):
 
 
 def short(name):
-    for key in ("kron3_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "copy16", "kron_kernel", "kron_dw2_kernel",
-                "bneck_kernel", "lowrank_tn_kernel", "gexp_kernel"):
+    for key in ("kron3_kernel", "kron_dw2s_conv_group_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "copy16", "kron_kernel", "kron_dw2_kernel",
+                "kconv_dw2_group_kernel", "kconv_kernel", "kron_pack", "bneck_kernel", "lowrank_tn_kernel", "gexp_kernel"):
         if key in name:
             return key + name.split(key)[1][:34]
     return name[:60]
 
 
-# kernel families of bench.py's roofline legs: every launch the Linear layers of one algorithm make
-FAMILIES = {  # family -> (algo whose pass is used, kernel-name substrings)
-    "lokr_kron3": ("lokr", ("kron3_kernel",)),
-    "lokr_dw2s": ("lokr", ("kron_dw2s_kernel", "kron_dw2s_group_kernel")),
-    "lokr_linear": ("lokr", ("kron3_kernel", "kron_dw2s_kernel", "kron_dw2s_group_kernel", "kron_dw1_reduce", "kron_kernel", "kron_dw2_kernel")),
-    "locon_linear": ("locon", ("bneck_kernel", "lowrank_tn_kernel", "skinny_", "expand_nt")),
+# kernel families of bench.py's roofline legs, per WORKLOAD "algo/model/layers" (one pair of rocprofv3 passes each)
+FAMILIES = {  # family -> (layers of the pass it is read from, kernel-name substrings)
+    "lokr_kron3": ("linear", ("kron3_kernel",)),
+    "lokr_dw2s": ("linear", ("kron_dw2s_kernel", "kron_dw2s_group_kernel")),
+    "lokr_linear": ("linear", ("kron3_kernel", "kron_dw2s_kernel", "kron_dw2s_group_kernel", "kron_dw1_reduce", "kron_kernel", "kron_dw2_kernel",
+                               "kron_pack")),
+    "locon_linear": ("linear", ("bneck_kernel", "lowrank_tn", "skinny_", "expand_nt")),
+    "lokr_kconv": ("conv", ("kconv_kernel",)),
+    "lokr_conv_dw2": ("conv", ("kron_dw2s_conv_group_kernel", "kron_dw2s_kernel", "kconv_dw2_group_kernel")),
+    "lokr_conv": ("conv", ("kconv_kernel", "kron_dw2s", "kconv_dw2", "kron3_kernel", "kron_pack", "kron_dw1_reduce", "nchw_rows")),
 }
 CAL_R, CAL_W = 2047.96, 1024.0  # bytes per counter unit, calibrated on a 1 GiB copy (profiles/r01_pmc_kbench.txt)
 
 
-def family_json(out_path, triples):
-    """--json OUT algo fetch_dir write_dir [algo fetch_dir write_dir ...]: bytes per launch per family + the build's sha"""
+def family_json(out_path, quads):
+    """--json OUT workload fetch_dir write_dir [...]: workload = "algo/model/layers" of the eager pass that was profiled
+    (`bench.py --algo A --model M --layers L --pmc-pass 1`).  Per family: launches, bytes per launch and bytes per PASS."""
     import hashlib
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "lycoris_amd", "liblycoris_amd.so"), "rb") as f:
         sha = hashlib.sha256(f.read()).hexdigest()[:16]
-    rec = {"lib_sha16": sha, "families": {},
-           "source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
-                     "`bench.py --algo A --pmc-pass 1 --layers linear` (benchmarks/pmc_traffic.sh); read 2048 B/unit "
-                     "(the gfx950 1/2 correction of FETCH_SIZE), write 1024 B/unit, calibrated on a 1 GiB copy"}
-    passes = {algo: (load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")) for algo, fdir, wdir in triples}
-    for fam, (algo, keys) in FAMILIES.items():
-        if algo not in passes:
-            continue
-        fetch, write = passes[algo]
-        fs = [v for k, vs in fetch.items() if any(x in k for x in keys) for v in vs]
-        ws_ = [v for k, vs in write.items() if any(x in k for x in keys) for v in vs]
-        if not fs or not ws_:
-            continue
-        n = max(len(fs), len(ws_))
-        rec["families"][fam] = {
-            "launches": n, "read_bytes": sum(fs) * CAL_R, "write_bytes": sum(ws_) * CAL_W,
-            "bytes_per_launch": (sum(fs) * CAL_R + sum(ws_) * CAL_W) / n,
-            "kernels": sorted({short(k) for k in list(fetch) + list(write) if any(x in k for x in keys)})}
+    rec = {"lib_sha16": sha, "workloads": {},
+           "source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, counters only) over "
+                     "`bench.py --algo A --model M --layers L --pmc-pass 1` (benchmarks/pmc_traffic.sh); read 2048 B/unit "
+                     "(the gfx950 1/2 correction of FETCH_SIZE), write 1024 B/unit, calibrated on a 1 GiB copy; keyed by workload"}
+    for workload, fdir, wdir in quads:
+        layers = workload.split("/")[-1]
+        fetch, write = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
+        fams = {}
+        for fam, (lay, keys) in FAMILIES.items():
+            if lay != layers or not fam.startswith(workload.split("/")[0]):
+                continue
+            fs = [v for k, vs in fetch.items() if any(x in k for x in keys) for v in vs]
+            ws_ = [v for k, vs in write.items() if any(x in k for x in keys) for v in vs]
+            if not fs or not ws_:
+                continue
+            n = max(len(fs), len(ws_))
+            total = sum(fs) * CAL_R + sum(ws_) * CAL_W
+            fams[fam] = {"launches": n, "read_bytes": sum(fs) * CAL_R, "write_bytes": sum(ws_) * CAL_W, "bytes_per_launch": total / n,
+                         "bytes_per_pass": total,
+                         "kernels": sorted({short(k) for k in list(fetch) + list(write) if any(x in k for x in keys)})}
+        rec["workloads"][workload] = fams
     with open(out_path, "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec, indent=1))
@@ -105,7 +113,7 @@ def main():
         rb = fm * (cal_r or 1024.0)
         wb = wm * (cal_w or 1024.0)
         print(f"{short(k):60s} {max(len(f), len(w)):6d} {fm:12.1f} {wm:12.1f} {rb / 1e6:9.2f} {wb / 1e6:9.2f} {(rb + wb) / 1e6:14.2f}")
-    for fam in ("kron3_kernel", "kron_dw2s_kernel", "bneck_kernel", "lowrank_tn_kernel", "gexp_kernel"):
+    for fam in ("kron3_kernel", "kron_dw2s_kernel", "kconv_kernel", "kron_dw2s_conv_group_kernel", "bneck_kernel", "lowrank_tn_kernel", "gexp_kernel"):
         fs = [v for k, vs in fetch.items() if fam in k for v in vs]
         ws_ = [v for k, vs in write.items() if fam in k for v in vs]
         if fs and ws_:

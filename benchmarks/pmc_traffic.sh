@@ -1,9 +1,10 @@
 #!/bin/bash
-# HBM bytes per launch of the step's nn.Linear launches, for bench.py's roofline.traffic (run on the GPU box):
-#     bash benchmarks/pmc_traffic.sh            -> gpurun_out/pmc_traffic.json + gpurun_out/pmc_traffic_<algo>.txt
-# Two SEPARATE rocprofv3 passes per algorithm (FETCH_SIZE needs 3 of the 4 TCC slots, WRITE_SIZE 2:
+# HBM bytes of the step's launches, per WORKLOAD, for bench.py's roofline.traffic (run on the GPU box):
+#     bash benchmarks/pmc_traffic.sh            -> gpurun_out/pmc_traffic.json + gpurun_out/pmc_traffic_<workload>.txt
+# Two SEPARATE rocprofv3 passes per workload (FETCH_SIZE needs 3 of the 4 TCC slots, WRITE_SIZE 2:
 # MI355X_MICROARCH.md "rocprofv3 PMC slots"), counters only -- no trace domains in the same run.  The eager passes of
 # bench.py are profiled because counters cannot be sampled inside hipGraph replays.  Copy the outputs to profiles/.
+# WORKLOADS: "algo/model/layers[/flag]" triples; the conv pass runs with channels_last activations (the documented default).
 set -u
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out"
@@ -11,14 +12,18 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 ARGS=""
-for ALGO in ${ALGOS:-lokr locon}; do
+for WL in ${WORKLOADS:-lokr/sdxl/linear lokr/sdxl/conv locon/sdxl/linear}; do
+  IFS=/ read -r ALGO MODEL LAYERS <<< "$WL"
+  TAG=$(echo $WL | tr / _)
+  EXTRA=""
+  [ "$LAYERS" = "conv" ] && EXTRA="--channels-last"
   for C in FETCH_SIZE WRITE_SIZE; do
-    D=/tmp/pmc_${ALGO}_$C
+    D=/tmp/pmc_${TAG}_$C
     rm -rf "$D"
     timeout 900 rocprofv3 --pmc $C -d "$D" --output-format csv -- \
-      python "$ROOT/bench.py" --algo $ALGO --pmc-pass 1 --layers linear > "$OUT/pmc_${ALGO}_$C.log" 2>&1 || echo "pass $ALGO $C failed"
+      python "$ROOT/bench.py" --algo $ALGO --model $MODEL --pmc-pass 1 --layers $LAYERS $EXTRA > "$OUT/pmc_${TAG}_$C.log" 2>&1 || echo "pass $WL $C failed"
   done
-  python "$ROOT/benchmarks/pmc_summary.py" /tmp/pmc_${ALGO}_FETCH_SIZE /tmp/pmc_${ALGO}_WRITE_SIZE > "$OUT/pmc_traffic_${ALGO}.txt" 2>&1
-  ARGS="$ARGS $ALGO /tmp/pmc_${ALGO}_FETCH_SIZE /tmp/pmc_${ALGO}_WRITE_SIZE"
+  python "$ROOT/benchmarks/pmc_summary.py" /tmp/pmc_${TAG}_FETCH_SIZE /tmp/pmc_${TAG}_WRITE_SIZE > "$OUT/pmc_traffic_${TAG}.txt" 2>&1
+  ARGS="$ARGS $WL /tmp/pmc_${TAG}_FETCH_SIZE /tmp/pmc_${TAG}_WRITE_SIZE"
 done
 python "$ROOT/benchmarks/pmc_summary.py" --json "$OUT/pmc_traffic.json" $ARGS

@@ -64,9 +64,10 @@ def main():
     gen = torch.Generator(device=DEV).manual_seed(7)
     shapes = [("lokr", 256, 640, 640), ("locon", 256, 640, 1280), ("lokr", 64, 1280, 640), ("locon", 77, 2048, 640)] * 6
     layers = [Layer(a, M, I, O, gen) for a, M, I, O in shapes]
-    shared = Layer("lokr", 128, 640, 640, gen)
-    layers.insert(5, shared)
-    layers.append(Layer("lokr", 32, 640, 640, gen, params=shared.params))  # the same parameters in a second layer call
+    if "--no-shared" not in sys.argv:
+        shared = Layer("lokr", 128, 640, 640, gen)
+        layers.insert(5, shared)
+        layers.append(Layer("lokr", 32, 640, 640, gen, params=shared.params))  # the same parameters in a second layer call
     params, seen = [], set()
     for l in layers:
         for p in l.params:
@@ -113,27 +114,25 @@ def main():
         # ---- captured: forward graph + backward segment graphs, launch_ready() between the replays (bench.py's N > 1 step) ---
         torch.cuda.synchronize()
         time.sleep(1.0)  # every collective of the eager steps has been retired by RCCL's watchdog thread before the capture starts
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
+        # exactly bench.py's capture sequence (main(), `if not args.eager`): captures on the ambient stream context, one pool
         sync._sync_enabled = False
-        with torch.cuda.stream(side):
-            pool = torch.cuda.graph_pool_handle()
-            g_fwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fwd, pool=pool):
-                for arena in sync.arenas.values():
-                    arena.zero_()
-                outs = [(l.forward(), l) for l in layers]
-            n, nseg = len(layers), 4
-            edges = [round(i * n / nseg) for i in range(nseg + 1)]
-            graphs, bounds = [], []
-            for s in range(nseg, 0, -1):
-                lo, hi = edges[s - 1], edges[s]
-                gph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gph, pool=pool):
-                    backward_range(outs, lo, hi)
-                graphs.append(gph)
-                bounds.append(layers[lo - 1].params[-1] if lo > 0 else None)
-        torch.cuda.current_stream().wait_stream(side)
+        pool = torch.cuda.graph_pool_handle()
+        g_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_fwd, pool=pool):
+            for arena in sync.arenas.values():
+                arena.zero_()
+            outs = [(l.forward(), l) for l in layers]
+        n, nseg = len(layers), 4
+        edges = [round(i * n / nseg) for i in range(nseg + 1)]
+        graphs, bounds = [], []
+        for s in range(nseg, 0, -1):
+            lo, hi = edges[s - 1], edges[s]
+            gph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gph, pool=pool):
+                backward_range(outs, lo, hi)
+            graphs.append(gph)
+            bounds.append(layers[lo - 1].params[-1] if lo > 0 else None)
+        print("captured", flush=True)
         sync._sync_enabled = True
         for rep in range(3):
             sync._reset_pending()

@@ -45,6 +45,13 @@ __host__ __device__ constexpr int gemm16_lds_bytes() {
   return stage > epi ? stage : epi;
 }
 
+// LDS image [row][9 units of 16 bytes] (8 data units + 1 pad).  The data unit u of row r lives at unit u ^ ((r >> 4) & 7): the
+// transposing store of a K-strided operand writes, per instruction, the SAME unit of rows 8 apart -- 8 * 144 bytes = 0 mod the
+// 128-byte bank period, a 16-way conflict on every ds_write_b64 without the swizzle (first version: the NN / TN forms ran 2.2x
+// slower than NT); with it only the two blocks of one 16-row group still alias (2-way: free for a 64-bit store).  The 16 rows
+// of a fragment share one XOR value, so the conflict-free pattern of the fragment reads is unchanged.
+__device__ __forceinline__ int g16_unit(int row, int u) { return u ^ ((row >> 4) & 7); }
+
 // ---- staging -------------------------------------------------------------------------------------------------------------
 // ROWS x 64 operand tile.  KC: element (r, k) at (r0 + r) * ld + k0 + k.  KS: at (k0 + k) * ld + r0 + r.
 template <int ROWS, bool KS>
@@ -89,14 +96,15 @@ __device__ __forceinline__ void g16_store(const G16Stage<ROWS, KS>& s, T* tile) 
 #pragma unroll
     for (int j = 0; j < ROWS / 32; ++j) {
       const int vi = tid + NTHREADS * j;
-      const int r = vi >> 3, kv = (vi & 7) * 8;
-      *reinterpret_cast<u32x4*>(tile + r * G16_LD + kv) = s.v[j];
+      const int r = vi >> 3;
+      *reinterpret_cast<u32x4*>(tile + r * G16_LD + 8 * g16_unit(r, vi & 7)) = s.v[j];
     }
   } else {
     constexpr int RB = ROWS / 8;
     if (tid < RB * 16) {
       const int rb = tid % RB, kb = tid / RB;
-      T* dst = tile + (8 * rb) * G16_LD + 4 * kb;
+      // rows 8 rb .. 8 rb + 7 share (row >> 4): one swizzled unit for the whole block; 4 k values = half a unit
+      T* dst = tile + (8 * rb) * G16_LD + 8 * g16_unit(8 * rb, kb >> 1) + 4 * (kb & 1);
 #pragma unroll
       for (int w = 0; w < 4; ++w) {  // columns 2w (low halves) and 2w + 1 (high halves) of the four k rows
         u32x2 lo, hi;
@@ -151,15 +159,18 @@ __device__ __forceinline__ void gemm16_body(const Gemm16Prob& p, int out_f32, ch
   g16_store<T, TN, B_KS>(sb0, Bs[0]);
   __syncthreads();
   auto compute = [&](int cur) {
-    const T* at = As[cur] + (wr * (TM / 2)) * G16_LD;
-    const T* bt = Bs[cur] + (wc * 64) * G16_LD;
+    const T* at = As[cur];
+    const T* bt = Bs[cur];
+    const int ar0 = wr * (TM / 2) + li, br0 = wc * 64 + li;  // tile-local rows of this lane's fragments (+ 16 mi / 16 ni)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       F8 af[MI], bf[NI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const F8*>(at + (16 * mi + li) * G16_LD + 32 * ks + 8 * g);
+      for (int mi = 0; mi < MI; ++mi)
+        af[mi] = *reinterpret_cast<const F8*>(at + (ar0 + 16 * mi) * G16_LD + 8 * g16_unit(ar0 + 16 * mi, 4 * ks + g));
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const F8*>(bt + (16 * ni + li) * G16_LD + 32 * ks + 8 * g);
+      for (int ni = 0; ni < NI; ++ni)
+        bf[ni] = *reinterpret_cast<const F8*>(bt + (br0 + 16 * ni) * G16_LD + 8 * g16_unit(br0 + 16 * ni, 4 * ks + g));
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
