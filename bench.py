@@ -171,7 +171,11 @@ class Inst:
         """the adapter delta; with `base` (the frozen layer's output) base + delta, fused where the kernels can"""
         ops, s, p = self.ops, self.spec, self.params
         lin = s["kind"] == "linear"
-        if self.algo == "lokr" and len(p) == 3:  # low-rank w2: the product the modules form (lycoris_amd/modules/lokr.py _w2_full)
+        if self.algo == "lokr" and len(p) == 3 and lin:  # low-rank w2 on nn.Linear: the factors go to the kernels as they are
+            if base is not None:
+                return ops.lokr_linear_lr(self.x, p[0], p[1], p[2], 1.0, base=base)
+            return ops.lokr_linear_lr(self.x, p[0], p[1], p[2], 1.0)
+        if self.algo == "lokr" and len(p) == 3:  # Conv2d: the product the modules form (lycoris_amd/modules/lokr.py _w2_full)
             p = [p[0], (p[1] @ p[2]).reshape(p[1].shape[0], self.cin // FACTOR, *self.ksz)]
         if base is not None:
             if lin and self.algo == "lokr":

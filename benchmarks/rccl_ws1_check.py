@@ -63,8 +63,12 @@ def main():
         print("nccl process group up", flush=True)
     gen = torch.Generator(device=DEV).manual_seed(7)
     shapes = [("lokr", 256, 640, 640), ("locon", 256, 640, 1280), ("lokr", 64, 1280, 640), ("locon", 77, 2048, 640)] * 6
+    if "--lokr-only" in sys.argv:
+        shapes = [s for s in shapes if s[0] == "lokr"]
+    if "--locon-only" in sys.argv:
+        shapes = [s for s in shapes if s[0] == "locon"]
     layers = [Layer(a, M, I, O, gen) for a, M, I, O in shapes]
-    if "--no-shared" not in sys.argv:
+    if "--no-shared" not in sys.argv and "--locon-only" not in sys.argv:
         shared = Layer("lokr", 128, 640, 640, gen)
         layers.insert(5, shared)
         layers.append(Layer("lokr", 32, 640, 640, gen, params=shared.params))  # the same parameters in a second layer call

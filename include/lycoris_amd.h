@@ -157,13 +157,30 @@ int lyc_lokr_conv2d_bwd(const void* g_rows, const void* x_rows, const float* w1,
  * lyc_lokr_pack_group refreshes the planes of MANY layers in one launch per 28 factors (full matrices, any strides): the
  * once-per-optimizer-step form. */
 typedef struct LycLokrPackItem {
-  const float* w2;     /* element (q, v, tap) at q*sq + v*sv + tap*st */
+  const float* w2;     /* element (q, v, tap) at q*sq + v*sv + tap*st; NULL: the low-rank pair below */
   int64_t sq, sv, st;
   int c, d, taps;
   void* planes_fwd;    /* lyc_lokr_planes_bytes(c, d, taps, 0) bytes, or NULL */
   void* planes_bwd;    /* lyc_lokr_planes_bytes(c, d, taps, 1) bytes, or NULL */
+  const float* w2a;    /* low rank (w2 == NULL): contiguous lokr_w2_a [c, rank] ...                       */
+  const float* w2b;    /* ... and lokr_w2_b [rank, d * taps] (the reference's layout, modules/lokr.py:131-136) */
+  int rank;
 } LycLokrPackItem;
 int lyc_lokr_pack_group(const LycLokrPackItem* items, int n, int dtype, void* stream);
+/* Low-rank w2 = w2a @ w2b: the activation path needs only the planes (packed straight from the two factors); the weight
+ * gradient dW2 [c, d] is taken in a caller-owned fp32 scratch (lyc_lokr_linear_bwd / lyc_lokr_wgrad_group with dw2 = scratch,
+ * zero-filled) and pushed through the product by ONE launch per 56 layers:
+ *     d_w2a += dW2 w2b^T,   d_w2b += w2a^T dW2          (fp32, accumulated atomically)
+ * replaces the reference's `w2a @ w2b` + its two autograd GEMMs per layer and step (functional/lokr.py:124-151). */
+typedef struct LycLokrLrChainItem {
+  const float* dw2;   /* [c, d]  */
+  const float* w2a;   /* [c, r]  */
+  const float* w2b;   /* [r, d]  */
+  float* d_w2a;       /* [c, r] +=   (NULL: factor frozen; not both) */
+  float* d_w2b;       /* [r, d] +=   (NULL: factor frozen) */
+  int c, d, r;
+} LycLokrLrChainItem;
+int lyc_lokr_lr_chain_group(const LycLokrLrChainItem* items, int n, void* stream);
 int lyc_lokr_linear_planes_ok(int64_t M, int a, int b, int c, int d, int dtype);
 int lyc_lokr_linear_fwd_planes(const void* x, const float* w1, const void* planes_fwd, const void* base, void* y, int64_t M, int a,
                                int b, int c, int d, float alpha, int dtype, void* stream);

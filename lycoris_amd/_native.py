@@ -31,6 +31,7 @@ SIGNATURES = {
     "lyc_lokr_conv2d_bwd": [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_lokr_conv_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LokrConvWgradItem
     "lyc_lokr_pack_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LokrPackItem
+    "lyc_lokr_lr_chain_group": [_vp, _i32, _vp],  # items: pointer to an array of LokrLrChainItem
     "lyc_lokr_linear_fwd_planes": [_vp, _fp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_lokr_linear_bwd_planes": [_vp, _vp, _fp, _vp, _vp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_lokr_pack_w2": [_fp, _i64, _i64, _i64, _fp, _i64, _i64, _fp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
@@ -87,7 +88,12 @@ class LoconWgradItem(ctypes.Structure):
 class LokrPackItem(ctypes.Structure):
     """LycLokrPackItem (include/lycoris_amd.h)"""
     _fields_ = [("w2", _vp), ("sq", _i64), ("sv", _i64), ("st", _i64), ("c", _i32), ("d", _i32), ("taps", _i32), ("planes_fwd", _vp),
-                ("planes_bwd", _vp)]
+                ("planes_bwd", _vp), ("w2a", _vp), ("w2b", _vp), ("rank", _i32)]
+
+
+class LokrLrChainItem(ctypes.Structure):
+    """LycLokrLrChainItem (include/lycoris_amd.h)"""
+    _fields_ = [("dw2", _vp), ("w2a", _vp), ("w2b", _vp), ("d_w2a", _vp), ("d_w2b", _vp), ("c", _i32), ("d", _i32), ("r", _i32)]
 
 
 class LokrConvWgradItem(ctypes.Structure):

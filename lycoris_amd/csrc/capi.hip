@@ -580,7 +580,7 @@ int lyc_lokr_pack_group(const LycLokrPackItem* items, int n, int dtype, void* st
   };
   for (int k = 0; k < n; ++k) {
     const LycLokrPackItem& it = items[k];
-    if (!it.w2 || it.c < 1 || it.d < 1 || it.taps < 1 || (it.c % 8) != 0 || (it.d % 8) != 0)
+    if ((!it.w2 && !(it.w2a && it.w2b && it.rank >= 1)) || it.c < 1 || it.d < 1 || it.taps < 1 || (it.c % 8) != 0 || (it.d % 8) != 0)
       return fail(LYC_ERR_ARG, "lokr_pack_group: item %d: bad factor (c, d must be positive multiples of 8)", k);
     if (!it.planes_fwd && !it.planes_bwd) continue;
     if (ga.n == KPG_MAX)
@@ -589,9 +589,37 @@ int lyc_lokr_pack_group(const LycLokrPackItem* items, int n, int dtype, void* st
     pa = KronPackArgs{};
     pa.w2 = it.w2; pa.sq = it.sq; pa.sv = it.sv; pa.st = it.st; pa.c = it.c; pa.d = it.d; pa.taps = it.taps;
     pa.fwd = it.planes_fwd; pa.bwd = it.planes_bwd;
+    if (!it.w2) {  // low rank: contiguous w2a [c, r], w2b [r, d * taps] (element (r, v, tap) at r * d * taps + v * taps + tap)
+      pa.w2a = it.w2a; pa.w2b = it.w2b; pa.rank = it.rank; pa.a_sq = it.rank; pa.a_sr = 1;
+      pa.b_sr = (long)it.d * it.taps; pa.b_sv = it.taps; pa.b_st = 1;
+    }
     pa.units_fwd = kron_plane_bytes(it.c, it.taps, it.d) / 2048;
     const long units = pa.units_fwd + kron_plane_bytes(it.d, it.taps, it.c) / 2048;
     ga.unit_end[ga.n] = (ga.n ? ga.unit_end[ga.n - 1] : 0) + round_up(units, NWAVES);
+    ++ga.n;
+  }
+  return flush();
+}
+
+int lyc_lokr_lr_chain_group(const LycLokrLrChainItem* items, int n, void* stream) {
+  if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "lokr_lr_chain_group: bad item list");
+  KronLrGroupArgs ga{};
+  auto flush = [&]() -> int {
+    if (ga.n == 0) return LYC_OK;
+    hipLaunchKernelGGL(kron_lr_chain_kernel, dim3((unsigned)ga.wg_end[ga.n - 1]), dim3(NTHREADS), 0, (hipStream_t)stream, ga);
+    ga = KronLrGroupArgs{};
+    return check_launch("lokr_lr_chain_group");
+  };
+  for (int k = 0; k < n; ++k) {
+    const LycLokrLrChainItem& it = items[k];
+    if (!it.dw2 || !it.w2a || !it.w2b || (!it.d_w2a && !it.d_w2b) || it.c < 1 || it.d < 1 || it.r < 1)
+      return fail(LYC_ERR_ARG, "lokr_lr_chain_group: item %d: bad arguments", k);
+    if (ga.n == KLR_MAX)
+      if (int rc = flush()) return rc;
+    KronLrItem& q = ga.p[ga.n];
+    q.dw2 = it.dw2; q.w2a = it.w2a; q.w2b = it.w2b; q.d_w2a = it.d_w2a; q.d_w2b = it.d_w2b; q.c = it.c; q.d = it.d; q.r = it.r;
+    const long wgs = cdiv((long)it.c * it.r + (long)it.r * it.d, NTHREADS);
+    ga.wg_end[ga.n] = (int)((ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs);
     ++ga.n;
   }
   return flush();

@@ -110,6 +110,64 @@ __global__ __launch_bounds__(NTHREADS) void kron_pack_group_kernel(KronPackGroup
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Low-rank w2 = w2a @ w2b (reference modules/lokr.py:131-136, 370; functional/lokr.py:124-151): the chain rule of the product
+//     d_w2a[q, r] += sum_v dW2[q, v] * w2b[r, v]        d_w2b[r, v] += sum_q w2a[q, r] * dW2[q, v]
+// for MANY layers per launch, from the dense dW2 [c, d] the grouped weight-gradient launch left in a scratch arena (fp32 FMAs:
+// 4 c d r flops per layer, a few GFLOP per SDXL step -- the two ATen GEMM launches per layer it replaces cost more in launches
+// than in arithmetic).  One thread per output element; a workgroup's threads walk r fastest (a dW2 row is a broadcast).
+// ---------------------------------------------------------------------------------------------------------------------
+struct KronLrItem {
+  const float* dw2;   // [c, d]
+  const float* w2a;   // [c, r]
+  const float* w2b;   // [r, d]
+  float* d_w2a;       // [c, r] +=   (NULL: not wanted)
+  float* d_w2b;       // [r, d] +=   (NULL: not wanted)
+  int c, d, r;
+};
+constexpr int KLR_MAX = 56;
+struct KronLrGroupArgs {
+  int n;
+  int wg_end[KLR_MAX];
+  KronLrItem p[KLR_MAX];
+};
+static_assert(sizeof(KronLrGroupArgs) <= 3840, "kernel arguments are limited to 4 KiB");
+
+__global__ __launch_bounds__(NTHREADS) void kron_lr_chain_kernel(KronLrGroupArgs ga) {
+  const int b = (int)blockIdx.x;
+  int p = 0;
+  while (p + 1 < ga.n && b >= ga.wg_end[p]) ++p;
+  const KronLrItem& it = ga.p[p];
+  const long e = (long)(b - (p ? ga.wg_end[p - 1] : 0)) * NTHREADS + threadIdx.x;
+  const long na = (long)it.c * it.r;
+  if (e < na) {  // d_w2a[q, rr]
+    if (!it.d_w2a) return;  // a frozen factor
+    const int q = (int)(e / it.r), rr = (int)(e - (long)q * it.r);
+    const float* g = it.dw2 + (long)q * it.d;
+    const float* w = it.w2b + (long)rr * it.d;
+    float s0 = 0.f, s1 = 0.f;
+    int v = 0;
+    for (; v + 1 < it.d; v += 2) {
+      s0 = fmaf(g[v], w[v], s0);
+      s1 = fmaf(g[v + 1], w[v + 1], s1);
+    }
+    if (v < it.d) s0 = fmaf(g[v], w[v], s0);
+    __hip_atomic_fetch_add(it.d_w2a + e, s0 + s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (e < na + (long)it.r * it.d) {  // d_w2b[rr, v]: consecutive threads -> consecutive v (coalesced dW2 rows)
+    const long f = e - na;
+    if (!it.d_w2b) return;
+    const int rr = (int)(f / it.d), v = (int)(f - (long)rr * it.d);
+    float s0 = 0.f, s1 = 0.f;
+    int q = 0;
+    for (; q + 1 < it.c; q += 2) {
+      s0 = fmaf(it.w2a[(long)q * it.r + rr], it.dw2[(long)q * it.d + v], s0);
+      s1 = fmaf(it.w2a[(long)(q + 1) * it.r + rr], it.dw2[(long)(q + 1) * it.d + v], s1);
+    }
+    if (q < it.c) s0 = fmaf(it.w2a[(long)q * it.r + rr], it.dw2[(long)q * it.d + v], s0);
+    __hip_atomic_fetch_add(it.d_w2b + f, s0 + s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Conv kernel
 // ---------------------------------------------------------------------------------------------------------------------
 struct KconvGeom {      // host-computed (capi.hip: plan_kconv)

@@ -189,6 +189,7 @@ struct DeferredLokr {
   float alpha;
   void* stream;
   c10::DeviceIndex device;
+  Tensor w2a, w2b, d_w2a, d_w2b;  // low-rank w2 = w2a @ w2b (all four defined): dw2 is then a slice of the flush's scratch arena
 };
 struct DeferredLocon {
   Tensor g, x, t, dt, down, up, dd, du;  // dd / du: the .grad targets (either may be undefined)
@@ -284,14 +285,30 @@ void flush_deferred(c10::DeviceIndex device) {
     while (hi < items.size() && items[hi].device == items[lo].device && items[hi].stream == items[lo].stream &&
            items[hi].code == items[lo].code)
       ++hi;
+    const c10::DeviceGuard guard(c10::Device(c10::kCUDA, items[lo].device));
+    const c10::hip::HIPStreamGuard sguard(c10::hip::getStreamFromExternal((hipStream_t)items[lo].stream, items[lo].device));
+    // low-rank layers: dW2 [c, d] of each goes to a slice of ONE zero-filled scratch arena, then through the product's chain rule
+    int64_t arena_floats = 0;
+    for (size_t i = lo; i < hi; ++i)
+      if (items[i].w2a.defined()) arena_floats += (int64_t)items[i].c * items[i].d;
+    Tensor arena;
+    if (arena_floats > 0) arena = at::zeros({arena_floats}, items[lo].g.options().dtype(at::kFloat));
     std::vector<LycLokrWgradItem> raw(hi - lo);
+    std::vector<LycLokrLrChainItem> chain;
+    int64_t off = 0;
     for (size_t i = lo; i < hi; ++i) {
       const DeferredLokr& it = items[i];
-      raw[i - lo] = LycLokrWgradItem{cptr(it.g), cptr(it.x), cfp(it.f1), mfp(it.dw1), mfp(it.dw2), mptr(it.ws), it.M,
+      float* dw2 = mfp(it.dw2);
+      if (it.w2a.defined()) {
+        dw2 = arena.mutable_data_ptr<float>() + off;
+        off += (int64_t)it.c * it.d;
+        chain.push_back(LycLokrLrChainItem{dw2, cfp(it.w2a), cfp(it.w2b), mfp(it.d_w2a), mfp(it.d_w2b), it.c, it.d, (int)it.w2a.size(1)});
+      }
+      raw[i - lo] = LycLokrWgradItem{cptr(it.g), cptr(it.x), cfp(it.f1), mfp(it.dw1), dw2, mptr(it.ws), it.M,
                                      it.a, it.b, it.c, it.d, it.alpha};
     }
-    const c10::DeviceGuard guard(c10::Device(c10::kCUDA, items[lo].device));
     check_rc(lyc_lokr_wgrad_group(raw.data(), (int)raw.size(), items[lo].code, items[lo].stream), "lyc_lokr_wgrad_group");
+    if (!chain.empty()) check_rc(lyc_lokr_lr_chain_group(chain.data(), (int)chain.size(), items[lo].stream), "lyc_lokr_lr_chain_group");
     join_ambient(items[lo].device, items[lo].stream);
     lo = hi;
   }
@@ -337,7 +354,12 @@ void flush_deferred(c10::DeviceIndex device) {
     for (int i = 0; i < 4; ++i) notify(it.p[i]);
   for (const DeferredLokr& it : items) {
     if (it.dw1.defined()) notify(it.w1);
-    notify(it.w2);
+    if (it.w2a.defined()) {
+      notify(it.w2a);
+      notify(it.w2b);
+    } else {
+      notify(it.w2);
+    }
   }
   for (const DeferredLocon& it : litems) {
     if (it.dd.defined()) notify(it.down);
@@ -391,8 +413,15 @@ struct PlaneEntry {
   int c = 0, d = 0, taps = 0;
   int64_t sq = 0, sv = 0, st = 0;
   const float* w2 = nullptr;
+  // low-rank pair (keyed on w2a): w2 == nullptr, planes packed from (w2a [c, rank], w2b [rank, d]); both version counters count
+  c10::weak_intrusive_ptr<c10::TensorImpl> owner_b;
+  const float* w2a = nullptr;
+  const float* w2b = nullptr;
+  int rank = 0;
+  int64_t version_b[2] = {-1, -1};
   c10::DeviceIndex device = 0;
-  explicit PlaneEntry(c10::weak_intrusive_ptr<c10::TensorImpl> o) : owner(std::move(o)) {}
+  explicit PlaneEntry(c10::weak_intrusive_ptr<c10::TensorImpl> o)
+      : owner(std::move(o)), owner_b(c10::weak_intrusive_ptr<c10::TensorImpl>(c10::intrusive_ptr<c10::TensorImpl>())) {}
 };
 struct PlaneCache {
   std::mutex mu;
@@ -406,7 +435,7 @@ void refresh_planes_locked(c10::DeviceIndex device, void* stream, bool force) {
   for (int slot = 0; slot < 2; ++slot) {
     std::vector<LycLokrPackItem> items;
     std::vector<PlaneEntry*> who;
-    std::vector<int64_t> vers;
+    std::vector<int64_t> vers, versb;
     for (auto it = g_planes.map.begin(); it != g_planes.map.end();) {
       PlaneEntry& e = it->second;
       auto owner = e.owner.lock();
@@ -414,13 +443,24 @@ void refresh_planes_locked(c10::DeviceIndex device, void* stream, bool force) {
         it = g_planes.map.erase(it);
         continue;
       }
+      int64_t vb = -1;
+      if (e.rank > 0) {
+        auto ob = e.owner_b.lock();
+        if (!ob) {
+          it = g_planes.map.erase(it);
+          continue;
+        }
+        vb = (int64_t)ob->version_counter().current_version();
+      }
       if (e.device == device && e.planes[slot].defined()) {
         const int64_t v = (int64_t)owner->version_counter().current_version();
-        if (force || v != e.version[slot]) {
+        if (force || v != e.version[slot] || vb != e.version_b[slot]) {
           char* base = static_cast<char*>(e.planes[slot].mutable_data_ptr());
-          items.push_back(LycLokrPackItem{e.w2, e.sq, e.sv, e.st, e.c, e.d, e.taps, base, base + lyc_lokr_planes_bytes(e.c, e.d, e.taps, 0)});
+          items.push_back(LycLokrPackItem{e.w2, e.sq, e.sv, e.st, e.c, e.d, e.taps, base, base + lyc_lokr_planes_bytes(e.c, e.d, e.taps, 0),
+                                          e.w2a, e.w2b, e.rank});
           who.push_back(&e);
           vers.push_back(v);
+          versb.push_back(vb);
         }
       }
       ++it;
@@ -428,7 +468,10 @@ void refresh_planes_locked(c10::DeviceIndex device, void* stream, bool force) {
     if (items.empty()) continue;
     const c10::DeviceGuard guard(c10::Device(c10::kCUDA, device));
     check_rc(lyc_lokr_pack_group(items.data(), (int)items.size(), slot == 0 ? LYC_BF16 : LYC_F16, stream), "lyc_lokr_pack_group");
-    for (size_t i = 0; i < who.size(); ++i) who[i]->version[slot] = vers[i];
+    for (size_t i = 0; i < who.size(); ++i) {
+      who[i]->version[slot] = vers[i];
+      who[i]->version_b[slot] = versb[i];
+    }
   }
 }
 
@@ -481,6 +524,53 @@ Tensor planes_for(const Tensor& w2, at::ScalarType act, void* stream) {
              "lyc_lokr_pack_w2");
     e.version[slot] = v;
   } else if (e.version[slot] != v) {
+    refresh_planes_locked(e.device, stream, false);
+  }
+  return e.planes[slot];
+}
+// the same for a low-rank pair w2a [c, r], w2b [r, d] (both leaves, fp32, contiguous): planes of w2a @ w2b, formed in the pack kernel
+Tensor planes_for_lr(const Tensor& w2a, const Tensor& w2b, at::ScalarType act, void* stream) {
+  if (!g_planes.enabled || !w2a.is_cuda() || !w2a.is_leaf() || !w2b.is_leaf() || w2a.scalar_type() != at::kFloat ||
+      w2b.scalar_type() != at::kFloat || !w2a.is_contiguous() || !w2b.is_contiguous() || w2a.dim() != 2 || w2b.dim() != 2)
+    return Tensor();
+  if (act != at::kBFloat16 && act != at::kHalf) return Tensor();
+  const int64_t c = w2a.size(0), r = w2a.size(1), d = w2b.size(1);
+  if ((c % 8) != 0 || (d % 8) != 0 || r < 1 || w2b.size(0) != r) return Tensor();
+  const int slot = act == at::kBFloat16 ? 0 : 1;
+  c10::TensorImpl* impl = w2a.unsafeGetTensorImpl();
+  std::lock_guard<std::mutex> lk(g_planes.mu);
+  auto it = g_planes.map.find(impl);
+  if (it != g_planes.map.end()) {
+    auto owner = it->second.owner.lock();
+    if (!owner || owner.get() != impl) {
+      g_planes.map.erase(it);
+      it = g_planes.map.end();
+    }
+  }
+  if (it == g_planes.map.end())
+    it = g_planes.map.emplace(impl, PlaneEntry(c10::weak_intrusive_ptr<c10::TensorImpl>(w2a.getIntrusivePtr()))).first;
+  PlaneEntry& e = it->second;
+  const float *pa = w2a.const_data_ptr<float>(), *pb = w2b.const_data_ptr<float>();
+  auto ob = e.owner_b.lock();
+  const bool same_view = e.rank == r && e.w2a == pa && e.w2b == pb && e.c == c && e.d == d && ob && ob.get() == w2b.unsafeGetTensorImpl();
+  if (!same_view) {
+    e.planes[0] = e.planes[1] = Tensor();
+    e.version[0] = e.version[1] = e.version_b[0] = e.version_b[1] = -1;
+    e.w2 = nullptr; e.w2a = pa; e.w2b = pb; e.rank = (int)r; e.c = (int)c; e.d = (int)d; e.taps = 1; e.sq = e.sv = e.st = 0;
+    e.owner_b = c10::weak_intrusive_ptr<c10::TensorImpl>(w2b.getIntrusivePtr());
+    e.device = w2a.device().index();
+  }
+  const int64_t va = (int64_t)w2a._version(), vb = (int64_t)w2b._version();
+  if (!e.planes[slot].defined()) {
+    const int64_t nb = lyc_lokr_planes_bytes((int)c, (int)d, 1, 0) + lyc_lokr_planes_bytes((int)c, (int)d, 1, 1);
+    e.planes[slot] = at::empty({nb}, w2a.options().dtype(at::kByte));
+    char* base = static_cast<char*>(e.planes[slot].mutable_data_ptr());
+    check_rc(lyc_lokr_pack_w2(nullptr, 0, 0, 0, pa, r, 1, pb, d, 1, 0, (int)r, (int)c, (int)d, 1, base,
+                              base + lyc_lokr_planes_bytes((int)c, (int)d, 1, 0), slot == 0 ? LYC_BF16 : LYC_F16, stream),
+             "lyc_lokr_pack_w2(low rank)");
+    e.version[slot] = va;
+    e.version_b[slot] = vb;
+  } else if (e.version[slot] != va || e.version_b[slot] != vb) {
     refresh_planes_locked(e.device, stream, false);
   }
   return e.planes[slot];
@@ -651,6 +741,124 @@ std::tuple<Tensor, Tensor, Tensor> lokr_linear_bwd_meta(const Tensor& g, const T
                                                         double alpha, bool need_dx, bool need_dw1, bool need_dw2) {
   return {need_dx ? at::empty_like(x) : x.new_empty({0}), need_dw1 ? at::empty_like(w1) : w1.new_empty({0}),
           need_dw2 ? at::empty_like(w2) : w2.new_empty({0})};
+}
+
+// =====================================================================================================================
+// LoKr on nn.Linear with a low-rank w2 = w2a @ w2b (reference modules/lokr.py:131-136, 370; functional/lokr.py:124-151)
+// =====================================================================================================================
+// The product is never formed as a tensor on the fast path: the operand planes are packed straight from the two factors
+// (once per optimizer step, planes_for_lr), and the weight gradient dW2 goes to a scratch [c, d] and through the product's chain
+// rule with one grouped kernel -- for parked layers at the end of the backward pass, together with their dW2.
+Tensor lokr_linear_lr_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2a, const Tensor& w2b, double alpha,
+                          const c10::optional<Tensor>& base) {
+  require_device(x, "input");
+  TORCH_CHECK(w1.dim() == 2 && w2a.dim() == 2 && w2b.dim() == 2 && w2a.size(1) == w2b.size(0), "lokr_linear_lr: w1 [a, b], w2a [c, r], w2b [r, d]");
+  const c10::DeviceGuard guard(x.device());
+  const int64_t a = w1.size(0), b = w1.size(1), c = w2a.size(0), d = w2b.size(1);
+  TORCH_CHECK(x.size(-1) == b * d, "adapter expects ", b * d, " input features, got ", x.sizes());
+  const int code = dtype_code(x.scalar_type());
+  Tensor rows = rows_of(x, b * d);
+  Tensor pl;
+  if (lyc_lokr_linear_planes_ok(rows.size(0), (int)a, (int)b, (int)c, (int)d, code) && (reinterpret_cast<uintptr_t>(cptr(rows)) & 15u) == 0)
+    pl = planes_for_lr(w2a, w2b, x.scalar_type(), stream_of(x));
+  if (!pl.defined()) return lokr_linear_fwd(x, w1, at::mm(f32c(w2a), f32c(w2b)), alpha, base);  // shapes off the fast path
+  Tensor f1 = f32c(w1);
+  auto oshape = x.sizes().vec();
+  oshape.back() = a * c;
+  Tensor y = at::empty({rows.size(0), a * c}, x.options());
+  Tensor bs;
+  if (base.has_value() && base->defined()) {
+    TORCH_CHECK(base->scalar_type() == x.scalar_type() && base->numel() == y.numel() && base->is_contiguous(),
+                "lokr_linear_lr: `base` must be the frozen layer's contiguous output in the activation dtype");
+    bs = *base;
+  }
+  check_rc(lyc_lokr_linear_fwd_planes(cptr(rows), cfp(f1), cptr(pl), cptr(bs), mptr(y), rows.size(0), (int)a, (int)b, (int)c, (int)d,
+                                      (float)alpha, code, stream_of(x)), "lyc_lokr_linear_fwd_planes");
+  return y.view(oshape);
+}
+
+struct LokrLinearLrFn : public torch::autograd::Function<LokrLinearLrFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w1, const Tensor& w2a, const Tensor& w2b, double alpha,
+                        const c10::optional<Tensor>& base) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    TORCH_CHECK(eager_cuda(x), "lycoris_amd::lokr_linear_lr is an eager op (trace the product w2a @ w2b through lokr_linear instead)");
+    Tensor y = lokr_linear_lr_fwd(x, w1, w2a, w2b, alpha, base);
+    expect(w1, x);
+    expect(w2a, x);
+    expect(w2b, x);
+    ctx->save_for_backward({x, w1, w2a, w2b});
+    ctx->saved_data["alpha"] = alpha;
+    ctx->saved_data["has_base"] = base.has_value() && base->defined();
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &w1 = saved[1], &w2a = saved[2], &w2b = saved[3];
+    const double alpha = ctx->saved_data["alpha"].toDouble();
+    const bool nx = ctx->needs_input_grad(0), n1 = ctx->needs_input_grad(1), na = ctx->needs_input_grad(2), nb2 = ctx->needs_input_grad(3);
+    const bool nbase = ctx->saved_data["has_base"].toBool() && ctx->needs_input_grad(4);
+    const Tensor& g = grads[0];
+    const c10::DeviceGuard guard(x.device());
+    const int64_t a = w1.size(0), b = w1.size(1), c = w2a.size(0), d = w2b.size(1), r = w2a.size(1);
+    const int code = dtype_code(x.scalar_type());
+    Tensor rows = rows_of(x, b * d), g2 = rows_of(g, a * c), f1 = f32c(w1), fa = f32c(w2a), fb = f32c(w2b);
+    GradTarget t1 = grad_target(w1, n1 || accum_wanted(w1));
+    const bool want_w2 = na || nb2 || accum_wanted(w2a) || accum_wanted(w2b);
+    GradTarget ta = grad_target(w2a, want_w2), tb = grad_target(w2b, want_w2);
+    const bool fast = lyc_lokr_linear_planes_ok(rows.size(0), (int)a, (int)b, (int)c, (int)d, code) &&
+                      (reinterpret_cast<uintptr_t>(cptr(g2)) & 15u) == 0;
+    Tensor pl = fast ? planes_for_lr(w2a, w2b, x.scalar_type(), stream_of(x)) : Tensor();
+    const bool want_dx = nx || t1.buf.defined();
+    Tensor dx, ws;
+    if (want_dx) dx = at::empty(rows.sizes(), x.options());
+    if (t1.buf.defined()) {
+      const int64_t nbytes = lyc_lokr_bwd_workspace_bytes(rows.size(0), (int)a, (int)b, (int)c, (int)d, code);
+      if (nbytes > 0) ws = at::empty({nbytes}, x.options().dtype(at::kByte));
+    }
+    // training configuration: every gradient goes straight into .grad -> dx now, dW1 / dW2 / chain in the grouped launches
+    const bool defer = g_defer.enabled && pl.defined() && want_w2 && !ta.hand_back && !tb.hand_back && !(t1.buf.defined() && t1.hand_back) &&
+                       fa.is_same(w2a) && fb.is_same(w2b) &&
+                       lyc_lokr_wgrad_deferrable(cptr(g2), cptr(rows), rows.size(0), (int)a, (int)b, (int)c, (int)d, code) &&
+                       (!t1.buf.defined() || ws.defined());
+    if (defer) {
+      if (want_dx)
+        check_rc(lyc_lokr_linear_bwd_planes(cptr(g2), cptr(rows), cfp(f1), planes_bwd_ptr(pl, c, d, 1), mptr(dx), mfp(t1.buf), nullptr,
+                                            mptr(ws), rows.size(0), (int)a, (int)b, (int)c, (int)d, (float)alpha, code | LYC_DEFER_WGRAD,
+                                            stream_of(x)), "lyc_lokr_linear_bwd_planes(dx)");
+      DeferredLokr item{g2, rows, f1, w1, Tensor(), t1.buf, Tensor(), ws, rows.size(0), (int)a, (int)b, (int)c, (int)d, code, (float)alpha,
+                        stream_of(x), x.device().index()};
+      item.w2a = w2a; item.w2b = w2b; item.d_w2a = ta.buf; item.d_w2b = tb.buf;
+      park_deferred(std::move(item));
+      return {nx ? dx.view(x.sizes()) : Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), nbase ? g : Tensor()};
+    }
+    // immediate: dW2 into a scratch, then the chain rule (one item)
+    Tensor dw2 = want_w2 ? at::zeros({c, d}, x.options().dtype(at::kFloat)) : Tensor();
+    if (pl.defined()) {
+      check_rc(lyc_lokr_linear_bwd_planes(cptr(g2), cptr(rows), cfp(f1), planes_bwd_ptr(pl, c, d, 1), mptr(dx), mfp(t1.buf), mfp(dw2),
+                                          mptr(ws), rows.size(0), (int)a, (int)b, (int)c, (int)d, (float)alpha, code, stream_of(x)),
+               "lyc_lokr_linear_bwd_planes");
+    } else {
+      Tensor f2 = at::mm(fa, fb);
+      check_rc(lyc_lokr_linear_bwd(cptr(g2), cptr(rows), cfp(f1), cfp(f2), mptr(dx), mfp(t1.buf), mfp(dw2), mptr(ws), rows.size(0), (int)a,
+                                   (int)b, (int)c, (int)d, (float)alpha, code, stream_of(x)), "lyc_lokr_linear_bwd");
+    }
+    if (want_w2) {
+      LycLokrLrChainItem ci{cfp(dw2), cfp(fa), cfp(fb), mfp(ta.buf), mfp(tb.buf), (int)c, (int)d, (int)r};
+      check_rc(lyc_lokr_lr_chain_group(&ci, 1, stream_of(x)), "lyc_lokr_lr_chain_group");
+    }
+    return {nx ? dx.view(x.sizes()) : Tensor(), finish_grad(w1, t1), finish_grad(w2a, ta), finish_grad(w2b, tb), Tensor(), nbase ? g : Tensor()};
+  }
+};
+Tensor lokr_linear_lr_autograd(const Tensor& x, const Tensor& w1, const Tensor& w2a, const Tensor& w2b, double alpha,
+                               const c10::optional<Tensor>& base) {
+  const GradAtApply ga_;
+  return LokrLinearLrFn::apply(amp(x), w1, w2a, w2b, alpha, base);
+}
+Tensor lokr_linear_lr_meta(const Tensor& x, const Tensor& w1, const Tensor& w2a, const Tensor& w2b, double alpha,
+                           const c10::optional<Tensor>& base) {
+  auto oshape = x.sym_sizes().vec();
+  oshape.back() = w1.sym_size(0) * w2a.sym_size(0);
+  return x.new_empty_symint(oshape);
 }
 
 // =====================================================================================================================
@@ -1469,6 +1677,7 @@ Tensor locon_conv2d_meta(const Tensor& x, const Tensor& down, const Tensor& up, 
 TORCH_LIBRARY(lycoris_amd, m) {
   // public ops: what lycoris_amd.ops / the modules call (autograd-aware)
   m.def("lokr_linear(Tensor x, Tensor w1, Tensor w2, float alpha, Tensor? base=None) -> Tensor");
+  m.def("lokr_linear_lr(Tensor x, Tensor w1, Tensor w2a, Tensor w2b, float alpha, Tensor? base=None) -> Tensor");
   m.def("locon_linear(Tensor x, Tensor down, Tensor up, float alpha) -> Tensor");
   m.def("loha_linear(Tensor x, Tensor w1a, Tensor w1b, Tensor w2a, Tensor w2b, float alpha) -> Tensor");
   m.def("chan_affine(Tensor a, Tensor w, Tensor? bias, float s0, float mult, int chan_dim) -> Tensor");
@@ -1494,6 +1703,7 @@ TORCH_LIBRARY(lycoris_amd, m) {
 
 TORCH_LIBRARY_IMPL(lycoris_amd, CUDA, m) {
   m.impl("lokr_linear", lokr_linear_fwd);
+  m.impl("lokr_linear_lr", lokr_linear_lr_fwd);
   m.impl("_lokr_linear_backward", lokr_linear_bwd);
   m.impl("locon_linear", locon_linear_cuda);
   m.impl("_locon_linear_forward", locon_linear_fwd);
@@ -1512,6 +1722,7 @@ TORCH_LIBRARY_IMPL(lycoris_amd, CUDA, m) {
 
 TORCH_LIBRARY_IMPL(lycoris_amd, Meta, m) {
   m.impl("lokr_linear", lokr_linear_meta);
+  m.impl("lokr_linear_lr", lokr_linear_lr_meta);
   m.impl("_lokr_linear_backward", lokr_linear_bwd_meta);
   m.impl("locon_linear", locon_linear_meta);
   m.impl("_locon_linear_forward", locon_linear_fwd_meta);
@@ -1530,6 +1741,7 @@ TORCH_LIBRARY_IMPL(lycoris_amd, Meta, m) {
 
 TORCH_LIBRARY_IMPL(lycoris_amd, Autograd, m) {
   m.impl("lokr_linear", lokr_linear_autograd);
+  m.impl("lokr_linear_lr", lokr_linear_lr_autograd);
   m.impl("locon_linear", locon_linear_autograd);
   m.impl("loha_linear", loha_linear_autograd);
   m.impl("chan_affine", chan_affine_autograd);

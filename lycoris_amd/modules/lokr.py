@@ -225,10 +225,18 @@ class LokrModule(LycorisBaseModule):
     def _forward_fused(self, x, base):
         if self.module_type != "linear":
             return None
-        w1, w2 = self._gate(self._w1_full()), self._w2_full()
+        w1 = self._gate(self._w1_full())
+        if self._w2_low_rank_native(x):  # the factors go to the kernels as they are: no w2_a @ w2_b product, no autograd mm
+            if not ops.lokr_linear_fusable(x, w1, ops._Shape2(self.lokr_w2_a.shape[0], self.lokr_w2_b.shape[1]), base):
+                return None
+            return ops.lokr_linear_lr(x, w1, self.lokr_w2_a, self.lokr_w2_b, self.scale * self.multiplier, base=base)
+        w2 = self._w2_full()
         if not ops.lokr_linear_fusable(x, w1, w2, base):
             return None
         return ops.lokr_linear(x, w1, w2, self.scale * self.multiplier, base=base)
+
+    def _w2_low_rank_native(self, x):
+        return not self.use_w2 and not self.tucker and self.module_type == "linear" and x.is_cuda
 
     def bypass_forward_diff(self, h, scale=1):
         """delta = (w1 (x) w2) h * alpha/r * scalar * scale, Kronecker-factored.
@@ -237,6 +245,8 @@ class LokrModule(LycorisBaseModule):
         path lokr.py:543-566, which is the canonical semantics."""
         alpha = self.scale * scale
         w1 = self._gate(self._w1_full())
+        if self._w2_low_rank_native(h):
+            return ops.lokr_linear_lr(h, w1, self.lokr_w2_a, self.lokr_w2_b, alpha)
         w2 = self._w2_full()
         if self.module_type == "linear":
             return ops.lokr_linear(h, w1, w2, alpha)

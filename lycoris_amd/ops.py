@@ -48,7 +48,7 @@ def _cpp() -> bool:
         ext.set_accum(_ACCUM["enabled"], _ACCUM["callback"])
         _DISPATCH["ext"] = ext
         ns = torch.ops.lycoris_amd  # the resolved overloads: skips the packet's per-call overload resolution (~1 us per call)
-        for name in ("lokr_linear", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d"):
+        for name in ("lokr_linear", "lokr_linear_lr", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d"):
             _OPS[name] = getattr(ns, name).default
     return True
 
@@ -638,6 +638,26 @@ def lokr_linear(x, w1, w2, alpha=1.0, base=None):
     if _cpp():
         return _OPS["lokr_linear"](x, w1, w2, float(alpha), base)
     return _AdapterLinear.apply(_LokrCore, alpha, _amp(x), w1, w2)
+
+
+def lokr_linear_lr(x, w1, w2a, w2b, alpha=1.0, base=None):
+    """LoKr with a low-rank second factor (reference modules/lokr.py:131-136: w2 = w2_a @ w2_b).  w1:[a,b]  w2a:[c,r]  w2b:[r,d].
+    The product is not materialised: the kernels' operand planes are packed from the two factors and the chain rule of the product
+    runs in the grouped weight-gradient launch (csrc/kron_conv.h kron_lr_chain_kernel).  Under tracing / python dispatch the product
+    is formed by autograd-visible `w2a @ w2b` and handed to lokr_linear."""
+    N.require_device(x, "input")
+    if not _cpp() or torch.compiler.is_compiling() or not x.is_cuda:
+        return lokr_linear(x, w1, w2a @ w2b, alpha, base)
+    if base is not None and not lokr_linear_fusable(x, w1, _Shape2(w2a.shape[0], w2b.shape[1]), base):
+        return base + lokr_linear_lr(x, w1, w2a, w2b, alpha)
+    return _OPS["lokr_linear_lr"](x, w1, w2a, w2b, float(alpha), base)
+
+
+class _Shape2:
+    """stands in for a [c, d] tensor where only `.shape` is read"""
+
+    def __init__(self, c, d):
+        self.shape = (c, d)
 
 
 def locon_linear(x, down, up, alpha=1.0):

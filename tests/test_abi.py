@@ -128,7 +128,8 @@ def test_ctypes_item_structs_match_the_header_layout(tmp_path):
     from lycoris_amd import _native as N
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
-    mirrors = {"LycLokrWgradItem": N.WgradItem, "LycLoconWgradItem": N.LoconWgradItem, "LycLohaWgradItem": N.LohaWgradItem}
+    mirrors = {"LycLokrWgradItem": N.WgradItem, "LycLoconWgradItem": N.LoconWgradItem, "LycLohaWgradItem": N.LohaWgradItem,
+               "LycLokrConvWgradItem": N.LokrConvWgradItem, "LycLokrPackItem": N.LokrPackItem, "LycLokrLrChainItem": N.LokrLrChainItem}
     lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{HEADER}"', "int main(void) {"]
     for cname, cls in mirrors.items():
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
