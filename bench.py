@@ -17,6 +17,7 @@ timing, PMC traffic of the same build from profiles/), "cpu_baseline" (reference
 graph vs graph -- the north-star comparator) and "base_plus_adapter" (the step with the frozen layers' own ops in it).
 """
 import argparse
+import ctypes
 import hashlib
 import json
 import math
@@ -72,6 +73,9 @@ def parse():
     ap.add_argument("--layers", default="all", help="'all', 'linear' or 'conv' (development)")
     ap.add_argument("--force-segments", action="store_true",
                     help="development: cut the backward into --segments graphs at N = 1 too (the N > 1 replay structure without the collectives)")
+    ap.add_argument("--rccl-ws1", action="store_true",
+                    help="run the N > 1 step on one GPU: nccl (= RCCL) process group of world_size 1, every gradient bucket all-reduced "
+                         "in place on the side stream between the backward segment graphs (MASTER_ADDR / MASTER_PORT / RANK from the env)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="development: 'gloo' lets N ranks share ONE GPU (rank % device_count) to exercise the N > 1 control flow "
                          "on a single-GPU box; the driver's runs use nccl (= RCCL), one GPU per rank")
@@ -287,7 +291,7 @@ def main():
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if world > 1 or args.rccl_ws1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -299,7 +303,9 @@ def main():
 
     insts = build_instances(args, dtype, dev)
     all_params = [p for it in insts for p in it.params]
-    sync = AdapterGradSync(all_params, bucket_bytes=32 << 20)
+    # --rccl-ws1: the N > 1 step on ONE GPU -- a world_size-1 RCCL group, every bucket really all-reduced (AVG, in place, side
+    # stream) between the replays of the backward segment graphs
+    sync = AdapterGradSync(all_params, bucket_bytes=32 << 20, always_reduce=bool(args.rccl_ws1))
     sync.attach_fused()  # kernels accumulate into the arena and report to the bucket counters (eager: overlap by hooks)
     from lycoris_amd import ops as _ops
     if args.no_defer:  # A/B: one weight-gradient launch per layer instead of the grouped launches
@@ -346,7 +352,7 @@ def main():
             # part of the step, captured here so that every replay packs the parameters of ITS step
             _ops.refresh_lokr_planes(force=True)
             outs = forward_all(insts)
-        nseg = max(1, min(args.segments if (world > 1 or args.force_segments) else 1, n_layers))
+        nseg = max(1, min(args.segments if (world > 1 or args.force_segments or args.rccl_ws1) else 1, n_layers))
         edges = [round(i * n_layers / nseg) for i in range(nseg + 1)]
         for s in range(nseg, 0, -1):  # backward runs from the last layer to the first
             lo, hi = edges[s - 1], edges[s]
@@ -362,7 +368,7 @@ def main():
             g_fwd.replay()
             for gph, upto in zip(graphs, seg_bounds):
                 gph.replay()
-                if world > 1 or args.force_segments:
+                if world > 1 or args.force_segments or args.rccl_ws1:
                     sync.launch_ready(upto)  # side stream: waits for this segment, runs beside the next ones
             sync.finish()
             opt.step()
@@ -375,6 +381,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    c0 = sync.collectives_launched
     for _ in range(args.warmup):
         step()
     barrier()
@@ -408,7 +415,7 @@ def main():
             "parallelism": f"dp{world}",
             "graph": "eager (no capture)" if args.eager else
                      f"hipGraph replay: 1 forward graph + {len(graphs)} backward segment(s)"
-                     + (", bucket all-reduces issued between segments on a side stream" if world > 1 else ""),
+                     + (", bucket all-reduces issued between segments on a side stream" if (world > 1 or args.rccl_ws1) else ""),
             "conv_memory_format": "channels_last" if args.channels_last else "contiguous (NCHW)",
             "inputs": "shared per shape (cache-resident)" if args.shared_inputs else
                       f"distinct x / g per layer instance: {act_bytes / 1e9:.2f} GB read per step",
@@ -427,9 +434,16 @@ def main():
         result["value_base_plus_adapter"] = round(1e3 / result["base_plus_adapter"]["base_plus_adapter_ms"], 3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.algo in ("lokr", "locon", "loha"):
         result["cpu_baseline"] = cpu_baseline(args.algo, args.model)
+    if args.rccl_ws1:
+        steps_run = args.warmup + args.steps
+        sync.collectives_launched -= c0
+        result["config"]["rccl_ws1"] = {"backend": dist.get_backend(), "buckets": len(sync.buckets),
+                                        "all_reduces_per_step": sync.collectives_launched / max(1, steps_run)}
     if rank == 0:
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)  # RCCL's version banner sits in the C stdio buffer: the JSON line is the LAST line
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or args.rccl_ws1:
         dist.destroy_process_group()
 
 

@@ -615,20 +615,20 @@ Tensor lokr_linear_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2, doub
 
 // dx (or undefined), and the factor gradients accumulated into dw1 / dw2 when those are defined
 Tensor lokr_linear_bwd_into(const Tensor& g, const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, bool need_dx,
-                            const Tensor& dw1, const Tensor& dw2) {
+                            const Tensor& dw1, const Tensor& dw2, bool f32_rows = false) {
   const c10::DeviceGuard guard(x.device());
   const int64_t a = w1.size(0), b = w1.size(1), c = w2.size(0), d = w2.size(1);
   Tensor rows = rows_of(x, b * d), g2 = rows_of(g, a * c), f1 = f32c(w1);
-  const int code = dtype_code(x.scalar_type());
+  const int code0 = dtype_code(x.scalar_type()), code = code0 | (f32_rows ? LYC_F32_ROWS : 0);  // f32_rows: dx in fp32 (the Conv2d lowering's col2im rounds once)
   const bool want_dx = need_dx || dw1.defined();  // the w1 gradient shares the pass over g that produces dx
   Tensor dx, ws;
-  if (want_dx) dx = at::empty(rows.sizes(), x.options());
+  if (want_dx) dx = at::empty(rows.sizes(), f32_rows ? x.options().dtype(at::kFloat) : x.options());
   if (dw1.defined()) {
-    const int64_t nbytes = lyc_lokr_bwd_workspace_bytes(rows.size(0), (int)a, (int)b, (int)c, (int)d, code);
+    const int64_t nbytes = lyc_lokr_bwd_workspace_bytes(rows.size(0), (int)a, (int)b, (int)c, (int)d, code0);
     if (nbytes > 0) ws = at::empty({nbytes}, x.options().dtype(at::kByte));
   }
   Tensor pl;
-  if (want_dx && lyc_lokr_linear_planes_ok(rows.size(0), (int)a, (int)b, (int)c, (int)d, code) &&
+  if (want_dx && !f32_rows && lyc_lokr_linear_planes_ok(rows.size(0), (int)a, (int)b, (int)c, (int)d, code0) &&
       (reinterpret_cast<uintptr_t>(cptr(g2)) & 15u) == 0)
     pl = planes_for(w2, x.scalar_type(), stream_of(x));
   if (pl.defined()) {
@@ -882,15 +882,16 @@ std::tuple<Tensor, Tensor> locon_linear_fwd(const Tensor& x, const Tensor& down,
 }
 
 Tensor locon_linear_bwd_into(const Tensor& g, const Tensor& x, const Tensor& down, const Tensor& up, const Tensor& t, double alpha,
-                             bool need_dx, const Tensor& dd, const Tensor& du) {
+                             bool need_dx, const Tensor& dd, const Tensor& du, bool f32_rows = false) {
   const c10::DeviceGuard guard(x.device());
   const int64_t r = down.size(0), I = down.size(1), O = up.size(0);
   Tensor rows = rows_of(x, I), g2 = rows_of(g, O), fd = f32c(down), fu = f32c(up);
   const int64_t M = rows.size(0);
   Tensor dt = at::empty({M, r}, x.options().dtype(at::kFloat));
-  Tensor dx = need_dx ? at::empty(rows.sizes(), x.options()) : Tensor();
+  Tensor dx = need_dx ? at::empty(rows.sizes(), f32_rows ? x.options().dtype(at::kFloat) : x.options()) : Tensor();
   check_rc(lyc_locon_linear_bwd(cptr(g2), cptr(rows), cfp(fd), cfp(fu), cfp(t), mfp(dt), mptr(dx), mfp(dd), mfp(du), M, (int)I,
-                                (int)O, (int)r, (float)alpha, dtype_code(x.scalar_type()), stream_of(x)), "lyc_locon_linear_bwd");
+                                (int)O, (int)r, (float)alpha, dtype_code(x.scalar_type()) | (f32_rows ? LYC_F32_ROWS : 0), stream_of(x)),
+           "lyc_locon_linear_bwd");
   return need_dx ? dx.view(x.sizes()) : Tensor();
 }
 
@@ -1001,7 +1002,7 @@ std::tuple<Tensor, Tensor> loha_linear_fwd(const Tensor& x, const Tensor& w1a, c
 }
 
 Tensor loha_linear_bwd_into(const Tensor& g, const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a,
-                            const Tensor& w2b, const Tensor& ws, double alpha, bool need_dx, Tensor (&d)[4]) {
+                            const Tensor& w2b, const Tensor& ws, double alpha, bool need_dx, Tensor (&d)[4], bool f32_rows = false) {
   const c10::DeviceGuard guard(x.device());
   const int64_t O = w1a.size(0), r = w1a.size(1), I = w1b.size(1);
   Tensor rows = rows_of(x, I), g2 = rows_of(g, O), a1 = f32c(w1a), b1 = f32c(w1b), a2 = f32c(w2a), b2 = f32c(w2b);
@@ -1011,10 +1012,10 @@ Tensor loha_linear_bwd_into(const Tensor& g, const Tensor& x, const Tensor& w1a,
   if (any)  // the factor-gradient kernel produces the four gradients as a set
     for (int i = 0; i < 4; ++i) tmp[i] = d[i].defined() ? d[i] : at::zeros(fs[i]->sizes(), fs[i]->options().dtype(at::kFloat));
   Tensor gw = any ? at::empty({O, I}, x.options().dtype(at::kFloat)) : Tensor();
-  Tensor dx = need_dx ? at::empty(rows.sizes(), x.options()) : Tensor();
+  Tensor dx = need_dx ? at::empty(rows.sizes(), f32_rows ? x.options().dtype(at::kFloat) : x.options()) : Tensor();
   check_rc(lyc_loha_linear_bwd(cptr(g2), cptr(rows), cfp(a1), cfp(b1), cfp(a2), cfp(b2), cptr(ws), mfp(gw), mptr(dx), mfp(tmp[0]),
                                mfp(tmp[1]), mfp(tmp[2]), mfp(tmp[3]), rows.size(0), (int)I, (int)O, (int)r, (float)alpha,
-                               dtype_code(x.scalar_type()), stream_of(x)), "lyc_loha_linear_bwd");
+                               dtype_code(x.scalar_type()) | (f32_rows ? LYC_F32_ROWS : 0), stream_of(x)), "lyc_loha_linear_bwd");
   return need_dx ? dx.view(x.sizes()) : Tensor();
 }
 
@@ -1672,6 +1673,207 @@ Tensor locon_conv2d_meta(const Tensor& x, const Tensor& down, const Tensor& up, 
   return conv2d_meta(x, down, up, alpha, s, p, d, false);
 }
 
+// =====================================================================================================================
+// Conv2d through the row kernels: every adapter on every Conv2d geometry the implicit kernels above do not take
+// (LoHa always; LoKr / LoCon with fp32 activations or factor shapes off their fast paths; 1x1 convolutions)
+// =====================================================================================================================
+// The Conv2d form of an adapter is its Linear form on the im2col matrix (include/lycoris_amd.h "Conv2d lowering"; reference:
+// F.conv2d in functional/general.py:6 with the [.., I*kh*kw] factor views of modules/{locon,loha,lokr}.py).  A 1x1 / stride 1 /
+// no-padding convolution needs no im2col at all: its row matrix is the NHWC view of x (free for a channels_last tensor).
+// algo: 0 = LoKr (f0 = w1 [a, b], f1 = w2 [c, d*kh*kw]), 1 = LoCon (f0 = down [r, C*kh*kw], f1 = up [O, r]),
+//       2 = LoHa (f0..f3 = w1a [O, r], w1b [r, C*kh*kw], w2a, w2b)
+enum { ALGO_LOKR = 0, ALGO_LOCON = 1, ALGO_LOHA = 2 };
+bool pointwise(const Geom& g) { return g.kh == 1 && g.kw == 1 && g.sh == 1 && g.sw == 1 && g.ph == 0 && g.pw == 0; }
+int64_t rows_out_features(int64_t algo, const Tensor& f0, const Tensor& f1) {
+  return algo == ALGO_LOKR ? f0.size(0) * f1.size(0) : algo == ALGO_LOCON ? f1.size(0) : f0.size(0);
+}
+int64_t rows_in_features(int64_t algo, const Tensor& f0, const Tensor& f1) {
+  return algo == ALGO_LOKR ? f0.size(1) * f1.size(1) : algo == ALGO_LOCON ? f0.size(1) : f1.size(1);
+}
+Tensor im2col_rows(const Tensor& x, const Geom& gm) {
+  const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+  Tensor xc = x.contiguous();
+  Tensor cols = at::empty({B * gm.Ho * gm.Wo, C * gm.kh * gm.kw}, x.options());
+  check_rc(lyc_im2col(cptr(xc), mptr(cols), B, C, H, W, gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, dtype_code(x.scalar_type()),
+                      stream_of(x)), "lyc_im2col");
+  return cols;
+}
+// (y [B, O, Ho, Wo], cols: the im2col matrix (empty for a 1x1 convolution: backward takes the rows from x), saved: LoCon's t /
+// LoHa's dW images)
+std::tuple<Tensor, Tensor, Tensor> adapter_conv2d_fwd(const Tensor& x, const Tensor& f0, const Tensor& f1, const c10::optional<Tensor>& f2,
+                                                      const c10::optional<Tensor>& f3, int64_t algo, double alpha, at::IntArrayRef kernel,
+                                                      at::IntArrayRef stride, at::IntArrayRef padding, at::IntArrayRef dilation) {
+  require_device(x, "input");
+  const c10::DeviceGuard dg(x.device());
+  TORCH_CHECK(x.dim() == 4, "Conv2d adapter expects NCHW input, got shape ", x.sizes());
+  TORCH_CHECK(algo >= ALGO_LOKR && algo <= ALGO_LOHA, "adapter_conv2d: algo ", algo);
+  TORCH_CHECK(algo != ALGO_LOHA || (f2.has_value() && f3.has_value()), "adapter_conv2d: LoHa takes four factors");
+  const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+  Geom gm = geom_of(kernel, stride, padding, dilation, H, W);
+  const int64_t I = rows_in_features(algo, f0, f1), O = rows_out_features(algo, f0, f1);
+  TORCH_CHECK(I == C * gm.kh * gm.kw, "adapter expects ", I, " = C*kh*kw im2col features, input has C=", C, ", kernel=", kernel);
+  const bool pw = pointwise(gm);
+  bool copied = true;
+  Tensor rows = pw ? rows_view(x, &copied) : im2col_rows(x, gm);
+  Tensor y_rows, saved;
+  if (algo == ALGO_LOKR) {
+    y_rows = lokr_linear_fwd(rows, f0, f1, alpha, c10::nullopt);
+    saved = at::empty({0}, x.options());
+  } else if (algo == ALGO_LOCON) {
+    std::tie(y_rows, saved) = locon_linear_fwd(rows, f0, f1, alpha);
+  } else {
+    std::tie(y_rows, saved) = loha_linear_fwd(rows, f0, f1, *f2, *f3, alpha);
+  }
+  (void)O;
+  return {from_rows(y_rows, B, gm.Ho, gm.Wo, pw && !copied), pw ? at::empty({0}, x.options()) : rows, saved};
+}
+
+// dx and the factor gradients accumulated into the defined d[i]
+Tensor adapter_conv2d_bwd_into(const Tensor& g, const Tensor& x_or_cols, bool is_cols, at::IntArrayRef xshape, bool x_cl, const Tensor& saved,
+                               const Tensor* f[4], int64_t algo, double alpha, const Geom& gm, bool need_dx, Tensor (&d)[4]) {
+  const c10::DeviceGuard dg(g.device());
+  const int64_t B = xshape[0], H = xshape[2], W = xshape[3];
+  bool cp;
+  Tensor g_rows = rows_view(g, &cp);
+  Tensor rows = is_cols ? x_or_cols : rows_view(x_or_cols, &cp);
+  const bool f32_rows = is_cols && g.scalar_type() != at::kFloat;  // col2im sums up to kh*kw row entries per pixel: fp32, rounded once
+  Tensor dx_rows;
+  if (algo == ALGO_LOKR) dx_rows = lokr_linear_bwd_into(g_rows, rows, *f[0], *f[1], alpha, need_dx, d[0], d[1], f32_rows);
+  else if (algo == ALGO_LOCON) dx_rows = locon_linear_bwd_into(g_rows, rows, *f[0], *f[1], saved, alpha, need_dx, d[0], d[1], f32_rows);
+  else dx_rows = loha_linear_bwd_into(g_rows, rows, *f[0], *f[1], *f[2], *f[3], saved, alpha, need_dx, d, f32_rows);
+  if (!need_dx) return Tensor();
+  if (!is_cols) return from_rows(dx_rows, B, H, W, x_cl);
+  Tensor dx = at::empty(xshape, g.options());
+  check_rc(lyc_col2im(cptr(dx_rows), mptr(dx), B, xshape[1], H, W, gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw,
+                      dtype_code(g.scalar_type()) | (f32_rows ? LYC_F32_ROWS : 0), stream_of(g)), "lyc_col2im");
+  return dx;
+}
+
+// the functional backward op (what a compiled graph calls): gradients as new tensors in the factors' dtypes
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> adapter_conv2d_bwd(const Tensor& g, const Tensor& x, const Tensor& cols, const Tensor& saved,
+                                                                      const Tensor& f0, const Tensor& f1, const c10::optional<Tensor>& f2,
+                                                                      const c10::optional<Tensor>& f3, int64_t algo, double alpha,
+                                                                      at::IntArrayRef kernel, at::IntArrayRef stride, at::IntArrayRef padding,
+                                                                      at::IntArrayRef dilation, bool need_dx, bool need_f) {
+  Geom gm = geom_of(kernel, stride, padding, dilation, x.size(2), x.size(3));
+  const bool pw = pointwise(gm);
+  Tensor u2 = f2.has_value() ? *f2 : Tensor(), u3 = f3.has_value() ? *f3 : Tensor();
+  const Tensor* f[4] = {&f0, &f1, &u2, &u3};
+  const int nf = algo == ALGO_LOHA ? 4 : 2;
+  Tensor d[4];
+  if (need_f)
+    for (int i = 0; i < nf; ++i) d[i] = at::zeros(f[i]->sizes(), f[i]->options().dtype(at::kFloat));
+  Tensor dx = adapter_conv2d_bwd_into(g, pw ? x : cols, !pw, x.sizes(), rows_are_free(x), saved, f, algo, alpha, gm, need_dx, d);
+  auto out = [&](int i) { return (need_f && i < nf) ? d[i].to(f[i]->scalar_type()) : at::empty({0}, f0.options()); };
+  return {dx.defined() ? dx : at::empty({0}, x.options()), out(0), out(1), out(2), out(3)};
+}
+
+struct AdapterConv2dFn : public torch::autograd::Function<AdapterConv2dFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& f0, const Tensor& f1, const c10::optional<Tensor>& f2,
+                        const c10::optional<Tensor>& f3, int64_t algo, double alpha, std::vector<int64_t> kernel, std::vector<int64_t> stride,
+                        std::vector<int64_t> padding, std::vector<int64_t> dilation) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_adapter_conv2d_forward", "")
+                         .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const c10::optional<Tensor>&,
+                                                                   const c10::optional<Tensor>&, int64_t, double, at::IntArrayRef,
+                                                                   at::IntArrayRef, at::IntArrayRef, at::IntArrayRef)>();
+    auto [y, cols, saved] = op.call(x, f0, f1, f2, f3, algo, alpha, kernel, stride, padding, dilation);
+    Tensor u2 = f2.has_value() ? *f2 : Tensor(), u3 = f3.has_value() ? *f3 : Tensor();
+    const Tensor* fs[4] = {&f0, &f1, &u2, &u3};
+    for (const Tensor* f : fs)
+      if (f->defined()) expect(*f, x);
+    ctx->save_for_backward({x, cols, saved, f0, f1, u2, u3});
+    ctx->saved_data["algo"] = algo;
+    ctx->saved_data["alpha"] = alpha;
+    ctx->saved_data["geom"] = std::vector<int64_t>{kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1]};
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const Tensor &x = s[0], &cols = s[1], &saved = s[2];
+    const int64_t algo = ctx->saved_data["algo"].toInt();
+    const double alpha = ctx->saved_data["alpha"].toDouble();
+    auto gv = ctx->saved_data["geom"].toIntVector();
+    const std::vector<int64_t> kernel{gv[0], gv[1]}, stride{gv[2], gv[3]}, padding{gv[4], gv[5]}, dilation{gv[6], gv[7]};
+    const int nf = algo == ALGO_LOHA ? 4 : 2;
+    const bool nx = ctx->needs_input_grad(0);
+    bool need[4] = {false, false, false, false}, any = false;
+    for (int i = 0; i < nf; ++i) any = (need[i] = ctx->needs_input_grad(1 + i)) || any;
+    const Tensor& g = grads[0];
+    variable_list out(11);
+    if (eager_cuda(g) && eager_cuda(x)) {
+      Geom gm = geom_of(kernel, stride, padding, dilation, x.size(2), x.size(3));
+      const bool pw = pointwise(gm);
+      const Tensor* f[4] = {&s[3], &s[4], &s[5], &s[6]};
+      GradTarget t[4];
+      Tensor d[4];
+      for (int i = 0; i < nf; ++i) {
+        t[i] = grad_target(*f[i], need[i] || accum_wanted(*f[i]));
+        d[i] = t[i].buf;
+      }
+      Tensor dx = adapter_conv2d_bwd_into(g, pw ? x : cols, !pw, x.sizes(), rows_are_free(x), saved, f, algo, alpha, gm, nx, d);
+      out[0] = dx;
+      for (int i = 0; i < nf; ++i) out[1 + i] = finish_grad(*f[i], t[i]);
+      return out;
+    }
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_adapter_conv2d_backward", "")
+                         .typed<std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor>(
+                             const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&, const c10::optional<Tensor>&,
+                             const c10::optional<Tensor>&, int64_t, double, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef,
+                             bool, bool)>();
+    c10::optional<Tensor> o2 = s[5].defined() ? c10::optional<Tensor>(s[5]) : c10::nullopt;
+    c10::optional<Tensor> o3 = s[6].defined() ? c10::optional<Tensor>(s[6]) : c10::nullopt;
+    auto [dx, d0, d1, d2, d3] = op.call(g, x, cols, saved, s[3], s[4], o2, o3, algo, alpha, kernel, stride, padding, dilation, nx, any);
+    out[0] = nx ? dx : Tensor();
+    const Tensor* dd[4] = {&d0, &d1, &d2, &d3};
+    for (int i = 0; i < nf; ++i) out[1 + i] = need[i] ? *dd[i] : Tensor();
+    return out;
+  }
+};
+Tensor adapter_conv2d_autograd(const Tensor& x, const Tensor& f0, const Tensor& f1, const c10::optional<Tensor>& f2,
+                               const c10::optional<Tensor>& f3, int64_t algo, double alpha, at::IntArrayRef kernel, at::IntArrayRef stride,
+                               at::IntArrayRef padding, at::IntArrayRef dilation) {
+  const GradAtApply ga_;
+  return AdapterConv2dFn::apply(amp(x), f0, f1, f2, f3, algo, alpha, kernel.vec(), stride.vec(), padding.vec(), dilation.vec());
+}
+Tensor adapter_conv2d_cuda(const Tensor& x, const Tensor& f0, const Tensor& f1, const c10::optional<Tensor>& f2, const c10::optional<Tensor>& f3,
+                           int64_t algo, double alpha, at::IntArrayRef kernel, at::IntArrayRef stride, at::IntArrayRef padding,
+                           at::IntArrayRef dilation) {
+  return std::get<0>(adapter_conv2d_fwd(x, f0, f1, f2, f3, algo, alpha, kernel, stride, padding, dilation));
+}
+std::tuple<Tensor, Tensor, Tensor> adapter_conv2d_fwd_meta(const Tensor& x, const Tensor& f0, const Tensor& f1, const c10::optional<Tensor>& f2,
+                                                           const c10::optional<Tensor>& f3, int64_t algo, double alpha, at::IntArrayRef kernel,
+                                                           at::IntArrayRef stride, at::IntArrayRef padding, at::IntArrayRef dilation) {
+  Geom gm = geom_of(kernel, stride, padding, dilation, x.size(2), x.size(3));
+  const int64_t B = x.size(0), C = x.size(1), O = rows_out_features(algo, f0, f1), M = B * gm.Ho * gm.Wo;
+  const bool pw = pointwise(gm);
+  Tensor y = at::empty({B, O, gm.Ho, gm.Wo},
+                       x.options().memory_format(pw && rows_are_free(x) ? at::MemoryFormat::ChannelsLast : at::MemoryFormat::Contiguous));
+  Tensor cols = pw ? x.new_empty({0}) : x.new_empty({M, C * gm.kh * gm.kw});
+  Tensor saved;
+  if (algo == ALGO_LOKR) saved = x.new_empty({0});
+  else if (algo == ALGO_LOCON) saved = x.new_empty({M, f0.size(0)}, x.options().dtype(at::kFloat));
+  else saved = x.new_empty({lyc_loha_workspace_bytes((int)O, (int)(C * gm.kh * gm.kw), dtype_code(x.scalar_type()))}, x.options().dtype(at::kByte));
+  return {y, cols, saved};
+}
+Tensor adapter_conv2d_meta(const Tensor& x, const Tensor& f0, const Tensor& f1, const c10::optional<Tensor>& f2, const c10::optional<Tensor>& f3,
+                           int64_t algo, double alpha, at::IntArrayRef kernel, at::IntArrayRef stride, at::IntArrayRef padding,
+                           at::IntArrayRef dilation) {
+  return std::get<0>(adapter_conv2d_fwd_meta(x, f0, f1, f2, f3, algo, alpha, kernel, stride, padding, dilation));
+}
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> adapter_conv2d_bwd_meta(const Tensor& g, const Tensor& x, const Tensor& cols, const Tensor& saved,
+                                                                           const Tensor& f0, const Tensor& f1, const c10::optional<Tensor>& f2,
+                                                                           const c10::optional<Tensor>& f3, int64_t algo, double alpha,
+                                                                           at::IntArrayRef kernel, at::IntArrayRef stride, at::IntArrayRef padding,
+                                                                           at::IntArrayRef dilation, bool need_dx, bool need_f) {
+  auto e = [&](const Tensor& t, bool n) { return n ? at::empty_like(t) : t.new_empty({0}); };
+  auto eo = [&](const c10::optional<Tensor>& t, bool n) { return (n && t.has_value()) ? at::empty_like(*t) : f0.new_empty({0}); };
+  Tensor dx = need_dx ? at::empty(x.sizes(), x.options().memory_format(pointwise(geom_of(kernel, stride, padding, dilation, x.size(2), x.size(3))) && rows_are_free(x)
+                                                                             ? at::MemoryFormat::ChannelsLast : at::MemoryFormat::Contiguous))
+                      : x.new_empty({0});
+  return {dx, e(f0, need_f), e(f1, need_f), eo(f2, need_f), eo(f3, need_f)};
+}
+
 }  // namespace
 
 TORCH_LIBRARY(lycoris_amd, m) {
@@ -1683,6 +1885,13 @@ TORCH_LIBRARY(lycoris_amd, m) {
   m.def("chan_affine(Tensor a, Tensor w, Tensor? bias, float s0, float mult, int chan_dim) -> Tensor");
   m.def("lokr_conv2d(Tensor x, Tensor w1, Tensor w2, float alpha, int[2] stride, int[2] padding, int[2] dilation) -> Tensor");
   m.def("locon_conv2d(Tensor x, Tensor down, Tensor up, float alpha, int[2] stride, int[2] padding, int[2] dilation) -> Tensor");
+  m.def("adapter_conv2d(Tensor x, Tensor f0, Tensor f1, Tensor? f2, Tensor? f3, int algo, float alpha, int[2] kernel, int[2] stride, "
+        "int[2] padding, int[2] dilation) -> Tensor");
+  m.def("_adapter_conv2d_forward(Tensor x, Tensor f0, Tensor f1, Tensor? f2, Tensor? f3, int algo, float alpha, int[2] kernel, int[2] stride, "
+        "int[2] padding, int[2] dilation) -> (Tensor, Tensor, Tensor)");
+  m.def("_adapter_conv2d_backward(Tensor g, Tensor x, Tensor cols, Tensor saved, Tensor f0, Tensor f1, Tensor? f2, Tensor? f3, int algo, "
+        "float alpha, int[2] kernel, int[2] stride, int[2] padding, int[2] dilation, bool need_dx, bool need_f) "
+        "-> (Tensor, Tensor, Tensor, Tensor, Tensor)");
   // forward / backward kernels as functional ops (what torch.compile traces through)
   m.def("_lokr_linear_backward(Tensor g, Tensor x, Tensor w1, Tensor w2, float alpha, bool need_dx, bool need_dw1, bool need_dw2) "
         "-> (Tensor, Tensor, Tensor)");
@@ -1718,6 +1927,9 @@ TORCH_LIBRARY_IMPL(lycoris_amd, CUDA, m) {
   m.impl("_lokr_conv2d_backward", lokr_conv2d_bwd);
   m.impl("_locon_conv2d_forward", locon_conv2d_fwd);
   m.impl("_locon_conv2d_backward", locon_conv2d_bwd);
+  m.impl("adapter_conv2d", adapter_conv2d_cuda);
+  m.impl("_adapter_conv2d_forward", adapter_conv2d_fwd);
+  m.impl("_adapter_conv2d_backward", adapter_conv2d_bwd);
 }
 
 TORCH_LIBRARY_IMPL(lycoris_amd, Meta, m) {
@@ -1737,6 +1949,9 @@ TORCH_LIBRARY_IMPL(lycoris_amd, Meta, m) {
   m.impl("_lokr_conv2d_backward", lokr_conv2d_bwd_meta);
   m.impl("_locon_conv2d_forward", locon_conv2d_fwd_meta);
   m.impl("_locon_conv2d_backward", locon_conv2d_bwd_meta);
+  m.impl("adapter_conv2d", adapter_conv2d_meta);
+  m.impl("_adapter_conv2d_forward", adapter_conv2d_fwd_meta);
+  m.impl("_adapter_conv2d_backward", adapter_conv2d_bwd_meta);
 }
 
 TORCH_LIBRARY_IMPL(lycoris_amd, Autograd, m) {
@@ -1747,6 +1962,7 @@ TORCH_LIBRARY_IMPL(lycoris_amd, Autograd, m) {
   m.impl("chan_affine", chan_affine_autograd);
   m.impl("lokr_conv2d", lokr_conv2d_implicit);
   m.impl("locon_conv2d", locon_conv2d_implicit);
+  m.impl("adapter_conv2d", adapter_conv2d_autograd);
 }
 
 PYBIND11_MODULE(_lyc_torch, m) {

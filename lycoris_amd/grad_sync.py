@@ -67,6 +67,7 @@ class AdapterGradSync:
         self._handles = []
         self._sync_enabled = True
         self._fused = False
+        self.collectives_launched = 0  # all-reduces issued since construction (diagnostics)
         self.launch_log: List[int] = []  # bucket indices in launch order of the current step (tests / diagnostics)
         # reverse registration order: the last layers' gradients are ready first during backward
         by_dtype = {}
@@ -188,6 +189,7 @@ class AdapterGradSync:
         self.launch_log.append(b.index)
         if not self._reduce:
             return
+        self.collectives_launched += 1
         if self.side_stream is not None:
             # the bucket's gradients were produced on the compute stream: order the collective after them
             self.side_stream.wait_stream(torch.cuda.current_stream(self.device))

@@ -48,7 +48,7 @@ def _cpp() -> bool:
         ext.set_accum(_ACCUM["enabled"], _ACCUM["callback"])
         _DISPATCH["ext"] = ext
         ns = torch.ops.lycoris_amd  # the resolved overloads: skips the packet's per-call overload resolution (~1 us per call)
-        for name in ("lokr_linear", "lokr_linear_lr", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d"):
+        for name in ("lokr_linear", "lokr_linear_lr", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d"):
             _OPS[name] = getattr(ns, name).default
     return True
 
@@ -683,6 +683,19 @@ def chan_affine(a, w, bias=None, s0=0.0, mult=1.0, chan_dim=-1):
     return _ChanAffine.apply(_amp(a), w, bias, s0, mult, chan_dim)
 
 
+_ROWS_ALGO = {"_LokrCore": 0, "_LoconCore": 1, "_LohaCore": 2}  # csrc/torch_ops.cpp ALGO_*
+
+
+def _rows_conv2d(core, alpha, geom, x, *factors):
+    """Conv2d through the row kernels (im2col lowering; the NHWC view for a 1x1 convolution): torch.ops.lycoris_amd.adapter_conv2d
+    (C++ dispatch + autograd, traceable) or the Python autograd.Function over the same C ABI calls"""
+    if _cpp():
+        f2, f3 = (factors[2], factors[3]) if len(factors) == 4 else (None, None)
+        return _OPS["adapter_conv2d"](x, factors[0], factors[1], f2, f3, _ROWS_ALGO[core.__name__], float(alpha), list(geom[0]),
+                                      list(geom[1]), list(geom[2]), list(geom[3]))
+    return _AdapterConv2d.apply(core, alpha, geom, x, *factors)
+
+
 def _geom(ksize, stride, padding, dilation):
     return (tuple(int(v) for v in ksize), tuple(stride), tuple(padding), tuple(dilation))
 
@@ -697,13 +710,14 @@ def locon_conv2d(x, down, up, alpha, stride, padding, dilation):
         if _cpp():
             return _OPS["locon_conv2d"](x, down, up, float(alpha), list(geom[1]), list(geom[2]), list(geom[3]))
         return _LoconConv2dImplicit.apply(alpha, geom, x, down, up)
-    return _AdapterConv2d.apply(_LoconCore, alpha, geom, x, down.reshape(r, -1), up.reshape(O, r))
+    return _rows_conv2d(_LoconCore, alpha, geom, x, down.reshape(r, -1), up.reshape(O, r))
 
 
 def loha_conv2d(x, w1a, w1b, w2a, w2b, alpha, shape, stride, padding, dilation):
     """w*a:[O, r]  w*b:[r, I*kh*kw];  shape = (O, I, kh, kw)"""
-    return _AdapterConv2d.apply(_LohaCore, alpha, _geom(shape[2:], stride, padding, dilation), _amp(x), w1a,
-                                w1b.reshape(w1b.shape[0], -1), w2a, w2b.reshape(w2b.shape[0], -1))
+    N.require_device(x, "input")
+    return _rows_conv2d(_LohaCore, alpha, _geom(shape[2:], stride, padding, dilation), _amp(x), w1a,
+                        w1b.reshape(w1b.shape[0], -1), w2a, w2b.reshape(w2b.shape[0], -1))
 
 
 def lokr_conv2d(x, w1, w2, alpha, stride, padding, dilation):
@@ -716,7 +730,7 @@ def lokr_conv2d(x, w1, w2, alpha, stride, padding, dilation):
         if _cpp():
             return _OPS["lokr_conv2d"](x, w1, w2, float(alpha), list(geom[1]), list(geom[2]), list(geom[3]))
         return _LokrConv2dImplicit.apply(alpha, geom, x, w1, w2)
-    return _AdapterConv2d.apply(_LokrCore, alpha, geom, x, w1, w2.reshape(w2.shape[0], -1))
+    return _rows_conv2d(_LokrCore, alpha, geom, x, w1, w2.reshape(w2.shape[0], -1))
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -93,6 +93,49 @@ def test_fused_accumulation_and_callback_from_the_cpp_backward():
         ops.fused_grad_accumulation(False, None)
 
 
+ROWS_CONV = [("loha", 3, 1, 1), ("loha", 1, 1, 0), ("lokr", 3, 2, 1), ("lokr", 1, 1, 0), ("locon", 3, 1, 1), ("locon", 1, 1, 0)]
+
+
+@pytest.mark.parametrize("channels_last", [False, True], ids=["nchw", "nhwc"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+@pytest.mark.parametrize("algo,k,stride,pad", ROWS_CONV, ids=[f"{a}_k{k}_s{s}" for a, k, s, _ in ROWS_CONV])
+def test_rows_lowered_conv2d_cpp_dispatch_equals_python_dispatch(algo, k, stride, pad, dtype, channels_last):
+    """torch.ops.lycoris_amd.adapter_conv2d (round 3): the im2col / NHWC-rows lowering of every adapter as ONE C++ op with the
+    same C ABI calls as the Python autograd.Function it replaces -- LoHa on any Conv2d, LoKr / LoCon off their implicit
+    kernels (fp32 activations; a 3-wide w1 here for the 16-bit case), 1x1 convolutions"""
+    from lycoris_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    rn = lambda *s, sc=1.0, dt=torch.float32: (torch.randn(*s, device=DEV, generator=g) * sc).to(dt).requires_grad_(True)
+    C, O = 48, 72
+    x = rn(2, C, 9, 8, dt=dtype)
+    if channels_last:
+        x = x.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    geo = ((stride, stride), (pad, pad), (1, 1))
+    if algo == "loha":
+        fs = [rn(O, 4, sc=0.3), rn(4, C * k * k), rn(O, 4, sc=0.3), rn(4, C * k * k)]
+        f = lambda: ops.loha_conv2d(x, *fs, 0.7, (O, C, k, k), *geo)
+    elif algo == "lokr":  # w1 3 x 3: not a shape of the implicit kernel
+        fs = [rn(3, 3, sc=0.3), rn(O // 3, C // 3, k, k, sc=0.1)]
+        f = lambda: ops.lokr_conv2d(x, *fs, 0.7, *geo)
+    else:  # rank 6: off the implicit LoCon kernel's rank tiles for 16-bit; fp32 always lowers
+        fs = [rn(6, C, k, k, sc=0.1), rn(O, 6, 1, 1, sc=0.1)]
+        f = lambda: ops.locon_conv2d(x, *fs, 0.7, *geo)
+
+    def run():
+        y = f()
+        gy = torch.ones_like(y) * 0.01
+        return [y.detach().clone()] + [t.clone() for t in torch.autograd.grad(y, [x] + fs, gy)]
+
+    a, b = _both(run)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert u.dtype == v.dtype and u.shape == v.shape, i
+        if i < 2:
+            assert torch.equal(u, v), (algo, i, float((u.float() - v.float()).abs().max()))
+            assert u.is_contiguous(memory_format=torch.channels_last) == v.is_contiguous(memory_format=torch.channels_last), i
+        else:
+            assert torch.allclose(u.float(), v.float(), rtol=1e-4, atol=1e-6), (algo, i)
+
+
 @pytest.mark.parametrize("algo", ["lokr", "locon", "loha"])
 def test_adapted_linear_layer_under_torch_compile(algo):
     """torch.compile(backend="aot_eager"): Dynamo + AOTAutograd trace forward AND backward of the adapted layer through the
@@ -124,14 +167,17 @@ def test_adapted_linear_layer_under_torch_compile(algo):
         assert torch.allclose(u.float(), v.float(), rtol=2e-2 if i < 2 else 1e-3, atol=1e-3), (algo, i)
 
 
-@pytest.mark.parametrize("algo", ["lokr", "locon"])
-def test_adapted_conv2d_layer_under_torch_compile(algo):
-    """the Conv2d ops trace too: forward = the public op, backward = lycoris_amd::_{lokr,locon}_conv2d_backward, both with Meta
-    kernels (reference: test/compile.py compiles a model with conv layers)"""
-    from lycoris_amd.modules import LoConModule, LokrModule
+@pytest.mark.parametrize("ksize", [3, 1], ids=["k3", "k1"])
+@pytest.mark.parametrize("algo", ["lokr", "locon", "loha"])
+def test_adapted_conv2d_layer_under_torch_compile(algo, ksize):
+    """the Conv2d ops trace too: forward = the public op, backward = lycoris_amd::_{lokr,locon}_conv2d_backward (implicit kernels)
+    or lycoris_amd::_adapter_conv2d_backward (LoHa; every 1x1 convolution), all with Meta kernels (reference: test/compile.py
+    compiles a model with conv layers)"""
+    from lycoris_amd.modules import LoConModule, LohaModule, LokrModule
     torch.manual_seed(0)
-    layer = nn.Conv2d(64, 128, 3, padding=1).to(DEV, torch.bfloat16).requires_grad_(False)
-    cls, kw = {"lokr": (LokrModule, dict(lora_dim=100000, alpha=1, factor=8)), "locon": (LoConModule, dict(lora_dim=8, alpha=4))}[algo]
+    layer = nn.Conv2d(64, 128, ksize, padding=ksize // 2).to(DEV, torch.bfloat16).requires_grad_(False)
+    cls, kw = {"lokr": (LokrModule, dict(lora_dim=100000, alpha=1, factor=8)), "locon": (LoConModule, dict(lora_dim=8, alpha=4)),
+               "loha": (LohaModule, dict(lora_dim=4, alpha=2))}[algo]
     mod = cls("m", layer, 1.0, **kw).to(DEV)
     with torch.no_grad():
         for p in mod.parameters():
@@ -152,6 +198,60 @@ def test_adapted_conv2d_layer_under_torch_compile(algo):
     for i, (u, v) in enumerate(zip(got, eager)):
         assert u.shape == v.shape, (algo, i)
         assert torch.allclose(u.float(), v.float(), rtol=2e-2 if i < 2 else 1e-3, atol=2e-3), (algo, i, float((u.float() - v.float()).abs().max()))
+
+
+class _ToyBlock(nn.Module):
+    """conv -> 1x1 conv -> (tokens) linear -> linear -> linear, the frozen layers of a mixed-algorithm preset"""
+
+    def __init__(self):
+        super().__init__()
+        self.conv_in = nn.Conv2d(32, 64, 3, padding=1)
+        self.proj = nn.Conv2d(64, 64, 1)
+        self.q = nn.Linear(64, 64)
+        self.ff1 = nn.Linear(64, 128)
+        self.ff2 = nn.Linear(128, 64)
+
+    def forward(self, x):
+        h = self.proj(torch.nn.functional.silu(self.conv_in(x)))
+        t = h.flatten(2).transpose(1, 2)
+        t = t + self.q(t)
+        return t + self.ff2(torch.nn.functional.gelu(self.ff1(t)))
+
+
+def test_mixed_algorithm_block_under_torch_compile_fullgraph():
+    """one graph, no break, over a block that mixes every algorithm and both layer types --
+    LoCon on the 3x3 conv, LoHa on the 1x1 conv, LoKr / LoHa / (IA)^3 on the Linears (reference: test/compile.py)"""
+    from lycoris_amd.modules import IA3Module, LoConModule, LohaModule, LokrModule
+    torch.manual_seed(1)
+    block = _ToyBlock().to(DEV, torch.bfloat16).requires_grad_(False)
+    plan = [("conv_in", LoConModule, dict(lora_dim=8, alpha=4)), ("proj", LohaModule, dict(lora_dim=4, alpha=2)),
+            ("q", LokrModule, dict(lora_dim=100000, alpha=1, factor=8)), ("ff1", LohaModule, dict(lora_dim=4, alpha=2)),
+            ("ff2", IA3Module, dict())]
+    mods = []
+    for name, cls, kw in plan:
+        m = cls(name, getattr(block, name), 1.0, **kw).to(DEV)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.randn_like(p) * 0.2)
+        m.apply_to()
+        mods.append(m)
+    params = [p for m in mods for p in m.parameters()]
+    x = torch.randn(2, 32, 8, 8, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+
+    def run(fn):
+        y = fn(x)
+        return [y.detach()] + list(torch.autograd.grad(y.float().pow(2).sum(), [x] + params))
+
+    eager = run(block)
+    torch._dynamo.reset()
+    compiled = torch.compile(block, backend="aot_eager", fullgraph=True)
+    got = run(compiled)
+    for m in mods:
+        m.restore()
+    for i, (u, v) in enumerate(zip(got, eager)):
+        assert u.shape == v.shape, i
+        den = float(v.float().norm()) or 1.0
+        assert float((u.float() - v.float()).norm()) / den <= 2e-2, (i, float((u.float() - v.float()).norm()) / den)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
