@@ -179,8 +179,10 @@ class Inst:
             if base is not None:
                 return ops.lokr_linear_lr(self.x, p[0], p[1], p[2], 1.0, base=base)
             return ops.lokr_linear_lr(self.x, p[0], p[1], p[2], 1.0)
-        if self.algo == "lokr" and len(p) == 3:  # Conv2d: the product the modules form (lycoris_amd/modules/lokr.py _w2_full)
-            p = [p[0], (p[1] @ p[2]).reshape(p[1].shape[0], self.cin // FACTOR, *self.ksz)]
+        if self.algo == "lokr" and len(p) == 3:  # Conv2d low-rank w2: planes from the factors where the patch kernels take the layer
+            if base is not None:
+                return base + self.forward()
+            return ops.lokr_conv2d_lr(self.x, p[0], p[1], p[2], 1.0, self.ksz, (s["stride"],) * 2, (s["pad"],) * 2, (1, 1))
         if base is not None:
             if lin and self.algo == "lokr":
                 return ops.lokr_linear(self.x, p[0], p[1], 1.0, base=base)

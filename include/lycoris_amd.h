@@ -173,12 +173,13 @@ int lyc_lokr_pack_group(const LycLokrPackItem* items, int n, int dtype, void* st
  *     d_w2a += dW2 w2b^T,   d_w2b += w2a^T dW2          (fp32, accumulated atomically)
  * replaces the reference's `w2a @ w2b` + its two autograd GEMMs per layer and step (functional/lokr.py:124-151). */
 typedef struct LycLokrLrChainItem {
-  const float* dw2;   /* [c, d]  */
+  const float* dw2;   /* [c, d]; Conv2d: [c, taps, d], the window-major layout lyc_lokr_conv_wgrad_group writes */
   const float* w2a;   /* [c, r]  */
-  const float* w2b;   /* [r, d]  */
+  const float* w2b;   /* [r, d]; Conv2d: [r, d * taps] with column v * taps + tap (reference layout, modules/lokr.py:131-136) */
   float* d_w2a;       /* [c, r] +=   (NULL: factor frozen; not both) */
-  float* d_w2b;       /* [r, d] +=   (NULL: factor frozen) */
+  float* d_w2b;       /* same layout as w2b, +=   (NULL: factor frozen) */
   int c, d, r;
+  int taps;           /* kh * kw; 0 or 1: nn.Linear */
 } LycLokrLrChainItem;
 int lyc_lokr_lr_chain_group(const LycLokrLrChainItem* items, int n, void* stream);
 int lyc_lokr_linear_planes_ok(int64_t M, int a, int b, int c, int d, int dtype);

@@ -93,7 +93,8 @@ class LokrPackItem(ctypes.Structure):
 
 class LokrLrChainItem(ctypes.Structure):
     """LycLokrLrChainItem (include/lycoris_amd.h)"""
-    _fields_ = [("dw2", _vp), ("w2a", _vp), ("w2b", _vp), ("d_w2a", _vp), ("d_w2b", _vp), ("c", _i32), ("d", _i32), ("r", _i32)]
+    _fields_ = [("dw2", _vp), ("w2a", _vp), ("w2b", _vp), ("d_w2a", _vp), ("d_w2b", _vp), ("c", _i32), ("d", _i32), ("r", _i32),
+                ("taps", _i32)]
 
 
 class LokrConvWgradItem(ctypes.Structure):

@@ -612,13 +612,14 @@ int lyc_lokr_lr_chain_group(const LycLokrLrChainItem* items, int n, void* stream
   };
   for (int k = 0; k < n; ++k) {
     const LycLokrLrChainItem& it = items[k];
-    if (!it.dw2 || !it.w2a || !it.w2b || (!it.d_w2a && !it.d_w2b) || it.c < 1 || it.d < 1 || it.r < 1)
+    if (!it.dw2 || !it.w2a || !it.w2b || (!it.d_w2a && !it.d_w2b) || it.c < 1 || it.d < 1 || it.r < 1 || it.taps < 0)
       return fail(LYC_ERR_ARG, "lokr_lr_chain_group: item %d: bad arguments", k);
     if (ga.n == KLR_MAX)
       if (int rc = flush()) return rc;
     KronLrItem& q = ga.p[ga.n];
     q.dw2 = it.dw2; q.w2a = it.w2a; q.w2b = it.w2b; q.d_w2a = it.d_w2a; q.d_w2b = it.d_w2b; q.c = it.c; q.d = it.d; q.r = it.r;
-    const long wgs = cdiv((long)it.c * it.r + (long)it.r * it.d, NTHREADS);
+    q.taps = it.taps > 0 ? it.taps : 1;
+    const long wgs = cdiv(kron_lr_threads(it.c, it.d, it.r, q.taps), NTHREADS);
     ga.wg_end[ga.n] = (int)((ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs);
     ++ga.n;
   }

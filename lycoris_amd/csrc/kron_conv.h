@@ -68,20 +68,58 @@ __device__ __forceinline__ void kron_pack_units(const KronPackArgs& a, long unit
   const int tap = (int)(k0 / Kt);
   const int kk0 = (int)(k0 - (long)tap * Kt);
   T h[8], l[8];
+  float val[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float v = 0.f;
-    if (n < N && tap < a.taps) {
-      const int q = fwd ? n : kk0 + e, vv = fwd ? kk0 + e : n;
-      if (a.w2 != nullptr) {
-        v = a.w2[q * a.sq + vv * a.sv + tap * a.st];
+  for (int e = 0; e < 8; ++e) val[e] = 0.f;
+  if (n < N && tap < a.taps) {
+    if (a.w2 != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int q = fwd ? n : kk0 + e, vv = fwd ? kk0 + e : n;
+        val[e] = a.w2[q * a.sq + vv * a.sv + tap * a.st];
+      }
+    } else if (fwd) {  // low rank, q = n fixed: one w2a value and 8 neighbouring w2b values per rank (16-byte loads for nn.Linear)
+      const float* ar = a.w2a + n * a.a_sq;
+      const float* bc = a.w2b + kk0 * a.b_sv + tap * a.b_st;
+      const bool vec = a.b_sv == 1 && ((reinterpret_cast<uintptr_t>(bc) | (uintptr_t)(a.b_sr * 4)) & 15u) == 0;
+      for (int r = 0; r < a.rank; ++r) {
+        const float av = ar[r * a.a_sr];
+        const float* br = bc + r * a.b_sr;
+        float bv[8];
+        if (vec) {
+          *reinterpret_cast<f32x4*>(bv) = *reinterpret_cast<const f32x4*>(br);
+          *reinterpret_cast<f32x4*>(bv + 4) = *reinterpret_cast<const f32x4*>(br + 4);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bv[e] = br[e * a.b_sv];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) val[e] = fmaf(av, bv[e], val[e]);
+      }
+    } else {           // low rank, column n fixed, q = kk0 + e: one w2b value per rank, 8 rows of w2a
+      const float* bc = a.w2b + n * a.b_sv + tap * a.b_st;
+      const float* a0 = a.w2a + kk0 * a.a_sq;
+      const bool vec = a.a_sr == 1 && (a.rank & 3) == 0 && ((reinterpret_cast<uintptr_t>(a0) | (uintptr_t)(a.a_sq * 4)) & 15u) == 0;
+      if (vec) {
+        for (int r = 0; r < a.rank; r += 4) {
+          const float b0 = bc[r * a.b_sr], b1 = bc[(r + 1) * a.b_sr], b2 = bc[(r + 2) * a.b_sr], b3 = bc[(r + 3) * a.b_sr];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a0 + e * a.a_sq + r);
+            val[e] = fmaf(av[3], b3, fmaf(av[2], b2, fmaf(av[1], b1, fmaf(av[0], b0, val[e]))));  // rank-ascending, as the scalar loop
+          }
+        }
       } else {
-        for (int r = 0; r < a.rank; ++r)
-          v = fmaf(a.w2a[q * a.a_sq + r * a.a_sr], a.w2b[r * a.b_sr + vv * a.b_sv + tap * a.b_st], v);
+        for (int r = 0; r < a.rank; ++r) {
+          const float bv = bc[r * a.b_sr];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) val[e] = fmaf(a0[e * a.a_sq + r * a.a_sr], bv, val[e]);
+        }
       }
     }
-    split_f<T>(v, h[e], l[e]);
   }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split_f<T>(val[e], h[e], l[e]);
   *reinterpret_cast<u32x4*>(plane + unit * 2048 + lane * 16) = *reinterpret_cast<u32x4*>(h);
   *reinterpret_cast<u32x4*>(plane + unit * 2048 + 1024 + lane * 16) = *reinterpret_cast<u32x4*>(l);
 }
@@ -114,15 +152,15 @@ __global__ __launch_bounds__(NTHREADS) void kron_pack_group_kernel(KronPackGroup
 //     d_w2a[q, r] += sum_v dW2[q, v] * w2b[r, v]        d_w2b[r, v] += sum_q w2a[q, r] * dW2[q, v]
 // for MANY layers per launch, from the dense dW2 [c, d] the grouped weight-gradient launch left in a scratch arena (fp32 FMAs:
 // 4 c d r flops per layer, a few GFLOP per SDXL step -- the two ATen GEMM launches per layer it replaces cost more in launches
-// than in arithmetic).  One thread per output element; a workgroup's threads walk r fastest (a dW2 row is a broadcast).
+// than in arithmetic).
 // ---------------------------------------------------------------------------------------------------------------------
 struct KronLrItem {
-  const float* dw2;   // [c, d]
+  const float* dw2;   // [c, taps, d]   (taps > 1: the window-major layout the Conv2d weight-gradient kernels write)
   const float* w2a;   // [c, r]
-  const float* w2b;   // [r, d]
-  float* d_w2a;       // [c, r] +=   (NULL: not wanted)
-  float* d_w2b;       // [r, d] +=   (NULL: not wanted)
-  int c, d, r;
+  const float* w2b;   // [r, d * taps]  (the reference's layout: column v * taps + tap)
+  float* d_w2a;       // [c, r] +=          (NULL: not wanted)
+  float* d_w2b;       // [r, d * taps] +=   (NULL: not wanted)
+  int c, d, r, taps;
 };
 constexpr int KLR_MAX = 56;
 struct KronLrGroupArgs {
@@ -132,39 +170,88 @@ struct KronLrGroupArgs {
 };
 static_assert(sizeof(KronLrGroupArgs) <= 3840, "kernel arguments are limited to 4 KiB");
 
+// Work split (round 3, second version: the first one ran one serial loop per output element -- 1440 .. 2880 dependent iterations for
+// a Conv2d layer -- and cost 2.0 ms of the rank-16 SDXL step):
+//   d_w2a: one WAVE per (row q, block of 16 ranks, chunk of KLR_CA columns).  Lanes stride the columns (dW2 and, for nn.Linear, w2b
+//          are read coalesced; every dW2 element is loaded once for 16 ranks), 16 register accumulators, a butterfly reduction
+//          over the wave, one atomic per (q, rank).
+//   d_w2b: one THREAD per (column, block of 16 ranks, chunk of KLR_KB rows): dW2 read coalesced once for 16 ranks, w2a values are
+//          wave-uniform loads, 16 atomics per thread.
+constexpr int KLR_RB = 16, KLR_CA = 1024, KLR_KB = 16;
+__host__ __device__ inline long kron_lr_threads_a(int c, int d, int r, int taps) {
+  const long D = (long)d * taps;
+  return (long)c * ((r + KLR_RB - 1) / KLR_RB) * ((D + KLR_CA - 1) / KLR_CA) * 64;
+}
+__host__ __device__ inline long kron_lr_threads(int c, int d, int r, int taps) {
+  const long D = (long)d * taps;
+  return kron_lr_threads_a(c, d, r, taps) + D * ((r + KLR_RB - 1) / KLR_RB) * ((c + KLR_KB - 1) / KLR_KB);
+}
+
 __global__ __launch_bounds__(NTHREADS) void kron_lr_chain_kernel(KronLrGroupArgs ga) {
   const int b = (int)blockIdx.x;
   int p = 0;
   while (p + 1 < ga.n && b >= ga.wg_end[p]) ++p;
   const KronLrItem& it = ga.p[p];
   const long e = (long)(b - (p ? ga.wg_end[p - 1] : 0)) * NTHREADS + threadIdx.x;
-  const long na = (long)it.c * it.r;
-  if (e < na) {  // d_w2a[q, rr]
+  const long D = (long)it.d * it.taps;
+  const int nrb = (it.r + KLR_RB - 1) / KLR_RB;
+  const long na = kron_lr_threads_a(it.c, it.d, it.r, it.taps);
+  if (e < na) {  // ---- d_w2a: a wave per (q, rank block, column chunk); na is a multiple of 64: the branch is wave-uniform
     if (!it.d_w2a) return;  // a frozen factor
-    const int q = (int)(e / it.r), rr = (int)(e - (long)q * it.r);
-    const float* g = it.dw2 + (long)q * it.d;
-    const float* w = it.w2b + (long)rr * it.d;
-    float s0 = 0.f, s1 = 0.f;
-    int v = 0;
-    for (; v + 1 < it.d; v += 2) {
-      s0 = fmaf(g[v], w[v], s0);
-      s1 = fmaf(g[v + 1], w[v + 1], s1);
+    const int lane = (int)(e & 63);
+    const long w = e >> 6;
+    const long nch = (D + KLR_CA - 1) / KLR_CA;
+    const long chunk = w % nch;
+    const int rb = (int)((w / nch) % nrb);
+    const int q = (int)(w / (nch * nrb));
+    const long col0 = chunk * KLR_CA, col1 = col0 + KLR_CA < D ? col0 + KLR_CA : D;
+    const float* g = it.dw2 + (long)q * D;
+    const float* wb = it.w2b + (long)rb * KLR_RB * D;
+    const int nr = it.r - rb * KLR_RB < KLR_RB ? it.r - rb * KLR_RB : KLR_RB;
+    float acc[KLR_RB];
+#pragma unroll
+    for (int j = 0; j < KLR_RB; ++j) acc[j] = 0.f;
+    for (long col = col0 + lane; col < col1; col += 64) {
+      const float gv = g[col];
+      const int tap = (int)(col / it.d);                      // dW2 column order: tap * d + v;  w2b: v * taps + tap
+      const long wcol = (col - (long)tap * it.d) * it.taps + tap;
+#pragma unroll
+      for (int j = 0; j < KLR_RB; ++j)
+        if (j < nr) acc[j] = fmaf(gv, wb[(long)j * D + wcol], acc[j]);
     }
-    if (v < it.d) s0 = fmaf(g[v], w[v], s0);
-    __hip_atomic_fetch_add(it.d_w2a + e, s0 + s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else if (e < na + (long)it.r * it.d) {  // d_w2b[rr, v]: consecutive threads -> consecutive v (coalesced dW2 rows)
-    const long f = e - na;
-    if (!it.d_w2b) return;
-    const int rr = (int)(f / it.d), v = (int)(f - (long)rr * it.d);
-    float s0 = 0.f, s1 = 0.f;
-    int q = 0;
-    for (; q + 1 < it.c; q += 2) {
-      s0 = fmaf(it.w2a[(long)q * it.r + rr], it.dw2[(long)q * it.d + v], s0);
-      s1 = fmaf(it.w2a[(long)(q + 1) * it.r + rr], it.dw2[(long)(q + 1) * it.d + v], s1);
+#pragma unroll
+    for (int j = 0; j < KLR_RB; ++j) {
+      float v = acc[j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0 && j < nr) __hip_atomic_fetch_add(it.d_w2a + (long)q * it.r + rb * KLR_RB + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (q < it.c) s0 = fmaf(it.w2a[(long)q * it.r + rr], it.dw2[(long)q * it.d + v], s0);
-    __hip_atomic_fetch_add(it.d_w2b + f, s0 + s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
   }
+  // ---- d_w2b[rr, (v, tap)]: neighbouring threads walk dW2's own column order
+  const long f = e - na;
+  const long nchb = (it.c + KLR_KB - 1) / KLR_KB;
+  if (f >= D * nrb * nchb || !it.d_w2b) return;
+  const long col = f % D;
+  const long t = f / D;
+  const int rb = (int)(t % nrb);
+  const int q0 = (int)(t / nrb) * KLR_KB, q1 = q0 + KLR_KB < it.c ? q0 + KLR_KB : it.c;
+  const int nr = it.r - rb * KLR_RB < KLR_RB ? it.r - rb * KLR_RB : KLR_RB;
+  const int tap = (int)(col / it.d);
+  const long wcol = (col - (long)tap * it.d) * it.taps + tap;
+  float acc[KLR_RB];
+#pragma unroll
+  for (int j = 0; j < KLR_RB; ++j) acc[j] = 0.f;
+  for (int q = q0; q < q1; ++q) {
+    const float gv = it.dw2[(long)q * D + col];
+    const float* wa = it.w2a + (long)q * it.r + rb * KLR_RB;
+#pragma unroll
+    for (int j = 0; j < KLR_RB; ++j)
+      if (j < nr) acc[j] = fmaf(wa[j], gv, acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < KLR_RB; ++j)
+    if (j < nr) __hip_atomic_fetch_add(it.d_w2b + (long)(rb * KLR_RB + j) * D + wcol, acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -206,6 +206,7 @@ struct DeferredLokrConv {
   float alpha;
   void* stream;
   c10::DeviceIndex device;
+  Tensor w2a, w2b, d_w2a, d_w2b;  // low-rank w2 (all four defined): dw2p is then a slice of the flush's scratch arena
 };
 struct DeferredLoha {
   Tensor g, x, f[4], p[4], d[4];  // f: fp32 contiguous factors, p: the parameters (for the sync callback), d: .grad targets
@@ -267,15 +268,31 @@ void flush_deferred(c10::DeviceIndex device) {
   for (size_t lo = 0; lo < citems.size();) {  // Conv2d LoKr layers: one call per (stream, dtype) run
     size_t hi = lo + 1;
     while (hi < citems.size() && citems[hi].stream == citems[lo].stream && citems[hi].code == citems[lo].code) ++hi;
+    const c10::DeviceGuard guard(c10::Device(c10::kCUDA, citems[lo].device));
+    const c10::hip::HIPStreamGuard sguard(c10::hip::getStreamFromExternal((hipStream_t)citems[lo].stream, citems[lo].device));
+    int64_t arena_floats = 0;  // low-rank layers: dW2 [c, kh, kw, d] into ONE zero-filled scratch, then the product's chain rule
+    for (size_t i = lo; i < hi; ++i)
+      if (citems[i].w2a.defined()) arena_floats += (int64_t)citems[i].c * citems[i].d * citems[i].geom[0] * citems[i].geom[1];
+    Tensor arena;
+    if (arena_floats > 0) arena = at::zeros({arena_floats}, citems[lo].g_rows.options().dtype(at::kFloat));
     std::vector<LycLokrConvWgradItem> raw(hi - lo);
+    std::vector<LycLokrLrChainItem> chain;
+    int64_t off = 0;
     for (size_t i = lo; i < hi; ++i) {
       const DeferredLokrConv& it = citems[i];
-      raw[i - lo] = LycLokrConvWgradItem{cptr(it.g_rows), cptr(it.x_rows), cfp(it.f1), mfp(it.dw1), mfp(it.dw2p), mptr(it.ws), it.B, it.H,
+      float* dw2p = mfp(it.dw2p);
+      if (it.w2a.defined()) {
+        const int taps = it.geom[0] * it.geom[1];
+        dw2p = arena.mutable_data_ptr<float>() + off;
+        off += (int64_t)it.c * it.d * taps;
+        chain.push_back(LycLokrLrChainItem{dw2p, cfp(it.w2a), cfp(it.w2b), mfp(it.d_w2a), mfp(it.d_w2b), it.c, it.d, (int)it.w2a.size(1), taps});
+      }
+      raw[i - lo] = LycLokrConvWgradItem{cptr(it.g_rows), cptr(it.x_rows), cfp(it.f1), mfp(it.dw1), dw2p, mptr(it.ws), it.B, it.H,
                                          it.W, it.dw1_blocks, it.a, it.b, it.c, it.d, it.geom[0], it.geom[1], it.geom[2], it.geom[3],
                                          it.geom[4], it.geom[5], it.geom[6], it.geom[7], it.alpha};
     }
-    const c10::DeviceGuard guard(c10::Device(c10::kCUDA, citems[lo].device));
     check_rc(lyc_lokr_conv_wgrad_group(raw.data(), (int)raw.size(), citems[lo].code, citems[lo].stream), "lyc_lokr_conv_wgrad_group");
+    if (!chain.empty()) check_rc(lyc_lokr_lr_chain_group(chain.data(), (int)chain.size(), citems[lo].stream), "lyc_lokr_lr_chain_group");
     join_ambient(citems[lo].device, citems[lo].stream);
     lo = hi;
   }
@@ -367,7 +384,12 @@ void flush_deferred(c10::DeviceIndex device) {
   }
   for (const DeferredLokrConv& it : citems) {
     if (it.dw1.defined()) notify(it.w1);
-    notify(it.w2);
+    if (it.w2a.defined()) {
+      notify(it.w2a);
+      notify(it.w2b);
+    } else {
+      notify(it.w2);
+    }
   }
 }
 
@@ -529,12 +551,13 @@ Tensor planes_for(const Tensor& w2, at::ScalarType act, void* stream) {
   return e.planes[slot];
 }
 // the same for a low-rank pair w2a [c, r], w2b [r, d] (both leaves, fp32, contiguous): planes of w2a @ w2b, formed in the pack kernel
-Tensor planes_for_lr(const Tensor& w2a, const Tensor& w2b, at::ScalarType act, void* stream) {
+Tensor planes_for_lr(const Tensor& w2a, const Tensor& w2b, at::ScalarType act, void* stream, int taps = 1) {
   if (!g_planes.enabled || !w2a.is_cuda() || !w2a.is_leaf() || !w2b.is_leaf() || w2a.scalar_type() != at::kFloat ||
       w2b.scalar_type() != at::kFloat || !w2a.is_contiguous() || !w2b.is_contiguous() || w2a.dim() != 2 || w2b.dim() != 2)
     return Tensor();
   if (act != at::kBFloat16 && act != at::kHalf) return Tensor();
-  const int64_t c = w2a.size(0), r = w2a.size(1), d = w2b.size(1);
+  if (taps < 1 || (w2b.size(1) % taps) != 0) return Tensor();
+  const int64_t c = w2a.size(0), r = w2a.size(1), d = w2b.size(1) / taps;  // w2b [r, d * taps]: column v * taps + tap
   if ((c % 8) != 0 || (d % 8) != 0 || r < 1 || w2b.size(0) != r) return Tensor();
   const int slot = act == at::kBFloat16 ? 0 : 1;
   c10::TensorImpl* impl = w2a.unsafeGetTensorImpl();
@@ -552,21 +575,22 @@ Tensor planes_for_lr(const Tensor& w2a, const Tensor& w2b, at::ScalarType act, v
   PlaneEntry& e = it->second;
   const float *pa = w2a.const_data_ptr<float>(), *pb = w2b.const_data_ptr<float>();
   auto ob = e.owner_b.lock();
-  const bool same_view = e.rank == r && e.w2a == pa && e.w2b == pb && e.c == c && e.d == d && ob && ob.get() == w2b.unsafeGetTensorImpl();
+  const bool same_view = e.rank == r && e.w2a == pa && e.w2b == pb && e.c == c && e.d == d && e.taps == taps && ob &&
+                         ob.get() == w2b.unsafeGetTensorImpl();
   if (!same_view) {
     e.planes[0] = e.planes[1] = Tensor();
     e.version[0] = e.version[1] = e.version_b[0] = e.version_b[1] = -1;
-    e.w2 = nullptr; e.w2a = pa; e.w2b = pb; e.rank = (int)r; e.c = (int)c; e.d = (int)d; e.taps = 1; e.sq = e.sv = e.st = 0;
+    e.w2 = nullptr; e.w2a = pa; e.w2b = pb; e.rank = (int)r; e.c = (int)c; e.d = (int)d; e.taps = taps; e.sq = e.sv = e.st = 0;
     e.owner_b = c10::weak_intrusive_ptr<c10::TensorImpl>(w2b.getIntrusivePtr());
     e.device = w2a.device().index();
   }
   const int64_t va = (int64_t)w2a._version(), vb = (int64_t)w2b._version();
   if (!e.planes[slot].defined()) {
-    const int64_t nb = lyc_lokr_planes_bytes((int)c, (int)d, 1, 0) + lyc_lokr_planes_bytes((int)c, (int)d, 1, 1);
+    const int64_t nb = lyc_lokr_planes_bytes((int)c, (int)d, taps, 0) + lyc_lokr_planes_bytes((int)c, (int)d, taps, 1);
     e.planes[slot] = at::empty({nb}, w2a.options().dtype(at::kByte));
     char* base = static_cast<char*>(e.planes[slot].mutable_data_ptr());
-    check_rc(lyc_lokr_pack_w2(nullptr, 0, 0, 0, pa, r, 1, pb, d, 1, 0, (int)r, (int)c, (int)d, 1, base,
-                              base + lyc_lokr_planes_bytes((int)c, (int)d, 1, 0), slot == 0 ? LYC_BF16 : LYC_F16, stream),
+    check_rc(lyc_lokr_pack_w2(nullptr, 0, 0, 0, pa, r, 1, pb, d * taps, taps, 1, (int)r, (int)c, (int)d, taps, base,
+                              base + lyc_lokr_planes_bytes((int)c, (int)d, taps, 0), slot == 0 ? LYC_BF16 : LYC_F16, stream),
              "lyc_lokr_pack_w2(low rank)");
     e.version[slot] = va;
     e.version_b[slot] = vb;
@@ -1587,6 +1611,146 @@ Tensor lokr_conv2d_implicit(const Tensor& x, const Tensor& w1, const Tensor& w2,
   return LokrConv2dFn::apply(amp(x), w1, w2, alpha, stride.vec(), padding.vec(), dilation.vec());
 }
 
+// ---- LoKr on nn.Conv2d with a low-rank w2 = w2a [c, r] @ w2b [r, d*kh*kw] (reference modules/lokr.py:131-136, 370) -----------------
+// Only where the patch kernels take both passes (lokr_conv2d_lr_ok): the planes are packed straight from the two factors, the
+// weight gradient goes through the grouped chain-rule launch.  Everything else forms the product (lycoris_amd/ops.py).
+bool lokr_conv2d_lr_ok(const Tensor& x, const Tensor& w1, const Tensor& w2a, const Tensor& w2b, at::IntArrayRef kernel,
+                       at::IntArrayRef stride, at::IntArrayRef padding, at::IntArrayRef dilation) {
+  if (!x.is_cuda() || !eager_cuda(x) || x.dim() != 4 || w1.dim() != 2 || w2a.dim() != 2 || w2b.dim() != 2) return false;
+  at::ScalarType act = x.scalar_type();
+  if (act == at::kFloat && at::autocast::is_autocast_enabled(at::kCUDA)) act = at::autocast::get_autocast_dtype(at::kCUDA);
+  if (act != at::kBFloat16 && act != at::kHalf) return false;
+  const int taps = (int)(kernel[0] * kernel[1]);
+  if (taps < 1 || w2b.size(1) % taps || w2a.size(1) != w2b.size(0)) return false;
+  const int64_t a = w1.size(0), b = w1.size(1), c = w2a.size(0), d = w2b.size(1) / taps;
+  if (x.size(1) != b * d || (c % 8) || (d % 8)) return false;
+  if (!g_planes.enabled || !w2a.is_leaf() || !w2b.is_leaf() || w2a.scalar_type() != at::kFloat || w2b.scalar_type() != at::kFloat ||
+      !w2a.is_contiguous() || !w2b.is_contiguous())
+    return false;
+  Geom gm = geom_of(kernel, stride, padding, dilation, x.size(2), x.size(3));
+  const int code = dtype_code(act);
+  for (int bw = 0; bw < 2; ++bw)
+    if (!lyc_lokr_conv2d_planes_ok(x.size(0), x.size(2), x.size(3), (int)a, (int)b, (int)c, (int)d, gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw,
+                                   gm.dh, gm.dw, code, bw))
+      return false;
+  return true;
+}
+
+struct LokrConv2dLrFn : public torch::autograd::Function<LokrConv2dLrFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w1, const Tensor& w2a, const Tensor& w2b, double alpha,
+                        std::vector<int64_t> kernel, std::vector<int64_t> stride, std::vector<int64_t> padding, std::vector<int64_t> dilation) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    require_device(x, "input");
+    TORCH_CHECK(lokr_conv2d_lr_ok(x, w1, w2a, w2b, kernel, stride, padding, dilation),
+                "lycoris_amd::lokr_conv2d_lr: layer off the patch kernels' fast path (form w2a @ w2b and call lokr_conv2d: ops.lokr_conv2d_lr does)");
+    const c10::DeviceGuard dg(x.device());
+    const int taps = (int)(kernel[0] * kernel[1]);
+    const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+    const int64_t a = w1.size(0), b = w1.size(1), c = w2a.size(0), d = w2b.size(1) / taps;
+    Geom gm = geom_of(kernel, stride, padding, dilation, H, W);
+    bool copied;
+    Tensor rows = rows_view(x, &copied), f1 = f32c(w1);
+    Tensor y = at::empty({B * gm.Ho * gm.Wo, a * c}, x.options());
+    const int code = dtype_code(x.scalar_type());
+    Tensor planes = planes_for_lr(w2a, w2b, x.scalar_type(), stream_of(x), taps);
+    TORCH_CHECK(planes.defined(), "lokr_conv2d_lr: no operand planes");
+    check_rc(lyc_lokr_conv2d_fwd_planes(cptr(rows), cfp(f1), cptr(planes), mptr(y), B, H, W, (int)a, (int)b, (int)c, (int)d, gm.kh, gm.kw,
+                                        gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, (float)alpha, code, stream_of(x)),
+             "lyc_lokr_conv2d_fwd_planes");
+    expect(w1, x);
+    expect(w2a, x);
+    expect(w2b, x);
+    ctx->save_for_backward({rows, w1, w2a, w2b});
+    ctx->saved_data["alpha"] = alpha;
+    ctx->saved_data["geom"] = std::vector<int64_t>{gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, gm.Ho, gm.Wo, B, C, H, W, !copied};
+    return from_rows(y, B, gm.Ho, gm.Wo, !copied);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const Tensor &rows = s[0], &w1 = s[1], &w2a = s[2], &w2b = s[3];
+    const double alpha = ctx->saved_data["alpha"].toDouble();
+    auto gv = ctx->saved_data["geom"].toIntVector();
+    const int64_t B = gv[10], C = gv[11], H = gv[12], W = gv[13];
+    const bool x_cl = gv[14] != 0;
+    const int taps = (int)(gv[0] * gv[1]);
+    const int64_t a = w1.size(0), b = w1.size(1), c = w2a.size(0), r = w2a.size(1), d = w2b.size(1) / taps;
+    const c10::DeviceGuard dg(rows.device());
+    bool cp;
+    Tensor g_rows = rows_view(grads[0], &cp);
+    const bool nx = ctx->needs_input_grad(0), n1 = ctx->needs_input_grad(1), na = ctx->needs_input_grad(2), nb2 = ctx->needs_input_grad(3);
+    Tensor f1 = f32c(w1);
+    const int code = dtype_code(rows.scalar_type());
+    const bool a1 = n1 || accum_wanted(w1), want_w2 = na || nb2 || accum_wanted(w2a) || accum_wanted(w2b);
+    Tensor dx_rows = (nx || a1) ? at::empty({B * H * W, C}, rows.options()) : Tensor();
+    GradTarget t1 = grad_target(w1, a1), ta = grad_target(w2a, want_w2), tb = grad_target(w2b, want_w2);
+    Tensor ws;
+    if (t1.buf.defined()) {
+      const int64_t nb = lyc_lokr_conv2d_bwd_workspace_bytes(B, H, W, (int)a, (int)b, (int)d);
+      if (nb > 0) ws = at::empty({nb}, rows.options().dtype(at::kByte));
+    }
+    // the planes of THIS step (the optimizer has not run between forward and backward: the cache entry is current)
+    Tensor planes = planes_for_lr(w2a, w2b, rows.scalar_type(), stream_of(rows), taps);
+    TORCH_CHECK(planes.defined(), "lokr_conv2d_lr: no operand planes in backward");
+    const void* planes_b = planes_bwd_ptr(planes, c, d, taps);
+    const bool defer = g_defer.enabled && want_w2 && !ta.hand_back && !tb.hand_back && t1.buf.defined() && !t1.hand_back && ws.defined() &&
+                       dx_rows.defined();
+    if (defer) {
+      check_rc(lyc_lokr_conv2d_bwd_planes(cptr(g_rows), cptr(rows), cfp(f1), nullptr, planes_b, mptr(dx_rows), mfp(t1.buf), nullptr, mptr(ws),
+                                          B, H, W, (int)a, (int)b, (int)c, (int)d, (int)gv[0], (int)gv[1], (int)gv[2], (int)gv[3], (int)gv[4],
+                                          (int)gv[5], (int)gv[6], (int)gv[7], (float)alpha, code | LYC_DEFER_WGRAD, stream_of(rows)),
+               "lyc_lokr_conv2d_bwd_planes(dx)");
+      DeferredLokrConv item{g_rows, rows, f1, w1, Tensor(), t1.buf, Tensor(), ws, B, H, W,
+                            lyc_lokr_conv2d_dx_blocks(B, H, W, (int)a, (int)b, (int)c, (int)d, (int)gv[0], (int)gv[1], (int)gv[2], (int)gv[3],
+                                                      (int)gv[4], (int)gv[5], (int)gv[6], (int)gv[7], code, 1),
+                            (int)a, (int)b, (int)c, (int)d, {(int)gv[0], (int)gv[1], (int)gv[2], (int)gv[3], (int)gv[4], (int)gv[5], (int)gv[6],
+                            (int)gv[7]}, code, (float)alpha, stream_of(rows), rows.device().index()};
+      item.w2a = w2a; item.w2b = w2b; item.d_w2a = ta.buf; item.d_w2b = tb.buf;
+      park_deferred(std::move(item));
+      return {nx ? from_rows(dx_rows, B, H, W, x_cl) : Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+    Tensor dw2p = want_w2 ? at::zeros({c, gv[0], gv[1], d}, rows.options().dtype(at::kFloat)) : Tensor();
+    check_rc(lyc_lokr_conv2d_bwd_planes(cptr(g_rows), cptr(rows), cfp(f1), nullptr, planes_b, mptr(dx_rows), mfp(t1.buf), mfp(dw2p), mptr(ws),
+                                        B, H, W, (int)a, (int)b, (int)c, (int)d, (int)gv[0], (int)gv[1], (int)gv[2], (int)gv[3], (int)gv[4],
+                                        (int)gv[5], (int)gv[6], (int)gv[7], (float)alpha, code, stream_of(rows)),
+             "lyc_lokr_conv2d_bwd_planes");
+    if (want_w2) {
+      LycLokrLrChainItem ci{cfp(dw2p), cfp(w2a), cfp(w2b), mfp(ta.buf), mfp(tb.buf), (int)c, (int)d, (int)r, taps};
+      check_rc(lyc_lokr_lr_chain_group(&ci, 1, stream_of(rows)), "lyc_lokr_lr_chain_group");
+    }
+    return {nx ? from_rows(dx_rows, B, H, W, x_cl) : Tensor(), finish_grad(w1, t1), finish_grad(w2a, ta), finish_grad(w2b, tb), Tensor(),
+            Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+// below autograd (inference_mode): the forward launch alone
+Tensor lokr_conv2d_lr_cuda(const Tensor& x, const Tensor& w1, const Tensor& w2a, const Tensor& w2b, double alpha, at::IntArrayRef kernel,
+                           at::IntArrayRef stride, at::IntArrayRef padding, at::IntArrayRef dilation) {
+  TORCH_CHECK(lokr_conv2d_lr_ok(x, w1, w2a, w2b, kernel, stride, padding, dilation), "lycoris_amd::lokr_conv2d_lr: layer off the patch kernels' fast path");
+  const c10::DeviceGuard dg(x.device());
+  const int taps = (int)(kernel[0] * kernel[1]);
+  const int64_t B = x.size(0), H = x.size(2), W = x.size(3), a = w1.size(0), b = w1.size(1), c = w2a.size(0), d = w2b.size(1) / taps;
+  Geom gm = geom_of(kernel, stride, padding, dilation, H, W);
+  bool copied;
+  Tensor rows = rows_view(x, &copied), f1 = f32c(w1);
+  Tensor y = at::empty({B * gm.Ho * gm.Wo, a * c}, x.options());
+  Tensor planes = planes_for_lr(w2a, w2b, x.scalar_type(), stream_of(x), taps);
+  TORCH_CHECK(planes.defined(), "lokr_conv2d_lr: no operand planes");
+  check_rc(lyc_lokr_conv2d_fwd_planes(cptr(rows), cfp(f1), cptr(planes), mptr(y), B, H, W, (int)a, (int)b, (int)c, (int)d, gm.kh, gm.kw, gm.sh,
+                                      gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, (float)alpha, dtype_code(x.scalar_type()), stream_of(x)),
+           "lyc_lokr_conv2d_fwd_planes");
+  return from_rows(y, B, gm.Ho, gm.Wo, !copied);
+}
+Tensor lokr_conv2d_lr_meta(const Tensor& x, const Tensor& w1, const Tensor& w2a, const Tensor& w2b, double alpha, at::IntArrayRef kernel,
+                           at::IntArrayRef stride, at::IntArrayRef padding, at::IntArrayRef dilation) {
+  Geom gm = geom_of(kernel, stride, padding, dilation, x.size(2), x.size(3));
+  return at::empty({x.size(0), w1.size(0) * w2a.size(0), gm.Ho, gm.Wo},
+                   x.options().memory_format(rows_are_free(x) ? at::MemoryFormat::ChannelsLast : at::MemoryFormat::Contiguous));
+}
+Tensor lokr_conv2d_lr_autograd(const Tensor& x, const Tensor& w1, const Tensor& w2a, const Tensor& w2b, double alpha, at::IntArrayRef kernel,
+                               at::IntArrayRef stride, at::IntArrayRef padding, at::IntArrayRef dilation) {
+  const GradAtApply ga_;
+  return LokrConv2dLrFn::apply(amp(x), w1, w2a, w2b, alpha, kernel.vec(), stride.vec(), padding.vec(), dilation.vec());
+}
+
 struct LoconConv2dFn : public torch::autograd::Function<LoconConv2dFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& down, const Tensor& up, double alpha,
                         std::vector<int64_t> stride, std::vector<int64_t> padding, std::vector<int64_t> dilation) {
@@ -1885,6 +2049,8 @@ TORCH_LIBRARY(lycoris_amd, m) {
   m.def("chan_affine(Tensor a, Tensor w, Tensor? bias, float s0, float mult, int chan_dim) -> Tensor");
   m.def("lokr_conv2d(Tensor x, Tensor w1, Tensor w2, float alpha, int[2] stride, int[2] padding, int[2] dilation) -> Tensor");
   m.def("locon_conv2d(Tensor x, Tensor down, Tensor up, float alpha, int[2] stride, int[2] padding, int[2] dilation) -> Tensor");
+  m.def("lokr_conv2d_lr(Tensor x, Tensor w1, Tensor w2a, Tensor w2b, float alpha, int[2] kernel, int[2] stride, int[2] padding, "
+        "int[2] dilation) -> Tensor");
   m.def("adapter_conv2d(Tensor x, Tensor f0, Tensor f1, Tensor? f2, Tensor? f3, int algo, float alpha, int[2] kernel, int[2] stride, "
         "int[2] padding, int[2] dilation) -> Tensor");
   m.def("_adapter_conv2d_forward(Tensor x, Tensor f0, Tensor f1, Tensor? f2, Tensor? f3, int algo, float alpha, int[2] kernel, int[2] stride, "
@@ -1928,6 +2094,7 @@ TORCH_LIBRARY_IMPL(lycoris_amd, CUDA, m) {
   m.impl("_locon_conv2d_forward", locon_conv2d_fwd);
   m.impl("_locon_conv2d_backward", locon_conv2d_bwd);
   m.impl("adapter_conv2d", adapter_conv2d_cuda);
+  m.impl("lokr_conv2d_lr", lokr_conv2d_lr_cuda);
   m.impl("_adapter_conv2d_forward", adapter_conv2d_fwd);
   m.impl("_adapter_conv2d_backward", adapter_conv2d_bwd);
 }
@@ -1950,6 +2117,7 @@ TORCH_LIBRARY_IMPL(lycoris_amd, Meta, m) {
   m.impl("_locon_conv2d_forward", locon_conv2d_fwd_meta);
   m.impl("_locon_conv2d_backward", locon_conv2d_bwd_meta);
   m.impl("adapter_conv2d", adapter_conv2d_meta);
+  m.impl("lokr_conv2d_lr", lokr_conv2d_lr_meta);
   m.impl("_adapter_conv2d_forward", adapter_conv2d_fwd_meta);
   m.impl("_adapter_conv2d_backward", adapter_conv2d_bwd_meta);
 }
@@ -1963,6 +2131,7 @@ TORCH_LIBRARY_IMPL(lycoris_amd, Autograd, m) {
   m.impl("lokr_conv2d", lokr_conv2d_implicit);
   m.impl("locon_conv2d", locon_conv2d_implicit);
   m.impl("adapter_conv2d", adapter_conv2d_autograd);
+  m.impl("lokr_conv2d_lr", lokr_conv2d_lr_autograd);
 }
 
 PYBIND11_MODULE(_lyc_torch, m) {
@@ -1974,6 +2143,10 @@ PYBIND11_MODULE(_lyc_torch, m) {
     g_accum.has_callback = !callback.is_none();
     *g_accum.callback = std::move(callback);
     g_accum.uses.clear();
+  });
+  m.def("lokr_conv2d_lr_ok", [](const Tensor& x, const Tensor& w1, const Tensor& w2a, const Tensor& w2b, std::vector<int64_t> kernel,
+                                std::vector<int64_t> stride, std::vector<int64_t> padding, std::vector<int64_t> dilation) {
+    return lokr_conv2d_lr_ok(x, w1, w2a, w2b, kernel, stride, padding, dilation);
   });
   m.def("set_planes_cache", [](bool enabled) {
     g_planes.enabled = enabled;

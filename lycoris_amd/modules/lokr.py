@@ -247,6 +247,9 @@ class LokrModule(LycorisBaseModule):
         w1 = self._gate(self._w1_full())
         if self._w2_low_rank_native(h):
             return ops.lokr_linear_lr(h, w1, self.lokr_w2_a, self.lokr_w2_b, alpha)
+        if not self.use_w2 and not self.tucker and self.module_type == "conv2d" and h.is_cuda:
+            stride, padding, dilation = conv_args(self.kw_dict)
+            return ops.lokr_conv2d_lr(h, w1, self.lokr_w2_a, self.lokr_w2_b, alpha, self.shape[2:], stride, padding, dilation)
         w2 = self._w2_full()
         if self.module_type == "linear":
             return ops.lokr_linear(h, w1, w2, alpha)

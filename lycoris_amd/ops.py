@@ -48,7 +48,7 @@ def _cpp() -> bool:
         ext.set_accum(_ACCUM["enabled"], _ACCUM["callback"])
         _DISPATCH["ext"] = ext
         ns = torch.ops.lycoris_amd  # the resolved overloads: skips the packet's per-call overload resolution (~1 us per call)
-        for name in ("lokr_linear", "lokr_linear_lr", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d"):
+        for name in ("lokr_linear", "lokr_linear_lr", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d", "lokr_conv2d_lr"):
             _OPS[name] = getattr(ns, name).default
     return True
 
@@ -731,6 +731,20 @@ def lokr_conv2d(x, w1, w2, alpha, stride, padding, dilation):
             return _OPS["lokr_conv2d"](x, w1, w2, float(alpha), list(geom[1]), list(geom[2]), list(geom[3]))
         return _LokrConv2dImplicit.apply(alpha, geom, x, w1, w2)
     return _rows_conv2d(_LokrCore, alpha, geom, x, w1, w2.reshape(w2.shape[0], -1))
+
+
+def lokr_conv2d_lr(x, w1, w2a, w2b, alpha, ksize, stride, padding, dilation):
+    """LoKr on nn.Conv2d with a low-rank second factor (reference modules/lokr.py:131-136): w1:[a, b]  w2a:[c, r]
+    w2b:[r, d*kh*kw].  Where the patch kernels take the layer (16-bit activations, leaf fp32 factors, geometry), the operand planes
+    are packed from the two factors and the chain rule of the product runs in the grouped weight-gradient launch; everywhere else
+    the product is formed (autograd-visible) and handed to lokr_conv2d."""
+    N.require_device(x, "input")
+    ksize, stride, padding, dilation = [int(v) for v in ksize], [int(v) for v in stride], [int(v) for v in padding], [int(v) for v in dilation]
+    if (_cpp() and not torch.compiler.is_compiling()
+            and _DISPATCH["ext"].lokr_conv2d_lr_ok(x, w1, w2a, w2b, ksize, stride, padding, dilation)):
+        return _OPS["lokr_conv2d_lr"](x, w1, w2a, w2b, float(alpha), ksize, stride, padding, dilation)
+    w2 = (w2a @ w2b).reshape(w2a.shape[0], -1, *ksize)
+    return lokr_conv2d(x, w1, w2, alpha, stride, padding, dilation)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -130,7 +130,10 @@ def test_rows_lowered_conv2d_cpp_dispatch_equals_python_dispatch(algo, k, stride
     for i, (u, v) in enumerate(zip(a, b)):
         assert u.dtype == v.dtype and u.shape == v.shape, i
         if i < 2:
-            assert torch.equal(u, v), (algo, i, float((u.float() - v.float()).abs().max()))
+            if dtype == torch.float32:  # the fp32 row kernels split K with atomics: equal to the last bits only
+                assert torch.allclose(u, v, rtol=1e-5, atol=1e-6), (algo, i, float((u - v).abs().max()))
+            else:
+                assert torch.equal(u, v), (algo, i, float((u.float() - v.float()).abs().max()))
             assert u.is_contiguous(memory_format=torch.channels_last) == v.is_contiguous(memory_format=torch.channels_last), i
         else:
             assert torch.allclose(u.float(), v.float(), rtol=1e-4, atol=1e-6), (algo, i)

@@ -240,3 +240,133 @@ def test_module_low_rank_linear_runs_the_native_op(monkeypatch):
     want = lin(x).float() + x.float() @ w.t()
     torch.cuda.synchronize()
     assert float((y.float() - want).norm() / want.norm()) <= 5e-3
+
+
+# ---- (e) Conv2d: w2 = w2a [c, r] @ w2b [r, d*kh*kw] -----------------------------------------------------------------------------
+def test_chain_group_with_window_taps():
+    """Conv2d: dW2 arrives window-major [c, kh*kw, d], w2b and its gradient are [r, d*kh*kw] with column v * taps + tap"""
+    from lycoris_amd import _native as N
+    gen = torch.Generator().manual_seed(41)
+    shapes = [(40, 40, 8, 9), (160, 160, 16, 9), (80, 40, 4, 9), (16, 24, 3, 4), (40, 120, 16, 1)]
+    items = (N.LokrLrChainItem * len(shapes))()
+    keep, want = [], []
+    for k, (c, d, r, taps) in enumerate(shapes):
+        dw2, dw264 = rnd((c, taps, d), torch.float32, gen)
+        a, a64 = rnd((c, r), torch.float32, gen, 0.3)
+        b, b64 = rnd((r, d * taps), torch.float32, gen, 0.3)
+        da, db = torch.zeros(c, r, device=DEV), torch.zeros(r, d * taps, device=DEV)
+        items[k] = N.LokrLrChainItem(N.ptr(dw2), N.ptr(a), N.ptr(b), N.ptr(da), N.ptr(db), c, d, r, taps)
+        keep.append((dw2, a, b, da, db))
+        g_ref = dw264.transpose(0, 2, 1).reshape(c, d * taps)  # [c, (v, tap)]: the reference's column order
+        want.append((g_ref @ b64.T, a64.T @ g_ref))
+    N.call("lyc_lokr_lr_chain_group", ctypes.cast(items, ctypes.c_void_p), len(shapes), N.stream_ptr(torch.device(DEV)))
+    torch.cuda.synchronize()
+    for k, ((_, _, _, da, db), (wa, wb)) in enumerate(zip(keep, want)):
+        assert err(da, wa) <= 2e-6, (k, shapes[k], err(da, wa))
+        assert err(db, wb) <= 2e-6, (k, shapes[k], err(db, wb))
+
+
+# (B, C, H, O, k, stride, r): SDXL resnet convs at three resolutions, a downsample conv, a channel-changing up-block conv
+CONV_LR = [(1, 320, 128, 320, 3, 1, 16), (1, 1280, 32, 1280, 3, 1, 16), (1, 640, 64, 640, 3, 2, 16), (1, 960, 64, 640, 3, 1, 16),
+           (2, 64, 12, 128, 3, 1, 4)]
+
+
+@DT16
+@pytest.mark.parametrize("shape", CONV_LR, ids=[f"B{s[0]}_{s[1]}x{s[2]}to{s[3]}_k{s[4]}s{s[5]}_r{s[6]}" for s in CONV_LR])
+def test_conv_op_matches_the_oracle(shape, dtype):
+    from lycoris_amd import ops
+    B, C, H, O, k, st, r = shape
+    if dtype == torch.float16 and shape not in (CONV_LR[0], CONV_LR[4]):
+        pytest.skip("fp16: two shapes")
+    gen = torch.Generator().manual_seed(sum(shape))
+    x, x64 = rnd((B, C, H, H), dtype, gen)
+    Ho = (H + 2 * (k // 2) - k) // st + 1
+    g, g64 = rnd((B, O, Ho, Ho), dtype, gen, 1.0 / np.sqrt(O))
+    w1, w1_64 = rnd((8, 8), torch.float32, gen, 0.3)
+    w2a, a64 = rnd((O // 8, r), torch.float32, gen, 0.3)
+    w2b, b64 = rnd((r, (C // 8) * k * k), torch.float32, gen, 0.1)
+    x.requires_grad_(True)
+    ps = [nn.Parameter(t) for t in (w1, w2a, w2b)]
+    ext = ops._DISPATCH["ext"] if ops._cpp() else None
+    native = ext.lokr_conv2d_lr_ok(x, ps[0], ps[1], ps[2], [k, k], [st, st], [k // 2, k // 2], [1, 1])
+    # stride 2 is not a geometry of the patch kernels: ops.lokr_conv2d_lr then forms the product and runs the row-gather kernels
+    assert native == (st == 1), "which path a layer takes is part of the contract"
+    y = ops.lokr_conv2d_lr(x, ps[0], ps[1], ps[2], 1.0, (k, k), (st, st), (k // 2, k // 2), (1, 1))
+    dx, d1, da, db = torch.autograd.grad(y, [x] + ps, g)
+    torch.cuda.synchronize()
+    ca = {"stride": st, "padding": k // 2, "dilation": 1}
+    y_ref = oracle.lokr.forward(x64, w1=w1_64, w2a=a64, w2b=b64, scale=1.0, kshape=(k, k), conv_args=ca)
+    gr = oracle.lokr.backward(x64, g64, w1=w1_64, w2a=a64, w2b=b64, scale=1.0, kshape=(k, k), conv_args=ca)
+    stol, f32 = TOL["store_out"][dtype], TOL["f32_out"][dtype]
+    assert err(y, y_ref, dtype) <= stol, err(y, y_ref, dtype)
+    assert err(dx, gr["dx"], dtype) <= stol, err(dx, gr["dx"], dtype)
+    assert err(d1, gr["w1"]) <= f32, err(d1, gr["w1"])
+    assert err(da, gr["w2a"]) <= f32, err(da, gr["w2a"])
+    assert err(db, gr["w2b"]) <= f32, err(db, gr["w2b"])
+
+
+def test_parked_low_rank_conv_layers_match_the_immediate_path():
+    from lycoris_amd import ops
+    torch.manual_seed(9)
+    mk = lambda *s, sc: nn.Parameter(torch.randn(*s, device=DEV) * sc)
+    layers = [(mk(8, 8, sc=0.3), mk(16, 4, sc=0.3), mk(4, 8 * 9, sc=0.2)) for _ in range(3)]
+    # a full-matrix conv layer in the same park list (its w2 and .grad in channels_last memory: the layout the kernels accumulate in)
+    full = (mk(8, 8, sc=0.3), nn.Parameter((torch.randn(16, 8, 3, 3, device=DEV) * 0.1).contiguous(memory_format=torch.channels_last)))
+    params = [p for l in layers for p in l] + list(full)
+    x = (torch.randn(2, 64, 12, 12, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    gy = (torch.randn(2, 128, 12, 12, device=DEV) * 0.1).to(torch.bfloat16)
+    geo = ((1, 1), (1, 1), (1, 1))
+
+    def net():
+        ys = [ops.lokr_conv2d_lr(x, w1, a, b, 0.5, (3, 3), *geo) for w1, a, b in layers + [layers[1]]]
+        ys.append(ops.lokr_conv2d(x, full[0], full[1], 0.5, *geo))
+        return sum(ys)
+
+    def run(defer):
+        seen = []
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        x.grad = None
+        ops.fused_grad_accumulation(True, callback=lambda p: seen.append(id(p)))
+        ops.deferred_weight_gradients(defer)
+        try:
+            net().backward(gy)
+            assert ops._DISPATCH["ext"].deferred_pending() == 0
+            torch.cuda.synchronize()
+            return x.grad.clone(), [p.grad.clone() for p in params], seen
+        finally:
+            ops.fused_grad_accumulation(False, None)
+            ops.deferred_weight_gradients(True, 48)
+
+    want = torch.autograd.grad(sum([ops.lokr_conv2d(x, w1, (a @ b).reshape(16, 8, 3, 3), 0.5, *geo) for w1, a, b in layers + [layers[1]]] +
+                                   [ops.lokr_conv2d(x, full[0], full[1], 0.5, *geo)]), params, gy)
+    dx0, g0, seen0 = run(False)
+    dx1, g1, seen1 = run(True)
+    assert torch.equal(dx0, dx1)
+    for u, v, w in zip(g0, g1, want):
+        assert float(u.abs().max()) > 0
+        assert float((u - v).norm() / u.norm()) <= 2e-5
+        assert float((v - w).norm() / w.norm()) <= 3e-4, float((v - w).norm() / w.norm())
+    assert sorted(seen0) == sorted(seen1) == sorted(id(p) for p in params)
+
+
+def test_module_low_rank_conv_runs_the_native_op(monkeypatch):
+    from lycoris_amd import ops
+    from lycoris_amd.modules import LokrModule
+    torch.manual_seed(8)
+    conv = nn.Conv2d(320, 640, 3, padding=1, bias=False).to(DEV, torch.bfloat16)
+    mod = LokrModule("t", conv, 1.0, 16, 8, factor=8).to(DEV)
+    assert hasattr(mod, "lokr_w2_a") and not mod.use_w2 and not mod.tucker
+    with torch.no_grad():
+        mod.lokr_w2_a.normal_(0, 0.3)
+        mod.lokr_w2_b.normal_(0, 0.1)
+    calls = []
+    real = ops._OPS["lokr_conv2d_lr"] if ops._cpp() else None
+    monkeypatch.setitem(ops._OPS, "lokr_conv2d_lr", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    x = torch.randn(1, 320, 32, 32, device=DEV, dtype=torch.bfloat16)
+    y = mod(x)
+    assert calls, "LokrModule did not take the low-rank Conv2d native path"
+    w = mod.get_diff_weight()[0].to(torch.bfloat16)
+    want = conv(x).float() + torch.nn.functional.conv2d(x, w, padding=1).float()
+    torch.cuda.synchronize()
+    assert float((y.float() - want).norm() / want.norm()) <= 1e-2

@@ -58,9 +58,10 @@ def test_pack_full_matrix_bit_exact(c, d, kh, layout, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-def test_pack_low_rank_product(dtype):
+@pytest.mark.parametrize("kh,r", [(3, 16), (1, 16), (1, 6)], ids=["conv3x3_r16", "linear_r16", "linear_r6"])  # Linear: the 16-byte-load paths
+def test_pack_low_rank_product(dtype, kh, r):
     """w2 = w2a @ w2b formed inside the pack kernel (reference modules/lokr.py:131-136, 370: lokr_w2_a [c, r], lokr_w2_b [r, d*k*k])"""
-    c, d, kh, r = 80, 40, 3, 16
+    c, d = 80, 40
     taps = kh * kh
     gen = torch.Generator().manual_seed(5)
     w2a, w2b = torch.randn(c, r, generator=gen) * 0.3, torch.randn(r, d * taps, generator=gen) * 0.3
