@@ -619,7 +619,7 @@ int lyc_lokr_lr_chain_group(const LycLokrLrChainItem* items, int n, void* stream
     KronLrItem& q = ga.p[ga.n];
     q.dw2 = it.dw2; q.w2a = it.w2a; q.w2b = it.w2b; q.d_w2a = it.d_w2a; q.d_w2b = it.d_w2b; q.c = it.c; q.d = it.d; q.r = it.r;
     q.taps = it.taps > 0 ? it.taps : 1;
-    const long wgs = cdiv(kron_lr_threads(it.c, it.d, it.r, q.taps), NTHREADS);
+    const long wgs = cdiv(kron_lr_waves(it.c, it.d, it.r, q.taps), NWAVES);
     ga.wg_end[ga.n] = (int)((ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs);
     ++ga.n;
   }

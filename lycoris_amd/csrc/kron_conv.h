@@ -170,21 +170,22 @@ struct KronLrGroupArgs {
 };
 static_assert(sizeof(KronLrGroupArgs) <= 3840, "kernel arguments are limited to 4 KiB");
 
-// Work split (round 3, second version: the first one ran one serial loop per output element -- 1440 .. 2880 dependent iterations for
-// a Conv2d layer -- and cost 2.0 ms of the rank-16 SDXL step):
-//   d_w2a: one WAVE per (row q, block of 16 ranks, chunk of KLR_CA columns).  Lanes stride the columns (dW2 and, for nn.Linear, w2b
-//          are read coalesced; every dW2 element is loaded once for 16 ranks), 16 register accumulators, a butterfly reduction
-//          over the wave, one atomic per (q, rank).
-//   d_w2b: one THREAD per (column, block of 16 ranks, chunk of KLR_KB rows): dW2 read coalesced once for 16 ranks, w2a values are
-//          wave-uniform loads, 16 atomics per thread.
-constexpr int KLR_RB = 16, KLR_CA = 1024, KLR_KB = 16;
-__host__ __device__ inline long kron_lr_threads_a(int c, int d, int r, int taps) {
+// Both products are small fp32 GEMMs (c, d = 40 .. 1280, r = 4 .. 64): they run on the fp32 matrix core (v_mfma_f32_16x16x4_f32:
+// exact fp32 products, no hi/lo split), ONE WAVE per 16 x 16 output tile and contraction chunk, partial tiles added atomically:
+//   d_w2a tile (16 rows q  x 16 ranks): A = dW2[q, col..]  B = w2b[rank, col..]   16 columns per step = one float4 load per operand
+//   d_w2b tile (16 ranks x 16 columns): A = w2a[q.., rank]  B = dW2[q.., col]     16 rows q per step
+// History (round 3, SDXL rank-16 step, 739 Linear layers): one thread per output element with a serial contraction loop: 2.0 ms;
+// a wave per row with 16 register accumulators + butterfly reductions: 1.25 ms (181 k waves of ~3 loop trips); this version: see
+// DESIGN.md 7.4.
+constexpr int KLR_CA = 512;   // columns of dW2 per d_w2a work item
+constexpr int KLR_CB = 256;   // rows of dW2 per d_w2b work item
+__host__ __device__ inline long kron_lr_waves_a(int c, int d, int r, int taps) {
   const long D = (long)d * taps;
-  return (long)c * ((r + KLR_RB - 1) / KLR_RB) * ((D + KLR_CA - 1) / KLR_CA) * 64;
+  return (long)((c + 15) / 16) * ((r + 15) / 16) * ((D + KLR_CA - 1) / KLR_CA);
 }
-__host__ __device__ inline long kron_lr_threads(int c, int d, int r, int taps) {
+__host__ __device__ inline long kron_lr_waves(int c, int d, int r, int taps) {
   const long D = (long)d * taps;
-  return kron_lr_threads_a(c, d, r, taps) + D * ((r + KLR_RB - 1) / KLR_RB) * ((c + KLR_KB - 1) / KLR_KB);
+  return kron_lr_waves_a(c, d, r, taps) + ((D + 15) / 16) * ((r + 15) / 16) * ((c + KLR_CB - 1) / KLR_CB);
 }
 
 __global__ __launch_bounds__(NTHREADS) void kron_lr_chain_kernel(KronLrGroupArgs ga) {
@@ -192,66 +193,96 @@ __global__ __launch_bounds__(NTHREADS) void kron_lr_chain_kernel(KronLrGroupArgs
   int p = 0;
   while (p + 1 < ga.n && b >= ga.wg_end[p]) ++p;
   const KronLrItem& it = ga.p[p];
-  const long e = (long)(b - (p ? ga.wg_end[p - 1] : 0)) * NTHREADS + threadIdx.x;
+  const long w = (long)(b - (p ? ga.wg_end[p - 1] : 0)) * NWAVES + (threadIdx.x >> 6);  // work item of this wave
+  const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
   const long D = (long)it.d * it.taps;
-  const int nrb = (it.r + KLR_RB - 1) / KLR_RB;
-  const long na = kron_lr_threads_a(it.c, it.d, it.r, it.taps);
-  if (e < na) {  // ---- d_w2a: a wave per (q, rank block, column chunk); na is a multiple of 64: the branch is wave-uniform
+  const int nrb = (it.r + 15) / 16;
+  const long na = kron_lr_waves_a(it.c, it.d, it.r, it.taps);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (w < na) {  // ---- d_w2a[16 q, 16 ranks] over one chunk of columns
     if (!it.d_w2a) return;  // a frozen factor
-    const int lane = (int)(e & 63);
-    const long w = e >> 6;
     const long nch = (D + KLR_CA - 1) / KLR_CA;
-    const long chunk = w % nch;
-    const int rb = (int)((w / nch) % nrb);
-    const int q = (int)(w / (nch * nrb));
-    const long col0 = chunk * KLR_CA, col1 = col0 + KLR_CA < D ? col0 + KLR_CA : D;
+    const long ch = w % nch;
+    const int rb = (int)((w / nch) % nrb), tq = (int)(w / (nch * nrb));
+    const int q = 16 * tq + li, rr = 16 * rb + li;
+    const bool qok = q < it.c, rok = rr < it.r;
     const float* g = it.dw2 + (long)q * D;
-    const float* wb = it.w2b + (long)rb * KLR_RB * D;
-    const int nr = it.r - rb * KLR_RB < KLR_RB ? it.r - rb * KLR_RB : KLR_RB;
-    float acc[KLR_RB];
+    const float* wb = it.w2b + (long)rr * D;
+    const long col1 = (ch + 1) * KLR_CA < D ? (ch + 1) * KLR_CA : D;
+    const bool vec = (((reinterpret_cast<uintptr_t>(it.dw2) | reinterpret_cast<uintptr_t>(it.w2b)) & 15u) == 0) && (D & 3) == 0;
+    for (long col = ch * KLR_CA + 4 * kq; col < col1 + 4 * kq; col += 16) {  // every lane runs the same number of trips
+      f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
+      if (col + 3 < col1 && (it.d & 3) == 0) {  // four columns of one tap (every shape of the fast paths: c, d multiples of 8)
+        if (qok) {
+          if (vec) av = *reinterpret_cast<const f32x4*>(g + col);
+          else { av[0] = g[col]; av[1] = g[col + 1]; av[2] = g[col + 2]; av[3] = g[col + 3]; }
+        }
+        if (rok) {
+          if (it.taps == 1) {
+            if (vec) bv = *reinterpret_cast<const f32x4*>(wb + col);
+            else { bv[0] = wb[col]; bv[1] = wb[col + 1]; bv[2] = wb[col + 2]; bv[3] = wb[col + 3]; }
+          } else {  // dW2 column tap * d + v  <->  w2b column v * taps + tap; the four share the tap (d % 8 == 0)
+            const int tap = (int)(col / it.d);
+            const long v0 = col - (long)tap * it.d;
 #pragma unroll
-    for (int j = 0; j < KLR_RB; ++j) acc[j] = 0.f;
-    for (long col = col0 + lane; col < col1; col += 64) {
-      const float gv = g[col];
-      const int tap = (int)(col / it.d);                      // dW2 column order: tap * d + v;  w2b: v * taps + tap
-      const long wcol = (col - (long)tap * it.d) * it.taps + tap;
+            for (int e = 0; e < 4; ++e) bv[e] = wb[(v0 + e) * it.taps + tap];
+          }
+        }
+      } else {  // ragged tail / odd d: element by element
 #pragma unroll
-      for (int j = 0; j < KLR_RB; ++j)
-        if (j < nr) acc[j] = fmaf(gv, wb[(long)j * D + wcol], acc[j]);
+        for (int e = 0; e < 4; ++e) {
+          const long cc = col + e;
+          if (cc < col1) {
+            const int tap = (int)(cc / it.d);
+            if (qok) av[e] = g[cc];
+            if (rok) bv[e] = wb[(cc - (long)tap * it.d) * it.taps + tap];
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
     }
+    const int oc = 16 * rb + li;  // output: rows 16 tq + 4 kq + e, column = rank oc
 #pragma unroll
-    for (int j = 0; j < KLR_RB; ++j) {
-      float v = acc[j];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0 && j < nr) __hip_atomic_fetch_add(it.d_w2a + (long)q * it.r + rb * KLR_RB + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int e = 0; e < 4; ++e) {
+      const int oq = 16 * tq + 4 * kq + e;
+      if (oq < it.c && oc < it.r) __hip_atomic_fetch_add(it.d_w2a + (long)oq * it.r + oc, acc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return;
   }
-  // ---- d_w2b[rr, (v, tap)]: neighbouring threads walk dW2's own column order
-  const long f = e - na;
-  const long nchb = (it.c + KLR_KB - 1) / KLR_KB;
-  if (f >= D * nrb * nchb || !it.d_w2b) return;
-  const long col = f % D;
-  const long t = f / D;
-  const int rb = (int)(t % nrb);
-  const int q0 = (int)(t / nrb) * KLR_KB, q1 = q0 + KLR_KB < it.c ? q0 + KLR_KB : it.c;
-  const int nr = it.r - rb * KLR_RB < KLR_RB ? it.r - rb * KLR_RB : KLR_RB;
-  const int tap = (int)(col / it.d);
-  const long wcol = (col - (long)tap * it.d) * it.taps + tap;
-  float acc[KLR_RB];
+  // ---- d_w2b[16 ranks, 16 columns] over one chunk of rows q
+  const long wbi = w - na;
+  const long nchb = (it.c + KLR_CB - 1) / KLR_CB;
+  const long tcols = (D + 15) / 16;
+  if (wbi >= tcols * nrb * nchb || !it.d_w2b) return;
+  const long ch = wbi % nchb;
+  const int rb = (int)((wbi / nchb) % nrb);
+  const long tc = wbi / (nchb * nrb);
+  const int rr = 16 * rb + li;          // A operand row
+  const long col = 16 * tc + li;        // B operand column (dW2 order)
+  const bool rok = rr < it.r, cok = col < D;
+  const int q1 = (int)((ch + 1) * KLR_CB < it.c ? (ch + 1) * KLR_CB : it.c);
+  for (int q0 = (int)(ch * KLR_CB) + 4 * kq; q0 < q1 + 4 * kq; q0 += 16) {
+    f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int j = 0; j < KLR_RB; ++j) acc[j] = 0.f;
-  for (int q = q0; q < q1; ++q) {
-    const float gv = it.dw2[(long)q * D + col];
-    const float* wa = it.w2a + (long)q * it.r + rb * KLR_RB;
+    for (int e = 0; e < 4; ++e) {
+      if (q0 + e < q1) {
+        if (rok) av[e] = it.w2a[(long)(q0 + e) * it.r + rr];
+        if (cok) bv[e] = it.dw2[(long)(q0 + e) * D + col];
+      }
+    }
 #pragma unroll
-    for (int j = 0; j < KLR_RB; ++j)
-      if (j < nr) acc[j] = fmaf(wa[j], gv, acc[j]);
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
   }
+  if (cok) {
+    const int tap = (int)(col / it.d);
+    const long wcol = (col - (long)tap * it.d) * it.taps + tap;
 #pragma unroll
-  for (int j = 0; j < KLR_RB; ++j)
-    if (j < nr) __hip_atomic_fetch_add(it.d_w2b + (long)(rb * KLR_RB + j) * D + wcol, acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int e = 0; e < 4; ++e) {
+      const int orr = 16 * rb + 4 * kq + e;
+      if (orr < it.r) __hip_atomic_fetch_add(it.d_w2b + (long)orr * D + wcol, acc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
