@@ -166,8 +166,16 @@ class AdapterGradSync:
         and backward pass, after its last accumulation -- a parameter shared by several layer calls is counted in the forward
         pass (csrc/torch_ops.cpp `expect()`) and reported when the last of its backward nodes has run."""
         from . import ops
-        ops.fused_grad_accumulation(enabled, callback=self._on_grad_ready if enabled else None)
+        ops.fused_grad_accumulation(enabled, callback=self._on_grad_ready if enabled else None,
+                                    batch_callback=self._on_grads_ready if enabled else None)
         self._fused = bool(enabled)
+
+    def _on_grads_ready(self, params):
+        """the reports of one grouped weight-gradient flush (csrc/torch_ops.cpp notify_many): one call instead of one per parameter"""
+        if not self._sync_enabled:
+            return
+        for p in params:
+            self._on_grad_ready(p)
 
     def _on_grad_ready(self, p):
         if not self._sync_enabled:

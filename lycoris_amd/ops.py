@@ -22,7 +22,7 @@ F32_ROWS = 0x100  # LYC_F32_ROWS
 # accumulate straight into it (their outputs are "+=" anyway) and autograd gets None for that input -- no temporary,
 # no zero-fill, no separate accumulate kernel.  `_ACCUM["callback"]` is told which parameters were updated so a
 # gradient-sync object can count them like a post-accumulate hook would.
-_ACCUM = {"enabled": False, "callback": None}
+_ACCUM = {"enabled": False, "callback": None, "batch_callback": None}
 
 # Host dispatch of the public entry points below:
 #   "cpp"    (default) torch.ops.lycoris_amd.* -- TORCH_LIBRARY custom ops, dispatch + autograd in C++ (csrc/torch_ops.cpp)
@@ -45,7 +45,7 @@ def _cpp() -> bool:
         return False
     if _DISPATCH["ext"] is None:
         ext = N.load_torch_ops()  # raises NativeLibraryError when the extension is missing: no silent fallback
-        ext.set_accum(_ACCUM["enabled"], _ACCUM["callback"])
+        ext.set_accum(_ACCUM["enabled"], _ACCUM["callback"], _ACCUM["batch_callback"])
         _DISPATCH["ext"] = ext
         ns = torch.ops.lycoris_amd  # the resolved overloads: skips the packet's per-call overload resolution (~1 us per call)
         for name in ("lokr_linear", "lokr_linear_lr", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d", "lokr_conv2d_lr"):
@@ -53,11 +53,14 @@ def _cpp() -> bool:
     return True
 
 
-def fused_grad_accumulation(enabled: bool = True, callback=None):
+def fused_grad_accumulation(enabled: bool = True, callback=None, batch_callback=None):
+    """`callback(param)` is told about every parameter whose gradient has just been accumulated into `.grad` by the kernels;
+    `batch_callback(list_of_params)` (optional) takes the reports of a whole grouped weight-gradient flush in ONE call."""
     _ACCUM["enabled"] = bool(enabled)
     _ACCUM["callback"] = callback
+    _ACCUM["batch_callback"] = batch_callback if callback is not None else None
     if _DISPATCH["ext"] is not None:
-        _DISPATCH["ext"].set_accum(bool(enabled), callback)
+        _DISPATCH["ext"].set_accum(bool(enabled), callback, _ACCUM["batch_callback"])
 
 
 def deferred_weight_gradients(enabled: bool = True, flush_at: int = 48):
