@@ -54,9 +54,12 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--channels-last", action="store_true",
-                    help="Conv2d activations in torch.channels_last memory (what `unet.to(memory_format=torch.channels_last)` gives): "
-                         "the NHWC row matrices are then free views, no transposes")
+    ap.add_argument("--channels-last", action="store_true", default=True,
+                    help="(default since round 3) Conv2d activations in torch.channels_last memory -- what "
+                         "`unet.to(memory_format=torch.channels_last)` gives and what DESIGN.md 2 documents as the layout of the native "
+                         "path: the NHWC row matrices are free views, no transposes")
+    ap.add_argument("--nchw", dest="channels_last", action="store_false",
+                    help="Conv2d activations in contiguous NCHW memory: two layout transposes per conv layer and pass on top (A/B leg)")
     ap.add_argument("--no-defer", action="store_true",
                     help="A/B: one LoKr weight-gradient launch per layer instead of the grouped launches")
     ap.add_argument("--rank", type=int, default=0,
@@ -412,13 +415,13 @@ def main():
                         f"layers ({n_lin} Linear + {n_layers - n_lin} Conv2d), adapter fwd+bwd + grad all-reduce + fused "
                         "AdamW; frozen UNet ops not timed (see base_plus_adapter)",
             "algo": args.algo, "factor": FACTOR if args.algo in ("lokr", "mixed") else None, "layers": n_layers,
-            "lokr_w2": (f"low rank {args.rank} (w2_a @ w2_b per call)" if args.rank else "full matrix") if args.algo in ("lokr", "mixed") else None,
+            "lokr_w2": (f"low rank {args.rank} (lokr_w2_a @ lokr_w2_b: planes packed from the factors, chain rule in the grouped launch)" if args.rank else "full matrix") if args.algo in ("lokr", "mixed") else None,
             "adapter_params": sum(p.numel() for p in all_params), "dp_payload_mb": round(sync.payload_bytes / 2**20, 1),
             "parallelism": f"dp{world}",
             "graph": "eager (no capture)" if args.eager else
                      f"hipGraph replay: 1 forward graph + {len(graphs)} backward segment(s)"
                      + (", bucket all-reduces issued between segments on a side stream" if (world > 1 or args.rccl_ws1) else ""),
-            "conv_memory_format": "channels_last" if args.channels_last else "contiguous (NCHW)",
+            "conv_memory_format": "channels_last (documented default, DESIGN.md 2; --nchw for the A/B leg)" if args.channels_last else "contiguous (NCHW)",
             "inputs": "shared per shape (cache-resident)" if args.shared_inputs else
                       f"distinct x / g per layer instance: {act_bytes / 1e9:.2f} GB read per step",
         },
@@ -809,7 +812,9 @@ def reference_leg(insts, sync, native_graph_ms):
             "reference_eager_ms": round(ref_eager, 2), "native_eager_ms": round(nat_eager, 2),
             "reference_graph_ms": round(ref_graph, 2), "native_graph_ms": round(nat_graph, 2),
             "speedup_eager_vs_eager": round(ref_eager / nat_eager, 2),
-            "speedup_graph_vs_graph": round(ref_graph / nat_graph, 2)}
+            "speedup_graph_vs_graph": round(ref_graph / nat_graph, 2),
+            # the north-star sentence read literally: the reference as its users run it (eager) against this path as bench.py runs it
+            "speedup_native_graph_vs_reference_eager": round(ref_eager / nat_graph, 2)}
 
 
 def base_leg(insts, sync):
