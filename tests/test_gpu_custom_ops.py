@@ -344,3 +344,31 @@ def test_pointwise_conv_on_a_channels_last_tensor_is_copy_free_and_equal(algo):
         outs.append([y.detach().float()] + [t.float() for t in grads])
     for u, v in zip(*outs):
         assert torch.allclose(u, v, rtol=1e-4, atol=1e-6), float((u - v).abs().max())
+
+
+@pytest.mark.parametrize("with_bias", [False, True], ids=["in_side", "out_side"])
+def test_chan_affine_on_a_channels_last_tensor_is_copy_free_and_equal(with_bias):
+    """(IA)^3 on nn.Conv2d: scaling the channel dimension of a channels_last tensor is the last-dimension case on its NHWC view --
+    same numbers as for the NCHW tensor, result in the caller's memory format (round 3: `.contiguous()` used to copy twice per pass)"""
+    from lycoris_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(9)
+    a = torch.randn(2, 48, 9, 8, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(1, 48, 1, 1, device=DEV, generator=g) * 0.3).requires_grad_(True)
+    bias = torch.randn(48, device=DEV, generator=g) if with_bias else None
+    gy = (torch.randn(2, 48, 9, 8, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+
+    def run(cl):
+        x = a.clone()
+        go = gy.clone()
+        if cl:
+            x, go = x.contiguous(memory_format=torch.channels_last), go.contiguous(memory_format=torch.channels_last)
+        x.requires_grad_(True)
+        y = ops.chan_affine(x, w, bias, 1.0 if with_bias else 0.0, 0.7, 1)
+        dx, dw = torch.autograd.grad(y, [x, w], go)
+        return y, dx, dw
+
+    y0, dx0, dw0 = run(False)
+    y1, dx1, dw1 = run(True)
+    assert y1.is_contiguous(memory_format=torch.channels_last) and dx1.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y0, y1.contiguous()) and torch.equal(dx0, dx1.contiguous())
+    assert torch.allclose(dw0, dw1, rtol=1e-4, atol=1e-6)
