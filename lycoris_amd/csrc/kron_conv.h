@@ -439,6 +439,8 @@ __global__ __launch_bounds__(NTHREADS) void kconv_kernel(KconvArgs ca) {
   char* zero_slot = kc_smem + gm.patch_bytes;
   char* ring = kc_smem + gm.patch_bytes + 1024;
   const int stage_bytes = kconv_stage_bytes(NI, gm.kss);
+  LYC_TRACE_DECL;  // benchmarks/ktrace_conv.cpp (-DLYC_TRACE): shader-clock stamps of workgroup 0; nothing in the library build
+  LYC_STAMP(0);
 
   // ---- B ring: stage s = k steps [s * kss, (s + 1) * kss) of the NI n tiles, unit (ni, kk) at ((ni * kss + kk) * 2048) ------
   const char* planes = static_cast<const char*>(ca.planes);
@@ -462,6 +464,7 @@ __global__ __launch_bounds__(NTHREADS) void kconv_kernel(KconvArgs ca) {
     }
   };
   issue_stage(0, ring);
+  LYC_STAMP(20);
 
   // ---- w1 block operand and tap table -------------------------------------------------------------------------------------
   float w1raw[4];
@@ -486,6 +489,7 @@ __global__ __launch_bounds__(NTHREADS) void kconv_kernel(KconvArgs ca) {
     kc_tapoff[tid] = (oi * gm.PW + oj) * gm.CP * (int)sizeof(T);
   }
   if (tid < 4) reinterpret_cast<uint32_t*>(zero_slot)[tid] = 0u;
+  LYC_STAMP(21);
 
   // ---- source patch: HBM -> LDS by LDS-DMA (buffer_load ... lds), every piece in flight at once ---------------------------------
   // One wave instruction fills 1 KiB of the patch image: lane l supplies the global address of the 16 bytes that belong at
@@ -527,6 +531,7 @@ __global__ __launch_bounds__(NTHREADS) void kconv_kernel(KconvArgs ca) {
     }
   }
 
+  LYC_STAMP(1);  // stage 0 of the ring and the whole patch requested
   // ---- this lane's two stage-1 rows: local pixel (ly, lx), group u; byte offset of (pixel, u) in the patch ----------------
   int rowbase[MI];
   bool row_ok[MI];
@@ -554,6 +559,7 @@ __global__ __launch_bounds__(NTHREADS) void kconv_kernel(KconvArgs ca) {
   const int zero_ofs = gm.patch_bytes;  // byte offset of the zero slot from the patch base
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage 0 has landed (LDS-DMA counts on vmcnt)
   __syncthreads();  // patch, tap table, zero slot, stage 0
+  LYC_STAMP(2);
 
   for (int s = 0; s < nstage; ++s) {
     char* buf = ring + (s & 1) * stage_bytes;
@@ -594,11 +600,15 @@ __global__ __launch_bounds__(NTHREADS) void kconv_kernel(KconvArgs ca) {
     } else {
       for (int kk = 0; kk < nk; ++kk) kstep(kk, gm.kss);
     }
+    if (s < 17) LYC_STAMP(3 + s);  // MFMAs of stage s issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage s + 1 has landed
     __syncthreads();  // ... everybody's has, and nobody still reads stage s's buffer
   }
+  LYC_STAMP(28);
 
   k3_epilogue_rows<T, MI, NI, WITH_DW1>(a, ring, acc, w1raw, row_ok, rofs, n0, (long)by * gridDim.x + bx);
+  LYC_STAMP(29);
+  LYC_TRACE_FLUSH();
 }
 
 }  // namespace lyc
