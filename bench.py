@@ -60,6 +60,8 @@ def parse():
                          "path: the NHWC row matrices are free views, no transposes")
     ap.add_argument("--nchw", dest="channels_last", action="store_false",
                     help="Conv2d activations in contiguous NCHW memory: two layout transposes per conv layer and pass on top (A/B leg)")
+    ap.add_argument("--overlap-leg", action="store_true",
+                    help="development: also time base + adapter with every layer's adapter on a side HIP stream (negative result, DESIGN.md 7.4)")
     ap.add_argument("--no-defer", action="store_true",
                     help="A/B: one LoKr weight-gradient launch per layer instead of the grouped launches")
     ap.add_argument("--rank", type=int, default=0,
@@ -245,10 +247,12 @@ class Inst:
 
 CHANNELS_LAST = False
 LOKR_RANK = 0
+OVERLAP_LEG = False
 
 
 def build_instances(args, dtype, dev):
-    global CHANNELS_LAST, LOKR_RANK
+    global CHANNELS_LAST, LOKR_RANK, OVERLAP_LEG
+    OVERLAP_LEG = bool(getattr(args, "overlap_leg", False))
     CHANNELS_LAST = bool(args.channels_last)
     LOKR_RANK = int(args.rank)
     gen = torch.Generator(device=dev).manual_seed(1234)
@@ -830,18 +834,48 @@ def base_leg(insts, sync):
     def both_pass():
         one_backward([(it.forward(base=it.base_forward()), it) for it in insts])
 
+    side = torch.cuda.Stream()
+
+    def both_overlap_pass():
+        """the same work with the adapter of every layer on a SIDE stream (lycoris_amd.stream_overlap): forked when the layer's input is
+        ready on the main stream, joined before `base + delta` -- the dependency structure of a real network, layer by layer.  The
+        frozen GEMM of a bs-1 layer leaves most of the 256 CUs idle (20-80 workgroups); the adapter's latency-bound launches run
+        beside it.  autograd runs each backward node on the stream of its forward, so the backward forks and joins the same way."""
+        cur = torch.cuda.current_stream()
+        outs = []
+        for it in insts:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                delta = it.forward()
+            base = it.base_forward()
+            cur.wait_stream(side)
+            delta.record_stream(cur)
+            outs.append((base + delta, it))
+        one_backward(outs)
+        cur.wait_stream(side)
+
     sync._sync_enabled = False
+    t_ov = None
     try:
         t_base = _graph_ms(base_pass, reps=2)
         t_both = _graph_ms(both_pass, reps=2)
+        if OVERLAP_LEG:  # --overlap-leg: measured SLOWER (91.9 vs 79.0 ms, round 3): every fork / join is a cross-queue dependency in the graph
+            try:
+                t_ov = _graph_ms(both_overlap_pass, reps=2)
+            except Exception as e:  # a capture that cannot fork / join on this stack must not take the bench line down
+                print(f"[bench] overlapped base + adapter leg failed: {type(e).__name__}: {e}", file=sys.stderr)
     finally:
         sync._sync_enabled = True
         for it in insts:
             it.W = None
         torch.cuda.empty_cache()
-    return {"base_only_ms": round(t_base, 2), "base_plus_adapter_ms": round(t_both, 2),
-            "adapter_share": round(max(t_both - t_base, 0.0) / t_both, 3),
-            "what": "frozen F.linear / F.conv2d forward + input-gradient backward of the same layers (random bf16 weights)"}
+    out = {"base_only_ms": round(t_base, 2), "base_plus_adapter_ms": round(t_both, 2),
+           "adapter_share": round(max(t_both - t_base, 0.0) / t_both, 3),
+           "what": "frozen F.linear / F.conv2d forward + input-gradient backward of the same layers (random bf16 weights)"}
+    if t_ov is not None:
+        out["base_plus_adapter_overlapped_ms"] = round(t_ov, 2)
+        out["overlap"] = "adapter launches of every layer on a side HIP stream, forked / joined per layer (captured in the same hipGraph)"
+    return out
 
 
 def cpu_baseline(algo, model):
