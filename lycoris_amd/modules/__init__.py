@@ -19,6 +19,9 @@ def get_module(lyco_state_dict, lora_name):
 
 @torch.no_grad()
 def make_module(lyco_type, params, lora_name, orig_module):
+    if isinstance(orig_module, torch.nn.Conv1d):  # checkpoint tensors [.., .., k] -> the native [.., .., 1, k] (modules/base.py _Conv1dTwin)
+        from .base import _lift1d
+        params = tuple(_lift1d(p) for p in params)
     try:
         return lyco_type.make_module_from_state_dict(lora_name, orig_module, *params)
     except NotImplementedError:

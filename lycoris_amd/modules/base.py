@@ -30,7 +30,64 @@ def _unsupported(what: str):
     )
 
 
-class LycorisBaseModule(nn.Module):
+class _Conv1dTwin(nn.Conv2d):
+    """nn.Conv1d seen as nn.Conv2d over [B, C, 1, L] (round 3).  The adapter kernels are Conv2d kernels; a 1-D convolution with a
+    window of k is the 2-D one with a 1 x k window, so a native module adapts an nn.Conv1d layer by being built on THIS object.
+    No parameters of its own: `weight` / `bias` are live views of the real layer's (device / dtype moves, in-place merges and
+    `.data` writes of either are seen by both), so the twin never has to be kept in sync."""
+
+    def __init__(self, real: nn.Conv1d):
+        nn.Module.__init__(self)  # deliberately not nn.Conv2d.__init__: nothing is allocated
+        self.__dict__["_real"] = real  # not a submodule: the frozen layer must stay out of the adapter's parameters
+        self.in_channels, self.out_channels = real.in_channels, real.out_channels
+        self.kernel_size = (1, real.kernel_size[0])
+        self.stride = (1, real.stride[0])
+        self.padding = real.padding if isinstance(real.padding, str) else (0, real.padding[0])
+        self.dilation = (1, real.dilation[0])
+        self.groups = real.groups
+        self.padding_mode = real.padding_mode
+        self.transposed = False
+        self.output_padding = (0, 0)
+
+    @property
+    def weight(self):
+        return self._real.weight.unsqueeze(2)
+
+    @property
+    def bias(self):
+        return self._real.bias
+
+    @bias.setter
+    def bias(self, value):
+        self._real.bias = value
+
+    def forward(self, x):
+        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+
+class _TwinMeta(type):
+    """Module construction on an nn.Conv1d layer: the class is instantiated on the layer's Conv2d twin, then told about the real
+    layer (forward patching, state-dict shapes).  Everything between -- parameter shapes, kernels, weight space -- is the Conv2d
+    path with a 1 x k window."""
+
+    def __call__(cls, lora_name, org_module=None, *args, **kwargs):
+        if isinstance(org_module, nn.Conv1d):
+            obj = super().__call__(lora_name, _Conv1dTwin(org_module), *args, **kwargs)
+            obj._attach_conv1d(org_module)
+            return obj
+        return super().__call__(lora_name, org_module, *args, **kwargs)
+
+
+def _lift1d(t):
+    """a Conv1d-shaped adapter tensor ([.., .., k]) in the native 4-D form ([.., .., 1, k]); everything else unchanged"""
+    return t.unsqueeze(2) if isinstance(t, torch.Tensor) and t.dim() == 3 else t
+
+
+def _drop1d(t):
+    return t.squeeze(2) if isinstance(t, torch.Tensor) and t.dim() == 4 and t.shape[2] == 1 else t
+
+
+class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
     name: str = "base"
     support_module: set = set()
     weight_list: list = []
@@ -40,6 +97,7 @@ class LycorisBaseModule(nn.Module):
                  module_dropout=0.0, rank_dropout_scale=False, bypass_mode=None, **kwargs):
         super().__init__()
         self.lora_name = lora_name
+        self._conv1d = None  # the real nn.Conv1d layer when this module was built on its Conv2d twin (_attach_conv1d)
         self.not_supported = False
         self.module = type(org_module)
         self.kw_dict = {}
@@ -145,7 +203,43 @@ class LycorisBaseModule(nn.Module):
     def custom_state_dict(self):
         return None
 
+    # ---- nn.Conv1d (round 3) ------------------------------------------------------------------------------------------
+    def _attach_conv1d(self, real: nn.Conv1d):
+        """called by the metaclass after construction on the twin: checkpoints keep the reference's Conv1d shapes ([.., .., k]; the
+        native parameters are [.., .., 1, k]), the real layer is the one whose forward gets patched, and weights handed OUT
+        (get_diff_weight / get_merged_weight without an explicit shape) have the Conv1d shape."""
+        object.__setattr__(self, "_conv1d", real)  # NOT a submodule: the frozen layer stays out of the adapter's parameters
+        self.module = type(real)
+        self._register_load_state_dict_pre_hook(self._lift1d_state_dict)
+        for name in ("get_diff_weight", "get_merged_weight"):
+            fn = getattr(self, name)
+
+            def wrapped(*a, _fn=fn, **k):
+                w, b = _fn(*a, **k)
+                explicit = k.get("shape") is not None or len(a) >= 2 and a[1] is not None
+                return (w if explicit else _drop1d(w)), b
+
+            setattr(self, name, wrapped)
+
+    def _lift1d_state_dict(self, state_dict, prefix, *_):
+        for k in [k for k in state_dict if k.startswith(prefix)]:
+            state_dict[k] = _lift1d(state_dict[k])
+
+    def _forward_1d(self, x, *args, **kwargs):
+        return self.forward(x.unsqueeze(2), *args, **kwargs).squeeze(2)
+
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        if self._conv1d is not None:
+            pre = args[1] if len(args) > 1 and prefix == "" else prefix
+            real = self._conv1d
+            object.__setattr__(self, "_conv1d", None)  # plain call below, then the Conv1d shapes
+            try:
+                out = self.state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+            finally:
+                object.__setattr__(self, "_conv1d", real)
+            for k in [k for k in out if k.startswith(pre)]:
+                out[k] = _drop1d(out[k])
+            return out
         custom = self.custom_state_dict()
         if custom is None:
             return super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
@@ -175,29 +269,45 @@ class LycorisBaseModule(nn.Module):
     def apply_to(self, **kwargs):
         if self.not_supported:
             return
-        layer = self.org_module[0]
+        layer = self._patched_layer()
         if not hasattr(layer, _ORIG):
             setattr(layer, _ORIG, layer.forward)
         stack = [w for w in getattr(layer, _STACK, []) if w is not self]
-        self.org_forward = layer.forward  # whatever is currently on top (the bare layer or another adapter)
+        self._below = layer.forward  # whatever is currently on top (the bare layer or another adapter)
+        self.org_forward = self._lifted(self._below)
         stack.append(self)
         setattr(layer, _STACK, stack)
-        layer.forward = self.forward
+        layer.forward = self.forward if self._conv1d is None else self._forward_1d
+
+    def _patched_layer(self):
+        return self.org_module[0] if self._conv1d is None else self._conv1d
+
+    def _lifted(self, fwd):
+        """the forward below this adapter as the module sees it: itself, or (Conv1d) [B, C, 1, L] -> [B, C', 1, L']"""
+        if self._conv1d is None:
+            return fwd
+        return lambda x, *a, **k: fwd(x.squeeze(2), *a, **k).unsqueeze(2)
 
     def restore(self):
         if self.not_supported:
             return
-        layer = self.org_module[0]
+        layer = self._patched_layer()
         stack = list(getattr(layer, _STACK, []))
-        original = getattr(layer, _ORIG, self.org_forward)
+        below = getattr(self, "_below", None)
+        original = getattr(layer, _ORIG, below if below is not None else self.org_forward)
         if self in stack:
             pos = stack.index(self)
             stack.pop(pos)
             if pos < len(stack):  # the adapter that sat on top of us now calls what we used to call
-                stack[pos].org_forward = self.org_forward
+                if below is not None and hasattr(stack[pos], "_lifted"):
+                    stack[pos]._below = below
+                    stack[pos].org_forward = stack[pos]._lifted(below)
+                else:
+                    stack[pos].org_forward = self.org_forward
         if stack:
             setattr(layer, _STACK, stack)
-            layer.forward = stack[-1].forward
+            top = stack[-1]
+            layer.forward = top._forward_1d if getattr(top, "_conv1d", None) is not None else top.forward
         else:
             layer.forward = original
             layer.__dict__.pop(_STACK, None)

@@ -192,7 +192,10 @@ def test_no_cpu_fallback_and_unsupported_features_fail_loudly():
     assert m.tucker and tuple(m.lora_mid.weight.shape) == (2, 2, 3, 3) and tuple(m.lora_down.weight.shape) == (2, 8, 1, 1)
     assert not LoConModule("m", nn.Conv2d(8, 8, 1), 1.0, 2, 1, use_tucker=True).tucker      # 1x1: nothing to factor
     with pytest.raises(NotImplementedError):
-        LohaModule("m", nn.Conv1d(8, 8, 3), 1.0, 2, 1)
+        LohaModule("m", nn.Conv3d(8, 8, 3), 1.0, 2, 1)
+    # nn.Conv1d is adapted through its Conv2d twin (1 x k window; modules/base.py _Conv1dTwin, tests/test_conv1d.py)
+    m = LohaModule("m", nn.Conv1d(8, 8, 3), 1.0, 2, 1)
+    assert tuple(m.state_dict()["hada_w1_b"].shape) == (2, 24) and m._conv1d is not None
     with pytest.raises(ValueError):
         LoConModule("m", nn.LayerNorm(8), 1.0, 2, 1)
     # layer variants the kernels do not take fail when the network is BUILT, not at the first step
