@@ -222,6 +222,7 @@ struct DeferredLokr {
   void* stream;
   c10::DeviceIndex device;
   Tensor w2a, w2b, d_w2a, d_w2b;  // low-rank w2 = w2a @ w2b (all four defined): dw2 is then a slice of the flush's scratch arena
+  Tensor w1a, w1b, d_w1a, d_w1b;  // decompose_both: w1 = w1a @ w1b; `f1` is the product, dw1 a slice of the scratch arena
 };
 struct DeferredLocon {
   Tensor g, x, t, dt, down, up, dd, du;  // dd / du: the .grad targets (either may be undefined)
@@ -338,8 +339,10 @@ void flush_deferred(c10::DeviceIndex device) {
     const c10::hip::HIPStreamGuard sguard(c10::hip::getStreamFromExternal((hipStream_t)items[lo].stream, items[lo].device));
     // low-rank layers: dW2 [c, d] of each goes to a slice of ONE zero-filled scratch arena, then through the product's chain rule
     int64_t arena_floats = 0;
-    for (size_t i = lo; i < hi; ++i)
+    for (size_t i = lo; i < hi; ++i) {
       if (items[i].w2a.defined()) arena_floats += (int64_t)items[i].c * items[i].d;
+      if (items[i].w1a.defined()) arena_floats += (int64_t)items[i].a * items[i].b;
+    }
     Tensor arena;
     if (arena_floats > 0) arena = at::zeros({arena_floats}, items[lo].g.options().dtype(at::kFloat));
     std::vector<LycLokrWgradItem> raw(hi - lo);
@@ -353,7 +356,13 @@ void flush_deferred(c10::DeviceIndex device) {
         off += (int64_t)it.c * it.d;
         chain.push_back(LycLokrLrChainItem{dw2, cfp(it.w2a), cfp(it.w2b), mfp(it.d_w2a), mfp(it.d_w2b), it.c, it.d, (int)it.w2a.size(1)});
       }
-      raw[i - lo] = LycLokrWgradItem{cptr(it.g), cptr(it.x), cfp(it.f1), mfp(it.dw1), dw2, mptr(it.ws), it.M,
+      float* dw1 = mfp(it.dw1);
+      if (it.w1a.defined()) {
+        dw1 = arena.mutable_data_ptr<float>() + off;
+        off += (int64_t)it.a * it.b;
+        chain.push_back(LycLokrLrChainItem{dw1, cfp(it.w1a), cfp(it.w1b), mfp(it.d_w1a), mfp(it.d_w1b), it.a, it.b, (int)it.w1a.size(1), 1});
+      }
+      raw[i - lo] = LycLokrWgradItem{cptr(it.g), cptr(it.x), cfp(it.f1), dw1, dw2, mptr(it.ws), it.M,
                                      it.a, it.b, it.c, it.d, it.alpha};
     }
     check_rc(lyc_lokr_wgrad_group(raw.data(), (int)raw.size(), items[lo].code, items[lo].stream), "lyc_lokr_wgrad_group");
@@ -404,7 +413,12 @@ void flush_deferred(c10::DeviceIndex device) {
   for (const DeferredLoha& it : hitems)
     for (int i = 0; i < 4; ++i) ready.push_back(it.p[i]);
   for (const DeferredLokr& it : items) {
-    if (it.dw1.defined()) ready.push_back(it.w1);
+    if (it.w1a.defined()) {
+      ready.push_back(it.w1a);
+      ready.push_back(it.w1b);
+    } else if (it.dw1.defined()) {
+      ready.push_back(it.w1);
+    }
     if (it.w2a.defined()) {
       ready.push_back(it.w2a);
       ready.push_back(it.w2b);
@@ -917,6 +931,104 @@ Tensor lokr_linear_lr_meta(const Tensor& x, const Tensor& w1, const Tensor& w2a,
                            const c10::optional<Tensor>& base) {
   auto oshape = x.sym_sizes().vec();
   oshape.back() = w1.sym_size(0) * w2a.sym_size(0);
+  return x.new_empty_symint(oshape);
+}
+
+// ---- decompose_both (reference modules/lokr.py:94-104, 358-381): w1 = w1a [a, r] @ w1b [r, b] as well ---------------------------------
+// The 8 x 8 product is formed once per call below autograd (one tiny launch); its gradient dW1 lands in a scratch and goes through
+// the same grouped chain-rule kernel as dW2 (c := a, d := b), so all four factors stay leaves: fused accumulation, deferral and the
+// DP callback apply.  Layers off the plane kernels' fast path keep the autograd-visible products (lycoris_amd/ops.py).
+struct LokrLinearLr2Fn : public torch::autograd::Function<LokrLinearLr2Fn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a, const Tensor& w2b,
+                        double alpha, const c10::optional<Tensor>& base) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    TORCH_CHECK(eager_cuda(x), "lycoris_amd::lokr_linear_lr2 is an eager op");
+    TORCH_CHECK(w1a.dim() == 2 && w1b.dim() == 2 && w1a.size(1) == w1b.size(0), "lokr_linear_lr2: w1a [a, r], w1b [r, b]");
+    const c10::DeviceGuard dg(x.device());
+    Tensor w1 = at::mm(f32c(w1a), f32c(w1b));  // grad mode is off inside Function::forward: a plain tensor
+    Tensor y = lokr_linear_lr_fwd(x, w1, w2a, w2b, alpha, base);
+    for (const Tensor* f : {&w1a, &w1b, &w2a, &w2b}) expect(*f, x);
+    ctx->save_for_backward({x, w1a, w1b, w2a, w2b});
+    ctx->saved_data["alpha"] = alpha;
+    ctx->saved_data["has_base"] = base.has_value() && base->defined();
+    ctx->saved_data["w1"] = w1;
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &w1a = saved[1], &w1b = saved[2], &w2a = saved[3], &w2b = saved[4];
+    const Tensor w1 = ctx->saved_data["w1"].toTensor();
+    const double alpha = ctx->saved_data["alpha"].toDouble();
+    const bool nx = ctx->needs_input_grad(0);
+    const bool nbase = ctx->saved_data["has_base"].toBool() && ctx->needs_input_grad(5);
+    const Tensor& g = grads[0];
+    const c10::DeviceGuard guard(x.device());
+    const int64_t a = w1.size(0), b = w1.size(1), c = w2a.size(0), d = w2b.size(1), r = w2a.size(1), r1 = w1a.size(1);
+    const int code = dtype_code(x.scalar_type());
+    Tensor rows = rows_of(x, b * d), g2 = rows_of(g, a * c), fa = f32c(w2a), fb = f32c(w2b), f1a = f32c(w1a), f1b = f32c(w1b);
+    const bool want_w1 = ctx->needs_input_grad(1) || ctx->needs_input_grad(2) || accum_wanted(w1a) || accum_wanted(w1b);
+    const bool want_w2 = ctx->needs_input_grad(3) || ctx->needs_input_grad(4) || accum_wanted(w2a) || accum_wanted(w2b);
+    GradTarget t1a = grad_target(w1a, want_w1), t1b = grad_target(w1b, want_w1), ta = grad_target(w2a, want_w2), tb = grad_target(w2b, want_w2);
+    const bool fast = lyc_lokr_linear_planes_ok(rows.size(0), (int)a, (int)b, (int)c, (int)d, code) &&
+                      (reinterpret_cast<uintptr_t>(cptr(g2)) & 15u) == 0;
+    Tensor pl = fast ? planes_for_lr(w2a, w2b, x.scalar_type(), stream_of(x)) : Tensor();
+    const bool want_dx = nx || want_w1;
+    Tensor dx, ws;
+    if (want_dx) dx = at::empty(rows.sizes(), x.options());
+    if (want_w1) {
+      const int64_t nbytes = lyc_lokr_bwd_workspace_bytes(rows.size(0), (int)a, (int)b, (int)c, (int)d, code);
+      if (nbytes > 0) ws = at::empty({nbytes}, x.options().dtype(at::kByte));
+    }
+    const bool defer = g_defer.enabled && pl.defined() && want_w1 && want_w2 && !ta.hand_back && !tb.hand_back && !t1a.hand_back && !t1b.hand_back &&
+                       fa.is_same(w2a) && fb.is_same(w2b) && f1a.is_same(w1a) && f1b.is_same(w1b) && ws.defined() &&
+                       lyc_lokr_wgrad_deferrable(cptr(g2), cptr(rows), rows.size(0), (int)a, (int)b, (int)c, (int)d, code);
+    if (defer) {
+      // dx now; dW1 partials stay in ws; dW1 / dW2 and both chain rules in the grouped launches.  On the deferrable (kron3) path the
+      // dw1 pointer of the dx launch is only a "w1 gradient wanted" flag (the partials go to ws, LYC_DEFER_WGRAD skips the
+      // reduction): ws itself serves as the non-null address
+      check_rc(lyc_lokr_linear_bwd_planes(cptr(g2), cptr(rows), cfp(w1), planes_bwd_ptr(pl, c, d, 1), mptr(dx),
+                                          reinterpret_cast<float*>(mptr(ws)), nullptr, mptr(ws),
+                                          rows.size(0), (int)a, (int)b, (int)c, (int)d, (float)alpha, code | LYC_DEFER_WGRAD, stream_of(x)),
+               "lyc_lokr_linear_bwd_planes(dx)");
+      DeferredLokr item{g2, rows, w1, Tensor(), Tensor(), t1a.buf, Tensor(), ws, rows.size(0), (int)a, (int)b, (int)c, (int)d, code, (float)alpha,
+                        stream_of(x), x.device().index()};
+      item.w2a = w2a; item.w2b = w2b; item.d_w2a = ta.buf; item.d_w2b = tb.buf;
+      item.w1a = w1a; item.w1b = w1b; item.d_w1a = t1a.buf; item.d_w1b = t1b.buf;
+      park_deferred(std::move(item));
+      return {nx ? shaped_like(dx, x) : Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), nbase ? g : Tensor()};
+    }
+    Tensor dw1 = want_w1 ? at::zeros({a, b}, x.options().dtype(at::kFloat)) : Tensor();
+    Tensor dw2 = want_w2 ? at::zeros({c, d}, x.options().dtype(at::kFloat)) : Tensor();
+    if (pl.defined()) {
+      check_rc(lyc_lokr_linear_bwd_planes(cptr(g2), cptr(rows), cfp(w1), planes_bwd_ptr(pl, c, d, 1), mptr(dx), mfp(dw1), mfp(dw2), mptr(ws),
+                                          rows.size(0), (int)a, (int)b, (int)c, (int)d, (float)alpha, code, stream_of(x)),
+               "lyc_lokr_linear_bwd_planes");
+    } else {
+      Tensor f2 = at::mm(fa, fb);
+      check_rc(lyc_lokr_linear_bwd(cptr(g2), cptr(rows), cfp(w1), cfp(f2), mptr(dx), mfp(dw1), mfp(dw2), mptr(ws), rows.size(0), (int)a, (int)b,
+                                   (int)c, (int)d, (float)alpha, code, stream_of(x)), "lyc_lokr_linear_bwd");
+    }
+    std::vector<LycLokrLrChainItem> chain;
+    if (want_w2) chain.push_back(LycLokrLrChainItem{cfp(dw2), cfp(fa), cfp(fb), mfp(ta.buf), mfp(tb.buf), (int)c, (int)d, (int)r, 1});
+    if (want_w1) chain.push_back(LycLokrLrChainItem{cfp(dw1), cfp(f1a), cfp(f1b), mfp(t1a.buf), mfp(t1b.buf), (int)a, (int)b, (int)r1, 1});
+    if (!chain.empty()) check_rc(lyc_lokr_lr_chain_group(chain.data(), (int)chain.size(), stream_of(x)), "lyc_lokr_lr_chain_group");
+    return {nx ? shaped_like(dx, x) : Tensor(), finish_grad(w1a, t1a), finish_grad(w1b, t1b), finish_grad(w2a, ta), finish_grad(w2b, tb), Tensor(),
+            nbase ? g : Tensor()};
+  }
+};
+Tensor lokr_linear_lr2_autograd(const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a, const Tensor& w2b, double alpha,
+                                const c10::optional<Tensor>& base) {
+  const GradAtApply ga_;
+  return LokrLinearLr2Fn::apply(amp(x), w1a, w1b, w2a, w2b, alpha, base);
+}
+Tensor lokr_linear_lr2_cuda(const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a, const Tensor& w2b, double alpha,
+                            const c10::optional<Tensor>& base) {
+  return lokr_linear_lr_fwd(x, at::mm(f32c(w1a), f32c(w1b)), w2a, w2b, alpha, base);
+}
+Tensor lokr_linear_lr2_meta(const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a, const Tensor& w2b, double alpha,
+                            const c10::optional<Tensor>& base) {
+  auto oshape = x.sym_sizes().vec();
+  oshape.back() = w1a.sym_size(0) * w2a.sym_size(0);
   return x.new_empty_symint(oshape);
 }
 
@@ -2091,6 +2203,7 @@ TORCH_LIBRARY(lycoris_amd, m) {
   // public ops: what lycoris_amd.ops / the modules call (autograd-aware)
   m.def("lokr_linear(Tensor x, Tensor w1, Tensor w2, float alpha, Tensor? base=None) -> Tensor");
   m.def("lokr_linear_lr(Tensor x, Tensor w1, Tensor w2a, Tensor w2b, float alpha, Tensor? base=None) -> Tensor");
+  m.def("lokr_linear_lr2(Tensor x, Tensor w1a, Tensor w1b, Tensor w2a, Tensor w2b, float alpha, Tensor? base=None) -> Tensor");
   m.def("locon_linear(Tensor x, Tensor down, Tensor up, float alpha) -> Tensor");
   m.def("loha_linear(Tensor x, Tensor w1a, Tensor w1b, Tensor w2a, Tensor w2b, float alpha) -> Tensor");
   m.def("chan_affine(Tensor a, Tensor w, Tensor? bias, float s0, float mult, int chan_dim) -> Tensor");
@@ -2126,6 +2239,7 @@ TORCH_LIBRARY(lycoris_amd, m) {
 TORCH_LIBRARY_IMPL(lycoris_amd, CUDA, m) {
   m.impl("lokr_linear", lokr_linear_fwd);
   m.impl("lokr_linear_lr", lokr_linear_lr_fwd);
+  m.impl("lokr_linear_lr2", lokr_linear_lr2_cuda);
   m.impl("_lokr_linear_backward", lokr_linear_bwd);
   m.impl("locon_linear", locon_linear_cuda);
   m.impl("_locon_linear_forward", locon_linear_fwd);
@@ -2149,6 +2263,7 @@ TORCH_LIBRARY_IMPL(lycoris_amd, CUDA, m) {
 TORCH_LIBRARY_IMPL(lycoris_amd, Meta, m) {
   m.impl("lokr_linear", lokr_linear_meta);
   m.impl("lokr_linear_lr", lokr_linear_lr_meta);
+  m.impl("lokr_linear_lr2", lokr_linear_lr2_meta);
   m.impl("_lokr_linear_backward", lokr_linear_bwd_meta);
   m.impl("locon_linear", locon_linear_meta);
   m.impl("_locon_linear_forward", locon_linear_fwd_meta);
@@ -2172,6 +2287,7 @@ TORCH_LIBRARY_IMPL(lycoris_amd, Meta, m) {
 TORCH_LIBRARY_IMPL(lycoris_amd, Autograd, m) {
   m.impl("lokr_linear", lokr_linear_autograd);
   m.impl("lokr_linear_lr", lokr_linear_lr_autograd);
+  m.impl("lokr_linear_lr2", lokr_linear_lr2_autograd);
   m.impl("locon_linear", locon_linear_autograd);
   m.impl("loha_linear", loha_linear_autograd);
   m.impl("chan_affine", chan_affine_autograd);

@@ -225,6 +225,12 @@ class LokrModule(LycorisBaseModule):
     def _forward_fused(self, x, base):
         if self.module_type != "linear":
             return None
+        if self._w2_low_rank_native(x) and not self.use_w1:  # decompose_both: all four factors go to the kernels as they are
+            w1s = ops._Shape2(self.lokr_w1_a.shape[0], self.lokr_w1_b.shape[1])
+            if not ops.lokr_linear_fusable(x, w1s, ops._Shape2(self.lokr_w2_a.shape[0], self.lokr_w2_b.shape[1]), base):
+                return None
+            return ops.lokr_linear_lr2(x, self._gate(self.lokr_w1_a), self.lokr_w1_b, self.lokr_w2_a, self.lokr_w2_b,
+                                       self.scale * self.multiplier, base=base)
         w1 = self._gate(self._w1_full())
         if self._w2_low_rank_native(x):  # the factors go to the kernels as they are: no w2_a @ w2_b product, no autograd mm
             if not ops.lokr_linear_fusable(x, w1, ops._Shape2(self.lokr_w2_a.shape[0], self.lokr_w2_b.shape[1]), base):
@@ -244,6 +250,8 @@ class LokrModule(LycorisBaseModule):
         Unlike upstream's bypass (lokr.py:538) this includes ``self.scale``, i.e. it equals the rebuild
         path lokr.py:543-566, which is the canonical semantics."""
         alpha = self.scale * scale
+        if self._w2_low_rank_native(h) and not self.use_w1:
+            return ops.lokr_linear_lr2(h, self._gate(self.lokr_w1_a), self.lokr_w1_b, self.lokr_w2_a, self.lokr_w2_b, alpha)
         w1 = self._gate(self._w1_full())
         if self._w2_low_rank_native(h):
             return ops.lokr_linear_lr(h, w1, self.lokr_w2_a, self.lokr_w2_b, alpha)

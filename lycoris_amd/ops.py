@@ -48,7 +48,7 @@ def _cpp() -> bool:
         ext.set_accum(_ACCUM["enabled"], _ACCUM["callback"], _ACCUM["batch_callback"])
         _DISPATCH["ext"] = ext
         ns = torch.ops.lycoris_amd  # the resolved overloads: skips the packet's per-call overload resolution (~1 us per call)
-        for name in ("lokr_linear", "lokr_linear_lr", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d", "lokr_conv2d_lr"):
+        for name in ("lokr_linear", "lokr_linear_lr", "lokr_linear_lr2", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d", "lokr_conv2d_lr"):
             _OPS[name] = getattr(ns, name).default
     return True
 
@@ -654,6 +654,18 @@ def lokr_linear_lr(x, w1, w2a, w2b, alpha=1.0, base=None):
     if base is not None and not lokr_linear_fusable(x, w1, _Shape2(w2a.shape[0], w2b.shape[1]), base):
         return base + lokr_linear_lr(x, w1, w2a, w2b, alpha)
     return _OPS["lokr_linear_lr"](x, w1, w2a, w2b, float(alpha), base)
+
+
+def lokr_linear_lr2(x, w1a, w1b, w2a, w2b, alpha=1.0, base=None):
+    """LoKr with BOTH factors low-rank (`decompose_both`, reference modules/lokr.py:94-104): w1 = w1a [a, r] @ w1b [r, b],
+    w2 = w2a [c, r] @ w2b [r, d].  The small product is formed once per call below autograd, both weight gradients go through the
+    grouped chain-rule launch; tracing / python dispatch / CPU form autograd-visible products and call lokr_linear."""
+    N.require_device(x, "input")
+    if not _cpp() or torch.compiler.is_compiling() or not x.is_cuda:
+        return lokr_linear(x, w1a @ w1b, w2a @ w2b, alpha, base)
+    if base is not None and not lokr_linear_fusable(x, _Shape2(w1a.shape[0], w1b.shape[1]), _Shape2(w2a.shape[0], w2b.shape[1]), base):
+        return base + lokr_linear_lr2(x, w1a, w1b, w2a, w2b, alpha)
+    return _OPS["lokr_linear_lr2"](x, w1a, w1b, w2a, w2b, float(alpha), base)
 
 
 class _Shape2:

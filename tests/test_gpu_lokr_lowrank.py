@@ -108,7 +108,7 @@ def test_op_matches_the_oracle_gradients_handed_back(shape, dtype):
     assert err(db, gr["w2b"]) <= f32, err(db, gr["w2b"])
     # the same layer through the materialised product: same kernels behind different operand sources
     y2 = ops.lokr_linear(x, ps[0], ps[1] @ ps[2], alpha)
-    assert float((y.float() - y2.float()).norm() / y2.float().norm()) <= 2e-3
+    assert float((y.detach().float() - y2.detach().float()).norm() / y2.detach().float().norm()) <= 2e-3
 
 
 class _Stack(nn.Module):
@@ -370,3 +370,79 @@ def test_module_low_rank_conv_runs_the_native_op(monkeypatch):
     want = conv(x).float() + torch.nn.functional.conv2d(x, w, padding=1).float()
     torch.cuda.synchronize()
     assert float((y.float() - want).norm() / want.norm()) <= 1e-2
+
+
+# ---- (f) decompose_both: w1 = w1a @ w1b as well (lokr_linear_lr2) ----------------------------------------------------------------
+LR2_SHAPES = [(1024, 8, 160, 160, 16, 2), (77, 8, 160, 256, 16, 4), (333, 8, 40, 24, 4, 2), (64, 4, 32, 48, 8, 1)]  # (M, a, c, d, r2, r1)
+
+
+@DT16
+@pytest.mark.parametrize("shape", LR2_SHAPES, ids=[f"M{s[0]}_a{s[1]}_c{s[2]}_d{s[3]}_r{s[4]}_r1{s[5]}" for s in LR2_SHAPES])
+def test_decompose_both_op_matches_the_oracle(shape, dtype):
+    from lycoris_amd import ops
+    M, a, c, d, r2, r1 = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    x, x64 = rnd((M, a * d), dtype, gen)
+    g, g64 = rnd((M, a * c), dtype, gen, 0.1)
+    w1a, a164 = rnd((a, r1), torch.float32, gen, 0.5)
+    w1b, b164 = rnd((r1, a), torch.float32, gen, 0.5)
+    w2a, a264 = rnd((c, r2), torch.float32, gen, 0.3)
+    w2b, b264 = rnd((r2, d), torch.float32, gen, 0.3)
+    x.requires_grad_(True)
+    ps = [nn.Parameter(t) for t in (w1a, w1b, w2a, w2b)]
+    y = ops.lokr_linear_lr2(x, *ps, 0.7)
+    grads = torch.autograd.grad(y, [x] + ps, g)
+    torch.cuda.synchronize()
+    kw = dict(w1a=a164, w1b=b164, w2a=a264, w2b=b264, scale=0.7)
+    y_ref = oracle.lokr.forward(x64, **kw)
+    gr = oracle.lokr.backward(x64, g64, **kw)
+    st, f32 = TOL["store_out"][dtype], TOL["f32_out"][dtype]
+    assert err(y, y_ref, dtype) <= st and err(grads[0], gr["dx"], dtype) <= st
+    for got, key in zip(grads[1:], ("w1a", "w1b", "w2a", "w2b")):
+        assert err(got, gr[key]) <= f32, (key, err(got, gr[key]))
+
+
+def test_decompose_both_parked_layers_match_autograd_through_the_products():
+    from lycoris_amd import ops
+    torch.manual_seed(12)
+    mk = lambda *s, sc: nn.Parameter(torch.randn(*s, device=DEV) * sc)
+    layers = [(mk(8, 2, sc=0.5), mk(2, 8, sc=0.5), mk(16, 4, sc=0.3), mk(4, 16, sc=0.3)) for _ in range(3)]
+    params = [p for l in layers for p in l]
+    x = (torch.randn(96, 128, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    gy = (torch.randn(96, 128, device=DEV) * 0.1).to(torch.bfloat16)
+
+    def net(materialise):
+        h = x
+        for l in layers + [layers[0]]:  # the first layer is applied twice
+            if materialise:
+                h = h + ops.lokr_linear(h, l[0] @ l[1], l[2] @ l[3], 0.5)
+            else:
+                h = h + ops.lokr_linear_lr2(h, *l, 0.5)
+        return h
+
+    want = torch.autograd.grad(net(True), params, gy)
+
+    def run(defer):
+        seen = []
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        x.grad = None
+        ops.fused_grad_accumulation(True, callback=lambda p: seen.append(id(p)))
+        ops.deferred_weight_gradients(defer)
+        try:
+            net(False).backward(gy)
+            assert ops._DISPATCH["ext"].deferred_pending() == 0
+            torch.cuda.synchronize()
+            return x.grad.clone(), [p.grad.clone() for p in params], seen
+        finally:
+            ops.fused_grad_accumulation(False, None)
+            ops.deferred_weight_gradients(True, 48)
+
+    dx0, g0, seen0 = run(False)
+    dx1, g1, seen1 = run(True)
+    assert torch.equal(dx0, dx1)
+    for u, v, w in zip(g0, g1, want):
+        assert float(u.abs().max()) > 0
+        assert float((u - v).norm() / u.norm()) <= 2e-5
+        assert float((v - w).norm() / w.norm()) <= 3e-4, float((v - w).norm() / w.norm())
+    assert sorted(seen0) == sorted(seen1) == sorted(id(p) for p in params)
