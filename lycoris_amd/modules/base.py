@@ -211,15 +211,26 @@ class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
         object.__setattr__(self, "_conv1d", real)  # NOT a submodule: the frozen layer stays out of the adapter's parameters
         self.module = type(real)
         self._register_load_state_dict_pre_hook(self._lift1d_state_dict)
-        for name in ("get_diff_weight", "get_merged_weight"):
-            fn = getattr(self, name)
 
-            def wrapped(*a, _fn=fn, **k):
-                w, b = _fn(*a, **k)
+    def __init_subclass__(cls, **kwargs):
+        """get_diff_weight / get_merged_weight of every algorithm hand a Conv1d-shaped weight OUT when the module adapts an nn.Conv1d
+        and the caller gave no explicit shape (class-level wrappers: nothing per instance, so copies / pickles stay self-contained)"""
+        super().__init_subclass__(**kwargs)
+        for name in ("get_diff_weight", "get_merged_weight"):
+            fn = cls.__dict__.get(name)
+            if fn is None or getattr(fn, "_conv1d_aware", False):
+                continue
+
+            def wrapped(self, *a, _fn=fn, **k):
+                w, b = _fn(self, *a, **k)
+                if self._conv1d is None:
+                    return w, b
                 explicit = k.get("shape") is not None or len(a) >= 2 and a[1] is not None
                 return (w if explicit else _drop1d(w)), b
 
-            setattr(self, name, wrapped)
+            wrapped._conv1d_aware = True
+            wrapped.__name__, wrapped.__doc__ = name, fn.__doc__
+            setattr(cls, name, wrapped)
 
     def _lift1d_state_dict(self, state_dict, prefix, *_):
         for k in [k for k in state_dict if k.startswith(prefix)]:
