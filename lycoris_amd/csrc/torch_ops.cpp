@@ -922,8 +922,16 @@ struct LokrLinearLrFn : public torch::autograd::Function<LokrLinearLrFn> {
     return {nx ? shaped_like(dx, x) : Tensor(), finish_grad(w1, t1), finish_grad(w2a, ta), finish_grad(w2b, tb), Tensor(), nbase ? g : Tensor()};
   }
 };
+// FakeTensor / meta / functionalised inputs (torch.compile tracing): the product is formed with differentiable ATen ops and the
+// traceable full-matrix op runs -- same function, no eager-only state (plane cache, park lists) touched
+Tensor lokr_linear_composite(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, const c10::optional<Tensor>& base) {
+  static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::lokr_linear", "")
+                       .typed<Tensor(const Tensor&, const Tensor&, const Tensor&, double, const c10::optional<Tensor>&)>();
+  return op.call(x, w1, w2, alpha, base);
+}
 Tensor lokr_linear_lr_autograd(const Tensor& x, const Tensor& w1, const Tensor& w2a, const Tensor& w2b, double alpha,
                                const c10::optional<Tensor>& base) {
+  if (!eager_cuda(x)) return lokr_linear_composite(x, w1, at::matmul(w2a, w2b), alpha, base);
   const GradAtApply ga_;
   return LokrLinearLrFn::apply(amp(x), w1, w2a, w2b, alpha, base);
 }
@@ -1018,6 +1026,7 @@ struct LokrLinearLr2Fn : public torch::autograd::Function<LokrLinearLr2Fn> {
 };
 Tensor lokr_linear_lr2_autograd(const Tensor& x, const Tensor& w1a, const Tensor& w1b, const Tensor& w2a, const Tensor& w2b, double alpha,
                                 const c10::optional<Tensor>& base) {
+  if (!eager_cuda(x)) return lokr_linear_composite(x, at::matmul(w1a, w1b), at::matmul(w2a, w2b), alpha, base);
   const GradAtApply ga_;
   return LokrLinearLr2Fn::apply(amp(x), w1a, w1b, w2a, w2b, alpha, base);
 }
@@ -1906,6 +1915,12 @@ Tensor lokr_conv2d_lr_meta(const Tensor& x, const Tensor& w1, const Tensor& w2a,
 }
 Tensor lokr_conv2d_lr_autograd(const Tensor& x, const Tensor& w1, const Tensor& w2a, const Tensor& w2b, double alpha, at::IntArrayRef kernel,
                                at::IntArrayRef stride, at::IntArrayRef padding, at::IntArrayRef dilation) {
+  if (!eager_cuda(x)) {  // tracing: the product as a [c, d, kh, kw] tensor through the traceable full-matrix Conv2d op
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::lokr_conv2d", "")
+                         .typed<Tensor(const Tensor&, const Tensor&, const Tensor&, double, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef)>();
+    Tensor w2 = at::matmul(w2a, w2b).reshape({w2a.size(0), -1, kernel[0], kernel[1]});
+    return op.call(x, w1, w2, alpha, stride, padding, dilation);
+  }
   const GradAtApply ga_;
   return LokrConv2dLrFn::apply(amp(x), w1, w2a, w2b, alpha, kernel.vec(), stride.vec(), padding.vec(), dilation.vec());
 }

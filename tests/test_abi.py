@@ -99,6 +99,22 @@ def test_torch_custom_ops_are_registered_with_meta_kernels():
     assert yc.shape == (2, 24, 5, 4) and [g.shape for g in gs] == [xg.shape, cd.shape, cu.shape]
     for name in ("_lokr_conv2d_backward", "_locon_conv2d_forward", "_locon_conv2d_backward"):
         assert hasattr(ns, name), name
+    # round 3: the rows-lowered Conv2d of every algorithm (LoHa / 1x1 / fp32), differentiable under tracing through its functional ops
+    for name in ("adapter_conv2d", "_adapter_conv2d_forward", "_adapter_conv2d_backward", "lokr_linear_lr", "lokr_linear_lr2", "lokr_conv2d_lr"):
+        assert hasattr(ns, name), name
+    hf = [torch.empty(24, 4, requires_grad=True, **m), torch.empty(4, 64 * 9, requires_grad=True, **m),
+          torch.empty(24, 4, requires_grad=True, **m), torch.empty(4, 64 * 9, requires_grad=True, **m)]
+    yh = ns.adapter_conv2d(xg, hf[0], hf[1], hf[2], hf[3], 2, 1.0, [3, 3], [2, 2], [1, 1], [1, 1])  # algo 2 = LoHa
+    gs = torch.autograd.grad(yh, [xg] + hf, torch.empty_like(yh))
+    assert yh.shape == (2, 24, 5, 4) and [g.shape for g in gs] == [xg.shape] + [f.shape for f in hf]
+    y1, cols, saved = ns._adapter_conv2d_forward(xg, torch.empty(4, 64, **m), torch.empty(24, 4, **m), None, None, 1, 1.0, [1, 1], [1, 1], [0, 0], [1, 1])
+    assert y1.shape == (2, 24, 9, 7) and cols.numel() == 0 and saved.shape == (2 * 9 * 7, 4)  # 1x1 LoCon: rows are the NHWC view, t saved
+    la, lb = torch.empty(16, 2, requires_grad=True, **m), torch.empty(2, 8, requires_grad=True, **m)
+    yl = ns.lokr_linear_lr(x, w1, la, lb, 1.0)  # traced: the composite form (product by ATen, then the traceable full-matrix op)
+    gs = torch.autograd.grad(yl, [x, w1, la, lb], torch.empty_like(yl))
+    assert yl.shape == (3, 5, 128) and [g.shape for g in gs] == [x.shape, w1.shape, la.shape, lb.shape]
+    assert ns.lokr_linear_lr2(x, torch.empty(8, 2, **m), torch.empty(2, 8, **m), torch.empty(16, 2, **m), torch.empty(2, 8, **m), 1.0).shape == (3, 5, 128)
+    assert ns.lokr_conv2d_lr(xc, torch.empty(8, 8, **m), torch.empty(4, 2, **m), torch.empty(2, 8 * 9, **m), 1.0, [3, 3], [1, 1], [1, 1], [1, 1]).shape == (2, 32, 9, 7)
 
 
 def test_cpu_tensors_are_rejected_by_the_custom_op_path():
