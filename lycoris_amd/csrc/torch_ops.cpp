@@ -766,7 +766,8 @@ struct LokrLinearFn : public torch::autograd::Function<LokrLinearFn> {
     at::AutoDispatchBelowADInplaceOrView guard;
     static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::lokr_linear", "")
                          .typed<Tensor(const Tensor&, const Tensor&, const Tensor&, double, const c10::optional<Tensor>&)>();
-    Tensor y = op.call(x, w1, w2, alpha, base);
+    // eager device tensors: straight to the kernel launch (the second trip through the dispatcher is ~1 us of host time per layer)
+    Tensor y = eager_cuda(x) ? lokr_linear_fwd(x, w1, w2, alpha, base) : op.call(x, w1, w2, alpha, base);
     expect(w1, x);
     expect(w2, x);
     ctx->save_for_backward({x, w1, w2});
@@ -1109,7 +1110,7 @@ struct LoconLinearFn : public torch::autograd::Function<LoconLinearFn> {
     at::AutoDispatchBelowADInplaceOrView guard;
     static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_locon_linear_forward", "")
                          .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, double)>();
-    auto [y, t] = op.call(x, down, up, alpha);
+    auto [y, t] = eager_cuda(x) ? locon_linear_fwd(x, down, up, alpha) : op.call(x, down, up, alpha);
     expect(down, x);
     expect(up, x);
     ctx->save_for_backward({x, down, up, t});
@@ -1240,7 +1241,7 @@ struct LohaLinearFn : public torch::autograd::Function<LohaLinearFn> {
     static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_loha_linear_forward", "")
                          .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&,
                                                            double)>();
-    auto [y, ws] = op.call(x, w1a, w1b, w2a, w2b, alpha);
+    auto [y, ws] = eager_cuda(x) ? loha_linear_fwd(x, w1a, w1b, w2a, w2b, alpha) : op.call(x, w1a, w1b, w2a, w2b, alpha);
     for (const Tensor* f : {&w1a, &w1b, &w2a, &w2b}) expect(*f, x);
     ctx->save_for_backward({x, w1a, w1b, w2a, w2b, ws});
     ctx->saved_data["alpha"] = alpha;
