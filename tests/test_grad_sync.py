@@ -194,3 +194,37 @@ def test_fused_accumulation_callback_drives_the_buckets():
         sync.attach_fused(False)
         sync.remove()
     assert not ops._ACCUM["enabled"] and ops._ACCUM["callback"] is None
+
+
+def _worker_ws1(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lycoris_amd.grad_sync import AdapterGradSync
+    params = [torch.nn.Parameter(torch.ones(4, 4)), torch.nn.Parameter(torch.ones(7))]
+    plain = AdapterGradSync(params, bucket_bytes=1)
+    assert not plain._reduce  # world_size 1: no collective unless asked for
+    plain.remove()
+    sync = AdapterGradSync(params, bucket_bytes=1, always_reduce=True)
+    assert sync._reduce and sync.world_size == 1
+    sync.zero_grad()
+    (params[0].sum() * 2 + params[1].sum()).backward()
+    launched = sync.collectives_launched
+    sync.finish()
+    ok = launched == 2 and bool(torch.all(params[0].grad == 2)) and bool(torch.all(params[1].grad == 1))
+    # the batched report of a grouped weight-gradient flush (csrc/torch_ops.cpp notify_many): one call, every parameter counted once
+    sync.zero_grad()
+    sync._on_grads_ready([params[1], params[0]])
+    ok = ok and sync.launch_log == [0, 1] and sync.collectives_launched == 4
+    sync.finish()
+    sync.remove()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
+def test_always_reduce_runs_the_collectives_at_world_size_1():
+    """round 3: `always_reduce=True` is how ONE GPU drives the real N > 1 step through RCCL (bench.py --rccl-ws1,
+    tests/test_gpu_grad_sync.py); here the same switch and the batched gradient-ready report over gloo on the CPU"""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_ws1, args=(1, _free_port(), None), nprocs=1, join=True)
