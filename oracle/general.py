@@ -139,6 +139,25 @@ def rebuild_tucker(t, wa, wb):
     return np.einsum("ij...,ip,jq->pq...", np.asarray(t, np.float64), np.asarray(wa, np.float64), np.asarray(wb, np.float64))
 
 
+def round_to(a, dtype):
+    """Round a float64 array the way ``tensor.to(dtype)`` rounds an fp32 tensor (round-to-nearest-even), back to float64.
+    ``dtype``: "bf16" / "f16" / "f32" (or a name containing "bfloat16" / "float16" / "float32", e.g. str(torch.bfloat16)).
+    The value passes through float32 first: the reference forms its weights in fp32 and THEN casts
+    (``get_weight(...).to(base_weight.dtype)``, modules/loha.py:310)."""
+    name = str(dtype)
+    a32 = np.asarray(a, dtype=np.float64).astype(np.float32)
+    if "bf16" in name or "bfloat16" in name:
+        u = np.ascontiguousarray(a32).view(np.uint32).astype(np.uint64)
+        u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16          # RNE on the dropped 16 bits (finite values)
+        return u.astype(np.uint32).view(np.float32).reshape(a32.shape).astype(np.float64)
+    if "f16" in name or "float16" in name:
+        with np.errstate(over="ignore"):
+            return a32.astype(np.float16).astype(np.float64)
+    if "f32" in name or "float32" in name:
+        return a32.astype(np.float64)
+    raise ValueError(f"round_to: unknown dtype {dtype!r}")
+
+
 def rel_err(a, b):
     """Norm-wise relative error ||a-b|| / ||b|| (the metric of SURVEY 8d)."""
     a = np.asarray(a, dtype=np.float64)

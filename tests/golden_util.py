@@ -11,8 +11,9 @@ def conv_args_of(meta):
     return {"stride": lk.get("stride", 1), "padding": lk.get("padding", 0), "dilation": lk.get("dilation", 1)}
 
 
-def oracle_eval(meta, a):
-    """Returns (delta, grads dict keyed like the golden file: 'dx', 'g.<param name>')."""
+def oracle_eval(meta, a, round_dw=None):
+    """Returns (delta, grads dict keyed like the golden file: 'dx', 'g.<param name>').
+    round_dw (LoHa only): evaluate with the reference's cast of the rebuilt weight (modules/loha.py:310, oracle.loha)."""
     algo = meta["algo"]
     ca = conv_args_of(meta)
     x, g, W = a["x"], a["g"], a["W"]
@@ -40,8 +41,8 @@ def oracle_eval(meta, a):
             r = t1.shape[0]
             ws = [raw[0].T, oracle.general.tucker_core(t1, raw[1]).reshape(r, -1),
                   raw[2].T, oracle.general.tucker_core(t2, raw[3]).reshape(r, -1)]
-        delta = oracle.loha.forward(x, *ws, eff, W.shape, ca)
-        dx, g1a, g1b, g2a, g2b = oracle.loha.backward(x, g, *ws, eff, W.shape, ca)
+        delta = oracle.loha.forward(x, *ws, eff, W.shape, ca, round_dw=round_dw)
+        dx, g1a, g1b, g2a, g2b = oracle.loha.backward(x, g, *ws, eff, W.shape, ca, round_dw=round_dw)
         if t1 is not None:
             gt1, g1b = oracle.general.tucker_core_grads(g1b, t1, raw[1])
             gt2, g2b = oracle.general.tucker_core_grads(g2b, t2, raw[3])

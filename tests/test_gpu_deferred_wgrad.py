@@ -347,6 +347,8 @@ def test_grouped_loha_factor_gradients_match_the_oracle(dtype):
         for name, d, want in zip(("w1a", "w1b", "w2a", "w2b"), ds, rf):
             assert err(d, want) <= TOL["f32_out"][dtype], (k, name, err(d, want))
         assert err(dx, rx, dtype) <= TOL["loha_store"][dtype], (k, "dx")
+        rx_cast = oracle.loha.backward(x64, g64, *f64, scale=alpha, round_dw=str(dtype))[0]  # modules/loha.py:310
+        assert err(dx, rx_cast, dtype) <= TOL["store_out"][dtype], (k, "dx@cast", err(dx, rx_cast, dtype))
 
 
 class _LohaStack(nn.Module):

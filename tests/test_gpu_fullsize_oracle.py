@@ -113,7 +113,14 @@ def test_loha_linear_fullsize(shape, dtype):
     errs = {"y": err(y, y_ref, dtype), "dx": err(grads[0], ref[0], dtype)}
     for n, gr, rf in zip(names[1:], grads[1:], ref[1:]):
         errs[n] = err(gr, rf)
-    check(f"loha_linear_full[{shape},{dtype}]", errs, _bounds(dtype, ["y", "dx"], names[1:], "loha_store"))
+    bounds = _bounds(dtype, ["y", "dx"], names[1:], "loha_store")
+    # the same quantities against the oracle evaluated WITH the reference's cast `get_weight(...).to(base_weight.dtype)`
+    # (modules/loha.py:310, oracle.loha round_dw): north-star bound 1e-3
+    y_cast = oracle.loha.forward(x64, a1, b1, a2, b2, 0.25, round_dw=str(dtype))
+    dx_cast = oracle.loha.backward(x64, g64, a1, b1, a2, b2, 0.25, round_dw=str(dtype))[0]
+    errs["y@cast"], errs["dx@cast"] = err(y, y_cast, dtype), err(grads[0], dx_cast, dtype)
+    bounds["y@cast"] = bounds["dx@cast"] = TOL["store_out"][dtype]
+    check(f"loha_linear_full[{shape},{dtype}]", errs, bounds)
 
 
 # ---- Conv2d at full size ------------------------------------------------------------------------------------------
@@ -172,11 +179,13 @@ def test_lokr_conv2d_fullsize(shape, dtype):
     check(f"lokr_conv_full[{shape},{dtype}]", errs, _bounds(dtype, ["y", "dx"], ["dw1", "dw2"]))
 
 
-@pytest.mark.parametrize("shape", CONV[:6] + [CONV[8], CONV[11]], ids=CIDS[:6] + [CIDS[8], CIDS[11]])
-def test_locon_conv2d_fullsize(shape):
+@DT16
+@pytest.mark.parametrize("shape", CONV, ids=CIDS)
+def test_locon_conv2d_fullsize(shape, dtype):
     from lycoris_amd import ops
     B, C, H, O, k, s = shape
-    dtype = torch.bfloat16
+    if dtype == torch.float16 and shape not in (CONV[0], CONV[1], CONV[2], CONV[3], CONV[4], CONV[8], CONV[11], CONV[16]):
+        pytest.skip("fp16: one shape per kernel plan")
     r = 16 if k == 1 else 8
     gen = torch.Generator().manual_seed(B + C + H + O + k + 1)
     x, x64 = rnd((B, C, H, H), dtype, gen)
@@ -193,14 +202,20 @@ def test_locon_conv2d_fullsize(shape):
     y_ref = oracle.locon.forward(x64, d64, u64, 1.0, ca)
     dx_ref, dd_ref, du_ref = oracle.locon.backward(x64, g64, d64, u64, 1.0, ca)
     errs = {"y": err(y, y_ref, dtype), "dx": err(dx, dx_ref, dtype), "d_down": err(dd, dd_ref), "d_up": err(du, du_ref)}
-    check(f"locon_conv_full[{shape}]", errs, _bounds(dtype, ["y", "dx"], ["d_down", "d_up"]))
+    check(f"locon_conv_full[{shape},{dtype}]", errs, _bounds(dtype, ["y", "dx"], ["d_down", "d_up"]))
 
 
-@pytest.mark.parametrize("shape", [CONV[1], CONV[2], CONV[4]], ids=[CIDS[1], CIDS[2], CIDS[4]])
-def test_loha_conv2d_fullsize(shape):
+_LOHA_CONV = [0, 1, 2, 3, 4, 5, 9, 13, 16]  # + (round 4) the 320-channel convs @128, 1x1 shortcut, SD1.5 bs 4, C != O, both strides
+
+
+@DT16
+@pytest.mark.parametrize("shape", [CONV[i] for i in _LOHA_CONV], ids=[CIDS[i] for i in _LOHA_CONV])
+def test_loha_conv2d_fullsize(shape, dtype):
     from lycoris_amd import ops
     B, C, H, O, k, s = shape
-    dtype, r = torch.bfloat16, 32
+    r = 32
+    if dtype == torch.float16 and shape not in (CONV[1], CONV[2], CONV[3], CONV[4]):
+        pytest.skip("fp16: one shape per lowering (3x3 s1, 3x3 s2, 1x1, batch 4)")
     gen = torch.Generator().manual_seed(B + C + H + O + k + 2)
     x, x64 = rnd((B, C, H, H), dtype, gen)
     Ho = (H + 2 * (k // 2) - k) // s + 1
@@ -222,7 +237,12 @@ def test_loha_conv2d_fullsize(shape):
     errs = {"y": err(y, y_ref, dtype), "dx": err(grads[0], ref[0], dtype)}
     for n, gr, rf in zip(names[1:], grads[1:], ref[1:]):
         errs[n] = err(gr, rf)
-    check(f"loha_conv_full[{shape}]", errs, _bounds(dtype, ["y", "dx"], names[1:], "loha_store"))
+    bounds = _bounds(dtype, ["y", "dx"], names[1:], "loha_store")
+    y_cast = oracle.loha.forward(x64, a1, b1, a2, b2, 0.25, (O, C, k, k), ca, round_dw=str(dtype))  # modules/loha.py:310
+    dx_cast = oracle.loha.backward(x64, g64, a1, b1, a2, b2, 0.25, (O, C, k, k), ca, round_dw=str(dtype))[0]
+    errs["y@cast"], errs["dx@cast"] = err(y, y_cast, dtype), err(grads[0], dx_cast, dtype)
+    bounds["y@cast"] = bounds["dx@cast"] = TOL["store_out"][dtype]
+    check(f"loha_conv_full[{shape},{dtype}]", errs, bounds)
 
 
 # ---- low-rank LoKr (BASELINE configs[3] "(low)": dim 16, and decompose_both) at full size -------------------------

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import oracle
-from gpu_util import TOL, check, err, rnd
+from gpu_util import TOL, check, err, rnd, loha_cast_pair
 
 pytestmark = pytest.mark.gpu
 DTYPES = [torch.float32, torch.bfloat16]
@@ -88,6 +88,7 @@ def test_loha_functional(dtype, conv):
     b = {"y": TOL["loha_store"][dtype], "dx": TOL["loha_store"][dtype]}
     for n, gr, rf in zip(["d_w1a", "d_w1b", "d_w2a", "d_w2b"], grads[1:], ref[1:]):
         errs[n], b[n] = err(gr, rf), TOL["f32_out"][dtype]
+    loha_cast_pair(errs, b, dtype, y, grads[0], x64, g64, (a1, b1, a2, b2), 0.5, shape, ca)
     check(f"loha_functional[{dtype},{conv}]", errs, b)
 
 

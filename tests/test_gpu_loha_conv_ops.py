@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import oracle
-from gpu_util import TOL, check, err, rnd
+from gpu_util import TOL, check, err, rnd, loha_cast_pair
 
 pytestmark = pytest.mark.gpu
 DTYPES = [torch.float32, torch.bfloat16, torch.float16]
@@ -42,6 +42,7 @@ def test_loha_linear(shape, dtype):
     for n, gr, rf in zip(names[1:], grads[1:], ref[1:]):
         errs[n] = err(gr, rf)
         bounds[n] = TOL["f32_out"][dtype]
+    loha_cast_pair(errs, bounds, dtype, y, grads[0], x64, g64, (a1, b1, a2, b2), alpha)
     check(f"loha_linear[{shape},{dtype}]", errs, bounds)
 
 
@@ -218,4 +219,5 @@ def test_loha_conv2d(shape, dtype):
     for n, gr, rf in zip(["d_w1a", "d_w1b", "d_w2a", "d_w2b"], grads[1:], ref[1:]):
         errs[n] = err(gr, rf)
         bounds[n] = TOL["f32_out"][dtype]
+    loha_cast_pair(errs, bounds, dtype, y, grads[0], x64, g64, (a1, b1, a2, b2), 0.5, wshape, _ca(s, p, d))
     check(f"loha_conv2d[{shape},{dtype}]", errs, bounds)

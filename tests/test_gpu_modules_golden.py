@@ -119,6 +119,22 @@ def test_module_16bit_activations_fp32_factors(name, dtype, golden_cases):
         f32 = 8e-3 if dtype == torch.bfloat16 else 2e-3
     errs = {"delta": err(delta, want_delta, dtype), "dx": err(grads[0], want["dx"], dtype)}
     bounds = {"delta": store, "dx": store}
+    if meta["algo"] == "loha" and not dora:
+        # the loose truth-relative bf16 bound paired with the north-star bound against the cast-restating oracle (loha.py:310)
+        cast_delta, cast = oracle_eval(meta, a, round_dw=str(dtype))
+        errs["delta@cast"], errs["dx@cast"] = err(delta, cast_delta, dtype), err(grads[0], cast["dx"], dtype)
+        bounds["delta@cast"] = bounds["dx@cast"] = 1e-3
+    if meta["algo"] == "ia3":  # (the adapter delta is bias-free on both sides: rebuild semantics)
+        # ... and (IA)^3 with the reference's bypass formulation + its storage roundings (modules/ia3.py:114-121)
+        import oracle
+        from golden_util import conv_args_of
+        on_in = bool(meta["mod"].get("train_on_input", False))
+        args = (a["W"], a["p.weight"], meta["multiplier"], on_in, conv_args_of(meta))
+        errs["delta@bypass"] = err(delta, oracle.ia3.bypass_forward(a["x"], *args, store=str(dtype))[0], dtype)
+        bdx, bdw = oracle.ia3.bypass_backward(a["x"], a["g"], *args, store=str(dtype))
+        errs["dx@bypass"] = err(grads[0], bdx, dtype)
+        errs["g.weight@bypass"] = err(grads[1 + [n for n, _ in params].index("weight")], bdw)
+        bounds["delta@bypass"] = bounds["dx@bypass"] = bounds["g.weight@bypass"] = 1e-3
     for (n, p), gr in zip(params, grads[1:]):
         assert gr.dtype == p.dtype == torch.float32
         if dora and n == "scalar":

@@ -68,3 +68,63 @@ def test_oracle_conv_against_torch_float64():
         assert oracle.general.rel_err(y, yt.detach().numpy()) < 1e-13
         assert oracle.general.rel_err(dx, dxt.numpy()) < 1e-13
         assert oracle.general.rel_err(dw, dwt.numpy()) < 1e-13
+
+
+# ---- storage-rounding restatements (round 4): pinned on the real reference run in 16 bits on the CPU --------------------------
+def _cast_cases():
+    blob = np.load(os.path.join(GOLDEN, "cast_cases.npz"))
+    with open(os.path.join(GOLDEN, "cast_cases.json")) as f:
+        metas = json.load(f)
+    return {n: (m, {k.split("/", 1)[1]: blob[k] for k in blob.files if k.startswith(n + "/")}) for n, m in metas.items()}
+
+
+CAST = _cast_cases()
+
+
+def test_round_to_is_torch_rounding():
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((257, 33)) * np.exp(rng.standard_normal((257, 33)) * 2)
+    for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16), ("f32", torch.float32)):
+        want = torch.from_numpy(a).float().to(dt).double().numpy()
+        assert np.array_equal(oracle.general.round_to(a, name), want), name
+        assert np.array_equal(oracle.general.round_to(a, str(dt)), want), name
+
+
+@pytest.mark.parametrize("name", sorted(n for n in CAST if n.startswith("loha_cast")))
+def test_loha_round_dw_is_the_reference_cast(name):
+    """oracle.loha.diff_weight(round_dw=...) against `get_weight(shape).to(base_weight.dtype)` of the reference module
+    (modules/loha.py:310): equal element for element except where the reference's fp32 rebuild sits within fp32 round-off of a
+    16-bit rounding boundary (the oracle rebuilds in float64)."""
+    meta, a = CAST[name]
+    dw = oracle.loha.diff_weight(a["p.hada_w1_a"], a["p.hada_w1_b"], a["p.hada_w2_a"], a["p.hada_w2_b"], meta["scale"],
+                                 tuple(meta["shape"]), round_dw=meta["dtype"])
+    assert dw.shape == a["dw"].shape
+    mism = np.mean(dw != a["dw"])
+    assert mism < 2e-3, (name, mism)
+    assert oracle.general.rel_err(dw, a["dw"]) < 2e-4, name
+    exact = oracle.loha.diff_weight(a["p.hada_w1_a"], a["p.hada_w1_b"], a["p.hada_w2_a"], a["p.hada_w2_b"], meta["scale"],
+                                    tuple(meta["shape"]))
+    e = oracle.general.rel_err(exact, a["dw"])  # the cast is what costs 2^-9 (bf16) / 2^-12 (fp16), not the restatement
+    assert (1e-3 < e < 3e-3) if meta["dtype"] == "bf16" else (1e-4 < e < 4e-4), (name, e)
+
+
+@pytest.mark.parametrize("name", sorted(n for n in CAST if n.startswith("ia3_bypass")))
+def test_ia3_bypass_restatement_matches_reference_16bit(name):
+    """oracle.ia3.bypass_forward / bypass_backward(store=...) against the reference's IA3Module.bypass_forward_diff run in 16 bits
+    (modules/ia3.py:114-125).  Bounds: rounding-boundary flips of the 16-bit intermediates (the CPU GEMM accumulates in another
+    order than numpy's float64) -- an order of magnitude below what dropping a rounding would cost."""
+    meta, a = CAST[name]
+    st, on_in = meta["dtype"], meta["on_input"]
+    delta, _ = oracle.ia3.bypass_forward(a["x"], a["W"], a["w"], 1.0, on_in, None, store=st)
+    dx, dw = oracle.ia3.bypass_backward(a["x"], a["g"], a["W"], a["w"], 1.0, on_in, None, store=st)
+    r = lambda v, dts: oracle.general.round_to(v, dts) if "float32" not in dts else v
+    u = 2.0 ** -8 if st == "bf16" else 2.0 ** -11
+    assert oracle.general.rel_err(r(delta, meta["delta_dtype"]), a["delta"]) < 0.2 * u, name
+    assert oracle.general.rel_err(r(dx, meta["dx_dtype"]), a["dx"]) < 0.2 * u, name
+    assert oracle.general.rel_err(dw, a["dw"]) < 0.2 * u, name
+    # without the storage roundings the restatement is the rebuild-path oracle (same function of the inputs)
+    d0, _ = oracle.ia3.bypass_forward(a["x"], a["W"], a["w"], 1.0, on_in)
+    assert oracle.general.rel_err(d0, oracle.ia3.forward(a["x"], a["W"], a["w"], 1.0, on_in)) < 1e-13
+    dx0, dw0 = oracle.ia3.bypass_backward(a["x"], a["g"], a["W"], a["w"], 1.0, on_in)
+    tx, tw = oracle.ia3.backward(a["x"], a["g"], a["W"], a["w"], 1.0, on_in)
+    assert oracle.general.rel_err(dx0, tx) < 1e-13 and oracle.general.rel_err(dw0, tw) < 1e-12
