@@ -1,0 +1,298 @@
+// k4bench.cpp -- kron3 (round 1-3 kernel, packed planes) vs kron4 (round 4) on the SDXL / SD1.5 LoKr Linear shapes: the same
+// launch is checked BIT FOR BIT against kron3 (same MFMA accumulation order) and timed inside a hipGraph over rotating
+// buffer sets (footprint > the 256 MiB Infinity Cache, so x / y stream from / to HBM as they do in a training step).
+//   benchmarks/k4bench [filter] [--trace]      (make -C lycoris_amd/csrc k4bench)
+// Development tool: parity proper is tests/ (oracle), this only guards kernel-vs-kernel equality while tiles are tuned.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../lycoris_amd/csrc/kron4.h"
+#include "../lycoris_amd/csrc/kron_conv.h"
+
+using namespace lyc;
+#define CK(x)                                                                                 \
+  do {                                                                                        \
+    hipError_t e_ = (x);                                                                      \
+    if (e_ != hipSuccess) {                                                                   \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));    \
+      exit(1);                                                                                \
+    }                                                                                         \
+  } while (0)
+
+__global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed, float scale) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    unsigned h = (unsigned)(i * 2654435761u) ^ seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    const float v = ((h & 0xffff) / 65536.0f - 0.5f) * 2.0f * scale;
+    unsigned u = __float_as_uint(v);
+    p[i] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  }
+}
+__global__ void fill_f32(float* p, size_t n, unsigned seed, float scale) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    unsigned h = (unsigned)(i * 2654435761u) ^ seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    p[i] = ((h & 0xffff) / 65536.0f - 0.5f) * 2.0f * scale;
+  }
+}
+__global__ void empty_kernel(int* p) {
+  if (p && threadIdx.x == 9999) *p = 1;
+}
+
+struct Shape {
+  const char* tag;
+  long M;
+  int I, O;
+};
+static const Shape SHAPES[] = {
+    {"attn1280", 1024, 1280, 1280}, {"ffup1280", 1024, 1280, 10240}, {"ffdn1280", 1024, 5120, 1280},
+    {"attn640", 4096, 640, 640},    {"ffup640", 4096, 640, 5120},    {"ffdn640", 4096, 2560, 640},
+    {"xattn1280", 77, 2048, 1280},  {"xattn640", 77, 2048, 640},     {"sd15_320", 16384, 320, 320},
+    {"temb", 1, 1280, 1280},
+};
+
+struct Set {
+  void *x, *g, *y, *dx, *base;
+  float* ws;
+};
+
+typedef void (*K4Fn)(Kron4Args);
+struct Variant {
+  const char* name;
+  int MI, NI, D;
+  K4Fn fn[3];  // per EPI
+};
+#define V(MI, NI, D)                                                                                          \
+  {"k4 " #MI "x" #NI " D" #D, MI, NI, D,                                                                     \
+   {kron4_kernel<__bf16, MI, NI, D, 0>, kron4_kernel<__bf16, MI, NI, D, 1>, kron4_kernel<__bf16, MI, NI, D, 2>}}
+static Variant VARIANTS[] = {V(2, 2, 3), V(1, 2, 3), V(2, 4, 3), V(2, 5, 3), V(2, 2, 2), V(1, 2, 2), V(2, 4, 2), V(2, 5, 2), V(2, 8, 2), V(4, 4, 2), V(4, 2, 2), V(4, 4, 3), V(4, 8, 2), V(1, 5, 2), V(1, 4, 2)};
+
+static bool g_eager = false;
+
+template <typename F>
+static float bench(hipStream_t st, int nlaunch, int reps, F&& fn) {
+  for (int i = 0; i < 2; ++i) fn(i);
+  CK(hipStreamSynchronize(st));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  if (g_eager) {
+    for (int r = 0; r < reps; ++r) {
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < nlaunch; ++i) fn(i);
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms = 0.f;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (ms < best) best = ms;
+    }
+    return best * 1e3f / nlaunch;
+  }
+  hipGraph_t g;
+  hipGraphExec_t ge;
+  CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  for (int i = 0; i < nlaunch; ++i) fn(i);
+  CK(hipStreamEndCapture(st, &g));
+  CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  CK(hipGraphLaunch(ge, st));
+  CK(hipStreamSynchronize(st));
+  for (int r = 0; r < reps; ++r) {
+    CK(hipEventRecord(e0, st));
+    CK(hipGraphLaunch(ge, st));
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  CK(hipGraphExecDestroy(ge));
+  CK(hipGraphDestroy(g));
+  return best * 1e3f / nlaunch;
+}
+
+static long cdivl(long a, long b) { return (a + b - 1) / b; }
+
+int main(int argc, char** argv) {
+  const char* filter = nullptr;
+  bool trace = false;
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--trace")) trace = true;
+    else if (!strcmp(argv[i], "--eager")) g_eager = true;
+    else filter = argv[i];
+  }
+  (void)trace;
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  const int G = 8;
+  {  // launch floor of this box
+    float us = bench(st, 200, 5, [&](int) { hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, st, nullptr); });
+    printf("# empty 256-workgroup launch inside a graph: %.2f us\n", us);
+  }
+  for (const Shape& s : SHAPES) {
+    if (filter && !strstr(s.tag, filter)) continue;
+    const long M = s.M;
+    const int I = s.I, O = s.O, c = O / G, d = I / G;
+    const size_t xb = (size_t)M * I * 2, yb = (size_t)M * O * 2;
+    int nsets = (int)((600u << 20) / (xb + yb)) + 1;
+    if (nsets > 64) nsets = 64;
+    if (nsets < 2) nsets = 2;
+    std::vector<Set> sets(nsets);
+    for (int i = 0; i < nsets; ++i) {
+      Set& z = sets[i];
+      CK(hipMalloc(&z.x, xb + 256)); CK(hipMalloc(&z.g, yb + 256)); CK(hipMalloc(&z.y, yb + 256)); CK(hipMalloc(&z.dx, xb + 256));
+      CK(hipMalloc(&z.base, yb + 256)); CK(hipMalloc(&z.ws, 4 << 20));
+      hipLaunchKernelGGL(fill_bf16, dim3(1024), dim3(256), 0, st, (unsigned short*)z.x, xb / 2, 11u + i, 1.0f);
+      hipLaunchKernelGGL(fill_bf16, dim3(1024), dim3(256), 0, st, (unsigned short*)z.g, yb / 2, 77u + i, 0.05f);
+      hipLaunchKernelGGL(fill_bf16, dim3(1024), dim3(256), 0, st, (unsigned short*)z.base, yb / 2, 99u + i, 1.0f);
+    }
+    float *w1, *w2;
+    CK(hipMalloc(&w1, 256)); CK(hipMalloc(&w2, (size_t)c * d * 4));
+    hipLaunchKernelGGL(fill_f32, dim3(1), dim3(64), 0, st, w1, (size_t)64, 5u, 0.3f);
+    hipLaunchKernelGGL(fill_f32, dim3(256), dim3(256), 0, st, w2, (size_t)c * d, 6u, 0.05f);
+    const long nf = kron_plane_bytes(c, 1, d), nb = kron_plane_bytes(d, 1, c);
+    char* planes;
+    CK(hipMalloc(&planes, nf + nb));
+    {
+      KronPackArgs pa{};
+      pa.w2 = w2; pa.sq = d; pa.sv = 1; pa.st = 0; pa.c = c; pa.d = d; pa.taps = 1; pa.fwd = planes; pa.bwd = planes + nf;
+      pa.units_fwd = nf / 2048;
+      hipLaunchKernelGGL((kron_pack_kernel<__bf16>), dim3((unsigned)cdivl((nf + nb) / 2048, NWAVES)), dim3(NTHREADS), 0, st, pa);
+    }
+    CK(hipStreamSynchronize(st));
+    void *yref, *yout;
+    const size_t big = xb > yb ? xb : yb;
+    CK(hipMalloc(&yref, big + 256)); CK(hipMalloc(&yout, big + 256));
+    std::vector<unsigned short> h_ref(big / 2), h_out(big / 2);
+    std::vector<float> h_ws(1 << 20);
+
+    for (int mode = 0; mode < 3; ++mode) {  // 0 fwd, 1 fwd + base, 2 bwd (dx + dW1 partials)
+      const bool bw = mode == 2;
+      const int K = bw ? c : d, N = bw ? d : c;
+      const size_t outb = bw ? xb : yb;
+      const double bytes = (double)xb + yb + (mode ? (double)outb : 0.0);  // algorithmic: read in, write out (+ base / xref)
+      auto k3args = [&](const Set& z, void* out) {
+        KronArgs ka{};
+        if (!bw) { ka.x = z.x; ka.y = out; ka.w1 = w1; ka.w2 = w2; ka.w2p = planes; ka.s1o = G; ka.s1i = 1; ka.s2n = d; ka.s2k = 1;
+                   ka.base = mode == 1 ? z.base : nullptr; }
+        else { ka.x = z.g; ka.y = out; ka.w1 = w1; ka.w2 = w2; ka.w2p = planes + nf; ka.dw1 = (float*)1; ka.dw1_ws = z.ws; ka.xref = z.x;
+               ka.s1o = 1; ka.s1i = G; ka.s2n = 1; ka.s2k = d; }
+        ka.M = M; ka.Gin = G; ka.K = K; ka.Gout = G; ka.N = N; ka.alpha = 0.5f;
+        return ka;
+      };
+      const long mt = cdivl(M, K3_RT / G);
+      const int ni3 = (mt * cdivl(N, 64) >= 384 && N > 32) ? 4 : 2;
+      dim3 g3((unsigned)mt, (unsigned)cdivl(N, 16 * ni3));
+      const int gm = (K % 32 == 0) ? 3 : 0;
+      const int lds3 = kron3_lds_bytes(ni3, cdivl(K, kron3_kc(ni3)) > 1 ? 2 : 1) + (gm == 3 ? kron3_xs_bytes() : 0);
+      auto launch3 = [&](const KronArgs& ka) {
+#define L3(NI_, DW1_, GM_, BASE_) hipLaunchKernelGGL((kron3_kernel<__bf16, NI_, DW1_, GM_, BASE_, true>), g3, dim3(NTHREADS), lds3, st, ka)
+        if (ni3 == 4) {
+          if (gm == 3) { if (bw) L3(4, true, 3, false); else if (mode == 1) L3(4, false, 3, true); else L3(4, false, 3, false); }
+          else { if (bw) L3(4, true, 0, false); else if (mode == 1) L3(4, false, 0, true); else L3(4, false, 0, false); }
+        } else {
+          if (gm == 3) { if (bw) L3(2, true, 3, false); else if (mode == 1) L3(2, false, 3, true); else L3(2, false, 3, false); }
+          else { if (bw) L3(2, true, 0, false); else if (mode == 1) L3(2, false, 0, true); else L3(2, false, 0, false); }
+        }
+      };
+      static bool attr_done = false;
+      if (!attr_done) {
+        attr_done = true;
+#define A3(NI_, DW1_, GM_, BASE_) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&kron3_kernel<__bf16, NI_, DW1_, GM_, BASE_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+        A3(4, true, 3, false); A3(4, false, 3, true); A3(4, false, 3, false); A3(4, true, 0, false); A3(4, false, 0, true); A3(4, false, 0, false);
+        A3(2, true, 3, false); A3(2, false, 3, true); A3(2, false, 3, false); A3(2, true, 0, false); A3(2, false, 0, true); A3(2, false, 0, false);
+        for (Variant& v : VARIANTS)
+          for (int e = 0; e < 3; ++e)
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn[e]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      }
+      // reference result (kron3, set 0)
+      CK(hipMemsetAsync(yref, 0xff, outb, st));
+      CK(hipMemsetAsync(sets[0].ws, 0, 4 << 20, st));
+      launch3(k3args(sets[0], yref));
+      CK(hipStreamSynchronize(st));
+      CK(hipGetLastError());
+      CK(hipMemcpy(h_ref.data(), yref, outb, hipMemcpyDeviceToHost));
+      double dw1_ref[64] = {0};
+      if (bw) {
+        const long nblk = (long)g3.x * g3.y;
+        CK(hipMemcpy(h_ws.data(), sets[0].ws, nblk * 64 * 4, hipMemcpyDeviceToHost));
+        for (long b = 0; b < nblk; ++b)
+          for (int e = 0; e < 64; ++e) dw1_ref[e] += h_ws[b * 64 + e];
+      }
+      const int nl = bytes > 3e7 ? 40 : 100;
+      float t3 = bench(st, nl, 5, [&](int i) { const Set& z = sets[i % nsets]; launch3(k3args(z, bw ? z.dx : z.y)); });
+      printf("%-10s M=%-5ld %4d->%-5d %-4s | kron3 NI=%d  %7.2f us %7.1f GB/s %.3f\n", s.tag, M, I, O,
+             mode == 0 ? "fwd" : mode == 1 ? "fwdB" : "bwd", ni3, t3, bytes / t3 * 1e-3, bytes / t3 * 1e-3 / 8000.0);
+
+      for (const Variant& v : VARIANTS) {
+        const int lds = kron4_lds_bytes(v.MI, v.NI, v.D);
+        if (lds > 160 * 1024) continue;
+        if (N < 16 * v.NI && v.NI > 2) continue;
+        dim3 g4((unsigned)cdivl(M * G, 64 * v.MI), (unsigned)cdivl(N, 16 * v.NI));
+        auto k4args = [&](const Set& z, void* out) {
+          Kron4Args a{};
+          a.x = bw ? z.g : z.x; a.y = out; a.planes = bw ? planes + nf : planes; a.w1 = w1;
+          a.aux = mode == 1 ? z.base : (bw ? z.x : nullptr); a.dw1_ws = z.ws;
+          a.x_bytes = (unsigned)(M * G * K * 2); a.y_bytes = (unsigned)(M * G * N * 2); a.plane_bytes = (unsigned)(bw ? nb : nf);
+          a.rows_total = (int)(M * G); a.K = K; a.N = N; a.KS = (K + 31) / 32; a.lg = 3;
+          a.s1o = bw ? 1 : G; a.s1i = bw ? G : 1; a.alpha = 0.5f;
+          return a;
+        };
+        CK(hipMemsetAsync(yout, 0xff, outb, st));
+        CK(hipMemsetAsync(sets[0].ws, 0, 4 << 20, st));
+        hipLaunchKernelGGL(v.fn[mode], g4, dim3(NTHREADS), lds, st, k4args(sets[0], yout));
+        CK(hipStreamSynchronize(st));
+        CK(hipGetLastError());
+        CK(hipMemcpy(h_out.data(), yout, outb, hipMemcpyDeviceToHost));
+        size_t mism = 0;
+        for (size_t i = 0; i < outb / 2; ++i) mism += h_out[i] != h_ref[i];
+        double dw1_err = 0;
+        if (bw) {
+          const long nblk = (long)g4.x * g4.y;
+          CK(hipMemcpy(h_ws.data(), sets[0].ws, nblk * 64 * 4, hipMemcpyDeviceToHost));
+          double sum[64] = {0}, nrm = 0;
+          for (long b = 0; b < nblk; ++b)
+            for (int e = 0; e < 64; ++e) sum[e] += h_ws[b * 64 + e];
+          for (int e = 0; e < 64; ++e) { dw1_err += (sum[e] - dw1_ref[e]) * (sum[e] - dw1_ref[e]); nrm += dw1_ref[e] * dw1_ref[e]; }
+          dw1_err = nrm > 0 ? sqrt(dw1_err / nrm) : sqrt(dw1_err);
+        }
+#ifdef LYC_TRACE
+        {  // phase stamps of workgroup LYC_TRACE_BLOCK under a full grid, cold inputs (another buffer set)
+          unsigned long long z[32] = {0}, h[32];
+          for (int rep = 0; rep < 2; ++rep) {
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(lyc_trace_buf), z, sizeof(z)));
+            hipLaunchKernelGGL(v.fn[mode], g4, dim3(NTHREADS), lds, st, k4args(sets[(rep + 1) % nsets], yout));
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(lyc_trace_buf), sizeof(h)));
+            printf("      trace rep %d:", rep);
+            for (int i = 0; i < 32; ++i) if (h[i]) printf(" [%d]+%llu", i, h[i] - h[0]);
+            printf("\n");
+          }
+        }
+#endif
+        float t4 = bench(st, nl, 5, [&](int i) {
+          const Set& z = sets[i % nsets];
+          hipLaunchKernelGGL(v.fn[mode], g4, dim3(NTHREADS), lds, st, k4args(z, bw ? z.dx : z.y));
+        });
+        printf("   %-12s grid %4ux%-3u lds %3dK | %7.2f us %7.1f GB/s %.3f  x%.2f  mism %zu%s", v.name, g4.x, g4.y, lds >> 10, t4,
+               bytes / t4 * 1e-3, bytes / t4 * 1e-3 / 8000.0, t3 / t4, mism, mism ? " <<<<" : "");
+        if (bw) printf("  dw1 relerr %.2e", dw1_err);
+        printf("\n");
+      }
+    }
+    for (Set& z : sets) {
+      CK(hipFree(z.x)); CK(hipFree(z.g)); CK(hipFree(z.y)); CK(hipFree(z.dx)); CK(hipFree(z.base)); CK(hipFree(z.ws));
+    }
+    CK(hipFree(w1)); CK(hipFree(w2)); CK(hipFree(planes)); CK(hipFree(yref)); CK(hipFree(yout));
+  }
+  return 0;
+}

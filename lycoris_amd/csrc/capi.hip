@@ -11,6 +11,7 @@
 #include "dense_kernels.h"
 #include "ia3_kernels.h"
 #include "kron3.h"
+#include "kron4.h"
 #include "kron_dw2s.h"
 #include "kron_conv.h"
 #include "kron_conv_dw2.h"
@@ -108,6 +109,89 @@ inline int kron3_pick_ni(const KronArgs& ka) {
   return (mt * cdiv(ka.N, 64) >= 384 && ka.N > 32) ? 4 : 2;
 }
 
+// ---- kron4 (round 4): nn.Linear rows on packed planes -------------------------------------------------------------------------
+// Tile plan from the measured shape sweep (benchmarks/k4bench.cpp, profiles/r04_k4bench*.log): the widest column tile whose grid
+// still has >= 256 workgroups (N % 80 == 0 -> five 16-column tiles: one or two column blocks for the 640- / 1280-wide layers, x
+// re-read 1-2x instead of 3-5x), otherwise the latency plan 64 rows x 32 columns; ring depth 2 when the whole K fits five k steps.
+struct Kron4Plan {
+  int MI, NI, D;
+};
+inline Kron4Plan kron4_plan(long rows, int K, int N) {
+  const int KS = (K + 31) / 32;
+  int ni = (N % 80 == 0) ? 5 : ((N % 64 == 0) ? 4 : 2);
+  if (ni > 2 && cdiv(rows, 128) * cdiv(N, 16 * ni) < 256) ni = 2;
+  if (ni == 5) return {2, 5, KS <= 5 ? 2 : 3};
+  if (ni == 4) return {2, 4, 3};
+  if (cdiv(rows, 128) * cdiv(N, 32) >= 1024) return {2, 2, 2};  // many short rows (SD1.5 320-wide layers at batch 4)
+  return {1, 2, 3};
+}
+inline bool kron4_dims_ok(long M, int G, int K, int N) {
+  return G >= 1 && (16 % G) == 0 && (K % 8) == 0 && (N % 8) == 0 && M > 0 && M * G * (long)K * 2 < (1L << 31) &&
+         M * G * (long)N * 2 < (1L << 31) && kron_plane_bytes(N, 1, K) < (1L << 31);
+}
+inline long kron4_blocks(long M, int G, int K, int N) {
+  const Kron4Plan p = kron4_plan(M * G, K, N);
+  return cdiv(M * G, 64 * p.MI) * cdiv(N, 16 * p.NI);
+}
+template <typename T>
+bool kron4_ok(const KronArgs& ka) {
+  if constexpr (sizeof(T) != 2) {
+    return false;
+  } else {
+    return ka.w2p != nullptr && !ka.gat.mode && !ka.out_f32 && ka.Gin == ka.Gout && kron4_dims_ok(ka.M, ka.Gin, ka.K, ka.N) &&
+           (reinterpret_cast<uintptr_t>(ka.x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(ka.y) & 7u) == 0 &&
+           (!ka.base || (reinterpret_cast<uintptr_t>(ka.base) & 7u) == 0) && (!ka.xref || (reinterpret_cast<uintptr_t>(ka.xref) & 7u) == 0) &&
+           (ka.dw1 == nullptr || ka.dw1_ws != nullptr);  // the w1 gradient leaves as per-workgroup partials only
+  }
+}
+template <typename T, int MI, int NI, int D>
+void launch_kron4_inst(const Kron4Args& a, int epi, dim3 grid, hipStream_t st) {
+  constexpr int lds = kron4_lds_bytes(MI, NI, D);
+  static_assert(lds <= 160 * 1024, "LDS");
+  auto go = [&](auto kern) {
+    if (lds > 64 * 1024) {  // more than the default dynamic-LDS window: opt in once per instantiation
+      static const hipError_t once =
+          hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)once;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, a);
+  };
+  if (epi == 0) go(kron4_kernel<T, MI, NI, D, 0>);
+  else if (epi == 1) go(kron4_kernel<T, MI, NI, D, 1>);
+  else go(kron4_kernel<T, MI, NI, D, 2>);
+}
+// returns the number of dw1 partial blocks the consumer has to sum (0: no w1 gradient requested)
+template <typename T>
+long launch_kron4(const KronArgs& ka, long dw1_blocks_total, hipStream_t st) {
+  const int G = ka.Gin;
+  const long rows = ka.M * G;
+  const Kron4Plan p = kron4_plan(rows, ka.K, ka.N);
+  Kron4Args a{};
+  a.x = ka.x; a.y = ka.y; a.planes = ka.w2p; a.w1 = ka.w1;
+  const int epi = ka.dw1 ? 2 : (ka.base ? 1 : 0);
+  a.aux = epi == 2 ? ka.xref : ka.base;
+  a.dw1_ws = ka.dw1_ws;
+  a.x_bytes = (unsigned)(rows * ka.K * 2); a.y_bytes = (unsigned)(rows * ka.N * 2);
+  a.plane_bytes = (unsigned)kron_plane_bytes(ka.N, 1, ka.K);
+  a.rows_total = (int)rows; a.K = ka.K; a.N = ka.N; a.KS = (ka.K + 31) / 32;
+  a.lg = 31 - __builtin_clz((unsigned)G);
+  a.s1o = (int)ka.s1o; a.s1i = (int)ka.s1i; a.alpha = ka.alpha;
+  dim3 grid((unsigned)cdiv(rows, 64 * p.MI), (unsigned)cdiv(ka.N, 16 * p.NI));
+  const long nwg = (long)grid.x * grid.y;
+  a.dw1_blocks = (int)(dw1_blocks_total > nwg ? dw1_blocks_total : nwg);
+  if (p.NI == 5) {
+    if (p.D == 2) launch_kron4_inst<T, 2, 5, 2>(a, epi, grid, st);
+    else launch_kron4_inst<T, 2, 5, 3>(a, epi, grid, st);
+  } else if (p.NI == 4) {
+    launch_kron4_inst<T, 2, 4, 3>(a, epi, grid, st);
+  } else if (p.MI == 2) {
+    launch_kron4_inst<T, 2, 2, 2>(a, epi, grid, st);
+  } else {
+    launch_kron4_inst<T, 1, 2, 3>(a, epi, grid, st);
+  }
+  return epi == 2 ? (long)a.dw1_blocks : 0;
+}
+
 // returns the number of workgroups (= number of dw1 partials when ka.dw1_ws is set)
 template <typename T>
 long launch_kron3(const KronArgs& ka, hipStream_t st) {
@@ -123,10 +207,34 @@ long launch_kron3(const KronArgs& ka, hipStream_t st) {
   return (long)grid.x * grid.y;
 }
 
+// Number of [a * b] dw1 partial blocks the dx launch of a 16-bit fast-path layer leaves in its workspace.  The consumer
+// (lyc_lokr_wgrad_group, the dW2 launch's reducer slice) knows only the layer's dimensions, not which kernel produced the
+// partials, so the count is a function of the dimensions alone: the larger of the two kernels' grids; the producer fills the
+// surplus blocks with zeros (kron4: in the kernel; kron3 on kron4-shaped dims: a memset behind the launch).
+inline long lokr_dx_partial_blocks(long M, int G, int K, int N) {
+  KronArgs ka{};
+  ka.M = M; ka.Gin = G; ka.K = K; ka.Gout = G; ka.N = N;
+  const long p3 = cdiv(M, K3_RT / G) * cdiv(N, 16 * kron3_pick_ni(ka));
+  if (!kron4_dims_ok(M, G, K, N)) return p3;
+  const long p4 = kron4_blocks(M, G, K, N);
+  return p3 > p4 ? p3 : p4;
+}
+
 template <typename T>
 long launch_kron(KronArgs ka, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
-    if (kron_fast_ok<T>(ka)) return launch_kron3<T>(ka, st);
+    if (kron4_ok<T>(ka)) return launch_kron4<T>(ka, ka.dw1 ? lokr_dx_partial_blocks(ka.M, ka.Gin, ka.K, ka.N) : 0, st);
+    if (kron_fast_ok<T>(ka)) {
+      const long p3 = launch_kron3<T>(ka, st);
+      if (ka.dw1 && ka.dw1_ws && !ka.gat.mode) {  // plain rows: the consumer sums the canonical number of blocks
+        const long pc = lokr_dx_partial_blocks(ka.M, ka.Gin, ka.K, ka.N);
+        if (pc > p3) {
+          (void)hipMemsetAsync(ka.dw1_ws + p3 * ka.Gin * ka.Gout, 0, (size_t)(pc - p3) * ka.Gin * ka.Gout * sizeof(float), st);
+          return pc;
+        }
+      }
+      return p3;
+    }
   }
   ka.dw1_ws = nullptr;  // the generic kernel accumulates dw1 with atomics
   const int TM = KronCfg<T>::RT / ka.Gin;
@@ -653,8 +761,10 @@ int lokr_linear_fwd_impl(const void* x, const float* w1, const float* w2, const 
 int64_t lyc_lokr_bwd_workspace_bytes(int64_t M, int a, int b, int c, int d, int dtype) {
   (void)c; (void)dtype;
   if (M <= 0 || a < 1 || b < 1 || d < 1 || a != b || a > 16) return 0;  // only the 16-bit fast path uses the scratch
-  // one G x G fp32 partial per workgroup of the dx launch, whose narrowest tiling is 128 rows x 32 columns
-  return (int64_t)cdiv(M, K3_RT / a) * cdiv(d, 32) * a * b * (int64_t)sizeof(float);
+  // one G x G fp32 partial per workgroup of the dx launch: kron3's narrowest tiling is 128 rows x 32 columns, kron4's 64 x 32
+  const int64_t k3 = (int64_t)cdiv(M, K3_RT / a) * cdiv(d, 32);
+  const int64_t k4 = (16 % a) == 0 ? (int64_t)cdiv(M * a, 64) * cdiv(d, 32) : 0;
+  return (k3 > k4 ? k3 : k4) * a * b * (int64_t)sizeof(float);
 }
 
 int lyc_lokr_linear_bwd(const void* g, const void* x, const float* w1, const float* w2, void* dx, float* dw1,
@@ -806,9 +916,8 @@ int lyc_lokr_wgrad_group(const LycLokrWgradItem* items, int n, int dtype, void* 
       if (it.dw1) {  // partials of the dx launch: one [a*b] block per workgroup of launch_kron3's grid
         KronArgs ka{};
         ka.M = it.M; ka.Gin = it.a; ka.K = it.c; ka.Gout = it.b; ka.N = it.d;
-        const int ni = kron3_pick_ni(ka);
         da.dw1_ws = static_cast<const float*>(it.ws); da.dw1 = it.dw1; da.dw1_n = it.a * it.b;
-        da.dw1_nblk = (int)(cdiv(it.M, K3_RT / it.a) * cdiv(it.d, 16 * ni));
+        da.dw1_nblk = (int)lokr_dx_partial_blocks(it.M, it.a, it.c, it.d);
         da.dw1_red = 1;
       }
       if (plan_dw2s(da, batch) != cfg) continue;

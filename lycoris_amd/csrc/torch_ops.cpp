@@ -94,6 +94,11 @@ struct Accum {
   // leaves a stale count: the report is then skipped, AdapterGradSync.finish() launches such buckets, and
   // reset_use_counts() (called by AdapterGradSync.zero_grad() / finish()) clears the map once per step.
   std::unordered_map<const void*, int> uses;
+  // autograd runs a leaf's AccumulateGrad node -- and with it the tensor's post-accumulate-grad hooks -- even when the backward
+  // node handed it an UNDEFINED gradient (torch >= 2.x: the hook of AdapterGradSync fires for every parameter of a
+  // loss.backward()).  A parameter the kernels report through notify() must not be counted a second time by that hook:
+  // `done_task` remembers the graph task (backward pass) in which a parameter was reported, fused_reports() tells the hook.
+  std::unordered_map<const void*, int> done_task;
 } g_accum;
 
 // torch::autograd::Function::apply runs forward() with grad mode OFF: whether a backward node is being built is only visible to
@@ -129,9 +134,24 @@ void notify(const Tensor& param) {
       if (--it->second > 0) return;  // another layer call of this pass still has to accumulate into the same .grad
       g_accum.uses.erase(it);
     }
+    g_accum.done_task[param.unsafeGetTensorImpl()] = torch::autograd::get_current_graph_task_id();
   }
   py::gil_scoped_acquire gil;
   if (!g_accum.callback->is_none()) (*g_accum.callback)(param);
+}
+
+// for the autograd hook of the same owner: true when the kernels report (or have reported, in the running backward pass) this
+// parameter themselves -- its AccumulateGrad ran on an undefined gradient and must not be counted
+bool fused_reports(const Tensor& param) {
+  if (!param.defined() || !g_accum.enabled || !g_accum.has_callback) return false;
+  std::lock_guard<std::mutex> lk(g_accum.mu);
+  const void* key = param.unsafeGetTensorImpl();
+  auto u = g_accum.uses.find(key);
+  if (u != g_accum.uses.end() && u->second > 0) return true;  // parked / still to run: the report comes later in this pass
+  auto d = g_accum.done_task.find(key);
+  if (d == g_accum.done_task.end()) return false;
+  const int task = torch::autograd::get_current_graph_task_id();
+  return task >= 0 && d->second == task;
 }
 
 // the same for a batch of parameters (the end-of-backward flush of the parked layers): ONE call into Python with the list of those
@@ -153,6 +173,7 @@ void notify_many(const std::vector<Tensor>& params) {
         if (--it->second > 0) continue;
         g_accum.uses.erase(it);
       }
+      g_accum.done_task[p.unsafeGetTensorImpl()] = torch::autograd::get_current_graph_task_id();
       done.push_back(p);
     }
   }
@@ -481,6 +502,7 @@ struct PlaneEntry {
   c10::weak_intrusive_ptr<c10::TensorImpl> owner;
   Tensor planes[2];          // [bf16, f16]: fwd role bytes, then bwd role bytes
   int64_t version[2] = {-1, -1};
+  int64_t epoch[2] = {-1, -1};  // PlaneCache::epoch the planes were packed in
   int c = 0, d = 0, taps = 0;
   int64_t sq = 0, sv = 0, st = 0;
   const float* w2 = nullptr;
@@ -498,7 +520,34 @@ struct PlaneCache {
   std::mutex mu;
   std::unordered_map<const void*, PlaneEntry> map;
   std::atomic<bool> enabled{true};
+  // the autograd version counter does not see writes through `p.data` (Prodigy, DAdaptation, 8-bit optimizers
+  // with raw kernels, master-weight copies `p.data.copy_(master)`).  So a STEP BOUNDARY makes every entry stale as well: `epoch`
+  // moves when `dirty` is found set by a forward-role lookup; `dirty` is set at the end of every backward pass that ran one of
+  // the adapter ops (engine final callback) and by the global optimizer-step post hook (ops.py).  The first layer call of the
+  // next forward pass then repacks every cached factor in one grouped launch -- what the version check already did for
+  // optimizers that bump the counter.  Forward recomputation inside a backward pass (activation checkpointing) sees `dirty`
+  // unset until that pass has ended.
+  std::atomic<bool> dirty{false};
+  int64_t epoch = 0;
+  int queued_task = -1;  // graph task whose end-of-backward "dirty" callback is already queued
 } g_planes;
+
+// called from the backward nodes of the LoKr ops: ONE final callback per backward pass marks the planes dirty
+void planes_mark_dirty_after_backward() {
+  if (!g_planes.enabled) return;
+  const int task = torch::autograd::get_current_graph_task_id();
+  if (task < 0) return;
+  {
+    std::lock_guard<std::mutex> lk(g_planes.mu);
+    if (g_planes.queued_task == task) return;
+    g_planes.queued_task = task;
+  }
+  torch::autograd::Engine::get_default_engine().queue_callback([]() { g_planes.dirty = true; });
+}
+// forward-role lookups: a step boundary has passed -> new epoch (caller holds g_planes.mu)
+void planes_new_epoch_if_dirty_locked(bool fwd_role) {
+  if (fwd_role && g_planes.dirty.exchange(false)) ++g_planes.epoch;
+}
 
 // must hold g_planes.mu.  Repacks every entry of `device` whose parameter changed (or all with `force`), one grouped launch per
 // 28 factors and dtype, on `stream`.
@@ -515,17 +564,29 @@ void refresh_planes_locked(c10::DeviceIndex device, void* stream, bool force) {
         continue;
       }
       int64_t vb = -1;
+      // the entry holds RAW pointers into the parameter's storage; `module.to(...)`, a `.data =` swap or
+      // CPU offload may have replaced / freed it since this entry was last validated by its own layer call.  Check the live
+      // owner before packing from the cached pointer; a mismatch drops the entry (the layer's next call starts over).
+      auto live = [&](const c10::intrusive_ptr<c10::TensorImpl>& t, const void* cached) {
+        return t->device_type() == c10::DeviceType::CUDA && t->device().index() == e.device && t->has_storage() &&
+               t->dtype() == caffe2::TypeMeta::Make<float>() && t->data() == cached;
+      };
+      bool ok = true;
       if (e.rank > 0) {
         auto ob = e.owner_b.lock();
-        if (!ob) {
-          it = g_planes.map.erase(it);
-          continue;
-        }
-        vb = (int64_t)ob->version_counter().current_version();
+        if (!ob || !live(ob, e.w2b) || !live(owner, e.w2a)) ok = false;
+        else vb = (int64_t)ob->version_counter().current_version();
+      } else {
+        ok = live(owner, e.w2) && owner->dim() >= 2 && owner->size(0) == e.c && owner->size(1) == e.d && owner->stride(0) == e.sq &&
+             owner->stride(1) == e.sv;
+      }
+      if (!ok) {
+        it = g_planes.map.erase(it);
+        continue;
       }
       if (e.device == device && e.planes[slot].defined()) {
         const int64_t v = (int64_t)owner->version_counter().current_version();
-        if (force || v != e.version[slot] || vb != e.version_b[slot]) {
+        if (force || v != e.version[slot] || vb != e.version_b[slot] || e.epoch[slot] != g_planes.epoch) {
           char* base = static_cast<char*>(e.planes[slot].mutable_data_ptr());
           items.push_back(LycLokrPackItem{e.w2, e.sq, e.sv, e.st, e.c, e.d, e.taps, base, base + lyc_lokr_planes_bytes(e.c, e.d, e.taps, 0),
                                           e.w2a, e.w2b, e.rank});
@@ -542,13 +603,16 @@ void refresh_planes_locked(c10::DeviceIndex device, void* stream, bool force) {
     for (size_t i = 0; i < who.size(); ++i) {
       who[i]->version[slot] = vers[i];
       who[i]->version_b[slot] = versb[i];
+      who[i]->epoch[slot] = g_planes.epoch;
     }
   }
 }
 
 // planes of the leaf factor `w2` ([c, d] or [c, d, kh, kw]) for activations of `act`, or an undefined tensor
-Tensor planes_for(const Tensor& w2, at::ScalarType act, void* stream) {
+Tensor planes_for(const Tensor& w2, at::ScalarType act, void* stream, bool fwd_role = false) {
   if (!g_planes.enabled || !w2.defined() || !w2.is_cuda() || !w2.is_leaf() || w2.scalar_type() != at::kFloat) return Tensor();
+  if (w2.is_inference()) return Tensor();  // no version counter: the kernels convert the fp32 tile themselves
+  if (!fwd_role) planes_mark_dirty_after_backward();  // a backward pass is running: its end is a step boundary
   if (act != at::kBFloat16 && act != at::kHalf) return Tensor();
   const c10::DispatchKeySet ks = w2.key_set();
   if (ks.has(c10::DispatchKey::Python) || ks.has(c10::DispatchKey::Meta) || ks.has(c10::DispatchKey::Functionalize)) return Tensor();
@@ -586,6 +650,7 @@ Tensor planes_for(const Tensor& w2, at::ScalarType act, void* stream) {
     e.device = w2.device().index();
   }
   const int64_t v = (int64_t)w2._version();
+  planes_new_epoch_if_dirty_locked(fwd_role);
   if (!e.planes[slot].defined()) {
     const int64_t nb = lyc_lokr_planes_bytes((int)c, (int)d, taps, 0) + lyc_lokr_planes_bytes((int)c, (int)d, taps, 1);
     e.planes[slot] = at::empty({nb}, w2.options().dtype(at::kByte));
@@ -594,13 +659,17 @@ Tensor planes_for(const Tensor& w2, at::ScalarType act, void* stream) {
                               base + lyc_lokr_planes_bytes((int)c, (int)d, taps, 0), slot == 0 ? LYC_BF16 : LYC_F16, stream),
              "lyc_lokr_pack_w2");
     e.version[slot] = v;
-  } else if (e.version[slot] != v) {
+    e.epoch[slot] = g_planes.epoch;
+  } else if (e.version[slot] != v || e.epoch[slot] != g_planes.epoch) {
     refresh_planes_locked(e.device, stream, false);
+    if (g_planes.map.find(impl) == g_planes.map.end()) return Tensor();  // (cannot happen for a just-validated entry; be safe)
   }
   return e.planes[slot];
 }
 // the same for a low-rank pair w2a [c, r], w2b [r, d] (both leaves, fp32, contiguous): planes of w2a @ w2b, formed in the pack kernel
-Tensor planes_for_lr(const Tensor& w2a, const Tensor& w2b, at::ScalarType act, void* stream, int taps = 1) {
+Tensor planes_for_lr(const Tensor& w2a, const Tensor& w2b, at::ScalarType act, void* stream, int taps = 1, bool fwd_role = false) {
+  if (w2a.defined() && w2b.defined() && (w2a.is_inference() || w2b.is_inference())) return Tensor();
+  if (!fwd_role) planes_mark_dirty_after_backward();
   if (!g_planes.enabled || !w2a.is_cuda() || !w2a.is_leaf() || !w2b.is_leaf() || w2a.scalar_type() != at::kFloat ||
       w2b.scalar_type() != at::kFloat || !w2a.is_contiguous() || !w2b.is_contiguous() || w2a.dim() != 2 || w2b.dim() != 2)
     return Tensor();
@@ -634,6 +703,7 @@ Tensor planes_for_lr(const Tensor& w2a, const Tensor& w2b, at::ScalarType act, v
     e.device = w2a.device().index();
   }
   const int64_t va = (int64_t)w2a._version(), vb = (int64_t)w2b._version();
+  planes_new_epoch_if_dirty_locked(fwd_role);
   if (!e.planes[slot].defined()) {
     const int64_t nb = lyc_lokr_planes_bytes((int)c, (int)d, taps, 0) + lyc_lokr_planes_bytes((int)c, (int)d, taps, 1);
     e.planes[slot] = at::empty({nb}, w2a.options().dtype(at::kByte));
@@ -643,8 +713,10 @@ Tensor planes_for_lr(const Tensor& w2a, const Tensor& w2b, at::ScalarType act, v
              "lyc_lokr_pack_w2(low rank)");
     e.version[slot] = va;
     e.version_b[slot] = vb;
-  } else if (e.version[slot] != va || e.version_b[slot] != vb) {
+    e.epoch[slot] = g_planes.epoch;
+  } else if (e.version[slot] != va || e.version_b[slot] != vb || e.epoch[slot] != g_planes.epoch) {
     refresh_planes_locked(e.device, stream, false);
+    if (g_planes.map.find(impl) == g_planes.map.end()) return Tensor();
   }
   return e.planes[slot];
 }
@@ -674,7 +746,7 @@ Tensor lokr_linear_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2, doub
   const int code = dtype_code(x.scalar_type());
   Tensor pl;
   if (lyc_lokr_linear_planes_ok(rows.size(0), (int)a, (int)b, (int)c, (int)d, code) && (reinterpret_cast<uintptr_t>(cptr(rows)) & 15u) == 0)
-    pl = planes_for(w2, x.scalar_type(), stream_of(x));
+    pl = planes_for(w2, x.scalar_type(), stream_of(x), /*fwd_role=*/true);
   if (pl.defined()) {
     check_rc(lyc_lokr_linear_fwd_planes(cptr(rows), cfp(f1), cptr(pl), cptr(bs), mptr(y), rows.size(0), (int)a, (int)b, (int)c, (int)d,
                                         (float)alpha, code, stream_of(x)), "lyc_lokr_linear_fwd_planes");
@@ -834,7 +906,7 @@ Tensor lokr_linear_lr_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2a, 
   Tensor rows = rows_of(x, b * d);
   Tensor pl;
   if (lyc_lokr_linear_planes_ok(rows.size(0), (int)a, (int)b, (int)c, (int)d, code) && (reinterpret_cast<uintptr_t>(cptr(rows)) & 15u) == 0)
-    pl = planes_for_lr(w2a, w2b, x.scalar_type(), stream_of(x));
+    pl = planes_for_lr(w2a, w2b, x.scalar_type(), stream_of(x), 1, /*fwd_role=*/true);
   if (!pl.defined()) return lokr_linear_fwd(x, w1, at::mm(f32c(w2a), f32c(w2b)), alpha, base);  // shapes off the fast path
   Tensor f1 = f32c(w1);
   auto oshape = x.sizes().vec();
@@ -1681,7 +1753,7 @@ struct LokrConv2dFn : public torch::autograd::Function<LokrConv2dFn> {
                                               gm.dw, code, 1) != 0;
     Tensor planes_f, planes_b;
     const int64_t bytes_f = lyc_lokr_planes_bytes((int)c, (int)d, gm.kh * gm.kw, 0), bytes_b = lyc_lokr_planes_bytes((int)c, (int)d, gm.kh * gm.kw, 1);
-    Tensor cached = (pf || pb) ? planes_for(w2, x.scalar_type(), stream_of(x)) : Tensor();  // leaf parameter: packed once per optimizer step
+    Tensor cached = (pf || pb) ? planes_for(w2, x.scalar_type(), stream_of(x), /*fwd_role=*/true) : Tensor();  // leaf parameter: packed once per optimizer step
     if (cached.defined()) {
       if (pf) planes_f = cached.narrow(0, 0, bytes_f);
       if (pb) planes_b = cached.narrow(0, bytes_f, bytes_b);
@@ -1821,7 +1893,7 @@ struct LokrConv2dLrFn : public torch::autograd::Function<LokrConv2dLrFn> {
     Tensor rows = rows_view(x, &copied), f1 = f32c(w1);
     Tensor y = at::empty({B * gm.Ho * gm.Wo, a * c}, x.options());
     const int code = dtype_code(x.scalar_type());
-    Tensor planes = planes_for_lr(w2a, w2b, x.scalar_type(), stream_of(x), taps);
+    Tensor planes = planes_for_lr(w2a, w2b, x.scalar_type(), stream_of(x), taps, /*fwd_role=*/true);
     TORCH_CHECK(planes.defined(), "lokr_conv2d_lr: no operand planes");
     check_rc(lyc_lokr_conv2d_fwd_planes(cptr(rows), cfp(f1), cptr(planes), mptr(y), B, H, W, (int)a, (int)b, (int)c, (int)d, gm.kh, gm.kw,
                                         gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, (float)alpha, code, stream_of(x)),
@@ -1901,7 +1973,7 @@ Tensor lokr_conv2d_lr_cuda(const Tensor& x, const Tensor& w1, const Tensor& w2a,
   bool copied;
   Tensor rows = rows_view(x, &copied), f1 = f32c(w1);
   Tensor y = at::empty({B * gm.Ho * gm.Wo, a * c}, x.options());
-  Tensor planes = planes_for_lr(w2a, w2b, x.scalar_type(), stream_of(x), taps);
+  Tensor planes = planes_for_lr(w2a, w2b, x.scalar_type(), stream_of(x), taps, /*fwd_role=*/true);
   TORCH_CHECK(planes.defined(), "lokr_conv2d_lr: no operand planes");
   check_rc(lyc_lokr_conv2d_fwd_planes(cptr(rows), cfp(f1), cptr(planes), mptr(y), B, H, W, (int)a, (int)b, (int)c, (int)d, gm.kh, gm.kw, gm.sh,
                                       gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, (float)alpha, dtype_code(x.scalar_type()), stream_of(x)),
@@ -2351,6 +2423,13 @@ PYBIND11_MODULE(_lyc_torch, m) {
   m.def("reset_use_counts", []() {  // once per optimizer step (AdapterGradSync.zero_grad / finish): drop counts of forwards
     std::lock_guard<std::mutex> lk(g_accum.mu);  // whose backward never ran
     g_accum.uses.clear();
+    g_accum.done_task.clear();
+  });
+  m.def("fused_reports", [](const Tensor& p) { return fused_reports(p); });
+  m.def("mark_planes_dirty", []() { g_planes.dirty = true; });  // step boundary (optimizer-step post hook, ops.py)
+  m.def("planes_epoch", []() {
+    std::lock_guard<std::mutex> lk(g_planes.mu);
+    return g_planes.epoch;
   });
   m.def("accum_enabled", []() { return g_accum.enabled; });
   m.def("set_defer", [](bool enabled, int flush_at) {

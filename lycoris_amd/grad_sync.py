@@ -94,7 +94,7 @@ class AdapterGradSync:
             if members:
                 self._close_bucket(arena, start, off, members)
         for p in self.params:
-            self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+            self._handles.append(p.register_post_accumulate_grad_hook(self._on_autograd_hook))
         self._reset_pending()
 
     # ---- construction helpers --------------------------------------------------------------------------------
@@ -169,6 +169,17 @@ class AdapterGradSync:
         ops.fused_grad_accumulation(enabled, callback=self._on_grad_ready if enabled else None,
                                     batch_callback=self._on_grads_ready if enabled else None)
         self._fused = bool(enabled)
+
+    def _on_autograd_hook(self, p):
+        """post-accumulate-grad hook.  autograd runs a leaf's AccumulateGrad node -- and this hook -- even when the backward node
+        returned NO gradient for it, which is what the kernels do when they accumulate into `.grad` themselves (torch >= 2.x;
+        found by tests/test_gpu_parity_round4.py: every fused parameter of a loss.backward() was counted twice and its bucket
+        all-reduced before the last gradient had arrived).  Parameters the kernels report are counted by THAT report only."""
+        if self._fused and self.device.type == "cuda":
+            from . import ops
+            if ops.fused_reports(p):
+                return
+        self._on_grad_ready(p)
 
     def _on_grads_ready(self, params):
         """the reports of one grouped weight-gradient flush (csrc/torch_ops.cpp notify_many): one call instead of one per parameter"""

@@ -47,6 +47,14 @@ def _cpp() -> bool:
         ext = N.load_torch_ops()  # raises NativeLibraryError when the extension is missing: no silent fallback
         ext.set_accum(_ACCUM["enabled"], _ACCUM["callback"], _ACCUM["batch_callback"])
         _DISPATCH["ext"] = ext
+        # A step boundary makes every cached LoKr operand plane stale, whatever the optimizer does to the version counters
+        # (Prodigy / DAdaptation / raw 8-bit kernels write through `p.data`, which does not bump them): every
+        # torch.optim.Optimizer.step() marks the cache dirty, and so does the end of every backward pass (csrc/torch_ops.cpp).
+        try:
+            from torch.optim.optimizer import register_optimizer_step_post_hook
+            register_optimizer_step_post_hook(lambda opt, args, kwargs: ext.mark_planes_dirty())
+        except ImportError:  # very old torch: the end-of-backward mark alone
+            pass
         ns = torch.ops.lycoris_amd  # the resolved overloads: skips the packet's per-call overload resolution (~1 us per call)
         for name in ("lokr_linear", "lokr_linear_lr", "lokr_linear_lr2", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d", "lokr_conv2d_lr"):
             _OPS[name] = getattr(ns, name).default
@@ -61,6 +69,14 @@ def fused_grad_accumulation(enabled: bool = True, callback=None, batch_callback=
     _ACCUM["batch_callback"] = batch_callback if callback is not None else None
     if _DISPATCH["ext"] is not None:
         _DISPATCH["ext"].set_accum(bool(enabled), callback, _ACCUM["batch_callback"])
+
+
+def fused_reports(param) -> bool:
+    """True when the kernels themselves report `param` to the fused-accumulation callback in the running backward pass (its
+    autograd post-accumulate hook, which fires on the undefined gradient the backward node returned, must then stay silent)."""
+    if not _cpp():
+        return False
+    return bool(_DISPATCH["ext"].fused_reports(param))
 
 
 def deferred_weight_gradients(enabled: bool = True, flush_at: int = 48):

@@ -69,3 +69,54 @@ def test_shared_module_reports_once_through_the_sync(defer):
         ops.deferred_weight_gradients(True)
         sync.attach_fused(False)
         sync.remove()
+
+
+def test_loss_backward_counts_every_fused_parameter_once():
+    """loss.backward() runs every leaf's AccumulateGrad node -- and AdapterGradSync's post-accumulate hook -- even for parameters
+    whose backward node returned no gradient because the kernels accumulated into `.grad` themselves.  Each parameter must be
+    counted ONCE (by the kernels' report), the bucket launched after the LAST of them, two micro-batches under no_sync()."""
+    import torch.nn as nn
+    from lycoris_amd import ops
+    from lycoris_amd.grad_sync import AdapterGradSync
+    from lycoris_amd.modules import IA3Module, LoConModule, LokrModule
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    l1, l2, l3 = (nn.Linear(128, 128).to(dev, torch.bfloat16).requires_grad_(False) for _ in range(3))
+    mods = [LoConModule("a", l1, 1.0, lora_dim=8, alpha=4), LokrModule("b", l2, 1.0, lora_dim=100000, alpha=1, factor=8),
+            IA3Module("c", l3, 1.0)]
+    for m in mods:
+        m.to(dev)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.randn_like(p) * 0.1)
+        m.apply_to()
+    params = [p for m in mods for p in m.parameters()]
+    sync = AdapterGradSync(params, bucket_bytes=1 << 30)  # ONE bucket: it may launch only after the last report
+    sync.attach_fused()
+    seen = []
+    orig = sync._on_grad_ready
+    sync._on_grad_ready = lambda p: (seen.append(id(p)), orig(p))[1]
+    ops.fused_grad_accumulation(True, callback=sync._on_grad_ready, batch_callback=lambda ps: [sync._on_grad_ready(p) for p in ps])
+    try:
+        sync.zero_grad()
+        for mb in range(2):
+            x = torch.randn(64, 128, device=dev).to(torch.bfloat16).requires_grad_(True)
+            y = l3(l2(l1(x)))
+            if mb == 0:
+                with sync.no_sync():
+                    y.backward(torch.ones_like(y))
+            else:
+                y.backward(torch.ones_like(y))  # raised "bucket already all-reduced" before the hook was made aware of the reports
+        assert sync.launch_log == [0]
+        sync.finish()
+        torch.cuda.synchronize()
+    finally:
+        for m in mods:
+            m.restore()
+        ops.discard_deferred()
+        sync.attach_fused(False)
+        sync.remove()
+    # both micro-batches reached the hook / callback; each parameter exactly once per micro-batch
+    assert sorted(seen) == sorted([id(p) for p in params] * 2)
+    for p in params:
+        assert p.grad is not None and float(p.grad.abs().max()) > 0

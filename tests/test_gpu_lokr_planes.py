@@ -367,3 +367,100 @@ def test_linear_plane_cache_one_grouped_refresh_per_step():
     for x, x64, w1, w1_64, w2, w2_64 in layers:
         y = _lin(x, w1, w2)
         assert err(y, oracle.lokr.forward(x64, w1=w1_64, w2=w2_64 - 0.005, scale=0.5), dtype) < TOL["store_out"][dtype]
+
+
+# ---- step boundaries the version counter does not see -------------------------------------------------------------------
+class _DataSGD(torch.optim.Optimizer):
+    """An optimizer that updates through `p.data` (Prodigy, DAdaptation, 8-bit optimizers with raw kernels, master-weight copies
+    do): `p._version` does NOT move."""
+
+    def __init__(self, params, lr):
+        super().__init__(params, dict(lr=lr))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is not None:
+                    p.data.add_(p.grad.to(p.dtype), alpha=-g["lr"])
+
+
+@pytest.mark.parametrize("how", ["backward_then_data_write", "optimizer_step_hook"])
+def test_linear_plane_cache_sees_data_style_updates(how):
+    """`p.data.add_()` leaves the autograd version counter where it was (asserted below): the cache must take the END OF A BACKWARD
+    PASS and every torch.optim step as step boundaries of their own, otherwise forward / dx keep using the planes of step 0 while
+    dW2 and the checkpoint follow the real parameter (silently wrong training)."""
+    from lycoris_amd import ops
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(91)
+    M, a, c, d = 160, 8, 40, 80
+    x, x64 = rnd((M, a * d), dtype, gen)
+    g, g64 = rnd((M, a * c), dtype, gen, 0.05)
+    w1, w1_64 = rnd((a, a), torch.float32, gen, 0.3)
+    w2, w2_64 = rnd((c, d), torch.float32, gen, 0.1)
+    w1 = torch.nn.Parameter(w1)
+    w2 = torch.nn.Parameter(w2)
+    xg = x.clone().requires_grad_(True)
+    y0 = _lin(xg, w1, w2)
+    assert err(y0, oracle.lokr.forward(x64, w1=w1_64, w2=w2_64, scale=0.5), dtype) < TOL["store_out"][dtype]
+    v0 = w2._version
+    if how == "backward_then_data_write":
+        y0.backward(g)  # plain autograd: w2.grad is produced, the pass ends -> the cache is marked dirty
+        with torch.no_grad():
+            w2.data.add_(w2.grad, alpha=-3.0)
+    else:
+        w2.grad = (torch.randn(c, d, generator=gen) * 0.05).to(dev())
+        _DataSGD([w2], lr=3.0).step()  # no backward of ours in between: the global optimizer-step post hook marks the cache
+    assert w2._version == v0, "this torch bumps the version counter on .data writes: the test no longer tests anything"
+    new64 = w2.detach().double().cpu().numpy()
+    assert oracle.general.rel_err(new64, w2_64) > 1e-2  # a real step
+    y1 = _lin(x, w1, w2)
+    assert err(y1, oracle.lokr.forward(x64, w1=w1_64, w2=new64, scale=0.5), dtype) < TOL["store_out"][dtype]
+    xg2 = x.clone().requires_grad_(True)
+    dx, = torch.autograd.grad(_lin(xg2, w1, w2), [xg2], g)
+    assert err(dx, oracle.lokr.backward(x64, g64, w1=w1_64, w2=new64, scale=0.5)["dx"], dtype) < TOL["store_out"][dtype]
+
+
+def test_plane_refresh_drops_entries_whose_storage_moved():
+    """refresh_lokr_planes(force=True) packs from pointers cached per entry: a parameter whose storage was replaced since its last
+    own layer call (`.data =` swap, `.to()`, offload) must be dropped, not read -- and its next call repacks."""
+    from lycoris_amd import ops
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(92)
+    M, a, c, d = 96, 8, 40, 40
+    x, x64 = rnd((M, a * d), dtype, gen)
+    w1, w1_64 = rnd((a, a), torch.float32, gen, 0.3)
+    ws = []
+    for _ in range(3):
+        w, w64 = rnd((c, d), torch.float32, gen, 0.1)
+        ws.append((torch.nn.Parameter(w), w64))
+    for w, _ in ws:
+        _lin(x, w1, w)
+    ext = ops._DISPATCH["ext"]
+    n0 = ext.planes_cache_size()
+    # swap the storage of the middle one (new allocation), free the old one
+    new, new64 = rnd((c, d), torch.float32, gen, 0.1)
+    ws[1][0].data = new.clone()
+    del new
+    torch.cuda.empty_cache()
+    ops.refresh_lokr_planes(force=True)  # must not touch the dead pointer
+    torch.cuda.synchronize()
+    assert ext.planes_cache_size() == n0 - 1
+    y = _lin(x, w1, ws[1][0])
+    assert err(y, oracle.lokr.forward(x64, w1=w1_64, w2=new64, scale=0.5), dtype) < TOL["store_out"][dtype]
+    assert ext.planes_cache_size() == n0
+
+
+def test_planes_skipped_for_inference_tensors():
+    """a parameter created under torch.inference_mode() has no version counter (`_version` raises): no planes, no crash"""
+    from lycoris_amd import ops
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(93)
+    M, a, c, d = 64, 8, 40, 40
+    x, x64 = rnd((M, a * d), dtype, gen)
+    with torch.inference_mode():
+        w1 = (torch.randn(a, a, generator=gen) * 0.3).to(dev())
+        w2 = torch.nn.Parameter((torch.randn(c, d, generator=gen) * 0.1).to(dev()), requires_grad=False)
+        y = _lin(x, w1, w2)
+    ref = oracle.lokr.forward(x64, w1=w1.double().cpu().numpy(), w2=w2.double().cpu().numpy(), scale=0.5)
+    assert err(y, ref, dtype) < TOL["store_out"][dtype]

@@ -140,9 +140,15 @@ def test_mixed_preset_block_every_grad_vs_oracle():
     hooks = []
     for n, m in mods.items():
         layer = m.org_module[0]
-        hooks.append(layer.register_forward_pre_hook(lambda mod_, inp, n=n: cap[n]["x"].append(inp[0].detach())))
-        hooks.append(layer.register_forward_hook(
-            lambda mod_, inp, out, n=n: out.register_hook(lambda gr, n=n: cap[n]["g"].append(gr.detach()))))
+        def pre(mod_, inp, n=n):
+            cap[n]["x"].append(inp[0].detach())
+
+        def post(mod_, inp, out, n=n):  # (a forward hook's return value would REPLACE the output: return None)
+            if out.requires_grad:
+                out.register_hook(lambda gr, n=n: cap[n]["g"].append(gr.detach()) and None)
+
+        hooks.append(layer.register_forward_pre_hook(pre))
+        hooks.append(layer.register_forward_hook(post))
     try:
         sync.zero_grad()
         for mb in range(2):  # two micro-batches: the first under no_sync() (gradient accumulation), the second reports
@@ -161,6 +167,7 @@ def test_mixed_preset_block_every_grad_vs_oracle():
             h.remove()
         for m in mods.values():
             m.restore()
+        ops.discard_deferred()  # (nothing is parked after a clean pass; a failed one must not leak into the next test)
         sync.attach_fused(False)
         sync.remove()
     errs, bounds = {}, {}
