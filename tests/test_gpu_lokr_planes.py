@@ -437,6 +437,7 @@ def test_plane_refresh_drops_entries_whose_storage_moved():
     for w, _ in ws:
         _lin(x, w1, w)
     ext = ops._DISPATCH["ext"]
+    ops.refresh_lokr_planes(force=True)  # (also purges the entries of parameters earlier tests have dropped)
     n0 = ext.planes_cache_size()
     # swap the storage of the middle one (new allocation), free the old one
     new, new64 = rnd((c, d), torch.float32, gen, 0.1)
