@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../lycoris_amd/csrc/kron4.h"
+#include "experiments/kron4r.h"
 #include "../lycoris_amd/csrc/kron_conv.h"
 
 using namespace lyc;
@@ -68,13 +69,24 @@ struct Set {
 typedef void (*K4Fn)(Kron4Args);
 struct Variant {
   const char* name;
-  int MI, NI, D;
+  int MI, NI, D, NP;
   K4Fn fn[3];  // per EPI
 };
-#define V(MI, NI, D)                                                                                          \
-  {"k4 " #MI "x" #NI " D" #D, MI, NI, D,                                                                     \
-   {kron4_kernel<__bf16, MI, NI, D, 0>, kron4_kernel<__bf16, MI, NI, D, 1>, kron4_kernel<__bf16, MI, NI, D, 2>}}
-static Variant VARIANTS[] = {V(2, 2, 3), V(1, 2, 3), V(2, 4, 3), V(2, 5, 3), V(2, 2, 2), V(1, 2, 2), V(2, 4, 2), V(2, 5, 2), V(2, 8, 2), V(4, 4, 2), V(4, 2, 2), V(4, 4, 3), V(4, 8, 2), V(1, 5, 2), V(1, 4, 2)};
+#define V(MI, NI, D, NP)                                                                                      \
+  {"k4 " #MI "x" #NI " D" #D " P" #NP, MI, NI, D, NP,                                                        \
+   {kron4_kernel<__bf16, MI, NI, D, 0, NP != 0>, kron4_kernel<__bf16, MI, NI, D, 1, NP != 0>, kron4_kernel<__bf16, MI, NI, D, 2, NP != 0>}}
+static Variant VARIANTS[] = {V(1, 2, 3, 0), V(1, 2, 3, 1), V(2, 2, 2, 0), V(2, 2, 2, 1), V(2, 4, 3, 0), V(2, 4, 3, 1), V(2, 5, 2, 0), V(2, 5, 2, 1),
+                             V(2, 5, 3, 0), V(2, 5, 3, 1), V(1, 4, 3, 1), V(1, 5, 3, 1), V(2, 4, 2, 1), V(4, 4, 2, 1)};
+
+struct RVariant {
+  const char* name;
+  int MI, NI, D, NW, NP;
+  K4Fn fn[3];
+};
+#define VR(MI, NI, D, NW, NP)                                                                                   \
+  {"k4r " #MI "x" #NI " D" #D " W" #NW " P" #NP, MI, NI, D, NW, NP,                                             \
+   {kron4r_kernel<__bf16, MI, NI, D, 0, NW, NP != 0>, kron4r_kernel<__bf16, MI, NI, D, 1, NW, NP != 0>, kron4r_kernel<__bf16, MI, NI, D, 2, NW, NP != 0>}}
+static RVariant RVARIANTS[] = {VR(2, 5, 3, 8, 1), VR(2, 5, 3, 16, 1), VR(2, 4, 3, 12, 1), VR(2, 4, 3, 16, 1), VR(2, 5, 2, 16, 1), VR(2, 5, 3, 8, 0)};
 
 static bool g_eager = false;
 
@@ -176,6 +188,7 @@ int main(int argc, char** argv) {
     std::vector<float> h_ws(1 << 20);
 
     for (int mode = 0; mode < 3; ++mode) {  // 0 fwd, 1 fwd + base, 2 bwd (dx + dW1 partials)
+      if (getenv("K4_MODE") && atoi(getenv("K4_MODE")) != mode) continue;
       const bool bw = mode == 2;
       const int K = bw ? c : d, N = bw ? d : c;
       const size_t outb = bw ? xb : yb;
@@ -213,6 +226,9 @@ int main(int argc, char** argv) {
         for (Variant& v : VARIANTS)
           for (int e = 0; e < 3; ++e)
             CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn[e]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (RVariant& v : RVARIANTS)
+          for (int e = 0; e < 3; ++e)
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn[e]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       }
       // reference result (kron3, set 0)
       CK(hipMemsetAsync(yref, 0xff, outb, st));
@@ -234,9 +250,11 @@ int main(int argc, char** argv) {
              mode == 0 ? "fwd" : mode == 1 ? "fwdB" : "bwd", ni3, t3, bytes / t3 * 1e-3, bytes / t3 * 1e-3 / 8000.0);
 
       for (const Variant& v : VARIANTS) {
+        if (getenv("K4_ONLY") && !strstr(v.name, getenv("K4_ONLY"))) continue;
         const int lds = kron4_lds_bytes(v.MI, v.NI, v.D);
         if (lds > 160 * 1024) continue;
         if (N < 16 * v.NI && v.NI > 2) continue;
+        if (v.NP && N % (16 * v.NI) != 0) continue;
         dim3 g4((unsigned)cdivl(M * G, 64 * v.MI), (unsigned)cdivl(N, 16 * v.NI));
         auto k4args = [&](const Set& z, void* out) {
           Kron4Args a{};
@@ -283,10 +301,86 @@ int main(int argc, char** argv) {
           const Set& z = sets[i % nsets];
           hipLaunchKernelGGL(v.fn[mode], g4, dim3(NTHREADS), lds, st, k4args(z, bw ? z.dx : z.y));
         });
-        printf("   %-12s grid %4ux%-3u lds %3dK | %7.2f us %7.1f GB/s %.3f  x%.2f  mism %zu%s", v.name, g4.x, g4.y, lds >> 10, t4,
+        printf("   %-16s grid %4ux%-3u lds %3dK | %7.2f us %7.1f GB/s %.3f  x%.2f  mism %zu%s", v.name, g4.x, g4.y, lds >> 10, t4,
                bytes / t4 * 1e-3, bytes / t4 * 1e-3 / 8000.0, t3 / t4, mism, mism ? " <<<<" : "");
         if (bw) printf("  dw1 relerr %.2e", dw1_err);
         printf("\n");
+      }
+      if (getenv("K4_ABLATE") && mode == 0) {
+        const int MI = 2, NI = 5;
+        dim3 g4((unsigned)cdivl(M * G, 64 * MI), (unsigned)cdivl(N, 16 * NI));
+        const int lds = kron4_lds_bytes(MI, NI, 2);
+        auto mk = [&](const Set& z) {
+          Kron4Args a{};
+          a.x = z.x; a.y = z.y; a.planes = planes; a.w1 = w1; a.dw1_ws = z.ws;
+          a.x_bytes = (unsigned)(M * G * K * 2); a.y_bytes = (unsigned)(M * G * N * 2); a.plane_bytes = (unsigned)nf;
+          a.rows_total = (int)(M * G); a.K = K; a.N = N; a.KS = (K + 31) / 32; a.lg = 3; a.s1o = G; a.s1i = 1; a.alpha = 0.5f;
+          return a;
+        };
+#define ABL(bits)                                                                                                              \
+        {                                                                                                                      \
+          auto kern = kron4_kernel<__bf16, 2, 5, 2, 0, false, bits>;                                                           \
+          CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+          float t = bench(st, nl, 5, [&](int i) { hipLaunchKernelGGL(kern, g4, dim3(NTHREADS), lds, st, mk(sets[i % nsets])); }); \
+          printf("   ablate %2d (1 no stage-2 mfma, 2 no stores, 4 no x dma, 8 no plane dma, 16 no stage-1 mfma): %7.2f us\n", bits, t); \
+        }
+        ABL(0) ABL(1) ABL(2) ABL(3) ABL(4) ABL(8) ABL(12) ABL(16) ABL(17) ABL(19) ABL(14) ABL(31) ABL(29)
+      }
+      if (!getenv("K4_NO_R"))
+      for (const RVariant& v : RVARIANTS) {
+        if (getenv("K4_ONLY") && !strstr(v.name, getenv("K4_ONLY"))) continue;
+        const int KS = (K + 31) / 32;
+        const int lds = kron4r_lds_bytes(v.MI, v.NI, v.D, KS, v.NW);
+        if (lds > 160 * 1024 || v.D > KS + 1) continue;
+        if (N < 16 * v.NI && v.NI > 2) continue;
+        if (v.NP && N % (16 * v.NI) != 0) continue;
+        const unsigned nby = (unsigned)cdivl(N, 16 * v.NI);
+        const long wtiles = cdivl(M * G, 16 * v.MI);
+        int per_cu = (160 * 1024) / lds;
+        if (per_cu * v.NW > 16) per_cu = 16 / v.NW;
+        for (int fill = 1; fill <= (per_cu >= 2 ? 2 : 1); ++fill) {
+          long gx = (256L * fill) / nby;
+          if (gx < 1) gx = 1;
+          if (gx * v.NW > wtiles) gx = cdivl(wtiles, v.NW);
+          dim3 g4((unsigned)gx, nby);
+          auto k4args = [&](const Set& z, void* out) {
+            Kron4Args a{};
+            a.x = bw ? z.g : z.x; a.y = out; a.planes = bw ? planes + nf : planes; a.w1 = w1;
+            a.aux = mode == 1 ? z.base : (bw ? z.x : nullptr); a.dw1_ws = z.ws;
+            a.x_bytes = (unsigned)(M * G * K * 2); a.y_bytes = (unsigned)(M * G * N * 2); a.plane_bytes = (unsigned)(bw ? nb : nf);
+            a.rows_total = (int)(M * G); a.K = K; a.N = N; a.KS = KS; a.lg = 3;
+            a.s1o = bw ? 1 : G; a.s1i = bw ? G : 1; a.alpha = 0.5f;
+            return a;
+          };
+          size_t mism = 0;
+          double dw1_err = 0;
+          for (int rep = 0; rep < 3; ++rep) {  // three runs: a race in the counted waits would show as a run-to-run difference
+            CK(hipMemsetAsync(yout, 0xff, outb, st));
+            CK(hipMemsetAsync(sets[0].ws, 0, 4 << 20, st));
+            hipLaunchKernelGGL(v.fn[mode], g4, dim3(64 * v.NW), lds, st, k4args(sets[0], yout));
+            CK(hipStreamSynchronize(st));
+            CK(hipGetLastError());
+            CK(hipMemcpy(h_out.data(), yout, outb, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < outb / 2; ++i) mism += h_out[i] != h_ref[i];
+          }
+          if (bw) {
+            const long nblk = (long)g4.x * g4.y;
+            CK(hipMemcpy(h_ws.data(), sets[0].ws, nblk * 64 * 4, hipMemcpyDeviceToHost));
+            double sum[64] = {0}, nrm = 0;
+            for (long b = 0; b < nblk; ++b)
+              for (int e = 0; e < 64; ++e) sum[e] += h_ws[b * 64 + e];
+            for (int e = 0; e < 64; ++e) { dw1_err += (sum[e] - dw1_ref[e]) * (sum[e] - dw1_ref[e]); nrm += dw1_ref[e] * dw1_ref[e]; }
+            dw1_err = nrm > 0 ? sqrt(dw1_err / nrm) : sqrt(dw1_err);
+          }
+          float t4 = bench(st, nl, 5, [&](int i) {
+            const Set& z = sets[i % nsets];
+            hipLaunchKernelGGL(v.fn[mode], g4, dim3(64 * v.NW), lds, st, k4args(z, bw ? z.dx : z.y));
+          });
+          printf("   %-16s grid %4ux%-3u lds %3dK | %7.2f us %7.1f GB/s %.3f  x%.2f  mism %zu%s", v.name, g4.x, g4.y, lds >> 10, t4,
+                 bytes / t4 * 1e-3, bytes / t4 * 1e-3 / 8000.0, t3 / t4, mism, mism ? " <<<<" : "");
+          if (bw) printf("  dw1 relerr %.2e", dw1_err);
+          printf("\n");
+        }
       }
     }
     for (Set& z : sets) {

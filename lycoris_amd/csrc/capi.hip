@@ -115,15 +115,18 @@ inline int kron3_pick_ni(const KronArgs& ka) {
 // re-read 1-2x instead of 3-5x), otherwise the latency plan 64 rows x 32 columns; ring depth 2 when the whole K fits five k steps.
 struct Kron4Plan {
   int MI, NI, D;
+  bool NP;  // paired column tiles: 16-byte stores (kron4.h); needs every tile of every column block to exist
 };
 inline Kron4Plan kron4_plan(long rows, int K, int N) {
   const int KS = (K + 31) / 32;
-  int ni = (N % 80 == 0) ? 5 : ((N % 64 == 0) ? 4 : 2);
+  // wide column tiles (64 columns = one 128-byte line per row and workgroup; 80 for the widths that are not multiples of 64) as long
+  // as the grid keeps >= 256 workgroups; otherwise the latency plan of 64 rows x 32 columns
+  int ni = (N % 64 == 0) ? 4 : ((N % 80 == 0) ? 5 : 2);
   if (ni > 2 && cdiv(rows, 128) * cdiv(N, 16 * ni) < 256) ni = 2;
-  if (ni == 5) return {2, 5, KS <= 5 ? 2 : 3};
-  if (ni == 4) return {2, 4, 3};
-  if (cdiv(rows, 128) * cdiv(N, 32) >= 1024) return {2, 2, 2};  // many short rows (SD1.5 320-wide layers at batch 4)
-  return {1, 2, 3};
+  if (ni >= 4) return {2, ni, KS <= 5 ? 2 : 3, true};
+  const bool np = (N % 32) == 0;
+  if (cdiv(rows, 128) * cdiv(N, 32) >= 1024) return {2, 2, 2, np};  // many short rows (SD1.5 320-wide layers at batch 4)
+  return {1, 2, 3, np};
 }
 inline bool kron4_dims_ok(long M, int G, int K, int N) {
   return G >= 1 && (16 % G) == 0 && (K % 8) == 0 && (N % 8) == 0 && M > 0 && M * G * (long)K * 2 < (1L << 31) &&
@@ -139,12 +142,12 @@ bool kron4_ok(const KronArgs& ka) {
     return false;
   } else {
     return ka.w2p != nullptr && !ka.gat.mode && !ka.out_f32 && ka.Gin == ka.Gout && kron4_dims_ok(ka.M, ka.Gin, ka.K, ka.N) &&
-           (reinterpret_cast<uintptr_t>(ka.x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(ka.y) & 7u) == 0 &&
-           (!ka.base || (reinterpret_cast<uintptr_t>(ka.base) & 7u) == 0) && (!ka.xref || (reinterpret_cast<uintptr_t>(ka.xref) & 7u) == 0) &&
+           (reinterpret_cast<uintptr_t>(ka.x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(ka.y) & 15u) == 0 &&
+           (!ka.base || (reinterpret_cast<uintptr_t>(ka.base) & 15u) == 0) && (!ka.xref || (reinterpret_cast<uintptr_t>(ka.xref) & 15u) == 0) &&
            (ka.dw1 == nullptr || ka.dw1_ws != nullptr);  // the w1 gradient leaves as per-workgroup partials only
   }
 }
-template <typename T, int MI, int NI, int D>
+template <typename T, int MI, int NI, int D, bool NP>
 void launch_kron4_inst(const Kron4Args& a, int epi, dim3 grid, hipStream_t st) {
   constexpr int lds = kron4_lds_bytes(MI, NI, D);
   static_assert(lds <= 160 * 1024, "LDS");
@@ -156,9 +159,9 @@ void launch_kron4_inst(const Kron4Args& a, int epi, dim3 grid, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, a);
   };
-  if (epi == 0) go(kron4_kernel<T, MI, NI, D, 0>);
-  else if (epi == 1) go(kron4_kernel<T, MI, NI, D, 1>);
-  else go(kron4_kernel<T, MI, NI, D, 2>);
+  if (epi == 0) go(kron4_kernel<T, MI, NI, D, 0, NP>);
+  else if (epi == 1) go(kron4_kernel<T, MI, NI, D, 1, NP>);
+  else go(kron4_kernel<T, MI, NI, D, 2, NP>);
 }
 // returns the number of dw1 partial blocks the consumer has to sum (0: no w1 gradient requested)
 template <typename T>
@@ -180,14 +183,17 @@ long launch_kron4(const KronArgs& ka, long dw1_blocks_total, hipStream_t st) {
   const long nwg = (long)grid.x * grid.y;
   a.dw1_blocks = (int)(dw1_blocks_total > nwg ? dw1_blocks_total : nwg);
   if (p.NI == 5) {
-    if (p.D == 2) launch_kron4_inst<T, 2, 5, 2>(a, epi, grid, st);
-    else launch_kron4_inst<T, 2, 5, 3>(a, epi, grid, st);
+    if (p.D == 2) launch_kron4_inst<T, 2, 5, 2, true>(a, epi, grid, st);
+    else launch_kron4_inst<T, 2, 5, 3, true>(a, epi, grid, st);
   } else if (p.NI == 4) {
-    launch_kron4_inst<T, 2, 4, 3>(a, epi, grid, st);
+    if (p.D == 2) launch_kron4_inst<T, 2, 4, 2, true>(a, epi, grid, st);
+    else launch_kron4_inst<T, 2, 4, 3, true>(a, epi, grid, st);
   } else if (p.MI == 2) {
-    launch_kron4_inst<T, 2, 2, 2>(a, epi, grid, st);
+    if (p.NP) launch_kron4_inst<T, 2, 2, 2, true>(a, epi, grid, st);
+    else launch_kron4_inst<T, 2, 2, 2, false>(a, epi, grid, st);
   } else {
-    launch_kron4_inst<T, 1, 2, 3>(a, epi, grid, st);
+    if (p.NP) launch_kron4_inst<T, 1, 2, 3, true>(a, epi, grid, st);
+    else launch_kron4_inst<T, 1, 2, 3, false>(a, epi, grid, st);
   }
   return epi == 2 ? (long)a.dw1_blocks : 0;
 }

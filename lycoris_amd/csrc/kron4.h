@@ -71,8 +71,175 @@ __device__ __forceinline__ void k4_wait_groups(int groups) {
 
 typedef __attribute__((address_space(3))) void* k4_lds_ptr;
 
+// ---- column permutation (NP) -------------------------------------------------------------------------------------------------------
+// The register epilogue leaves lane (row li, g) with 4 consecutive columns per 16-column MFMA tile: 8-byte stores, 16 rows x 32 bytes
+// per wave instruction.  The write path takes that badly: a 21 MB output costs 6.3 us in 32-byte pieces, 3.8 us in 64-byte pieces,
+// 3.2 us in full lines (benchmarks/stbench.cpp, profiles/r04_stbench.log; the ablation of profiles/r04_k4_ablation.log shows the
+// stores -- not the matrix work, not the operand traffic -- are what the (1024, 1280 -> 10240) forward waits for).  Which w2 rows
+// form MFMA tile t is free, so tiles are formed in PAIRS: row i of tile 2q + e holds column 32 q + 8 (i >> 2) + 4 e + (i & 3) of the
+// column block.  Lane g then owns 8 CONSECUTIVE columns 32 q + 8 g .. + 7 across the pair: one 16-byte store (and one 16-byte base /
+// xref load) per row and pair.  The planes stay as they are (kron_conv.h); the permutation is applied by the per-lane SOURCE address
+// of the plane DMA.  An odd last tile of the block keeps the 8-byte form.  Needs N % (16 NI) == 0 (every tile of every block exists).
+template <int NI>
+__device__ __forceinline__ constexpr bool k4_paired(int ni) {
+  return ni < 2 * (NI / 2);
+}
+// DMA source offset (bytes, relative to the first unit of the tile's pair / of the tile) of lane `lane` for MFMA tile `ni`
+template <int NI, bool NP>
+__device__ __forceinline__ unsigned k4_plane_voff(int lane, int ni, int KS) {
+  if (NP && k4_paired<NI>(ni)) {
+    const int i = lane & 15, g = lane >> 4;
+    return (unsigned)(i >> 3) * (unsigned)KS * 2048u + (unsigned)(g * 16 + 8 * ((i >> 2) & 1) + 4 * (ni & 1) + (i & 3)) * 16u;
+  }
+  return (unsigned)lane * 16u;
+}
+// first n tile (relative to the block) whose units the DMA of MFMA tile `ni` starts from
+template <int NI, bool NP>
+__device__ __forceinline__ int k4_plane_tile(int ni) {
+  return (NP && k4_paired<NI>(ni)) ? (ni & ~1) : ni;
+}
+
+// base / xref pieces of one 16 MI-row tile: auxv[mi][ni] = the 4 values (8 bytes) lane (li, g) needs for MFMA tile ni
+template <int MI, int NI, bool NP>
+__device__ __forceinline__ void k4_load_aux(u32x2 (&auxv)[MI][NI], const __amdgpu_buffer_rsrc_t& rsa, const unsigned (&rofs)[MI], int nt0, int N,
+                                            int g) {
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      if (NP && k4_paired<NI>(ni)) {
+        if (ni & 1) continue;
+        const int gn = (nt0 + ni) * 16 + 8 * g;
+        const unsigned off = gn < N ? rofs[mi] + (unsigned)gn * 2u : K4_OOB;  // out of bounds reads as zero
+        const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, (int)off, 0, 0));
+        auxv[mi][ni] = u32x2{v[0], v[1]};
+        auxv[mi][ni + 1] = u32x2{v[2], v[3]};
+      } else {
+        const int gn = (nt0 + ni) * 16 + 4 * g;
+        const unsigned off = gn < N ? rofs[mi] + (unsigned)gn * 2u : K4_OOB;
+        auxv[mi][ni] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsa, (int)off, 0, 0));
+      }
+    }
+  }
+}
+
+// Register epilogue of one 16 MI x 16 NI tile (kron3.h): stage 2 on the matrix cores, fused `base + delta`, dW1 contribution, stores.
+// ABL (benchmarks only): bit 1 = no stage-2 matrix work, bit 2 = no stores.
+template <typename T, int MI, int NI, int EPI, bool NP, int ABL>
+__device__ __forceinline__ void k4_epilogue(f32x4 (&acc)[MI][NI], const typename Mma16<T>::frag& a2h, const typename Mma16<T>::frag& a2l,
+                                            const typename Mma16<T>::frag& ident, const u32x2 (&auxv)[MI][NI], const unsigned (&rofs)[MI],
+                                            const __amdgpu_buffer_rsrc_t& rsy, int nt0, int N, int g, float alpha, f32x4& cdw) {
+  using F4 = typename Mma16<T>::frag;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    u32x2 ov[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      T h[4], l[4];
+      k3_split4<T>(acc[mi][ni], h, l);
+      const F4 sh = *reinterpret_cast<F4*>(h), sl = *reinterpret_cast<F4*>(l);
+      f32x4 yv = zero4();
+      if constexpr ((ABL & 1) != 0) {
+        yv = acc[mi][ni];
+      } else {
+        yv = Mma16<T>::mma(sh, a2h, yv);
+        yv = Mma16<T>::mma(sl, a2h, yv);
+        yv = Mma16<T>::mma(sh, a2l, yv);
+      }
+      acc[mi][ni] = zero4();
+      float bb[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (EPI == 1) {  // fused `base + delta`: fp32 add, one rounding
+        T bt[4];
+        *reinterpret_cast<u32x2*>(bt) = auxv[mi][ni];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bb[e] = TT<T>::to_f(bt[e]);
+      }
+      T o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = TT<T>::from_f(alpha * yv[e] + bb[e]);
+      ov[ni] = *reinterpret_cast<u32x2*>(o);
+      if constexpr (EPI == 2) {
+        // S1 (hi, lo) transposed through the matrix core: lane (li = row, 4g+e = tile column) -- exact, the values are T
+        const f32x4 th = Mma16<T>::mma(sh, ident, zero4());
+        const f32x4 tl = Mma16<T>::mma(sl, ident, zero4());
+        T thv[4], tlv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          thv[e] = TT<T>::from_f(th[e]);
+          tlv[e] = TT<T>::from_f(tl[e]);
+        }
+        const F4 bf = *reinterpret_cast<const F4*>(&auxv[mi][ni]);  // xref fragment B[k = tile column][j = row li]; zero outside
+        cdw = Mma16<T>::mma(*reinterpret_cast<F4*>(thv), bf, cdw);
+        cdw = Mma16<T>::mma(*reinterpret_cast<F4*>(tlv), bf, cdw);
+      }
+    }
+    if constexpr ((ABL & 2) != 0) {
+      if (alpha != 123.f) continue;
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      if (NP && k4_paired<NI>(ni)) {
+        if (ni & 1) continue;
+        const int gn = (nt0 + ni) * 16 + 8 * g;  // N % (16 NI) == 0: all in or all out
+        const unsigned off = gn < N ? rofs[mi] + (unsigned)gn * 2u : K4_OOB;  // out-of-bounds stores are dropped
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{ov[ni][0], ov[ni][1], ov[ni + 1][0], ov[ni + 1][1]}, rsy, (int)off, 0, 0);
+      } else {
+        const int gn = (nt0 + ni) * 16 + 4 * g;
+        const unsigned off = gn < N ? rofs[mi] + (unsigned)gn * 2u : K4_OOB;
+        __builtin_amdgcn_raw_buffer_store_b64(ov[ni], rsy, (int)off, 0, 0);
+      }
+    }
+  }
+}
+
+// w1 operand of stage 2 (raw fp32, converted where it is used) and the identity of the dW1 transposes
+template <typename T>
+__device__ __forceinline__ void k4_w1_frags(const float (&w1raw)[4], typename Mma16<T>::frag& a2h, typename Mma16<T>::frag& a2l) {
+  using F4 = typename Mma16<T>::frag;
+  T h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split_f<T>(w1raw[j], h[j], l[j]);
+  a2h = *reinterpret_cast<F4*>(h);
+  a2l = *reinterpret_cast<F4*>(l);
+}
+template <typename T>
+__device__ __forceinline__ typename Mma16<T>::frag k4_identity(int li, int g) {
+  using F4 = typename Mma16<T>::frag;
+  T idv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) idv[e] = TT<T>::from_f((4 * g + e) == li ? 1.f : 0.f);
+  return *reinterpret_cast<F4*>(idv);
+}
+// cross-wave sum of the dW1 accumulators through `red` (NW KiB) and the per-workgroup partial
+template <int NW>
+__device__ __forceinline__ void k4_dw1_partial(const Kron4Args& a, float* red, const f32x4& cdw, int tid, int wave, int li, int g, int lg) {
+  const int G = 1 << lg;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * g + r) * 16 + li] = cdw[r];
+  __syncthreads();
+  if (tid < G * G) {
+    // cdw: D[i = (m', u)][j = (m'', po)], lane (col j = li, rows 4g+r); only the diagonal blocks m' == m'' count
+    const int u = tid >> lg, po = tid & (G - 1);
+    float s = 0.f;
+    for (int b = 0; b < (16 >> lg); ++b) {
+      const int e = ((b << lg) + u) * 16 + (b << lg) + po;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[256 * w + e];
+    }
+    const int e = po * a.s1o + u * a.s1i;  // position in dw1 memory order
+    const int nwg = (int)(gridDim.x * gridDim.y), me = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    a.dw1_ws[(long)me * (G * G) + e] = a.alpha * s;
+    // the consumer (lyc_lokr_wgrad_group / the dW2 launch's reducer slice) derives the block count from the layer's dimensions
+    // alone (capi.hip: lokr_dx_partial_blocks): blocks beyond this grid are written as zeros
+    for (int z = nwg + me; z < a.dw1_blocks; z += nwg) a.dw1_ws[(long)z * (G * G) + e] = 0.f;
+  }
+}
+
 // EPI: 0 = forward, 1 = forward with the fused `base + delta` epilogue, 2 = backward dx with the dW1 partials
-template <typename T, int MI, int NI, int D, int EPI>
+// NP : paired column tiles (16-byte stores, above).  ABL != 0: ablation builds of benchmarks/k4bench.cpp (results are garbage):
+//      1 = no stage-2 matrix work, 2 = no stores, 4 = no x DMA, 8 = no plane DMA, 16 = no stage-1 matrix work.
+template <typename T, int MI, int NI, int D, int EPI, bool NP = false, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS) void kron4_kernel(Kron4Args a) {
   extern __shared__ __attribute__((aligned(1024))) char k4_smem[];
   using F8 = typename TT<T>::frag;
@@ -105,24 +272,17 @@ __global__ __launch_bounds__(NTHREADS) void kron4_kernel(Kron4Args a) {
       w1raw[j] = ((kk >> lg) == mi_) ? v : 0.f;
     }
   }
-  // output-row bookkeeping (also the addresses of base / xref): row R = (m, p) of this lane per mi, first column per ni
+  // output-row bookkeeping (also the addresses of base / xref): row R = (m, p) of this lane per mi
   unsigned rofs[MI];  // R * N * 2 bytes, or out of bounds for rows >= rows_total
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int R = row0 + (wave * MI + mi) * 16 + li;
     rofs[mi] = R < a.rows_total ? (unsigned)R * (unsigned)N * 2u : K4_OOB;
   }
-  u32x2 auxv[AUX ? MI : 1][AUX ? NI : 1];
+  u32x2 auxv[MI][NI];
   if constexpr (AUX) {
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.aux), 0, (int)a.y_bytes, K4_RSRC_FLAGS);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int gn = (nt0 + ni) * 16 + 4 * g;
-        const unsigned off = gn < N ? rofs[mi] + (unsigned)gn * 2u : K4_OOB;  // out of bounds reads as zero
-        auxv[mi][ni] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsa, (int)off, 0, 0));
-      }
+    k4_load_aux<MI, NI, NP>(auxv, rsa, rofs, nt0, N, g);
   }
 
   // ---- DMA addressing ------------------------------------------------------------------------------------------------------------
@@ -153,24 +313,29 @@ __global__ __launch_bounds__(NTHREADS) void kron4_kernel(Kron4Args a) {
   for (int j = 0; j < PPW; ++j) {
     const int p = wave + NWAVES * j;
     preal[j] = p < 2 * NI;
-    int nt = nt0 + (p >> 1);
+    const int ni = p >> 1;
+    int nt = nt0 + k4_plane_tile<NI, NP>(ni);
     if (nt > ntiles - 1) nt = ntiles - 1;  // beyond N: a valid duplicate, its columns are never stored
     pbase[j] = ((unsigned)(nt * KS) * 2u + (unsigned)(p & 1)) * 1024u;
-    pv[j] = preal[j] ? (unsigned)lane * 16u : K4_OOB;
+    pv[j] = preal[j] ? k4_plane_voff<NI, NP>(lane, ni, KS) : K4_OOB;
     pdst[j] = preal[j] ? p * 1024 : OFF_TRASH + wave * 1024;
   }
   auto issue = [&](int ks, int slot) {
     const bool last = ks == KS - 1;
     const unsigned sx = (unsigned)ks * 64u;
+    if constexpr ((ABL & 4) == 0) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      char* dst = k4_smem + OFF_X + slot * SLOT_X + (wave * MI + mi) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (k4_lds_ptr)dst, 16, (int)(last ? vxl[mi] : vx[mi]), (int)sx, 0, 0);
+      for (int mi = 0; mi < MI; ++mi) {
+        char* dst = k4_smem + OFF_X + slot * SLOT_X + (wave * MI + mi) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (k4_lds_ptr)dst, 16, (int)(last ? vxl[mi] : vx[mi]), (int)sx, 0, 0);
+      }
     }
+    if constexpr ((ABL & 8) == 0) {
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-      char* dst = k4_smem + (preal[j] ? slot * SLOT_P : 0) + pdst[j];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (k4_lds_ptr)dst, 16, (int)pv[j], (int)(pbase[j] + (unsigned)ks * 2048u), 0, 0);
+      for (int j = 0; j < PPW; ++j) {
+        char* dst = k4_smem + (preal[j] ? slot * SLOT_P : 0) + pdst[j];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (k4_lds_ptr)dst, 16, (int)pv[j], (int)(pbase[j] + (unsigned)ks * 2048u), 0, 0);
+      }
     }
   };
 
@@ -205,104 +370,39 @@ __global__ __launch_bounds__(NTHREADS) void kron4_kernel(Kron4Args a) {
       bh[ni] = *reinterpret_cast<const F8*>(ps + ni * 2048);
       bl[ni] = *reinterpret_cast<const F8*>(ps + ni * 2048 + 1024);
     }
+    if constexpr ((ABL & 16) != 0) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT<T>::mma(af[mi], bh[ni], acc[mi][ni]);
+        for (int mi = 0; mi < MI; ++mi)
+          acc[mi][ni] += __builtin_bit_cast(f32x4, af[mi]) + __builtin_bit_cast(f32x4, bh[ni]) + __builtin_bit_cast(f32x4, bl[ni]);
+    } else {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT<T>::mma(af[mi], bl[ni], acc[mi][ni]);
+        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT<T>::mma(af[mi], bh[ni], acc[mi][ni]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT<T>::mma(af[mi], bl[ni], acc[mi][ni]);
+    }
     prev = slot;
     slot = slot + 1 == D ? 0 : slot + 1;
   }
   LYC_STAMP(4);
 
-  // ---- epilogue, all in registers (kron3.h) ------------------------------------------------------------------------------------------
-  F4 a2h, a2l;
-  {
-    T h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) split_f<T>(w1raw[j], h[j], l[j]);
-    a2h = *reinterpret_cast<F4*>(h);
-    a2l = *reinterpret_cast<F4*>(l);
-  }
-  F4 ident;  // identity as a B operand: B[k = 4g+e][j = li]
-  if constexpr (EPI == 2) {
-    T idv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) idv[e] = TT<T>::from_f((4 * g + e) == li ? 1.f : 0.f);
-    ident = *reinterpret_cast<F4*>(idv);
-  }
+  // ---- epilogue, all in registers -------------------------------------------------------------------------------------------------
+  F4 a2h, a2l, ident = {};
+  k4_w1_frags<T>(w1raw, a2h, a2l);
+  if constexpr (EPI == 2) ident = k4_identity<T>(li, g);
   const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.y_bytes, K4_RSRC_FLAGS);
   f32x4 cdw = zero4();
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int gn = (nt0 + ni) * 16 + 4 * g;  // first of this lane's 4 output columns (N % 4 == 0: all in or all out)
-      T h[4], l[4];
-      k3_split4<T>(acc[mi][ni], h, l);
-      const F4 sh = *reinterpret_cast<F4*>(h), sl = *reinterpret_cast<F4*>(l);
-      f32x4 yv = zero4();
-      yv = Mma16<T>::mma(sh, a2h, yv);
-      yv = Mma16<T>::mma(sl, a2h, yv);
-      yv = Mma16<T>::mma(sh, a2l, yv);
-      float bb[4] = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (EPI == 1) {  // fused `base + delta`: fp32 add, one rounding
-        T bt[4];
-        *reinterpret_cast<u32x2*>(bt) = auxv[mi][ni];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bb[e] = TT<T>::to_f(bt[e]);
-      }
-      T o[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = TT<T>::from_f(a.alpha * yv[e] + bb[e]);
-      const unsigned off = gn < N ? rofs[mi] + (unsigned)gn * 2u : K4_OOB;  // out-of-bounds stores are dropped
-      __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<u32x2*>(o), rsy, (int)off, 0, 0);
-      if constexpr (EPI == 2) {
-        // S1 (hi, lo) transposed through the matrix core: lane (li = row, 4g+e = n) -- exact, the values are T
-        const f32x4 th = Mma16<T>::mma(sh, ident, zero4());
-        const f32x4 tl = Mma16<T>::mma(sl, ident, zero4());
-        T thv[4], tlv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          thv[e] = TT<T>::from_f(th[e]);
-          tlv[e] = TT<T>::from_f(tl[e]);
-        }
-        const F4 bf = *reinterpret_cast<const F4*>(&auxv[mi][ni]);  // xref fragment B[k = n][j = row li]; zero outside the matrix
-        cdw = Mma16<T>::mma(*reinterpret_cast<F4*>(thv), bf, cdw);
-        cdw = Mma16<T>::mma(*reinterpret_cast<F4*>(tlv), bf, cdw);
-      }
-    }
-  }
+  k4_epilogue<T, MI, NI, EPI, NP, ABL>(acc, a2h, a2l, ident, auxv, rofs, rsy, nt0, N, g, a.alpha, cdw);
   LYC_STAMP(5);
   LYC_TRACE_FLUSH();
-
-  if constexpr (EPI == 2) {
-    // cdw: D[i = (m', u)][j = (m'', po)], lane (col j = li, rows 4g+r); only the diagonal blocks m' == m'' count.  Cross-wave sum
-    // through the trash slot (every DMA of this workgroup has landed: the last k step waited vmcnt(0) in every wave... of ITS
-    // OWN operations -- hence the barrier before the writes).
-    float* red = reinterpret_cast<float*>(k4_smem + OFF_TRASH);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * g + r) * 16 + li] = cdw[r];
-    __syncthreads();
-    if (tid < G * G) {
-      const int u = tid >> lg, po = tid & (G - 1);
-      float s = 0.f;
-      for (int b = 0; b < (16 >> lg); ++b) {
-        const int e = ((b << lg) + u) * 16 + (b << lg) + po;
-        s += red[e] + red[256 + e] + red[512 + e] + red[768 + e];
-      }
-      const int e = po * a.s1o + u * a.s1i;  // position in dw1 memory order
-      const int nwg = (int)(gridDim.x * gridDim.y), me = (int)(blockIdx.y * gridDim.x + blockIdx.x);
-      a.dw1_ws[(long)me * (G * G) + e] = a.alpha * s;
-      // the consumer (lyc_lokr_wgrad_group / the dW2 launch's reducer slice) derives the block count from the layer's dimensions
-      // alone (capi.hip: lokr_dx_partial_blocks): blocks beyond this grid are written as zeros
-      for (int z = nwg + me; z < a.dw1_blocks; z += nwg) a.dw1_ws[(long)z * (G * G) + e] = 0.f;
-    }
-  }
+  // (the trash slot: every DMA of this workgroup has landed -- the last k step waited vmcnt(0) in every wave, of ITS OWN operations;
+  //  k4_dw1_partial starts with a barrier)
+  if constexpr (EPI == 2) k4_dw1_partial<NWAVES>(a, reinterpret_cast<float*>(k4_smem + OFF_TRASH), cdw, tid, wave, li, g, lg);
 }
 
 }  // namespace lyc
