@@ -71,6 +71,8 @@ def parse():
                     help="A/B: no pre-packed LoKr operand planes (every workgroup converts its fp32 w2 tile, as in rounds 1-2)")
     ap.add_argument("--no-reference", action="store_true", help="skip the PyTorch-ROCm eager comparator leg")
     ap.add_argument("--no-base", action="store_true", help="skip the base+adapter leg")
+    ap.add_argument("--no-per-algo", action="store_true",
+                    help="skip the per_algo object (short runs of the other BASELINE configs in child processes)")
     ap.add_argument("--shared-inputs", action="store_true",
                     help="development: instances of one shape share x / g (cache-resident, the round-1 behaviour)")
     ap.add_argument("--eager", action="store_true", help="time the step without hipGraph capture (Python-driven)")
@@ -409,8 +411,12 @@ def main():
     model_name = "SDXL UNet 1024x1024 bs=1/GPU" if args.model == "sdxl" else "SD1.5 UNet 512x512 bs=4/GPU"
     n_lin = sum(1 for it in insts if it.spec["kind"] == "linear")
     result = {
-        "metric": f"{'SDXL' if args.model == 'sdxl' else 'SD1.5'} UNet adapter train steps/sec "
-                  f"(bs={'1' if args.model == 'sdxl' else '4'}/GPU), " + ALGO_LABEL[args.algo],
+        # BASELINE.json's metric, verbatim; `value` = the hot path of this repository (adapter fwd + bwd + grad sync + AdamW over every
+        # adapted layer), `value_base_plus_adapter` = the same step with the frozen layers' own ops in it
+        "metric": "SDXL UNet train steps/sec (bs=1/GPU) per algo at 1/2/4/8 MI355X",
+        "metric_detail": f"{'SDXL' if args.model == 'sdxl' else 'SD1.5'} UNet adapter train steps/sec "
+                         f"(bs={'1' if args.model == 'sdxl' else '4'}/GPU), " + ALGO_LABEL[args.algo]
+                         + "; value = adapter-only step (frozen UNet ops not timed), value_base_plus_adapter = with them",
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
@@ -437,10 +443,12 @@ def main():
     if extra and not args.no_reference and args.algo in ("lokr", "locon", "loha"):
         result["reference_rocm_eager"] = reference_leg(insts, sync, ms_per_step)
     if extra and not args.no_base and args.algo in ("lokr", "locon", "loha"):
-        result["base_plus_adapter"] = base_leg(insts, sync)
-        # SURVEY 8d defines the step WITH the frozen layers' forward + dx ops: the contract number next to `value`
-        # (forward + backward of base and adapter; the optimizer and arena fill add ~1.3 ms more, see ms_per_step)
-        result["value_base_plus_adapter"] = round(1e3 / result["base_plus_adapter"]["base_plus_adapter_ms"], 3)
+        result["base_plus_adapter"] = base_leg(insts, sync, opt, _ops)
+        # SURVEY 8d defines the step WITH the frozen layers' forward + dx ops, the arena fill and AdamW: the contract number next
+        # to `value`
+        result["value_base_plus_adapter"] = round(1e3 / result["base_plus_adapter"]["step_ms"], 3)
+    if extra and not args.no_per_algo and args.algo == "lokr" and args.model == "sdxl" and not args.rank and args.layers == "all":
+        result["per_algo"] = per_algo_legs()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.algo in ("lokr", "locon", "loha"):
         result["cpu_baseline"] = cpu_baseline(args.algo, args.model)
     if args.rccl_ws1:
@@ -687,12 +695,12 @@ def roofline(insts, args, dtype, dev):
         k3_ms, k3_bytes = t_fwd + t_dx, b_fwd + b_dx
         ach = k3_bytes / (k3_ms * 1e-3) / 1e9
         hot = nbytes / ((t_fwd + t_dx + t_wg) * 1e-3) / 1e9
-        out["families_ms"] = {"kron3_forward": round(t_fwd, 3), "kron3_backward_dx_dw1": round(t_dx, 3),
+        out["families_ms"] = {"kron_forward": round(t_fwd, 3), "kron_backward_dx_dw1": round(t_dx, 3),
                               "kron_dw2s_grouped": round(t_wg, 3), "kron_dw2s_one_launch_per_layer": round(t_dw2, 3),
                               "backward_one_call_per_layer": round(t_bwd, 3)}
         out.update({"operand_planes": bool(use_planes),
-                    "kernel": "lyc::kron3_kernel (LoKr forward + backward dx / dW1 launches of the Linear layers"
-                              + (", w2 from pre-packed hi/lo planes by LDS-DMA" if use_planes else "") + "); the weight "
+                    "kernel": ("lyc::kron4_kernel" if use_planes else "lyc::kron3_kernel") + " (LoKr forward + backward dx / dW1 launches of the "
+                              "Linear layers" + (", both operands by LDS-DMA, w2 from pre-packed hi/lo planes" if use_planes else "") + "); the weight "
                               "gradients run grouped (lyc::kron_dw2s_group_kernel, 24 layers per launch, re-reads g and x): "
                               "families_ms",
                     "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -702,6 +710,55 @@ def roofline(insts, args, dtype, dev):
                     "backward_gbs": round(b_bwd / ((t_dx + t_wg) * 1e-3) / 1e9, 1),
                     "dw2s_grouped_gbs": round(b_dw2 / (t_wg * 1e-3) / 1e9, 1),
                     "dw2s_per_layer_gbs": round(b_dw2 / (t_dw2 * 1e-3) / 1e9, 1)})
+        # per shape: forward and dx launches of each distinct Linear shape in their own graphs (<= 12 instances,
+        # every instance its own x / g), HIP events.  mfma_model = matrix-core busy fraction from the launch's instruction count
+        # (stage 1: 2 v_mfma_16x16x32 per 16x16x32 block, stage 2: 3 v_mfma_16x16x16 per 16x16 tile, + 4 with dW1; 16 cycles each)
+        # over 1024 SIMDs at 2.1 GHz -- the measured counters are in profiles/ (r04_pmc_*).
+        shapes = {}
+        for k, cl in enumerate(calls):
+            key = layer_rows(cl[0].spec)
+            shapes.setdefault(key, []).append(k)
+        table = []
+        for (M, I, O), idx in sorted(shapes.items(), key=lambda kv: -len(kv[1])):
+            idx = idx[:12]
+            sub = [calls[k] for k in idx]
+
+            def f_sub():
+                for it, rows, g, fs, bufs in sub:
+                    (a, b), (c, d) = fs[0].shape, fs[1].shape
+                    if use_planes:
+                        y = torch.empty(rows.shape[0], a * c, dtype=dtype, device=dev)
+                        N.call("lyc_lokr_linear_fwd_planes", N.ptr(rows), N.ptr(fs[0]), N.ptr(planes[id(it)][0]), None, N.ptr(y), rows.shape[0],
+                               a, b, c, d, 1.0, code, N.stream_ptr(dev))
+                    else:
+                        core.fwd(rows, fs, 1.0)
+
+            def b_sub():
+                for k in idx:
+                    it, rows, g, fs, bufs = calls[k]
+                    (a, b), (c, d) = fs[0].shape, fs[1].shape
+                    if use_planes:
+                        N.call("lyc_lokr_linear_bwd_planes", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(planes[id(it)][1]), N.ptr(dxs[k]),
+                               N.ptr(bufs[0]), None, N.ptr(wss[k]), rows.shape[0], a, b, c, d, 1.0, code | 0x200, N.stream_ptr(dev))
+                    else:
+                        N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(dxs[k]), N.ptr(bufs[0]),
+                               None, N.ptr(wss[k]), rows.shape[0], a, b, c, d, 1.0, code | 0x200, N.stream_ptr(dev))
+
+            tf = _graph_ms(f_sub) * 1e3 / len(idx)
+            tb = _graph_ms(b_sub) * 1e3 / len(idx)
+            bf_, bb_ = esz * M * (I + O), esz * M * (O + 2 * I)
+            rows8, Kf, Nf = M * FACTOR, I // FACTOR, O // FACTOR
+
+            def mfma_frac(K, Nn, us, dw1):
+                tiles = -(-rows8 // 16) * -(-Nn // 16)
+                n = tiles * (2 * -(-K // 32) + 3 + (4 if dw1 else 0))
+                return n * 16 / (1024 * us * 1e-6 * 2.1e9)
+            table.append({"M": M, "I": I, "O": O, "count": len(shapes[(M, I, O)]),
+                          "fwd_us": round(tf, 2), "fwd_gbs": round(bf_ / tf * 1e-3, 1), "fwd_frac": round(bf_ / tf * 1e-3 / HBM_PEAK_GBS, 4),
+                          "fwd_mfma_model": round(mfma_frac(Kf, Nf, tf, False), 3),
+                          "bwd_us": round(tb, 2), "bwd_gbs": round(bb_ / tb * 1e-3, 1), "bwd_frac": round(bb_ / tb * 1e-3 / HBM_PEAK_GBS, 4),
+                          "bwd_mfma_model": round(mfma_frac(Nf, Kf, tb, True), 3)})
+        out["per_shape"] = table
         conv = conv_leg(insts, args, dtype)
         if conv:
             out["conv"] = conv
@@ -821,7 +878,32 @@ def reference_leg(insts, sync, native_graph_ms):
             "speedup_native_graph_vs_reference_eager": round(ref_eager / nat_graph, 2)}
 
 
-def base_leg(insts, sync):
+def per_algo_legs():
+    """BASELINE.json's other single-GPU configurations, driver-run: LoCon SDXL, LoCon SD1.5 bs 4 (configs[1]), LoHa SDXL (configs[2]),
+    (IA)^3, mixed preset fp16 (configs[4]) -- each a short run of this script in a child process (its own 6 GB of activations),
+    reduced to ms / step and the roofline of its dominant kernel family."""
+    import subprocess
+    legs = [("locon_sdxl", ["--algo", "locon"]), ("locon_sd15_bs4", ["--algo", "locon", "--model", "sd15"]),
+            ("loha_sdxl", ["--algo", "loha"]), ("ia3_sdxl", ["--algo", "ia3"]), ("mixed_sdxl_fp16", ["--algo", "mixed", "--dtype", "fp16"])]
+    out = {}
+    for name, extra in legs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-reference",
+               "--no-base", "--no-per-algo"] + extra
+        try:
+            t0 = time.perf_counter()
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")][-1]
+            d = json.loads(line)
+            rl = d.get("roofline") or {}
+            out[name] = {"ms_per_step": d["ms_per_step"], "steps_per_s": d["value"], "dtype": d["dtype"], "layers": d["config"]["layers"],
+                         "roofline": {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "families_ms") if k in rl},
+                         "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:  # a failing leg must not take the headline line down
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
+def base_leg(insts, sync, opt=None, ops_=None):
     """the step with the frozen layers' own ops in it (rocBLAS / MIOpen forward + dx-only backward), next to
     the adapter-only number: base alone, and base + adapter (out = base + delta, one autograd.grad for both)."""
     def one_backward(outs):  # ONE engine invocation for all layers, as loss.backward() is one for a real network
@@ -869,9 +951,29 @@ def base_leg(insts, sync):
         for it in insts:
             it.W = None
         torch.cuda.empty_cache()
+    # the rest of the step: arena fill, plane refresh, fused AdamW (eager launches, HIP events on the current stream)
+    t_rest = 0.0
+    if opt is not None:
+        def rest():
+            for arena in sync.arenas.values():
+                arena.zero_()
+            ops_.refresh_lokr_planes(force=True)
+            opt.step()
+        rest()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(3):
+            rest()
+        e1.record()
+        e1.synchronize()
+        t_rest = e0.elapsed_time(e1) / 3
     out = {"base_only_ms": round(t_base, 2), "base_plus_adapter_ms": round(t_both, 2),
+           "fill_refresh_adamw_ms": round(t_rest, 2), "step_ms": round(t_both + t_rest, 2),
            "adapter_share": round(max(t_both - t_base, 0.0) / t_both, 3),
-           "what": "frozen F.linear / F.conv2d forward + input-gradient backward of the same layers (random bf16 weights)"}
+           "what": "frozen F.linear / F.conv2d forward + input-gradient backward of the same layers (random bf16 weights) with the "
+                   "adapter forward / backward in the same hipGraph; step_ms adds the gradient-arena fill, the operand-plane refresh "
+                   "and fused AdamW over the adapter parameters"}
     if t_ov is not None:
         out["base_plus_adapter_overlapped_ms"] = round(t_ov, 2)
         out["overlap"] = "adapter launches of every layer on a side HIP stream, forked / joined per layer (captured in the same hipGraph)"
@@ -879,10 +981,11 @@ def base_leg(insts, sync):
 
 
 def cpu_baseline(algo, model):
-    """The reference's CPU path (rebuild: dW -> dense op -> autograd), restated in oracle/torch_cpu.py, timed on the host
-    cores of this box on a BOUNDED sample (~15 s): one instance of every distinct Linear shape, fp32 and bf16, 3 reps
-    after a warm-up; conv shapes with <= 4096 output pixels once in fp32 while the budget lasts.  The step time is
-    extrapolated with the per-shape counts (unmeasured conv shapes charged at the measured per-MAC conv cost)."""
+    """The reference's CPU path (rebuild: dW -> dense op -> autograd), restated in oracle/torch_cpu.py (the Python reference cannot
+    travel to the GPU box), timed on the host cores of this box on a BOUNDED sample (~25 s): one instance of every distinct Linear
+    shape, fp32 and bf16, best of 3 after a warm-up; then EVERY distinct Conv2d shape once in fp32, smallest first, while the budget
+    lasts (no per-MAC charge for shapes that were timed).  The step time is the sum over the shape counts; a conv
+    shape the budget did not reach is charged at the per-MAC cost of the largest conv that was timed with the same window, and says so."""
     from oracle import torch_cpu
     cores = min(os.cpu_count() or 1, 64)  # beyond ~64 threads the small GEMMs only oversubscribe
     torch.set_num_threads(cores)
@@ -902,47 +1005,52 @@ def cpu_baseline(algo, model):
         return [torch.randn(O, 32) * 0.1, torch.randn(32, cin * kk), torch.randn(O, 32) * 0.1, torch.randn(32, cin * kk)]
 
     t_start = time.perf_counter()
-    budget = 18.0
-    tot = {"fp32": 0.0, "bf16": 0.0}
-    seen, measured, conv_macs_left, mac_cost = {}, 0, 0, 0.0
-    r16 = [0.0, 0.0]  # bf16 / fp32 seconds over the shapes timed in both
-    for spec in specs:
-        M, Ie, O = layer_rows(spec)
-        macs = spec["count"] * M * Ie * O
-        key = (spec["kind"], M, Ie, O, spec.get("stride", 1))
-        if key in seen:
-            tot["fp32"] += seen[key]["fp32"] * spec["count"]
-            tot["bf16"] += (seen[key]["bf16"] if seen[key]["bf16"] is not None else float("nan")) * spec["count"]
-            continue
-        over = time.perf_counter() - t_start > budget
-        if spec["kind"] == "conv" and (M > 4096 or over):
-            conv_macs_left += macs
-            continue
-        if over:
-            conv_macs_left += macs  # charged like a conv MAC (pessimistic for the few remaining Linear shapes)
-            continue
-        t32 = torch_cpu.time_layer(algo, spec, factors, torch.float32, reps=3 if spec["kind"] == "linear" else 1)
-        t16 = None
-        if spec["kind"] == "linear" and t32 < 0.4 and time.perf_counter() - t_start < budget * 0.6:
-            t16 = torch_cpu.time_layer(algo, spec, factors, torch.bfloat16, reps=3)
-            r16[0] += t16
-            r16[1] += t32
-        seen[key] = {"fp32": t32, "bf16": t16}
-        tot["fp32"] += t32 * spec["count"]
-        tot["bf16"] += (t16 if t16 is not None else float("nan")) * spec["count"]
-        measured += 1
-        if spec["kind"] == "conv":
-            mac_cost = max(mac_cost, t32 / (M * Ie * O))
-    tot["fp32"] += conv_macs_left * mac_cost
-    # bf16: shapes not timed in bf16 (convs, slow or late shapes) are scaled by the measured bf16 / fp32 ratio
+    budget = 26.0
+    key_of = lambda sp: (sp["kind"], *layer_rows(sp), sp.get("k", 1), sp.get("stride", 1))
+    distinct = {}
+    for sp in specs:
+        distinct.setdefault(key_of(sp), [sp, 0])[1] += sp["count"]
+    lin = [v for k, v in distinct.items() if k[0] == "linear"]
+    conv = sorted([v for k, v in distinct.items() if k[0] != "linear"], key=lambda v: np_prod(layer_rows(v[0])))
+    t32, t16 = {}, {}
+    r16 = [0.0, 0.0]
+    for sp, cnt in lin:
+        k = key_of(sp)
+        t32[k] = torch_cpu.time_layer(algo, sp, factors, torch.float32, reps=3)
+        if t32[k] < 0.4 and time.perf_counter() - t_start < budget * 0.45:
+            t16[k] = torch_cpu.time_layer(algo, sp, factors, torch.bfloat16, reps=3)
+            r16[0] += t16[k]
+            r16[1] += t32[k]
+    timed_conv, charged = 0, []
+    per_mac = {}  # window size -> (macs, seconds) of the largest conv timed
+    for sp, cnt in conv:
+        k = key_of(sp)
+        macs = np_prod(layer_rows(sp))
+        if time.perf_counter() - t_start < budget:
+            t32[k] = torch_cpu.time_layer(algo, sp, factors, torch.float32, reps=1)
+            timed_conv += 1
+            per_mac[sp["k"]] = (macs, t32[k])
+        else:
+            ref = per_mac.get(sp["k"]) or max(per_mac.values(), default=(1, 0.0))
+            t32[k] = macs * ref[1] / ref[0]
+            charged.append(f"{sp['C']}->{sp['O']}@{sp['H']} k{sp['k']}s{sp['stride']}")
+    tot32 = sum(t32[key_of(sp)] * cnt for sp, cnt in lin + conv)
     ratio16 = r16[0] / r16[1] if r16[1] > 0 else None
-    return {"value": round(1.0 / tot["fp32"], 5), "unit": "steps/s", "cores": cores, "kind": "port",
+    return {"value": round(1.0 / tot32, 5), "unit": "steps/s", "cores": cores, "kind": "port",
             "bf16_over_fp32_time_ratio": round(ratio16, 3) if ratio16 else None,
-            "bf16_value": round(1.0 / (tot["fp32"] * ratio16), 5) if ratio16 else None,
-            "sample": f"oracle/torch_cpu.py (reference rebuild path restated in torch CPU ops), {measured} distinct layer shapes "
-                      f"(Linear: fp32 and bf16, best of 3 after a warm-up; small convs once, fp32) in "
-                      f"{time.perf_counter() - t_start:.1f}s, extrapolated by shape counts to the whole step; conv shapes with "
-                      "> 4096 output pixels charged per MAC at the slowest measured conv"}
+            "bf16_value": round(1.0 / (tot32 * ratio16), 5) if ratio16 else None,
+            "sample": f"oracle/torch_cpu.py (reference rebuild path restated in torch CPU ops): {len(lin)} distinct Linear shapes (fp32 and "
+                      f"bf16, best of 3 after a warm-up) and {timed_conv} of {len(conv)} distinct Conv2d shapes (fp32, once, smallest first) "
+                      f"timed in {time.perf_counter() - t_start:.1f}s; step time = sum over the shape counts"
+                      + (f"; NOT reached by the budget, charged per MAC of the largest timed conv with the same window: {', '.join(charged)}"
+                         if charged else "")}
+
+
+def np_prod(t):
+    r = 1
+    for v in t:
+        r *= int(v)
+    return r
 
 
 if __name__ == "__main__":
