@@ -678,8 +678,18 @@ def roofline(insts, args, dtype, dev):
                     N.call("lyc_lokr_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(dxs[k]), N.ptr(bufs[0]),
                            None, N.ptr(wss[k]), rows.shape[0], a, b, c, d, 1.0, code | 0x200, N.stream_ptr(dev))
 
-        def grouped_wgrad():
+        tb = int(N.load().lyc_lokr_wgrad_table_bytes(len(calls)))
+        wg_table = torch.empty(tb, dtype=torch.uint8, device=dev)
+        _KEEP.append(wg_table)
+
+        def grouped_wgrad():  # as csrc/torch_ops.cpp flushes them: problem table in device scratch, one launch per tile class
+            N.call("lyc_lokr_wgrad_group_ws", ctypes.cast(items, ctypes.c_void_p), len(calls), code, N.ptr(wg_table), tb, N.stream_ptr(dev))
+
+        def grouped_wgrad_24():  # without the scratch: 24 layers per launch (kernel arguments)
             N.call("lyc_lokr_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(calls), code, N.stream_ptr(dev))
+
+        def grouped_wgrad_tile_s():  # the round 1-3 tile plan (LYC_WGRAD_TILE_S), A/B leg
+            N.call("lyc_lokr_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(calls), code | 0x400, N.stream_ptr(dev))
 
         def per_layer_dw2():
             for it, rows, g, fs, bufs in calls:
@@ -689,6 +699,8 @@ def roofline(insts, args, dtype, dev):
 
         t_dx = _graph_ms(only_dx)
         t_wg = _graph_ms(grouped_wgrad)
+        t_wg_24 = _graph_ms(grouped_wgrad_24)
+        t_wg_s = _graph_ms(grouped_wgrad_tile_s)
         t_dw2 = _graph_ms(per_layer_dw2)
         b_dw2 = sum(esz * (it.spec["M"] * (it.spec["I"] + it.spec["O"])) + 4 * sum(p.numel() for p in it.params) for it in lin)
         b_dx = b_bwd  # g + x (dW1) + dx + factors: the SURVEY 8d backward bytes belong to this launch
@@ -696,19 +708,21 @@ def roofline(insts, args, dtype, dev):
         ach = k3_bytes / (k3_ms * 1e-3) / 1e9
         hot = nbytes / ((t_fwd + t_dx + t_wg) * 1e-3) / 1e9
         out["families_ms"] = {"kron_forward": round(t_fwd, 3), "kron_backward_dx_dw1": round(t_dx, 3),
-                              "kron_dw2s_grouped": round(t_wg, 3), "kron_dw2s_one_launch_per_layer": round(t_dw2, 3),
+                              "kron_dw2_grouped": round(t_wg, 3), "kron_dw2_grouped_24_per_launch": round(t_wg_24, 3),
+                              "kron_dw2_grouped_narrow_tiles_r3": round(t_wg_s, 3),
+                              "kron_dw2s_one_launch_per_layer": round(t_dw2, 3),
                               "backward_one_call_per_layer": round(t_bwd, 3)}
         out.update({"operand_planes": bool(use_planes),
                     "kernel": ("lyc::kron4_kernel" if use_planes else "lyc::kron3_kernel") + " (LoKr forward + backward dx / dW1 launches of the "
                               "Linear layers" + (", both operands by LDS-DMA, w2 from pre-packed hi/lo planes" if use_planes else "") + "); the weight "
-                              "gradients run grouped (lyc::kron_dw2s_group_kernel, 24 layers per launch, re-reads g and x): "
+                              "gradients run grouped (lyc::kron_dw2f_table_kernel: full-width output tiles, one launch per tile class, re-reads g and x): "
                               "families_ms",
                     "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
                     "avg_launch_us": round(k3_ms * 1e3 / (2 * n_l), 2), "launches_per_layer": 2,
                     "algorithmic_bytes_per_launch": int(k3_bytes / (2 * n_l)),
                     "hot_path_gbs": round(hot, 1), "hot_path_frac": round(hot / HBM_PEAK_GBS, 4),
                     "backward_gbs": round(b_bwd / ((t_dx + t_wg) * 1e-3) / 1e9, 1),
-                    "dw2s_grouped_gbs": round(b_dw2 / (t_wg * 1e-3) / 1e9, 1),
+                    "dw2_grouped_gbs": round(b_dw2 / (t_wg * 1e-3) / 1e9, 1),
                     "dw2s_per_layer_gbs": round(b_dw2 / (t_dw2 * 1e-3) / 1e9, 1)})
         # per shape: forward and dx launches of each distinct Linear shape in their own graphs (<= 12 instances,
         # every instance its own x / g), HIP events.  mfma_model = matrix-core busy fraction from the launch's instruction count

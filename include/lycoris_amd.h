@@ -28,10 +28,13 @@ extern "C" {
 enum { LYC_F32 = 0, LYC_F16 = 1, LYC_BF16 = 2 };
 /* OR-able into `dtype`: the row-matrix side of the call (dx of the *_linear_bwd entry points, dcols of lyc_col2im)
  * is fp32 instead of `dtype`.  Used by the Conv2d lowering so that col2im sums un-rounded rows and rounds once. */
-enum { LYC_F32_ROWS = 0x100, LYC_DEFER_WGRAD = 0x200 };
+enum { LYC_F32_ROWS = 0x100, LYC_DEFER_WGRAD = 0x200,
+       /* lyc_lokr_wgrad_group only: use the round 1-3 tile plan (80 x 32 outputs per wave, rows split over the waves: kron_dw2s.h) for
+        * every item instead of the full-width tiles of kron_dw2f.h -- the A/B and regression-test switch (an argument, not getenv) */
+       LYC_WGRAD_TILE_S = 0x400 };
 enum { LYC_OK = 0, LYC_ERR_ARG = 1, LYC_ERR_UNSUPPORTED = 2, LYC_ERR_LAUNCH = 3 };
 
-#define LYC_ABI_VERSION 8
+#define LYC_ABI_VERSION 9
 int lyc_abi_version(void);
 const char* lyc_last_error(void);
 
@@ -75,6 +78,13 @@ typedef struct LycLokrWgradItem {
 } LycLokrWgradItem;
 int lyc_lokr_wgrad_deferrable(const void* g, const void* x, int64_t M, int a, int b, int c, int d, int dtype);
 int lyc_lokr_wgrad_group(const LycLokrWgradItem* items, int n, int dtype, void* stream);
+/* The same with a caller-owned device scratch of lyc_lokr_wgrad_table_bytes(n) bytes (16-byte aligned, alive until the launches have
+ * run): the problems are then written to a table in that scratch and ALL layers of a tile class run in ONE launch (round 4: no
+ * launch tails between groups of 24 layers, two workgroups per CU throughout) instead of ceil(n / 24).  table == NULL or
+ * table_bytes too small: exactly lyc_lokr_wgrad_group.  Capture-safe: the table is written by kernels whose arguments carry the
+ * problems, not by a host copy. */
+int64_t lyc_lokr_wgrad_table_bytes(int n);
+int lyc_lokr_wgrad_group_ws(const LycLokrWgradItem* items, int n, int dtype, void* table, int64_t table_bytes, void* stream);
 
 /* The same for LoCon on nn.Linear: call lyc_locon_linear_bwd with d_down == d_up == NULL (dx launch only; `dt` is still
  * written), keep (g, x, t, dt) alive, and hand batches to lyc_locon_wgrad_group: d_up += alpha * g^T t, d_down += dt^T x for

@@ -13,7 +13,7 @@ import torch
 
 _LIB_NAME = "liblycoris_amd.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 LYC_F32, LYC_F16, LYC_BF16 = 0, 1, 2
 _DTYPE_CODE = {torch.float32: LYC_F32, torch.float16: LYC_F16, torch.bfloat16: LYC_BF16}
@@ -25,6 +25,7 @@ SIGNATURES = {
     "lyc_lokr_linear_fwd": [_vp, _fp, _fp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_lokr_linear_bwd": [_vp, _vp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_lokr_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of WgradItem
+    "lyc_lokr_wgrad_group_ws": [_vp, _i32, _i32, _vp, _i64, _vp],  # + device scratch of lyc_lokr_wgrad_table_bytes(n)
     "lyc_locon_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LoconWgradItem
     "lyc_loha_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LohaWgradItem
     "lyc_lokr_conv2d_fwd": [_vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
@@ -67,6 +68,7 @@ VALUE_SIGNATURES = {
     "lyc_lokr_linear_planes_ok": ([_i64, _i32, _i32, _i32, _i32, _i32], ctypes.c_int),
     "lyc_lokr_conv2d_dx_blocks": ([_i64, _i64, _i64] + [_i32] * 14, ctypes.c_int64),
     "lyc_lokr_conv2d_planes_ok": ([_i64, _i64, _i64] + [_i32] * 14, ctypes.c_int),
+    "lyc_lokr_wgrad_table_bytes": ([_i32], ctypes.c_int64),
     "lyc_lokr_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32], ctypes.c_int),  # 1 / 0, not an error code
     "lyc_locon_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32], ctypes.c_int),
     "lyc_loha_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32], ctypes.c_int),

@@ -1,6 +1,8 @@
 // capi.hip -- C ABI launchers (include/lycoris_amd.h).  gfx950 only.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <algorithm>
+#include <unordered_map>
 #include <vector>
 #include <stdarg.h>
 #include <stdio.h>
@@ -13,6 +15,7 @@
 #include "kron3.h"
 #include "kron4.h"
 #include "kron_dw2s.h"
+#include "kron_dw2f.h"
 #include "kron_conv.h"
 #include "kron_conv_dw2.h"
 #include "loha_mfma.h"
@@ -879,10 +882,193 @@ int lyc_lokr_wgrad_deferrable(const void* g, const void* x, int64_t M, int a, in
   return lokr_wgrad_fast(g, x, M, a, b, c, d, dtype) ? 1 : 0;
 }
 
+extern "C++" {
+namespace {
+// ---- full-width tiles (kron_dw2f.h) ---------------------------------------------------------------------------------------------
+// tile classes by the factor's size: up to 80 (5 MFMA tiles) or up to 160 (10) outputs per side; every wave keeps 5 x 5 MFMA tiles
+enum { DW2F_1010 = 0, DW2F_55, DW2F_105, DW2F_510, DW2F_NCFG };
+struct Dw2fCfg { int TI, TJ, WK; };
+constexpr Dw2fCfg DW2F_CFG[DW2F_NCFG] = {{10, 10, 1}, {5, 5, 4}, {10, 5, 2}, {5, 10, 2}};
+inline bool dw2f_ok(const LycLokrWgradItem& it) {
+  // small factors (SD1.5's 40 x 40) would leave most of a 80 x 80 tile empty: they stay on the narrow tiles of kron_dw2s.h
+  return it.c >= 64 && it.d >= 64 && it.M * it.a * (long)it.c * 2 < (1L << 30) && it.M * it.a * (long)it.d * 2 < (1L << 30);
+}
+inline int dw2f_cfg_of(const LycLokrWgradItem& it) {
+  const bool bi = it.c > 80, bj = it.d > 80;
+  return bi ? (bj ? DW2F_1010 : DW2F_105) : (bj ? DW2F_510 : DW2F_55);
+}
+template <typename T, int TI, int TJ, int WR, int WC, int WK, int D>
+void launch_dw2f_inst(const KronDw2fGroupArgs* ga, const KronDw2fItem* items, const int* wg_end, int n, unsigned grid, hipStream_t st) {
+  constexpr int lds = kron_dw2f_lds_bytes(TI, TJ, WK, D);
+  if (ga) {
+    auto kern = kron_dw2f_group_kernel<T, TI, TJ, WR, WC, WK, D>;
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)once;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, *ga);
+  } else {
+    auto kern = kron_dw2f_table_kernel<T, TI, TJ, WR, WC, WK, D>;
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)once;
+#ifdef LYC_TUNE
+    if (getenv("LYC_DW2F_OCC")) {
+      int nb = -1;
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), NTHREADS, lds);
+      hipFuncAttributes fa{};
+      (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
+      fprintf(stderr, "dw2f<%d,%d,%d,%d,%d,%d>: lds %d B, occupancy %d blocks/CU (%s), regs %d, static lds %zu, grid %u\n", TI, TJ, WR, WC, WK, D, lds, nb,
+              hipGetErrorString(e), fa.numRegs, fa.sharedSizeBytes, grid);
+    }
+#endif
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, items, wg_end, n);
+  }
+}
+template <typename T>
+void launch_dw2f(int cfg, const KronDw2fGroupArgs* ga, const KronDw2fItem* items, const int* wg_end, int n, unsigned grid, hipStream_t st) {
+  switch (cfg) {
+    case DW2F_1010: launch_dw2f_inst<T, 10, 10, 2, 2, 1, 3>(ga, items, wg_end, n, grid, st); break;
+    case DW2F_55: launch_dw2f_inst<T, 5, 5, 1, 1, 4, 2>(ga, items, wg_end, n, grid, st); break;
+    case DW2F_105: launch_dw2f_inst<T, 10, 5, 2, 1, 2, 3>(ga, items, wg_end, n, grid, st); break;
+    default: launch_dw2f_inst<T, 5, 10, 1, 2, 2, 3>(ga, items, wg_end, n, grid, st); break;
+  }
+}
+inline long dw2f_item_wgs(const KronDw2fItem& q) {
+  return round_up((long)q.tiles_i * q.tiles_j * q.nslab, 8) + round_up(q.dw1_ws ? q.dw1_red : 0, 8);
+}
+inline size_t dw2f_table_bytes(long n) { return (size_t)round_up(n * (long)sizeof(KronDw2fItem), 16) + (size_t)round_up(n * 4L, 16); }
+
+// the items `take[k]` of the list on full-width tiles.  With a device table: one launch per tile class (+ the table writers);
+// without: one launch per DW2F_MAX items.
+int lokr_wgrad_group_f(const LycLokrWgradItem* items, const std::vector<char>& take, int n, int dt, hipStream_t st, void* table,
+                       int64_t table_bytes) {
+  long n_wide = 0;
+  for (int k = 0; k < n; ++k) n_wide += take[k] ? 1 : 0;
+  const bool use_table = table != nullptr && (reinterpret_cast<uintptr_t>(table) & 15u) == 0 && table_bytes >= (int64_t)dw2f_table_bytes(n_wide);
+  KronDw2fItem* t_items = static_cast<KronDw2fItem*>(table);
+  int* t_ends = use_table ? reinterpret_cast<int*>(static_cast<char*>(table) + round_up(n_wide * (long)sizeof(KronDw2fItem), 16)) : nullptr;
+  long t_used = 0;
+  for (int cfg = 0; cfg < DW2F_NCFG; ++cfg) {
+    const Dw2fCfg cf = DW2F_CFG[cfg];
+    std::vector<KronDw2fItem> qs;
+    for (int k = 0; k < n; ++k) {
+      if (!take[k] || dw2f_cfg_of(items[k]) != cfg) continue;
+      const LycLokrWgradItem& it = items[k];
+      KronDw2fItem q{};
+      q.Q = it.g; q.P = it.x; q.W = it.w1; q.out = it.dw2; q.rows_total = (int)(it.M * it.a); q.I = it.c; q.J = it.d;
+      q.lg = 31 - __builtin_clz((unsigned)it.a);
+      q.ws = it.b; q.wt = 1; q.os = it.d; q.alpha = it.alpha;
+      q.tiles_i = (int)cdiv(it.c, 16 * cf.TI); q.tiles_j = (int)cdiv(it.d, 16 * cf.TJ);
+      // slabs: `slab_rows` rows each, fewer when the output is large (every slab adds the whole tile with fp32 atomics:
+      // ~300-400 elements / ns chip-wide)
+      const long unit = 32L * cf.WK;
+      long slab_rows = 1024, cap = 2000000;
+#ifdef LYC_TUNE  // development builds only (benchmarks/dw2_ab.py); the product library is built without it
+      if (const char* e = getenv("LYC_DW2F_ROWS")) slab_rows = atol(e);
+      if (const char* e = getenv("LYC_DW2F_CAP")) cap = atol(e);
+#endif
+      long ns = cdiv(q.rows_total, slab_rows);
+      const long out_elems = (long)it.c * it.d;
+      while (ns > 1 && ns * out_elems > cap) --ns;
+      if (ns < 1) ns = 1;
+      q.rows_per_slab = (int)(cdiv(cdiv(q.rows_total, ns), unit) * unit);
+      q.nslab = (int)cdiv(q.rows_total, q.rows_per_slab);
+      q.plain = q.nslab == 1 ? 1 : 0;
+#ifdef LYC_TUNE
+      if (getenv("LYC_DW2F_NOSTORE")) q.plain = 2;
+#endif
+      if (it.dw1) {
+        q.dw1_ws = static_cast<const float*>(it.ws); q.dw1 = it.dw1; q.dw1_n = it.a * it.b;
+        q.dw1_nblk = (int)lokr_dx_partial_blocks(it.M, it.a, it.c, it.d);
+        long r = q.dw1_nblk / 256;
+        q.dw1_red = (int)(r > 8 ? 8 : r < 1 ? 1 : r);
+      }
+      qs.push_back(q);
+    }
+    if (qs.empty()) continue;
+    // a parameter that appears twice in one launch (shared module) must be added atomically
+    auto unshare = [](KronDw2fItem* p, int cnt) {
+      for (int i = 0; i < cnt; ++i)
+        for (int j = 0; j < i; ++j)
+          if (p[i].out == p[j].out || (p[i].dw1 && p[i].dw1 == p[j].dw1)) {
+            if (p[i].plain == 1) p[i].plain = 0;
+            if (p[j].plain == 1) p[j].plain = 0;
+          }
+    };
+    if (use_table) {
+      // longest workgroups first: the tail of the launch is then made of short ones
+      std::stable_sort(qs.begin(), qs.end(), [](const KronDw2fItem& x, const KronDw2fItem& y) { return x.rows_per_slab > y.rows_per_slab; });
+      {  // shared outputs: by pointer (the list can hold hundreds of layers)
+        std::unordered_map<const void*, int> seen;
+        for (const KronDw2fItem& q : qs) { ++seen[q.out]; if (q.dw1) ++seen[q.dw1]; }
+        for (KronDw2fItem& q : qs)
+          if (q.plain == 1 && (seen[q.out] > 1 || (q.dw1 && seen[q.dw1] > 1))) q.plain = 0;
+      }
+      long total = 0;
+      for (const KronDw2fItem& q : qs) total += dw2f_item_wgs(q);
+      if (total > (1L << 30)) return fail(LYC_ERR_ARG, "lokr_wgrad_group: too many workgroups in one launch");
+      long wg_base = 0;
+      for (size_t lo = 0; lo < qs.size(); lo += DW2F_MAX) {
+        KronDw2fGroupArgs ga{};
+        ga.n = (int)std::min<size_t>(DW2F_MAX, qs.size() - lo);
+        long acc = 0;
+        for (int i = 0; i < ga.n; ++i) {
+          ga.p[i] = qs[lo + i];
+          acc += dw2f_item_wgs(qs[lo + i]);
+          ga.wg_end[i] = (int)acc;
+        }
+        hipLaunchKernelGGL(kron_dw2f_table_write_kernel, dim3(1), dim3(64), 0, st, ga, t_items + t_used, t_ends + t_used, (int)lo, (int)wg_base);
+        wg_base += acc;
+      }
+      if (dt == LYC_BF16) launch_dw2f<__bf16>(cfg, nullptr, t_items + t_used, t_ends + t_used, (int)qs.size(), (unsigned)total, st);
+      else launch_dw2f<_Float16>(cfg, nullptr, t_items + t_used, t_ends + t_used, (int)qs.size(), (unsigned)total, st);
+      t_used += (long)qs.size();
+      if (int rc = check_launch("lokr_wgrad_group(full-width tiles, table)")) return rc;
+    } else {
+      for (size_t lo = 0; lo < qs.size(); lo += DW2F_MAX) {
+        KronDw2fGroupArgs ga{};
+        ga.n = (int)std::min<size_t>(DW2F_MAX, qs.size() - lo);
+        long acc = 0;
+        for (int i = 0; i < ga.n; ++i) {
+          ga.p[i] = qs[lo + i];
+          acc += dw2f_item_wgs(qs[lo + i]);
+          ga.wg_end[i] = (int)acc;
+        }
+        unshare(ga.p, ga.n);
+        if (dt == LYC_BF16) launch_dw2f<__bf16>(cfg, &ga, nullptr, nullptr, 0, (unsigned)acc, st);
+        else launch_dw2f<_Float16>(cfg, &ga, nullptr, nullptr, 0, (unsigned)acc, st);
+        if (int rc = check_launch("lokr_wgrad_group(full-width tiles)")) return rc;
+      }
+    }
+  }
+  return LYC_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+#ifdef LYC_TRACE
+extern "C" int lyc_trace_read(unsigned long long* host32) {  // development builds: the shader-clock stamps of the last traced kernel
+  return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(lyc::lyc_trace_buf), 32 * sizeof(unsigned long long));
+}
+#endif
+int64_t lyc_lokr_wgrad_table_bytes(int n) { return n > 0 ? (int64_t)dw2f_table_bytes(n) : 0; }
+
 int lyc_lokr_wgrad_group(const LycLokrWgradItem* items, int n, int dtype, void* stream) {
+  return lyc_lokr_wgrad_group_ws(items, n, dtype, nullptr, 0, stream);
+}
+
+int lyc_lokr_wgrad_group_ws(const LycLokrWgradItem* items, int n, int dtype, void* table, int64_t table_bytes, void* stream) {
   if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "lokr_wgrad_group: bad item list");
   hipStream_t st = (hipStream_t)stream;
   const int dt = dtype & 0xff;
+  // full-width tiles (kron_dw2f.h) for every item they fit, unless the caller pins the round 1-3 plan (LYC_WGRAD_TILE_S)
+  std::vector<char> wide((size_t)(n > 0 ? n : 0), 0);
+  bool any_wide = false;
+  if (!(dtype & LYC_WGRAD_TILE_S) && (dt == LYC_BF16 || dt == LYC_F16))
+    for (int k = 0; k < n; ++k) {
+      const LycLokrWgradItem& it = items[k];
+      if (it.g && it.x && it.w1 && it.dw2 && it.a == it.b && it.a >= 1 && (16 % it.a) == 0 && (it.c % 8) == 0 && (it.d % 8) == 0 && it.M > 0 &&
+          lokr_wgrad_fast(it.g, it.x, it.M, it.a, it.b, it.c, it.d, dtype) && (!it.dw1 || it.ws) && dw2f_ok(it))
+        wide[k] = 1, any_wide = true;
+    }
   // The batch plans (fewer, longer slabs; 80 x 32 tiles) assume that the other layers of the call supply the parallelism: a
   // call with a handful of layers (a backward pass over one or two modules) is planned like single launches.
   const bool batch = n >= LYC_GROUP_MIN;
@@ -909,6 +1095,7 @@ int lyc_lokr_wgrad_group(const LycLokrWgradItem* items, int n, int dtype, void* 
     };
     for (int k = 0; k < n; ++k) {
       const LycLokrWgradItem& it = items[k];
+      if (wide[k]) continue;
       if (cfg == 0) {  // validate once
         if (int rc = check_kron_dims(it.M, it.a, it.b, it.c, it.d)) return rc;
         if (!it.g || !it.x || !it.w1 || !it.dw2) return fail(LYC_ERR_ARG, "lokr_wgrad_group: item %d: null pointer", k);
@@ -941,6 +1128,7 @@ int lyc_lokr_wgrad_group(const LycLokrWgradItem* items, int n, int dtype, void* 
     }
     if (int rc = flush()) return rc;
   }
+  if (any_wide) return lokr_wgrad_group_f(items, wide, n, dt, st, table, table_bytes);
   return LYC_OK;
 }
 

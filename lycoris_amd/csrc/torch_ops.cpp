@@ -386,7 +386,11 @@ void flush_deferred(c10::DeviceIndex device) {
       raw[i - lo] = LycLokrWgradItem{cptr(it.g), cptr(it.x), cfp(it.f1), dw1, dw2, mptr(it.ws), it.M,
                                      it.a, it.b, it.c, it.d, it.alpha};
     }
-    check_rc(lyc_lokr_wgrad_group(raw.data(), (int)raw.size(), items[lo].code, items[lo].stream), "lyc_lokr_wgrad_group");
+    // the problem table of the one-launch-per-tile-class path lives in a caching-allocator block of the flush stream
+    const int64_t tbytes = lyc_lokr_wgrad_table_bytes((int)raw.size());
+    Tensor table = at::empty({tbytes}, items[lo].g.options().dtype(at::kByte));
+    check_rc(lyc_lokr_wgrad_group_ws(raw.data(), (int)raw.size(), items[lo].code, table.mutable_data_ptr(), tbytes, items[lo].stream),
+             "lyc_lokr_wgrad_group_ws");
     if (!chain.empty()) check_rc(lyc_lokr_lr_chain_group(chain.data(), (int)chain.size(), items[lo].stream), "lyc_lokr_lr_chain_group");
     join_ambient(items[lo].device, items[lo].stream);
     lo = hi;

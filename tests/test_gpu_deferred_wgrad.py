@@ -1,5 +1,7 @@
-"""GPU: deferred, grouped LoKr weight gradients (lyc_lokr_linear_bwd | LYC_DEFER_WGRAD + lyc_lokr_wgrad_group,
-csrc/kron_dw2s.h: kron_dw2s_group_kernel; host side csrc/torch_ops.cpp: park_deferred / flush_deferred).
+"""GPU: deferred, grouped LoKr weight gradients (lyc_lokr_linear_bwd | LYC_DEFER_WGRAD + lyc_lokr_wgrad_group[_ws],
+csrc/kron_dw2f.h: full-width tiles, from the kernel arguments or from a problem table in device scratch; csrc/kron_dw2s.h: the
+round 1-3 narrow tiles, still used for small factors and selectable with LYC_WGRAD_TILE_S; host side csrc/torch_ops.cpp:
+park_deferred / flush_deferred).
 
 The grouped launch computes the same autograd products as the per-layer launches (reference: the factor gradients of
 lycoris/modules/lokr.py:543-566), only scheduled together, so the checks are: (a) C ABI: a batch of layers of every tile
@@ -23,7 +25,11 @@ DEFER = 0x200  # LYC_DEFER_WGRAD
 # (M, a = b, c, d): SDXL attention (32x32 tiles, 20 slabs when launched alone), the 77-token context, a 640-wide layer,
 # a problem on the 64x64 tile configuration (M * a >= 16 k rows), ragged rows / tiny factors, a single row
 SHAPES = [(1024, 8, 160, 160), (77, 8, 160, 256), (4096, 8, 80, 80), (4096, 8, 128, 128), (50, 4, 16, 8), (1, 8, 40, 160),
-          (333, 16, 24, 40)]
+          (333, 16, 24, 40),
+          # the full-width tile classes of kron_dw2f.h: 160 x 80 and 80 x 160 (two waves on the rows), several tiles per slab,
+          # ragged tiles in both directions, one slab only (the plain store path), a = 16 and a = 4
+          (256, 8, 320, 72), (256, 8, 72, 320), (300, 8, 64, 72), (33, 8, 168, 200), (700, 16, 88, 96), (513, 4, 160, 160)]
+MODES = {"args": 0, "table": 0, "narrow": 0x400}  # LYC_WGRAD_TILE_S
 
 
 def _problem(gen, M, a, c, d, dtype):
@@ -51,7 +57,7 @@ def _per_layer(N, g, x, w1, w2, alpha, code):  # (g, x, w1, w2): device tensors
     return dx, dw1, dw2
 
 
-def _deferred(N, probs, alpha, code, shared=()):
+def _deferred(N, probs, alpha, code, shared=(), mode="args"):
     """dx launches with LYC_DEFER_WGRAD, then ONE lyc_lokr_wgrad_group call over all problems.  `shared`: pairs (i, j) of
     problems whose dw1 / dw2 are the SAME buffers (a module applied twice)."""
     items = (N.WgradItem * len(probs))()
@@ -71,21 +77,30 @@ def _deferred(N, probs, alpha, code, shared=()):
         items[k] = N.WgradItem(N.ptr(g), N.ptr(x), N.ptr(w1), N.ptr(dw1), N.ptr(dw2), N.ptr(ws), M, a, b, c, d, alpha)
         keep.append(ws)
         outs.append((dx, dw1, dw2))
-    N.call("lyc_lokr_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(probs), code, N.stream_ptr(probs[0][1].device))
+    if mode == "table":
+        tb = int(N.load().lyc_lokr_wgrad_table_bytes(len(probs)))
+        table = torch.empty(tb, dtype=torch.uint8, device=DEV)
+        N.call("lyc_lokr_wgrad_group_ws", ctypes.cast(items, ctypes.c_void_p), len(probs), code, N.ptr(table), tb,
+               N.stream_ptr(probs[0][1].device))
+    else:
+        N.call("lyc_lokr_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(probs), code | MODES[mode],
+               N.stream_ptr(probs[0][1].device))
     torch.cuda.synchronize()
     return outs
 
 
+@pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-def test_grouped_weight_gradients_match_the_oracle_and_the_per_layer_path(dtype):
+def test_grouped_weight_gradients_match_the_oracle_and_the_per_layer_path(dtype, mode):
     from lycoris_amd import _native as N
     gen = torch.Generator().manual_seed(11)
     code = N.dtype_code(dtype)
     alpha = 0.7
     both = [_problem(gen, *s, dtype) for s in SHAPES]
     both += [_problem(gen, 64, 8, 16, 16, dtype) for _ in range(30)]  # > 24 items of one configuration: two launches
+    both += [_problem(gen, 40, 8, 64, 64, dtype) for _ in range(27)]  # the same on the full-width tiles
     probs, host = [b[0] for b in both], [b[1] for b in both]
-    got = _deferred(N, probs, alpha, code)
+    got = _deferred(N, probs, alpha, code, mode=mode)
     bound = TOL["f32_out"][dtype]
     for k, (h, (dx, dw1, dw2)) in enumerate(zip(host, got)):
         r1, r2 = _oracle(h, alpha)
@@ -97,15 +112,16 @@ def test_grouped_weight_gradients_match_the_oracle_and_the_per_layer_path(dtype)
             assert err(dw1, p1.double().cpu().numpy()) <= 1e-5 and err(dw2, p2.double().cpu().numpy()) <= 1e-5, k
 
 
-def test_a_parameter_that_appears_twice_in_one_group_is_added_atomically():
+@pytest.mark.parametrize("mode,cd", [("args", 32), ("args", 160), ("table", 160), ("narrow", 160)])
+def test_a_parameter_that_appears_twice_in_one_group_is_added_atomically(mode, cd):
     from lycoris_amd import _native as N
     gen = torch.Generator().manual_seed(12)
     dtype, alpha = torch.bfloat16, 1.0
     code = N.dtype_code(dtype)
-    (ga, xa, w1, w2), ha = _problem(gen, 256, 8, 32, 32, dtype)   # one slab each: the plain (non-atomic) store path when alone
-    (gb, xb, _, _), hb = _problem(gen, 256, 8, 32, 32, dtype)
+    (ga, xa, w1, w2), ha = _problem(gen, 64, 8, cd, cd, dtype)   # one slab each: the plain (non-atomic) store path when alone
+    (gb, xb, _, _), hb = _problem(gen, 64, 8, cd, cd, dtype)
     hb = (hb[0], hb[1], ha[2], ha[3])
-    got = _deferred(N, [(ga, xa, w1, w2), (gb, xb, w1, w2)], alpha, code, shared=[(1, 0)])
+    got = _deferred(N, [(ga, xa, w1, w2), (gb, xb, w1, w2)], alpha, code, shared=[(1, 0)], mode=mode)
     a1, a2 = _oracle(ha, alpha)
     b1, b2 = _oracle(hb, alpha)
     assert got[0][1].data_ptr() == got[1][1].data_ptr()
