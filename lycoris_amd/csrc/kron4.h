@@ -240,7 +240,7 @@ __device__ __forceinline__ void k4_dw1_partial(const Kron4Args& a, float* red, c
 // NP : paired column tiles (16-byte stores, above).  ABL != 0: ablation builds of benchmarks/k4bench.cpp (results are garbage):
 //      1 = no stage-2 matrix work, 2 = no stores, 4 = no x DMA, 8 = no plane DMA, 16 = no stage-1 matrix work.
 template <typename T, int MI, int NI, int D, int EPI, bool NP = false, int ABL = 0>
-__global__ __launch_bounds__(NTHREADS) void kron4_kernel(Kron4Args a) {
+__global__ __launch_bounds__(NTHREADS, 2) void kron4_kernel(Kron4Args a) {
   extern __shared__ __attribute__((aligned(1024))) char k4_smem[];
   using F8 = typename TT<T>::frag;
   using F4 = typename Mma16<T>::frag;
