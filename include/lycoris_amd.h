@@ -31,7 +31,14 @@ enum { LYC_F32 = 0, LYC_F16 = 1, LYC_BF16 = 2 };
 enum { LYC_F32_ROWS = 0x100, LYC_DEFER_WGRAD = 0x200,
        /* lyc_lokr_wgrad_group only: use the round 1-3 tile plan (80 x 32 outputs per wave, rows split over the waves: kron_dw2s.h) for
         * every item instead of the full-width tiles of kron_dw2f.h -- the A/B and regression-test switch (an argument, not getenv) */
-       LYC_WGRAD_TILE_S = 0x400 };
+       LYC_WGRAD_TILE_S = 0x400,
+       /* lyc_lokr_conv_wgrad_group, experiment builds (-DLYC_EXPERIMENT_CONV_DW2_PATCH) only: the LDS-patch weight-gradient kernel of
+        * benchmarks/experiments/kron_conv_dw2.h where its plan covers the layer; ignored by the product library */
+       LYC_CONV_WGRAD_PATCH = 0x800 };
+/* The *_planes Conv2d entry points and lyc_lokr_conv2d_planes_ok / _dx_blocks: pin the patch kernel's row tile (mi = 2, 4 or 8: 64 * mi
+ * stage-1 rows per workgroup) instead of letting the host plan it -- for tests, which otherwise reach only the smallest tile with
+ * their small problems (rounds 2-3 read an environment variable for this). */
+#define LYC_KCONV_ROW_TILE(mi) (((mi) & 0xf) << 12)
 enum { LYC_OK = 0, LYC_ERR_ARG = 1, LYC_ERR_UNSUPPORTED = 2, LYC_ERR_LAUNCH = 3 };
 
 #define LYC_ABI_VERSION 9

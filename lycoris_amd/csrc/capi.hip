@@ -17,7 +17,9 @@
 #include "kron_dw2s.h"
 #include "kron_dw2f.h"
 #include "kron_conv.h"
-#include "kron_conv_dw2.h"
+#ifdef LYC_EXPERIMENT_CONV_DW2_PATCH  // benchmarks/experiments/README.md: measured and dropped (5.9 ms vs 2.2 ms), not in the product build
+#include "../../benchmarks/experiments/kron_conv_dw2.h"
+#endif
 #include "loha_mfma.h"
 #include "gemm16.h"
 #include "lokr_kernels.h"
@@ -1239,7 +1241,8 @@ bool plan_kconv_mi(const KronArgs& ka, int mi, KconvGeom& gm, int ni, int ksteps
   return kconv_lds_bytes(ni, gm) <= 160 * 1024;
 }
 
-bool plan_kconv(const KronArgs& ka, int64_t B, KconvGeom& gm, int& mi, int& ni, int& ksteps) {
+inline int kconv_pin(int dtype) { return (dtype >> 12) & 0xf; }  // LYC_KCONV_ROW_TILE
+bool plan_kconv(const KronArgs& ka, int64_t B, KconvGeom& gm, int& mi, int& ni, int& ksteps, int pin_mi = 0) {
   const KronGather& gt = ka.gat;
   const int G = ka.Gin;
   if (G != ka.Gout || (G != 4 && G != 8 && G != 16) || (ka.K % 8) != 0 || (ka.N % 8) != 0 || gt.taps < 1 || gt.taps > 64) return false;
@@ -1259,8 +1262,7 @@ bool plan_kconv(const KronArgs& ka, int64_t B, KconvGeom& gm, int& mi, int& ni, 
   const long ctiles = cdiv(ka.N, 16 * ni);
   KconvGeom g2{};
   bool have = false;
-  const char* force = getenv("LYC_KCONV_MI");  // tests: pin the row tile (2 / 4 / 8) so that small problems reach every instantiation
-  const int only = force ? atoi(force) : 0;
+  const int only = pin_mi;  // LYC_KCONV_ROW_TILE(mi) in the call's dtype argument: tests pin the row tile (2 / 4 / 8) so that small problems reach every instantiation
   for (int cand = 8; cand >= 2; cand >>= 1) {
     if (only && cand != only) continue;
     KconvGeom t{};
@@ -1294,10 +1296,10 @@ void launch_kconv_ni(int ni, const KconvArgs& ca, dim3 grid, int lds, hipStream_
 
 // returns the number of workgroups, or -1 when the problem is not plannable
 template <typename T>
-long launch_kconv(const KronArgs& ka, const void* planes, int64_t B, hipStream_t st) {
+long launch_kconv(const KronArgs& ka, const void* planes, int64_t B, hipStream_t st, int pin_mi) {
   KconvArgs ca{};
   int mi = 0, ni = 0, ksteps = 0;
-  if (!plan_kconv(ka, B, ca.gm, mi, ni, ksteps)) return -1;
+  if (!plan_kconv(ka, B, ca.gm, mi, ni, ksteps, pin_mi)) return -1;
   ca.k = ka;
   ca.planes = planes;
   ca.ksteps = ksteps;
@@ -1360,7 +1362,7 @@ int lyc_lokr_conv2d_planes_ok(int64_t B, int64_t H, int64_t W, int a, int b, int
   ka.gat = make_gather(backward ? 2 : 1, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
   KconvGeom gm{};
   int mi, ni, ks;
-  return plan_kconv(ka, B, gm, mi, ni, ks) ? mi : 0;  // != 0: covered; the value is the row tile (64 * value stage-1 rows per workgroup)
+  return plan_kconv(ka, B, gm, mi, ni, ks, kconv_pin(dtype)) ? mi : 0;  // != 0: covered; the value is the row tile (64 * value stage-1 rows per workgroup)
 }
 
 int lyc_lokr_conv2d_fwd_planes(const void* x_rows, const float* w1, const void* planes_fwd, void* y_rows, int64_t B, int64_t H,
@@ -1375,8 +1377,8 @@ int lyc_lokr_conv2d_fwd_planes(const void* x_rows, const float* w1, const void* 
   ka.M = B * cd.Ho * cd.Wo; ka.Gin = b; ka.K = d; ka.Gout = a; ka.N = c;
   ka.s1o = b; ka.s1i = 1; ka.alpha = alpha;
   ka.gat = make_gather(1, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
-  const long n = (dtype & 0xff) == LYC_BF16 ? launch_kconv<__bf16>(ka, planes_fwd, B, (hipStream_t)stream)
-                                            : launch_kconv<_Float16>(ka, planes_fwd, B, (hipStream_t)stream);
+  const long n = (dtype & 0xff) == LYC_BF16 ? launch_kconv<__bf16>(ka, planes_fwd, B, (hipStream_t)stream, kconv_pin(dtype))
+                                            : launch_kconv<_Float16>(ka, planes_fwd, B, (hipStream_t)stream, kconv_pin(dtype));
   if (n < 0) return fail(LYC_ERR_UNSUPPORTED, "lokr_conv2d_fwd_planes: geometry outside the patch kernel (see lyc_lokr_conv2d_planes_ok)");
   return check_launch("lokr_conv2d_fwd_planes");
 }
@@ -1422,7 +1424,7 @@ int lokr_conv2d_bwd_impl(const void* g_rows, const void* x_rows, const float* w1
     ka.gat = make_gather(2, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
     long nblk = -1;
     if (planes_bwd) {  // LDS source patch + pre-packed operand planes (kron_conv.h)
-      nblk = bf ? launch_kconv<__bf16>(ka, planes_bwd, B, st) : launch_kconv<_Float16>(ka, planes_bwd, B, st);
+      nblk = bf ? launch_kconv<__bf16>(ka, planes_bwd, B, st, kconv_pin(dtype)) : launch_kconv<_Float16>(ka, planes_bwd, B, st, kconv_pin(dtype));
       if (nblk < 0 && !w2p)
         return fail(LYC_ERR_UNSUPPORTED, "lokr_conv2d_bwd_planes: geometry outside the patch kernel (see lyc_lokr_conv2d_planes_ok)");
     }
@@ -1485,22 +1487,21 @@ int64_t lyc_lokr_conv2d_dx_blocks(int64_t B, int64_t H, int64_t W, int a, int b,
   if (with_planes) {
     KconvGeom gm{};
     int mi, ni, ks;
-    if (plan_kconv(ka, B, gm, mi, ni, ks)) return (int64_t)B * gm.tiles_h * gm.tiles_w * cdiv(ka.N, 16 * ni);
+    if (plan_kconv(ka, B, gm, mi, ni, ks, kconv_pin(dtype))) return (int64_t)B * gm.tiles_h * gm.tiles_w * cdiv(ka.N, 16 * ni);
   }
-  (void)dtype;
   return (int64_t)cdiv(ka.M, K3_RT / ka.Gin) * cdiv(ka.N, 16 * kron3_pick_ni(ka));
 }
 
 extern "C++" {
 namespace {
+#ifdef LYC_EXPERIMENT_CONV_DW2_PATCH
 // plan of the patch kernel (kron_conv_dw2.h) for one layer; false: the row-gather kernel takes it
 bool plan_kd(const LycLokrConvWgradItem& it, const ConvDims& cd, KdItem& k) {
   const int G = it.a;
   if (it.a != it.b || (G != 4 && G != 8 && G != 16) || (it.c % 8) != 0 || (it.d % 8) != 0) return false;
   // Measured (profiles/r03_c5_*): correct, but 5.9 ms per SDXL step against 2.2 ms for the grouped row-gather kernel -- its
   // per-block address arithmetic (runtime divisions in a 168-way unrolled loop) issues ~8000 instructions per tile and wave.
-  // Kept as an opt-in (and under test) until that is table-driven; the row-gather kernel is the default.
-  if (!getenv("LYC_CONV_DW2_PATCH")) return false;
+  // Experiment builds only (-DLYC_EXPERIMENT_CONV_DW2_PATCH), selected per call with LYC_CONV_WGRAD_PATCH in `dtype`.
   k = KdItem{};
   k.g = it.g_rows; k.x = it.x_rows; k.w1 = it.w1; k.out = it.dw2p;
   k.B = (int)it.B; k.G = G; k.I = it.c; k.J = it.d;
@@ -1534,6 +1535,7 @@ bool plan_kd(const LycLokrConvWgradItem& it, const ConvDims& cd, KdItem& k) {
   k.ws = it.b; k.wt = 1; k.os = cd.taps * it.d; k.alpha = it.alpha;
   return true;
 }
+#endif
 }  // namespace
 }  // extern "C++"
 
@@ -1542,6 +1544,7 @@ int lyc_lokr_conv_wgrad_group(const LycLokrConvWgradItem* items_in, int n, int d
   hipStream_t st = (hipStream_t)stream;
   const int dt = dtype & 0xff;
   if (n > 0 && dt != LYC_BF16 && dt != LYC_F16) return fail(LYC_ERR_UNSUPPORTED, "lokr_conv_wgrad_group: 16-bit activations only");
+#ifdef LYC_EXPERIMENT_CONV_DW2_PATCH
   // ---- layers the patch kernel covers (stride-1 / small-patch geometries): kconv_dw2_group_kernel, 12 layers per launch ------
   std::vector<LycLokrConvWgradItem> rest;
   {
@@ -1575,7 +1578,7 @@ int lyc_lokr_conv_wgrad_group(const LycLokrConvWgradItem* items_in, int n, int d
                                    it.x_rows, it.g_rows))
         return rc;
       KdItem kd{};
-      if (it.B < 1 || !plan_kd(it, cd, kd)) {
+      if (it.B < 1 || !(dtype & LYC_CONV_WGRAD_PATCH) || !plan_kd(it, cd, kd)) {
         rest.push_back(it);
         continue;
       }
@@ -1595,6 +1598,9 @@ int lyc_lokr_conv_wgrad_group(const LycLokrConvWgradItem* items_in, int n, int d
     }
     if (int rc = flush()) return rc;
   }
+#else
+  std::vector<LycLokrConvWgradItem> rest(items_in, items_in + n);
+#endif
   const LycLokrConvWgradItem* items = rest.data();
   n = (int)rest.size();
   const bool batch = n >= 4;  // a few conv layers already fill the chip (their row counts are 8 x those of the Linear layers)
