@@ -76,7 +76,11 @@ def parse():
     ap.add_argument("--shared-inputs", action="store_true",
                     help="development: instances of one shape share x / g (cache-resident, the round-1 behaviour)")
     ap.add_argument("--eager", action="store_true", help="time the step without hipGraph capture (Python-driven)")
-    ap.add_argument("--segments", type=int, default=8, help="backward graph segments (N > 1: collectives in between)")
+    ap.add_argument("--segments", type=int, default=0,
+                    help="backward graph segments at N > 1 (collectives in between); 0 = cut at the gradient-bucket boundaries, one "
+                         "segment per bucket (default), K > 0 = K equal segments (rounds 2-3)")
+    ap.add_argument("--collective", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
+                    help="per bucket: one in-place all-reduce (default) or an in-place reduce-scatter + all-gather pair")
     ap.add_argument("--layers", default="all", help="'all', 'linear' or 'conv' (development)")
     ap.add_argument("--force-segments", action="store_true",
                     help="development: cut the backward into --segments graphs at N = 1 too (the N > 1 replay structure without the collectives)")
@@ -278,10 +282,12 @@ def forward_all(insts):
 
 def backward_range(outs, lo, hi):
     """backward of outs[lo:hi] in reverse order.  autograd.grad instead of .backward(): dx is produced and dropped (a
-    real UNet hands it to the previous layer); the factor gradients go straight into the arena (fused accumulation)."""
+    real UNet hands it to the previous layer); the factor gradients go straight into the arena (fused accumulation: the kernels
+    add them into `.grad` and hand nothing back -- hence allow_unused; the factors are listed because a backward call computes
+    only what it is asked for, csrc/torch_ops.cpp)."""
     seg = outs[lo:hi][::-1]
     if seg:  # ONE engine invocation for the whole segment, as loss.backward() is one for a real network
-        torch.autograd.grad([y for y, _ in seg], [it.x for _, it in seg], [it.g for _, it in seg])
+        torch.autograd.grad([y for y, _ in seg], [t for _, it in seg for t in [it.x] + it.params], [it.g for _, it in seg], allow_unused=True)
 
 
 def lib_sha():
@@ -316,7 +322,7 @@ def main():
     all_params = [p for it in insts for p in it.params]
     # --rccl-ws1: the N > 1 step on ONE GPU -- a world_size-1 RCCL group, every bucket really all-reduced (AVG, in place, side
     # stream) between the replays of the backward segment graphs
-    sync = AdapterGradSync(all_params, bucket_bytes=32 << 20, always_reduce=bool(args.rccl_ws1))
+    sync = AdapterGradSync(all_params, bucket_bytes=32 << 20, always_reduce=bool(args.rccl_ws1), collective=args.collective)
     sync.attach_fused()  # kernels accumulate into the arena and report to the bucket counters (eager: overlap by hooks)
     from lycoris_amd import ops as _ops
     if args.no_defer:  # A/B: one weight-gradient launch per layer instead of the grouped launches
@@ -363,24 +369,49 @@ def main():
             # part of the step, captured here so that every replay packs the parameters of ITS step
             _ops.refresh_lokr_planes(force=True)
             outs = forward_all(insts)
-        nseg = max(1, min(args.segments if (world > 1 or args.force_segments or args.rccl_ws1) else 1, n_layers))
-        edges = [round(i * n_layers / nseg) for i in range(nseg + 1)]
-        for s in range(nseg, 0, -1):  # backward runs from the last layer to the first
-            lo, hi = edges[s - 1], edges[s]
+        multi = world > 1 or args.force_segments or args.rccl_ws1
+        # segment edges (layer positions, descending) and the buckets each segment completes.  Default: cut exactly where a
+        # gradient bucket becomes complete -- one segment per bucket (SDXL LoKr: 5), no segment boundary that launches nothing
+        order = {p: i for i, it in enumerate(insts) for p in it.params}
+        cuts = sync.bucket_boundaries(order)
+        if not multi:
+            edges = [0]
+        elif args.segments > 0:
+            nseg = max(1, min(args.segments, n_layers))
+            edges = sorted({round(i * n_layers / nseg) for i in range(nseg)}, reverse=True)
+        else:
+            edges = sorted(set(cuts), reverse=True)
+        plan, done = [], set()
+        for e in edges:
+            ready = [i for i, c in enumerate(cuts) if c >= e and i not in done]
+            done.update(ready)
+            plan.append(ready)
+        # (the collectives themselves are NOT captured: recording RCCL's all-reduce into the backward graph on a forked side stream
+        # segfaults on this stack -- torch 2.10 + rocm 7.0, world_size-1 group, profiles/r04_ws1_variants.log)
+        hi = n_layers
+        for e in edges:  # backward runs from the last layer to the first
             gph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gph, pool=pool):
-                backward_range(outs, lo, hi)
+                backward_range(outs, e, hi)
             graphs.append(gph)
-            seg_bounds.append(insts[lo - 1].params[-1] if lo > 0 else None)  # first parameter NOT yet finished
+            hi = e
         sync._sync_enabled = True
+
+        seg_done = [torch.cuda.Event() for _ in graphs]
 
         def step():
             sync._reset_pending()
             g_fwd.replay()
-            for gph, upto in zip(graphs, seg_bounds):
+            prev = None
+            for k, (gph, ready) in enumerate(zip(graphs, plan)):
                 gph.replay()
-                if world > 1 or args.force_segments or args.rccl_ws1:
-                    sync.launch_ready(upto)  # side stream: waits for this segment, runs beside the next ones
+                if multi:
+                    seg_done[k].record()
+                    if prev is not None:  # the collectives of segment k - 1 are enqueued AFTER segment k has been submitted: the
+                        sync.launch_buckets(plan[prev], after=seg_done[prev])  # GPU runs it while the host talks to RCCL
+                    prev = k
+            if multi and prev is not None:
+                sync.launch_buckets(plan[prev], after=seg_done[prev])
             sync.finish()
             opt.step()
     else:
@@ -430,7 +461,9 @@ def main():
             "parallelism": f"dp{world}",
             "graph": "eager (no capture)" if args.eager else
                      f"hipGraph replay: 1 forward graph + {len(graphs)} backward segment(s)"
-                     + (", bucket all-reduces issued between segments on a side stream" if (world > 1 or args.rccl_ws1) else ""),
+                     + ((", bucket collectives (" + args.collective + ") "
+                         + ("issued between the bucket-aligned segments" if args.segments <= 0 else "issued between the segments")
+                         + " on a side stream") if (world > 1 or args.rccl_ws1) else ""),
             "conv_memory_format": "channels_last (documented default, DESIGN.md 2; --nchw for the A/B leg)" if args.channels_last else "contiguous (NCHW)",
             "inputs": "shared per shape (cache-resident)" if args.shared_inputs else
                       f"distinct x / g per layer instance: {act_bytes / 1e9:.2f} GB read per step",
@@ -589,7 +622,7 @@ def roofline(insts, args, dtype, dev):
     def bwd():
         if core is None:
             for it in lin:
-                torch.autograd.grad(saved[id(it)], [it.x], it.g, retain_graph=True)  # dw goes into the arena
+                torch.autograd.grad(saved[id(it)], [it.x] + it.params, it.g, retain_graph=True, allow_unused=True)  # dw goes into the arena
             return
         for it, rows, g, fs, bufs in calls:
             core.bwd(g, rows, fs, saved[id(it)][1], 1.0, True, [True] * len(fs), False, bufs)
@@ -920,12 +953,13 @@ def per_algo_legs():
 def base_leg(insts, sync, opt=None, ops_=None):
     """the step with the frozen layers' own ops in it (rocBLAS / MIOpen forward + dx-only backward), next to
     the adapter-only number: base alone, and base + adapter (out = base + delta, one autograd.grad for both)."""
-    def one_backward(outs):  # ONE engine invocation for all layers, as loss.backward() is one for a real network
+    def one_backward(outs, factors=True):  # ONE engine invocation for all layers, as loss.backward() is one for a real network
         outs = outs[::-1]
-        torch.autograd.grad([y for y, _ in outs], [it.x for _, it in outs], [it.g for _, it in outs])
+        wrt = [t for _, it in outs for t in [it.x] + (it.params if factors else [])]
+        torch.autograd.grad([y for y, _ in outs], wrt, [it.g for _, it in outs], allow_unused=True)
 
     def base_pass():
-        one_backward([(it.base_forward(), it) for it in insts])
+        one_backward([(it.base_forward(), it) for it in insts], factors=False)
 
     def both_pass():
         one_backward([(it.forward(base=it.base_forward()), it) for it in insts])

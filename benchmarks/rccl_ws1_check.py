@@ -49,7 +49,8 @@ class Layer:
 
 def backward_range(outs, lo, hi):
     seg = outs[lo:hi][::-1]
-    torch.autograd.grad([y for y, _ in seg], [l.x for _, l in seg], [l.g for _, l in seg])
+    # the factors are listed: a backward call computes (and the kernels add into `.grad`) only what it is asked for
+    torch.autograd.grad([y for y, _ in seg], [t for _, l in seg for t in [l.x] + list(l.params)], [l.g for _, l in seg], allow_unused=True)
 
 
 def main():

@@ -46,10 +46,16 @@ class _Bucket:
 
 class AdapterGradSync:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20,
-                 process_group=None, average: bool = True, always_reduce: bool = False):
+                 process_group=None, average: bool = True, always_reduce: bool = False, collective: str = "all_reduce"):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("AdapterGradSync: no trainable parameters")
+        if collective not in ("all_reduce", "reduce_scatter"):
+            raise ValueError("AdapterGradSync: collective must be 'all_reduce' or 'reduce_scatter'")
+        # "reduce_scatter": every bucket as an in-place reduce-scatter + all-gather pair (each rank reduces 1 / N of the
+        # bucket; same bytes on the wire as a ring all-reduce, but the two halves are separate collectives that RCCL schedules over
+        # all xGMI links and a sharded optimizer could run between them).  Same result as "all_reduce" up to summation order.
+        self.collective = collective
         self.group = process_group
         self.average = average
         self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -203,15 +209,19 @@ class AdapterGradSync:
         if b.pending == 0:
             self._launch(b)
 
-    def _launch(self, b: _Bucket):
+    def _launch(self, b: _Bucket, after=None):
         b.launched = True
         self.launch_log.append(b.index)
         if not self._reduce:
             return
         self.collectives_launched += 1
         if self.side_stream is not None:
-            # the bucket's gradients were produced on the compute stream: order the collective after them
-            self.side_stream.wait_stream(torch.cuda.current_stream(self.device))
+            # the bucket's gradients were produced on the compute stream: order the collective after them (`after`: an event
+            # recorded when they were complete -- work enqueued on the compute stream since then is NOT waited for)
+            if after is not None:
+                self.side_stream.wait_event(after)
+            else:
+                self.side_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.side_stream):
                 b.work = self._all_reduce(b.flat)
         else:
@@ -219,6 +229,8 @@ class AdapterGradSync:
 
     def _all_reduce(self, flat):
         backend = dist.get_backend(self.group)
+        if self.collective == "reduce_scatter":
+            return self._reduce_scatter_all_gather(flat, backend)
         if self.average and backend == "nccl":
             return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -227,6 +239,57 @@ class AdapterGradSync:
             flat.div_(self.world_size)
             return None
         return work
+
+    def _reduce_scatter_all_gather(self, flat, backend):
+        """in place: rank r reduces elements [r * chunk, (r + 1) * chunk) of the bucket (its shard is a view of the bucket at that
+        offset: the in-place form of both collectives), then every rank gathers all shards; the < world_size elements that do not
+        divide go through a small all-reduce"""
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        n = flat.numel()
+        chunk = n // world
+        nccl = backend == "nccl"  # collectives of one communicator run in issue order on its stream: no waits between them
+        avg_native = self.average and nccl
+        op = dist.ReduceOp.AVG if avg_native else dist.ReduceOp.SUM
+        work = None
+        if chunk > 0:
+            main = flat[:chunk * world]
+            shard = main[rank * chunk:(rank + 1) * chunk]
+            w = dist.reduce_scatter_tensor(shard, main, op=op, group=self.group, async_op=True)
+            if not nccl:
+                w.wait()
+                if self.average:
+                    shard.div_(world)
+            work = dist.all_gather_into_tensor(main, shard, group=self.group, async_op=True)
+            if not nccl:
+                work.wait()
+        if chunk * world < n:
+            tail = flat[chunk * world:]
+            work = dist.all_reduce(tail, op=op, group=self.group, async_op=True)  # after the all-gather in the communicator's order
+            if not nccl:
+                work.wait()
+                if self.average:
+                    tail.div_(world)
+        return work if nccl else None
+
+    def bucket_boundaries(self, order):
+        """For callers that replay the backward pass in captured segments (no hooks fire inside a hipGraph): `order[p]` = position
+        of parameter p's layer in FORWARD order.  Returns, per bucket in launch order, the smallest position among its parameters
+        -- the bucket is complete once backward has run down to that layer.  Cutting the segments at exactly these positions gives
+        one segment per bucket (SDXL LoKr: 5) instead of an arbitrary number of equal ones."""
+        return [min(order[p] for p in b.params) for b in self.buckets]
+
+    def launch_buckets(self, indices, after=None):
+        """launch the collectives of the given buckets (precomputed per segment by the caller: no scan, no host synchronisation --
+        only the stream wait / collective enqueue of `_launch`).  `after`: an event recorded on the compute stream right behind the
+        segment that completed these buckets; the caller can then submit the NEXT segment's graph first and enqueue the collectives
+        while the GPU already runs it (the enqueue costs tens of microseconds of host time per collective, which otherwise sit
+        between two graph launches with the GPU idle)."""
+        for i in indices:
+            b = self.buckets[i]
+            if not b.launched:
+                b.pending = 0
+                self._launch(b, after)
 
     def all_reduce_now(self):
         """Launch the collective of every bucket that has not been launched in this step -- for callers whose backward

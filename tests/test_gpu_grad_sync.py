@@ -58,7 +58,7 @@ def test_shared_module_reports_once_through_the_sync(defer):
         for _ in range(2):
             reports.clear()
             sync.zero_grad()
-            torch.autograd.grad(run(), xs, gs)
+            torch.autograd.grad(run(), xs + [w1, w2] + other, gs, allow_unused=True)  # the factors are asked for; the kernels add them in place
             assert sorted(reports) == sorted({id(w1), id(w2), id(other[0]), id(other[1])}), "one report per parameter"
             assert all(b.launched for b in sync.buckets)
             sync.finish()
