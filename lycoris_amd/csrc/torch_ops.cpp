@@ -15,6 +15,7 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/extension.h>
+#include <ATen/SavedTensorHooks.h>
 #include <torch/library.h>
 
 #include <hip/hip_runtime_api.h>
@@ -119,8 +120,19 @@ bool will_report(const Tensor& factor, const Tensor& x, bool cl = false) {
   if (!gr.defined() || gr.scalar_type() != at::kFloat || gr.device() != factor.device()) return false;
   return cl ? gr.permute({0, 2, 3, 1}).is_contiguous() : gr.is_contiguous();  // cl: cl_grad_target()'s condition
 }
+// A forward that runs INSIDE a backward pass under saved-tensor hooks is the recomputation of non-reentrant activation checkpointing
+// (torch.utils.checkpoint(use_reentrant=False), the diffusers default): its nodes only re-create the saved tensors of the ORIGINAL
+// nodes and never run backward themselves, so they must not be counted (the counts never reached 0, no report fired from
+// inside the backward pass and every bucket went out in finish() -- the DP overlap was silently lost).  Reentrant checkpointing
+// recomputes inside a backward pass too, but without saved-tensor hooks, and runs the recomputed nodes in a nested pass: counted.
+// (Both at once -- reentrant checkpointing inside a user's own saved_tensors_hooks -- is taken for the first case: a parameter shared
+// by two layer calls is then reported once per call, which AdapterGradSync refuses loudly instead of reducing early in silence.)
+bool inside_checkpoint_recompute() {
+  return torch::autograd::get_current_graph_task_id() >= 0 && at::SavedTensorDefaultHooks::is_enabled() &&
+         at::SavedTensorDefaultHooks::get_hooks().has_value();
+}
 void expect(const Tensor& param, const Tensor& x, bool cl = false) {
-  if (!will_report(param, x, cl)) return;
+  if (!will_report(param, x, cl) || inside_checkpoint_recompute()) return;
   std::lock_guard<std::mutex> lk(g_accum.mu);
   ++g_accum.uses[param.unsafeGetTensorImpl()];
 }
@@ -194,6 +206,30 @@ bool eager_cuda(const Tensor& t) {
 // loss.backward() needs every leaf that requires grad; a gradient probe such as torch.autograd.grad(loss, [x]) needs none of the
 // factors and leaves their `.grad` alone.  Callers that drive backward through autograd.grad and want the factor gradients list the
 // factors among its inputs (allow_unused=True: the kernel has already added them into `.grad`, nothing is handed back).
+
+// ---- saved variables that keep the identity of the parameters ---------------------------------------------------------------------
+// Saved-tensor hooks hand the backward node COPIES of what the forward saved: non-reentrant activation checkpointing (the diffusers
+// default) recomputes the forward and keeps `x.detach()` of every saved tensor, offloading hooks bring a fresh device copy.  For an
+// activation that is all the backward needs.  For a factor it loses the Parameter: the copy has no `.grad` to accumulate into and
+// is not the tensor the DP bucket counters know -- the gradient then went through AccumulateGrad, unreported, and its bucket was
+// reduced in finish() instead of inside the backward pass (found by tests/test_gpu_grad_sync.py, round 4).  Leaf inputs that
+// require grad (never the activation at index 0) are therefore also kept as plain references in saved_data, which the hooks do not
+// see, and put back in place of their copies.
+void save_vars(AutogradContext* ctx, torch::autograd::variable_list vars) {
+  for (size_t i = 1; i < vars.size(); ++i)
+    if (vars[i].defined() && vars[i].is_leaf() && vars[i].requires_grad()) ctx->saved_data["lyc_leaf" + std::to_string(i)] = vars[i];
+  ctx->save_for_backward(std::move(vars));
+}
+torch::autograd::variable_list saved_vars(AutogradContext* ctx) {
+  torch::autograd::variable_list s = ctx->get_saved_variables();
+  for (size_t i = 1; i < s.size(); ++i) {
+    auto it = ctx->saved_data.find("lyc_leaf" + std::to_string(i));
+    if (it == ctx->saved_data.end() || !it->second.isTensor()) continue;
+    const Tensor& p = it->second.toTensor();
+    if (p.defined() && s[i].defined() && !s[i].is_same(p) && s[i].sizes() == p.sizes()) s[i] = p;
+  }
+  return s;
+}
 
 // the tensor the kernel accumulates into: existing .grad (hand_back = false) or a fresh zero buffer (hand_back = true)
 struct GradTarget {
@@ -845,13 +881,13 @@ struct LokrLinearFn : public torch::autograd::Function<LokrLinearFn> {
     Tensor y = eager_cuda(x) ? lokr_linear_fwd(x, w1, w2, alpha, base) : op.call(x, w1, w2, alpha, base);
     expect(w1, x);
     expect(w2, x);
-    ctx->save_for_backward({x, w1, w2});
+    save_vars(ctx, {x, w1, w2});
     ctx->saved_data["alpha"] = alpha;
     ctx->saved_data["has_base"] = base.has_value() && base->defined();
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    auto saved = ctx->get_saved_variables();
+    auto saved = saved_vars(ctx);
     const Tensor &x = saved[0], &w1 = saved[1], &w2 = saved[2];
     const double alpha = ctx->saved_data["alpha"].toDouble();
     const bool nx = ctx->needs_input_grad(0), n1 = ctx->needs_input_grad(1), n2 = ctx->needs_input_grad(2);
@@ -935,13 +971,13 @@ struct LokrLinearLrFn : public torch::autograd::Function<LokrLinearLrFn> {
     expect(w1, x);
     expect(w2a, x);
     expect(w2b, x);
-    ctx->save_for_backward({x, w1, w2a, w2b});
+    save_vars(ctx, {x, w1, w2a, w2b});
     ctx->saved_data["alpha"] = alpha;
     ctx->saved_data["has_base"] = base.has_value() && base->defined();
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    auto saved = ctx->get_saved_variables();
+    auto saved = saved_vars(ctx);
     const Tensor &x = saved[0], &w1 = saved[1], &w2a = saved[2], &w2b = saved[3];
     const double alpha = ctx->saved_data["alpha"].toDouble();
     const bool nx = ctx->needs_input_grad(0), n1 = ctx->needs_input_grad(1), na = ctx->needs_input_grad(2), nb2 = ctx->needs_input_grad(3);
@@ -1032,14 +1068,14 @@ struct LokrLinearLr2Fn : public torch::autograd::Function<LokrLinearLr2Fn> {
     Tensor w1 = at::mm(f32c(w1a), f32c(w1b));  // grad mode is off inside Function::forward: a plain tensor
     Tensor y = lokr_linear_lr_fwd(x, w1, w2a, w2b, alpha, base);
     for (const Tensor* f : {&w1a, &w1b, &w2a, &w2b}) expect(*f, x);
-    ctx->save_for_backward({x, w1a, w1b, w2a, w2b});
+    save_vars(ctx, {x, w1a, w1b, w2a, w2b});
     ctx->saved_data["alpha"] = alpha;
     ctx->saved_data["has_base"] = base.has_value() && base->defined();
     ctx->saved_data["w1"] = w1;
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    auto saved = ctx->get_saved_variables();
+    auto saved = saved_vars(ctx);
     const Tensor &x = saved[0], &w1a = saved[1], &w1b = saved[2], &w2a = saved[3], &w2b = saved[4];
     const Tensor w1 = ctx->saved_data["w1"].toTensor();
     const double alpha = ctx->saved_data["alpha"].toDouble();
@@ -1188,12 +1224,12 @@ struct LoconLinearFn : public torch::autograd::Function<LoconLinearFn> {
     auto [y, t] = eager_cuda(x) ? locon_linear_fwd(x, down, up, alpha) : op.call(x, down, up, alpha);
     expect(down, x);
     expect(up, x);
-    ctx->save_for_backward({x, down, up, t});
+    save_vars(ctx, {x, down, up, t});
     ctx->saved_data["alpha"] = alpha;
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    auto saved = ctx->get_saved_variables();
+    auto saved = saved_vars(ctx);
     const Tensor &x = saved[0], &down = saved[1], &up = saved[2], &t = saved[3];
     const double alpha = ctx->saved_data["alpha"].toDouble();
     const bool nx = ctx->needs_input_grad(0), nd = ctx->needs_input_grad(1), nu = ctx->needs_input_grad(2);
@@ -1318,12 +1354,12 @@ struct LohaLinearFn : public torch::autograd::Function<LohaLinearFn> {
                                                            double)>();
     auto [y, ws] = eager_cuda(x) ? loha_linear_fwd(x, w1a, w1b, w2a, w2b, alpha) : op.call(x, w1a, w1b, w2a, w2b, alpha);
     for (const Tensor* f : {&w1a, &w1b, &w2a, &w2b}) expect(*f, x);
-    ctx->save_for_backward({x, w1a, w1b, w2a, w2b, ws});
+    save_vars(ctx, {x, w1a, w1b, w2a, w2b, ws});
     ctx->saved_data["alpha"] = alpha;
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    auto s = ctx->get_saved_variables();
+    auto s = saved_vars(ctx);
     const double alpha = ctx->saved_data["alpha"].toDouble();
     const bool nx = ctx->needs_input_grad(0);
     bool nf[4], any = false;
@@ -1445,14 +1481,14 @@ struct ChanAffineFn : public torch::autograd::Function<ChanAffineFn> {
                          .typed<Tensor(const Tensor&, const Tensor&, const c10::optional<Tensor>&, double, double, int64_t)>();
     Tensor out = op.call(a, w, bias, s0, mult, chan_dim);
     expect(w, a);
-    ctx->save_for_backward({a, w, bias.has_value() ? *bias : Tensor()});
+    save_vars(ctx, {a, w, bias.has_value() ? *bias : Tensor()});
     ctx->saved_data["s0"] = s0;
     ctx->saved_data["mult"] = mult;
     ctx->saved_data["chan_dim"] = at::maybe_wrap_dim(chan_dim, a.dim());
     return out;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    auto s = ctx->get_saved_variables();
+    auto s = saved_vars(ctx);
     const Tensor &a = s[0], &w = s[1];
     c10::optional<Tensor> bias = s[2].defined() ? c10::optional<Tensor>(s[2]) : c10::nullopt;
     const double s0 = ctx->saved_data["s0"].toDouble(), mult = ctx->saved_data["mult"].toDouble();
@@ -1683,7 +1719,7 @@ struct LokrConv2dTraceFn : public torch::autograd::Function<LokrConv2dTraceFn> {
     static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::lokr_conv2d", "")
                          .typed<Tensor(const Tensor&, const Tensor&, const Tensor&, double, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef)>();
     Tensor y = op.call(x, w1, w2, alpha, stride, padding, dilation);
-    ctx->save_for_backward({x, w1, w2});
+    save_vars(ctx, {x, w1, w2});
     ctx->saved_data["alpha"] = alpha;
     ctx->saved_data["stride"] = stride;
     ctx->saved_data["padding"] = padding;
@@ -1691,7 +1727,7 @@ struct LokrConv2dTraceFn : public torch::autograd::Function<LokrConv2dTraceFn> {
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    auto s = ctx->get_saved_variables();
+    auto s = saved_vars(ctx);
     const bool nx = ctx->needs_input_grad(0), n1 = ctx->needs_input_grad(1), n2 = ctx->needs_input_grad(2);
     static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_lokr_conv2d_backward", "")
                          .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, double,
@@ -1709,7 +1745,7 @@ struct LoconConv2dTraceFn : public torch::autograd::Function<LoconConv2dTraceFn>
                          .typed<std::tuple<Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, double, at::IntArrayRef,
                                                            at::IntArrayRef, at::IntArrayRef)>();
     auto [y, t] = op.call(x, down, up, alpha, stride, padding, dilation);
-    ctx->save_for_backward({x, down, up, t});
+    save_vars(ctx, {x, down, up, t});
     ctx->saved_data["alpha"] = alpha;
     ctx->saved_data["stride"] = stride;
     ctx->saved_data["padding"] = padding;
@@ -1717,7 +1753,7 @@ struct LoconConv2dTraceFn : public torch::autograd::Function<LoconConv2dTraceFn>
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    auto s = ctx->get_saved_variables();
+    auto s = saved_vars(ctx);
     const bool nx = ctx->needs_input_grad(0), nd = ctx->needs_input_grad(1), nu = ctx->needs_input_grad(2);
     static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_locon_conv2d_backward", "")
                          .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&,
@@ -1782,13 +1818,13 @@ struct LokrConv2dFn : public torch::autograd::Function<LokrConv2dFn> {
     }
     expect(w1, x);
     expect(w2, x, /*cl=*/true);
-    ctx->save_for_backward({rows, w1, w2, planes_b});
+    save_vars(ctx, {rows, w1, w2, planes_b});
     ctx->saved_data["alpha"] = alpha;
     ctx->saved_data["geom"] = std::vector<int64_t>{gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, gm.Ho, gm.Wo, B, C, H, W, !copied};
     return from_rows(y, B, gm.Ho, gm.Wo, !copied);
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    auto s = ctx->get_saved_variables();
+    auto s = saved_vars(ctx);
     const Tensor &rows = s[0], &w1 = s[1], &w2 = s[2];
     const double alpha = ctx->saved_data["alpha"].toDouble();
     auto gv = ctx->saved_data["geom"].toIntVector();
@@ -1904,13 +1940,13 @@ struct LokrConv2dLrFn : public torch::autograd::Function<LokrConv2dLrFn> {
     expect(w1, x);
     expect(w2a, x);
     expect(w2b, x);
-    ctx->save_for_backward({rows, w1, w2a, w2b});
+    save_vars(ctx, {rows, w1, w2a, w2b});
     ctx->saved_data["alpha"] = alpha;
     ctx->saved_data["geom"] = std::vector<int64_t>{gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, gm.Ho, gm.Wo, B, C, H, W, !copied};
     return from_rows(y, B, gm.Ho, gm.Wo, !copied);
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    auto s = ctx->get_saved_variables();
+    auto s = saved_vars(ctx);
     const Tensor &rows = s[0], &w1 = s[1], &w2a = s[2], &w2b = s[3];
     const double alpha = ctx->saved_data["alpha"].toDouble();
     auto gv = ctx->saved_data["geom"].toIntVector();
@@ -2022,13 +2058,13 @@ struct LoconConv2dFn : public torch::autograd::Function<LoconConv2dFn> {
              "lyc_locon_conv2d_fwd");
     expect(down, x, /*cl=*/true);
     expect(up, x);
-    ctx->save_for_backward({rows, down, up, t});
+    save_vars(ctx, {rows, down, up, t});
     ctx->saved_data["alpha"] = alpha;
     ctx->saved_data["geom"] = std::vector<int64_t>{gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, gm.Ho, gm.Wo, B, C, H, W, !copied};
     return from_rows(y, B, gm.Ho, gm.Wo, !copied);
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    auto s = ctx->get_saved_variables();
+    auto s = saved_vars(ctx);
     const Tensor &rows = s[0], &down = s[1], &up = s[2], &t = s[3];
     const double alpha = ctx->saved_data["alpha"].toDouble();
     auto gv = ctx->saved_data["geom"].toIntVector();
@@ -2196,14 +2232,14 @@ struct AdapterConv2dFn : public torch::autograd::Function<AdapterConv2dFn> {
     const Tensor* fs[4] = {&f0, &f1, &u2, &u3};
     for (const Tensor* f : fs)
       if (f->defined()) expect(*f, x);
-    ctx->save_for_backward({x, cols, saved, f0, f1, u2, u3});
+    save_vars(ctx, {x, cols, saved, f0, f1, u2, u3});
     ctx->saved_data["algo"] = algo;
     ctx->saved_data["alpha"] = alpha;
     ctx->saved_data["geom"] = std::vector<int64_t>{kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1]};
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    auto s = ctx->get_saved_variables();
+    auto s = saved_vars(ctx);
     const Tensor &x = s[0], &cols = s[1], &saved = s[2];
     const int64_t algo = ctx->saved_data["algo"].toInt();
     const double alpha = ctx->saved_data["alpha"].toDouble();
@@ -2428,6 +2464,7 @@ PYBIND11_MODULE(_lyc_torch, m) {
     g_accum.uses.clear();
     g_accum.done_task.clear();
   });
+  m.def("debug_recompute_state", []() { return std::make_tuple(torch::autograd::get_current_graph_task_id(), at::SavedTensorDefaultHooks::is_enabled(), (int)at::SavedTensorDefaultHooks::get_tls_state().stack.size(), inside_checkpoint_recompute()); });
   m.def("fused_reports", [](const Tensor& p) { return fused_reports(p); });
   m.def("mark_planes_dirty", []() { g_planes.dirty = true; });  // step boundary (optimizer-step post hook, ops.py)
   m.def("planes_epoch", []() {

@@ -37,6 +37,8 @@ class _Conv1dTwin(nn.Conv2d):
     `.data` writes of either are seen by both), so the twin never has to be kept in sync."""
 
     def __init__(self, real: nn.Conv1d):
+        if real.padding_mode != "zeros":  # the same construction-time rejection an nn.Conv2d layer gets (ADVICE r3)
+            raise _unsupported(f"nn.Conv1d with padding_mode={real.padding_mode!r}")
         nn.Module.__init__(self)  # deliberately not nn.Conv2d.__init__: nothing is allocated
         self.__dict__["_real"] = real  # not a submodule: the frozen layer must stay out of the adapter's parameters
         self.in_channels, self.out_channels = real.in_channels, real.out_channels
@@ -57,9 +59,17 @@ class _Conv1dTwin(nn.Conv2d):
     def bias(self):
         return self._real.bias
 
-    @bias.setter
-    def bias(self, value):
-        self._real.bias = value
+    def __setattr__(self, name, value):
+        # nn.Module.__setattr__ sends an nn.Parameter to register_parameter BEFORE any property setter is looked at (and that raises
+        # "attribute 'bias' already exists" because of the property): `layer.bias = nn.Parameter(b)` of the merge paths
+        # (merge_to / onfly_merge on a bias-less layer) has to reach the REAL layer.  `weight` likewise, in the real layer's 3-D shape.
+        if name == "bias":
+            self._real.bias = value
+        elif name == "weight":
+            w = value.data if isinstance(value, nn.Parameter) else value
+            self._real.weight = nn.Parameter(w.squeeze(2) if w.dim() == 4 else w, requires_grad=bool(getattr(value, "requires_grad", False)))
+        else:
+            super().__setattr__(name, value)
 
     def forward(self, x):
         return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)

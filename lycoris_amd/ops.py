@@ -63,7 +63,12 @@ def _cpp() -> bool:
 
 def fused_grad_accumulation(enabled: bool = True, callback=None, batch_callback=None):
     """`callback(param)` is told about every parameter whose gradient has just been accumulated into `.grad` by the kernels;
-    `batch_callback(list_of_params)` (optional) takes the reports of a whole grouped weight-gradient flush in ONE call."""
+    `batch_callback(list_of_params)` (optional) takes the reports of a whole grouped weight-gradient flush in ONE call.
+
+    A parameter used by several layer calls of one forward pass is reported once, after the last of its backward nodes: the forward
+    counts the nodes it creates (csrc/torch_ops.cpp expect()).  Counts of forward passes that are never differentiated (a validation
+    forward outside no_grad, a pass that raised) stay behind: owners call `reset_use_counts()` at their step boundary --
+    AdapterGradSync does in zero_grad() / finish().  The recomputation of non-reentrant activation checkpointing is not counted."""
     _ACCUM["enabled"] = bool(enabled)
     _ACCUM["callback"] = callback
     _ACCUM["batch_callback"] = batch_callback if callback is not None else None

@@ -144,3 +144,23 @@ def test_load_state_dict_accepts_conv1d_shaped_tensors():
     b = LoConModule("t", layer, 1.0, lora_dim=4, alpha=2)
     b.load_state_dict(a.state_dict(), strict=False)
     assert torch.equal(b.lora_up.weight, a.lora_up.weight) and torch.equal(b.lora_down.weight, a.lora_down.weight)
+
+
+def test_twin_forwards_parameter_assignments_to_the_real_layer_and_rejects_other_padding_modes():
+    """`layer.bias = nn.Parameter(b)` through the twin (the merge paths on a bias-less layer) -- nn.Module.__setattr__
+    would send the Parameter to register_parameter before the property setter is ever looked at; non-'zeros' padding modes are
+    refused when the twin is built, as they are for nn.Conv2d."""
+    from lycoris_amd.modules.base import _Conv1dTwin
+    layer = nn.Conv1d(16, 24, 3, padding=1, bias=False)
+    twin = _Conv1dTwin(layer)
+    assert twin.bias is None
+    twin.bias = nn.Parameter(torch.ones(24))
+    assert layer.bias is not None and torch.equal(layer.bias, torch.ones(24)) and twin.bias is layer.bias
+    twin.bias = None
+    assert layer.bias is None
+    w = torch.randn(24, 16, 1, 3)
+    twin.weight = nn.Parameter(w)
+    assert tuple(layer.weight.shape) == (24, 16, 3) and torch.equal(twin.weight, w)
+    assert "bias" not in dict(twin.named_parameters()) and list(twin.parameters()) == []  # still no parameters of its own
+    with pytest.raises(NotImplementedError):
+        LoConModule("t", nn.Conv1d(16, 24, 3, padding=1, padding_mode="circular"), 1.0, 2, 1)

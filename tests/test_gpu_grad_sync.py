@@ -120,3 +120,45 @@ def test_loss_backward_counts_every_fused_parameter_once():
     assert sorted(seen) == sorted([id(p) for p in params] * 2)
     for p in params:
         assert p.grad is not None and float(p.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("reentrant", [False, True], ids=["non_reentrant", "reentrant"])
+def test_activation_checkpointing_keeps_the_in_backward_reports(reentrant):
+    """under torch.utils.checkpoint the forward runs twice (original + recomputation) but only one set of backward
+    nodes runs.  Every parameter must still be reported from INSIDE the backward pass (all buckets launched before finish()), once,
+    with the right gradients -- including a module applied twice."""
+    import torch.nn as nn
+    from torch.utils.checkpoint import checkpoint
+    from lycoris_amd import ops
+    from lycoris_amd.grad_sync import AdapterGradSync
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    f32 = dict(device=DEV, dtype=torch.float32, generator=gen)
+    pairs = [(nn.Parameter(torch.randn(8, 8, **f32) * 0.3), nn.Parameter(torch.randn(80, 80, **f32) * 0.05)) for _ in range(3)]
+    params = [p for pr in pairs for p in pr]
+    x = torch.randn(128, 640, device=DEV, dtype=torch.bfloat16, generator=gen).requires_grad_(True)
+    g = torch.randn(128, 640, device=DEV, dtype=torch.bfloat16, generator=gen) * 0.05
+
+    def block(h):
+        for k in (0, 1, 0):  # pair 0 is applied twice inside the checkpointed region
+            h = h + ops.lokr_linear(h, pairs[k][0], pairs[k][1], 1.0)
+        return h
+
+    def net(h, ckpt):
+        h = checkpoint(block, h, use_reentrant=reentrant) if ckpt else block(h)
+        return h + ops.lokr_linear(h, pairs[2][0], pairs[2][1], 1.0)
+
+    want = [t.clone() for t in torch.autograd.grad(net(x, False), params, g)]
+    sync = AdapterGradSync(params, bucket_bytes=1)
+    sync.attach_fused()
+    try:
+        for _ in range(2):
+            sync.zero_grad()
+            net(x, True).backward(g)
+            assert sorted(sync.launch_log) == list(range(len(sync.buckets))), "every bucket launched from inside the backward pass"
+            sync.finish()
+            torch.cuda.synchronize()
+            for p, w in zip(params, want):
+                assert float((p.grad - w).norm() / w.norm()) < 1e-5
+    finally:
+        sync.attach_fused(False)
+        sync.remove()
