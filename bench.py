@@ -806,6 +806,67 @@ def roofline(insts, args, dtype, dev):
                           "bwd_us": round(tb, 2), "bwd_gbs": round(bb_ / tb * 1e-3, 1), "bwd_frac": round(bb_ / tb * 1e-3 / HBM_PEAK_GBS, 4),
                           "bwd_mfma_model": round(mfma_frac(Nf, Kf, tb, True), 3)})
         out["per_shape"] = table
+        # Sibling projections in one launch (lyc_lokr_linear_fwd_group / _bwd_group): the to_q / to_k / to_v layers of an
+        # attention block (3 of every 6 dim -> dim layers) and to_k / to_v of its cross-attention (the M = 77 layers, in pairs) share
+        # their input in the real UNet and are independent of each other.  Measured here as an A/B over the SAME layer instances:
+        # per-layer launches (what the module API and the headline step do) against one grouped launch per sibling set.
+        if use_planes and args.model == "sdxl":
+            sib = {}
+            for (M, I, O), gsz, tag in (((1024, 1280, 1280), 3, "attn1_qkv_1280"), ((77, 2048, 1280), 2, "attn2_kv_1280"),
+                                        ((4096, 640, 640), 3, "attn1_qkv_640"), ((77, 2048, 640), 2, "attn2_kv_640")):
+                idx = shapes.get((M, I, O), [])
+                blocks = {(1024, 1280, 1280): 60, (77, 2048, 1280): 60, (4096, 640, 640): 10, (77, 2048, 640): 10}[(M, I, O)]
+                nset = min(len(idx) // gsz, 20)
+                if nset < 1:
+                    continue
+                sets = [idx[i * gsz:(i + 1) * gsz] for i in range(nset)]
+                a = FACTOR
+                c, d = O // a, I // a
+                ys = {k: torch.empty(M, O, dtype=dtype, device=dev) for st_ in sets for k in st_}
+                fw_items, bw_items = [], []
+                for st_ in sets:
+                    fw = (N.LinearGroupItem * gsz)()
+                    bw = (N.LinearGroupItem * gsz)()
+                    for j, k in enumerate(st_):
+                        it, rows, g, fs, bufs = calls[k]
+                        fw[j] = N.LinearGroupItem(N.ptr(rows), N.ptr(fs[0]), N.ptr(planes[id(it)][0]), None, N.ptr(ys[k]), None, M, 1.0)
+                        bw[j] = N.LinearGroupItem(N.ptr(g), N.ptr(fs[0]), N.ptr(planes[id(it)][1]), N.ptr(rows), N.ptr(dxs[k]), N.ptr(wss[k]), M, 1.0)
+                    fw_items.append(fw)
+                    bw_items.append(bw)
+                _KEEP.extend([ys, fw_items, bw_items])
+
+                def f_each():
+                    for st_ in sets:
+                        for k in st_:
+                            it, rows, g, fs, bufs = calls[k]
+                            N.call("lyc_lokr_linear_fwd_planes", N.ptr(rows), N.ptr(fs[0]), N.ptr(planes[id(it)][0]), None, N.ptr(ys[k]), M, a, a, c, d,
+                                   1.0, code, N.stream_ptr(dev))
+
+                def f_group():
+                    for fw in fw_items:
+                        N.call("lyc_lokr_linear_fwd_group", ctypes.cast(fw, ctypes.c_void_p), gsz, a, a, c, d, code, N.stream_ptr(dev))
+
+                def b_each():
+                    for st_ in sets:
+                        for k in st_:
+                            it, rows, g, fs, bufs = calls[k]
+                            N.call("lyc_lokr_linear_bwd_planes", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(planes[id(it)][1]), N.ptr(dxs[k]),
+                                   N.ptr(bufs[0]), None, N.ptr(wss[k]), M, a, a, c, d, 1.0, code | 0x200, N.stream_ptr(dev))
+
+                def b_group():
+                    for bw in bw_items:
+                        N.call("lyc_lokr_linear_bwd_group", ctypes.cast(bw, ctypes.c_void_p), gsz, a, a, c, d, code, N.stream_ptr(dev))
+
+                t = {nm: _graph_ms(fn) * 1e3 / nset for nm, fn in (("fwd_per_layer", f_each), ("fwd_grouped", f_group), ("dx_per_layer", b_each),
+                                                                    ("dx_grouped", b_group))}
+                sib[tag] = {"layers_per_group": gsz, "groups_in_unet": blocks, **{k_: round(v, 2) for k_, v in t.items()},
+                            "saving_ms_per_step": round(blocks * (t["fwd_per_layer"] - t["fwd_grouped"] + t["dx_per_layer"] - t["dx_grouped"]) * 1e-3, 3)}
+            if sib:
+                sib["unit"] = "us per sibling group (hipGraph, HIP events)"
+                sib["saving_ms_per_step_total"] = round(sum(v["saving_ms_per_step"] for v in sib.values() if isinstance(v, dict)), 3)
+                sib["note"] = ("not part of `value`: the headline step launches layer by layer, as the reference's module API does; a caller that owns "
+                               "the attention block can issue its projections through the grouped entry points (INTEGRATION.md)")
+                out["sibling_groups"] = sib
         conv = conv_leg(insts, args, dtype)
         if conv:
             out["conv"] = conv

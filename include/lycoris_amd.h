@@ -205,6 +205,29 @@ int lyc_lokr_linear_fwd_planes(const void* x, const float* w1, const void* plane
 int lyc_lokr_linear_bwd_planes(const void* g, const void* x, const float* w1, const void* planes_bwd, void* dx, float* dw1,
                                float* dw2, void* ws, int64_t M, int a, int b, int c, int d, float alpha, int dtype, void* stream);
 int64_t lyc_lokr_planes_bytes(int c, int d, int taps, int backward);
+/* Sibling projections in ONE launch (round 4): up to 4 problems per launch (longer lists run in chunks) that share (a, b, c, d) --
+ * the to_q / to_k / to_v projections of an attention block, to_k / to_v of a cross-attention (reference call sites: one
+ * LokrModule.forward per projection, modules/lokr.py:436-486, each on the same hidden state).  A single 1024-token projection fills
+ * a third of the chip for ~5 us; the group is planned like one layer with the rows of all of them.  Results are bit-identical to
+ * the per-layer *_planes entry points.
+ *   forward : in = x [M, b*d], planes = planes_fwd, aux = base [M, a*c] or NULL, out = y [M, a*c], ws unused
+ *   backward: in = g [M, a*c], planes = planes_bwd, out = dx [M, b*d]; aux = x [M, b*d] and ws = the layer's scratch
+ *             (lyc_lokr_bwd_workspace_bytes) when the w1 gradient is wanted -- its partials are left in ws exactly as by
+ *             lyc_lokr_linear_bwd_planes(dtype | LYC_DEFER_WGRAD), to be finished (with dW2) by lyc_lokr_wgrad_group[_ws]
+ * All items of a call agree on which optional operands they pass.  LYC_ERR_UNSUPPORTED (nothing launched) when an item is not on
+ * the packed-plane fast path: call the per-layer entry points instead. */
+typedef struct LycLokrLinearGroupItem {
+  const void* in;
+  const float* w1;     /* [a, b] */
+  const void* planes;
+  const void* aux;
+  void* out;
+  void* ws;
+  int64_t M;
+  float alpha;
+} LycLokrLinearGroupItem;
+int lyc_lokr_linear_fwd_group(const LycLokrLinearGroupItem* items, int n, int a, int b, int c, int d, int dtype, void* stream);
+int lyc_lokr_linear_bwd_group(const LycLokrLinearGroupItem* items, int n, int a, int b, int c, int d, int dtype, void* stream);
 int lyc_lokr_pack_w2(const float* w2, int64_t sq, int64_t sv, int64_t st, const float* w2a, int64_t a_sq, int64_t a_sr,
                      const float* w2b, int64_t b_sr, int64_t b_sv, int64_t b_st, int rank, int c, int d, int taps,
                      void* planes_fwd, void* planes_bwd, int dtype, void* stream);

@@ -24,6 +24,8 @@ _vp, _fp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, c
 SIGNATURES = {
     "lyc_lokr_linear_fwd": [_vp, _fp, _fp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_lokr_linear_bwd": [_vp, _vp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    "lyc_lokr_linear_fwd_group": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],  # items: pointer to an array of LinearGroupItem
+    "lyc_lokr_linear_bwd_group": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "lyc_lokr_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of WgradItem
     "lyc_lokr_wgrad_group_ws": [_vp, _i32, _i32, _vp, _i64, _vp],  # + device scratch of lyc_lokr_wgrad_table_bytes(n)
     "lyc_locon_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LoconWgradItem
@@ -110,6 +112,11 @@ class WgradItem(ctypes.Structure):
     """LycLokrWgradItem (include/lycoris_amd.h)"""
     _fields_ = [("g", _vp), ("x", _vp), ("w1", _vp), ("dw1", _vp), ("dw2", _vp), ("ws", _vp), ("M", _i64),
                 ("a", _i32), ("b", _i32), ("c", _i32), ("d", _i32), ("alpha", _f32)]
+
+class LinearGroupItem(ctypes.Structure):
+    """LycLokrLinearGroupItem (include/lycoris_amd.h)"""
+    _fields_ = [("inp", _vp), ("w1", _vp), ("planes", _vp), ("aux", _vp), ("out", _vp), ("ws", _vp), ("M", _i64), ("alpha", _f32)]
+
 
 _lock = threading.RLock()  # re-entrant: load_torch_ops() calls load() while holding it
 _lib = None

@@ -168,15 +168,12 @@ void launch_kron4_inst(const Kron4Args& a, int epi, dim3 grid, hipStream_t st) {
   else if (epi == 1) go(kron4_kernel<T, MI, NI, D, 1, NP>);
   else go(kron4_kernel<T, MI, NI, D, 2, NP>);
 }
-// returns the number of dw1 partial blocks the consumer has to sum (0: no w1 gradient requested)
-template <typename T>
-long launch_kron4(const KronArgs& ka, long dw1_blocks_total, hipStream_t st) {
+inline Kron4Args kron4_args(const KronArgs& ka, int& epi) {
   const int G = ka.Gin;
   const long rows = ka.M * G;
-  const Kron4Plan p = kron4_plan(rows, ka.K, ka.N);
   Kron4Args a{};
   a.x = ka.x; a.y = ka.y; a.planes = ka.w2p; a.w1 = ka.w1;
-  const int epi = ka.dw1 ? 2 : (ka.base ? 1 : 0);
+  epi = ka.dw1 ? 2 : (ka.base ? 1 : 0);
   a.aux = epi == 2 ? ka.xref : ka.base;
   a.dw1_ws = ka.dw1_ws;
   a.x_bytes = (unsigned)(rows * ka.K * 2); a.y_bytes = (unsigned)(rows * ka.N * 2);
@@ -184,6 +181,15 @@ long launch_kron4(const KronArgs& ka, long dw1_blocks_total, hipStream_t st) {
   a.rows_total = (int)rows; a.K = ka.K; a.N = ka.N; a.KS = (ka.K + 31) / 32;
   a.lg = 31 - __builtin_clz((unsigned)G);
   a.s1o = (int)ka.s1o; a.s1i = (int)ka.s1i; a.alpha = ka.alpha;
+  return a;
+}
+// returns the number of dw1 partial blocks the consumer has to sum (0: no w1 gradient requested)
+template <typename T>
+long launch_kron4(const KronArgs& ka, long dw1_blocks_total, hipStream_t st) {
+  const long rows = ka.M * ka.Gin;
+  const Kron4Plan p = kron4_plan(rows, ka.K, ka.N);
+  int epi = 0;
+  Kron4Args a = kron4_args(ka, epi);
   dim3 grid((unsigned)cdiv(rows, 64 * p.MI), (unsigned)cdiv(ka.N, 16 * p.NI));
   const long nwg = (long)grid.x * grid.y;
   a.dw1_blocks = (int)(dw1_blocks_total > nwg ? dw1_blocks_total : nwg);
@@ -201,6 +207,60 @@ long launch_kron4(const KronArgs& ka, long dw1_blocks_total, hipStream_t st) {
     else launch_kron4_inst<T, 1, 2, 3, false>(a, epi, grid, st);
   }
   return epi == 2 ? (long)a.dw1_blocks : 0;
+}
+
+// ---- several problems of one shape class in ONE launch (kron4_group_kernel) ------------------------------------------------------
+inline long lokr_dx_partial_blocks(long M, int G, int K, int N);
+template <typename T, int MI, int NI, int D, bool NP>
+void launch_kron4_group_inst(const Kron4GroupArgs& ga, int epi, dim3 grid, hipStream_t st) {
+  constexpr int lds = kron4_lds_bytes(MI, NI, D);
+  auto go = [&](auto kern) {
+    if (lds > 64 * 1024) {
+      static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)once;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, ga);
+  };
+  if (epi == 0) go(kron4_group_kernel<T, MI, NI, D, 0, NP>);
+  else if (epi == 1) go(kron4_group_kernel<T, MI, NI, D, 1, NP>);
+  else go(kron4_group_kernel<T, MI, NI, D, 2, NP>);
+}
+// `kas`: n <= K4_GROUP_MAX problems with equal (G, K, N) and the same epilogue; the tile plan is the one of their rows TAKEN TOGETHER
+// (three 1024-row projections are planned like one 3072-row layer: wider column tiles, a full chip)
+template <typename T>
+int launch_kron4_group(const KronArgs* kas, int n, hipStream_t st) {
+  long rows_sum = 0, rows_max = 0;
+  for (int i = 0; i < n; ++i) {
+    rows_sum += kas[i].M * kas[i].Gin;
+    rows_max = std::max<long>(rows_max, kas[i].M * kas[i].Gin);
+  }
+  const Kron4Plan p = kron4_plan(rows_sum, kas[0].K, kas[0].N);
+  Kron4GroupArgs ga{};
+  ga.n = n;
+  int epi = 0;
+  const unsigned gy = (unsigned)cdiv(kas[0].N, 16 * p.NI);
+  for (int i = 0; i < n; ++i) {
+    ga.p[i] = kron4_args(kas[i], epi);
+    ga.nbx[i] = (int)cdiv(kas[i].M * kas[i].Gin, 64 * p.MI);
+    const long nwg = (long)ga.nbx[i] * gy;
+    const long want = kas[i].dw1 ? lokr_dx_partial_blocks(kas[i].M, kas[i].Gin, kas[i].K, kas[i].N) : 0;
+    ga.p[i].dw1_blocks = (int)(want > nwg ? want : nwg);
+  }
+  const dim3 grid((unsigned)cdiv(rows_max, 64 * p.MI), gy, (unsigned)n);
+  if (p.NI == 5) {
+    if (p.D == 2) launch_kron4_group_inst<T, 2, 5, 2, true>(ga, epi, grid, st);
+    else launch_kron4_group_inst<T, 2, 5, 3, true>(ga, epi, grid, st);
+  } else if (p.NI == 4) {
+    if (p.D == 2) launch_kron4_group_inst<T, 2, 4, 2, true>(ga, epi, grid, st);
+    else launch_kron4_group_inst<T, 2, 4, 3, true>(ga, epi, grid, st);
+  } else if (p.MI == 2) {
+    if (p.NP) launch_kron4_group_inst<T, 2, 2, 2, true>(ga, epi, grid, st);
+    else launch_kron4_group_inst<T, 2, 2, 2, false>(ga, epi, grid, st);
+  } else {
+    if (p.NP) launch_kron4_group_inst<T, 1, 2, 3, true>(ga, epi, grid, st);
+    else launch_kron4_group_inst<T, 1, 2, 3, false>(ga, epi, grid, st);
+  }
+  return LYC_OK;
 }
 
 // returns the number of workgroups (= number of dw1 partials when ka.dw1_ws is set)
@@ -681,6 +741,56 @@ int lyc_lokr_linear_bwd_planes(const void* g, const void* x, const float* w1, co
   if (!lokr_planes_usable(g, M, a, b, c, d, dtype))
     return fail(LYC_ERR_UNSUPPORTED, "lokr_linear_bwd_planes: the planes serve the 16-bit fast path only (lyc_lokr_linear_planes_ok)");
   return lokr_linear_bwd_impl(g, x, w1, nullptr, planes_bwd, dx, dw1, dw2, ws, M, a, b, c, d, alpha, dtype, stream);
+}
+
+// ---- sibling projections in one launch (round 4) -----------------------------------------------------------------------
+extern "C++" {
+namespace {
+int lokr_linear_group(const LycLokrLinearGroupItem* items, int n, int a, int b, int c, int d, int dtype, void* stream, bool backward) {
+  const char* who = backward ? "lokr_linear_bwd_group" : "lokr_linear_fwd_group";
+  if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "%s: bad item list", who);
+  if (n == 0) return LYC_OK;
+  const int dt = dtype & 0xff;
+  if ((dt != LYC_BF16 && dt != LYC_F16) || (dtype & ~0xff)) return fail(LYC_ERR_UNSUPPORTED, "%s: 16-bit activations, no dtype flags", who);
+  std::vector<KronArgs> kas((size_t)n);
+  for (int k = 0; k < n; ++k) {
+    const LycLokrLinearGroupItem& it = items[k];
+    if (!it.in || !it.w1 || !it.planes || !it.out) return fail(LYC_ERR_ARG, "%s: item %d: null pointer", who, k);
+    if (int rc = check_kron_dims(it.M, a, b, c, d)) return rc;
+    if (it.M < 1 || !lokr_planes_usable(it.in, it.M, a, b, c, d, dtype))
+      return fail(LYC_ERR_UNSUPPORTED, "%s: item %d is not on the packed-plane fast path (lyc_lokr_linear_planes_ok)", who, k);
+    if ((it.aux != nullptr) != (items[0].aux != nullptr) || (backward && (it.ws != nullptr) != (it.aux != nullptr)))
+      return fail(LYC_ERR_ARG, "%s: item %d: every item of a group takes the same operands (base / x + ws: all or none)", who, k);
+    KronArgs& ka = kas[(size_t)k];
+    ka = KronArgs{};
+    ka.x = it.in; ka.y = it.out; ka.w1 = it.w1; ka.w2p = it.planes; ka.alpha = it.alpha; ka.M = it.M;
+    if (!backward) {
+      ka.base = it.aux;
+      ka.Gin = b; ka.K = d; ka.Gout = a; ka.N = c; ka.s1o = b; ka.s1i = 1; ka.s2n = d; ka.s2k = 1;
+    } else {
+      ka.xref = it.aux; ka.dw1 = it.aux ? reinterpret_cast<float*>(it.ws) : nullptr;  // only a "w1 gradient wanted" flag: the partials go to ws
+      ka.dw1_ws = static_cast<float*>(it.ws);
+      ka.Gin = a; ka.K = c; ka.Gout = b; ka.N = d; ka.s1o = 1; ka.s1i = b; ka.s2n = 1; ka.s2k = d;
+    }
+    const bool ok = dt == LYC_BF16 ? kron4_ok<__bf16>(ka) : kron4_ok<_Float16>(ka);
+    if (!ok) return fail(LYC_ERR_UNSUPPORTED, "%s: item %d: 16-byte aligned operands and sizes below 2 GiB are required", who, k);
+  }
+  for (int lo = 0; lo < n; lo += K4_GROUP_MAX) {
+    const int cnt = std::min(K4_GROUP_MAX, n - lo);
+    if (dt == LYC_BF16) launch_kron4_group<__bf16>(kas.data() + lo, cnt, (hipStream_t)stream);
+    else launch_kron4_group<_Float16>(kas.data() + lo, cnt, (hipStream_t)stream);
+    if (int rc = check_launch(who)) return rc;
+  }
+  return LYC_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int lyc_lokr_linear_fwd_group(const LycLokrLinearGroupItem* items, int n, int a, int b, int c, int d, int dtype, void* stream) {
+  return lokr_linear_group(items, n, a, b, c, d, dtype, stream, false);
+}
+int lyc_lokr_linear_bwd_group(const LycLokrLinearGroupItem* items, int n, int a, int b, int c, int d, int dtype, void* stream) {
+  return lokr_linear_group(items, n, a, b, c, d, dtype, stream, true);
 }
 
 // one pack launch for MANY layers (Linear or Conv2d factors given as full matrices): the once-per-optimizer-step refresh

@@ -212,7 +212,8 @@ __device__ __forceinline__ typename Mma16<T>::frag k4_identity(int li, int g) {
 }
 // cross-wave sum of the dW1 accumulators through `red` (NW KiB) and the per-workgroup partial
 template <int NW>
-__device__ __forceinline__ void k4_dw1_partial(const Kron4Args& a, float* red, const f32x4& cdw, int tid, int wave, int li, int g, int lg) {
+__device__ __forceinline__ void k4_dw1_partial(const Kron4Args& a, float* red, const f32x4& cdw, int tid, int wave, int li, int g, int lg,
+                                               int me = (int)(blockIdx.y * gridDim.x + blockIdx.x), int nwg = (int)(gridDim.x * gridDim.y)) {
   const int G = 1 << lg;
   __syncthreads();
 #pragma unroll
@@ -228,7 +229,6 @@ __device__ __forceinline__ void k4_dw1_partial(const Kron4Args& a, float* red, c
       for (int w = 0; w < NW; ++w) s += red[256 * w + e];
     }
     const int e = po * a.s1o + u * a.s1i;  // position in dw1 memory order
-    const int nwg = (int)(gridDim.x * gridDim.y), me = (int)(blockIdx.y * gridDim.x + blockIdx.x);
     a.dw1_ws[(long)me * (G * G) + e] = a.alpha * s;
     // the consumer (lyc_lokr_wgrad_group / the dW2 launch's reducer slice) derives the block count from the layer's dimensions
     // alone (capi.hip: lokr_dx_partial_blocks): blocks beyond this grid are written as zeros
@@ -239,8 +239,9 @@ __device__ __forceinline__ void k4_dw1_partial(const Kron4Args& a, float* red, c
 // EPI: 0 = forward, 1 = forward with the fused `base + delta` epilogue, 2 = backward dx with the dW1 partials
 // NP : paired column tiles (16-byte stores, above).  ABL != 0: ablation builds of benchmarks/k4bench.cpp (results are garbage):
 //      1 = no stage-2 matrix work, 2 = no stores, 4 = no x DMA, 8 = no plane DMA, 16 = no stage-1 matrix work.
+// (bx, by) of (nbx, nby): the workgroup's row / column tile within ITS problem (a launch may carry several problems)
 template <typename T, int MI, int NI, int D, int EPI, bool NP = false, int ABL = 0>
-__global__ __launch_bounds__(NTHREADS, 2) void kron4_kernel(Kron4Args a) {
+__device__ __forceinline__ void kron4_body(const Kron4Args& a, const int bx, const int by, const int nbx, const int nby) {
   extern __shared__ __attribute__((aligned(1024))) char k4_smem[];
   using F8 = typename TT<T>::frag;
   using F4 = typename Mma16<T>::frag;
@@ -255,8 +256,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void kron4_kernel(Kron4Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = a.K, N = a.N, KS = a.KS, lg = a.lg, G = 1 << lg;
   const unsigned K2 = (unsigned)K * 2u;
-  const int row0 = (int)blockIdx.x * (64 * MI);
-  const int nt0 = (int)blockIdx.y * NI;
+  const int row0 = bx * (64 * MI);
+  const int nt0 = by * NI;
   LYC_TRACE_DECL;
   LYC_STAMP(0);
 
@@ -402,7 +403,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void kron4_kernel(Kron4Args a) {
   LYC_TRACE_FLUSH();
   // (the trash slot: every DMA of this workgroup has landed -- the last k step waited vmcnt(0) in every wave, of ITS OWN operations;
   //  k4_dw1_partial starts with a barrier)
-  if constexpr (EPI == 2) k4_dw1_partial<NWAVES>(a, reinterpret_cast<float*>(k4_smem + OFF_TRASH), cdw, tid, wave, li, g, lg);
+  if constexpr (EPI == 2) k4_dw1_partial<NWAVES>(a, reinterpret_cast<float*>(k4_smem + OFF_TRASH), cdw, tid, wave, li, g, lg, by * nbx + bx, nbx * nby);
+}
+
+template <typename T, int MI, int NI, int D, int EPI, bool NP = false, int ABL = 0>
+__global__ __launch_bounds__(NTHREADS, 2) void kron4_kernel(Kron4Args a) {
+  kron4_body<T, MI, NI, D, EPI, NP, ABL>(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y);
+}
+
+// Several problems of ONE tile plan in one launch (round 4: the q / k / v projections of an attention block, the k / v projections
+// of a cross-attention -- same shapes, same input or not): blockIdx.z selects the problem, whose own row-tile count may be smaller
+// than the grid's.  A 5 us launch that fills a third of the chip becomes one launch that fills it.
+constexpr int K4_GROUP_MAX = 4;
+struct Kron4GroupArgs {
+  int n;
+  int nbx[K4_GROUP_MAX];
+  Kron4Args p[K4_GROUP_MAX];
+};
+template <typename T, int MI, int NI, int D, int EPI, bool NP = false>
+__global__ __launch_bounds__(NTHREADS, 2) void kron4_group_kernel(Kron4GroupArgs ga) {
+  const int z = (int)blockIdx.z;
+  if ((int)blockIdx.x >= ga.nbx[z]) return;
+  const Kron4Args a = ga.p[z];
+  kron4_body<T, MI, NI, D, EPI, NP, 0>(a, (int)blockIdx.x, (int)blockIdx.y, ga.nbx[z], (int)gridDim.y);
 }
 
 }  // namespace lyc
