@@ -446,6 +446,8 @@ __global__ __launch_bounds__(NTHREADS) void kconv_kernel(KconvArgs ca) {
   const char* planes = static_cast<const char*>(ca.planes);
   const int nstage = (ca.ksteps + gm.kss - 1) / gm.kss;
   const int ntiles_n = (N + 15) / 16;
+  const __amdgpu_buffer_rsrc_t rs_planes =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(planes), 0, (int)((long)ntiles_n * ca.ksteps * 2048), 0x00020000);
   auto issue_stage = [&](int s, char* buf) {
     // NI * kss units of 2 KiB = 2 * NI * kss pieces of 1 KiB; piece p -> wave p % 4 (wave-uniform loop)
     const int npiece = 2 * NI * gm.kss;
@@ -457,9 +459,9 @@ __global__ __launch_bounds__(NTHREADS) void kconv_kernel(KconvArgs ca) {
       if (nt >= ntiles_n) nt = ntiles_n - 1;  // column tile beyond N: a valid duplicate (its results are never stored; finite
                                               // values keep the dW1 partial, which multiplies them by zeros, finite)
       if (ks < ca.ksteps) {
-        const char* src = planes + ((nt * ca.ksteps + ks) * 2 + half) * 1024 + lane * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(buf + p * 1024), 16, 0, 0);
+        // buffer_load ... lds (descriptor form) instead of global_load_lds: -3 .. -5 % per launch (profiles/r04_ktrace_conv.log)
+        const unsigned off = (unsigned)(((nt * ca.ksteps + ks) * 2 + half) * 1024 + lane * 16);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_planes, (__attribute__((address_space(3))) void*)(buf + p * 1024), 16, (int)off, 0, 0, 0);
       }
     }
   };
