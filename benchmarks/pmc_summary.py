@@ -25,7 +25,7 @@ def load(d, counter):
 
 
 def short(name):
-    for key in ("kron3_kernel", "kron_dw2s_conv_group_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "copy16", "kron_kernel", "kron_dw2_kernel",
+    for key in ("kron4_kernel", "kron4_group_kernel", "kron_dw2f_table_kernel", "kron_dw2f_group_kernel", "kron3_kernel", "kron_dw2s_conv_group_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "copy16", "kron_kernel", "kron_dw2_kernel",
                 "kconv_dw2_group_kernel", "kconv_kernel", "kron_pack", "bneck_kernel", "lowrank_tn_kernel", "gexp_kernel"):
         if key in name:
             return key + name.split(key)[1][:34]
@@ -34,10 +34,10 @@ def short(name):
 
 # kernel families of bench.py's roofline legs, per WORKLOAD "algo/model/layers" (one pair of rocprofv3 passes each)
 FAMILIES = {  # family -> (layers of the pass it is read from, kernel-name substrings)
-    "lokr_kron3": ("linear", ("kron3_kernel",)),
-    "lokr_dw2s": ("linear", ("kron_dw2s_kernel", "kron_dw2s_group_kernel")),
-    "lokr_linear": ("linear", ("kron3_kernel", "kron_dw2s_kernel", "kron_dw2s_group_kernel", "kron_dw1_reduce", "kron_kernel", "kron_dw2_kernel",
-                               "kron_pack")),
+    "lokr_kron3": ("linear", ("kron3_kernel", "kron4_kernel")),  # the forward / dx launches (round 4: kron4 on packed planes)
+    "lokr_dw2s": ("linear", ("kron_dw2s_kernel", "kron_dw2s_group_kernel", "kron_dw2f_table_kernel", "kron_dw2f_group_kernel")),
+    "lokr_linear": ("linear", ("kron3_kernel", "kron4_kernel", "kron_dw2s_kernel", "kron_dw2s_group_kernel", "kron_dw2f_table_kernel",
+                               "kron_dw2f_group_kernel", "kron_dw2f_table_write_kernel", "kron_dw1_reduce", "kron_kernel", "kron_dw2_kernel", "kron_pack")),
     "locon_linear": ("linear", ("bneck_kernel", "lowrank_tn", "skinny_", "expand_nt")),
     "lokr_kconv": ("conv", ("kconv_kernel",)),
     "lokr_conv_dw2": ("conv", ("kron_dw2s_conv_group_kernel", "kron_dw2s_kernel", "kconv_dw2_group_kernel")),
@@ -113,7 +113,7 @@ def main():
         rb = fm * (cal_r or 1024.0)
         wb = wm * (cal_w or 1024.0)
         print(f"{short(k):60s} {max(len(f), len(w)):6d} {fm:12.1f} {wm:12.1f} {rb / 1e6:9.2f} {wb / 1e6:9.2f} {(rb + wb) / 1e6:14.2f}")
-    for fam in ("kron3_kernel", "kron_dw2s_kernel", "kconv_kernel", "kron_dw2s_conv_group_kernel", "bneck_kernel", "lowrank_tn_kernel", "gexp_kernel"):
+    for fam in ("kron4_kernel", "kron_dw2f_table_kernel", "kron3_kernel", "kron_dw2s_kernel", "kconv_kernel", "kron_dw2s_conv_group_kernel", "bneck_kernel", "lowrank_tn_kernel", "gexp_kernel"):
         fs = [v for k, vs in fetch.items() if fam in k for v in vs]
         ws_ = [v for k, vs in write.items() if fam in k for v in vs]
         if fs and ws_:
