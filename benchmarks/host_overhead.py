@@ -45,7 +45,15 @@ def native_training(algo, ls):
     all layers run in grouped launches (ops.fused_grad_accumulation + the default deferral): only dx comes back from autograd"""
     fn = ops.lokr_linear if algo == "lokr" else ops.locon_linear
     ys = [fn(x, fs[0], fs[1], 1.0) for x, g, fs, W in ls]
-    torch.autograd.grad(ys, [x for x, g, fs, W in ls], [g for x, g, fs, W in ls])  # one engine call
+    # the factors are listed (a backward call computes only what it is asked for, round 4); the kernels add their gradients in place
+    torch.autograd.grad(ys, [t for x, g, fs, W in ls for t in [x] + fs], [g for x, g, fs, W in ls], allow_unused=True)  # one engine call
+
+
+def native_training_backward(algo, ls):
+    """the same through .backward() (every leaf that requires grad is asked for; x.grad is accumulated by autograd as well)"""
+    fn = ops.lokr_linear if algo == "lokr" else ops.locon_linear
+    ys = [fn(x, fs[0], fs[1], 1.0) for x, g, fs, W in ls]
+    torch.autograd.backward(ys, [g for x, g, fs, W in ls])
 
 
 def reference(algo, ls):
@@ -82,6 +90,7 @@ for algo in ("lokr", "locon"):
     ops.fused_grad_accumulation(True, None)
     try:
         row["native_cpp_training_config_us"] = round(wall(lambda: native_training(algo, ls)), 1)
+        row["native_cpp_training_config_backward_us"] = round(wall(lambda: native_training_backward(algo, ls)), 1)
     finally:
         ops.fused_grad_accumulation(False, None)
         for x, g, fs, W in ls:

@@ -215,15 +215,20 @@ bool eager_cuda(const Tensor& t) {
 // reduced in finish() instead of inside the backward pass (found by tests/test_gpu_grad_sync.py, round 4).  Leaf inputs that
 // require grad (never the activation at index 0) are therefore also kept as plain references in saved_data, which the hooks do not
 // see, and put back in place of their copies.
+const std::string& leaf_key(size_t i) {  // no string building on the per-layer path
+  static const std::string keys[8] = {"lyc_leaf0", "lyc_leaf1", "lyc_leaf2", "lyc_leaf3", "lyc_leaf4", "lyc_leaf5", "lyc_leaf6", "lyc_leaf7"};
+  return keys[i < 8 ? i : 7];
+}
 void save_vars(AutogradContext* ctx, torch::autograd::variable_list vars) {
+  TORCH_INTERNAL_ASSERT(vars.size() <= 8);
   for (size_t i = 1; i < vars.size(); ++i)
-    if (vars[i].defined() && vars[i].is_leaf() && vars[i].requires_grad()) ctx->saved_data["lyc_leaf" + std::to_string(i)] = vars[i];
+    if (vars[i].defined() && vars[i].is_leaf() && vars[i].requires_grad()) ctx->saved_data[leaf_key(i)] = vars[i];
   ctx->save_for_backward(std::move(vars));
 }
 torch::autograd::variable_list saved_vars(AutogradContext* ctx) {
   torch::autograd::variable_list s = ctx->get_saved_variables();
   for (size_t i = 1; i < s.size(); ++i) {
-    auto it = ctx->saved_data.find("lyc_leaf" + std::to_string(i));
+    auto it = ctx->saved_data.find(leaf_key(i));
     if (it == ctx->saved_data.end() || !it->second.isTensor()) continue;
     const Tensor& p = it->second.toTensor();
     if (p.defined() && s[i].defined() && !s[i].is_same(p) && s[i].sizes() == p.sizes()) s[i] = p;

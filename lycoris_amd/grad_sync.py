@@ -104,6 +104,41 @@ class AdapterGradSync:
         self._reset_pending()
 
     # ---- construction helpers --------------------------------------------------------------------------------
+    # ---- flat parameters: the optimizer step as ONE elementwise pass ------------------------------------------------------------
+    def flat_parameters(self):
+        """Re-home every registered parameter into a flat arena per dtype (same order as the gradient arena: `p.data` becomes a view,
+        values, shapes, strides and the Parameter objects themselves stay) and return one flat leaf per dtype whose `.grad` is the
+        gradient arena.  An optimizer built on the returned list updates all adapter parameters in one multi-tensor chunk stream
+
+            opt = torch.optim.AdamW(sync.flat_parameters(), lr=..., fused=True)
+
+        instead of walking 1 576 small tensors (SDXL LoKr: 1.40 -> ~0.3 ms per step, bench.py).  All parameters of one arena share
+        the optimizer hyper-parameters; layers that need their own (LoRA+ ratios, text-encoder learning rates) get their own
+        AdapterGradSync, or a regular per-tensor optimizer.  state_dict() of the modules is unaffected (views serialise as
+        tensors); the optimizer's own state is per flat tensor.  The update does not move the modules' version counters: the LoKr
+        plane cache follows step boundaries (optimizer-step hook), not versions."""
+        if getattr(self, "_flat", None) is not None:
+            return self._flat
+        flats = []
+        for dtype, garena in self.arenas.items():
+            parena = torch.empty_like(garena)
+            off = 0
+            with torch.no_grad():
+                for p in reversed(self.params):
+                    if p.dtype != dtype:
+                        continue
+                    n = p.numel()
+                    dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                    view = parena[off:off + n].as_strided(p.shape, p.stride()) if dense else parena[off:off + n].view_as(p)
+                    view.copy_(p)
+                    p.data = view
+                    off += n
+            flat = torch.nn.Parameter(parena, requires_grad=True)
+            flat.grad = garena
+            flats.append(flat)
+        self._flat = flats
+        return flats
+
     def _close_bucket(self, arena, start, end, members):
         b = _Bucket(flat=arena[start:end], n_params=len(members), params=list(members), index=len(self.buckets))
         for p in members:

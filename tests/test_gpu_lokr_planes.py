@@ -405,6 +405,41 @@ def test_linear_plane_cache_sees_data_style_updates(how):
     assert err(dx, oracle.lokr.backward(x64, g64, w1=w1_64, w2=new64, scale=0.5)["dx"], dtype) < TOL["store_out"][dtype]
 
 
+def test_flat_parameter_arena_updates_reach_the_planes():
+    """AdapterGradSync.flat_parameters(): the factors become views of one arena and the optimizer updates the ARENA (a different
+    tensor: the factors' version counters never move, and re-homing swaps their storage after the planes were packed once).  The
+    forward and dx after the step must use the updated w2."""
+    from lycoris_amd.grad_sync import AdapterGradSync
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(93)
+    M, a, c, d = 160, 8, 40, 80
+    x, x64 = rnd((M, a * d), dtype, gen)
+    g, g64 = rnd((M, a * c), dtype, gen, 0.05)
+    w1, w1_64 = rnd((a, a), torch.float32, gen, 0.3)
+    w2, w2_64 = rnd((c, d), torch.float32, gen, 0.1)
+    w1, w2 = torch.nn.Parameter(w1), torch.nn.Parameter(w2)
+    y0 = _lin(x, w1, w2)  # planes packed from the ORIGINAL storage
+    sync = AdapterGradSync([w1, w2])
+    flats = sync.flat_parameters()
+    assert w2.data.untyped_storage().data_ptr() == flats[0].data.untyped_storage().data_ptr()
+    assert err(_lin(x, w1, w2), oracle.lokr.forward(x64, w1=w1_64, w2=w2_64, scale=0.5), dtype) < TOL["store_out"][dtype]  # re-homed: repacked
+    opt = torch.optim.SGD(flats, lr=3.0)
+    sync.zero_grad()
+    xg = x.clone().requires_grad_(True)
+    _lin(xg, w1, w2).backward(g)
+    sync.finish()
+    v0 = w2._version
+    opt.step()
+    assert w2._version == v0  # updated through the flat leaf
+    new1, new2 = w1.detach().double().cpu().numpy(), w2.detach().double().cpu().numpy()
+    assert oracle.general.rel_err(new2, w2_64) > 1e-3  # a real step
+    assert err(_lin(x, w1, w2), oracle.lokr.forward(x64, w1=new1, w2=new2, scale=0.5), dtype) < TOL["store_out"][dtype]
+    xg2 = x.clone().requires_grad_(True)
+    dx, = torch.autograd.grad(_lin(xg2, w1, w2), [xg2], g)
+    assert err(dx, oracle.lokr.backward(x64, g64, w1=new1, w2=new2, scale=0.5)["dx"], dtype) < TOL["store_out"][dtype]
+    sync.remove()
+
+
 def test_plane_refresh_drops_entries_whose_storage_moved():
     """refresh_lokr_planes(force=True) packs from pointers cached per entry: a parameter whose storage was replaced since its last
     own layer call (`.data =` swap, `.to()`, offload) must be dropped, not read -- and its next call repacks."""

@@ -293,3 +293,33 @@ def test_always_reduce_runs_the_collectives_at_world_size_1():
     tests/test_gpu_grad_sync.py); here the same switch and the batched gradient-ready report over gloo on the CPU"""
     import torch.multiprocessing as mp
     mp.spawn(_worker_ws1, args=(1, _free_port(), None), nprocs=1, join=True)
+
+
+def test_flat_parameters_give_the_same_adamw_step_as_per_tensor_parameters():
+    """flat_parameters(): the registered parameters become views of one arena per dtype; AdamW over the flat leaf must move every
+    parameter exactly as AdamW over the individual tensors does (the update is elementwise), including a channels_last conv factor."""
+    from lycoris_amd.grad_sync import AdapterGradSync
+    torch.manual_seed(3)
+    shapes = [(8, 8), (160, 16), (3,), (12, 6, 3, 3)]
+    ref = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    ref[3] = torch.nn.Parameter(ref[3].detach().contiguous(memory_format=torch.channels_last))
+    mine = [torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in ref]
+    sync = AdapterGradSync(mine)
+    flats = sync.flat_parameters()
+    assert len(flats) == 1 and flats[0].grad.data_ptr() == sync.arenas[torch.float32].data_ptr()
+    assert all(p.data.untyped_storage().data_ptr() == flats[0].data.untyped_storage().data_ptr() for p in mine)
+    assert mine[3].is_contiguous(memory_format=torch.channels_last) and all(torch.equal(a, b) for a, b in zip(mine, ref))
+    o_ref = torch.optim.AdamW(ref, lr=1e-2, weight_decay=0.1)
+    o_mine = torch.optim.AdamW(flats, lr=1e-2, weight_decay=0.1)
+    for step in range(3):
+        sync.zero_grad()
+        o_ref.zero_grad()
+        for plist in (ref, mine):
+            sum(((p * (i + 1 + step)) ** 2).sum() for i, p in enumerate(plist)).backward()
+        sync.finish()
+        o_ref.step()
+        o_mine.step()
+        for a, b in zip(mine, ref):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), step
+    sd = {f"p{i}": p for i, p in enumerate(mine)}
+    assert all(v.shape == r.shape for v, r in zip(sd.values(), ref))
