@@ -1043,6 +1043,21 @@ void launch_dw2f(int cfg, const KronDw2fGroupArgs* ga, const KronDw2fItem* items
     default: launch_dw2f_inst<T, 5, 10, 1, 2, 2, 3>(ga, items, wg_end, n, grid, st); break;
   }
 }
+// Conv2d form: problems in the kernel arguments only (a UNet has a few dozen conv layers, each with thousands of workgroups)
+template <typename T>
+void launch_dw2f_conv(int cfg, const KronDw2fGroupArgs& ga, unsigned grid, hipStream_t st) {
+  auto go = [&](auto kern, int lds) {
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)once;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, ga);
+  };
+  switch (cfg) {
+    case DW2F_1010: go(kron_dw2f_group_kernel<T, 10, 10, 2, 2, 1, 3, true>, kron_dw2f_lds_bytes(10, 10, 1, 3)); break;
+    case DW2F_55: go(kron_dw2f_group_kernel<T, 5, 5, 1, 1, 4, 2, true>, kron_dw2f_lds_bytes(5, 5, 4, 2)); break;
+    case DW2F_105: go(kron_dw2f_group_kernel<T, 10, 5, 2, 1, 2, 3, true>, kron_dw2f_lds_bytes(10, 5, 2, 3)); break;
+    default: go(kron_dw2f_group_kernel<T, 5, 10, 1, 2, 2, 3, true>, kron_dw2f_lds_bytes(5, 10, 2, 3)); break;
+  }
+}
 inline long dw2f_item_wgs(const KronDw2fItem& q) {
   return round_up((long)q.tiles_i * q.tiles_j * q.nslab, 8) + round_up(q.dw1_ws ? q.dw1_red : 0, 8);
 }
@@ -1654,6 +1669,75 @@ int lyc_lokr_conv_wgrad_group(const LycLokrConvWgradItem* items_in, int n, int d
   hipStream_t st = (hipStream_t)stream;
   const int dt = dtype & 0xff;
   if (n > 0 && dt != LYC_BF16 && dt != LYC_F16) return fail(LYC_ERR_UNSUPPORTED, "lokr_conv_wgrad_group: 16-bit activations only");
+  // ---- full-width tiles (kron_dw2f.h, Conv2d form: the taps are column blocks of one virtual [rows, taps * d] operand whose shifted
+  //      source rows arrive by per-lane DMA offsets) for every layer they fit, unless the caller pins the round 1-3 plan ---------------
+  std::vector<char> wide((size_t)n, 0);
+  if (!(dtype & LYC_WGRAD_TILE_S)) {
+    for (int cfg = 0; cfg < DW2F_NCFG; ++cfg) {
+      const Dw2fCfg cf = DW2F_CFG[cfg];
+      KronDw2fGroupArgs ga{};
+      auto flush = [&]() -> int {
+        if (ga.n == 0) return LYC_OK;
+        for (int i = 0; i < ga.n; ++i)
+          for (int j = 0; j < i; ++j)
+            if (ga.p[i].out == ga.p[j].out || (ga.p[i].dw1 && ga.p[i].dw1 == ga.p[j].dw1)) ga.p[i].plain = ga.p[j].plain = 0;
+        const unsigned grid = (unsigned)ga.wg_end[ga.n - 1];
+        if (dt == LYC_BF16) launch_dw2f_conv<__bf16>(cfg, ga, grid, st);
+        else launch_dw2f_conv<_Float16>(cfg, ga, grid, st);
+        ga = KronDw2fGroupArgs{};
+        return check_launch("lokr_conv_wgrad_group(full-width tiles)");
+      };
+      for (int k = 0; k < n; ++k) {
+        const LycLokrConvWgradItem& it = items_in[k];
+        if (!it.g_rows || !it.x_rows || !it.w1 || !it.dw2p || it.B < 1 || (it.dw1 && (!it.ws || it.dw1_blocks < 1))) continue;  // reported below
+        ConvDims cd{};
+        if (lokr_conv_check(cd, it.B, it.H, it.W, it.a, it.b, it.c, it.d, it.kh, it.kw, it.sh, it.sw, it.ph, it.pw, it.dh, it.dw, dtype, it.x_rows,
+                            it.g_rows))
+          continue;  // reported by the loop below
+        const long J = (long)cd.taps * it.d, rows = it.B * cd.Ho * cd.Wo * it.a;
+        const int my = (it.c > 80 ? (J > 80 ? DW2F_1010 : DW2F_105) : (J > 80 ? DW2F_510 : DW2F_55));
+        const bool fits = it.c >= 40 && J >= 64 && cd.taps <= 255 && it.kw <= 255 && it.sh <= 255 && it.sw <= 255 && it.ph <= 255 && it.pw <= 255 &&
+                          it.dh <= 255 && it.dw <= 255 && rows * it.c * 2 < (1L << 30) && it.B * it.H * it.W * (long)it.a * it.d * 2 < (1L << 30) &&
+                          rows < (1L << 30) && (long)it.c * J < (1L << 24);
+        if (!fits || my != cfg) continue;
+        KronDw2fItem q{};
+        q.Q = it.g_rows; q.P = it.x_rows; q.W = it.w1; q.out = it.dw2p; q.rows_total = (int)rows; q.I = it.c; q.J = (int)J;
+        q.lg = 31 - __builtin_clz((unsigned)it.a);
+        q.ws = it.b; q.wt = 1; q.os = (int)J; q.alpha = it.alpha;
+        q.tiles_i = (int)cdiv(it.c, 16 * cf.TI); q.tiles_j = (int)cdiv(J, 16 * cf.TJ);
+        q.p_bytes = (unsigned)(it.B * it.H * it.W * (long)it.a * it.d * 2);
+        q.Hs = (int)it.H; q.Ws = (int)it.W; q.Hd = (int)cd.Ho; q.Wd = (int)cd.Wo; q.dtap = it.d;
+        q.taps = (unsigned char)cd.taps; q.kw = (unsigned char)it.kw; q.sh = (unsigned char)it.sh; q.sw = (unsigned char)it.sw;
+        q.ph = (unsigned char)it.ph; q.pw = (unsigned char)it.pw; q.dh = (unsigned char)it.dh; q.dw = (unsigned char)it.dw;
+        const long unit = 32L * cf.WK;
+        long ns = cdiv(q.rows_total, 2048);  // rows are cheap here (narrow factors, 9 taps of columns): longer slabs, fewer atomics
+        const long out_elems = (long)it.c * J;
+        while (ns > 1 && ns * out_elems > 4000000) --ns;
+        q.rows_per_slab = (int)(cdiv(cdiv(q.rows_total, ns), unit) * unit);
+        q.nslab = (int)cdiv(q.rows_total, q.rows_per_slab);
+        q.plain = q.nslab == 1 ? 1 : 0;
+        if (it.dw1) {
+          q.dw1_ws = static_cast<const float*>(it.ws); q.dw1 = it.dw1; q.dw1_n = it.a * it.b; q.dw1_nblk = (int)it.dw1_blocks;
+          long r = it.dw1_blocks / 256;
+          q.dw1_red = (int)(r > 8 ? 8 : r < 1 ? 1 : r);
+        }
+        const long wgs = dw2f_item_wgs(q);
+        const long before = ga.n ? ga.wg_end[ga.n - 1] : 0;
+        if (ga.n == DW2F_MAX || before + wgs > (1L << 30))
+          if (int rc = flush()) return rc;
+        ga.p[ga.n] = q;
+        ga.wg_end[ga.n] = (int)((ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs);
+        ++ga.n;
+        wide[(size_t)k] = 1;
+      }
+      if (int rc = flush()) return rc;
+    }
+  }
+  std::vector<LycLokrConvWgradItem> narrow_items;
+  for (int k = 0; k < n; ++k)
+    if (!wide[(size_t)k]) narrow_items.push_back(items_in[k]);
+  items_in = narrow_items.data();
+  n = (int)narrow_items.size();
 #ifdef LYC_EXPERIMENT_CONV_DW2_PATCH
   // ---- layers the patch kernel covers (stride-1 / small-patch geometries): kconv_dw2_group_kernel, 12 layers per launch ------
   std::vector<LycLokrConvWgradItem> rest;

@@ -39,6 +39,12 @@ struct KronDw2fItem {
   int dw1_nblk, dw1_n, dw1_red;
   float alpha;
   int plain;            // 1: one slab and nobody else adds into `out` during this launch -> load / add / store instead of atomics
+  // Conv2d form (taps > 1 or a strided / padded 1x1): P is a VIRTUAL [rows_total, taps * dtap] matrix whose row (destination pixel,
+  // t) and column (tap, v) is x_rows[(source pixel of the tap) * G + t, v], zero outside the image (lycoris modules/lokr.py: the
+  // F.conv2d of the rebuilt weight; the gather of csrc/kron_dw2s.h).  J = taps * dtap, out element (i, tap, v) at i * os + tap * dtap + v.
+  unsigned p_bytes;     // bytes of x_rows (the P descriptor covers the whole source matrix)
+  int Hs, Ws, Hd, Wd, dtap;
+  unsigned char taps, kw, sh, sw, ph, pw, dh, dw;  // taps == 0: plain rows (nn.Linear)
 };
 constexpr int DW2F_MAX = 24;
 struct KronDw2fGroupArgs {
@@ -46,7 +52,7 @@ struct KronDw2fGroupArgs {
   int wg_end[DW2F_MAX];  // exclusive prefix of the workgroup counts (tiles * slabs + reducers, per problem)
   KronDw2fItem p[DW2F_MAX];
 };
-static_assert(sizeof(KronDw2fGroupArgs) <= 3584, "kernel arguments are limited to 4 KiB");
+static_assert(sizeof(KronDw2fGroupArgs) <= 4000, "kernel arguments are limited to 4 KiB");
 
 __host__ __device__ constexpr int kron_dw2f_slot_bytes(int TI, int TJ, int WK) { return WK * 32 * 16 * (TI + TJ) * 2; }
 __host__ __device__ constexpr int kron_dw2f_lds_bytes(int TI, int TJ, int WK, int D) { return D * kron_dw2f_slot_bytes(TI, TJ, WK) + 1024; }
@@ -79,7 +85,7 @@ __device__ __forceinline__ void k2f_lgkm10(u32x2 (&r)[5][2]) {
 
 // TI x TJ: workgroup tile in units of 16; WR x WC x WK = 4 waves; D: ring depth (super steps).  `o_`: index of this workgroup within
 // the problem's range (a multiple of 8 workgroups for the tile work, then the w1-gradient reducers).
-template <typename T, int TI, int TJ, int WR, int WC, int WK, int D>
+template <typename T, int TI, int TJ, int WR, int WC, int WK, int D, bool CONV = false>
 __device__ __forceinline__ void kron_dw2f_body(const KronDw2fItem& it, const int o_) {
   static_assert(WR * WC * WK == NWAVES && TI % WR == 0 && TJ % WC == 0, "wave grid");
   extern __shared__ __attribute__((aligned(1024))) char k2f_smem[];
@@ -88,8 +94,9 @@ __device__ __forceinline__ void kron_dw2f_body(const KronDw2fItem& it, const int
   static_assert(SI == 5 && SJ == 5, "every wave keeps 5 x 5 MFMA tiles (k2f_lgkm10)");
   constexpr int QB = 32 * TI * 32, PB = 32 * TJ * 32;       // bytes of one 32-row step of Q / P in LDS (row pitch 32 TI / 32 TJ bytes)
   constexpr int SLOT = WK * (QB + PB);
-  constexpr int PIECES = SLOT / 1024, PPW = (PIECES + NWAVES - 1) / NWAVES;
-  static_assert(SLOT % 1024 == 0, "slot size");
+  constexpr int NQ = WK * TI, NP = WK * TJ;                 // 1 KiB pieces of the Q / P parts of a slot
+  constexpr int PQW = (NQ + NWAVES - 1) / NWAVES, PJW = (NP + NWAVES - 1) / NWAVES, PPW = PQW + PJW;
+  static_assert(SLOT == (NQ + NP) * 1024, "slot size");
   constexpr int QP = TI * 32, PP = TJ * 32;                 // LDS row pitches (bytes)
   constexpr int QCH = 2 * TI, PCH = 2 * TJ;                 // 16-byte chunks per row
   // Row pitch 320 bytes (10 tiles): source-side swizzle -- the DMA puts chunk c of row r at chunk c ^ (2 * ((r >> 2) & 1)), i.e. odd
@@ -145,36 +152,78 @@ __device__ __forceinline__ void kron_dw2f_body(const KronDw2fItem& it, const int
   // Q / P descriptors cover rows [0, rend) of the matrices: rows of the slab's last super step beyond `rend` (and whole super steps
   // beyond the slab: the schedule below is static) read as zeros
   const unsigned qpitch = (unsigned)I * 2u, ppitch = (unsigned)J * 2u;
+  const unsigned ppitch_src = CONV ? (unsigned)it.dtap * 2u : ppitch;  // Conv2d: a row of x_rows holds ONE pixel-group's dtap channels
   const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(it.Q), 0, (int)((unsigned)rend * qpitch), K4_RSRC_FLAGS);
-  const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(it.P), 0, (int)((unsigned)rend * ppitch), K4_RSRC_FLAGS);
-  // (QB = 1 KiB * TI and PB = 1 KiB * TJ: a piece never straddles the Q / P parts of a step)
+  const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(it.P), 0,
+                                                                       CONV ? (int)it.p_bytes : (int)((unsigned)rend * ppitch), K4_RSRC_FLAGS);
+  // Pieces (1 KiB of the slot image = 64 lanes x 16 bytes): the NQ = WK * TI pieces of the Q parts and the NP = WK * TJ pieces of the P
+  // parts are dealt to the waves separately (piece wave + 4 j of each kind), so whether operation j of a wave is a Q or a P piece is
+  // known at compile time.  Every wave issues exactly PPW = ceil(NQ / 4) + ceil(NP / 4) operations per super step -- surplus ones go
+  // to the trash KiB, out of bounds -- so the vmcnt bookkeeping is the same constant in all waves.
   unsigned voff[PPW];  // source offset of this lane's chunk for super step 0 (bytes), or out of bounds
+  // Conv2d: per P piece the destination pixel of the lane's row (image, y, x: advanced by 32 WK / G pixels per super step), the tap's
+  // source displacement and the byte offset of (t, v) within a source pixel
+  int cb[CONV ? PJW : 1], cy[CONV ? PJW : 1], cx[CONV ? PJW : 1], coy[CONV ? PJW : 1], cox[CONV ? PJW : 1], crow[CONV ? PJW : 1];
+  unsigned ccol[CONV ? PJW : 1];
 #pragma unroll
   for (int jx = 0; jx < PPW; ++jx) {
-    const int p = wave + NWAVES * jx;
-    const int k = p / (TI + TJ), c = p - k * (TI + TJ);  // step of the super step, piece within the step (wave-uniform)
-    const bool q = c < TI;
-    const int chunk = (q ? c : c - TI) * 64 + lane;      // 16-byte chunk within the Q (P) part
+    const bool q = jx < PQW;                              // compile time after unrolling
+    const int idx = wave + NWAVES * (q ? jx : jx - PQW);  // piece among the Q (P) pieces
+    const int per = q ? TI : TJ;
+    const int k = idx / per, c = idx - k * per;           // step of the super step, piece within the step's Q (P) part
+    const int chunk = c * 64 + lane;                      // 16-byte chunk within the Q (P) part
     const int row = chunk / (q ? QCH : PCH);
     int col = chunk - row * (q ? QCH : PCH);
     if (q ? QSW : PSW) col ^= 2 * ((row >> 2) & 1);
     const int gcol = (q ? i0 : j0) + col * 8;            // first element column of the chunk
-    const bool ok = p < PIECES && gcol < (q ? I : J);    // I, J % 8 == 0: a chunk is all in or all out
+    const bool ok = idx < (q ? NQ : NP) && gcol < (q ? I : J);  // I, J % 8 == 0: a chunk is all in or all out
     voff[jx] = ok ? (unsigned)(rbeg + k * 32 + row) * (q ? qpitch : ppitch) + (unsigned)gcol * 2u : K4_OOB;
+    if constexpr (CONV) {
+      if (!q) {
+        const int e = jx - PQW;
+        const int r0 = rbeg + k * 32 + row;
+        const int dpix = r0 >> lg, t = r0 & (G - 1);
+        const int hw = it.Hd * it.Wd;
+        cb[e] = dpix / hw;
+        const int rem = dpix - cb[e] * hw;
+        cy[e] = rem / it.Wd;
+        cx[e] = rem - cy[e] * it.Wd;
+        const int tap = ok ? gcol / it.dtap : 0, v = gcol - tap * it.dtap;  // dtap % 8 == 0: a chunk lies within one tap
+        const int ky = tap / it.kw, kx = tap - ky * it.kw;
+        coy[e] = ky * it.dh - it.ph;
+        cox[e] = kx * it.dw - it.pw;
+        ccol[e] = (unsigned)(t * it.dtap + v) * 2u;
+        crow[e] = ok ? r0 : 0x40000000;  // beyond every rend: the piece stays out of bounds
+      }
+    }
   }
-  // every wave issues exactly PPW operations per super step (pieces past the image go to the trash KiB, out of bounds): the vmcnt
-  // bookkeeping is the same compile-time constant in all waves
+  // Called with s = 0, 1, 2, ... in this order (the Conv2d state advances).
   auto issue = [&](int s, int slot) {
 #pragma unroll
     for (int jx = 0; jx < PPW; ++jx) {
-      const int p = wave + NWAVES * jx;
-      const int k = p / (TI + TJ), c = p - k * (TI + TJ);
-      const bool q = c < TI;
+      const bool q = jx < PQW;
+      const int idx = wave + NWAVES * (q ? jx : jx - PQW);
+      const int per = q ? TI : TJ;
+      const int k = idx / per, c = idx - k * per;
       // the row advance goes into the per-lane offset (not into soffset): the out-of-bounds test of rows >= rend then does not
       // depend on how the descriptor's range check treats the scalar offset; K4_OOB + advance may wrap for matrices close to
       // 2 GiB, which is why the host keeps them below 1 GiB (dw2f_ok)
-      const unsigned v = voff[jx] + (unsigned)s * (unsigned)(32 * WK) * (q ? qpitch : ppitch);
-      char* dst = k2f_smem + (p < PIECES ? slot * SLOT + p * 1024 : TRASH);
+      unsigned v = voff[jx] + (unsigned)s * (unsigned)(32 * WK) * (q ? qpitch : ppitch);
+      if constexpr (CONV) {
+        if (!q) {
+          const int e = jx - PQW;
+          const int ys = cy[e] * it.sh + coy[e], xs = cx[e] * it.sw + cox[e];
+          const bool in = crow[e] < rend && ys >= 0 && ys < it.Hs && xs >= 0 && xs < it.Ws;
+          v = in ? (unsigned)(((cb[e] * it.Hs + ys) * it.Ws + xs) << lg) * ppitch_src + ccol[e] : K4_OOB;
+          crow[e] += 32 * WK;
+          cx[e] += (32 * WK) >> lg;
+          while (cx[e] >= it.Wd) {
+            cx[e] -= it.Wd;
+            if (++cy[e] >= it.Hd) { cy[e] = 0; ++cb[e]; }
+          }
+        }
+      }
+      char* dst = k2f_smem + (idx < (q ? NQ : NP) ? slot * SLOT + k * (QB + PB) + (q ? 0 : QB) + c * 1024 : TRASH);
       if (q) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (k4_lds_ptr)dst, 16, (int)v, 0, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (k4_lds_ptr)dst, 16, (int)v, 0, 0, 0);
     }
@@ -357,14 +406,14 @@ __device__ __forceinline__ void kron_dw2f_body(const KronDw2fItem& it, const int
 // (a) up to DW2F_MAX problems in the kernel arguments
 // __launch_bounds__(256, 2): two workgroups per CU -- and, with at most 256 registers per lane, the compiler keeps the MFMA
 // accumulators in VGPRs (no v_accvgpr_read in front of the hi / lo split: 70 of 275 VALU instructions per step, PMC-counted)
-template <typename T, int TI, int TJ, int WR, int WC, int WK, int D>
+template <typename T, int TI, int TJ, int WR, int WC, int WK, int D, bool CONV = false>
 __global__ __launch_bounds__(NTHREADS, 2) void kron_dw2f_group_kernel(KronDw2fGroupArgs ga) {
   const int b = (int)blockIdx.x;
   int pi = 0;
   while (pi + 1 < ga.n && b >= ga.wg_end[pi]) ++pi;  // uniform: scalar loads from the kernel-argument segment
   const int b0 = pi ? ga.wg_end[pi - 1] : 0;
   const KronDw2fItem it = ga.p[pi];
-  kron_dw2f_body<T, TI, TJ, WR, WC, WK, D>(it, b - b0);
+  kron_dw2f_body<T, TI, TJ, WR, WC, WK, D, CONV>(it, b - b0);
 }
 
 // (b) any number of problems in a device table (written by kron_dw2f_table_write_kernel launches in front of this one): ONE launch

@@ -185,15 +185,23 @@ def test_every_sdxl_conv_takes_the_patch_kernel_where_lds_allows():
     assert n_f >= n - 6 and n_b >= n - 2, (n, n_f, n_b)
 
 
+@pytest.mark.parametrize("tiles", ["full_width", "narrow"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-def test_conv_wgrad_group_vs_oracle(dtype):
+def test_conv_wgrad_group_vs_oracle(dtype, tiles):
     """lyc_lokr_conv_wgrad_group over ALL geometries of the list in one call (the deferred form: dx launches with LYC_DEFER_WGRAD
-    leave the dw1 partials in `ws`, the grouped launch computes dw2p and reduces dw1) on the row-gather kernel.  (The LDS-patch
-    weight-gradient kernel of round 3 was measured slower and lives in benchmarks/experiments/ now, outside the product build.)"""
+    leave the dw1 partials in `ws`, the grouped launch computes dw2p and reduces dw1).  `full_width`: the Conv2d form of
+    kron_dw2f.h (round 4: the taps as column blocks of one virtual operand, shifted source rows by per-lane DMA offsets) for the
+    layers it fits, the row-gather kernel of kron_dw2s.h for the rest; `narrow`: LYC_WGRAD_TILE_S pins the row-gather kernel for
+    every layer.  (The LDS-patch kernel of round 3 lives in benchmarks/experiments/, outside the product build.)"""
     import ctypes
+    kernel = tiles
     lib = N.load()
     code = N.dtype_code(dtype)
-    geoms = GEOMS + [GEOMS[0]]  # one layer twice: two items on different tensors
+    # + the tile classes of the full-width kernel the list above does not reach: 160 x 80 (c > 80, one narrow column block: a 1x1
+    # window with stride 2 and padding), 80 x 80 (1x1), dilation and factor 4 / 16 on wide factors, three slabs of rows (B = 3)
+    wide = [(1, 9, 9, 8, 168, 72, 1, 2, 1, 1), (2, 7, 6, 8, 40, 64, 1, 1, 0, 1), (1, 10, 10, 8, 48, 24, 3, 1, 2, 2), (1, 8, 12, 4, 64, 48, 3, 1, 1, 1),
+            (1, 8, 8, 16, 48, 16, 3, 1, 1, 1), (3, 20, 20, 8, 88, 40, 3, 1, 1, 1)]
+    geoms = GEOMS + [GEOMS[0]] + wide  # (one layer twice: two items on different tensors)
     items = (N.LokrConvWgradItem * len(geoms))()
     keep, want = [], []
     for k, geom in enumerate(geoms):
@@ -231,7 +239,8 @@ def test_conv_wgrad_group_vs_oracle(dtype):
         keep += [x_rows, g_rows, dx_rows, ws, w1]
         gr = oracle.lokr.backward(x64, g64, w1=w1_64, w2=w2_64, scale=0.5, kshape=(kk, kk), conv_args={"stride": s, "padding": p, "dilation": dl})
         want.append((geom, dw1, dw2p, gr, (c, kk, d)))
-    N.call("lyc_lokr_conv_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(geoms), code, N.stream_ptr(dev()))
+    N.call("lyc_lokr_conv_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(geoms), code | (0x400 if tiles == "narrow" else 0),
+           N.stream_ptr(dev()))
     torch.cuda.synchronize()
     for k, (geom, dw1, dw2p, gr, (c, kk, d)) in enumerate(want):
         errs = {"dw1": err(dw1, gr["w1"]), "dw2": err(dw2p.view(c, kk, kk, d).permute(0, 3, 1, 2), gr["w2"])}
