@@ -362,11 +362,15 @@ def main():
     torch.cuda.synchronize()
 
     graphs, seg_bounds = [], []
+    # capture_error_mode="thread_local" on every capture below: with a process group alive, c10d's watchdog THREAD polls the events of
+    # the warm-up step's collectives; in the default "global" mode such a query during a capture is an error and aborts the process
+    # (hipErrorStreamCaptureUnsupported: seen once with --collective reduce_scatter, profiles/r04_final_ws1.log) -- a hazard for every
+    # N > 1 run, whatever the collective
     if not args.eager:
         sync._sync_enabled = False  # inside a capture nothing may be launched from the callbacks
         pool = torch.cuda.graph_pool_handle()
         g_fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_fwd, pool=pool):
+        with torch.cuda.graph(g_fwd, pool=pool, capture_error_mode="thread_local"):
             for arena in sync.arenas.values():
                 arena.zero_()
             # the optimizer changed every factor: repack the cached LoKr operand planes (one grouped launch per 28 factors) --
@@ -395,7 +399,7 @@ def main():
         hi = n_layers
         for e in edges:  # backward runs from the last layer to the first
             gph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gph, pool=pool):
+            with torch.cuda.graph(gph, pool=pool, capture_error_mode="thread_local"):
                 backward_range(outs, e, hi)
             graphs.append(gph)
             hi = e
@@ -517,7 +521,7 @@ def _graph_ms(fn, reps=4):
         fn()  # warm-up on this stream
         torch.cuda.synchronize()
         gph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gph, stream=st):
+        with torch.cuda.graph(gph, stream=st, capture_error_mode="thread_local"):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         gph.replay()

@@ -137,7 +137,7 @@ def main():
         sync._sync_enabled = False
         pool = torch.cuda.graph_pool_handle()
         g_fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_fwd, pool=pool):
+        with torch.cuda.graph(g_fwd, pool=pool, capture_error_mode="thread_local"):
             for arena in sync.arenas.values():
                 arena.zero_()
             outs = [(l.forward(), l) for l in layers]
@@ -147,7 +147,7 @@ def main():
         for s in range(nseg, 0, -1):
             lo, hi = edges[s - 1], edges[s]
             gph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gph, pool=pool):
+            with torch.cuda.graph(gph, pool=pool, capture_error_mode="thread_local"):
                 backward_range(outs, lo, hi)
             graphs.append(gph)
             bounds.append(layers[lo - 1].params[-1] if lo > 0 else None)
