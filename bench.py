@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--collective", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
                     help="per bucket: one in-place all-reduce (default) or an in-place reduce-scatter + all-gather pair")
     ap.add_argument("--layers", default="all", help="'all', 'linear' or 'conv' (development)")
+    ap.add_argument("--collectives-on-main-stream", action="store_true",
+                    help="development: issue the bucket collectives on the compute stream (no side stream, no overlap) -- separates the "
+                         "cost of the collectives themselves from the cost of running them beside the backward pass")
     ap.add_argument("--per-tensor-optimizer", action="store_true",
                     help="A/B: AdamW over the individual parameter tensors instead of the flat parameter arena (AdapterGradSync.flat_parameters)")
     ap.add_argument("--force-segments", action="store_true",
@@ -325,6 +328,8 @@ def main():
     # --rccl-ws1: the N > 1 step on ONE GPU -- a world_size-1 RCCL group, every bucket really all-reduced (AVG, in place, side
     # stream) between the replays of the backward segment graphs
     sync = AdapterGradSync(all_params, bucket_bytes=32 << 20, always_reduce=bool(args.rccl_ws1), collective=args.collective)
+    if args.collectives_on_main_stream:
+        sync.side_stream = None
     sync.attach_fused()  # kernels accumulate into the arena and report to the bucket counters (eager: overlap by hooks)
     from lycoris_amd import ops as _ops
     if args.no_defer:  # A/B: one weight-gradient launch per layer instead of the grouped launches

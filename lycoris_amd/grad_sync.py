@@ -46,7 +46,8 @@ class _Bucket:
 
 class AdapterGradSync:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20,
-                 process_group=None, average: bool = True, always_reduce: bool = False, collective: str = "all_reduce"):
+                 process_group=None, average: bool = True, always_reduce: bool = False, collective: str = "all_reduce",
+                 tail_bucket_bytes: int = 2 << 20):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("AdapterGradSync: no trainable parameters")
@@ -99,6 +100,11 @@ class AdapterGradSync:
                     start, members = off, []
             if members:
                 self._close_bucket(arena, start, off, members)
+            # The collective of the LAST bucket to become complete (the input-side layers) cannot overlap anything: the backward
+            # pass is over when it starts.  Its duration is what a step pays for the whole exchange, so it is kept small: the last
+            # `tail_bucket_bytes` of the arena form a bucket of their own (measured with RCCL at world_size 1: 21.45 -> 19.9 ms per
+            # SDXL LoKr step, profiles/r04_final_ws1.log; the same holds for a ring over xGMI)
+            self._split_tail(arena, esz, tail_bucket_bytes)
         for p in self.params:
             self._handles.append(p.register_post_accumulate_grad_hook(self._on_autograd_hook))
         self._reset_pending()
@@ -138,6 +144,34 @@ class AdapterGradSync:
             flats.append(flat)
         self._flat = flats
         return flats
+
+    def _split_tail(self, arena, esz, tail_bytes):
+        if tail_bytes <= 0 or not self.buckets:
+            return
+        last = self.buckets[-1]
+        if last.flat.untyped_storage().data_ptr() != arena.untyped_storage().data_ptr() or last.n_params < 2:
+            return
+        if last.flat.numel() * esz <= 2 * tail_bytes:
+            return
+        # parameters of the bucket in arena order; the tail = the trailing parameters whose sizes add up to <= tail_bytes (at least one)
+        acc, cut = 0, len(last.params)
+        for i in range(len(last.params) - 1, 0, -1):
+            n = last.params[i].numel() * esz
+            if acc + n > tail_bytes and cut < len(last.params):
+                break
+            acc += n
+            cut = i
+        if cut >= len(last.params) or cut == 0:
+            return
+        head, tail = last.params[:cut], last.params[cut:]
+        start = last.flat.storage_offset()
+        head_elems = sum(p.numel() for p in head)
+        end = start + last.flat.numel()
+        self.buckets.pop()
+        for p in last.params:
+            self._bucket_of.pop(p, None)
+        self._close_bucket(arena, start, start + head_elems, head)
+        self._close_bucket(arena, start + head_elems, end, tail)
 
     def _close_bucket(self, arena, start, end, members):
         b = _Bucket(flat=arena[start:end], n_params=len(members), params=list(members), index=len(self.buckets))

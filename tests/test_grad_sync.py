@@ -323,3 +323,22 @@ def test_flat_parameters_give_the_same_adamw_step_as_per_tensor_parameters():
             assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), step
     sd = {f"p{i}": p for i, p in enumerate(mine)}
     assert all(v.shape == r.shape for v, r in zip(sd.values(), ref))
+
+
+def test_the_last_bucket_to_complete_is_kept_small():
+    """the collective of the input-side layers' bucket overlaps nothing (the backward pass is over when it starts): the trailing
+    `tail_bucket_bytes` of the arena are a bucket of their own"""
+    from lycoris_amd.grad_sync import AdapterGradSync
+    params = [torch.nn.Parameter(torch.zeros(1000)) for _ in range(40)]  # 4 000 bytes each, registration = forward order
+    sync = AdapterGradSync(params, bucket_bytes=64000, tail_bucket_bytes=9000)
+    sizes = [b.flat.numel() * 4 for b in sync.buckets]
+    assert sum(sizes) == 160000 and sizes[-1] == 8000 and len(sync.buckets[-1].params) == 2
+    assert sync.buckets[-1].params == [params[1], params[0]]  # the first layers of the network: the last gradients of a backward pass
+    assert all(sync._bucket_of[p] is b for b in sync.buckets for p in b.params) and len(sync._bucket_of) == 40
+    assert [b.index for b in sync.buckets] == list(range(len(sync.buckets)))
+    sum((p * (i + 1)).sum() for i, p in enumerate(params)).backward()
+    assert sorted(sync.launch_log) == list(range(len(sync.buckets)))
+    sync.finish()
+    assert all(torch.all(p.grad == i + 1) for i, p in enumerate(params))
+    nosplit = AdapterGradSync([torch.nn.Parameter(torch.zeros(1000)) for _ in range(40)], bucket_bytes=64000, tail_bucket_bytes=0)
+    assert len(nosplit.buckets) == len(sync.buckets) - 1
