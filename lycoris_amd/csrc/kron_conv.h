@@ -417,7 +417,7 @@ struct KconvArgs {
 };
 
 template <typename T, int MI, int NI, bool WITH_DW1>
-__global__ __launch_bounds__(NTHREADS) void kconv_kernel(KconvArgs ca) {
+__global__ __launch_bounds__(NTHREADS, (MI <= 4 && MI * NI <= 12) ? 2 : 1) void kconv_kernel(KconvArgs ca) {
   extern __shared__ __attribute__((aligned(1024))) char kc_smem[];
   const KronArgs& a = ca.k;
   const KconvGeom& gm = ca.gm;
@@ -596,12 +596,12 @@ __global__ __launch_bounds__(NTHREADS) void kconv_kernel(KconvArgs ca) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT<T>::mma(af[mi], bl[ni], acc[mi][ni]);
     };
-    if (gm.kss == 4 && nk == 4) {  // the common case, straight-line: the fragment reads of step kk + 1 issue under the MFMAs of kk
+    // ONE code region updates the accumulators: four guarded steps (kss <= 4).  Two alternative regions (a straight-line body for
+    // full stages, a loop for the rest) made the register allocator copy every AGPR accumulator at their join -- 318 / 478 / 638
+    // v_accvgpr_mov per stage in the MI = 8 instantiations (round 4, `hipcc -S`), more cycles than the stage's MFMAs for NI = 2.
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) kstep(kk, 4);
-    } else {
-      for (int kk = 0; kk < nk; ++kk) kstep(kk, gm.kss);
-    }
+    for (int kk = 0; kk < 4; ++kk)
+      if (kk < nk) kstep(kk, gm.kss);
     if (s < 17) LYC_STAMP(3 + s);  // MFMAs of stage s issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage s + 1 has landed
     __syncthreads();  // ... everybody's has, and nobody still reads stage s's buffer
