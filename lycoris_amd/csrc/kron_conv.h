@@ -417,7 +417,7 @@ struct KconvArgs {
 };
 
 template <typename T, int MI, int NI, bool WITH_DW1>
-__global__ __launch_bounds__(NTHREADS, (MI <= 4 && MI * NI <= 12) ? 2 : 1) void kconv_kernel(KconvArgs ca) {
+__global__ __launch_bounds__(NTHREADS, (MI * NI <= 24) ? 2 : 1) void kconv_kernel(KconvArgs ca) {
   extern __shared__ __attribute__((aligned(1024))) char kc_smem[];
   const KronArgs& a = ca.k;
   const KconvGeom& gm = ca.gm;
