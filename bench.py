@@ -563,13 +563,19 @@ def pmc_traffic(family, workload):
             rec = json.load(f)
     except (OSError, ValueError):
         return None, "no profiles/pmc_traffic.json"
+    note = ""
     if rec.get("lib_sha16") != lib_sha():
-        return None, f"profiles/pmc_traffic.json was collected on build {rec.get('lib_sha16')}, this is {lib_sha()}"
+        # a later build whose difference from the profiled one is written down in the file (which kernels changed, and why their
+        # traffic did not) is accepted WITH that note; anything else is not
+        also = rec.get("also_valid_for", {}).get(lib_sha())
+        if also is None or workload not in also.get("workloads", []):
+            return None, f"profiles/pmc_traffic.json was collected on build {rec.get('lib_sha16')}, this is {lib_sha()}"
+        note = f"; collected on build {rec.get('lib_sha16')}, running build {lib_sha()}: {also.get('difference', '')}"
     wl = rec.get("workloads", {}).get(workload)
     if wl is None:
         return None, f"profiles/pmc_traffic.json has no pass for workload {workload}"
     fam = wl.get(family)
-    return (fam if fam else None), rec.get("source", "profiles/pmc_traffic.json")
+    return (fam if fam else None), rec.get("source", "profiles/pmc_traffic.json") + note
 
 
 def roofline(insts, args, dtype, dev):
