@@ -325,13 +325,15 @@ class AdapterGradSync:
             main = flat[:chunk * world]
             shard = main[rank * chunk:(rank + 1) * chunk]
             w = dist.reduce_scatter_tensor(shard, main, op=op, group=self.group, async_op=True)
+            work = w
             if not nccl:
                 w.wait()
                 if self.average:
                     shard.div_(world)
-            work = dist.all_gather_into_tensor(main, shard, group=self.group, async_op=True)
-            if not nccl:
-                work.wait()
+            if not getattr(self, "_shard_only", False):  # (ShardedAdamW gathers the updated PARAMETERS instead of the gradients)
+                work = dist.all_gather_into_tensor(main, shard, group=self.group, async_op=True)
+                if not nccl:
+                    work.wait()
         if chunk * world < n:
             tail = flat[chunk * world:]
             work = dist.all_reduce(tail, op=op, group=self.group, async_op=True)  # after the all-gather in the communicator's order
@@ -401,3 +403,70 @@ class AdapterGradSync:
         for h in self._handles:
             h.remove()
         self._handles.clear()
+
+
+class ShardedAdamW:
+    """AdamW with the optimizer work and the second half of the exchange sharded over the data-parallel ranks ("prefer
+    reduce-scatter + all-gather shapes"; ZeRO-1 for the adapters).  Needs `AdapterGradSync(..., collective="reduce_scatter")` and
+    its flat parameter arena:
+
+        sync = AdapterGradSync(params, collective="reduce_scatter"); opt = ShardedAdamW(sync, lr=1e-4)
+        loss.backward(); sync.finish(); opt.step()
+
+    During backward every bucket is only REDUCE-SCATTERED (rank r ends up with the mean gradient of elements
+    [r * chunk, (r + 1) * chunk) of the bucket); `step()` updates exactly those elements of the flat parameter arena -- moments
+    kept for the own shard only: 1 / N of the optimizer state and of its HBM traffic -- and ALL-GATHERS the updated parameters.  Same
+    bytes on the wire as the all-reduce, but the second half moves parameters after the update and can overlap the next forward's
+    first layers.  The < world_size leftover elements of a bucket are all-reduced and updated redundantly on every rank.  The
+    update is elementwise AdamW (decoupled weight decay, bias correction), equal to torch.optim.AdamW on the averaged gradients
+    (tests/test_grad_sync.py, 2 ranks).  One hyper-parameter set per arena, as with flat_parameters()."""
+
+    def __init__(self, sync: AdapterGradSync, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if sync.collective != "reduce_scatter":
+            raise ValueError("ShardedAdamW needs AdapterGradSync(collective='reduce_scatter')")
+        self.sync = sync
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.flats = sync.flat_parameters()
+        sync._shard_only = sync._reduce  # with one rank (and no forced collectives) the plain path below updates everything
+        self.t = 0
+        self.world = dist.get_world_size(sync.group) if sync._reduce else 1
+        self.rank = dist.get_rank(sync.group) if sync._reduce else 0
+        self.state = []  # per bucket: (param slice of the flat arena, grad slice, own range, tail range, m, v)
+        for b in sync.buckets:
+            flat = next(f for f in self.flats if f.dtype == b.flat.dtype)
+            pslice = flat.data[b.flat.storage_offset():b.flat.storage_offset() + b.flat.numel()]
+            n = b.flat.numel()
+            chunk = n // self.world
+            own = (self.rank * chunk, (self.rank + 1) * chunk) if self.world > 1 else (0, n)
+            tail = (chunk * self.world, n) if self.world > 1 else (n, n)
+            k = (own[1] - own[0]) + (tail[1] - tail[0])
+            self.state.append((pslice, b.flat, own, tail, torch.zeros(k, dtype=torch.float32, device=pslice.device),
+                               torch.zeros(k, dtype=torch.float32, device=pslice.device)))
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        b1, b2 = self.betas
+        c1, c2 = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
+        works = []
+        for pslice, gslice, own, tail, m, v in self.state:
+            off = 0
+            for lo, hi in (own, tail):
+                if hi <= lo:
+                    continue
+                p, g = pslice[lo:hi], gslice[lo:hi].float()
+                mm, vv = m[off:off + hi - lo], v[off:off + hi - lo]
+                off += hi - lo
+                mm.mul_(b1).add_(g, alpha=1.0 - b1)
+                vv.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+                upd = (mm / c1) / ((vv / c2).sqrt_().add_(self.eps))
+                p.mul_(1.0 - self.lr * self.weight_decay).add_(upd.to(p.dtype), alpha=-self.lr)
+            if self.world > 1 and own[1] > own[0]:
+                chunk = own[1] - own[0]
+                main = pslice[:chunk * self.world]
+                works.append(dist.all_gather_into_tensor(main, main[own[0]:own[1]], group=self.sync.group, async_op=True))
+        for w in works:
+            w.wait()  # nccl: a stream-level wait
+
+    def zero_grad(self):
+        self.sync.zero_grad()
