@@ -17,6 +17,12 @@ every gradient into bucket buffers and back.  Here the adapter gradients *live* 
     routes its per-parameter notification to the same bucket counters, so the collectives are launched from inside
     the backward pass there too.
 
+  * round 4: `collective="reduce_scatter"` runs every bucket as an in-place reduce-scatter + all-gather pair; the last bucket to
+    become complete (the input-side layers: its collective overlaps nothing) is kept small (`tail_bucket_bytes`);
+    `bucket_boundaries()` / `launch_buckets()` serve callers that replay the backward pass in captured segments;
+    `flat_parameters()` re-homes the parameters into a twin arena so that an optimizer steps ONE flat leaf per dtype, and
+    `ShardedAdamW` shards the optimizer step and the second half of the exchange over the ranks (ZeRO-1 for the adapters).
+
 The frozen base model is never touched: only adapter parameters are registered.  Do NOT also wrap the network in
 DDP.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by one link, so buckets are
 kept large (default 32 MiB: ~0.4 ms on a ring) and few; SDXL payloads are 25-790 MB.
