@@ -8,24 +8,13 @@ import csv, glob
 f = glob.glob('/tmp/ws1t/**/*kernel_trace.csv', recursive=True)[0]
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(f))]
 rows.sort()
-# the timed steps are the last ones: take the last 40 % of the trace
-t0 = rows[0][0]; t1 = rows[-1][1]
-cut = t1 - int((t1 - t0) * 0.25)
-sel = [r for r in rows if r[0] >= cut]
-span = (sel[-1][1] - sel[0][0]) / 1e6
-busy = 0; cur_end = sel[0][0]; gaps = []
-for s, e, n in sel:
-    if s > cur_end:
-        gaps.append((s - cur_end, n[:60]))
-    if e > cur_end:
-        busy += e - max(s, cur_end); cur_end = e
-print(f"window {span:.2f} ms, GPU busy (union of kernels) {busy / 1e6:.2f} ms, idle {span - busy / 1e6:.2f} ms, kernels {len(sel)}")
-gaps.sort(reverse=True)
-print("largest gaps (us, kernel that followed):", [(round(g / 1e3, 1), n) for g, n in gaps[:12]])
-rc = [(e - s) / 1e3 for s, e, n in sel if 'ccl' in n.lower()]
-print("RCCL kernels in window:", len(rc), "total us", round(sum(rc), 1), "max", round(max(rc), 1) if rc else None)
-names = {}
-for s, e, n in sel:
-    if 'ccl' in n.lower(): names[n[:80]] = names.get(n[:80], 0) + 1
-print(names)
+idx = [i for i, r in enumerate(rows) if 'oneRankReduce' in r[2] or 'ccl' in r[2].lower()]
+print("collective kernels in the trace:", len(idx))
+# the last 12 collectives (two timed steps): duration, idle time of the GPU right before it starts and right after it ends
+for i in idx[-12:]:
+    s, e, n = rows[i]
+    prev_end = max(r[1] for r in rows[max(0, i - 40):i]) if i else s
+    nxt = next((r[0] for r in rows[i + 1:i + 40] if r[0] >= e), e)
+    running = sum(1 for r in rows[max(0, i - 40):i + 40] if r[0] < e and r[1] > s) - 1
+    print(f"  {n[:48]:48s} dur {(e - s) / 1e3:7.1f} us | GPU idle before {max(0, s - prev_end) / 1e3:7.1f} us, after {max(0, nxt - e) / 1e3:7.1f} us | kernels overlapping it: {running}")
 PY
