@@ -82,6 +82,7 @@ def parse():
     ap.add_argument("--collective", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
                     help="per bucket: one in-place all-reduce (default) or an in-place reduce-scatter + all-gather pair")
     ap.add_argument("--layers", default="all", help="'all', 'linear' or 'conv' (development)")
+    ap.add_argument("--host-timing", action="store_true", help="development: also report the host time to SUBMIT one step (config.host_submit_ms)")
     ap.add_argument("--collectives-on-main-stream", action="store_true",
                     help="development: issue the bucket collectives on the compute stream (no side stream, no overlap) -- separates the "
                          "cost of the collectives themselves from the cost of running them beside the backward pass")
@@ -450,6 +451,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     ms_per_step = elapsed / args.steps * 1e3
+    host_submit_ms = None
+    if args.host_timing:  # how long does the HOST need to submit one step (no waiting for the GPU)?  3 steps from an idle queue
+        barrier()
+        th = time.perf_counter()
+        for _ in range(3):
+            step()
+        host_submit_ms = (time.perf_counter() - th) / 3 * 1e3
+        barrier()
     value = world * args.steps / elapsed  # whole job: every rank processes its own batch (weak scaling)
 
     model_name = "SDXL UNet 1024x1024 bs=1/GPU" if args.model == "sdxl" else "SD1.5 UNet 512x512 bs=4/GPU"
@@ -471,7 +480,7 @@ def main():
             "algo": args.algo, "factor": FACTOR if args.algo in ("lokr", "mixed") else None, "layers": n_layers,
             "lokr_w2": (f"low rank {args.rank} (lokr_w2_a @ lokr_w2_b: planes packed from the factors, chain rule in the grouped launch)" if args.rank else "full matrix") if args.algo in ("lokr", "mixed") else None,
             "adapter_params": sum(p.numel() for p in all_params), "dp_payload_mb": round(sync.payload_bytes / 2**20, 1),
-            "parallelism": f"dp{world}",
+            "parallelism": f"dp{world}", **({"host_submit_ms": round(host_submit_ms, 2)} if host_submit_ms is not None else {}),
             "optimizer": "torch.optim.AdamW(fused=True) over " + ("the individual parameter tensors" if args.per_tensor_optimizer else
                                                                   "one flat parameter arena per dtype (AdapterGradSync.flat_parameters)"),
             "graph": "eager (no capture)" if args.eager else
