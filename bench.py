@@ -93,9 +93,14 @@ def parse():
     ap.add_argument("--rccl-ws1", action="store_true",
                     help="run the N > 1 step on one GPU: nccl (= RCCL) process group of world_size 1, every gradient bucket all-reduced "
                          "in place on the side stream between the backward segment graphs (MASTER_ADDR / MASTER_PORT / RANK from the env)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="development: 'gloo' lets N ranks share ONE GPU (rank % device_count) to exercise the N > 1 control flow "
-                         "on a single-GPU box; the driver's runs use nccl (= RCCL), one GPU per rank")
+    ap.add_argument("--capture-collectives", action="store_true",
+                    help="--backend rccl only: record the bucket collectives INTO one backward hipGraph (the communicator's stream is "
+                         "forked into the capture); default: they are enqueued between the replays of the backward segment graphs")
+    ap.add_argument("--backend", default="rccl", choices=["rccl", "nccl", "gloo"],
+                    help="'rccl' (default): the ProcessGroup-free communicator of lycoris_amd.grad_sync (ncclCommInitRank once, "
+                         "collectives as plain stream work; no torch.distributed process group exists); 'nccl': the same collectives "
+                         "through c10d's ProcessGroupNCCL (rounds 3-4, A/B); 'gloo' (development) lets N ranks share ONE GPU "
+                         "(rank % device_count) to exercise the N > 1 control flow on a single-GPU box")
     ap.add_argument("--pmc-pass", type=int, default=0,
                     help="run N eager compute passes and exit (for rocprofv3 --pmc, which cannot sample inside graph replays)")
     a = ap.parse_args()
@@ -305,17 +310,43 @@ def lib_sha():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it (no WORLD_SIZE in the environment): re-run this very command line
+    as N ranks under torch.distributed.run -- one process per GPU, rendezvous on 127.0.0.1 -- and pass rank 0's JSON line through.
+    The driver's own form (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) sets WORLD_SIZE and never
+    comes here."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    dev_index = local_rank if args.backend != "gloo" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    comm = None
     if world > 1 or args.rccl_ws1:
-        if args.backend == "nccl":
+        if args.backend == "rccl":  # no process group at all: the 128-byte id travels through the launcher's store
+            from lycoris_amd.grad_sync import RcclCommunicator
+            comm = RcclCommunicator.from_env(dev) if world > 1 else RcclCommunicator(0, 1, dev)
+            assert comm.world == world and comm.rank == rank
+        elif args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
@@ -328,8 +359,8 @@ def main():
     all_params = [p for it in insts for p in it.params]
     # --rccl-ws1: the N > 1 step on ONE GPU -- a world_size-1 RCCL group, every bucket really all-reduced (AVG, in place, side
     # stream) between the replays of the backward segment graphs
-    sync = AdapterGradSync(all_params, bucket_bytes=32 << 20, always_reduce=bool(args.rccl_ws1), collective=args.collective)
-    if args.collectives_on_main_stream:
+    sync = AdapterGradSync(all_params, bucket_bytes=32 << 20, always_reduce=bool(args.rccl_ws1), collective=args.collective, comm=comm)
+    if args.collectives_on_main_stream and comm is None:
         sync.side_stream = None
     sync.attach_fused()  # kernels accumulate into the arena and report to the bucket counters (eager: overlap by hooks)
     from lycoris_amd import ops as _ops
@@ -403,12 +434,30 @@ def main():
         # (the collectives themselves are NOT captured: recording RCCL's all-reduce into the backward graph on a forked side stream
         # segfaults on this stack -- torch 2.10 + rocm 7.0, world_size-1 group, profiles/r04_ws1_variants.log)
         hi = n_layers
-        for e in edges:  # backward runs from the last layer to the first
+        captured_collectives = bool(args.capture_collectives and comm is not None and multi)
+        if captured_collectives:
+            # round 5: with the ProcessGroup-free communicator a collective is plain stream work, so the whole backward pass -- the
+            # segments AND the bucket collectives behind them -- is ONE graph: wait_current() forks the communicator's stream into the
+            # capture behind the segment that completes the bucket, join() brings it back before the capture ends.  The host then
+            # submits two graphs per step and never talks to RCCL.
             gph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gph, pool=pool, capture_error_mode="thread_local"):
-                backward_range(outs, e, hi)
+                for e, ready in zip(edges, plan):
+                    backward_range(outs, e, hi)
+                    sync.launch_buckets(ready)
+                    hi = e
+                comm.join()
+            sync._comm_pending = False
             graphs.append(gph)
-            hi = e
+            plan = [[]]
+            multi = False  # nothing is left to do between replays
+        else:
+            for e in edges:  # backward runs from the last layer to the first
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph, pool=pool, capture_error_mode="thread_local"):
+                    backward_range(outs, e, hi)
+                graphs.append(gph)
+                hi = e
         sync._sync_enabled = True
 
         seg_done = [torch.cuda.Event() for _ in graphs]
@@ -434,7 +483,10 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            if comm is not None:
+                comm.barrier()
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     c0 = sync.collectives_launched
@@ -446,7 +498,9 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 and comm is not None:
+        elapsed = comm.max_over_ranks(elapsed)
+    elif world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -486,8 +540,10 @@ def main():
             "graph": "eager (no capture)" if args.eager else
                      f"hipGraph replay: 1 forward graph + {len(graphs)} backward segment(s)"
                      + ((", bucket collectives (" + args.collective + ") "
-                         + ("issued between the bucket-aligned segments" if args.segments <= 0 else "issued between the segments")
-                         + " on a side stream") if (world > 1 or args.rccl_ws1) else ""),
+                         + ("captured inside the backward graph" if (not args.eager and captured_collectives) else
+                            ("issued between the bucket-aligned segments" if args.segments <= 0 else "issued between the segments"))
+                         + (" on the communicator's own stream (ProcessGroup-free RCCL, lycoris_amd.grad_sync.RcclCommunicator)"
+                            if comm is not None else " on a side stream (c10d " + args.backend + ")")) if (world > 1 or args.rccl_ws1) else ""),
             "conv_memory_format": "channels_last (documented default, DESIGN.md 2; --nchw for the A/B leg)" if args.channels_last else "contiguous (NCHW)",
             "inputs": "shared per shape (cache-resident)" if args.shared_inputs else
                       f"distinct x / g per layer instance: {act_bytes / 1e9:.2f} GB read per step",
@@ -511,13 +567,18 @@ def main():
     if args.rccl_ws1:
         steps_run = args.warmup + args.steps
         sync.collectives_launched -= c0
-        result["config"]["rccl_ws1"] = {"backend": dist.get_backend(), "buckets": len(sync.buckets),
-                                        "all_reduces_per_step": sync.collectives_launched / max(1, steps_run)}
+        result["config"]["rccl_ws1"] = {"backend": "rccl (ProcessGroup-free communicator)" if comm is not None else "c10d " + dist.get_backend(),
+                                        "buckets": len(sync.buckets),
+                                        "all_reduces_per_step": sync.collectives_launched / max(1, steps_run),
+                                        "note": "RCCL returns early from an in-place collective of a 1-rank communicator: this run measures "
+                                                "the ordering / submission cost of the exchange, not ring time" if comm is not None else None}
     if rank == 0:
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)  # RCCL's version banner sits in the C stdio buffer: the JSON line is the LAST line
         print(json.dumps(result), flush=True)
-    if world > 1 or args.rccl_ws1:
+    if comm is not None:
+        comm.destroy()
+    elif world > 1 or args.rccl_ws1:
         dist.destroy_process_group()
 
 

@@ -9,6 +9,10 @@ side stream before the optimizer -- and checks that the gradients equal the ones
 
     MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 RANK=0 WORLD_SIZE=1 python benchmarks/rccl_ws1_check.py
 
+Round 5: `--comm rccl` runs the same steps through the ProcessGroup-free communicator (lycoris_amd.grad_sync.RcclCommunicator:
+ncclCommInitRank once, collectives as plain work on its own HIP stream) -- no torch.distributed process group exists -- plus the
+communicator's primitives on their own and a step whose bucket collectives are RECORDED INSIDE the backward hipGraph.
+
 Also checks a module shared by two layer calls through the sync (its bucket used to be reduced early).
 Prints "rccl-ws1 ok" and exits 0.  Run by tests/test_gpu_grad_sync.py in a child process.
 """
@@ -23,7 +27,7 @@ import torch
 import torch.distributed as dist
 
 from lycoris_amd import ops
-from lycoris_amd.grad_sync import AdapterGradSync
+from lycoris_amd.grad_sync import AdapterGradSync, RcclCommunicator
 
 DEV = torch.device("cuda:0")
 
@@ -58,6 +62,27 @@ def main():
     # --eager-only (what tests/test_gpu_grad_sync.py runs by default: see its docstring)
     no_pg, skip_eager, eager_only = "--no-pg" in sys.argv, "--skip-eager" in sys.argv, "--eager-only" in sys.argv
     torch.cuda.set_device(0)
+    own = "--comm" in sys.argv and sys.argv[sys.argv.index("--comm") + 1] == "rccl"
+    comm = None
+    if own:
+        no_pg = True
+        comm = RcclCommunicator(0, 1, DEV)
+        assert not dist.is_initialized()
+        # the primitives, in place, ordered against the compute stream by events only
+        t = torch.randn(1 << 20, device=DEV)
+        ref = t.clone()
+        comm.wait_current()
+        comm.all_reduce(t, comm.AVG)
+        comm.reduce_scatter(t[:t.numel()], t, comm.SUM)   # world 1: the shard IS the buffer
+        comm.all_gather(t, t[:t.numel()])
+        comm.broadcast(t, 0)
+        comm.join()
+        t.add_(1.0)  # on the compute stream, behind the join
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref + 1.0)
+        comm.barrier()
+        assert comm.max_over_ranks(3.5) == 3.5
+        print("rccl communicator up (ProcessGroup-free), primitives ok", flush=True)
     if not no_pg:
         dist.init_process_group("nccl", device_id=DEV)
         assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
@@ -108,7 +133,7 @@ def main():
         return worst
 
     # ---- eager: collectives launched from inside the backward by the fused-accumulation callback -------------------------
-    sync = AdapterGradSync(params, bucket_bytes=(32 << 20) if "--big-buckets" in sys.argv else (256 << 10), always_reduce=not no_pg)
+    sync = AdapterGradSync(params, bucket_bytes=(32 << 20) if "--big-buckets" in sys.argv else (256 << 10), always_reduce=(not no_pg) or own, comm=comm)
     assert len(sync.buckets) >= 3 or len(shapes) < 24 or "--big-buckets" in sys.argv, len(sync.buckets)  # several buckets
     print(f"{len(sync.buckets)} buckets", flush=True)
     sync.attach_fused()
@@ -162,11 +187,41 @@ def main():
             sync.finish()
             e = check(f"graph step {rep}")
         print(f"captured: 1 forward graph + {nseg} backward segments, bucket all-reduces between the replays, rel-err {e:.1e}", flush=True)
+        if own:  # the collectives recorded INTO one backward graph: the communicator's stream is forked into the capture and joined back
+            cuts = sync.bucket_boundaries({p: i for i, l in enumerate(layers) for p in l.params})
+            bedges = sorted(set(cuts), reverse=True)
+            done, bplan = set(), []
+            for e_ in bedges:
+                ready = [i for i, c in enumerate(cuts) if c >= e_ and i not in done]
+                done.update(ready)
+                bplan.append(ready)
+            sync._sync_enabled = False
+            sync._reset_pending()
+            g_bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_bwd, pool=pool, capture_error_mode="thread_local"):
+                hi = n
+                for e_, ready in zip(bedges, bplan):
+                    backward_range(outs, e_, hi)
+                    sync.launch_buckets(ready)
+                    hi = e_
+                if hi > 0:
+                    backward_range(outs, 0, hi)
+                comm.join()
+            sync._comm_pending = False
+            sync._sync_enabled = True
+            for rep in range(3):
+                sync._reset_pending()
+                g_fwd.replay()
+                g_bwd.replay()
+                e = check(f"captured-collectives step {rep}")
+            print(f"captured: ONE backward graph with {sum(len(r) for r in bplan)} bucket collectives recorded inside it, rel-err {e:.1e}", flush=True)
     finally:
         sync.attach_fused(False)
         sync.remove()
         if not no_pg and dist.is_initialized():
             dist.destroy_process_group()
+        if comm is not None:
+            comm.destroy()
     print("rccl-ws1 ok", flush=True)
 
 

@@ -892,6 +892,7 @@ struct LokrLinearFn : public torch::autograd::Function<LokrLinearFn> {
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    planes_mark_dirty_after_backward();  // the end of this backward pass is a step boundary for the plane cache (every LoKr node, on every path)
     auto saved = saved_vars(ctx);
     const Tensor &x = saved[0], &w1 = saved[1], &w2 = saved[2];
     const double alpha = ctx->saved_data["alpha"].toDouble();
@@ -982,6 +983,7 @@ struct LokrLinearLrFn : public torch::autograd::Function<LokrLinearLrFn> {
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    planes_mark_dirty_after_backward();  // the end of this backward pass is a step boundary for the plane cache (every LoKr node, on every path)
     auto saved = saved_vars(ctx);
     const Tensor &x = saved[0], &w1 = saved[1], &w2a = saved[2], &w2b = saved[3];
     const double alpha = ctx->saved_data["alpha"].toDouble();
@@ -1080,6 +1082,7 @@ struct LokrLinearLr2Fn : public torch::autograd::Function<LokrLinearLr2Fn> {
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    planes_mark_dirty_after_backward();  // the end of this backward pass is a step boundary for the plane cache (every LoKr node, on every path)
     auto saved = saved_vars(ctx);
     const Tensor &x = saved[0], &w1a = saved[1], &w1b = saved[2], &w2a = saved[3], &w2b = saved[4];
     const Tensor w1 = ctx->saved_data["w1"].toTensor();
@@ -1732,6 +1735,7 @@ struct LokrConv2dTraceFn : public torch::autograd::Function<LokrConv2dTraceFn> {
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    planes_mark_dirty_after_backward();  // the end of this backward pass is a step boundary for the plane cache (every LoKr node, on every path)
     auto s = saved_vars(ctx);
     const bool nx = ctx->needs_input_grad(0), n1 = ctx->needs_input_grad(1), n2 = ctx->needs_input_grad(2);
     static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_lokr_conv2d_backward", "")
@@ -1829,6 +1833,7 @@ struct LokrConv2dFn : public torch::autograd::Function<LokrConv2dFn> {
     return from_rows(y, B, gm.Ho, gm.Wo, !copied);
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    planes_mark_dirty_after_backward();  // the end of this backward pass is a step boundary for the plane cache (every LoKr node, on every path)
     auto s = saved_vars(ctx);
     const Tensor &rows = s[0], &w1 = s[1], &w2 = s[2];
     const double alpha = ctx->saved_data["alpha"].toDouble();
@@ -1951,6 +1956,7 @@ struct LokrConv2dLrFn : public torch::autograd::Function<LokrConv2dLrFn> {
     return from_rows(y, B, gm.Ho, gm.Wo, !copied);
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    planes_mark_dirty_after_backward();  // the end of this backward pass is a step boundary for the plane cache (every LoKr node, on every path)
     auto s = saved_vars(ctx);
     const Tensor &rows = s[0], &w1 = s[1], &w2a = s[2], &w2b = s[3];
     const double alpha = ctx->saved_data["alpha"].toDouble();
@@ -2247,6 +2253,7 @@ struct AdapterConv2dFn : public torch::autograd::Function<AdapterConv2dFn> {
     auto s = saved_vars(ctx);
     const Tensor &x = s[0], &cols = s[1], &saved = s[2];
     const int64_t algo = ctx->saved_data["algo"].toInt();
+    if (algo == ALGO_LOKR) planes_mark_dirty_after_backward();
     const double alpha = ctx->saved_data["alpha"].toDouble();
     auto gv = ctx->saved_data["geom"].toIntVector();
     const std::vector<int64_t> kernel{gv[0], gv[1]}, stride{gv[2], gv[3]}, padding{gv[4], gv[5]}, dilation{gv[6], gv[7]};
@@ -2429,8 +2436,11 @@ TORCH_LIBRARY_IMPL(lycoris_amd, Autograd, m) {
   m.impl("lokr_conv2d_lr", lokr_conv2d_lr_autograd);
 }
 
+void lyc_bind_rccl(py::module_& m);  // rccl_comm.cpp: the ProcessGroup-free communicator of the DP gradient exchange
+
 PYBIND11_MODULE(_lyc_torch, m) {
   m.doc() = "lycoris_amd: TORCH_LIBRARY(lycoris_amd) custom ops over liblycoris_amd.so";
+  lyc_bind_rccl(m);
   m.def("set_accum", [](bool enabled, py::object callback, py::object batch_callback) {
     std::lock_guard<std::mutex> lk(g_accum.mu);
     g_accum.enabled = enabled;

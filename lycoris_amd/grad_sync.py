@@ -27,6 +27,10 @@ The frozen base model is never touched: only adapter parameters are registered. 
 DDP.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by one link, so buckets are
 kept large (default 32 MiB: ~0.4 ms on a ring) and few; SDXL payloads are 25-790 MB.
 
+  * round 5: `comm=RcclCommunicator(...)` takes the exchange off c10d altogether ("a separate ProcessGroup-free RCCL
+    communicator object created once per process"): ncclCommInitRank once, the bucket collectives are plain work on the
+    communicator's own HIP stream ordered by events (csrc/rccl_comm.cpp) -- no Work objects, no watchdog thread, capturable.
+
 Works on CPU tensors with the gloo backend too (that is how tests/test_grad_sync.py covers the N > 1 path).
 """
 from __future__ import annotations
@@ -37,6 +41,104 @@ from typing import Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
+
+
+class RcclCommunicator:
+    """A ProcessGroup-free RCCL communicator (csrc/rccl_comm.cpp): one per process and GPU, created once.
+
+        comm = RcclCommunicator.from_env(device)            # under torchrun / any env:// launcher: id through the launcher's store
+        comm = RcclCommunicator(rank, world, device, store) # any object with set(key, bytes) / get(key) -> bytes
+        comm = RcclCommunicator.from_process_group()        # id broadcast through an existing (e.g. gloo) group
+        sync = AdapterGradSync(params, comm=comm)
+
+    Collectives are enqueued on the communicator's own high-priority HIP stream; `wait_current()` / `wait_event()` order them behind
+    the producer of the data, `join()` makes the caller's stream wait for them.  Nothing here synchronises the host."""
+
+    SUM, AVG, MAX = 0, 1, 2
+
+    def __init__(self, rank: int, world: int, device, store=None, unique_id: Optional[bytes] = None, key: str = "lycoris_amd/rccl_uid"):
+        from . import _native
+        ext = _native.load_torch_ops()
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise ValueError("RcclCommunicator needs a HIP device")
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        if unique_id is None:
+            if store is None:
+                if world != 1:
+                    raise ValueError("RcclCommunicator: world > 1 needs a store (or the unique id) to agree on the communicator")
+                unique_id = ext.rccl_unique_id()
+            elif rank == 0:
+                unique_id = ext.rccl_unique_id()
+                store.set(key, unique_id)
+            else:
+                unique_id = bytes(store.get(key))  # blocks until rank 0 has published it
+        torch.cuda.init()
+        self._c = ext.RcclComm(unique_id, int(rank), int(world), int(index))
+        self.rank, self.world, self.device = int(rank), int(world), torch.device("cuda", index)
+
+    @classmethod
+    def from_env(cls, device, key: str = "lycoris_amd/rccl_uid"):
+        """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torchrun sets them; the id travels through the launcher's own store
+        (torch.distributed.rendezvous: no process group is created)."""
+        import os
+        if int(os.environ.get("WORLD_SIZE", "1")) == 1 and "MASTER_PORT" not in os.environ:
+            return cls(0, 1, device)
+        store, rank, world = next(iter(dist.rendezvous("env://")))
+        return cls(rank, world, device, store=store, key=key)
+
+    @classmethod
+    def from_process_group(cls, group=None, device=None):
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        from . import _native
+        box = [_native.load_torch_ops().rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, device, unique_id=box[0])
+
+    # ---- ordering ------------------------------------------------------------------------------------------------------------
+    def wait_current(self):
+        self._c.wait_current()
+
+    def wait_event(self, event: "torch.cuda.Event"):
+        self._c.wait_event(event.cuda_event)
+
+    def join(self):
+        self._c.join()
+
+    def synchronize(self):
+        self._c.synchronize()
+
+    # ---- collectives (in place, on the communicator's stream) ------------------------------------------------------------------
+    def all_reduce(self, t, op=0):
+        self._c.all_reduce(t, op)
+
+    def reduce_scatter(self, shard, full, op=0):
+        self._c.reduce_scatter(shard, full, op)
+
+    def all_gather(self, full, shard):
+        self._c.all_gather(full, shard)
+
+    def broadcast(self, t, root=0):
+        self._c.broadcast(t, root)
+
+    def barrier(self):
+        """host-blocking: every rank's compute stream has reached this point"""
+        if getattr(self, "_token", None) is None:
+            self._token = torch.zeros(1, device=self.device)
+        self.wait_current()
+        self._c.all_reduce(self._token, 0)
+        self._c.synchronize()
+
+    def max_over_ranks(self, value: float) -> float:
+        t = torch.tensor([value], device=self.device, dtype=torch.float64)
+        self.wait_current()
+        self._c.all_reduce(t, self.MAX)
+        self._c.synchronize()
+        return float(t)
+
+    def destroy(self):
+        self._c.destroy()
 
 
 @dataclass(eq=False)
@@ -53,7 +155,7 @@ class _Bucket:
 class AdapterGradSync:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20,
                  process_group=None, average: bool = True, always_reduce: bool = False, collective: str = "all_reduce",
-                 tail_bucket_bytes: int = 2 << 20):
+                 tail_bucket_bytes: int = 0, comm: Optional[RcclCommunicator] = None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("AdapterGradSync: no trainable parameters")
@@ -65,15 +167,23 @@ class AdapterGradSync:
         self.collective = collective
         self.group = process_group
         self.average = average
-        self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        # `always_reduce`: issue the collectives even at world_size 1 (a process group must be initialised) -- lets ONE GPU drive
+        # `comm`: the ProcessGroup-free communicator (round 5) -- the collectives are then plain stream work of `comm`, torch.distributed
+        # is not touched on the data path (and need not be initialised at all)
+        self.comm = comm
+        if comm is not None:
+            self.world_size = comm.world
+        else:
+            self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # `always_reduce`: issue the collectives even at world_size 1 (a process group or `comm` must exist) -- lets ONE GPU drive
         # the RCCL path end to end (benchmarks/rccl_ws1_check.py); a no-op all-reduce is otherwise skipped
-        self._reduce = self.world_size > 1 or (always_reduce and dist.is_available() and dist.is_initialized())
+        self._reduce = self.world_size > 1 or (always_reduce and (comm is not None or (dist.is_available() and dist.is_initialized())))
         dev = self.params[0].device
         if any(p.device != dev for p in self.params):
             raise ValueError("AdapterGradSync: all adapter parameters must live on one device")
         self.device = dev
-        self.side_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        if comm is not None and comm.device != dev:
+            raise ValueError(f"AdapterGradSync: the communicator is bound to {comm.device}, the parameters live on {dev}")
+        self.side_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" and comm is None else None  # (`comm` owns its stream)
         self.arenas = {}
         self.buckets: List[_Bucket] = []
         self._bucket_of = {}
@@ -107,9 +217,10 @@ class AdapterGradSync:
             if members:
                 self._close_bucket(arena, start, off, members)
             # The collective of the LAST bucket to become complete (the input-side layers) cannot overlap anything: the backward
-            # pass is over when it starts.  Its duration is what a step pays for the whole exchange, so it is kept small: the last
-            # `tail_bucket_bytes` of the arena form a bucket of their own (measured with RCCL at world_size 1: 21.45 -> 19.9 ms per
-            # SDXL LoKr step, profiles/r04_final_ws1.log; the same holds for a ring over xGMI)
+            # pass is over when it starts.  Its duration is what a step pays for the whole exchange, so it CAN be kept small: the last
+            # `tail_bucket_bytes` of the arena then form a bucket of their own.  Off by default: at world_size 1 it bought
+            # nothing (21.58 ms with a 2 MiB tail against 21.45 ms without, profiles/r04_final_ws1.log) and costs one more collective
+            # per step; whether it pays on a ring over xGMI needs a multi-GPU measurement.
             self._split_tail(arena, esz, tail_bucket_bytes)
         for p in self.params:
             self._handles.append(p.register_post_accumulate_grad_hook(self._on_autograd_hook))
@@ -290,7 +401,15 @@ class AdapterGradSync:
         if not self._reduce:
             return
         self.collectives_launched += 1
-        if self.side_stream is not None:
+        if self.comm is not None:
+            # stream work only: the communicator's stream waits for the bucket's gradients, then runs the collective(s) in place
+            if after is not None:
+                self.comm.wait_event(after)
+            else:
+                self.comm.wait_current()
+            self._comm_reduce(b.flat)
+            self._comm_pending = True
+        elif self.side_stream is not None:
             # the bucket's gradients were produced on the compute stream: order the collective after them (`after`: an event
             # recorded when they were complete -- work enqueued on the compute stream since then is NOT waited for)
             if after is not None:
@@ -314,6 +433,24 @@ class AdapterGradSync:
             flat.div_(self.world_size)
             return None
         return work
+
+    def _comm_reduce(self, flat):
+        """the bucket through the ProcessGroup-free communicator: all-reduce, or reduce-scatter + all-gather (`collective`)"""
+        c = self.comm
+        op = c.AVG if self.average else c.SUM
+        if self.collective != "reduce_scatter":
+            c.all_reduce(flat, op)
+            return
+        world, rank, n = c.world, c.rank, flat.numel()
+        chunk = n // world
+        if chunk > 0:
+            main = flat[:chunk * world]
+            shard = main[rank * chunk:(rank + 1) * chunk]
+            c.reduce_scatter(shard, main, op)
+            if not getattr(self, "_shard_only", False):
+                c.all_gather(main, shard)
+        if chunk * world < n:
+            c.all_reduce(flat[chunk * world:], op)
 
     def _reduce_scatter_all_gather(self, flat, backend):
         """in place: rank r reduces elements [r * chunk, (r + 1) * chunk) of the bucket (its shard is a view of the bucket at that
@@ -398,7 +535,11 @@ class AdapterGradSync:
             if b.work is not None:
                 b.work.wait()  # on nccl this is a stream-level wait, not a host sync
                 b.work = None
-        if self.side_stream is not None:
+        if self.comm is not None:
+            if getattr(self, "_comm_pending", False):
+                self.comm.join()  # the compute stream waits for the collectives (an event; no host synchronisation)
+                self._comm_pending = False
+        elif self.side_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
         self._reset_pending()
         if self.device.type == "cuda" and self._fused:
@@ -423,56 +564,72 @@ class ShardedAdamW:
     [r * chunk, (r + 1) * chunk) of the bucket); `step()` updates exactly those elements of the flat parameter arena -- moments
     kept for the own shard only: 1 / N of the optimizer state and of its HBM traffic -- and ALL-GATHERS the updated parameters.  Same
     bytes on the wire as the all-reduce, but the second half moves parameters after the update and can overlap the next forward's
-    first layers.  The < world_size leftover elements of a bucket are all-reduced and updated redundantly on every rank.  The
-    update is elementwise AdamW (decoupled weight decay, bias correction), equal to torch.optim.AdamW on the averaged gradients
-    (tests/test_grad_sync.py, 2 ranks).  One hyper-parameter set per arena, as with flat_parameters()."""
+    first layers.  The < world_size leftover elements of a bucket are all-reduced and updated redundantly on every rank.
+
+    The update itself is `torch.optim.AdamW` (fused multi-tensor kernel on the GPU: ONE launch per step) over views of the rank's
+    shards -- element for element the update of torch.optim.AdamW on the averaged gradients (tests/test_grad_sync.py, 2 ranks).
+    One hyper-parameter set per arena, as with flat_parameters().  Because the parameters change through views of the arena (no
+    version counter of a module parameter moves), `step()` marks the LoKr operand-plane cache dirty itself.
+
+    Status: exercised under 2-rank gloo on the CPU and through RCCL at world_size 1 on one GPU (tests/test_gpu_grad_sync.py); never
+    measured on several GPUs."""
 
     def __init__(self, sync: AdapterGradSync, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         if sync.collective != "reduce_scatter":
             raise ValueError("ShardedAdamW needs AdapterGradSync(collective='reduce_scatter')")
         self.sync = sync
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.flats = sync.flat_parameters()
         sync._shard_only = sync._reduce  # with one rank (and no forced collectives) the plain path below updates everything
-        self.t = 0
-        self.world = dist.get_world_size(sync.group) if sync._reduce else 1
-        self.rank = dist.get_rank(sync.group) if sync._reduce else 0
-        self.state = []  # per bucket: (param slice of the flat arena, grad slice, own range, tail range, m, v)
+        self.world = sync.world_size if sync._reduce else 1
+        if sync.comm is not None:
+            self.rank = sync.comm.rank if sync._reduce else 0
+        else:
+            self.rank = dist.get_rank(sync.group) if sync._reduce else 0
+        self.gathers = []  # per bucket: (all elements that divide over the ranks, this rank's shard of them)
+        shards = []
         for b in sync.buckets:
             flat = next(f for f in self.flats if f.dtype == b.flat.dtype)
-            pslice = flat.data[b.flat.storage_offset():b.flat.storage_offset() + b.flat.numel()]
+            lo0 = b.flat.storage_offset()
             n = b.flat.numel()
+            pslice = flat.data[lo0:lo0 + n]
             chunk = n // self.world
             own = (self.rank * chunk, (self.rank + 1) * chunk) if self.world > 1 else (0, n)
             tail = (chunk * self.world, n) if self.world > 1 else (n, n)
-            k = (own[1] - own[0]) + (tail[1] - tail[0])
-            self.state.append((pslice, b.flat, own, tail, torch.zeros(k, dtype=torch.float32, device=pslice.device),
-                               torch.zeros(k, dtype=torch.float32, device=pslice.device)))
+            for lo, hi in (own, tail):
+                if hi > lo:
+                    q = torch.nn.Parameter(pslice[lo:hi], requires_grad=True)  # a view: the update lands in the arena
+                    q.grad = b.flat[lo:hi]
+                    shards.append(q)
+            if self.world > 1 and chunk > 0:
+                main = pslice[:chunk * self.world]
+                self.gathers.append((main, main[own[0]:own[1]]))
+        on_gpu = sync.device.type == "cuda"
+        self.inner = torch.optim.AdamW(shards, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **({"fused": True} if on_gpu else {}))
+        self.param_groups = self.inner.param_groups
 
     @torch.no_grad()
     def step(self):
-        self.t += 1
-        b1, b2 = self.betas
-        c1, c2 = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
-        works = []
-        for pslice, gslice, own, tail, m, v in self.state:
-            off = 0
-            for lo, hi in (own, tail):
-                if hi <= lo:
-                    continue
-                p, g = pslice[lo:hi], gslice[lo:hi].float()
-                mm, vv = m[off:off + hi - lo], v[off:off + hi - lo]
-                off += hi - lo
-                mm.mul_(b1).add_(g, alpha=1.0 - b1)
-                vv.mul_(b2).addcmul_(g, g, value=1.0 - b2)
-                upd = (mm / c1) / ((vv / c2).sqrt_().add_(self.eps))
-                p.mul_(1.0 - self.lr * self.weight_decay).add_(upd.to(p.dtype), alpha=-self.lr)
-            if self.world > 1 and own[1] > own[0]:
-                chunk = own[1] - own[0]
-                main = pslice[:chunk * self.world]
-                works.append(dist.all_gather_into_tensor(main, main[own[0]:own[1]], group=self.sync.group, async_op=True))
-        for w in works:
-            w.wait()  # nccl: a stream-level wait
+        self.inner.step()
+        sync = self.sync
+        if self.gathers:
+            if sync.comm is not None:
+                sync.comm.wait_current()  # the update ran on the current stream
+                for main, shard in self.gathers:
+                    sync.comm.all_gather(main, shard)
+                sync.comm.join()
+            else:
+                works = [dist.all_gather_into_tensor(main, shard, group=sync.group, async_op=True) for main, shard in self.gathers]
+                for w in works:
+                    w.wait()  # nccl: a stream-level wait
+        if sync.device.type == "cuda":
+            from . import ops
+            ops.mark_planes_dirty()  # parameters changed through views of the arena: no version counter of a module moved
 
-    def zero_grad(self):
+    def zero_grad(self, set_to_none: bool = False):
         self.sync.zero_grad()
+
+    def state_dict(self):
+        return self.inner.state_dict()
+
+    def load_state_dict(self, sd):
+        self.inner.load_state_dict(sd)

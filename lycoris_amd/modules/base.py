@@ -7,9 +7,10 @@ class methods ``algo_check`` / ``extract_state_dict`` / ``make_module_from_state
 attribute names (``_lycoris_wrappers``, ``_lycoris_original_forward``) are used on the wrapped layer so native
 and reference adapters can be stacked on one layer.
 
-What is NOT here on purpose: any CPU arithmetic for ``forward``.  ``forward`` always runs the HIP kernels and
-raises on CPU tensors.  ``get_diff_weight`` / ``merge_to`` materialise dW with plain tensor ops -- that is the
-definition of merging, it is off the training hot path.
+``forward`` on a HIP tensor always runs the HIP kernels (and fails loudly without the extension); a host tensor takes the same
+entry points of ``lycoris_amd.ops`` and is evaluated there by the ATen composite forms of ``lycoris_amd/composite.py`` (device
+dispatch, round 5: BASELINE configs[0] trains a small MLP on the CPU).  ``get_diff_weight`` / ``merge_to`` materialise dW with
+plain tensor ops on the CPU -- that is the definition of merging, it is off the training hot path.
 """
 from __future__ import annotations
 
@@ -369,8 +370,15 @@ class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
         (apply_weight_decompose, locon.py:239-260); the norms come from the fused rebuild + norm kernel."""
         from .. import ops
         mode = ops.CH_ROW if self.wd_on_out else ops.CH_COL
-        norm2 = ops.weight_norm2(self._ws_algo, W, self._ws_factors(), self.scale, mode)
-        s = self.dora_scale.reshape(-1).float() / (norm2.sqrt() + torch.finfo(self.dora_scale.dtype).eps)
+        if W.is_cuda:
+            norm2 = ops.weight_norm2(self._ws_algo, W, self._ws_factors(), self.scale, mode)
+            s = self.dora_scale.reshape(-1).float() / (norm2.sqrt() + torch.finfo(self.dora_scale.dtype).eps)
+        else:  # host tensors (BASELINE configs[0]-style plumbing runs): the norms of W + dW from the rebuilt weight, autograd-visible
+            dw = self.get_diff_weight(1.0, tuple(W.shape))[0]
+            merged = W.to(torch.promote_types(W.dtype, dw.dtype)) + dw.reshape(W.shape)
+            norm2 = merged.reshape(W.shape[0], -1).pow(2).sum(1) if self.wd_on_out else \
+                merged.transpose(0, 1).reshape(W.shape[1], -1).pow(2).sum(1)
+            s = self.dora_scale.reshape(-1).to(norm2.dtype) / (norm2.sqrt() + torch.finfo(self.dora_scale.dtype).eps)
         if multiplier != 1:
             s = multiplier * (s - 1) + 1
         return s

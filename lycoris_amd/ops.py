@@ -14,6 +14,7 @@ from __future__ import annotations
 import torch
 
 from . import _native as N
+from . import composite as _host  # the ops' forms for tensors that are not on the HIP device (BASELINE configs[0])
 
 F32_ROWS = 0x100  # LYC_F32_ROWS
 
@@ -112,6 +113,14 @@ def refresh_lokr_planes(force: bool = False):
     call (with force=True) in front of the forward pass, so that each replay sees the parameters of its own step."""
     if _cpp():
         _DISPATCH["ext"].refresh_planes(bool(force))
+
+
+def mark_planes_dirty():
+    """Tell the LoKr operand-plane cache that parameters have changed (a step boundary).  torch.optim optimizers and the end of every
+    backward pass that ran a LoKr op do this by themselves; an optimizer that is NOT a torch.optim.Optimizer and writes through
+    `p.data` / views of a flat arena (no version counter moves) calls this after its update."""
+    if _cpp():
+        _DISPATCH["ext"].mark_planes_dirty()
 
 
 def lokr_planes_cache(enabled: bool = True):
@@ -656,7 +665,8 @@ def lokr_linear_fusable(x, w1, w2, base):
 def lokr_linear(x, w1, w2, alpha=1.0, base=None):
     """w1:[a,b]  w2:[c,d]  x:[..., b*d] -> [..., a*c];  with `base` (the frozen layer's output): base + delta, fused into the
     kernel's epilogue when lokr_linear_fusable(...), a separate add otherwise"""
-    N.require_device(x, "input")
+    if not x.is_cuda:  # device dispatch: host tensors take the ATen composite form (composite.py); device tensors the HIP kernels, always
+        return _host.lokr_linear(x, w1, w2, alpha, base)
     if base is not None and not lokr_linear_fusable(x, w1, w2, base):
         return base + lokr_linear(x, w1, w2, alpha)
     if _cpp():
@@ -669,8 +679,7 @@ def lokr_linear_lr(x, w1, w2a, w2b, alpha=1.0, base=None):
     The product is not materialised: the kernels' operand planes are packed from the two factors and the chain rule of the product
     runs in the grouped weight-gradient launch (csrc/kron_conv.h kron_lr_chain_kernel).  Under tracing / python dispatch the product
     is formed by autograd-visible `w2a @ w2b` and handed to lokr_linear."""
-    N.require_device(x, "input")
-    if not _cpp() or torch.compiler.is_compiling() or not x.is_cuda:
+    if not x.is_cuda or not _cpp() or torch.compiler.is_compiling():
         return lokr_linear(x, w1, w2a @ w2b, alpha, base)
     if base is not None and not lokr_linear_fusable(x, w1, _Shape2(w2a.shape[0], w2b.shape[1]), base):
         return base + lokr_linear_lr(x, w1, w2a, w2b, alpha)
@@ -681,8 +690,7 @@ def lokr_linear_lr2(x, w1a, w1b, w2a, w2b, alpha=1.0, base=None):
     """LoKr with BOTH factors low-rank (`decompose_both`, reference modules/lokr.py:94-104): w1 = w1a [a, r] @ w1b [r, b],
     w2 = w2a [c, r] @ w2b [r, d].  The small product is formed once per call below autograd, both weight gradients go through the
     grouped chain-rule launch; tracing / python dispatch / CPU form autograd-visible products and call lokr_linear."""
-    N.require_device(x, "input")
-    if not _cpp() or torch.compiler.is_compiling() or not x.is_cuda:
+    if not x.is_cuda or not _cpp() or torch.compiler.is_compiling():
         return lokr_linear(x, w1a @ w1b, w2a @ w2b, alpha, base)
     if base is not None and not lokr_linear_fusable(x, _Shape2(w1a.shape[0], w1b.shape[1]), _Shape2(w2a.shape[0], w2b.shape[1]), base):
         return base + lokr_linear_lr2(x, w1a, w1b, w2a, w2b, alpha)
@@ -698,7 +706,8 @@ class _Shape2:
 
 def locon_linear(x, down, up, alpha=1.0):
     """down:[r,I]  up:[O,r]"""
-    N.require_device(x, "input")
+    if not x.is_cuda:
+        return _host.locon_linear(x, down, up, alpha)
     if _cpp():
         return _OPS["locon_linear"](x, down, up, float(alpha))
     return _AdapterLinear.apply(_LoconCore, alpha, _amp(x), down, up)
@@ -706,14 +715,16 @@ def locon_linear(x, down, up, alpha=1.0):
 
 def loha_linear(x, w1a, w1b, w2a, w2b, alpha=1.0):
     """w*a:[O,r]  w*b:[r,I]"""
-    N.require_device(x, "input")
+    if not x.is_cuda:
+        return _host.loha_linear(x, w1a, w1b, w2a, w2b, alpha)
     if _cpp():
         return _OPS["loha_linear"](x, w1a, w1b, w2a, w2b, float(alpha))
     return _AdapterLinear.apply(_LohaCore, alpha, _amp(x), w1a, w1b, w2a, w2b)
 
 
 def chan_affine(a, w, bias=None, s0=0.0, mult=1.0, chan_dim=-1):
-    N.require_device(a, "input")
+    if not a.is_cuda:
+        return _host.chan_affine(a, w, bias, s0, mult, chan_dim)
     if _cpp():
         return _OPS["chan_affine"](a, w, bias, float(s0), float(mult), int(chan_dim))
     return _ChanAffine.apply(_amp(a), w, bias, s0, mult, chan_dim)
@@ -739,7 +750,8 @@ def _geom(ksize, stride, padding, dilation):
 def locon_conv2d(x, down, up, alpha, stride, padding, dilation):
     """down:[r, I, kh, kw]  up:[O, r, 1, 1]"""
     r, O = down.shape[0], up.shape[0]
-    N.require_device(x, "input")
+    if not x.is_cuda:
+        return _host.locon_conv2d(x, down, up, alpha, stride, padding, dilation)
     x = _amp(x)
     geom = _geom(down.shape[2:], stride, padding, dilation)
     if x.dim() == 4 and not _is_pointwise(geom) and _locon_conv_implicit_ok(x, down, up):
@@ -751,7 +763,8 @@ def locon_conv2d(x, down, up, alpha, stride, padding, dilation):
 
 def loha_conv2d(x, w1a, w1b, w2a, w2b, alpha, shape, stride, padding, dilation):
     """w*a:[O, r]  w*b:[r, I*kh*kw];  shape = (O, I, kh, kw)"""
-    N.require_device(x, "input")
+    if not x.is_cuda:
+        return _host.loha_conv2d(x, w1a, w1b, w2a, w2b, alpha, shape, stride, padding, dilation)
     return _rows_conv2d(_LohaCore, alpha, _geom(shape[2:], stride, padding, dilation), _amp(x), w1a,
                         w1b.reshape(w1b.shape[0], -1), w2a, w2b.reshape(w2b.shape[0], -1))
 
@@ -759,7 +772,8 @@ def loha_conv2d(x, w1a, w1b, w2a, w2b, alpha, shape, stride, padding, dilation):
 def lokr_conv2d(x, w1, w2, alpha, stride, padding, dilation):
     """w1:[a, b]  w2:[c, d, kh, kw].  The channel index u*d + v makes im2col's (channel, kh, kw) column order the
     grouped (u, (v, kh, kw)) order of the Kronecker kernel, so w2 is simply viewed as [c, d*kh*kw]."""
-    N.require_device(x, "input")
+    if not x.is_cuda:
+        return _host.lokr_conv2d(x, w1, w2, alpha, stride, padding, dilation)
     x = _amp(x)
     geom = _geom(w2.shape[2:], stride, padding, dilation)
     if x.dim() == 4 and not _is_pointwise(geom) and _lokr_conv_implicit_ok(x, w1, w2):
@@ -774,9 +788,8 @@ def lokr_conv2d_lr(x, w1, w2a, w2b, alpha, ksize, stride, padding, dilation):
     w2b:[r, d*kh*kw].  Where the patch kernels take the layer (16-bit activations, leaf fp32 factors, geometry), the operand planes
     are packed from the two factors and the chain rule of the product runs in the grouped weight-gradient launch; everywhere else
     the product is formed (autograd-visible) and handed to lokr_conv2d."""
-    N.require_device(x, "input")
     ksize, stride, padding, dilation = [int(v) for v in ksize], [int(v) for v in stride], [int(v) for v in padding], [int(v) for v in dilation]
-    if (_cpp() and not torch.compiler.is_compiling()
+    if (x.is_cuda and _cpp() and not torch.compiler.is_compiling()
             and _DISPATCH["ext"].lokr_conv2d_lr_ok(x, w1, w2a, w2b, ksize, stride, padding, dilation)):
         return _OPS["lokr_conv2d_lr"](x, w1, w2a, w2b, float(alpha), ksize, stride, padding, dilation)
     w2 = (w2a @ w2b).reshape(w2a.shape[0], -1, *ksize)

@@ -117,13 +117,17 @@ def test_torch_custom_ops_are_registered_with_meta_kernels():
     assert ns.lokr_conv2d_lr(xc, torch.empty(8, 8, **m), torch.empty(4, 2, **m), torch.empty(2, 8 * 9, **m), 1.0, [3, 3], [1, 1], [1, 1], [1, 1]).shape == (2, 32, 9, 7)
 
 
-def test_cpu_tensors_are_rejected_by_the_custom_op_path():
+def test_cpu_tensors_take_the_composite_forms_not_the_custom_ops():
+    """device dispatch (round 5): a host tensor is evaluated by lycoris_amd/composite.py (tests/test_cpu_composite.py pins the numbers);
+    the custom ops themselves still refuse a CPU tensor -- they are the HIP path"""
     import torch
-    from lycoris_amd import ops
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        ops.lokr_linear(torch.randn(4, 64), torch.randn(8, 8), torch.randn(8, 8), 1.0)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        ops.chan_affine(torch.randn(4, 64), torch.randn(64))
+    from lycoris_amd import _native, ops
+    y = ops.lokr_linear(torch.randn(4, 64), torch.randn(8, 8), torch.randn(8, 8), 1.0)
+    assert y.shape == (4, 64) and y.device.type == "cpu"
+    assert ops.chan_affine(torch.randn(4, 64), torch.randn(64)).shape == (4, 64)
+    _native.load_torch_ops()
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.lycoris_amd.lokr_linear(torch.randn(4, 64), torch.randn(8, 8), torch.randn(8, 8), 1.0, None)
 
 
 def test_loading_the_custom_op_extension_first_does_not_deadlock():

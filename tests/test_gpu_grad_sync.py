@@ -29,6 +29,18 @@ def test_rccl_world_size_1_eager_and_segmented_graph_step():
     assert out.returncode == 0 and "rccl-ws1 ok" in out.stdout, tail
 
 
+def test_processgroup_free_rccl_communicator_world_size_1():
+    """round 5: the same steps through lycoris_amd.grad_sync.RcclCommunicator (ncclCommInitRank, own stream, events): primitives,
+    eager step with in-backward collectives, segmented graph step, and the collectives recorded inside one backward hipGraph"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "benchmarks", "rccl_ws1_check.py"), "--comm", "rccl"], capture_output=True,
+                         text=True, timeout=300, cwd=ROOT, env=env, preexec_fn=lambda: resource.setrlimit(resource.RLIMIT_CORE, (0, 0)))
+    tail = (out.stdout + out.stderr)[-2500:]
+    assert out.returncode == 0 and "rccl-ws1 ok" in out.stdout and "recorded inside it" in out.stdout, tail
+
+
 @pytest.mark.parametrize("defer", [True, False], ids=["deferred", "per_layer"])
 def test_shared_module_reports_once_through_the_sync(defer):
     from lycoris_amd import ops
