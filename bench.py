@@ -73,6 +73,10 @@ def parse():
     ap.add_argument("--no-base", action="store_true", help="skip the base+adapter leg")
     ap.add_argument("--no-per-algo", action="store_true",
                     help="skip the per_algo object (short runs of the other BASELINE configs in child processes)")
+    ap.add_argument("--no-siblings", action="store_true",
+                    help="A/B, the round 1-4 layout: every layer instance owns its input and is launched on its own (default: the "
+                         "to_q / to_k / to_v layers of a self-attention and to_k / to_v of a cross-attention read ONE tensor, as in the "
+                         "UNet, and LoKr runs each such set as one grouped launch -- what the modules do behind the reference API)")
     ap.add_argument("--shared-inputs", action="store_true",
                     help="development: instances of one shape share x / g (cache-resident, the round-1 behaviour)")
     ap.add_argument("--eager", action="store_true", help="time the step without hipGraph capture (Python-driven)")
@@ -83,6 +87,10 @@ def parse():
                     help="per bucket: one in-place all-reduce (default) or an in-place reduce-scatter + all-gather pair")
     ap.add_argument("--layers", default="all", help="'all', 'linear' or 'conv' (development)")
     ap.add_argument("--host-timing", action="store_true", help="development: also report the host time to SUBMIT one step (config.host_submit_ms)")
+    ap.add_argument("--collectives-on-side-stream", action="store_true",
+                    help="N > 1 with the ProcessGroup-free communicator: bucket collectives on the communicator's own stream between the "
+                         "bucket-aligned backward segments (overlap).  Default for the captured step: on the compute stream behind the backward "
+                         "graph -- a second stream that waits on the graph-launching stream slows every graph launch (profiles/r05_ws1_*)")
     ap.add_argument("--collectives-on-main-stream", action="store_true",
                     help="development: issue the bucket collectives on the compute stream (no side stream, no overlap) -- separates the "
                          "cost of the collectives themselves from the cost of running them beside the backward pass")
@@ -93,6 +101,10 @@ def parse():
     ap.add_argument("--rccl-ws1", action="store_true",
                     help="run the N > 1 step on one GPU: nccl (= RCCL) process group of world_size 1, every gradient bucket all-reduced "
                          "in place on the side stream between the backward segment graphs (MASTER_ADDR / MASTER_PORT / RANK from the env)")
+    ap.add_argument("--dev-idle-comm", action="store_true", help="development: create the RCCL communicator, never use it (plain N = 1 step)")
+    ap.add_argument("--dev-hop-only", action="store_true", help="development: --rccl-ws1 with the collectives themselves skipped (marks, waits, join only)")
+    ap.add_argument("--comm-high-priority", action="store_true", help="development: the communicator's stream at high priority (A/B: it slows the whole step 3.5x)")
+    ap.add_argument("--comm-torch-stream", action="store_true", help="development: the communicator enqueues on a torch pool stream")
     ap.add_argument("--capture-collectives", action="store_true",
                     help="--backend rccl only: record the bucket collectives INTO one backward hipGraph (the communicator's stream is "
                          "forked into the capture); default: they are enqueued between the replays of the backward segment graphs")
@@ -136,7 +148,7 @@ def layer_specs(model, algo):
 class Inst:
     """One adapted layer instance: its own input x, upstream gradient g and fp32 adapter factors."""
 
-    def __init__(self, spec, algo, dtype, dev, gen, share=None):
+    def __init__(self, spec, algo, dtype, dev, gen, share=None, share_x=None):
         from lycoris_amd import ops
         self.ops, self.spec, self.algo = ops, spec, algo
         M, _, O = layer_rows(spec)
@@ -149,6 +161,7 @@ class Inst:
             xs, gs = (spec["B"], spec["C"], spec["H"], spec["W"]), (spec["B"], O, ho, ho)
             cin, ksz = spec["C"], (spec["k"], spec["k"])
         self.cin, self.ksz, self.O = cin, ksz, O
+        self.sibs = None  # [leader, ...]: the instances that read the same tensor (set by build_instances)
         if share is not None:
             self.x, self.g, self.base = share.x, share.g, share.base
         else:
@@ -157,6 +170,8 @@ class Inst:
                 # out-side (IA)^3 acts on the frozen layer's OUTPUT: x is not read at all
                 self.base = torch.randn(*gs, device=dev, dtype=dtype, generator=gen).requires_grad_(True)
                 self.x = self.base
+            elif share_x is not None:
+                self.x = share_x.x  # a sibling projection: the same tensor object as its set's first member
             else:
                 self.x = torch.randn(*xs, device=dev, dtype=dtype, generator=gen).requires_grad_(True)
             gshape = xs if (algo == "ia3" and spec.get("side") == "in") else gs
@@ -265,11 +280,13 @@ class Inst:
 CHANNELS_LAST = False
 LOKR_RANK = 0
 OVERLAP_LEG = False
+SIBLINGS = True
 
 
 def build_instances(args, dtype, dev):
-    global CHANNELS_LAST, LOKR_RANK, OVERLAP_LEG
+    global CHANNELS_LAST, LOKR_RANK, OVERLAP_LEG, SIBLINGS
     OVERLAP_LEG = bool(getattr(args, "overlap_leg", False))
+    SIBLINGS = not getattr(args, "no_siblings", False)
     CHANNELS_LAST = bool(args.channels_last)
     LOKR_RANK = int(args.rank)
     gen = torch.Generator(device=dev).manual_seed(1234)
@@ -280,15 +297,68 @@ def build_instances(args, dtype, dev):
         if args.layers == "conv" and spec["kind"] != "conv":
             continue
         first = None
-        for _ in range(count):
-            inst = Inst(spec, algo, dtype, dev, gen, share=first if args.shared_inputs else None)
+        sib = int(spec.get("sib", 1)) if (SIBLINGS and spec["kind"] == "linear" and not (algo == "ia3" and spec.get("side", "out") == "out")) else 1
+        grp = []
+        for k in range(count):
+            lead = grp[0] if (sib > 1 and k % sib != 0) else None
+            inst = Inst(spec, algo, dtype, dev, gen, share=first if args.shared_inputs else None, share_x=lead)
             first = first or inst
+            if sib > 1:
+                if lead is None:
+                    grp = [inst]
+                else:
+                    grp.append(inst)
+                inst.sibs = grp
             insts.append(inst)
+    for pos, it in enumerate(insts):
+        it.pos = pos
     return insts
 
 
-def forward_all(insts):
-    return [(it.forward(), it) for it in insts]
+def _groupable(it):
+    """a sibling set that goes out as ONE launch: LoKr on nn.Linear with full-matrix factors (ops.lokr_linear_group, the op the
+    modules' sibling sets call -- lycoris_amd/modules/siblings.py)"""
+    return (SIBLINGS and it.sibs is not None and len(it.sibs) > 1 and it.algo == "lokr" and it.spec["kind"] == "linear" and len(it.params) == 2
+            and it.x.dtype != torch.float32)
+
+
+def forward_all(insts, with_base=False):
+    """[(output, instance)] in layer order.  A sibling set whose members are all in `insts` is launched by its first member."""
+    present = {id(it) for it in insts}
+    outs, parked = [], {}
+    for it in insts:
+        if id(it) in parked:
+            outs.append((parked.pop(id(it)), it))
+            continue
+        grp = it.sibs
+        if grp is not None and grp[0] is it and _groupable(it) and all(id(m) in present for m in grp):
+            bases = [m.base_forward() for m in grp] if with_base else None
+            ys = it.ops.lokr_linear_group(it.x, [m.params[0] for m in grp], [m.params[1] for m in grp], [1.0] * len(grp), bases)
+            for m, y in zip(grp[1:], ys[1:]):
+                parked[id(m)] = y
+            outs.append((ys[0], it))
+        else:
+            outs.append((it.forward(base=it.base_forward()) if with_base else it.forward(), it))
+    return outs
+
+
+def _wrt(items, factors=True):
+    """the tensors a backward call differentiates with respect to: each instance's input (once per tensor: siblings share it) and,
+    with `factors`, its parameters"""
+    seen, out = set(), []
+    for it in items:
+        for t in [it.x] + (list(it.params) if factors else []):
+            if id(t) not in seen:
+                seen.add(id(t))
+                out.append(t)
+    return out
+
+
+def set_aligned(insts, e):
+    """the largest position <= e that does not cut a sibling set (its members are one autograd node)"""
+    if 0 < e < len(insts) and insts[e].sibs is not None and _groupable(insts[e]):
+        return insts[e].sibs[0].pos
+    return e
 
 
 def backward_range(outs, lo, hi):
@@ -298,7 +368,7 @@ def backward_range(outs, lo, hi):
     only what it is asked for, csrc/torch_ops.cpp)."""
     seg = outs[lo:hi][::-1]
     if seg:  # ONE engine invocation for the whole segment, as loss.backward() is one for a real network
-        torch.autograd.grad([y for y, _ in seg], [t for _, it in seg for t in [it.x] + it.params], [it.g for _, it in seg], allow_unused=True)
+        torch.autograd.grad([y for y, _ in seg], _wrt([it for _, it in seg]), [it.g for _, it in seg], allow_unused=True)
 
 
 def lib_sha():
@@ -344,12 +414,18 @@ def main():
     if world > 1 or args.rccl_ws1:
         if args.backend == "rccl":  # no process group at all: the 128-byte id travels through the launcher's store
             from lycoris_amd.grad_sync import RcclCommunicator
-            comm = RcclCommunicator.from_env(dev) if world > 1 else RcclCommunicator(0, 1, dev)
+            inline = not (args.collectives_on_side_stream or args.capture_collectives or args.eager)  # eager steps overlap (hooks drive the buckets)
+            kw = dict(high_priority=args.comm_high_priority, stream=torch.cuda.Stream(device=dev) if args.comm_torch_stream else None,
+                      on_current_stream=inline)
+            comm = RcclCommunicator.from_env(dev, **kw) if world > 1 else RcclCommunicator(0, 1, dev, **kw)
             assert comm.world == world and comm.rank == rank
         elif args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+    if args.dev_idle_comm:
+        from lycoris_amd.grad_sync import RcclCommunicator
+        _KEEP.append(RcclCommunicator(0, 1, dev))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
 
@@ -360,6 +436,8 @@ def main():
     # --rccl-ws1: the N > 1 step on ONE GPU -- a world_size-1 RCCL group, every bucket really all-reduced (AVG, in place, side
     # stream) between the replays of the backward segment graphs
     sync = AdapterGradSync(all_params, bucket_bytes=32 << 20, always_reduce=bool(args.rccl_ws1), collective=args.collective, comm=comm)
+    if args.dev_hop_only:
+        sync._comm_reduce = lambda flat: None
     if args.collectives_on_main_stream and comm is None:
         sync.side_stream = None
     sync.attach_fused()  # kernels accumulate into the arena and report to the bucket counters (eager: overlap by hooks)
@@ -372,7 +450,7 @@ def main():
     # multi-tensor chunk stream instead of a walk over 1 576 small tensors (--per-tensor-optimizer: the round 1-3 form, A/B)
     opt = torch.optim.AdamW(all_params if args.per_tensor_optimizer else sync.flat_parameters(), lr=1e-4, fused=True)
     n_layers = len(insts)
-    act_bytes = sum(t.numel() * t.element_size() for it in insts for t in {id(it.x): it.x, id(it.g): it.g}.values())
+    act_bytes = sum(t.numel() * t.element_size() for t in {id(t): t for it in insts for t in (it.x, it.g)}.values())
 
     if args.pmc_pass:
         for _ in range(args.pmc_pass):
@@ -414,16 +492,19 @@ def main():
             # part of the step, captured here so that every replay packs the parameters of ITS step
             _ops.refresh_lokr_planes(force=True)
             outs = forward_all(insts)
-        multi = world > 1 or args.force_segments or args.rccl_ws1
+        inline_comm = comm is not None and comm.on_current_stream
+        multi = (world > 1 or args.force_segments or args.rccl_ws1) and not (inline_comm and not args.force_segments)
         # segment edges (layer positions, descending) and the buckets each segment completes.  Default: cut exactly where a
         # gradient bucket becomes complete -- one segment per bucket (SDXL LoKr: 5), no segment boundary that launches nothing
-        order = {p: i for i, it in enumerate(insts) for p in it.params}
+        # (a sibling set is ONE autograd node: its parameters are complete when the set's first member has been reached, and no
+        #  segment edge may fall inside it)
+        order = {p: (it.sibs[0].pos if (it.sibs is not None and _groupable(it)) else i) for i, it in enumerate(insts) for p in it.params}
         cuts = sync.bucket_boundaries(order)
         if not multi:
             edges = [0]
         elif args.segments > 0:
             nseg = max(1, min(args.segments, n_layers))
-            edges = sorted({round(i * n_layers / nseg) for i in range(nseg)}, reverse=True)
+            edges = sorted({set_aligned(insts, round(i * n_layers / nseg)) for i in range(nseg)}, reverse=True)
         else:
             edges = sorted(set(cuts), reverse=True)
         plan, done = [], set()
@@ -460,7 +541,7 @@ def main():
                 hi = e
         sync._sync_enabled = True
 
-        seg_done = [torch.cuda.Event() for _ in graphs]
+        seg_done = [None] * len(graphs)
 
         def step():
             sync._reset_pending()
@@ -469,13 +550,16 @@ def main():
             for k, (gph, ready) in enumerate(zip(graphs, plan)):
                 gph.replay()
                 if multi:
-                    seg_done[k].record()
+                    seg_done[k] = sync.mark()
                     if prev is not None:  # the collectives of segment k - 1 are enqueued AFTER segment k has been submitted: the
                         sync.launch_buckets(plan[prev], after=seg_done[prev])  # GPU runs it while the host talks to RCCL
                     prev = k
             if multi and prev is not None:
                 sync.launch_buckets(plan[prev], after=seg_done[prev])
-            sync.finish()
+            if captured_collectives:
+                sync._reset_pending()  # (the collectives and the join are nodes of the backward graph)
+            else:
+                sync.finish()
             opt.step()
     else:
         step = eager_step
@@ -543,10 +627,21 @@ def main():
                          + ("captured inside the backward graph" if (not args.eager and captured_collectives) else
                             ("issued between the bucket-aligned segments" if args.segments <= 0 else "issued between the segments"))
                          + (" on the communicator's own stream (ProcessGroup-free RCCL, lycoris_amd.grad_sync.RcclCommunicator)"
-                            if comm is not None else " on a side stream (c10d " + args.backend + ")")) if (world > 1 or args.rccl_ws1) else ""),
+                            if comm is not None else " on a side stream (c10d " + args.backend + ")")) if ((world > 1 or args.rccl_ws1) and multi) else "")
+                     + ((", bucket collectives (" + args.collective + ") on the compute stream behind the backward graph (ProcessGroup-free RCCL, "
+                         "lycoris_amd.grad_sync.RcclCommunicator; no second queue: --collectives-on-side-stream for the overlapped form)")
+                        if ((world > 1 or args.rccl_ws1) and not args.eager and inline_comm and not multi) else ""),
             "conv_memory_format": "channels_last (documented default, DESIGN.md 2; --nchw for the A/B leg)" if args.channels_last else "contiguous (NCHW)",
             "inputs": "shared per shape (cache-resident)" if args.shared_inputs else
-                      f"distinct x / g per layer instance: {act_bytes / 1e9:.2f} GB read per step",
+                      (f"every layer instance owns its upstream gradient g; inputs x as in the UNet: the to_q / to_k / to_v layers of a "
+                       f"self-attention and to_k / to_v of a cross-attention read ONE tensor ({sum(1 for it in insts if it.sibs is not None)} of "
+                       f"{n_layers} layers in {sum(1 for it in insts if it.sibs is not None and it.sibs[0] is it)} sibling sets), every other "
+                       f"layer its own: {act_bytes / 1e9:.2f} GB of distinct activations per step" if SIBLINGS else
+                       f"distinct x / g per layer instance (round 1-4 layout): {act_bytes / 1e9:.2f} GB read per step"),
+            "sibling_sets": ("LoKr nn.Linear sibling sets run as ONE grouped launch each (ops.lokr_linear_group: one forward launch, one autograd "
+                             "node, one backward dx launch) -- the op the modules' sibling sets call behind the reference API "
+                             "(lycoris_amd/modules/siblings.py)" if (SIBLINGS and any(_groupable(it) for it in insts)) else
+                             ("per-layer launches (sets share their input only)" if SIBLINGS else "off (--no-siblings)")),
         },
     }
     extra = rank == 0 and world == 1 and not args.eager
@@ -675,8 +770,11 @@ def roofline(insts, args, dtype, dev):
         rows = it.x.detach().reshape(-1, I)
         bufs = [torch.zeros_like(f) for f in fs]
         calls.append((it, rows, it.g.reshape(-1, O), fs, bufs))
-        b_fwd += esz * (M * I + M * O) + nfac
-        b_bwd += esz * (M * O + 2 * M * I) + 2 * nfac
+        # SURVEY 8d per layer: forward x + y, backward g + x + dx, factors once per pass.  A sibling set that goes out as ONE launch
+        # reads its shared input once per pass: the x term is counted for the set's first member only (fewer algorithmic bytes)
+        own_x = not (_groupable(it) and it.sibs[0] is not it)
+        b_fwd += esz * ((M * I if own_x else 0) + M * O) + nfac
+        b_bwd += esz * (M * O + (2 if own_x else 1) * M * I) + 2 * nfac
         flops += 3 * 2 * M * O * I
     saved = {}
 
@@ -695,10 +793,50 @@ def roofline(insts, args, dtype, dev):
                     N_.stream_ptr(dev))
             planes[id(it)] = (pl, pl[nf:])
 
+    # launch units of the LoKr step: a layer, or a sibling set as one grouped launch (what forward_all / the modules issue)
+    units, k_of = [], {id(cl[0]): k for k, cl in enumerate(calls)}
+    if use_planes:
+        import ctypes as _ct
+        ys_pre = {}
+        for k, (it, rows, g, fs, bufs) in enumerate(calls):
+            if _groupable(it) and all(id(m) in k_of for m in it.sibs):
+                if it.sibs[0] is it:
+                    units.append([k_of[id(m)] for m in it.sibs])
+            else:
+                units.append([k])
+        for u in units:
+            if len(u) > 1:
+                for k in u:
+                    it, rows, g, fs, bufs = calls[k]
+                    ys_pre[k] = torch.empty(rows.shape[0], fs[0].shape[0] * fs[1].shape[0], dtype=dtype, device=dev)
+        fw_items = {}
+        for u in units:
+            if len(u) > 1:
+                arr = (N_.LinearGroupItem * len(u))()
+                for j, k in enumerate(u):
+                    it, rows, g, fs, bufs = calls[k]
+                    arr[j] = N_.LinearGroupItem(N_.ptr(rows), N_.ptr(fs[0]), N_.ptr(planes[id(it)][0]), None, N_.ptr(ys_pre[k]), None, rows.shape[0], 1.0)
+                fw_items[u[0]] = arr
+        _KEEP.extend([ys_pre, fw_items])
+
     def fwd():
         if core is None:  # ia3
             for it in lin:
                 saved[id(it)] = it.forward()
+            return
+        if use_planes:
+            for u in units:
+                it, rows, g, fs, bufs = calls[u[0]]
+                (a, b), (c, d) = fs[0].shape, fs[1].shape
+                if len(u) > 1:
+                    N_.call("lyc_lokr_linear_fwd_group", _ct.cast(fw_items[u[0]], _ct.c_void_p), len(u), a, b, c, d, code_, N_.stream_ptr(dev))
+                    for k in u:
+                        saved[id(calls[k][0])] = (ys_pre[k], ())
+                else:
+                    y = torch.empty(rows.shape[0], a * c, dtype=dtype, device=dev)
+                    N_.call("lyc_lokr_linear_fwd_planes", N_.ptr(rows), N_.ptr(fs[0]), N_.ptr(planes[id(it)][0]), None, N_.ptr(y), rows.shape[0],
+                            a, b, c, d, 1.0, code_, N_.stream_ptr(dev))
+                    saved[id(it)] = (y, ())
             return
         for it, rows, g, fs, bufs in calls:
             if use_planes:
@@ -792,7 +930,31 @@ def roofline(insts, args, dtype, dev):
                                    rows.shape[0], a, b, c, d, 1.0)
         _KEEP.extend([items, wss, dxs])
 
+        bw_items = {}
+        if use_planes:
+            for u in units:
+                if len(u) > 1:
+                    arr = (N.LinearGroupItem * len(u))()
+                    for j, k in enumerate(u):
+                        it, rows, g, fs, bufs = calls[k]
+                        arr[j] = N.LinearGroupItem(N.ptr(g), N.ptr(fs[0]), N.ptr(planes[id(it)][1]), N.ptr(rows), N.ptr(dxs[k]), N.ptr(wss[k]), rows.shape[0], 1.0)
+                    bw_items[u[0]] = arr
+            _KEEP.append(bw_items)
+
         def only_dx():
+            if use_planes:
+                for u in units:
+                    it, rows, g, fs, bufs = calls[u[0]]
+                    (a, b), (c, d) = fs[0].shape, fs[1].shape
+                    if len(u) > 1:  # the set's dx launches as one; the n results are summed into the shared input's gradient
+                        N.call("lyc_lokr_linear_bwd_group", ctypes.cast(bw_items[u[0]], ctypes.c_void_p), len(u), a, b, c, d, code, N.stream_ptr(dev))
+                        for k in u[1:]:
+                            dxs[u[0]].add_(dxs[k])
+                    else:
+                        k = u[0]
+                        N.call("lyc_lokr_linear_bwd_planes", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(planes[id(it)][1]), N.ptr(dxs[k]),
+                               N.ptr(bufs[0]), None, N.ptr(wss[k]), rows.shape[0], a, b, c, d, 1.0, code | 0x200, N.stream_ptr(dev))
+                return
             for k, (it, rows, g, fs, bufs) in enumerate(calls):
                 (a, b), (c, d) = fs[0].shape, fs[1].shape
                 if use_planes:
@@ -837,13 +999,17 @@ def roofline(insts, args, dtype, dev):
                               "kron_dw2s_one_launch_per_layer": round(t_dw2, 3),
                               "backward_one_call_per_layer": round(t_bwd, 3)}
         out.update({"operand_planes": bool(use_planes),
-                    "kernel": ("lyc::kron4_kernel" if use_planes else "lyc::kron3_kernel") + " (LoKr forward + backward dx / dW1 launches of the "
+                    "kernel": ("lyc::kron4_kernel / lyc::kron4_group_kernel (one body)" if use_planes else "lyc::kron3_kernel") + " (LoKr forward + backward dx / dW1 launches of the "
                               "Linear layers" + (", both operands by LDS-DMA, w2 from pre-packed hi/lo planes" if use_planes else "") + "); the weight "
                               "gradients run grouped (lyc::kron_dw2f_table_kernel: full-width output tiles, one launch per tile class, re-reads g and x): "
                               "families_ms",
                     "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "avg_launch_us": round(k3_ms * 1e3 / (2 * n_l), 2), "launches_per_layer": 2,
-                    "algorithmic_bytes_per_launch": int(k3_bytes / (2 * n_l)),
+                    "launches": 2 * (len(units) if use_planes else n_l),
+                    "launches_note": (f"{sum(1 for u in units if len(u) > 1)} sibling sets ({sum(len(u) for u in units if len(u) > 1)} layers) as one "
+                                      f"lyc::kron4_group_kernel launch each, {sum(1 for u in units if len(u) == 1)} layers on their own; forward + "
+                                      "backward dx (the in-place sums of the sets' dx are inside the backward time)") if use_planes else "one per layer and pass",
+                    "avg_launch_us": round(k3_ms * 1e3 / (2 * (len(units) if use_planes else n_l)), 2),
+                    "algorithmic_bytes_per_launch": int(k3_bytes / (2 * (len(units) if use_planes else n_l))),
                     "hot_path_gbs": round(hot, 1), "hot_path_frac": round(hot / HBM_PEAK_GBS, 4),
                     "backward_gbs": round(b_bwd / ((t_dx + t_wg) * 1e-3) / 1e9, 1),
                     "dw2_grouped_gbs": round(b_dw2 / (t_wg * 1e-3) / 1e9, 1),
@@ -955,8 +1121,8 @@ def roofline(insts, args, dtype, dev):
             if sib:
                 sib["unit"] = "us per sibling group (hipGraph, HIP events)"
                 sib["saving_ms_per_step_total"] = round(sum(v["saving_ms_per_step"] for v in sib.values() if isinstance(v, dict)), 3)
-                sib["note"] = ("not part of `value`: the headline step launches layer by layer, as the reference's module API does; a caller that owns "
-                               "the attention block can issue its projections through the grouped entry points (INTEGRATION.md)")
+                sib["note"] = ("A/B over the same layer instances.  Since round 5 the grouped form IS what `value` runs: the modules find their "
+                               "sibling sets behind the reference API (lycoris_amd/modules/siblings.py) and bench.py issues the same op")
                 out["sibling_groups"] = sib
         conv = conv_leg(insts, args, dtype)
         if conv:
@@ -1051,7 +1217,7 @@ def reference_leg(insts, sync, native_graph_ms):
     sd-scripts user gets without whole-step capture) and hipGraph vs hipGraph (kernel time)."""
     def ref_pass():
         outs = [(it.reference_forward(), it) for it in insts][::-1]
-        torch.autograd.grad([y for y, _ in outs], [t for _, it in outs for t in [it.x] + it.params], [it.g for _, it in outs])
+        torch.autograd.grad([y for y, _ in outs], _wrt([it for _, it in outs]), [it.g for _, it in outs])
 
     def nat_pass():
         backward_range(forward_all(insts), 0, len(insts))
@@ -1107,14 +1273,13 @@ def base_leg(insts, sync, opt=None, ops_=None):
     the adapter-only number: base alone, and base + adapter (out = base + delta, one autograd.grad for both)."""
     def one_backward(outs, factors=True):  # ONE engine invocation for all layers, as loss.backward() is one for a real network
         outs = outs[::-1]
-        wrt = [t for _, it in outs for t in [it.x] + (it.params if factors else [])]
-        torch.autograd.grad([y for y, _ in outs], wrt, [it.g for _, it in outs], allow_unused=True)
+        torch.autograd.grad([y for y, _ in outs], _wrt([it for _, it in outs], factors), [it.g for _, it in outs], allow_unused=True)
 
     def base_pass():
         one_backward([(it.base_forward(), it) for it in insts], factors=False)
 
     def both_pass():
-        one_backward([(it.forward(base=it.base_forward()), it) for it in insts])
+        one_backward(forward_all(insts, with_base=True))
 
     side = torch.cuda.Stream()
 

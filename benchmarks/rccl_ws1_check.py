@@ -197,6 +197,11 @@ def main():
                 bplan.append(ready)
             sync._sync_enabled = False
             sync._reset_pending()
+            g_fwd = torch.cuda.CUDAGraph()  # a fresh forward: the segment captures above consumed the first one's autograd graph
+            with torch.cuda.graph(g_fwd, pool=pool, capture_error_mode="thread_local"):
+                for arena in sync.arenas.values():
+                    arena.zero_()
+                outs = [(l.forward(), l) for l in layers]
             g_bwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_bwd, pool=pool, capture_error_mode="thread_local"):
                 hi = n

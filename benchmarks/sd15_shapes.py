@@ -14,8 +14,8 @@ Same entry format as benchmarks/sdxl_shapes.py.
 def sd15_unet_layers(batch: int = 4):
     L = []
 
-    def lin(count, M, I, O, tag):
-        L.append(dict(kind="linear", M=M, I=I, O=O, count=count, tag=tag))
+    def lin(count, M, I, O, tag, sib=1):
+        L.append(dict(kind="linear", M=M, I=I, O=O, count=count, tag=tag, sib=sib))  # sib: see benchmarks/sdxl_shapes.py
 
     def conv(count, hw_in, C, O, k, stride, tag):
         L.append(dict(kind="conv", B=batch, C=C, H=hw_in, W=hw_in, O=O, k=k, stride=stride, pad=k // 2, count=count, tag=tag))
@@ -23,8 +23,9 @@ def sd15_unet_layers(batch: int = 4):
     def transformer(count, d, hw):
         tok = batch * hw * hw
         conv(2 * count, hw, d, d, 1, 1, f"proj_in/out 1x1 @{d}")
-        lin(6 * count, tok, d, d, f"attn1 q/k/v/out + attn2 q/out @{d}")
-        lin(2 * count, batch * 77, 768, d, f"attn2 to_k/to_v @{d}")
+        lin(3 * count, tok, d, d, f"attn1 to_q/to_k/to_v @{d}", sib=3)
+        lin(3 * count, tok, d, d, f"attn1 to_out + attn2 to_q/to_out @{d}")
+        lin(2 * count, batch * 77, 768, d, f"attn2 to_k/to_v @{d}", sib=2)
         lin(count, tok, d, 8 * d, f"ff.net.0.proj (GEGLU) @{d}")
         lin(count, tok, 4 * d, d, f"ff.net.2 @{d}")
 

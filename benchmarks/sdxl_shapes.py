@@ -12,23 +12,27 @@ Each entry: dict(kind="linear", M, I, O, count) or dict(kind="conv", B, C, H, W,
 def sdxl_unet_layers(batch: int = 1):
     L = []
 
-    def lin(count, M, I, O, tag):
-        L.append(dict(kind="linear", M=M * batch, I=I, O=O, count=count, tag=tag))
+    def lin(count, M, I, O, tag, sib=1):
+        # sib = n: every n consecutive instances read the SAME tensor (to_q / to_k / to_v of a self-attention take the block's hidden
+        # state, to_k / to_v of a cross-attention the text context): what the host model's call pattern gives the adapters
+        L.append(dict(kind="linear", M=M * batch, I=I, O=O, count=count, tag=tag, sib=sib))
 
     def conv(count, hw_in, C, O, k, stride, tag):
         L.append(dict(kind="conv", B=batch, C=C, H=hw_in, W=hw_in, O=O, k=k, stride=stride, pad=k // 2, count=count, tag=tag))
 
     # transformer blocks at 32x32 (1024 tokens, d=1280): 60 blocks (10 per Transformer2DModel x 6)
-    lin(372, 1024, 1280, 1280, "attn q/k/v/out (self+cross q/out) + proj_in/out @1280")
+    lin(180, 1024, 1280, 1280, "attn1 to_q/to_k/to_v @1280", sib=3)
+    lin(192, 1024, 1280, 1280, "attn1 to_out, attn2 to_q/to_out, proj_in/out @1280")
     lin(60, 1024, 1280, 10240, "ff.net.0.proj (GEGLU) @1280")
     lin(60, 1024, 5120, 1280, "ff.net.2 @1280")
     # transformer blocks at 64x64 (4096 tokens, d=640): 10 blocks (2 per Transformer2DModel x 5)
-    lin(70, 4096, 640, 640, "attn + proj_in/out @640")
+    lin(30, 4096, 640, 640, "attn1 to_q/to_k/to_v @640", sib=3)
+    lin(40, 4096, 640, 640, "attn1 to_out, attn2 to_q/to_out, proj_in/out @640")
     lin(10, 4096, 640, 5120, "ff.net.0.proj @640")
     lin(10, 4096, 2560, 640, "ff.net.2 @640")
     # cross-attention K/V from the 77 x 2048 text context
-    lin(120, 77, 2048, 1280, "attn2 to_k/to_v @1280")
-    lin(20, 77, 2048, 640, "attn2 to_k/to_v @640")
+    lin(120, 77, 2048, 1280, "attn2 to_k/to_v @1280", sib=2)
+    lin(20, 77, 2048, 640, "attn2 to_k/to_v @640", sib=2)
     # ResnetBlock2D.time_emb_proj (one row)
     lin(5, 1, 1280, 320, "time_emb_proj->320")
     lin(5, 1, 1280, 640, "time_emb_proj->640")

@@ -7,7 +7,8 @@
 // 19.6 ms step for 6 collectives whose GPU time is 0.4 ms.  Here a collective is nothing but stream work:
 //
 //     ncclCommInitRank once (the 128-byte id travels through whatever key-value store the launcher provides)
-//     one HIP stream owned by the communicator (high priority: a bucket's ring must not queue behind 700 backward launches)
+//     one HIP stream owned by the communicator (default priority: a HIGH-priority stream made every kernel of the step slower on
+//     this stack -- 73.7 against 21.0 ms per SDXL step, profiles/r05_ws1_stream_and_event_ab.log)
 //     wait_current() / wait_event(e): the communicator's stream waits for the gradients of the bucket
 //     all_reduce / reduce_scatter / all_gather: ncclXxx(..., comm, stream) -- in place on the gradient arena
 //     join(): the caller's stream waits for everything enqueued so far
@@ -64,7 +65,8 @@ ncclRedOp_t nccl_op(int op) {
 
 class RcclComm {
  public:
-  RcclComm(const std::string& id, int rank, int world, int device) : rank_(rank), world_(world), device_(device) {
+  RcclComm(const std::string& id, int rank, int world, int device, bool high_priority, uintptr_t external_stream, bool on_current_stream)
+      : rank_(rank), world_(world), device_(device), on_current_(on_current_stream) {
     TORCH_CHECK(id.size() == sizeof(ncclUniqueId), "lycoris_amd RCCL: the unique id must be ", sizeof(ncclUniqueId), " bytes");
     TORCH_CHECK(world >= 1 && rank >= 0 && rank < world, "lycoris_amd RCCL: rank ", rank, " of ", world);
     ncclUniqueId uid;
@@ -74,9 +76,20 @@ class RcclComm {
     LYC_HIP(hipSetDevice(device));
     int lo = 0, hi = 0;
     LYC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi = numerically lowest = highest priority
-    LYC_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
-    LYC_HIP(hipEventCreateWithFlags(&ev_in_, hipEventDisableTiming));
-    LYC_HIP(hipEventCreateWithFlags(&ev_out_, hipEventDisableTiming));
+    if (external_stream != 0) {  // a stream the caller owns (e.g. one of torch's pool streams) and keeps alive
+      stream_ = reinterpret_cast<hipStream_t>(external_stream);
+      own_stream_ = false;
+    } else {
+      LYC_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, high_priority ? hi : 0));
+    }
+    // Ordering events with a DEVICE-scope release: a default HIP event performs a system-scope release when it is recorded (L2
+    // write-back for host visibility) -- measured on the SDXL step: five default-flag events between the backward segments cost
+    // +1.5 ms per step with collectives that do nothing at all (profiles/r05_ws1_stream_and_event_ab.log).  All consumers of these
+    // events are streams of the same device; what crosses devices is RCCL's own business.
+    constexpr unsigned kFlags = hipEventDisableTiming | hipEventReleaseToDevice;
+    LYC_HIP(hipEventCreateWithFlags(&ev_in_, kFlags));
+    LYC_HIP(hipEventCreateWithFlags(&ev_out_, kFlags));
+    for (hipEvent_t& e : marks_) LYC_HIP(hipEventCreateWithFlags(&e, kFlags));
     {
       py::gil_scoped_release nogil;  // the bootstrap blocks until every rank has arrived
       LYC_NCCL(ncclCommInitRank(&comm_, world, uid, rank));
@@ -92,7 +105,8 @@ class RcclComm {
       comm_ = nullptr;
       (void)hipEventDestroy(ev_in_);
       (void)hipEventDestroy(ev_out_);
-      (void)hipStreamDestroy(stream_);
+      for (hipEvent_t e : marks_) (void)hipEventDestroy(e);
+      if (own_stream_) (void)hipStreamDestroy(stream_);
     }
   }
 
@@ -100,24 +114,44 @@ class RcclComm {
   int world() const { return world_; }
   int device() const { return device_; }
   uintptr_t stream() const { return reinterpret_cast<uintptr_t>(stream_); }
+  bool on_current_stream() const { return on_current_; }
+  // the stream a collective is enqueued on: the communicator's own, or (on_current_stream) whatever stream is current at the call --
+  // the exchange is then ordinary in-order work of the compute stream: no events, no second queue (see grad_sync.py for when that wins)
+  hipStream_t launch_stream() const { return on_current_ ? c10::hip::getCurrentHIPStream(device_).stream() : stream_; }
 
   // the communicator's stream waits for everything enqueued so far on the caller's current stream
   void wait_current() {
+    if (on_current_) return;
     hipStream_t cur = c10::hip::getCurrentHIPStream(device_).stream();
     LYC_HIP(hipEventRecord(ev_in_, cur));
     LYC_HIP(hipStreamWaitEvent(stream_, ev_in_, 0));
   }
+  // mark(): remember "everything enqueued so far on the caller's current stream" (one of a ring of kMarks events; returns its slot),
+  // wait_mark(slot): the communicator's stream waits for exactly that point -- later work of the caller's stream is NOT waited for
+  int mark() {
+    hipStream_t cur = c10::hip::getCurrentHIPStream(device_).stream();
+    const int slot = next_mark_;
+    next_mark_ = (next_mark_ + 1) % kMarks;
+    LYC_HIP(hipEventRecord(marks_[slot], cur));
+    return slot;
+  }
+  void wait_mark(int slot) {
+    if (on_current_) return;
+    TORCH_CHECK(slot >= 0 && slot < kMarks, "lycoris_amd RCCL: bad mark ", slot);
+    LYC_HIP(hipStreamWaitEvent(stream_, marks_[slot], 0));
+  }
   // ... or for an event the caller recorded earlier (torch.cuda.Event.cuda_event): later work of the caller's stream is NOT waited for
-  void wait_event(uintptr_t ev) { LYC_HIP(hipStreamWaitEvent(stream_, reinterpret_cast<hipEvent_t>(ev), 0)); }
+  void wait_event(uintptr_t ev) { if (on_current_) return; LYC_HIP(hipStreamWaitEvent(stream_, reinterpret_cast<hipEvent_t>(ev), 0)); }
   // the caller's current stream waits for everything enqueued so far on the communicator's stream
   void join() {
+    if (on_current_) return;
     hipStream_t cur = c10::hip::getCurrentHIPStream(device_).stream();
     LYC_HIP(hipEventRecord(ev_out_, stream_));
     LYC_HIP(hipStreamWaitEvent(cur, ev_out_, 0));
   }
   void synchronize() {
     py::gil_scoped_release nogil;
-    LYC_HIP(hipStreamSynchronize(stream_));
+    LYC_HIP(hipStreamSynchronize(launch_stream()));
   }
 
   void check(const Tensor& t, const char* what) const {
@@ -127,7 +161,7 @@ class RcclComm {
   // in place
   void all_reduce(const Tensor& t, int op) {
     check(t, "all_reduce buffer");
-    LYC_NCCL(ncclAllReduce(t.const_data_ptr(), t.mutable_data_ptr(), (size_t)t.numel(), nccl_type(t), nccl_op(op), comm_, stream_));
+    LYC_NCCL(ncclAllReduce(t.const_data_ptr(), t.mutable_data_ptr(), (size_t)t.numel(), nccl_type(t), nccl_op(op), comm_, launch_stream()));
   }
   // shard = reduce over the ranks of full[rank * n, (rank + 1) * n); `shard` may be that very slice of `full` (in place)
   void reduce_scatter(const Tensor& shard, const Tensor& full, int op) {
@@ -135,18 +169,18 @@ class RcclComm {
     check(full, "reduce_scatter buffer");
     TORCH_CHECK(full.numel() == shard.numel() * world_ && full.scalar_type() == shard.scalar_type(),
                 "lycoris_amd RCCL: reduce_scatter needs full.numel() == world * shard.numel()");
-    LYC_NCCL(ncclReduceScatter(full.const_data_ptr(), shard.mutable_data_ptr(), (size_t)shard.numel(), nccl_type(full), nccl_op(op), comm_, stream_));
+    LYC_NCCL(ncclReduceScatter(full.const_data_ptr(), shard.mutable_data_ptr(), (size_t)shard.numel(), nccl_type(full), nccl_op(op), comm_, launch_stream()));
   }
   void all_gather(const Tensor& full, const Tensor& shard) {
     check(shard, "all_gather shard");
     check(full, "all_gather buffer");
     TORCH_CHECK(full.numel() == shard.numel() * world_ && full.scalar_type() == shard.scalar_type(),
                 "lycoris_amd RCCL: all_gather needs full.numel() == world * shard.numel()");
-    LYC_NCCL(ncclAllGather(shard.const_data_ptr(), full.mutable_data_ptr(), (size_t)shard.numel(), nccl_type(full), comm_, stream_));
+    LYC_NCCL(ncclAllGather(shard.const_data_ptr(), full.mutable_data_ptr(), (size_t)shard.numel(), nccl_type(full), comm_, launch_stream()));
   }
   void broadcast(const Tensor& t, int root) {
     check(t, "broadcast buffer");
-    LYC_NCCL(ncclBroadcast(t.const_data_ptr(), t.mutable_data_ptr(), (size_t)t.numel(), nccl_type(t), root, comm_, stream_));
+    LYC_NCCL(ncclBroadcast(t.const_data_ptr(), t.mutable_data_ptr(), (size_t)t.numel(), nccl_type(t), root, comm_, launch_stream()));
   }
   void group_start() { LYC_NCCL(ncclGroupStart()); }
   void group_end() { LYC_NCCL(ncclGroupEnd()); }
@@ -155,6 +189,11 @@ class RcclComm {
   ncclComm_t comm_ = nullptr;
   hipStream_t stream_ = nullptr;
   hipEvent_t ev_in_ = nullptr, ev_out_ = nullptr;
+  bool own_stream_ = true;
+  bool on_current_ = false;
+  static constexpr int kMarks = 64;
+  hipEvent_t marks_[kMarks] = {};
+  int next_mark_ = 0;
   int rank_, world_, device_;
 };
 
@@ -172,14 +211,20 @@ void lyc_bind_rccl(py::module_& m) {
     return v;
   });
   py::class_<RcclComm>(m, "RcclComm")
-      .def(py::init([](py::bytes id, int rank, int world, int device) { return new RcclComm(std::string(id), rank, world, device); }),
-           py::arg("unique_id"), py::arg("rank"), py::arg("world"), py::arg("device"))
+      .def(py::init([](py::bytes id, int rank, int world, int device, bool high_priority, uintptr_t external_stream, bool on_current_stream) {
+             return new RcclComm(std::string(id), rank, world, device, high_priority, external_stream, on_current_stream);
+           }),
+           py::arg("unique_id"), py::arg("rank"), py::arg("world"), py::arg("device"), py::arg("high_priority") = false,
+           py::arg("external_stream") = 0, py::arg("on_current_stream") = false)
+      .def_property_readonly("on_current_stream", &RcclComm::on_current_stream)
       .def_property_readonly("rank", &RcclComm::rank)
       .def_property_readonly("world", &RcclComm::world)
       .def_property_readonly("device", &RcclComm::device)
       .def_property_readonly("stream", &RcclComm::stream)
       .def("wait_current", &RcclComm::wait_current)
       .def("wait_event", &RcclComm::wait_event)
+      .def("mark", &RcclComm::mark)
+      .def("wait_mark", &RcclComm::wait_mark)
       .def("join", &RcclComm::join)
       .def("synchronize", &RcclComm::synchronize)
       .def("all_reduce", &RcclComm::all_reduce, py::arg("tensor"), py::arg("op") = 0)

@@ -935,6 +935,213 @@ std::tuple<Tensor, Tensor, Tensor> lokr_linear_bwd_meta(const Tensor& g, const T
 }
 
 // =====================================================================================================================
+// Sibling projections of ONE input in one launch (round 5; VERDICT r4 #4: "wire the sibling groups into the modules")
+// =====================================================================================================================
+// to_q / to_k / to_v of a self-attention block and to_k / to_v of a cross-attention read the same tensor; the reference calls one
+// LokrModule.forward per projection (modules/lokr.py:543-566).  `lokr_linear_group(x, factors, alphas, bases)` is those n forwards as
+// ONE dispatcher call, ONE forward launch (lyc_lokr_linear_fwd_group, with the fused `base + delta` epilogue when bases are given),
+// ONE autograd node with n outputs and ONE backward dx launch (lyc_lokr_linear_bwd_group) whose n results are summed into the
+// gradient of the shared input; the weight gradients are parked per problem exactly like a single layer's.  Results are
+// bit-identical to n lokr_linear calls (tests/test_gpu_lokr_group.py).  Anything not on the packed-plane fast path runs the
+// problems one by one through the single-layer functions -- same numbers, n launches.
+//   factors = [w1_0, w2_0, w1_1, w2_1, ...] (all [a, b] / [c, d] with equal dims), bases = [] or n tensors
+std::vector<Tensor> lokr_linear_group_fwd(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList bases) {
+  require_device(x, "input");
+  const c10::DeviceGuard guard(x.device());
+  const size_t n = alphas.size();
+  TORCH_CHECK(n >= 1 && factors.size() == 2 * n && (bases.empty() || bases.size() == n), "lokr_linear_group: n alphas, 2n factors, 0 or n bases");
+  const Tensor &w10 = factors[0], &w20 = factors[1];
+  TORCH_CHECK(w10.dim() == 2 && w20.dim() == 2, "lokr_linear_group: w1 [a, b], w2 [c, d]");
+  const int64_t a = w10.size(0), b = w10.size(1), c = w20.size(0), d = w20.size(1);
+  for (size_t i = 0; i < n; ++i)
+    TORCH_CHECK(factors[2 * i].sizes() == w10.sizes() && factors[2 * i + 1].sizes() == w20.sizes(),
+                "lokr_linear_group: the problems of a group share (a, b, c, d)");
+  TORCH_CHECK(x.size(-1) == b * d, "adapter expects ", b * d, " input features, got ", x.sizes());
+  Tensor rows = rows_of(x, b * d);
+  auto oshape = x.sizes().vec();
+  oshape.back() = a * c;
+  const int code = dtype_code(x.scalar_type());
+  const int64_t M = rows.size(0);
+  std::vector<Tensor> ys(n), pls(n), f1s(n);
+  bool fast = n >= 2 && lyc_lokr_linear_planes_ok(M, (int)a, (int)b, (int)c, (int)d, code) && (reinterpret_cast<uintptr_t>(cptr(rows)) & 15u) == 0;
+  for (size_t i = 0; i < n && fast; ++i) {
+    if (!bases.empty()) {
+      const Tensor& bs = bases[i];
+      fast = bs.defined() && bs.scalar_type() == x.scalar_type() && bs.numel() == M * a * c && bs.is_contiguous() &&
+             (reinterpret_cast<uintptr_t>(cptr(bs)) & 15u) == 0;
+      if (!fast) break;
+    }
+    pls[i] = planes_for(factors[2 * i + 1], x.scalar_type(), stream_of(x), /*fwd_role=*/true);
+    fast = pls[i].defined();
+  }
+  if (!fast) {  // one by one: the single-layer forward (which picks its own kernel); `base` added on this side when it cannot be fused
+    for (size_t i = 0; i < n; ++i) {
+      c10::optional<Tensor> bs = bases.empty() ? c10::nullopt : c10::optional<Tensor>(bases[i]);
+      ys[i] = lokr_linear_fwd(x, factors[2 * i], factors[2 * i + 1], alphas[i], bs);
+    }
+    return ys;
+  }
+  std::vector<LycLokrLinearGroupItem> items(n);
+  for (size_t i = 0; i < n; ++i) {
+    f1s[i] = f32c(factors[2 * i]);
+    ys[i] = at::empty({M, a * c}, x.options());
+    items[i] = LycLokrLinearGroupItem{cptr(rows), cfp(f1s[i]), cptr(pls[i]), bases.empty() ? nullptr : cptr(bases[i]), mptr(ys[i]), nullptr, M,
+                                      (float)alphas[i]};
+  }
+  check_rc(lyc_lokr_linear_fwd_group(items.data(), (int)n, (int)a, (int)b, (int)c, (int)d, code, stream_of(x)), "lyc_lokr_linear_fwd_group");
+  for (size_t i = 0; i < n; ++i) ys[i] = ys[i].view(oshape);
+  return ys;
+}
+
+struct LokrLinearGroupFn : public torch::autograd::Function<LokrLinearGroupFn> {
+  // vars = [x, w1_0, w2_0, ..., w1_{n-1}, w2_{n-1}, base_0 ... base_{n-1} (optional)]
+  static variable_list forward(AutogradContext* ctx, at::TensorList vars, std::vector<double> alphas) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    const size_t n = alphas.size();
+    const bool has_base = vars.size() == 1 + 3 * n;
+    TORCH_CHECK(vars.size() == 1 + 2 * n || has_base, "lokr_linear_group: bad argument list");
+    const Tensor& x = vars[0];
+    at::TensorList factors = vars.slice(1, 2 * n);
+    at::TensorList bases = has_base ? vars.slice(1 + 2 * n, n) : at::TensorList();
+    std::vector<Tensor> ys;
+    if (eager_cuda(x)) {
+      ys = lokr_linear_group_fwd(x, factors, alphas, bases);
+    } else {
+      static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::lokr_linear_group", "")
+                           .typed<std::vector<Tensor>(const Tensor&, at::TensorList, at::ArrayRef<double>, at::TensorList)>();
+      ys = op.call(x, factors, alphas, bases);
+    }
+    for (size_t i = 0; i < 2 * n; ++i) expect(vars[1 + i], x);
+    ctx->saved_data["alphas"] = alphas;
+    ctx->saved_data["has_base"] = has_base;
+    ctx->saved_data["n"] = (int64_t)n;
+    // (saved by reference in saved_data where they are leaves: save_vars' identity rule, for up to 1 + 2n <= 9 tensors)
+    variable_list keep(vars.begin(), vars.begin() + 1 + 2 * n);
+    for (size_t i = 1; i < keep.size(); ++i)
+      if (keep[i].defined() && keep[i].is_leaf() && keep[i].requires_grad()) ctx->saved_data["lyc_gleaf" + std::to_string(i)] = keep[i];
+    ctx->save_for_backward(std::move(keep));
+    return ys;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    planes_mark_dirty_after_backward();
+    variable_list s = ctx->get_saved_variables();
+    for (size_t i = 1; i < s.size(); ++i) {  // the parameters themselves, not the copies saved-tensor hooks hand back (see save_vars)
+      auto it = ctx->saved_data.find("lyc_gleaf" + std::to_string(i));
+      if (it == ctx->saved_data.end() || !it->second.isTensor()) continue;
+      const Tensor& p = it->second.toTensor();
+      if (p.defined() && s[i].defined() && !s[i].is_same(p) && s[i].sizes() == p.sizes()) s[i] = p;
+    }
+    const size_t n = (size_t)ctx->saved_data["n"].toInt();
+    const std::vector<double> alphas = ctx->saved_data["alphas"].toDoubleVector();
+    const bool has_base = ctx->saved_data["has_base"].toBool();
+    const Tensor& x = s[0];
+    const bool nx = ctx->needs_input_grad(0);
+    variable_list out(1 + (has_base ? 3 : 2) * n);
+    const c10::DeviceGuard guard(x.device());
+    const Tensor &w10 = s[1], &w20 = s[2];
+    const int64_t a = w10.size(0), b = w10.size(1), c = w20.size(0), d = w20.size(1);
+    const int code = x.defined() && x.is_cuda() ? dtype_code(x.scalar_type()) : 0;
+    // ---- the grouped fast path: every problem deferrable (fused accumulation into .grad, 16-bit planes), every grad defined -------
+    bool fast = n >= 2 && g_defer.enabled && eager_cuda(x);
+    std::vector<GradTarget> t1(n), t2(n);
+    std::vector<Tensor> g2(n), pl(n);
+    Tensor rows;
+    if (fast) {
+      rows = rows_of(x, b * d);
+      for (size_t i = 0; i < n && fast; ++i) {
+        fast = grads[i].defined() && eager_cuda(grads[i]);
+        if (!fast) break;
+        const Tensor &w1 = s[1 + 2 * i], &w2 = s[2 + 2 * i];
+        t1[i] = grad_target(w1, ctx->needs_input_grad(1 + 2 * i));
+        t2[i] = grad_target(w2, ctx->needs_input_grad(2 + 2 * i));
+        fast = t2[i].buf.defined() && !t2[i].hand_back && t1[i].buf.defined() && !t1[i].hand_back;
+        if (!fast) break;
+        g2[i] = rows_of(grads[i], a * c);
+        fast = lyc_lokr_wgrad_deferrable(cptr(g2[i]), cptr(rows), rows.size(0), (int)a, (int)b, (int)c, (int)d, code) != 0;
+        if (!fast) break;
+        pl[i] = planes_for(w2, x.scalar_type(), stream_of(x));
+        fast = pl[i].defined();
+      }
+    }
+    if (fast) {
+      const int64_t M = rows.size(0);
+      const int64_t nbytes = lyc_lokr_bwd_workspace_bytes(M, (int)a, (int)b, (int)c, (int)d, code);
+      TORCH_CHECK(nbytes > 0, "lycoris_amd: deferrable layer without a dw1 workspace");
+      std::vector<Tensor> dxs(n), wss(n), f1s(n);
+      std::vector<LycLokrLinearGroupItem> items(n);
+      for (size_t i = 0; i < n; ++i) {
+        f1s[i] = f32c(s[1 + 2 * i]);
+        dxs[i] = at::empty(rows.sizes(), x.options());
+        wss[i] = at::empty({nbytes}, x.options().dtype(at::kByte));
+        items[i] = LycLokrLinearGroupItem{cptr(g2[i]), cfp(f1s[i]), planes_bwd_ptr(pl[i], c, d, 1), cptr(rows), mptr(dxs[i]), mptr(wss[i]), M,
+                                          (float)alphas[i]};
+      }
+      check_rc(lyc_lokr_linear_bwd_group(items.data(), (int)n, (int)a, (int)b, (int)c, (int)d, code, stream_of(x)), "lyc_lokr_linear_bwd_group");
+      for (size_t i = 0; i < n; ++i)
+        park_deferred(DeferredLokr{g2[i], rows, f1s[i], s[1 + 2 * i], s[2 + 2 * i], t1[i].buf, t2[i].buf, wss[i], M, (int)a, (int)b, (int)c,
+                                   (int)d, code, (float)alphas[i], stream_of(x), x.device().index()});
+      if (nx) {  // d(sum of the problems)/dx: the n results summed in place (what autograd's accumulation does for n separate nodes)
+        for (size_t i = 1; i < n; ++i) dxs[0].add_(dxs[i]);
+        out[0] = shaped_like(dxs[0], x);
+      }
+    } else {  // problem by problem, through the single-layer backward (deferred where it can be)
+      Tensor dx_sum;
+      for (size_t i = 0; i < n; ++i) {
+        if (!grads[i].defined()) continue;
+        const Tensor &w1 = s[1 + 2 * i], &w2 = s[2 + 2 * i];
+        const bool n1 = ctx->needs_input_grad(1 + 2 * i), n2 = ctx->needs_input_grad(2 + 2 * i);
+        Tensor dx, d1, d2;
+        if (eager_cuda(grads[i]) && eager_cuda(x)) {
+          GradTarget u1 = grad_target(w1, n1), u2 = grad_target(w2, n2);
+          bool done = false;
+          if (g_defer.enabled && u2.buf.defined() && !u2.hand_back && !(u1.buf.defined() && u1.hand_back))
+            done = lokr_linear_bwd_deferred(grads[i], x, w1, w2, alphas[i], nx, u1.buf, u2.buf, dx);
+          if (!done) {
+            dx = lokr_linear_bwd_into(grads[i], x, w1, w2, alphas[i], nx, u1.buf, u2.buf);
+            d1 = finish_grad(w1, u1);
+            d2 = finish_grad(w2, u2);
+          }
+        } else {
+          static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_lokr_linear_backward", "")
+                               .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&,
+                                                                         double, bool, bool, bool)>();
+          auto [rx, r1, r2] = op.call(grads[i], x, w1, w2, alphas[i], nx, n1, n2);
+          if (nx) dx = rx;
+          if (n1) d1 = r1;
+          if (n2) d2 = r2;
+        }
+        out[1 + 2 * i] = d1;
+        out[2 + 2 * i] = d2;
+        if (dx.defined()) dx_sum = dx_sum.defined() ? dx_sum + dx : dx;
+      }
+      if (nx) out[0] = dx_sum;
+    }
+    if (has_base)
+      for (size_t i = 0; i < n; ++i)
+        if (ctx->needs_input_grad(1 + 2 * n + i)) out[1 + 2 * n + i] = grads[i];  // d(base + delta)/d base = 1
+    out.resize(out.size() + 2);  // `alphas` is one non-tensor input (surplus undefined entries are dropped by the engine)
+    return out;
+  }
+};
+
+std::vector<Tensor> lokr_linear_group_autograd(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList bases) {
+  const GradAtApply ga_;
+  variable_list vars;
+  vars.reserve(1 + factors.size() + bases.size());
+  vars.push_back(amp(x));
+  for (const Tensor& t : factors) vars.push_back(t);
+  for (const Tensor& t : bases) vars.push_back(t);
+  return LokrLinearGroupFn::apply(at::TensorList(vars), alphas.vec());  // (a TensorList: a std::vector<Tensor> argument is not seen as variables)
+}
+std::vector<Tensor> lokr_linear_group_meta(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList bases) {
+  auto oshape = x.sym_sizes().vec();
+  oshape.back() = factors[0].sym_size(0) * factors[1].sym_size(0);
+  std::vector<Tensor> ys;
+  for (size_t i = 0; i < alphas.size(); ++i) ys.push_back(x.new_empty_symint(oshape));
+  return ys;
+}
+
+// =====================================================================================================================
 // LoKr on nn.Linear with a low-rank w2 = w2a @ w2b (reference modules/lokr.py:131-136, 370; functional/lokr.py:124-151)
 // =====================================================================================================================
 // The product is never formed as a tensor on the fast path: the operand planes are packed straight from the two factors
@@ -2341,6 +2548,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> adapter_conv2d_bwd_meta(const
 TORCH_LIBRARY(lycoris_amd, m) {
   // public ops: what lycoris_amd.ops / the modules call (autograd-aware)
   m.def("lokr_linear(Tensor x, Tensor w1, Tensor w2, float alpha, Tensor? base=None) -> Tensor");
+  m.def("lokr_linear_group(Tensor x, Tensor[] factors, float[] alphas, Tensor[] bases) -> Tensor[]");
   m.def("lokr_linear_lr(Tensor x, Tensor w1, Tensor w2a, Tensor w2b, float alpha, Tensor? base=None) -> Tensor");
   m.def("lokr_linear_lr2(Tensor x, Tensor w1a, Tensor w1b, Tensor w2a, Tensor w2b, float alpha, Tensor? base=None) -> Tensor");
   m.def("locon_linear(Tensor x, Tensor down, Tensor up, float alpha) -> Tensor");
@@ -2377,6 +2585,7 @@ TORCH_LIBRARY(lycoris_amd, m) {
 
 TORCH_LIBRARY_IMPL(lycoris_amd, CUDA, m) {
   m.impl("lokr_linear", lokr_linear_fwd);
+  m.impl("lokr_linear_group", lokr_linear_group_fwd);
   m.impl("lokr_linear_lr", lokr_linear_lr_fwd);
   m.impl("lokr_linear_lr2", lokr_linear_lr2_cuda);
   m.impl("_lokr_linear_backward", lokr_linear_bwd);
@@ -2401,6 +2610,7 @@ TORCH_LIBRARY_IMPL(lycoris_amd, CUDA, m) {
 
 TORCH_LIBRARY_IMPL(lycoris_amd, Meta, m) {
   m.impl("lokr_linear", lokr_linear_meta);
+  m.impl("lokr_linear_group", lokr_linear_group_meta);
   m.impl("lokr_linear_lr", lokr_linear_lr_meta);
   m.impl("lokr_linear_lr2", lokr_linear_lr2_meta);
   m.impl("_lokr_linear_backward", lokr_linear_bwd_meta);
@@ -2425,6 +2635,7 @@ TORCH_LIBRARY_IMPL(lycoris_amd, Meta, m) {
 
 TORCH_LIBRARY_IMPL(lycoris_amd, Autograd, m) {
   m.impl("lokr_linear", lokr_linear_autograd);
+  m.impl("lokr_linear_group", lokr_linear_group_autograd);
   m.impl("lokr_linear_lr", lokr_linear_lr_autograd);
   m.impl("lokr_linear_lr2", lokr_linear_lr2_autograd);
   m.impl("locon_linear", locon_linear_autograd);

@@ -56,7 +56,8 @@ class RcclCommunicator:
 
     SUM, AVG, MAX = 0, 1, 2
 
-    def __init__(self, rank: int, world: int, device, store=None, unique_id: Optional[bytes] = None, key: str = "lycoris_amd/rccl_uid"):
+    def __init__(self, rank: int, world: int, device, store=None, unique_id: Optional[bytes] = None, key: str = "lycoris_amd/rccl_uid",
+                 high_priority: bool = False, stream: Optional["torch.cuda.Stream"] = None, on_current_stream: bool = False):
         from . import _native
         ext = _native.load_torch_ops()
         device = torch.device(device)
@@ -74,18 +75,27 @@ class RcclCommunicator:
             else:
                 unique_id = bytes(store.get(key))  # blocks until rank 0 has published it
         torch.cuda.init()
-        self._c = ext.RcclComm(unique_id, int(rank), int(world), int(index))
+        self._stream = stream  # (kept alive: the communicator enqueues on it)
+        # on_current_stream: every collective is enqueued on whatever stream is current at the call -- ordinary in-order work of the
+        # compute stream, no events, no second HIP queue.  Measured on the captured SDXL step (profiles/r05_ws1_*): while a SECOND
+        # stream waits on an event of the stream that launches hipGraphs, every graph launch gets slower (host 2.06 -> 2.75 ms per
+        # 900-node graph; ~1 ms on the 18.4 ms step) -- about the ring time of the 153 MB exchange the side stream would hide.  Callers
+        # that replay captured steps therefore default to this mode; eager training (long frozen backward, kernels launched one by
+        # one: a hop costs 25 us) keeps the communicator's own stream and overlaps.
+        self.on_current_stream = bool(on_current_stream)
+        self._c = ext.RcclComm(unique_id, int(rank), int(world), int(index), bool(high_priority), 0 if stream is None else int(stream.cuda_stream),
+                               self.on_current_stream)
         self.rank, self.world, self.device = int(rank), int(world), torch.device("cuda", index)
 
     @classmethod
-    def from_env(cls, device, key: str = "lycoris_amd/rccl_uid"):
+    def from_env(cls, device, key: str = "lycoris_amd/rccl_uid", **kw):
         """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torchrun sets them; the id travels through the launcher's own store
         (torch.distributed.rendezvous: no process group is created)."""
         import os
         if int(os.environ.get("WORLD_SIZE", "1")) == 1 and "MASTER_PORT" not in os.environ:
-            return cls(0, 1, device)
+            return cls(0, 1, device, **kw)
         store, rank, world = next(iter(dist.rendezvous("env://")))
-        return cls(rank, world, device, store=store, key=key)
+        return cls(rank, world, device, store=store, key=key, **kw)
 
     @classmethod
     def from_process_group(cls, group=None, device=None):
@@ -100,8 +110,17 @@ class RcclCommunicator:
     def wait_current(self):
         self._c.wait_current()
 
-    def wait_event(self, event: "torch.cuda.Event"):
-        self._c.wait_event(event.cuda_event)
+    def wait_event(self, event):
+        """`event`: a mark (int, from mark()) or a torch.cuda.Event recorded on a stream of this device"""
+        if isinstance(event, int):
+            self._c.wait_mark(event)
+        else:
+            self._c.wait_event(event.cuda_event)
+
+    def mark(self) -> int:
+        """remember this point of the current stream (a device-scope event of the communicator's ring of 64); wait_event(mark) later
+        orders the communicator's stream behind exactly this point"""
+        return self._c.mark()
 
     def join(self):
         self._c.join()
@@ -492,6 +511,16 @@ class AdapterGradSync:
         -- the bucket is complete once backward has run down to that layer.  Cutting the segments at exactly these positions gives
         one segment per bucket (SDXL LoKr: 5) instead of an arbitrary number of equal ones."""
         return [min(order[p] for p in b.params) for b in self.buckets]
+
+    def mark(self):
+        """a point of the compute stream `launch_buckets(..., after=mark)` can order collectives behind: the communicator's own
+        device-scope event when there is one (a default torch.cuda.Event does a system-scope release at record time: +0.3 ms of GPU
+        time per event between two backward segments), else a recorded torch.cuda.Event"""
+        if self.comm is not None:
+            return self.comm.mark()
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
 
     def launch_buckets(self, indices, after=None):
         """launch the collectives of the given buckets (precomputed per segment by the caller: no scan, no host synchronisation --

@@ -14,6 +14,7 @@ import torch.nn as nn
 from .. import ops
 from ..functional.general import conv_args, factorization
 from ..functional.lokr import make_kron
+from . import siblings as _siblings
 from .base import LycorisBaseModule, _unsupported
 
 logger = logging.getLogger("LyCORIS")
@@ -87,6 +88,7 @@ class LokrModule(LycorisBaseModule):
             self.lokr_w2_a = nn.Parameter(torch.empty(out_k, lora_dim))
             self.lokr_w2_b = nn.Parameter(torch.empty(lora_dim, in_n * kprod))
         self._kron_dims = (out_l, in_m, out_k, in_n)
+        object.__setattr__(self, "_sib", None)  # the sibling set this module was found in (modules/siblings.py); not state, not a submodule
 
         self._init_scale(lora_dim, alpha, rs_lora, use_scalar, force_unit_scale=self.use_w1 and self.use_w2)
         if self.use_w2:
@@ -222,6 +224,28 @@ class LokrModule(LycorisBaseModule):
         return scaled, orig_norm * ratio.to(orig_norm.device)
 
     # ---- hot path --------------------------------------------------------------------------------------------------
+    def _sibling_eligible(self, x):
+        """on the plain `base + delta` path of a full-matrix LoKr nn.Linear layer (what lyc_lokr_linear_fwd_group takes)?"""
+        return (self.module_type == "linear" and self.use_w1 and self.use_w2 and not self.wd and x.is_cuda and not x.is_inference()
+                and x.dtype in (torch.bfloat16, torch.float16)
+                and not (self.training and (self.module_dropout or self.rank_dropout or (self.bypass_mode and self.dropout))))
+
+    def forward(self, x, *args, **kwargs):
+        # to_q / to_k / to_v called with one tensor run as ONE launch (modules/siblings.py); everything else is the per-layer path
+        if not args and not kwargs and isinstance(x, torch.Tensor) and self._sibling_eligible(x) and not torch.compiler.is_compiling():
+            y = _siblings.forward(self, x)
+            if y is not None:
+                return y
+        return super().forward(x, *args, **kwargs)
+
+    def apply_to(self, **kwargs):
+        _siblings.forget(self)
+        return super().apply_to(**kwargs)
+
+    def restore(self):
+        _siblings.forget(self)
+        return super().restore()
+
     def _forward_fused(self, x, base):
         if self.module_type != "linear":
             return None

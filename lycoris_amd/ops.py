@@ -57,7 +57,7 @@ def _cpp() -> bool:
         except ImportError:  # very old torch: the end-of-backward mark alone
             pass
         ns = torch.ops.lycoris_amd  # the resolved overloads: skips the packet's per-call overload resolution (~1 us per call)
-        for name in ("lokr_linear", "lokr_linear_lr", "lokr_linear_lr2", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d", "lokr_conv2d_lr"):
+        for name in ("lokr_linear", "lokr_linear_group", "lokr_linear_lr", "lokr_linear_lr2", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d", "lokr_conv2d_lr"):
             _OPS[name] = getattr(ns, name).default
     return True
 
@@ -672,6 +672,23 @@ def lokr_linear(x, w1, w2, alpha=1.0, base=None):
     if _cpp():
         return _OPS["lokr_linear"](x, w1, w2, float(alpha), base)
     return _AdapterLinear.apply(_LokrCore, alpha, _amp(x), w1, w2)
+
+
+def lokr_linear_group(x, w1s, w2s, alphas, bases=None):
+    """n LoKr projections of ONE input (to_q / to_k / to_v of a self-attention block, to_k / to_v of a cross-attention: all with equal
+    factor shapes) as one call: one forward launch, one autograd node with n outputs, one backward dx launch (csrc/torch_ops.cpp
+    LokrLinearGroupFn over lyc_lokr_linear_fwd_group / _bwd_group).  Returns the list of `base_i + delta_i` (or `delta_i` without
+    bases); bit-identical to n lokr_linear calls.  Host tensors, tracing and the python dispatch run the n calls one by one."""
+    n = len(w1s)
+    if len(w2s) != n or len(alphas) != n or (bases is not None and len(bases) != n):
+        raise ValueError("lokr_linear_group: w1s, w2s, alphas (and bases) must have one entry per problem")
+    if n == 1 or not x.is_cuda or not _cpp() or torch.compiler.is_compiling():
+        return [lokr_linear(x, w1s[i], w2s[i], alphas[i], None if bases is None else bases[i]) for i in range(n)]
+    if bases is not None and not all(lokr_linear_fusable(x, w1s[i], w2s[i], bases[i]) for i in range(n)):
+        ys = lokr_linear_group(x, w1s, w2s, alphas)
+        return [b + y for b, y in zip(bases, ys)]
+    factors = [t for pair in zip(w1s, w2s) for t in pair]
+    return list(_OPS["lokr_linear_group"](x, factors, [float(a) for a in alphas], [] if bases is None else list(bases)))
 
 
 def lokr_linear_lr(x, w1, w2a, w2b, alpha=1.0, base=None):

@@ -1,0 +1,192 @@
+"""GPU: sibling projections behind the module API (round 5; VERDICT r4 next #4a).
+
+  * torch.ops.lycoris_amd.lokr_linear_group (one forward launch, one autograd node with n outputs, one backward dx launch, parked
+    weight gradients) against the float64 oracle and, bit for bit, against n lokr_linear calls;
+  * stock attention-shaped host code (to_q(h), to_k(ctx), to_v(ctx)) adapted by LokrModule: the modules find their sibling sets on
+    the first forward pass (modules/siblings.py) and from the second pass on run them as grouped launches -- same bits in the
+    outputs, same gradients, fewer launches.
+Reference call sites: one LokrModule.forward per projection, lycoris/modules/lokr.py:543-566."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import oracle
+from gpu_util import TOL, check, err, rnd
+from lycoris_amd import ops
+from lycoris_amd.modules import LokrModule, siblings
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+# (M, a, c, d, n): q / k / v of a 1280-wide SDXL block, k / v of its cross-attention, a 640-wide block, ragged small case
+CASES = [(1024, 8, 160, 160, 3), (77, 8, 160, 256, 2), (4096, 8, 80, 80, 3), (130, 4, 24, 40, 4)]
+
+
+@pytest.mark.parametrize("with_base", [False, True], ids=["delta", "base_plus_delta"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", CASES, ids=[f"M{c[0]}_a{c[1]}_c{c[2]}_d{c[3]}_n{c[4]}" for c in CASES])
+def test_group_op_matches_the_oracle_and_the_per_layer_op(case, dtype, with_base):
+    M, a, c, d, n = case
+    gen = torch.Generator().manual_seed(M + a + c + d + n)
+    x, x64 = rnd((M, a * d), dtype, gen)
+    alphas = [0.7, 1.0, 0.4, 1.3][:n]
+    w1s, w2s, bases, gs, f64 = [], [], [], [], []
+    for i in range(n):
+        w1, w1_64 = rnd((a, a), torch.float32, gen, 0.3)
+        w2, w2_64 = rnd((c, d), torch.float32, gen, 0.1)
+        b, b64 = rnd((M, a * c), dtype, gen)
+        g, g64 = rnd((M, a * c), dtype, gen, 0.1)
+        w1s.append(torch.nn.Parameter(w1)); w2s.append(torch.nn.Parameter(w2)); bases.append(b); gs.append(g)
+        f64.append((w1_64, w2_64, b64, g64))
+    params = [p for pair in zip(w1s, w2s) for p in pair]
+
+    def per_layer():
+        xr = x.clone().requires_grad_(True)
+        ys = [ops.lokr_linear(xr, w1s[i], w2s[i], alphas[i], bases[i] if with_base else None) for i in range(n)]
+        grads = torch.autograd.grad(ys, [xr] + params, gs)
+        return ys, grads
+
+    def grouped():
+        xr = x.clone().requires_grad_(True)
+        ys = ops.lokr_linear_group(xr, w1s, w2s, alphas, bases if with_base else None)
+        grads = torch.autograd.grad(ys, [xr] + params, gs)
+        return ys, grads
+
+    ys_p, gr_p = per_layer()
+    ys_g, gr_g = grouped()
+    torch.cuda.synchronize()
+    errs, bounds = {}, {}
+    dx_want = 0.0
+    for i in range(n):
+        assert torch.equal(ys_g[i], ys_p[i]), f"y[{i}] differs from the per-layer launch"
+        w1_64, w2_64, b64, g64 = f64[i]
+        y64 = oracle.lokr.forward(x64, w1=w1_64, w2=w2_64, scale=alphas[i])
+        if with_base:  # fused epilogue: fp32 add, one rounding
+            y64 = y64 + b64
+        errs[f"y{i}"], bounds[f"y{i}"] = err(ys_g[i], y64, dtype), TOL["store_out"][dtype]
+        gr = oracle.lokr.backward(x64, g64, w1=w1_64, w2=w2_64, scale=alphas[i])
+        dx_want = dx_want + gr["dx"]
+        errs[f"dw1_{i}"], bounds[f"dw1_{i}"] = err(gr_g[1 + 2 * i], gr["w1"]), TOL["f32_out"][dtype]
+        errs[f"dw2_{i}"], bounds[f"dw2_{i}"] = err(gr_g[2 + 2 * i], gr["w2"]), TOL["f32_out"][dtype]
+        assert torch.equal(gr_g[1 + 2 * i], gr_p[1 + 2 * i]) or err(gr_g[1 + 2 * i], gr_p[1 + 2 * i].double().cpu().numpy()) < 1e-6
+    # the shared input's gradient: n 16-bit results summed in 16 bits (as autograd's accumulation does): n roundings
+    errs["dx"], bounds["dx"] = err(gr_g[0], dx_want), (n + 1) * TOL["store_out"][dtype]
+    errs["dx_vs_per_layer"] = err(gr_g[0], gr_p[0].double().cpu().numpy())
+    bounds["dx_vs_per_layer"] = n * TOL["store_out"][dtype]
+    check(f"sibling_group_op[{case},{dtype},{with_base}]", errs, bounds)
+
+
+def test_group_op_in_the_training_configuration_accumulates_into_grad_and_reports_once():
+    """fused accumulation + deferred, grouped weight gradients (the configuration bench.py and AdapterGradSync run): one backward dx
+    launch for the set, .grad complete when backward() returns, one report per parameter"""
+    M, a, c, d, n = 1024, 8, 160, 160, 3
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(11)
+    x, x64 = rnd((M, a * d), dtype, gen)
+    w1s, w2s, gs, f64 = [], [], [], []
+    for i in range(n):
+        w1, w1_64 = rnd((a, a), torch.float32, gen, 0.3)
+        w2, w2_64 = rnd((c, d), torch.float32, gen, 0.1)
+        g, g64 = rnd((M, a * c), dtype, gen, 0.1)
+        w1s.append(torch.nn.Parameter(w1)); w2s.append(torch.nn.Parameter(w2)); gs.append(g); f64.append((w1_64, w2_64, g64))
+    params = [p for pair in zip(w1s, w2s) for p in pair]
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    reports = []
+    ops.fused_grad_accumulation(True, callback=lambda p: reports.append(id(p)))
+    try:
+        xr = x.clone().requires_grad_(True)
+        ys = ops.lokr_linear_group(xr, w1s, w2s, [1.0] * n)
+        torch.autograd.backward(ys, gs)
+        torch.cuda.synchronize()
+    finally:
+        ops.fused_grad_accumulation(False, None)
+    assert sorted(reports) == sorted(id(p) for p in params)
+    errs, bounds = {}, {}
+    dx_want = 0.0
+    for i in range(n):
+        gr = oracle.lokr.backward(x64, f64[i][2], w1=f64[i][0], w2=f64[i][1])
+        dx_want = dx_want + gr["dx"]
+        errs[f"dw1_{i}"], bounds[f"dw1_{i}"] = err(w1s[i].grad, gr["w1"]), TOL["f32_out"][dtype]
+        errs[f"dw2_{i}"], bounds[f"dw2_{i}"] = err(w2s[i].grad, gr["w2"]), TOL["f32_out"][dtype]
+    errs["dx"], bounds["dx"] = err(xr.grad, dx_want), (n + 1) * TOL["store_out"][dtype]
+    check("sibling_group_op_training_configuration", errs, bounds)
+
+
+class Attn(nn.Module):
+    """diffusers' Attention call pattern: to_q(h), to_k(ctx), to_v(ctx), to_out(.)"""
+
+    def __init__(self, d, dc, heads=20):
+        super().__init__()
+        self.to_q, self.to_k, self.to_v, self.to_out = nn.Linear(d, d, bias=False), nn.Linear(dc, d, bias=False), nn.Linear(dc, d, bias=False), nn.Linear(d, d)
+        self.heads = heads
+
+    def forward(self, h, ctx=None):
+        ctx = h if ctx is None else ctx
+        q, k, v = self.to_q(h), self.to_k(ctx), self.to_v(ctx)
+        B, T, D = q.shape
+        sp = lambda t: t.view(B, -1, self.heads, D // self.heads).transpose(1, 2)
+        a = torch.nn.functional.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B, T, D)
+        return self.to_out(a)
+
+
+class Block(nn.Module):
+    def __init__(self, d=1280, dc=2048):
+        super().__init__()
+        self.attn1, self.attn2 = Attn(d, d), Attn(d, dc)
+
+    def forward(self, h, ctx):
+        h = h + self.attn1(h)
+        return h + self.attn2(h, ctx)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_adapted_attention_block_groups_its_projections_with_identical_results(dtype):
+    torch.manual_seed(0)
+    block = Block().to(DEV, dtype).requires_grad_(False)
+    gen = torch.Generator().manual_seed(1)
+    mods = []
+    for name, layer in block.named_modules():
+        if isinstance(layer, nn.Linear):
+            m = LokrModule(name.replace(".", "_"), layer, 1.0, 10000, 1, factor=8).to(DEV)
+            with torch.no_grad():
+                m.lokr_w2.copy_((torch.randn(m.lokr_w2.shape, generator=gen) * 0.05).to(DEV))
+            m.apply_to()
+            mods.append(m)
+    params = [p for m in mods for p in m.parameters()]
+    h0 = (torch.randn(1, 1024, 1280, generator=gen) * 0.5).to(DEV, dtype)
+    ctx = (torch.randn(1, 77, 2048, generator=gen) * 0.5).to(DEV, dtype)
+    gout = (torch.randn(1, 1024, 1280, generator=gen) * 0.05).to(DEV, dtype)
+
+    def run():
+        h = h0.clone().requires_grad_(True)
+        y = block(h, ctx)
+        grads = torch.autograd.grad(y, [h] + params, gout)
+        torch.cuda.synchronize()
+        return y.detach().clone(), [g.clone() for g in grads]
+
+    for k in ("sets", "launches", "hits", "dissolved"):
+        siblings._STATE[k] = 0
+    siblings.enable(False)
+    want = run()
+    siblings.enable(True)
+    learn = run()
+    by = {m.lora_name: m for m in mods}
+    assert [r().lora_name for r in by["attn1_to_q"]._sib.members] == ["attn1_to_q", "attn1_to_k", "attn1_to_v"]
+    assert [r().lora_name for r in by["attn2_to_k"]._sib.members] == ["attn2_to_k", "attn2_to_v"]
+    got = run()
+    st = siblings.stats()
+    assert st["launches"] == 2 and st["hits"] == 3 and st["dissolved"] == 0, st
+    assert torch.equal(learn[0], want[0])
+    # the forward pass is the same bits (same kernels, same accumulation order); the gradient of the shared input is summed in one
+    # more order (n 16-bit results added in place), every other gradient comes from the same kernels
+    assert torch.equal(got[0], want[0])
+    errs = {"dh": float((got[1][0].float() - want[1][0].float()).norm() / want[1][0].float().norm())}
+    bounds = {"dh": 3 * TOL["store_out"][dtype]}
+    for i, (a_, b_) in enumerate(zip(got[1][1:], want[1][1:])):
+        errs[f"g{i}"] = float((a_ - b_).norm() / (b_.norm() + 1e-30))
+        bounds[f"g{i}"] = 2e-3  # downstream of dh's summation order (16-bit activations), not of the adapter kernels
+    check(f"sibling_modules[{dtype}]", errs, bounds)
+    for m in mods:
+        m.restore()

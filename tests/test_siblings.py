@@ -1,0 +1,154 @@
+"""Sibling projections behind the module API (modules/siblings.py): the set-finding logic on host tensors (the GPU parity of the
+grouped launches is tests/test_gpu_lokr_group.py).  The eligibility test of LokrModule asks for a 16-bit HIP tensor; here it is
+relaxed to "any tensor" so that the same code runs on the CPU, where ops.lokr_linear_group evaluates the problems one by one."""
+import pytest
+import torch
+import torch.nn as nn
+
+from lycoris_amd.modules import LokrModule
+from lycoris_amd.modules import siblings
+
+
+class Attn(nn.Module):
+    """the call pattern of diffusers' Attention: to_q(h), to_k(ctx), to_v(ctx), to_out(.)"""
+
+    def __init__(self, d=64, dc=64):
+        super().__init__()
+        self.to_q, self.to_k, self.to_v, self.to_out = nn.Linear(d, d), nn.Linear(dc, d), nn.Linear(dc, d), nn.Linear(d, d)
+
+    def forward(self, h, ctx=None):
+        ctx = h if ctx is None else ctx
+        q, k, v = self.to_q(h), self.to_k(ctx), self.to_v(ctx)
+        a = torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v
+        return self.to_out(a)
+
+
+class Block(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.attn1, self.attn2 = Attn(64, 64), Attn(64, 32)
+
+    def forward(self, h, ctx):
+        h = h + self.attn1(h)
+        return h + self.attn2(h, ctx)
+
+
+@pytest.fixture()
+def host_eligible(monkeypatch):
+    monkeypatch.setattr(LokrModule, "_sibling_eligible",
+                        lambda self, x: self.module_type == "linear" and self.use_w1 and self.use_w2 and not self.wd
+                        and not (self.training and (self.module_dropout or self.rank_dropout)))
+    siblings.enable(True)
+    for k in ("sets", "launches", "hits", "dissolved"):
+        siblings._STATE[k] = 0
+    yield
+    siblings.enable(True)
+
+
+def adapt(block, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    mods = []
+    for name, layer in block.named_modules():
+        if isinstance(layer, nn.Linear):
+            m = LokrModule(name.replace(".", "_"), layer, 1.0, 10000, 1, factor=4)
+            with torch.no_grad():
+                m.lokr_w2.copy_(torch.randn(m.lokr_w2.shape, generator=g) * 0.1)
+            m.apply_to()
+            mods.append(m)
+    return mods
+
+
+def run(block, h, ctx):
+    h = h.clone().requires_grad_(True)
+    y = block(h, ctx)
+    params = [p for m in block._mods for p in m.parameters()]
+    grads = torch.autograd.grad(y.square().sum(), [h] + params)
+    return y.detach(), [g.clone() for g in grads]
+
+
+def test_sets_form_from_the_call_pattern_and_change_nothing_but_the_launch_count(host_eligible):
+    torch.manual_seed(0)
+    block = Block()
+    block._mods = adapt(block)
+    h, ctx = torch.randn(2, 9, 64), torch.randn(2, 5, 32)
+    siblings.enable(False)
+    want = run(block, h, ctx)
+    siblings.enable(True)
+    first = run(block, h, ctx)            # learning pass: per-layer path, sets are formed
+    by_name = {m.lora_name: m for m in block._mods}
+    s1, s2 = by_name["attn1_to_q"]._sib, by_name["attn2_to_k"]._sib
+    assert s1 is not None and [r().lora_name for r in s1.members] == ["attn1_to_q", "attn1_to_k", "attn1_to_v"]
+    assert s2 is not None and [r().lora_name for r in s2.members] == ["attn2_to_k", "attn2_to_v"]
+    assert by_name["attn2_to_q"]._sib is None and by_name["attn1_to_out"]._sib is None
+    assert siblings.stats()["sets"] == 2 and siblings.stats()["launches"] == 0
+    second = run(block, h, ctx)           # steady state: 2 grouped launches, 3 parked results fetched
+    st = siblings.stats()
+    assert st["launches"] == 2 and st["hits"] == 3 and st["dissolved"] == 0
+    for got in (first, second):
+        assert torch.allclose(got[0], want[0], atol=1e-6)
+        for a, b in zip(got[1], want[1]):
+            assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+    third = run(block, torch.randn(2, 9, 64), ctx)  # new tensors, same pattern
+    assert siblings.stats()["launches"] == 4 and siblings.stats()["dissolved"] == 0 and third[0].shape == want[0].shape
+
+
+def test_a_changed_call_pattern_dissolves_the_set_and_the_result_stays_right(host_eligible):
+    torch.manual_seed(1)
+    attn = Attn()
+    attn._mods = adapt(attn)
+    h = torch.randn(3, 7, 64)
+    attn(h)  # learn: q, k, v share h
+    q = attn._mods[0]
+    assert q._sib is not None and len(q._sib.members) == 3
+    other = torch.randn(3, 7, 64)
+    siblings.enable(False)
+    want_k = attn.to_k(other)
+    siblings.enable(True)
+    yq = attn.to_q(h)                 # leader: runs the group, parks k and v
+    assert len(q._sib.pending) == 2
+    got_k = attn.to_k(other)          # ... but k is called with ANOTHER tensor: the set is dissolved, the per-layer path answers
+    assert torch.allclose(got_k, want_k, atol=1e-6) and q._sib is None and siblings.stats()["dissolved"] == 1
+    assert yq.shape == (3, 7, 64)
+    # an in-place write between the calls is the same thing (version counter)
+    attn(h)
+    assert attn._mods[0]._sib is not None
+    attn.to_q(h)
+    with torch.no_grad():
+        h.add_(1.0)
+    siblings.enable(False)
+    want_k = attn.to_k(h)
+    siblings.enable(True)
+    assert torch.allclose(attn.to_k(h), want_k, atol=1e-6) and attn._mods[0]._sib is None
+
+
+def test_restore_forgets_the_set_and_dropout_variants_stay_on_the_per_layer_path(host_eligible):
+    torch.manual_seed(2)
+    attn = Attn()
+    attn._mods = adapt(attn)
+    h = torch.randn(2, 4, 64)
+    attn(h)
+    q, k, v, _ = attn._mods
+    assert q._sib is k._sib is v._sib is not None
+    k.restore()
+    assert q._sib is None and k._sib is None and v._sib is None
+    k.apply_to()
+    attn(h)
+    assert q._sib is not None
+    v.rank_dropout, v.training = 0.5, True       # v leaves the plain path: the leader must not compute it
+    y = attn.to_q(h)
+    assert q._sib is None and y.shape == (2, 4, 64)
+
+
+def test_not_more_than_four_members_and_only_equal_shapes(host_eligible):
+    torch.manual_seed(3)
+    layers = [nn.Linear(64, 64) for _ in range(6)] + [nn.Linear(64, 128)]
+    mods = []
+    for i, l in enumerate(layers):
+        m = LokrModule(f"l{i}", l, 1.0, 10000, 1, factor=4)
+        m.apply_to()
+        mods.append(m)
+    x = torch.randn(5, 64)
+    for l in layers:
+        l(x)
+    assert len(mods[0]._sib.members) == 4 and mods[4]._sib is not mods[0]._sib
+    assert mods[6]._sib is None or all(r() is not mods[6] for r in mods[0]._sib.members)
