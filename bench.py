@@ -101,6 +101,7 @@ def parse():
     ap.add_argument("--rccl-ws1", action="store_true",
                     help="run the N > 1 step on one GPU: nccl (= RCCL) process group of world_size 1, every gradient bucket all-reduced "
                          "in place on the side stream between the backward segment graphs (MASTER_ADDR / MASTER_PORT / RANK from the env)")
+    ap.add_argument("--dev-base-only", action="store_true", help="development: run the base + adapter leg alone and exit (for rocprofv3 --kernel-trace)")
     ap.add_argument("--dev-idle-comm", action="store_true", help="development: create the RCCL communicator, never use it (plain N = 1 step)")
     ap.add_argument("--dev-hop-only", action="store_true", help="development: --rccl-ws1 with the collectives themselves skipped (marks, waits, join only)")
     ap.add_argument("--comm-high-priority", action="store_true", help="development: the communicator's stream at high priority (A/B: it slows the whole step 3.5x)")
@@ -452,6 +453,9 @@ def main():
     n_layers = len(insts)
     act_bytes = sum(t.numel() * t.element_size() for t in {id(t): t for it in insts for t in (it.x, it.g)}.values())
 
+    if args.dev_base_only:
+        print(json.dumps(base_leg(insts, sync, opt, _ops)), flush=True)
+        return
     if args.pmc_pass:
         for _ in range(args.pmc_pass):
             sync.zero_grad()
@@ -901,7 +905,7 @@ def roofline(insts, args, dtype, dev):
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "algorithmic_flops_per_layer": int(flops / n_l)})
         return out
-    fam = {"lokr": "lokr_kron3", "locon": "locon_linear", "ia3": "ia3"}[lin[0].algo]
+    fam = {"lokr": "lokr_kron4", "locon": "locon_linear", "ia3": "ia3"}[lin[0].algo]
     nbytes = b_fwd + b_bwd
     hot = nbytes / (t_ms * 1e-3) / 1e9
     workload = f"{lin[0].algo if algo != 'mixed' else 'mixed'}/{args.model}/linear"
@@ -948,8 +952,8 @@ def roofline(insts, args, dtype, dev):
                     (a, b), (c, d) = fs[0].shape, fs[1].shape
                     if len(u) > 1:  # the set's dx launches as one; the n results are summed into the shared input's gradient
                         N.call("lyc_lokr_linear_bwd_group", ctypes.cast(bw_items[u[0]], ctypes.c_void_p), len(u), a, b, c, d, code, N.stream_ptr(dev))
-                        for k in u[1:]:
-                            dxs[u[0]].add_(dxs[k])
+                        srcs = (ctypes.c_void_p * len(u))(*[dxs[k].data_ptr() for k in u])
+                        N.call("lyc_sum_rows", ctypes.cast(srcs, ctypes.c_void_p), len(u), N.ptr(dxs[u[0]]), dxs[u[0]].numel(), code, N.stream_ptr(dev))
                     else:
                         k = u[0]
                         N.call("lyc_lokr_linear_bwd_planes", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(planes[id(it)][1]), N.ptr(dxs[k]),
@@ -1007,13 +1011,16 @@ def roofline(insts, args, dtype, dev):
                     "launches": 2 * (len(units) if use_planes else n_l),
                     "launches_note": (f"{sum(1 for u in units if len(u) > 1)} sibling sets ({sum(len(u) for u in units if len(u) > 1)} layers) as one "
                                       f"lyc::kron4_group_kernel launch each, {sum(1 for u in units if len(u) == 1)} layers on their own; forward + "
-                                      "backward dx (the in-place sums of the sets' dx are inside the backward time)") if use_planes else "one per layer and pass",
+                                      "backward dx (the one-pass sums of the sets' dx results, lyc_sum_rows, are inside the backward time)") if use_planes else "one per layer and pass",
                     "avg_launch_us": round(k3_ms * 1e3 / (2 * (len(units) if use_planes else n_l)), 2),
                     "algorithmic_bytes_per_launch": int(k3_bytes / (2 * (len(units) if use_planes else n_l))),
                     "hot_path_gbs": round(hot, 1), "hot_path_frac": round(hot / HBM_PEAK_GBS, 4),
                     "backward_gbs": round(b_bwd / ((t_dx + t_wg) * 1e-3) / 1e9, 1),
                     "dw2_grouped_gbs": round(b_dw2 / (t_wg * 1e-3) / 1e9, 1),
                     "dw2s_per_layer_gbs": round(b_dw2 / (t_dw2 * 1e-3) / 1e9, 1)})
+        if tr:  # HBM bytes of the family over one pass (every launch of it, the sets' one-pass dx sums included) per forward / dx launch
+            out["traffic"] = int(tr["bytes_per_pass"] / out["launches"])
+            out["traffic_over_algorithmic"] = round(tr["bytes_per_pass"] / k3_bytes, 3)
         # per shape: forward and dx launches of each distinct Linear shape in their own graphs (<= 12 instances,
         # every instance its own x / g), HIP events.  mfma_model = matrix-core busy fraction from the launch's instruction count
         # (stage 1: 2 v_mfma_16x16x32 per 16x16x32 block, stage 2: 3 v_mfma_16x16x16 per 16x16 tile, + 4 with dW1; 16 cycles each)

@@ -25,7 +25,7 @@ def load(d, counter):
 
 
 def short(name):
-    for key in ("kron4_kernel", "kron4_group_kernel", "kron_dw2f_table_kernel", "kron_dw2f_group_kernel", "kron3_kernel", "kron_dw2s_conv_group_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "copy16", "kron_kernel", "kron_dw2_kernel",
+    for key in ("kron4_group_kernel", "kron4_kernel", "sum_rows_kernel", "gemm16_kernel", "loha_rebuild", "loha_factor_grad", "kron_dw2f_table_kernel", "kron_dw2f_group_kernel", "kron3_kernel", "kron_dw2s_conv_group_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "copy16", "kron_kernel", "kron_dw2_kernel",
                 "kconv_dw2_group_kernel", "kconv_kernel", "kron_pack", "bneck_kernel", "lowrank_tn_kernel", "gexp_kernel"):
         if key in name:
             return key + name.split(key)[1][:34]
@@ -34,14 +34,22 @@ def short(name):
 
 # kernel families of bench.py's roofline legs, per WORKLOAD "algo/model/layers" (one pair of rocprofv3 passes each)
 FAMILIES = {  # family -> (layers of the pass it is read from, kernel-name substrings)
-    "lokr_kron3": ("linear", ("kron3_kernel", "kron4_kernel")),  # the forward / dx launches (round 4: kron4 on packed planes)
+    # the forward / dx launches of the LoKr nn.Linear layers: kron4 on packed planes (kron4_group_kernel: sibling sets in one launch,
+    # round 5; "kron4_kernel" does not match it) + the one-pass sum of a set's dx results; kron3 where there are no planes
+    "lokr_kron4": ("linear", ("kron3_kernel", "kron4_kernel", "kron4_group_kernel", "sum_rows_kernel")),
     "lokr_dw2s": ("linear", ("kron_dw2s_kernel", "kron_dw2s_group_kernel", "kron_dw2f_table_kernel", "kron_dw2f_group_kernel")),
-    "lokr_linear": ("linear", ("kron3_kernel", "kron4_kernel", "kron_dw2s_kernel", "kron_dw2s_group_kernel", "kron_dw2f_table_kernel",
-                               "kron_dw2f_group_kernel", "kron_dw2f_table_write_kernel", "kron_dw1_reduce", "kron_kernel", "kron_dw2_kernel", "kron_pack")),
+    "lokr_linear": ("linear", ("kron3_kernel", "kron4_kernel", "kron4_group_kernel", "sum_rows_kernel", "kron_dw2s_kernel", "kron_dw2s_group_kernel",
+                               "kron_dw2f_table_kernel", "kron_dw2f_group_kernel", "kron_dw2f_table_write_kernel", "kron_dw1_reduce", "kron_kernel",
+                               "kron_dw2_kernel", "kron_pack")),
     "locon_linear": ("linear", ("bneck_kernel", "lowrank_tn", "skinny_", "expand_nt")),
+    "locon_conv": ("conv", ("bneck_kernel", "lowrank_tn", "gexp_kernel", "skinny_", "expand_nt", "nchw_rows")),
+    "loha_linear": ("linear", ("gemm16_kernel", "loha_rebuild", "loha_factor_grad")),
     "lokr_kconv": ("conv", ("kconv_kernel",)),
-    "lokr_conv_dw2": ("conv", ("kron_dw2s_conv_group_kernel", "kron_dw2s_kernel", "kconv_dw2_group_kernel")),
-    "lokr_conv": ("conv", ("kconv_kernel", "kron_dw2s", "kconv_dw2", "kron3_kernel", "kron_pack", "kron_dw1_reduce", "nchw_rows")),
+    # the Conv2d weight gradients: since round 4 mostly on kron_dw2f (Conv2d form: table / group kernels); VERDICT r4 weak #6: the
+    # round-4 list left those two launches out
+    "lokr_conv_dw2": ("conv", ("kron_dw2s_conv_group_kernel", "kron_dw2s_kernel", "kconv_dw2_group_kernel", "kron_dw2f_group_kernel",
+                               "kron_dw2f_table_kernel", "kron_dw2f_table_write_kernel")),
+    "lokr_conv": ("conv", ("kconv_kernel", "kron_dw2s", "kron_dw2f", "kconv_dw2", "kron3_kernel", "kron4_kernel", "kron_pack", "kron_dw1_reduce", "nchw_rows")),
 }
 CAL_R, CAL_W = 2047.96, 1024.0  # bytes per counter unit, calibrated on a 1 GiB copy (profiles/r01_pmc_kbench.txt)
 

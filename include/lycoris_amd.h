@@ -41,7 +41,7 @@ enum { LYC_F32_ROWS = 0x100, LYC_DEFER_WGRAD = 0x200,
 #define LYC_KCONV_ROW_TILE(mi) (((mi) & 0xf) << 12)
 enum { LYC_OK = 0, LYC_ERR_ARG = 1, LYC_ERR_UNSUPPORTED = 2, LYC_ERR_LAUNCH = 3 };
 
-#define LYC_ABI_VERSION 9
+#define LYC_ABI_VERSION 10
 int lyc_abi_version(void);
 const char* lyc_last_error(void);
 
@@ -228,6 +228,12 @@ typedef struct LycLokrLinearGroupItem {
 } LycLokrLinearGroupItem;
 int lyc_lokr_linear_fwd_group(const LycLokrLinearGroupItem* items, int n, int a, int b, int c, int d, int dtype, void* stream);
 int lyc_lokr_linear_bwd_group(const LycLokrLinearGroupItem* items, int n, int a, int b, int c, int d, int dtype, void* stream);
+/* dst = src[0] + ... + src[n - 1], n <= 4, `numel` elements of the 16-bit `dtype` each (numel % 8 == 0, 16-byte aligned pointers):
+ * fp32 accumulation, one rounding.  The gradient of a tensor that n sibling projections read -- the n dx results of
+ * lyc_lokr_linear_bwd_group -- in ONE pass (autograd's accumulation, which this replaces for a grouped set, makes n - 1 passes with
+ * a rounding each; reference: the implicit gradient accumulation of torch.autograd for lokr.py:543-566 called n times on one
+ * tensor).  dst may be src[0]. */
+int lyc_sum_rows(const void* const* src, int n, void* dst, int64_t numel, int dtype, void* stream);
 int lyc_lokr_pack_w2(const float* w2, int64_t sq, int64_t sv, int64_t st, const float* w2a, int64_t a_sq, int64_t a_sr,
                      const float* w2b, int64_t b_sr, int64_t b_sv, int64_t b_st, int rank, int c, int d, int taps,
                      void* planes_fwd, void* planes_bwd, int dtype, void* stream);

@@ -793,6 +793,25 @@ int lyc_lokr_linear_bwd_group(const LycLokrLinearGroupItem* items, int n, int a,
   return lokr_linear_group(items, n, a, b, c, d, dtype, stream, true);
 }
 
+int lyc_sum_rows(const void* const* src, int n, void* dst, int64_t numel, int dtype, void* stream) {
+  if (n < 1 || n > 4 || !src || !dst || numel < 0) return fail(LYC_ERR_ARG, "sum_rows: 1 <= n <= 4 sources");
+  const int dt = dtype & 0xff;
+  if (dt != LYC_BF16 && dt != LYC_F16) return fail(LYC_ERR_UNSUPPORTED, "sum_rows: 16-bit tensors");
+  if (numel == 0) return LYC_OK;
+  SumArgs sa{};
+  for (int i = 0; i < n; ++i) {
+    if (!src[i] || (reinterpret_cast<uintptr_t>(src[i]) & 15u)) return fail(LYC_ERR_ARG, "sum_rows: source %d is null or not 16-byte aligned", i);
+    sa.src[i] = src[i];
+  }
+  if ((numel % 8) != 0 || (reinterpret_cast<uintptr_t>(dst) & 15u)) return fail(LYC_ERR_ARG, "sum_rows: numel %% 8 == 0 and an aligned destination");
+  sa.dst = dst; sa.total = numel; sa.n = n;
+  long blocks = cdiv(numel / 8, (long)NTHREADS);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (dt == LYC_BF16) hipLaunchKernelGGL((sum_rows_kernel<__bf16>), dim3((unsigned)blocks), dim3(NTHREADS), 0, (hipStream_t)stream, sa);
+  else hipLaunchKernelGGL((sum_rows_kernel<_Float16>), dim3((unsigned)blocks), dim3(NTHREADS), 0, (hipStream_t)stream, sa);
+  return check_launch("sum_rows");
+}
+
 // one pack launch for MANY layers (Linear or Conv2d factors given as full matrices): the once-per-optimizer-step refresh
 int lyc_lokr_pack_group(const LycLokrPackItem* items, int n, int dtype, void* stream) {
   if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "lokr_pack_group: bad item list");

@@ -26,6 +26,42 @@ struct ChanArgs {
   int vec;             // chan_reduce, inner == 1: the host verified C % VEC == 0 and 16-byte alignment (vector layout)
 };
 
+// dst = src[0] + ... + src[n - 1] (n <= 4), fp32 accumulation, ONE rounding: the gradient of a tensor that n sibling projections read
+// (round 5: the n dx results of lyc_lokr_linear_bwd_group; autograd's accumulation does n - 1 passes with a rounding each).
+struct SumArgs {
+  const void* src[4];
+  void* dst;
+  long total;  // elements, a multiple of the 16-byte vector
+  int n;
+};
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void sum_rows_kernel(SumArgs a) {
+  constexpr int VEC = TT<T>::VEC;
+  const long nvec = a.total / VEC;
+  const long stride = (long)gridDim.x * NTHREADS;
+  for (long v = (long)blockIdx.x * NTHREADS + threadIdx.x; v < nvec; v += stride) {
+    u32x4 raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)  // all loads of a vector before the first use; absent sources re-read source 0 (selected out below)
+      raw[i] = *reinterpret_cast<const u32x4*>(static_cast<const T*>(a.src[i < a.n ? i : 0]) + v * VEC);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      T iv[VEC];
+      *reinterpret_cast<u32x4*>(iv) = raw[i];
+      const float on = i < a.n ? 1.f : 0.f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += on * TT<T>::to_f(iv[e]);
+    }
+    T ov[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) ov[e] = TT<T>::from_f(acc[e]);
+    *reinterpret_cast<u32x4*>(static_cast<T*>(a.dst) + v * VEC) = *reinterpret_cast<u32x4*>(ov);
+  }
+}
+
 // out[o, c, i] = a[o, c, i] * (s0 + w[c] * mult) - bias[c] * w[c] * mult
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void chan_scale_kernel(ChanArgs a) {

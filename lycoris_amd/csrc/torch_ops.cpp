@@ -1080,8 +1080,14 @@ struct LokrLinearGroupFn : public torch::autograd::Function<LokrLinearGroupFn> {
       for (size_t i = 0; i < n; ++i)
         park_deferred(DeferredLokr{g2[i], rows, f1s[i], s[1 + 2 * i], s[2 + 2 * i], t1[i].buf, t2[i].buf, wss[i], M, (int)a, (int)b, (int)c,
                                    (int)d, code, (float)alphas[i], stream_of(x), x.device().index()});
-      if (nx) {  // d(sum of the problems)/dx: the n results summed in place (what autograd's accumulation does for n separate nodes)
-        for (size_t i = 1; i < n; ++i) dxs[0].add_(dxs[i]);
+      if (nx) {  // d(sum of the problems)/dx: the n results summed in ONE pass, fp32 accumulation, one rounding (autograd's
+        // accumulation for n separate nodes makes n - 1 passes with a rounding each); chunks of 4 sources
+        for (size_t lo = 1; lo < n; lo += 3) {
+          const void* src[4] = {cptr(dxs[0]), nullptr, nullptr, nullptr};
+          int cnt = 1;
+          for (size_t i = lo; i < n && cnt < 4; ++i) src[cnt++] = cptr(dxs[i]);
+          check_rc(lyc_sum_rows(src, cnt, mptr(dxs[0]), dxs[0].numel(), code, stream_of(x)), "lyc_sum_rows");
+        }
         out[0] = shaped_like(dxs[0], x);
       }
     } else {  // problem by problem, through the single-layer backward (deferred where it can be)

@@ -159,8 +159,6 @@ def _ca(k, s):
 def test_lokr_conv2d_fullsize(shape, dtype):
     from lycoris_amd import ops
     B, C, H, O, k, s = shape
-    if dtype == torch.float16 and shape not in (CONV[0], CONV[1], CONV[2], CONV[8], CONV[11]):
-        pytest.skip("fp16: one shape per kernel plan")
     gen = torch.Generator().manual_seed(B + C + H + O + k)
     x, x64 = rnd((B, C, H, H), dtype, gen)
     Ho = (H + 2 * (k // 2) - k) // s + 1
@@ -184,8 +182,6 @@ def test_lokr_conv2d_fullsize(shape, dtype):
 def test_locon_conv2d_fullsize(shape, dtype):
     from lycoris_amd import ops
     B, C, H, O, k, s = shape
-    if dtype == torch.float16 and shape not in (CONV[0], CONV[1], CONV[2], CONV[3], CONV[4], CONV[8], CONV[11], CONV[16]):
-        pytest.skip("fp16: one shape per kernel plan")
     r = 16 if k == 1 else 8
     gen = torch.Generator().manual_seed(B + C + H + O + k + 1)
     x, x64 = rnd((B, C, H, H), dtype, gen)
@@ -214,8 +210,6 @@ def test_loha_conv2d_fullsize(shape, dtype):
     from lycoris_amd import ops
     B, C, H, O, k, s = shape
     r = 32
-    if dtype == torch.float16 and shape not in (CONV[1], CONV[2], CONV[3], CONV[4]):
-        pytest.skip("fp16: one shape per lowering (3x3 s1, 3x3 s2, 1x1, batch 4)")
     gen = torch.Generator().manual_seed(B + C + H + O + k + 2)
     x, x64 = rnd((B, C, H, H), dtype, gen)
     Ho = (H + 2 * (k // 2) - k) // s + 1

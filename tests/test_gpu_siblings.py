@@ -70,11 +70,37 @@ def test_group_op_matches_the_oracle_and_the_per_layer_op(case, dtype, with_base
         errs[f"dw1_{i}"], bounds[f"dw1_{i}"] = err(gr_g[1 + 2 * i], gr["w1"]), TOL["f32_out"][dtype]
         errs[f"dw2_{i}"], bounds[f"dw2_{i}"] = err(gr_g[2 + 2 * i], gr["w2"]), TOL["f32_out"][dtype]
         assert torch.equal(gr_g[1 + 2 * i], gr_p[1 + 2 * i]) or err(gr_g[1 + 2 * i], gr_p[1 + 2 * i].double().cpu().numpy()) < 1e-6
-    # the shared input's gradient: n 16-bit results summed in 16 bits (as autograd's accumulation does): n roundings
+    # the shared input's gradient.  No fused accumulation here, so the node takes its problem-by-problem path and the n 16-bit
+    # results are added in 16 bits like autograd's accumulation: n roundings (the one-pass fp32 sum is the training-configuration test)
     errs["dx"], bounds["dx"] = err(gr_g[0], dx_want), (n + 1) * TOL["store_out"][dtype]
     errs["dx_vs_per_layer"] = err(gr_g[0], gr_p[0].double().cpu().numpy())
     bounds["dx_vs_per_layer"] = n * TOL["store_out"][dtype]
     check(f"sibling_group_op[{case},{dtype},{with_base}]", errs, bounds)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+def test_sum_rows_is_the_fp32_sum_rounded_once(n, dtype):
+    """lyc_sum_rows: dst = src[0] + ... + src[n - 1] with fp32 accumulation and one rounding (bit-exact against torch's fp32 sum),
+    also in place (dst = src[0]) and on a size that is not a multiple of the grid"""
+    import ctypes
+    from lycoris_amd import _native as N
+    gen = torch.Generator().manual_seed(n)
+    for numel in (8, 1024 * 1280, 77 * 2048 + 8):
+        srcs = [(torch.randn(numel, generator=gen) * 3).to(dtype).to(DEV) for _ in range(n)]
+        want = torch.stack([s.float() for s in srcs]).sum(0).to(dtype) if n > 1 else srcs[0].clone()
+        if n == 3:  # fp32 addition is not associative: the kernel adds in source order
+            want = ((srcs[0].float() + srcs[1].float()) + srcs[2].float()).to(dtype)
+        if n == 4:
+            want = (((srcs[0].float() + srcs[1].float()) + srcs[2].float()) + srcs[3].float()).to(dtype)
+        dst = torch.empty_like(srcs[0])
+        arr = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+        N.call("lyc_sum_rows", ctypes.cast(arr, ctypes.c_void_p), n, N.ptr(dst), numel, N.dtype_code(dtype), N.stream_ptr(DEV))
+        torch.cuda.synchronize()
+        assert torch.equal(dst, want), (n, numel)
+        N.call("lyc_sum_rows", ctypes.cast(arr, ctypes.c_void_p), n, N.ptr(srcs[0]), numel, N.dtype_code(dtype), N.stream_ptr(DEV))
+        torch.cuda.synchronize()
+        assert torch.equal(srcs[0], want), ("in place", n, numel)
 
 
 def test_group_op_in_the_training_configuration_accumulates_into_grad_and_reports_once():
@@ -110,7 +136,9 @@ def test_group_op_in_the_training_configuration_accumulates_into_grad_and_report
         dx_want = dx_want + gr["dx"]
         errs[f"dw1_{i}"], bounds[f"dw1_{i}"] = err(w1s[i].grad, gr["w1"]), TOL["f32_out"][dtype]
         errs[f"dw2_{i}"], bounds[f"dw2_{i}"] = err(w2s[i].grad, gr["w2"]), TOL["f32_out"][dtype]
-    errs["dx"], bounds["dx"] = err(xr.grad, dx_want), (n + 1) * TOL["store_out"][dtype]
+    # against the UNROUNDED float64 sum: each of the n results is stored in 16 bits once (the kernels' outputs), then lyc_sum_rows adds
+    # them in fp32 and rounds once more -- measured 2.4e-3 in bf16 (the in-16-bit accumulation of n separate nodes: 2.9e-3)
+    errs["dx"], bounds["dx"] = err(xr.grad, dx_want), 3 * TOL["store_out"][dtype]
     check("sibling_group_op_training_configuration", errs, bounds)
 
 
