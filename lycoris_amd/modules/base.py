@@ -124,7 +124,7 @@ class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
             self.shape = (org_module.out_channels, org_module.in_channels, *org_module.kernel_size)
             self.op = (F.conv1d, F.conv2d, F.conv3d)[nd - 1]
             self.dim = org_module.out_channels
-            self.kw_dict = {"stride": org_module.stride, "padding": org_module.padding,
+            self.kw_dict = {"stride": org_module.stride, "padding": self._int_padding(org_module),
                             "dilation": org_module.dilation, "groups": org_module.groups}
             if nd == 2:
                 # fail when the network is BUILT (not at the first training step) for layer variants the kernels do not
@@ -168,6 +168,24 @@ class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
         self.multiplier = multiplier
         self.org_forward = org_module.forward
         self.org_module = [org_module]  # list: keeps the frozen layer out of this module's parameters
+
+    @staticmethod
+    def _int_padding(org_module):
+        """padding="valid" / "same" of the frozen layer as the integer padding the kernels take (round 5; the reference hands the
+        string through to F.conv*, modules/base.py:101-121).  "same" needs stride 1 (torch enforces it) and pads dilation * (k - 1) in
+        total per dimension; when that is odd torch pads one more element on the right, which no symmetric integer expresses."""
+        pad = org_module.padding
+        if not isinstance(pad, str):
+            return pad
+        if pad == "valid":
+            return tuple(0 for _ in org_module.kernel_size)
+        if pad == "same":
+            total = [d * (k - 1) for k, d in zip(org_module.kernel_size, org_module.dilation)]
+            if any(t % 2 for t in total):
+                raise _unsupported(f'padding="same" with an asymmetric pad (kernel {tuple(org_module.kernel_size)}, dilation '
+                                   f"{tuple(org_module.dilation)})")
+            return tuple(t // 2 for t in total)
+        raise _unsupported(f"padding={pad!r}")
 
     # ---- registry protocol (lycoris/modules/__init__.py:33-46) -------------------------------------------------
     @classmethod

@@ -205,8 +205,10 @@ def test_host_tensors_run_and_unsupported_features_fail_loudly():
     for cls in (LoConModule, LohaModule, LokrModule):
         with pytest.raises(NotImplementedError, match="grouped"):
             cls("m", nn.Conv2d(8, 8, 3, groups=2), 1.0, 2, 1)
-        with pytest.raises(NotImplementedError, match="padding"):
-            cls("m", nn.Conv2d(8, 8, 3, padding="same"), 1.0, 2, 1)
+        assert cls("m", nn.Conv2d(8, 8, 3, padding="same", dilation=2), 1.0, 2, 1).kw_dict["padding"] == (2, 2)  # round 5: as integers
+        assert cls("m", nn.Conv2d(8, 8, 3, padding="valid"), 1.0, 2, 1).kw_dict["padding"] == (0, 0)
+        with pytest.raises(NotImplementedError, match="asymmetric"):
+            cls("m", nn.Conv2d(8, 8, 4, padding="same"), 1.0, 2, 1)
         with pytest.raises(NotImplementedError, match="padding_mode"):
             cls("m", nn.Conv2d(8, 8, 3, padding=1, padding_mode="reflect"), 1.0, 2, 1)
 
