@@ -899,10 +899,13 @@ def roofline(insts, args, dtype, dev):
                               "backward_one_call_per_layer": round(t_bwd, 3)}
         t_ms = t_fwd + t_dx + t_wg
         ach = flops / (t_ms * 1e-3) / 1e12
+        tr, src = pmc_traffic("loha_linear", f"loha/{args.model}/linear")
         out.update({"bound": "mfma", "kernel": "LoHa dense contractions y = x dW^T, dx = g dW, G = g^T x of the Linear layers "
                                               "(+ dW rebuild and Hadamard chain rule)",
                     "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                    # HBM bytes of the family (gemm16 + rebuild + factor gradients) over one pass, per layer
+                    "traffic": int(tr["bytes_per_pass"] / n_l) if tr else None, "traffic_source": src,
                     "algorithmic_flops_per_layer": int(flops / n_l)})
         return out
     fam = {"lokr": "lokr_kron4", "locon": "locon_linear", "ia3": "ia3"}[lin[0].algo]

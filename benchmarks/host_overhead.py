@@ -56,6 +56,18 @@ def native_training_backward(algo, ls):
     torch.autograd.backward(ys, [g for x, g, fs, W in ls])
 
 
+def native_training_grouped(algo, ls):
+    """round 5: sets of three layers reading ONE tensor (to_q / to_k / to_v) through ops.lokr_linear_group -- one dispatch, one autograd
+    node and one backward call per set; microseconds per LAYER"""
+    ys, wrt = [], []
+    for i in range(0, len(ls) - 2, 3):
+        x = ls[i][0]
+        ys += ops.lokr_linear_group(x, [ls[i + j][2][0] for j in range(3)], [ls[i + j][2][1] for j in range(3)], [1.0, 1.0, 1.0])
+        wrt += [x] + [f for j in range(3) for f in ls[i + j][2]]
+    n = len(ys)
+    torch.autograd.grad(ys, wrt, [ls[k][1] for k in range(n)], allow_unused=True)
+
+
 def reference(algo, ls):
     ys = []
     for x, g, fs, W in ls:
@@ -91,6 +103,8 @@ for algo in ("lokr", "locon"):
     try:
         row["native_cpp_training_config_us"] = round(wall(lambda: native_training(algo, ls)), 1)
         row["native_cpp_training_config_backward_us"] = round(wall(lambda: native_training_backward(algo, ls)), 1)
+        if algo == "lokr":
+            row["native_cpp_training_config_sibling_sets_of_3_us"] = round(wall(lambda: native_training_grouped(algo, ls)) * N_LAYERS / (N_LAYERS // 3 * 3), 1)
     finally:
         ops.fused_grad_accumulation(False, None)
         for x, g, fs, W in ls:

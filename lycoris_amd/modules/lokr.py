@@ -232,7 +232,8 @@ class LokrModule(LycorisBaseModule):
 
     def forward(self, x, *args, **kwargs):
         # to_q / to_k / to_v called with one tensor run as ONE launch (modules/siblings.py); everything else is the per-layer path
-        if not args and not kwargs and isinstance(x, torch.Tensor) and self._sibling_eligible(x) and not torch.compiler.is_compiling():
+        # (is_compiling() first: under torch.compile the whole branch folds away and dynamo never sees the eligibility test)
+        if not torch.compiler.is_compiling() and not args and not kwargs and isinstance(x, torch.Tensor) and self._sibling_eligible(x):
             y = _siblings.forward(self, x)
             if y is not None:
                 return y
