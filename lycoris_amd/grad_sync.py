@@ -55,6 +55,7 @@ class RcclCommunicator:
     the producer of the data, `join()` makes the caller's stream wait for them.  Nothing here synchronises the host."""
 
     SUM, AVG, MAX = 0, 1, 2
+    _created = 0
 
     def __init__(self, rank: int, world: int, device, store=None, unique_id: Optional[bytes] = None, key: str = "lycoris_amd/rccl_uid",
                  high_priority: bool = False, stream: Optional["torch.cuda.Stream"] = None, on_current_stream: bool = False):
@@ -69,11 +70,15 @@ class RcclCommunicator:
                 if world != 1:
                     raise ValueError("RcclCommunicator: world > 1 needs a store (or the unique id) to agree on the communicator")
                 unique_id = ext.rccl_unique_id()
-            elif rank == 0:
-                unique_id = ext.rccl_unique_id()
-                store.set(key, unique_id)
             else:
-                unique_id = bytes(store.get(key))  # blocks until rank 0 has published it
+                # every rank creates its communicators in the same order: the n-th one of a process uses the n-th key
+                RcclCommunicator._created += 1
+                key = f"{key}/{RcclCommunicator._created}"
+                if rank == 0:
+                    unique_id = ext.rccl_unique_id()
+                    store.set(key, unique_id)
+                else:
+                    unique_id = bytes(store.get(key))  # blocks until rank 0 has published it
         torch.cuda.init()
         self._stream = stream  # (kept alive: the communicator enqueues on it)
         # on_current_stream: every collective is enqueued on whatever stream is current at the call -- ordinary in-order work of the

@@ -411,3 +411,89 @@ def test_sharded_adamw_single_process_is_plain_adamw():
             sum(((p + step) ** 3).sum() for p in plist).backward()
         sync.finish(); opt.step(); o_ref.step()
         assert all(torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(mine, ref))
+
+
+# ---- round 5: the ProcessGroup-free communicator path (host logic; the real thing runs in tests/test_gpu_grad_sync.py) -----------------
+class _FakeComm:
+    """records what AdapterGradSync asks of a communicator; `world` ranks, this is rank `rank`"""
+    SUM, AVG, MAX = 0, 1, 2
+
+    def __init__(self, world=2, rank=0, on_current_stream=False):
+        self.world, self.rank, self.device, self.on_current_stream = world, rank, torch.device("cpu"), on_current_stream
+        self.log = []
+
+    def wait_current(self): self.log.append(("wait_current",))
+    def wait_event(self, e): self.log.append(("wait_event", e))
+    def mark(self): self.log.append(("mark",)); return len(self.log)
+    def join(self): self.log.append(("join",))
+    def all_reduce(self, t, op=0): self.log.append(("all_reduce", t.numel(), op)); t.mul_(0.5) if op == 1 else None
+    def reduce_scatter(self, shard, full, op=0): self.log.append(("reduce_scatter", shard.numel(), full.numel(), op))
+    def all_gather(self, full, shard): self.log.append(("all_gather", full.numel(), shard.numel()))
+
+
+def test_communicator_path_orders_every_bucket_behind_its_gradients_and_joins_once():
+    from lycoris_amd.grad_sync import AdapterGradSync
+    params = [torch.nn.Parameter(torch.ones(1000)) for _ in range(6)]
+    comm = _FakeComm()
+    sync = AdapterGradSync(params, bucket_bytes=8000, comm=comm)   # 3 buckets of 2 parameters, no process group anywhere
+    assert sync.world_size == 2 and sync.side_stream is None and len(sync.buckets) == 3
+    sync.zero_grad()
+    loss = sum((p * (i + 1)).sum() for i, p in enumerate(params))
+    loss.backward()
+    # the hooks fired during backward: every bucket = wait for the compute stream, then ONE in-place all-reduce (AVG)
+    assert [e[0] for e in comm.log] == ["wait_current", "all_reduce"] * 3 and all(e[2] == comm.AVG for e in comm.log if e[0] == "all_reduce")
+    sync.finish()
+    assert comm.log[-1] == ("join",) and [e[0] for e in comm.log].count("join") == 1
+    assert torch.allclose(params[0].grad, torch.full((1000,), 0.5))  # (the fake "averages" by halving)
+    # segment callers: a mark of the compute stream, collectives ordered behind exactly that mark
+    comm.log.clear()
+    sync.zero_grad()
+    m = sync.mark()
+    sync.launch_buckets([0, 2], after=m)
+    assert [e[0] for e in comm.log] == ["mark", "wait_event", "all_reduce", "wait_event", "all_reduce"] and comm.log[1][1] == m
+    sync.finish()  # launches the bucket nobody asked for, joins
+    assert [e[0] for e in comm.log][-3:] == ["wait_current", "all_reduce", "join"]
+
+
+def test_communicator_path_reduce_scatter_shapes_and_unique_id_exchange(monkeypatch):
+    import threading
+    import types
+    import lycoris_amd.grad_sync as gs
+    from lycoris_amd import _native
+    params = [torch.nn.Parameter(torch.ones(1001))]
+    comm = _FakeComm(world=2, rank=1)
+    sync = gs.AdapterGradSync(params, comm=comm, collective="reduce_scatter")
+    sync.zero_grad()
+    params[0].sum().backward()
+    sync.finish()
+    ops_ = [e for e in comm.log if e[0] in ("reduce_scatter", "all_gather", "all_reduce")]
+    assert ops_ == [("reduce_scatter", 500, 1000, comm.AVG), ("all_gather", 1000, 500), ("all_reduce", 1, comm.AVG)]
+    # the 128-byte id: rank 0 publishes it under the n-th key of the process, the others block on the same key
+    made = []
+    fake = types.SimpleNamespace(rccl_unique_id=lambda: b"U" * 128,
+                                 RcclComm=lambda uid, rank, world, idx, hp, ext, cur: made.append((uid, rank, world, cur)))
+    monkeypatch.setattr(_native, "load_torch_ops", lambda: fake)
+    monkeypatch.setattr(torch.cuda, "init", lambda: None)
+
+    class Store(dict):
+        cv = threading.Condition()
+
+        def set(self, k, v):
+            with self.cv:
+                self[k] = v
+                self.cv.notify_all()
+
+        def get(self, k):
+            with self.cv:
+                assert self.cv.wait_for(lambda: k in self, timeout=10)
+                return self[k]
+
+    st = Store()
+    monkeypatch.setattr(gs.RcclCommunicator, "_created", 0)
+    gs.RcclCommunicator(0, 2, "cuda:0", store=st, on_current_stream=True)   # rank 0 publishes
+    monkeypatch.setattr(gs.RcclCommunicator, "_created", 0)                  # (another process: its own count)
+    gs.RcclCommunicator(1, 2, "cuda:0", store=st)                            # rank 1 reads the same key
+    assert sorted(m[1] for m in made) == [0, 1] and all(m[0] == b"U" * 128 for m in made) and made[0][3] is True
+    assert list(st) == ["lycoris_amd/rccl_uid/1"]
+    with pytest.raises(ValueError, match="store"):
+        gs.RcclCommunicator(0, 2, "cuda:0")
