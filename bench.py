@@ -953,10 +953,9 @@ def roofline(insts, args, dtype, dev):
                 for u in units:
                     it, rows, g, fs, bufs = calls[u[0]]
                     (a, b), (c, d) = fs[0].shape, fs[1].shape
-                    if len(u) > 1:  # the set's dx launches as one; the n results are summed into the shared input's gradient
-                        N.call("lyc_lokr_linear_bwd_group", ctypes.cast(bw_items[u[0]], ctypes.c_void_p), len(u), a, b, c, d, code, N.stream_ptr(dev))
-                        srcs = (ctypes.c_void_p * len(u))(*[dxs[k].data_ptr() for k in u])
-                        N.call("lyc_sum_rows", ctypes.cast(srcs, ctypes.c_void_p), len(u), N.ptr(dxs[u[0]]), dxs[u[0]].numel(), code, N.stream_ptr(dev))
+                    if len(u) > 1:  # the set's dx as ONE launch that stores the sum of the n results (the shared input's gradient)
+                        N.call("lyc_lokr_linear_bwd_group_sum", ctypes.cast(bw_items[u[0]], ctypes.c_void_p), len(u), a, b, c, d, N.ptr(dxs[u[0]]),
+                               code, N.stream_ptr(dev))
                     else:
                         k = u[0]
                         N.call("lyc_lokr_linear_bwd_planes", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(planes[id(it)][1]), N.ptr(dxs[k]),
@@ -1006,7 +1005,7 @@ def roofline(insts, args, dtype, dev):
                               "kron_dw2s_one_launch_per_layer": round(t_dw2, 3),
                               "backward_one_call_per_layer": round(t_bwd, 3)}
         out.update({"operand_planes": bool(use_planes),
-                    "kernel": ("lyc::kron4_kernel / lyc::kron4_group_kernel (one body)" if use_planes else "lyc::kron3_kernel") + " (LoKr forward + backward dx / dW1 launches of the "
+                    "kernel": ("lyc::kron4_kernel / lyc::kron4_group_kernel / lyc::kron4_sum_kernel (one body)" if use_planes else "lyc::kron3_kernel") + " (LoKr forward + backward dx / dW1 launches of the "
                               "Linear layers" + (", both operands by LDS-DMA, w2 from pre-packed hi/lo planes" if use_planes else "") + "); the weight "
                               "gradients run grouped (lyc::kron_dw2f_table_kernel: full-width output tiles, one launch per tile class, re-reads g and x): "
                               "families_ms",
@@ -1014,7 +1013,7 @@ def roofline(insts, args, dtype, dev):
                     "launches": 2 * (len(units) if use_planes else n_l),
                     "launches_note": (f"{sum(1 for u in units if len(u) > 1)} sibling sets ({sum(len(u) for u in units if len(u) > 1)} layers) as one "
                                       f"lyc::kron4_group_kernel launch each, {sum(1 for u in units if len(u) == 1)} layers on their own; forward + "
-                                      "backward dx (the one-pass sums of the sets' dx results, lyc_sum_rows, are inside the backward time)") if use_planes else "one per layer and pass",
+                                      "backward dx (a set's dx launch stores the SUM of its n results: lyc::kron4_sum_kernel)") if use_planes else "one per layer and pass",
                     "avg_launch_us": round(k3_ms * 1e3 / (2 * (len(units) if use_planes else n_l)), 2),
                     "algorithmic_bytes_per_launch": int(k3_bytes / (2 * (len(units) if use_planes else n_l))),
                     "hot_path_gbs": round(hot, 1), "hot_path_frac": round(hot / HBM_PEAK_GBS, 4),

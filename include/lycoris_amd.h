@@ -228,6 +228,12 @@ typedef struct LycLokrLinearGroupItem {
 } LycLokrLinearGroupItem;
 int lyc_lokr_linear_fwd_group(const LycLokrLinearGroupItem* items, int n, int a, int b, int c, int d, int dtype, void* stream);
 int lyc_lokr_linear_bwd_group(const LycLokrLinearGroupItem* items, int n, int a, int b, int c, int d, int dtype, void* stream);
+/* The same backward for n <= 4 problems that read ONE tensor (equal M): dx_sum [M, b*d] = sum_i dx_i, formed in registers -- a
+ * workgroup walks the n problems of its tile and stores the fp32 sum once (one rounding; no dx_i is written, `out` of the items is
+ * ignored); aux = x and ws (the w1 partials, as above) are required.  Replaces n - 1 passes of autograd's gradient accumulation for
+ * lokr.py:543-566 called n times on one tensor. */
+int lyc_lokr_linear_bwd_group_sum(const LycLokrLinearGroupItem* items, int n, int a, int b, int c, int d, void* dx_sum, int dtype,
+                                  void* stream);
 /* dst = src[0] + ... + src[n - 1], n <= 4, `numel` elements of the 16-bit `dtype` each (numel % 8 == 0, 16-byte aligned pointers):
  * fp32 accumulation, one rounding.  The gradient of a tensor that n sibling projections read -- the n dx results of
  * lyc_lokr_linear_bwd_group -- in ONE pass (autograd's accumulation, which this replaces for a grouped set, makes n - 1 passes with

@@ -59,6 +59,7 @@ SIGNATURES = {
     "lyc_im2col": [_vp, _vp, _i64, _i64, _i64, _i64] + [_i32] * 8 + [_i32, _vp],
     "lyc_col2im": [_vp, _vp, _i64, _i64, _i64, _i64] + [_i32] * 8 + [_i32, _vp],
     "lyc_sum_rows": [_vp, _i32, _vp, _i64, _i32, _vp],
+    "lyc_lokr_linear_bwd_group_sum": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "lyc_nchw_to_rows": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "lyc_rows_to_nchw": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
 }

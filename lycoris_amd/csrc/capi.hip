@@ -263,6 +263,49 @@ int launch_kron4_group(const KronArgs* kas, int n, hipStream_t st) {
   return LYC_OK;
 }
 
+// n <= K4_GROUP_MAX backward problems with equal (M, G, K, N) whose dx results are wanted as their SUM only (the gradient of the one
+// tensor n sibling projections read): kron4_sum_kernel, planned like ONE of the problems -- a workgroup walks all n
+template <typename T, int MI, int NI, int D, bool NP>
+void launch_kron4_sum_inst(const Kron4GroupArgs& ga, void* dx_sum, dim3 grid, hipStream_t st) {
+  constexpr int lds = kron4_lds_bytes(MI, NI, D);
+  auto kern = kron4_sum_kernel<T, MI, NI, D, NP>;
+  if (lds > 64 * 1024) {
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)once;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, ga, dx_sum);
+}
+template <typename T>
+int launch_kron4_sum(const KronArgs* kas, int n, void* dx_sum, hipStream_t st) {
+  const long rows = kas[0].M * kas[0].Gin;
+  const Kron4Plan p = kron4_plan(rows, kas[0].K, kas[0].N);
+  Kron4GroupArgs ga{};
+  ga.n = n;
+  int epi = 0;
+  const dim3 grid((unsigned)cdiv(rows, 64 * p.MI), (unsigned)cdiv(kas[0].N, 16 * p.NI));
+  const long nwg = (long)grid.x * grid.y;
+  for (int i = 0; i < n; ++i) {
+    ga.p[i] = kron4_args(kas[i], epi);
+    ga.nbx[i] = (int)grid.x;
+    const long want = lokr_dx_partial_blocks(kas[i].M, kas[i].Gin, kas[i].K, kas[i].N);
+    ga.p[i].dw1_blocks = (int)(want > nwg ? want : nwg);
+  }
+  if (p.NI == 5) {
+    if (p.D == 2) launch_kron4_sum_inst<T, 2, 5, 2, true>(ga, dx_sum, grid, st);
+    else launch_kron4_sum_inst<T, 2, 5, 3, true>(ga, dx_sum, grid, st);
+  } else if (p.NI == 4) {
+    if (p.D == 2) launch_kron4_sum_inst<T, 2, 4, 2, true>(ga, dx_sum, grid, st);
+    else launch_kron4_sum_inst<T, 2, 4, 3, true>(ga, dx_sum, grid, st);
+  } else if (p.MI == 2) {
+    if (p.NP) launch_kron4_sum_inst<T, 2, 2, 2, true>(ga, dx_sum, grid, st);
+    else launch_kron4_sum_inst<T, 2, 2, 2, false>(ga, dx_sum, grid, st);
+  } else {
+    if (p.NP) launch_kron4_sum_inst<T, 1, 2, 3, true>(ga, dx_sum, grid, st);
+    else launch_kron4_sum_inst<T, 1, 2, 3, false>(ga, dx_sum, grid, st);
+  }
+  return LYC_OK;
+}
+
 // returns the number of workgroups (= number of dw1 partials when ka.dw1_ws is set)
 template <typename T>
 long launch_kron3(const KronArgs& ka, hipStream_t st) {
@@ -746,8 +789,11 @@ int lyc_lokr_linear_bwd_planes(const void* g, const void* x, const float* w1, co
 // ---- sibling projections in one launch (round 4) -----------------------------------------------------------------------
 extern "C++" {
 namespace {
-int lokr_linear_group(const LycLokrLinearGroupItem* items, int n, int a, int b, int c, int d, int dtype, void* stream, bool backward) {
-  const char* who = backward ? "lokr_linear_bwd_group" : "lokr_linear_fwd_group";
+int lokr_linear_group(const LycLokrLinearGroupItem* items, int n, int a, int b, int c, int d, int dtype, void* stream, bool backward,
+                      void* dx_sum = nullptr) {
+  const char* who = dx_sum ? "lokr_linear_bwd_group_sum" : (backward ? "lokr_linear_bwd_group" : "lokr_linear_fwd_group");
+  if (dx_sum && (n < 1 || n > K4_GROUP_MAX)) return fail(LYC_ERR_UNSUPPORTED, "%s: 1 .. %d problems", who, K4_GROUP_MAX);
+  if (dx_sum && (reinterpret_cast<uintptr_t>(dx_sum) & 15u)) return fail(LYC_ERR_ARG, "%s: dx_sum must be 16-byte aligned", who);
   if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "%s: bad item list", who);
   if (n == 0) return LYC_OK;
   const int dt = dtype & 0xff;
@@ -755,7 +801,9 @@ int lokr_linear_group(const LycLokrLinearGroupItem* items, int n, int a, int b, 
   std::vector<KronArgs> kas((size_t)n);
   for (int k = 0; k < n; ++k) {
     const LycLokrLinearGroupItem& it = items[k];
-    if (!it.in || !it.w1 || !it.planes || !it.out) return fail(LYC_ERR_ARG, "%s: item %d: null pointer", who, k);
+    if (!it.in || !it.w1 || !it.planes || (!it.out && !dx_sum)) return fail(LYC_ERR_ARG, "%s: item %d: null pointer", who, k);
+    if (dx_sum && (it.M != items[0].M || !it.aux || !it.ws))
+      return fail(LYC_ERR_ARG, "%s: item %d: the problems of a sum share M and all carry x + their scratch (the w1 partials)", who, k);
     if (int rc = check_kron_dims(it.M, a, b, c, d)) return rc;
     if (it.M < 1 || !lokr_planes_usable(it.in, it.M, a, b, c, d, dtype))
       return fail(LYC_ERR_UNSUPPORTED, "%s: item %d is not on the packed-plane fast path (lyc_lokr_linear_planes_ok)", who, k);
@@ -763,7 +811,7 @@ int lokr_linear_group(const LycLokrLinearGroupItem* items, int n, int a, int b, 
       return fail(LYC_ERR_ARG, "%s: item %d: every item of a group takes the same operands (base / x + ws: all or none)", who, k);
     KronArgs& ka = kas[(size_t)k];
     ka = KronArgs{};
-    ka.x = it.in; ka.y = it.out; ka.w1 = it.w1; ka.w2p = it.planes; ka.alpha = it.alpha; ka.M = it.M;
+    ka.x = it.in; ka.y = dx_sum ? dx_sum : it.out; ka.w1 = it.w1; ka.w2p = it.planes; ka.alpha = it.alpha; ka.M = it.M;
     if (!backward) {
       ka.base = it.aux;
       ka.Gin = b; ka.K = d; ka.Gout = a; ka.N = c; ka.s1o = b; ka.s1i = 1; ka.s2n = d; ka.s2k = 1;
@@ -774,6 +822,11 @@ int lokr_linear_group(const LycLokrLinearGroupItem* items, int n, int a, int b, 
     }
     const bool ok = dt == LYC_BF16 ? kron4_ok<__bf16>(ka) : kron4_ok<_Float16>(ka);
     if (!ok) return fail(LYC_ERR_UNSUPPORTED, "%s: item %d: 16-byte aligned operands and sizes below 2 GiB are required", who, k);
+  }
+  if (dx_sum) {
+    if (dt == LYC_BF16) launch_kron4_sum<__bf16>(kas.data(), n, dx_sum, (hipStream_t)stream);
+    else launch_kron4_sum<_Float16>(kas.data(), n, dx_sum, (hipStream_t)stream);
+    return check_launch(who);
   }
   for (int lo = 0; lo < n; lo += K4_GROUP_MAX) {
     const int cnt = std::min(K4_GROUP_MAX, n - lo);
@@ -791,6 +844,11 @@ int lyc_lokr_linear_fwd_group(const LycLokrLinearGroupItem* items, int n, int a,
 }
 int lyc_lokr_linear_bwd_group(const LycLokrLinearGroupItem* items, int n, int a, int b, int c, int d, int dtype, void* stream) {
   return lokr_linear_group(items, n, a, b, c, d, dtype, stream, true);
+}
+int lyc_lokr_linear_bwd_group_sum(const LycLokrLinearGroupItem* items, int n, int a, int b, int c, int d, void* dx_sum, int dtype,
+                                  void* stream) {
+  if (!dx_sum) return fail(LYC_ERR_ARG, "lokr_linear_bwd_group_sum: null dx_sum");
+  return lokr_linear_group(items, n, a, b, c, d, dtype, stream, true, dx_sum);
 }
 
 int lyc_sum_rows(const void* const* src, int n, void* dst, int64_t numel, int dtype, void* stream) {

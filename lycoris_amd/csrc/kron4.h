@@ -123,12 +123,34 @@ __device__ __forceinline__ void k4_load_aux(u32x2 (&auxv)[MI][NI], const __amdgp
   }
 }
 
+// The stores of one 16 MI x 16 NI tile of T values (`ov[mi][ni]` = the 4 values lane (li, g) holds of MFMA tile ni): 16-byte stores over
+// paired column tiles (NP), 8-byte stores otherwise; out-of-range rows / columns are dropped by the descriptor.
+template <int MI, int NI, bool NP>
+__device__ __forceinline__ void k4_store_row(const u32x2 (&ov)[NI], unsigned rof, const __amdgpu_buffer_rsrc_t& rsy, int nt0, int N, int g) {
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    if (NP && k4_paired<NI>(ni)) {
+      if (ni & 1) continue;
+      const int gn = (nt0 + ni) * 16 + 8 * g;  // N % (16 NI) == 0: all in or all out
+      const unsigned off = gn < N ? rof + (unsigned)gn * 2u : K4_OOB;  // out-of-bounds stores are dropped
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{ov[ni][0], ov[ni][1], ov[ni + 1][0], ov[ni + 1][1]}, rsy, (int)off, 0, 0);
+    } else {
+      const int gn = (nt0 + ni) * 16 + 4 * g;
+      const unsigned off = gn < N ? rof + (unsigned)gn * 2u : K4_OOB;
+      __builtin_amdgcn_raw_buffer_store_b64(ov[ni], rsy, (int)off, 0, 0);
+    }
+  }
+}
+
 // Register epilogue of one 16 MI x 16 NI tile (kron3.h): stage 2 on the matrix cores, fused `base + delta`, dW1 contribution, stores.
 // ABL (benchmarks only): bit 1 = no stage-2 matrix work, bit 2 = no stores.
-template <typename T, int MI, int NI, int EPI, bool NP, int ABL>
+// ACC (round 5, kron4_sum_kernel): nothing is stored; alpha * (stage-2 result) is ADDED to `ysum` in fp32 -- the caller runs several
+// problems through one workgroup and stores their sum once.
+template <typename T, int MI, int NI, int EPI, bool NP, int ABL, bool ACC = false>
 __device__ __forceinline__ void k4_epilogue(f32x4 (&acc)[MI][NI], const typename Mma16<T>::frag& a2h, const typename Mma16<T>::frag& a2l,
                                             const typename Mma16<T>::frag& ident, const u32x2 (&auxv)[MI][NI], const unsigned (&rofs)[MI],
-                                            const __amdgpu_buffer_rsrc_t& rsy, int nt0, int N, int g, float alpha, f32x4& cdw) {
+                                            const __amdgpu_buffer_rsrc_t& rsy, int nt0, int N, int g, float alpha, f32x4& cdw,
+                                            f32x4 (*ysum)[NI] = nullptr) {
   using F4 = typename Mma16<T>::frag;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
@@ -154,10 +176,15 @@ __device__ __forceinline__ void k4_epilogue(f32x4 (&acc)[MI][NI], const typename
 #pragma unroll
         for (int e = 0; e < 4; ++e) bb[e] = TT<T>::to_f(bt[e]);
       }
-      T o[4];
+      if constexpr (ACC) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = TT<T>::from_f(alpha * yv[e] + bb[e]);
-      ov[ni] = *reinterpret_cast<u32x2*>(o);
+        for (int e = 0; e < 4; ++e) ysum[mi][ni][e] += alpha * yv[e];
+      } else {
+        T o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = TT<T>::from_f(alpha * yv[e] + bb[e]);
+        ov[ni] = *reinterpret_cast<u32x2*>(o);
+      }
       if constexpr (EPI == 2) {
         // S1 (hi, lo) transposed through the matrix core: lane (li = row, 4g+e = tile column) -- exact, the values are T
         const f32x4 th = Mma16<T>::mma(sh, ident, zero4());
@@ -176,19 +203,7 @@ __device__ __forceinline__ void k4_epilogue(f32x4 (&acc)[MI][NI], const typename
     if constexpr ((ABL & 2) != 0) {
       if (alpha != 123.f) continue;
     }
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      if (NP && k4_paired<NI>(ni)) {
-        if (ni & 1) continue;
-        const int gn = (nt0 + ni) * 16 + 8 * g;  // N % (16 NI) == 0: all in or all out
-        const unsigned off = gn < N ? rofs[mi] + (unsigned)gn * 2u : K4_OOB;  // out-of-bounds stores are dropped
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{ov[ni][0], ov[ni][1], ov[ni + 1][0], ov[ni + 1][1]}, rsy, (int)off, 0, 0);
-      } else {
-        const int gn = (nt0 + ni) * 16 + 4 * g;
-        const unsigned off = gn < N ? rofs[mi] + (unsigned)gn * 2u : K4_OOB;
-        __builtin_amdgcn_raw_buffer_store_b64(ov[ni], rsy, (int)off, 0, 0);
-      }
-    }
+    if constexpr (!ACC) k4_store_row<MI, NI, NP>(ov, rofs[mi], rsy, nt0, N, g);
   }
 }
 
@@ -240,8 +255,9 @@ __device__ __forceinline__ void k4_dw1_partial(const Kron4Args& a, float* red, c
 // NP : paired column tiles (16-byte stores, above).  ABL != 0: ablation builds of benchmarks/k4bench.cpp (results are garbage):
 //      1 = no stage-2 matrix work, 2 = no stores, 4 = no x DMA, 8 = no plane DMA, 16 = no stage-1 matrix work.
 // (bx, by) of (nbx, nby): the workgroup's row / column tile within ITS problem (a launch may carry several problems)
-template <typename T, int MI, int NI, int D, int EPI, bool NP = false, int ABL = 0>
-__device__ __forceinline__ void kron4_body(const Kron4Args& a, const int bx, const int by, const int nbx, const int nby) {
+template <typename T, int MI, int NI, int D, int EPI, bool NP = false, int ABL = 0, bool ACC = false>
+__device__ __forceinline__ void kron4_body(const Kron4Args& a, const int bx, const int by, const int nbx, const int nby,
+                                           f32x4 (*ysum)[NI] = nullptr) {
   extern __shared__ __attribute__((aligned(1024))) char k4_smem[];
   using F8 = typename TT<T>::frag;
   using F4 = typename Mma16<T>::frag;
@@ -398,7 +414,7 @@ __device__ __forceinline__ void kron4_body(const Kron4Args& a, const int bx, con
   if constexpr (EPI == 2) ident = k4_identity<T>(li, g);
   const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.y_bytes, K4_RSRC_FLAGS);
   f32x4 cdw = zero4();
-  k4_epilogue<T, MI, NI, EPI, NP, ABL>(acc, a2h, a2l, ident, auxv, rofs, rsy, nt0, N, g, a.alpha, cdw);
+  k4_epilogue<T, MI, NI, EPI, NP, ABL, ACC>(acc, a2h, a2l, ident, auxv, rofs, rsy, nt0, N, g, a.alpha, cdw, ysum);
   LYC_STAMP(5);
   LYC_TRACE_FLUSH();
   // (the trash slot: every DMA of this workgroup has landed -- the last k step waited vmcnt(0) in every wave, of ITS OWN operations;
@@ -426,6 +442,44 @@ __global__ __launch_bounds__(NTHREADS, 2) void kron4_group_kernel(Kron4GroupArgs
   if ((int)blockIdx.x >= ga.nbx[z]) return;
   const Kron4Args a = ga.p[z];
   kron4_body<T, MI, NI, D, EPI, NP, 0>(a, (int)blockIdx.x, (int)blockIdx.y, ga.nbx[z], (int)gridDim.y);
+}
+
+// The gradient of a tensor that n sibling projections read (round 5): dx = sum_i dx_i.  ONE workgroup per (row tile, column tile)
+// runs the n problems one after the other -- each with its own operand ring, stage 1, stage 2 and dW1 partials, exactly as
+// kron4_body<EPI 2> does -- adds the stage-2 results in fp32 registers and stores the sum ONCE: no dx_i ever reaches HBM, and the
+// separate summation pass (lyc_sum_rows: 4.7 us per set, 140 sets per SDXL step) is gone.  The sum is rounded once (n separate
+// nodes: n roundings + n - 1 more in autograd's accumulation).  All problems share rows_total, K, N, G.
+template <typename T, int MI, int NI, int D, bool NP = false>
+__global__ __launch_bounds__(NTHREADS, 2) void kron4_sum_kernel(Kron4GroupArgs ga, void* dx_sum) {
+  const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+  f32x4 ysum[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) ysum[mi][ni] = zero4();
+  for (int z = 0; z < ga.n; ++z) {
+    kron4_body<T, MI, NI, D, 2, NP, 0, true>(ga.p[z], bx, by, (int)gridDim.x, (int)gridDim.y, ysum);
+    __syncthreads();  // the dW1 reduction scratch and the ring slots are free before the next problem's first DMA lands in them
+  }
+  const Kron4Args& a = ga.p[0];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = a.N, nt0 = by * NI, row0 = bx * (64 * MI);
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(dx_sum, 0, (int)a.y_bytes, K4_RSRC_FLAGS);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int R = row0 + (wave * MI + mi) * 16 + li;
+    const unsigned rof = R < a.rows_total ? (unsigned)R * (unsigned)N * 2u : K4_OOB;
+    u32x2 ov[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      T o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = TT<T>::from_f(ysum[mi][ni][e]);
+      ov[ni] = *reinterpret_cast<u32x2*>(o);
+    }
+    k4_store_row<MI, NI, NP>(ov, rof, rsy, nt0, N, g);
+  }
 }
 
 }  // namespace lyc

@@ -1069,19 +1069,28 @@ struct LokrLinearGroupFn : public torch::autograd::Function<LokrLinearGroupFn> {
       TORCH_CHECK(nbytes > 0, "lycoris_amd: deferrable layer without a dw1 workspace");
       std::vector<Tensor> dxs(n), wss(n), f1s(n);
       std::vector<LycLokrLinearGroupItem> items(n);
+      // n <= 4 (every sibling set the modules form): the n results are summed in registers and stored once (kron4_sum_kernel)
+      const bool in_kernel_sum = nx && n <= 4;
+      Tensor dx_sum;
+      if (in_kernel_sum) dx_sum = at::empty(rows.sizes(), x.options());
       for (size_t i = 0; i < n; ++i) {
         f1s[i] = f32c(s[1 + 2 * i]);
-        dxs[i] = at::empty(rows.sizes(), x.options());
+        if (!in_kernel_sum) dxs[i] = at::empty(rows.sizes(), x.options());
         wss[i] = at::empty({nbytes}, x.options().dtype(at::kByte));
-        items[i] = LycLokrLinearGroupItem{cptr(g2[i]), cfp(f1s[i]), planes_bwd_ptr(pl[i], c, d, 1), cptr(rows), mptr(dxs[i]), mptr(wss[i]), M,
-                                          (float)alphas[i]};
+        items[i] = LycLokrLinearGroupItem{cptr(g2[i]), cfp(f1s[i]), planes_bwd_ptr(pl[i], c, d, 1), cptr(rows), in_kernel_sum ? nullptr : mptr(dxs[i]),
+                                          mptr(wss[i]), M, (float)alphas[i]};
       }
-      check_rc(lyc_lokr_linear_bwd_group(items.data(), (int)n, (int)a, (int)b, (int)c, (int)d, code, stream_of(x)), "lyc_lokr_linear_bwd_group");
+      if (in_kernel_sum)
+        check_rc(lyc_lokr_linear_bwd_group_sum(items.data(), (int)n, (int)a, (int)b, (int)c, (int)d, mptr(dx_sum), code, stream_of(x)),
+                 "lyc_lokr_linear_bwd_group_sum");
+      else
+        check_rc(lyc_lokr_linear_bwd_group(items.data(), (int)n, (int)a, (int)b, (int)c, (int)d, code, stream_of(x)), "lyc_lokr_linear_bwd_group");
       for (size_t i = 0; i < n; ++i)
         park_deferred(DeferredLokr{g2[i], rows, f1s[i], s[1 + 2 * i], s[2 + 2 * i], t1[i].buf, t2[i].buf, wss[i], M, (int)a, (int)b, (int)c,
                                    (int)d, code, (float)alphas[i], stream_of(x), x.device().index()});
-      if (nx) {  // d(sum of the problems)/dx: the n results summed in ONE pass, fp32 accumulation, one rounding (autograd's
-        // accumulation for n separate nodes makes n - 1 passes with a rounding each); chunks of 4 sources
+      if (in_kernel_sum) {
+        out[0] = shaped_like(dx_sum, x);
+      } else if (nx) {  // more than 4 problems: the n results summed in ONE pass per 4 sources, fp32 accumulation (lyc_sum_rows)
         for (size_t lo = 1; lo < n; lo += 3) {
           const void* src[4] = {cptr(dxs[0]), nullptr, nullptr, nullptr};
           int cnt = 1;
