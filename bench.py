@@ -6,8 +6,11 @@ shapes: benchmarks/sdxl_shapes.py = 788 layers at 1024x1024, benchmarks/sd15_sha
 adapter forward (delta) and backward (dx per layer; the factor gradients of the Linear layers in grouped launches of 18-24
 layers each, accumulated straight into the flat gradient arena -- DESIGN.md 1) of every layer, the arena zero-fill, the data-parallel mean all-reduce of the adapter gradients (N > 1: RCCL, launched bucket by
 bucket between the backward segments so it overlaps the rest of the backward) and a fused AdamW update.  EVERY layer
-instance owns its activation buffers (x and the upstream gradient g): a step reads the ~6 GB a real step reads, from
-HBM, not from the 256 MB Infinity Cache.  The compute of a step is captured in hipGraphs and replayed.
+instance owns its upstream gradient g; the inputs x are laid out as in the UNet: to_q / to_k / to_v of a self-attention and to_k / to_v
+of a cross-attention read ONE tensor (round 5: such sibling sets of LoKr nn.Linear layers run as one grouped launch each, through the
+same op the modules' sibling sets call behind the reference API; --no-siblings = the round 1-4 layout), every other layer owns its x:
+a step reads the ~6 GB a real step reads, from HBM, not from the 256 MB Infinity Cache.  The compute of a step is captured in hipGraphs
+and replayed.  `python bench.py --gpus N` without a launcher around it starts its own N ranks (torch.distributed.run on 127.0.0.1).
 
     python bench.py --gpus N --steps K --warmup W [--algo lokr|locon|loha|ia3|mixed] [--model sdxl|sd15] [--dtype ..]
 
