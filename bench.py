@@ -322,7 +322,7 @@ def build_instances(args, dtype, dev):
 def _groupable(it):
     """a sibling set that goes out as ONE launch: LoKr on nn.Linear with full-matrix factors (ops.lokr_linear_group, the op the
     modules' sibling sets call -- lycoris_amd/modules/siblings.py)"""
-    return (SIBLINGS and it.sibs is not None and len(it.sibs) > 1 and it.algo == "lokr" and it.spec["kind"] == "linear" and len(it.params) == 2
+    return (SIBLINGS and it.sibs is not None and len(it.sibs) > 1 and it.algo == "lokr" and it.spec["kind"] == "linear" and len(it.params) in (2, 3)
             and it.x.dtype != torch.float32)
 
 
@@ -337,7 +337,11 @@ def forward_all(insts, with_base=False):
         grp = it.sibs
         if grp is not None and grp[0] is it and _groupable(it) and all(id(m) in present for m in grp):
             bases = [m.base_forward() for m in grp] if with_base else None
-            ys = it.ops.lokr_linear_group(it.x, [m.params[0] for m in grp], [m.params[1] for m in grp], [1.0] * len(grp), bases)
+            if len(it.params) == 2:
+                ys = it.ops.lokr_linear_group(it.x, [m.params[0] for m in grp], [m.params[1] for m in grp], [1.0] * len(grp), bases)
+            else:  # --rank: low-rank w2 = w2_a @ w2_b
+                ys = it.ops.lokr_linear_lr_group(it.x, [m.params[0] for m in grp], [m.params[1] for m in grp], [m.params[2] for m in grp],
+                                                 [1.0] * len(grp), bases)
             for m, y in zip(grp[1:], ys[1:]):
                 parked[id(m)] = y
             outs.append((ys[0], it))

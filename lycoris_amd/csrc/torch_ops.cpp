@@ -940,22 +940,29 @@ std::tuple<Tensor, Tensor, Tensor> lokr_linear_bwd_meta(const Tensor& g, const T
 // to_q / to_k / to_v of a self-attention block and to_k / to_v of a cross-attention read the same tensor; the reference calls one
 // LokrModule.forward per projection (modules/lokr.py:543-566).  `lokr_linear_group(x, factors, alphas, bases)` is those n forwards as
 // ONE dispatcher call, ONE forward launch (lyc_lokr_linear_fwd_group, with the fused `base + delta` epilogue when bases are given),
-// ONE autograd node with n outputs and ONE backward dx launch (lyc_lokr_linear_bwd_group) whose n results are summed into the
-// gradient of the shared input; the weight gradients are parked per problem exactly like a single layer's.  Results are
-// bit-identical to n lokr_linear calls (tests/test_gpu_lokr_group.py).  Anything not on the packed-plane fast path runs the
-// problems one by one through the single-layer functions -- same numbers, n launches.
-//   factors = [w1_0, w2_0, w1_1, w2_1, ...] (all [a, b] / [c, d] with equal dims), bases = [] or n tensors
-std::vector<Tensor> lokr_linear_group_fwd(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList bases) {
+// ONE autograd node with n outputs and ONE backward launch that stores the SUM of the n dx results (lyc_lokr_linear_bwd_group_sum);
+// the weight gradients are parked per problem exactly like a single layer's.  Forward results are bit-identical to n lokr_linear calls
+// (tests/test_gpu_siblings.py).  Anything not on the packed-plane fast path runs the problems one by one through the single-layer
+// functions -- same numbers, n launches.
+//   F = 2 (lokr_linear_group)   : factors = [w1_0, w2_0, w1_1, w2_1, ...]            full-matrix w2 [c, d]
+//   F = 3 (lokr_linear_lr_group): factors = [w1_0, w2a_0, w2b_0, w1_1, ...]          low-rank w2 = w2a [c, r] @ w2b [r, d] (lokr.py:131-136):
+//                                 planes packed from the pair, dW2 through the grouped chain rule, as lokr_linear_lr
+//   bases = [] or n tensors; all problems share (a, b, c, d)
+Tensor lokr_linear_lr_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2a, const Tensor& w2b, double alpha, const c10::optional<Tensor>& base);
+std::tuple<Tensor, Tensor, Tensor, Tensor> lokr_linear_lr_bwd_one(const Tensor& g, const Tensor& x, const Tensor& w1, const Tensor& w2a,
+                                                                  const Tensor& w2b, double alpha, bool nx, bool n1, bool na, bool nb2);
+
+std::vector<Tensor> lokr_group_fwd_impl(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList bases, const size_t F) {
   require_device(x, "input");
   const c10::DeviceGuard guard(x.device());
   const size_t n = alphas.size();
-  TORCH_CHECK(n >= 1 && factors.size() == 2 * n && (bases.empty() || bases.size() == n), "lokr_linear_group: n alphas, 2n factors, 0 or n bases");
-  const Tensor &w10 = factors[0], &w20 = factors[1];
-  TORCH_CHECK(w10.dim() == 2 && w20.dim() == 2, "lokr_linear_group: w1 [a, b], w2 [c, d]");
-  const int64_t a = w10.size(0), b = w10.size(1), c = w20.size(0), d = w20.size(1);
+  TORCH_CHECK(n >= 1 && factors.size() == F * n && (bases.empty() || bases.size() == n), "lokr_linear_group: n alphas, ", F, "n factors, 0 or n bases");
+  const Tensor& w10 = factors[0];
+  TORCH_CHECK(w10.dim() == 2 && factors[1].dim() == 2 && factors[F - 1].dim() == 2, "lokr_linear_group: 2-D factors");
+  const int64_t a = w10.size(0), b = w10.size(1), c = factors[1].size(0), d = factors[F - 1].size(1);
   for (size_t i = 0; i < n; ++i)
-    TORCH_CHECK(factors[2 * i].sizes() == w10.sizes() && factors[2 * i + 1].sizes() == w20.sizes(),
-                "lokr_linear_group: the problems of a group share (a, b, c, d)");
+    for (size_t j = 0; j < F; ++j)
+      TORCH_CHECK(factors[F * i + j].sizes() == factors[j].sizes(), "lokr_linear_group: the problems of a group share their factor shapes");
   TORCH_CHECK(x.size(-1) == b * d, "adapter expects ", b * d, " input features, got ", x.sizes());
   Tensor rows = rows_of(x, b * d);
   auto oshape = x.sizes().vec();
@@ -971,19 +978,21 @@ std::vector<Tensor> lokr_linear_group_fwd(const Tensor& x, at::TensorList factor
              (reinterpret_cast<uintptr_t>(cptr(bs)) & 15u) == 0;
       if (!fast) break;
     }
-    pls[i] = planes_for(factors[2 * i + 1], x.scalar_type(), stream_of(x), /*fwd_role=*/true);
+    pls[i] = F == 2 ? planes_for(factors[2 * i + 1], x.scalar_type(), stream_of(x), /*fwd_role=*/true)
+                    : planes_for_lr(factors[3 * i + 1], factors[3 * i + 2], x.scalar_type(), stream_of(x), 1, /*fwd_role=*/true);
     fast = pls[i].defined();
   }
   if (!fast) {  // one by one: the single-layer forward (which picks its own kernel); `base` added on this side when it cannot be fused
     for (size_t i = 0; i < n; ++i) {
       c10::optional<Tensor> bs = bases.empty() ? c10::nullopt : c10::optional<Tensor>(bases[i]);
-      ys[i] = lokr_linear_fwd(x, factors[2 * i], factors[2 * i + 1], alphas[i], bs);
+      ys[i] = F == 2 ? lokr_linear_fwd(x, factors[2 * i], factors[2 * i + 1], alphas[i], bs)
+                     : lokr_linear_lr_fwd(x, factors[3 * i], factors[3 * i + 1], factors[3 * i + 2], alphas[i], bs);
     }
     return ys;
   }
   std::vector<LycLokrLinearGroupItem> items(n);
   for (size_t i = 0; i < n; ++i) {
-    f1s[i] = f32c(factors[2 * i]);
+    f1s[i] = f32c(factors[F * i]);
     ys[i] = at::empty({M, a * c}, x.options());
     items[i] = LycLokrLinearGroupItem{cptr(rows), cfp(f1s[i]), cptr(pls[i]), bases.empty() ? nullptr : cptr(bases[i]), mptr(ys[i]), nullptr, M,
                                       (float)alphas[i]};
@@ -992,31 +1001,39 @@ std::vector<Tensor> lokr_linear_group_fwd(const Tensor& x, at::TensorList factor
   for (size_t i = 0; i < n; ++i) ys[i] = ys[i].view(oshape);
   return ys;
 }
+std::vector<Tensor> lokr_linear_group_fwd(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList bases) {
+  return lokr_group_fwd_impl(x, factors, alphas, bases, 2);
+}
+std::vector<Tensor> lokr_linear_lr_group_fwd(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList bases) {
+  return lokr_group_fwd_impl(x, factors, alphas, bases, 3);
+}
 
 struct LokrLinearGroupFn : public torch::autograd::Function<LokrLinearGroupFn> {
-  // vars = [x, w1_0, w2_0, ..., w1_{n-1}, w2_{n-1}, base_0 ... base_{n-1} (optional)]
-  static variable_list forward(AutogradContext* ctx, at::TensorList vars, std::vector<double> alphas) {
+  // vars = [x, F factors per problem ..., base_0 ... base_{n-1} (optional)]
+  static variable_list forward(AutogradContext* ctx, at::TensorList vars, std::vector<double> alphas, int64_t F_) {
     at::AutoDispatchBelowADInplaceOrView guard;
-    const size_t n = alphas.size();
-    const bool has_base = vars.size() == 1 + 3 * n;
-    TORCH_CHECK(vars.size() == 1 + 2 * n || has_base, "lokr_linear_group: bad argument list");
+    const size_t n = alphas.size(), F = (size_t)F_;
+    const bool has_base = vars.size() == 1 + (F + 1) * n;
+    TORCH_CHECK(vars.size() == 1 + F * n || has_base, "lokr_linear_group: bad argument list");
     const Tensor& x = vars[0];
-    at::TensorList factors = vars.slice(1, 2 * n);
-    at::TensorList bases = has_base ? vars.slice(1 + 2 * n, n) : at::TensorList();
+    at::TensorList factors = vars.slice(1, F * n);
+    at::TensorList bases = has_base ? vars.slice(1 + F * n, n) : at::TensorList();
     std::vector<Tensor> ys;
     if (eager_cuda(x)) {
-      ys = lokr_linear_group_fwd(x, factors, alphas, bases);
+      ys = lokr_group_fwd_impl(x, factors, alphas, bases, F);
     } else {
+      TORCH_CHECK(F == 2, "lycoris_amd::lokr_linear_lr_group is an eager op (trace the products through lokr_linear_group instead)");
       static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::lokr_linear_group", "")
                            .typed<std::vector<Tensor>(const Tensor&, at::TensorList, at::ArrayRef<double>, at::TensorList)>();
       ys = op.call(x, factors, alphas, bases);
     }
-    for (size_t i = 0; i < 2 * n; ++i) expect(vars[1 + i], x);
+    for (size_t i = 0; i < F * n; ++i) expect(vars[1 + i], x);
     ctx->saved_data["alphas"] = alphas;
     ctx->saved_data["has_base"] = has_base;
     ctx->saved_data["n"] = (int64_t)n;
-    // (saved by reference in saved_data where they are leaves: save_vars' identity rule, for up to 1 + 2n <= 9 tensors)
-    variable_list keep(vars.begin(), vars.begin() + 1 + 2 * n);
+    ctx->saved_data["F"] = F_;
+    // (saved by reference in saved_data where they are leaves: save_vars' identity rule, for up to 1 + 3 * 4 tensors)
+    variable_list keep(vars.begin(), vars.begin() + 1 + F * n);
     for (size_t i = 1; i < keep.size(); ++i)
       if (keep[i].defined() && keep[i].is_leaf() && keep[i].requires_grad()) ctx->saved_data["lyc_gleaf" + std::to_string(i)] = keep[i];
     ctx->save_for_backward(std::move(keep));
@@ -1031,19 +1048,20 @@ struct LokrLinearGroupFn : public torch::autograd::Function<LokrLinearGroupFn> {
       const Tensor& p = it->second.toTensor();
       if (p.defined() && s[i].defined() && !s[i].is_same(p) && s[i].sizes() == p.sizes()) s[i] = p;
     }
-    const size_t n = (size_t)ctx->saved_data["n"].toInt();
+    const size_t n = (size_t)ctx->saved_data["n"].toInt(), F = (size_t)ctx->saved_data["F"].toInt();
     const std::vector<double> alphas = ctx->saved_data["alphas"].toDoubleVector();
     const bool has_base = ctx->saved_data["has_base"].toBool();
     const Tensor& x = s[0];
     const bool nx = ctx->needs_input_grad(0);
-    variable_list out(1 + (has_base ? 3 : 2) * n);
+    variable_list out(1 + (F + (has_base ? 1 : 0)) * n);
     const c10::DeviceGuard guard(x.device());
-    const Tensor &w10 = s[1], &w20 = s[2];
-    const int64_t a = w10.size(0), b = w10.size(1), c = w20.size(0), d = w20.size(1);
+    const int64_t a = s[1].size(0), b = s[1].size(1), c = s[2].size(0), d = s[F].size(1);
     const int code = x.defined() && x.is_cuda() ? dtype_code(x.scalar_type()) : 0;
+    auto W1 = [&](size_t i) -> const Tensor& { return s[1 + F * i]; };
+    auto W2 = [&](size_t i, size_t j) -> const Tensor& { return s[2 + F * i + j]; };  // F = 2: j = 0 (w2); F = 3: j = 0 / 1 (w2a / w2b)
     // ---- the grouped fast path: every problem deferrable (fused accumulation into .grad, 16-bit planes), every grad defined -------
     bool fast = n >= 2 && g_defer.enabled && eager_cuda(x);
-    std::vector<GradTarget> t1(n), t2(n);
+    std::vector<GradTarget> t1(n), t2(n), t3(n);
     std::vector<Tensor> g2(n), pl(n);
     Tensor rows;
     if (fast) {
@@ -1051,15 +1069,24 @@ struct LokrLinearGroupFn : public torch::autograd::Function<LokrLinearGroupFn> {
       for (size_t i = 0; i < n && fast; ++i) {
         fast = grads[i].defined() && eager_cuda(grads[i]);
         if (!fast) break;
-        const Tensor &w1 = s[1 + 2 * i], &w2 = s[2 + 2 * i];
-        t1[i] = grad_target(w1, ctx->needs_input_grad(1 + 2 * i));
-        t2[i] = grad_target(w2, ctx->needs_input_grad(2 + 2 * i));
-        fast = t2[i].buf.defined() && !t2[i].hand_back && t1[i].buf.defined() && !t1[i].hand_back;
+        t1[i] = grad_target(W1(i), ctx->needs_input_grad(1 + F * i));
+        fast = t1[i].buf.defined() && !t1[i].hand_back;
+        if (!fast) break;
+        if (F == 2) {
+          t2[i] = grad_target(W2(i, 0), ctx->needs_input_grad(2 + 2 * i));
+          fast = t2[i].buf.defined() && !t2[i].hand_back;
+        } else {  // both halves of the product are wanted together (one dW2 scratch, one chain-rule item); fp32 contiguous leaves
+          const bool want = ctx->needs_input_grad(2 + 3 * i) && ctx->needs_input_grad(3 + 3 * i);
+          t2[i] = grad_target(W2(i, 0), want);
+          t3[i] = grad_target(W2(i, 1), want);
+          fast = want && t2[i].buf.defined() && !t2[i].hand_back && t3[i].buf.defined() && !t3[i].hand_back &&
+                 f32c(W2(i, 0)).is_same(W2(i, 0)) && f32c(W2(i, 1)).is_same(W2(i, 1));
+        }
         if (!fast) break;
         g2[i] = rows_of(grads[i], a * c);
         fast = lyc_lokr_wgrad_deferrable(cptr(g2[i]), cptr(rows), rows.size(0), (int)a, (int)b, (int)c, (int)d, code) != 0;
         if (!fast) break;
-        pl[i] = planes_for(w2, x.scalar_type(), stream_of(x));
+        pl[i] = F == 2 ? planes_for(W2(i, 0), x.scalar_type(), stream_of(x)) : planes_for_lr(W2(i, 0), W2(i, 1), x.scalar_type(), stream_of(x));
         fast = pl[i].defined();
       }
     }
@@ -1074,7 +1101,7 @@ struct LokrLinearGroupFn : public torch::autograd::Function<LokrLinearGroupFn> {
       Tensor dx_sum;
       if (in_kernel_sum) dx_sum = at::empty(rows.sizes(), x.options());
       for (size_t i = 0; i < n; ++i) {
-        f1s[i] = f32c(s[1 + 2 * i]);
+        f1s[i] = f32c(W1(i));
         if (!in_kernel_sum) dxs[i] = at::empty(rows.sizes(), x.options());
         wss[i] = at::empty({nbytes}, x.options().dtype(at::kByte));
         items[i] = LycLokrLinearGroupItem{cptr(g2[i]), cfp(f1s[i]), planes_bwd_ptr(pl[i], c, d, 1), cptr(rows), in_kernel_sum ? nullptr : mptr(dxs[i]),
@@ -1085,9 +1112,17 @@ struct LokrLinearGroupFn : public torch::autograd::Function<LokrLinearGroupFn> {
                  "lyc_lokr_linear_bwd_group_sum");
       else
         check_rc(lyc_lokr_linear_bwd_group(items.data(), (int)n, (int)a, (int)b, (int)c, (int)d, code, stream_of(x)), "lyc_lokr_linear_bwd_group");
-      for (size_t i = 0; i < n; ++i)
-        park_deferred(DeferredLokr{g2[i], rows, f1s[i], s[1 + 2 * i], s[2 + 2 * i], t1[i].buf, t2[i].buf, wss[i], M, (int)a, (int)b, (int)c,
-                                   (int)d, code, (float)alphas[i], stream_of(x), x.device().index()});
+      for (size_t i = 0; i < n; ++i) {
+        if (F == 2) {
+          park_deferred(DeferredLokr{g2[i], rows, f1s[i], W1(i), W2(i, 0), t1[i].buf, t2[i].buf, wss[i], M, (int)a, (int)b, (int)c,
+                                     (int)d, code, (float)alphas[i], stream_of(x), x.device().index()});
+        } else {
+          DeferredLokr item{g2[i], rows, f1s[i], W1(i), Tensor(), t1[i].buf, Tensor(), wss[i], M, (int)a, (int)b, (int)c, (int)d, code,
+                            (float)alphas[i], stream_of(x), x.device().index()};
+          item.w2a = W2(i, 0); item.w2b = W2(i, 1); item.d_w2a = t2[i].buf; item.d_w2b = t3[i].buf;
+          park_deferred(std::move(item));
+        }
+      }
       if (in_kernel_sum) {
         out[0] = shaped_like(dx_sum, x);
       } else if (nx) {  // more than 4 problems: the n results summed in ONE pass per 4 sources, fp32 accumulation (lyc_sum_rows)
@@ -1103,50 +1138,67 @@ struct LokrLinearGroupFn : public torch::autograd::Function<LokrLinearGroupFn> {
       Tensor dx_sum;
       for (size_t i = 0; i < n; ++i) {
         if (!grads[i].defined()) continue;
-        const Tensor &w1 = s[1 + 2 * i], &w2 = s[2 + 2 * i];
-        const bool n1 = ctx->needs_input_grad(1 + 2 * i), n2 = ctx->needs_input_grad(2 + 2 * i);
-        Tensor dx, d1, d2;
-        if (eager_cuda(grads[i]) && eager_cuda(x)) {
-          GradTarget u1 = grad_target(w1, n1), u2 = grad_target(w2, n2);
-          bool done = false;
-          if (g_defer.enabled && u2.buf.defined() && !u2.hand_back && !(u1.buf.defined() && u1.hand_back))
-            done = lokr_linear_bwd_deferred(grads[i], x, w1, w2, alphas[i], nx, u1.buf, u2.buf, dx);
-          if (!done) {
-            dx = lokr_linear_bwd_into(grads[i], x, w1, w2, alphas[i], nx, u1.buf, u2.buf);
-            d1 = finish_grad(w1, u1);
-            d2 = finish_grad(w2, u2);
-          }
+        Tensor dx;
+        if (F == 3) {
+          TORCH_CHECK(eager_cuda(grads[i]) && eager_cuda(x), "lycoris_amd::lokr_linear_lr_group is an eager op");
+          auto [rx, r1, ra, rb] = lokr_linear_lr_bwd_one(grads[i], x, W1(i), W2(i, 0), W2(i, 1), alphas[i], nx, ctx->needs_input_grad(1 + 3 * i),
+                                                         ctx->needs_input_grad(2 + 3 * i), ctx->needs_input_grad(3 + 3 * i));
+          dx = rx;
+          out[1 + 3 * i] = r1;
+          out[2 + 3 * i] = ra;
+          out[3 + 3 * i] = rb;
         } else {
-          static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_lokr_linear_backward", "")
-                               .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&,
-                                                                         double, bool, bool, bool)>();
-          auto [rx, r1, r2] = op.call(grads[i], x, w1, w2, alphas[i], nx, n1, n2);
-          if (nx) dx = rx;
-          if (n1) d1 = r1;
-          if (n2) d2 = r2;
+          const Tensor &w1 = W1(i), &w2 = W2(i, 0);
+          const bool n1 = ctx->needs_input_grad(1 + 2 * i), n2 = ctx->needs_input_grad(2 + 2 * i);
+          Tensor d1, d2;
+          if (eager_cuda(grads[i]) && eager_cuda(x)) {
+            GradTarget u1 = grad_target(w1, n1), u2 = grad_target(w2, n2);
+            bool done = false;
+            if (g_defer.enabled && u2.buf.defined() && !u2.hand_back && !(u1.buf.defined() && u1.hand_back))
+              done = lokr_linear_bwd_deferred(grads[i], x, w1, w2, alphas[i], nx, u1.buf, u2.buf, dx);
+            if (!done) {
+              dx = lokr_linear_bwd_into(grads[i], x, w1, w2, alphas[i], nx, u1.buf, u2.buf);
+              d1 = finish_grad(w1, u1);
+              d2 = finish_grad(w2, u2);
+            }
+          } else {
+            static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::_lokr_linear_backward", "")
+                                 .typed<std::tuple<Tensor, Tensor, Tensor>(const Tensor&, const Tensor&, const Tensor&, const Tensor&,
+                                                                           double, bool, bool, bool)>();
+            auto [rx, r1, r2] = op.call(grads[i], x, w1, w2, alphas[i], nx, n1, n2);
+            if (nx) dx = rx;
+            if (n1) d1 = r1;
+            if (n2) d2 = r2;
+          }
+          out[1 + 2 * i] = d1;
+          out[2 + 2 * i] = d2;
         }
-        out[1 + 2 * i] = d1;
-        out[2 + 2 * i] = d2;
         if (dx.defined()) dx_sum = dx_sum.defined() ? dx_sum + dx : dx;
       }
       if (nx) out[0] = dx_sum;
     }
     if (has_base)
       for (size_t i = 0; i < n; ++i)
-        if (ctx->needs_input_grad(1 + 2 * n + i)) out[1 + 2 * n + i] = grads[i];  // d(base + delta)/d base = 1
-    out.resize(out.size() + 2);  // `alphas` is one non-tensor input (surplus undefined entries are dropped by the engine)
+        if (ctx->needs_input_grad(1 + F * n + i)) out[1 + F * n + i] = grads[i];  // d(base + delta)/d base = 1
+    out.resize(out.size() + 3);  // `alphas` and `F` are non-tensor inputs (surplus undefined entries are dropped by the engine)
     return out;
   }
 };
 
-std::vector<Tensor> lokr_linear_group_autograd(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList bases) {
+std::vector<Tensor> lokr_group_autograd_impl(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList bases, int64_t F) {
   const GradAtApply ga_;
   variable_list vars;
   vars.reserve(1 + factors.size() + bases.size());
   vars.push_back(amp(x));
   for (const Tensor& t : factors) vars.push_back(t);
   for (const Tensor& t : bases) vars.push_back(t);
-  return LokrLinearGroupFn::apply(at::TensorList(vars), alphas.vec());  // (a TensorList: a std::vector<Tensor> argument is not seen as variables)
+  return LokrLinearGroupFn::apply(at::TensorList(vars), alphas.vec(), F);  // (a TensorList: a std::vector<Tensor> argument is not seen as variables)
+}
+std::vector<Tensor> lokr_linear_group_autograd(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList bases) {
+  return lokr_group_autograd_impl(x, factors, alphas, bases, 2);
+}
+std::vector<Tensor> lokr_linear_lr_group_autograd(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList bases) {
+  return lokr_group_autograd_impl(x, factors, alphas, bases, 3);
 }
 std::vector<Tensor> lokr_linear_group_meta(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList bases) {
   auto oshape = x.sym_sizes().vec();
@@ -1190,6 +1242,61 @@ Tensor lokr_linear_lr_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2a, 
   return y.view(oshape);
 }
 
+// the backward of ONE low-rank layer (dx now; the factor gradients parked for the grouped launches where they can be, else dW2 into a
+// scratch + the chain rule): shared by LokrLinearLrFn and the problem-by-problem path of the sibling-group node
+std::tuple<Tensor, Tensor, Tensor, Tensor> lokr_linear_lr_bwd_one(const Tensor& g, const Tensor& x, const Tensor& w1, const Tensor& w2a,
+                                                                  const Tensor& w2b, double alpha, bool nx, bool n1, bool na, bool nb2) {
+  const c10::DeviceGuard guard(x.device());
+  const int64_t a = w1.size(0), b = w1.size(1), c = w2a.size(0), d = w2b.size(1), r = w2a.size(1);
+  const int code = dtype_code(x.scalar_type());
+  Tensor rows = rows_of(x, b * d), g2 = rows_of(g, a * c), f1 = f32c(w1), fa = f32c(w2a), fb = f32c(w2b);
+  GradTarget t1 = grad_target(w1, n1);
+  const bool want_w2 = na || nb2;
+  GradTarget ta = grad_target(w2a, want_w2), tb = grad_target(w2b, want_w2);
+  const bool fast = lyc_lokr_linear_planes_ok(rows.size(0), (int)a, (int)b, (int)c, (int)d, code) &&
+                    (reinterpret_cast<uintptr_t>(cptr(g2)) & 15u) == 0;
+  Tensor pl = fast ? planes_for_lr(w2a, w2b, x.scalar_type(), stream_of(x)) : Tensor();
+  const bool want_dx = nx || t1.buf.defined();
+  Tensor dx, ws;
+  if (want_dx) dx = at::empty(rows.sizes(), x.options());
+  if (t1.buf.defined()) {
+    const int64_t nbytes = lyc_lokr_bwd_workspace_bytes(rows.size(0), (int)a, (int)b, (int)c, (int)d, code);
+    if (nbytes > 0) ws = at::empty({nbytes}, x.options().dtype(at::kByte));
+  }
+  // training configuration: every gradient goes straight into .grad -> dx now, dW1 / dW2 / chain in the grouped launches
+  const bool defer = g_defer.enabled && pl.defined() && want_w2 && !ta.hand_back && !tb.hand_back && !(t1.buf.defined() && t1.hand_back) &&
+                     fa.is_same(w2a) && fb.is_same(w2b) &&
+                     lyc_lokr_wgrad_deferrable(cptr(g2), cptr(rows), rows.size(0), (int)a, (int)b, (int)c, (int)d, code) &&
+                     (!t1.buf.defined() || ws.defined());
+  if (defer) {
+    if (want_dx)
+      check_rc(lyc_lokr_linear_bwd_planes(cptr(g2), cptr(rows), cfp(f1), planes_bwd_ptr(pl, c, d, 1), mptr(dx), mfp(t1.buf), nullptr,
+                                          mptr(ws), rows.size(0), (int)a, (int)b, (int)c, (int)d, (float)alpha, code | LYC_DEFER_WGRAD,
+                                          stream_of(x)), "lyc_lokr_linear_bwd_planes(dx)");
+    DeferredLokr item{g2, rows, f1, w1, Tensor(), t1.buf, Tensor(), ws, rows.size(0), (int)a, (int)b, (int)c, (int)d, code, (float)alpha,
+                      stream_of(x), x.device().index()};
+    item.w2a = w2a; item.w2b = w2b; item.d_w2a = ta.buf; item.d_w2b = tb.buf;
+    park_deferred(std::move(item));
+    return {nx ? shaped_like(dx, x) : Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+  // immediate: dW2 into a scratch, then the chain rule (one item)
+  Tensor dw2 = want_w2 ? at::zeros({c, d}, x.options().dtype(at::kFloat)) : Tensor();
+  if (pl.defined()) {
+    check_rc(lyc_lokr_linear_bwd_planes(cptr(g2), cptr(rows), cfp(f1), planes_bwd_ptr(pl, c, d, 1), mptr(dx), mfp(t1.buf), mfp(dw2),
+                                        mptr(ws), rows.size(0), (int)a, (int)b, (int)c, (int)d, (float)alpha, code, stream_of(x)),
+             "lyc_lokr_linear_bwd_planes");
+  } else {
+    Tensor f2 = at::mm(fa, fb);
+    check_rc(lyc_lokr_linear_bwd(cptr(g2), cptr(rows), cfp(f1), cfp(f2), mptr(dx), mfp(t1.buf), mfp(dw2), mptr(ws), rows.size(0), (int)a,
+                                 (int)b, (int)c, (int)d, (float)alpha, code, stream_of(x)), "lyc_lokr_linear_bwd");
+  }
+  if (want_w2) {
+    LycLokrLrChainItem ci{cfp(dw2), cfp(fa), cfp(fb), mfp(ta.buf), mfp(tb.buf), (int)c, (int)d, (int)r};
+    check_rc(lyc_lokr_lr_chain_group(&ci, 1, stream_of(x)), "lyc_lokr_lr_chain_group");
+  }
+  return {nx ? shaped_like(dx, x) : Tensor(), finish_grad(w1, t1), finish_grad(w2a, ta), finish_grad(w2b, tb)};
+}
+
 struct LokrLinearLrFn : public torch::autograd::Function<LokrLinearLrFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w1, const Tensor& w2a, const Tensor& w2b, double alpha,
                         const c10::optional<Tensor>& base) {
@@ -1211,56 +1318,8 @@ struct LokrLinearLrFn : public torch::autograd::Function<LokrLinearLrFn> {
     const double alpha = ctx->saved_data["alpha"].toDouble();
     const bool nx = ctx->needs_input_grad(0), n1 = ctx->needs_input_grad(1), na = ctx->needs_input_grad(2), nb2 = ctx->needs_input_grad(3);
     const bool nbase = ctx->saved_data["has_base"].toBool() && ctx->needs_input_grad(4);
-    const Tensor& g = grads[0];
-    const c10::DeviceGuard guard(x.device());
-    const int64_t a = w1.size(0), b = w1.size(1), c = w2a.size(0), d = w2b.size(1), r = w2a.size(1);
-    const int code = dtype_code(x.scalar_type());
-    Tensor rows = rows_of(x, b * d), g2 = rows_of(g, a * c), f1 = f32c(w1), fa = f32c(w2a), fb = f32c(w2b);
-    GradTarget t1 = grad_target(w1, n1);
-    const bool want_w2 = na || nb2;
-    GradTarget ta = grad_target(w2a, want_w2), tb = grad_target(w2b, want_w2);
-    const bool fast = lyc_lokr_linear_planes_ok(rows.size(0), (int)a, (int)b, (int)c, (int)d, code) &&
-                      (reinterpret_cast<uintptr_t>(cptr(g2)) & 15u) == 0;
-    Tensor pl = fast ? planes_for_lr(w2a, w2b, x.scalar_type(), stream_of(x)) : Tensor();
-    const bool want_dx = nx || t1.buf.defined();
-    Tensor dx, ws;
-    if (want_dx) dx = at::empty(rows.sizes(), x.options());
-    if (t1.buf.defined()) {
-      const int64_t nbytes = lyc_lokr_bwd_workspace_bytes(rows.size(0), (int)a, (int)b, (int)c, (int)d, code);
-      if (nbytes > 0) ws = at::empty({nbytes}, x.options().dtype(at::kByte));
-    }
-    // training configuration: every gradient goes straight into .grad -> dx now, dW1 / dW2 / chain in the grouped launches
-    const bool defer = g_defer.enabled && pl.defined() && want_w2 && !ta.hand_back && !tb.hand_back && !(t1.buf.defined() && t1.hand_back) &&
-                       fa.is_same(w2a) && fb.is_same(w2b) &&
-                       lyc_lokr_wgrad_deferrable(cptr(g2), cptr(rows), rows.size(0), (int)a, (int)b, (int)c, (int)d, code) &&
-                       (!t1.buf.defined() || ws.defined());
-    if (defer) {
-      if (want_dx)
-        check_rc(lyc_lokr_linear_bwd_planes(cptr(g2), cptr(rows), cfp(f1), planes_bwd_ptr(pl, c, d, 1), mptr(dx), mfp(t1.buf), nullptr,
-                                            mptr(ws), rows.size(0), (int)a, (int)b, (int)c, (int)d, (float)alpha, code | LYC_DEFER_WGRAD,
-                                            stream_of(x)), "lyc_lokr_linear_bwd_planes(dx)");
-      DeferredLokr item{g2, rows, f1, w1, Tensor(), t1.buf, Tensor(), ws, rows.size(0), (int)a, (int)b, (int)c, (int)d, code, (float)alpha,
-                        stream_of(x), x.device().index()};
-      item.w2a = w2a; item.w2b = w2b; item.d_w2a = ta.buf; item.d_w2b = tb.buf;
-      park_deferred(std::move(item));
-      return {nx ? shaped_like(dx, x) : Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), nbase ? g : Tensor()};
-    }
-    // immediate: dW2 into a scratch, then the chain rule (one item)
-    Tensor dw2 = want_w2 ? at::zeros({c, d}, x.options().dtype(at::kFloat)) : Tensor();
-    if (pl.defined()) {
-      check_rc(lyc_lokr_linear_bwd_planes(cptr(g2), cptr(rows), cfp(f1), planes_bwd_ptr(pl, c, d, 1), mptr(dx), mfp(t1.buf), mfp(dw2),
-                                          mptr(ws), rows.size(0), (int)a, (int)b, (int)c, (int)d, (float)alpha, code, stream_of(x)),
-               "lyc_lokr_linear_bwd_planes");
-    } else {
-      Tensor f2 = at::mm(fa, fb);
-      check_rc(lyc_lokr_linear_bwd(cptr(g2), cptr(rows), cfp(f1), cfp(f2), mptr(dx), mfp(t1.buf), mfp(dw2), mptr(ws), rows.size(0), (int)a,
-                                   (int)b, (int)c, (int)d, (float)alpha, code, stream_of(x)), "lyc_lokr_linear_bwd");
-    }
-    if (want_w2) {
-      LycLokrLrChainItem ci{cfp(dw2), cfp(fa), cfp(fb), mfp(ta.buf), mfp(tb.buf), (int)c, (int)d, (int)r};
-      check_rc(lyc_lokr_lr_chain_group(&ci, 1, stream_of(x)), "lyc_lokr_lr_chain_group");
-    }
-    return {nx ? shaped_like(dx, x) : Tensor(), finish_grad(w1, t1), finish_grad(w2a, ta), finish_grad(w2b, tb), Tensor(), nbase ? g : Tensor()};
+    auto [dx, d1, da, db] = lokr_linear_lr_bwd_one(grads[0], x, w1, w2a, w2b, alpha, nx, n1, na, nb2);
+    return {dx, d1, da, db, Tensor(), nbase ? grads[0] : Tensor()};
   }
 };
 // FakeTensor / meta / functionalised inputs (torch.compile tracing): the product is formed with differentiable ATen ops and the
@@ -2564,6 +2623,7 @@ TORCH_LIBRARY(lycoris_amd, m) {
   // public ops: what lycoris_amd.ops / the modules call (autograd-aware)
   m.def("lokr_linear(Tensor x, Tensor w1, Tensor w2, float alpha, Tensor? base=None) -> Tensor");
   m.def("lokr_linear_group(Tensor x, Tensor[] factors, float[] alphas, Tensor[] bases) -> Tensor[]");
+  m.def("lokr_linear_lr_group(Tensor x, Tensor[] factors, float[] alphas, Tensor[] bases) -> Tensor[]");
   m.def("lokr_linear_lr(Tensor x, Tensor w1, Tensor w2a, Tensor w2b, float alpha, Tensor? base=None) -> Tensor");
   m.def("lokr_linear_lr2(Tensor x, Tensor w1a, Tensor w1b, Tensor w2a, Tensor w2b, float alpha, Tensor? base=None) -> Tensor");
   m.def("locon_linear(Tensor x, Tensor down, Tensor up, float alpha) -> Tensor");
@@ -2601,6 +2661,7 @@ TORCH_LIBRARY(lycoris_amd, m) {
 TORCH_LIBRARY_IMPL(lycoris_amd, CUDA, m) {
   m.impl("lokr_linear", lokr_linear_fwd);
   m.impl("lokr_linear_group", lokr_linear_group_fwd);
+  m.impl("lokr_linear_lr_group", lokr_linear_lr_group_fwd);
   m.impl("lokr_linear_lr", lokr_linear_lr_fwd);
   m.impl("lokr_linear_lr2", lokr_linear_lr2_cuda);
   m.impl("_lokr_linear_backward", lokr_linear_bwd);
@@ -2626,6 +2687,7 @@ TORCH_LIBRARY_IMPL(lycoris_amd, CUDA, m) {
 TORCH_LIBRARY_IMPL(lycoris_amd, Meta, m) {
   m.impl("lokr_linear", lokr_linear_meta);
   m.impl("lokr_linear_group", lokr_linear_group_meta);
+  m.impl("lokr_linear_lr_group", lokr_linear_group_meta);
   m.impl("lokr_linear_lr", lokr_linear_lr_meta);
   m.impl("lokr_linear_lr2", lokr_linear_lr2_meta);
   m.impl("_lokr_linear_backward", lokr_linear_bwd_meta);
@@ -2651,6 +2713,7 @@ TORCH_LIBRARY_IMPL(lycoris_amd, Meta, m) {
 TORCH_LIBRARY_IMPL(lycoris_amd, Autograd, m) {
   m.impl("lokr_linear", lokr_linear_autograd);
   m.impl("lokr_linear_group", lokr_linear_group_autograd);
+  m.impl("lokr_linear_lr_group", lokr_linear_lr_group_autograd);
   m.impl("lokr_linear_lr", lokr_linear_lr_autograd);
   m.impl("lokr_linear_lr2", lokr_linear_lr2_autograd);
   m.impl("locon_linear", locon_linear_autograd);

@@ -17,7 +17,8 @@ calls ``layer(x)`` three times.  This file makes the modules find their siblings
   left the plain path (dropout variants, DoRA, restore()), a member that died.  The per-layer path then runs as if nothing happened,
   so the numbers can never depend on the grouping -- only the launch count does.
 
-Scope: LoKr on nn.Linear with full-matrix factors (the headline configuration).  ``enable(False)`` switches the mechanism off.
+Scope: LoKr on nn.Linear with a full `lokr_w1` and either a full-matrix `lokr_w2` (the headline configuration) or the low-rank pair
+`lokr_w2_a @ lokr_w2_b` (BASELINE configs[3]); a set holds one kind only.  ``enable(False)`` switches the mechanism off.
 """
 from __future__ import annotations
 
@@ -69,7 +70,8 @@ class SiblingSet:
 
 
 def _key(mod, x):
-    return (tuple(mod.lokr_w1.shape), tuple(mod.lokr_w2.shape), x.dtype, x.device, tuple(x.shape))
+    w2 = (tuple(mod.lokr_w2.shape),) if mod.use_w2 else (tuple(mod.lokr_w2_a.shape), tuple(mod.lokr_w2_b.shape))
+    return (tuple(mod.lokr_w1.shape), w2, x.dtype, x.device, tuple(x.shape))
 
 
 def forget(mod):
@@ -106,8 +108,11 @@ def forward(mod, x) -> Optional[torch.Tensor]:
                 return None
             st.pending.clear()  # (results nobody fetched: a sibling skipped its call in the last pass)
             bases = [m.org_forward(x) for m in members]
-            ys = ops.lokr_linear_group(x, [m._gate(m.lokr_w1) for m in members], [m.lokr_w2 for m in members],
-                                       [m.scale * m.multiplier for m in members], bases)
+            w1s, alphas = [m._gate(m.lokr_w1) for m in members], [m.scale * m.multiplier for m in members]
+            if mod.use_w2:
+                ys = ops.lokr_linear_group(x, w1s, [m.lokr_w2 for m in members], alphas, bases)
+            else:  # low-rank second factor: the pairs go to the kernels as they are (planes from the factors, grouped chain rule)
+                ys = ops.lokr_linear_lr_group(x, w1s, [m.lokr_w2_a for m in members], [m.lokr_w2_b for m in members], alphas, bases)
             ver = x._version
             for m, y in zip(members[1:], ys[1:]):
                 st.pending[id(m)] = (x, ver, y)

@@ -57,7 +57,7 @@ def _cpp() -> bool:
         except ImportError:  # very old torch: the end-of-backward mark alone
             pass
         ns = torch.ops.lycoris_amd  # the resolved overloads: skips the packet's per-call overload resolution (~1 us per call)
-        for name in ("lokr_linear", "lokr_linear_group", "lokr_linear_lr", "lokr_linear_lr2", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d", "lokr_conv2d_lr"):
+        for name in ("lokr_linear", "lokr_linear_group", "lokr_linear_lr_group", "lokr_linear_lr", "lokr_linear_lr2", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d", "lokr_conv2d_lr"):
             _OPS[name] = getattr(ns, name).default
     return True
 
@@ -689,6 +689,21 @@ def lokr_linear_group(x, w1s, w2s, alphas, bases=None):
         return [b + y for b, y in zip(bases, ys)]
     factors = [t for pair in zip(w1s, w2s) for t in pair]
     return list(_OPS["lokr_linear_group"](x, factors, [float(a) for a in alphas], [] if bases is None else list(bases)))
+
+
+def lokr_linear_lr_group(x, w1s, w2as, w2bs, alphas, bases=None):
+    """lokr_linear_group for the low-rank second factor w2 = w2a @ w2b (reference modules/lokr.py:131-136): the planes of every problem
+    are packed from its pair, the weight gradients go through the grouped chain rule -- as lokr_linear_lr, n projections per call."""
+    n = len(w1s)
+    if len(w2as) != n or len(w2bs) != n or len(alphas) != n or (bases is not None and len(bases) != n):
+        raise ValueError("lokr_linear_lr_group: w1s, w2as, w2bs, alphas (and bases) must have one entry per problem")
+    if n == 1 or not x.is_cuda or not _cpp() or torch.compiler.is_compiling():
+        return [lokr_linear_lr(x, w1s[i], w2as[i], w2bs[i], alphas[i], None if bases is None else bases[i]) for i in range(n)]
+    if bases is not None and not all(lokr_linear_fusable(x, w1s[i], _Shape2(w2as[i].shape[0], w2bs[i].shape[1]), bases[i]) for i in range(n)):
+        ys = lokr_linear_lr_group(x, w1s, w2as, w2bs, alphas)
+        return [b + y for b, y in zip(bases, ys)]
+    factors = [t for tri in zip(w1s, w2as, w2bs) for t in tri]
+    return list(_OPS["lokr_linear_lr_group"](x, factors, [float(a) for a in alphas], [] if bases is None else list(bases)))
 
 
 def lokr_linear_lr(x, w1, w2a, w2b, alpha=1.0, base=None):

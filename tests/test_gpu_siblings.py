@@ -144,6 +144,61 @@ def test_group_op_in_the_training_configuration_accumulates_into_grad_and_report
     check(f"sibling_group_op_training_configuration[{case},{dtype}]", errs, bounds)
 
 
+@pytest.mark.parametrize("training", [False, True], ids=["autograd", "training_configuration"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", [(1024, 8, 160, 160, 3, 16), (77, 8, 160, 256, 2, 16), (130, 4, 24, 40, 4, 4)],
+                         ids=lambda c: f"M{c[0]}_a{c[1]}_c{c[2]}_d{c[3]}_n{c[4]}_r{c[5]}")
+def test_low_rank_group_op_matches_the_oracle(case, dtype, training):
+    """lokr_linear_lr_group: the sibling set with w2 = w2a @ w2b (reference modules/lokr.py:131-136; BASELINE configs[3] "(low)"): planes
+    packed from the pairs, one forward launch, one backward launch that stores the sum of the dx results, the weight gradients through
+    the grouped chain rule -- forward bits equal to n lokr_linear_lr calls, every gradient against the float64 oracle"""
+    M, a, c, d, n, r = case
+    gen = torch.Generator().manual_seed(M + r + n)
+    x, x64 = rnd((M, a * d), dtype, gen)
+    w1s, w2as, w2bs, gs, f64 = [], [], [], [], []
+    for i in range(n):
+        w1, w1_64 = rnd((a, a), torch.float32, gen, 0.3)
+        w2a, a64 = rnd((c, r), torch.float32, gen, 0.3)
+        w2b, b64 = rnd((r, d), torch.float32, gen, 0.3)
+        g, g64 = rnd((M, a * c), dtype, gen, 0.1)
+        w1s.append(torch.nn.Parameter(w1)); w2as.append(torch.nn.Parameter(w2a)); w2bs.append(torch.nn.Parameter(w2b)); gs.append(g)
+        f64.append((w1_64, a64, b64, g64))
+    params = [p for tri in zip(w1s, w2as, w2bs) for p in tri]
+    alphas = [0.5, 1.0, 0.25, 0.75][:n]
+    xp = x.clone().requires_grad_(True)
+    ys_p = [ops.lokr_linear_lr(xp, w1s[i], w2as[i], w2bs[i], alphas[i]) for i in range(n)]
+    if training:
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        ops.fused_grad_accumulation(True, callback=lambda p: None)
+    try:
+        xr = x.clone().requires_grad_(True)
+        ys = ops.lokr_linear_lr_group(xr, w1s, w2as, w2bs, alphas)
+        if training:
+            torch.autograd.backward(ys, gs)
+            grads = [xr.grad] + [p.grad for p in params]
+        else:
+            grads = list(torch.autograd.grad(ys, [xr] + params, gs))
+        torch.cuda.synchronize()
+    finally:
+        if training:
+            ops.fused_grad_accumulation(False, None)
+    errs, bounds = {}, {}
+    dx_want = 0.0
+    for i in range(n):
+        assert torch.equal(ys[i], ys_p[i]), f"y[{i}] differs from the per-layer op"
+        w1_64, a64, b64, g64 = f64[i]
+        gr = oracle.lokr.backward(x64, g64, w1=w1_64, w2a=a64, w2b=b64, scale=alphas[i])
+        dx_want = dx_want + gr["dx"]
+        for j, k in enumerate(("w1", "w2a", "w2b")):
+            errs[f"d{k}_{i}"], bounds[f"d{k}_{i}"] = err(grads[1 + 3 * i + j], gr[k]), TOL["f32_out"][dtype]
+    if training:  # one launch, the sum formed in fp32 registers and rounded once
+        errs["dx"], bounds["dx"] = err(grads[0], dx_want, dtype), TOL["store_out"][dtype]
+    else:         # problem by problem, the n 16-bit results added like autograd's accumulation
+        errs["dx"], bounds["dx"] = err(grads[0], dx_want), (n + 1) * TOL["store_out"][dtype]
+    check(f"sibling_group_lr[{case},{dtype},{training}]", errs, bounds)
+
+
 class Attn(nn.Module):
     """diffusers' Attention call pattern: to_q(h), to_k(ctx), to_v(ctx), to_out(.)"""
 
@@ -171,17 +226,20 @@ class Block(nn.Module):
         return h + self.attn2(h, ctx)
 
 
+@pytest.mark.parametrize("rank", [10000, 16], ids=["full_matrix", "rank16"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-def test_adapted_attention_block_groups_its_projections_with_identical_results(dtype):
+def test_adapted_attention_block_groups_its_projections_with_identical_results(dtype, rank):
     torch.manual_seed(0)
     block = Block().to(DEV, dtype).requires_grad_(False)
     gen = torch.Generator().manual_seed(1)
     mods = []
     for name, layer in block.named_modules():
         if isinstance(layer, nn.Linear):
-            m = LokrModule(name.replace(".", "_"), layer, 1.0, 10000, 1, factor=8).to(DEV)
-            with torch.no_grad():
-                m.lokr_w2.copy_((torch.randn(m.lokr_w2.shape, generator=gen) * 0.05).to(DEV))
+            m = LokrModule(name.replace(".", "_"), layer, 1.0, rank, 1, factor=8).to(DEV)
+            with torch.no_grad():  # (the zero-initialised factor would make every delta zero)
+                tgt = m.lokr_w2 if m.use_w2 else m.lokr_w2_b
+                tgt.copy_((torch.randn(tgt.shape, generator=gen) * 0.05).to(DEV))
+            assert m.use_w2 == (rank == 10000)
             m.apply_to()
             mods.append(m)
     params = [p for m in mods for p in m.parameters()]
@@ -217,6 +275,6 @@ def test_adapted_attention_block_groups_its_projections_with_identical_results(d
     for i, (a_, b_) in enumerate(zip(got[1][1:], want[1][1:])):
         errs[f"g{i}"] = float((a_ - b_).norm() / (b_.norm() + 1e-30))
         bounds[f"g{i}"] = 2e-3  # downstream of dh's summation order (16-bit activations), not of the adapter kernels
-    check(f"sibling_modules[{dtype}]", errs, bounds)
+    check(f"sibling_modules[{dtype},{rank}]", errs, bounds)
     for m in mods:
         m.restore()
