@@ -1277,7 +1277,8 @@ def per_algo_legs():
             d = json.loads(line)
             rl = d.get("roofline") or {}
             out[name] = {"ms_per_step": d["ms_per_step"], "steps_per_s": d["value"], "dtype": d["dtype"], "layers": d["config"]["layers"],
-                         "roofline": {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "families_ms") if k in rl},
+                         "roofline": {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic",
+                                                                "families_ms") if k in rl},
                          "wall_s": round(time.perf_counter() - t0, 1)}
         except Exception as e:  # a failing leg must not take the headline line down
             out[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
