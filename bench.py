@@ -320,10 +320,10 @@ def build_instances(args, dtype, dev):
 
 
 def _groupable(it):
-    """a sibling set that goes out as ONE launch: LoKr on nn.Linear with full-matrix factors (ops.lokr_linear_group, the op the
-    modules' sibling sets call -- lycoris_amd/modules/siblings.py)"""
-    return (SIBLINGS and it.sibs is not None and len(it.sibs) > 1 and it.algo == "lokr" and it.spec["kind"] == "linear" and len(it.params) in (2, 3)
-            and it.x.dtype != torch.float32)
+    """a sibling set that goes out as ONE launch: LoKr (full-matrix or low-rank w2) or LoCon on nn.Linear -- ops.lokr_linear_group /
+    lokr_linear_lr_group / locon_linear_group, the ops the modules' sibling sets call (lycoris_amd/modules/siblings.py)"""
+    return (SIBLINGS and it.sibs is not None and len(it.sibs) > 1 and it.spec["kind"] == "linear" and it.x.dtype != torch.float32
+            and ((it.algo == "lokr" and len(it.params) in (2, 3)) or it.algo == "locon"))
 
 
 def forward_all(insts, with_base=False):
@@ -337,7 +337,11 @@ def forward_all(insts, with_base=False):
         grp = it.sibs
         if grp is not None and grp[0] is it and _groupable(it) and all(id(m) in present for m in grp):
             bases = [m.base_forward() for m in grp] if with_base else None
-            if len(it.params) == 2:
+            if it.algo == "locon":  # (no fused epilogue: base + delta is an elementwise add, as in the modules)
+                ys = it.ops.locon_linear_group(it.x, [m.params[0] for m in grp], [m.params[1] for m in grp], [1.0] * len(grp))
+                if bases is not None:
+                    ys = [b + y for b, y in zip(bases, ys)]
+            elif len(it.params) == 2:
                 ys = it.ops.lokr_linear_group(it.x, [m.params[0] for m in grp], [m.params[1] for m in grp], [1.0] * len(grp), bases)
             else:  # --rank: low-rank w2 = w2_a @ w2_b
                 ys = it.ops.lokr_linear_lr_group(it.x, [m.params[0] for m in grp], [m.params[1] for m in grp], [m.params[2] for m in grp],

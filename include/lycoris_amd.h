@@ -41,7 +41,7 @@ enum { LYC_F32_ROWS = 0x100, LYC_DEFER_WGRAD = 0x200,
 #define LYC_KCONV_ROW_TILE(mi) (((mi) & 0xf) << 12)
 enum { LYC_OK = 0, LYC_ERR_ARG = 1, LYC_ERR_UNSUPPORTED = 2, LYC_ERR_LAUNCH = 3 };
 
-#define LYC_ABI_VERSION 10
+#define LYC_ABI_VERSION 11
 int lyc_abi_version(void);
 const char* lyc_last_error(void);
 
@@ -287,6 +287,24 @@ int lyc_locon_linear_fwd(const void* x, const float* down, const float* up, floa
 int lyc_locon_linear_bwd(const void* g, const void* x, const float* down, const float* up, const float* t,
                          float* dt, void* dx, float* d_down, float* d_up, int64_t M, int I, int O, int r,
                          float alpha, int dtype, void* stream);
+/* Sibling projections in ONE launch (round 5), as lyc_lokr_linear_fwd_group for LoCon: n <= 4 layers of equal (I, O, r) and M --
+ * the to_q / to_k / to_v adapters of an attention block (reference: one LoConModule.forward per projection, modules/locon.py:309-332).
+ *   forward : in = x [M, I], mid = t [M, r] fp32 (written; keep it for the backward call), out = y [M, O] = alpha * (x down^T) up^T
+ *   backward: in = g [M, O], mid = dt [M, r] fp32 (written), out = dx [M, I] = (alpha * g up) down -- the dx launch of
+ *             lyc_locon_linear_bwd with NULL gradient pointers; the factor gradients follow through lyc_locon_wgrad_group
+ * Bit-identical to the per-layer entry points.  LYC_ERR_UNSUPPORTED (nothing launched) off the fused 16-bit rank-r path or for shape
+ * classes without a grouped instantiation (r > 32): call the per-layer entry points instead. */
+typedef struct LycLoconLinearGroupItem {
+  const void* in;
+  const float* down;   /* [r, I] */
+  const float* up;     /* [O, r] */
+  float* mid;
+  void* out;
+  int64_t M;
+  float alpha;
+} LycLoconLinearGroupItem;
+int lyc_locon_linear_fwd_group(const LycLoconLinearGroupItem* items, int n, int I, int O, int r, int dtype, void* stream);
+int lyc_locon_linear_bwd_group(const LycLoconLinearGroupItem* items, int n, int I, int O, int r, int dtype, void* stream);
 
 /* LoCon on nn.Conv2d without im2col (reference: lycoris/modules/locon.py:286-332 with F.conv2d -- lora_down is the
  * kh x kw convolution [r, C, kh, kw], lora_up the 1x1 convolution [O, r, 1, 1]; functional/locon.py:64-85).

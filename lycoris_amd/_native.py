@@ -13,7 +13,7 @@ import torch
 
 _LIB_NAME = "liblycoris_amd.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 LYC_F32, LYC_F16, LYC_BF16 = 0, 1, 2
 _DTYPE_CODE = {torch.float32: LYC_F32, torch.float16: LYC_F16, torch.bfloat16: LYC_BF16}
@@ -59,6 +59,8 @@ SIGNATURES = {
     "lyc_im2col": [_vp, _vp, _i64, _i64, _i64, _i64] + [_i32] * 8 + [_i32, _vp],
     "lyc_col2im": [_vp, _vp, _i64, _i64, _i64, _i64] + [_i32] * 8 + [_i32, _vp],
     "lyc_sum_rows": [_vp, _i32, _vp, _i64, _i32, _vp],
+    "lyc_locon_linear_fwd_group": [_vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "lyc_locon_linear_bwd_group": [_vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "lyc_lokr_linear_bwd_group_sum": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "lyc_nchw_to_rows": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "lyc_rows_to_nchw": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
@@ -114,6 +116,11 @@ class WgradItem(ctypes.Structure):
     """LycLokrWgradItem (include/lycoris_amd.h)"""
     _fields_ = [("g", _vp), ("x", _vp), ("w1", _vp), ("dw1", _vp), ("dw2", _vp), ("ws", _vp), ("M", _i64),
                 ("a", _i32), ("b", _i32), ("c", _i32), ("d", _i32), ("alpha", _f32)]
+
+class LoconGroupItem(ctypes.Structure):
+    """LycLoconLinearGroupItem (include/lycoris_amd.h)"""
+    _fields_ = [("inp", _vp), ("down", _vp), ("up", _vp), ("mid", _vp), ("out", _vp), ("M", _i64), ("alpha", _f32)]
+
 
 class LinearGroupItem(ctypes.Structure):
     """LycLokrLinearGroupItem (include/lycoris_amd.h)"""

@@ -606,6 +606,49 @@ void launch_bneck(const BneckArgs& b, hipStream_t st) {
     launch_bneck_rt<T, 4>(b, st);
 }
 
+// ---- sibling LoCon projections in one launch (bneck_group_kernel, round 5) ---------------------------------------------------------
+// n <= BNECK_GROUP_MAX problems of equal shape and factor layout: the tile plan of launch_bneck_rt / _v with the column slices
+// chosen for ALL problems together (rows * n workgroups per slice).  Returns false when the shape class is not instantiated for the
+// group kernel (ranks above 32, the 8-wave reduce, gathers): the caller launches layer by layer.
+template <typename T, int MI, int RT>
+bool launch_bneck_group_v(BneckGroupArgs& ga, bool vec, hipStream_t st) {
+  constexpr int NW = 4;
+  const BneckArgs& b0 = ga.p[0];
+  const long rows = cdiv(b0.M, 16 * MI);
+  long ns = b0.out != nullptr ? 256 / (rows * ga.n) : 1;
+  if (ns > cdiv(b0.N2, 16 * NW)) ns = cdiv(b0.N2, 16 * NW);
+  if (ns > 8) ns = 8;
+  if (ns < 1) ns = 1;
+  for (int i = 0; i < ga.n; ++i) ga.p[i].nsplit = (int)ns;
+  const dim3 grid((unsigned)rows, (unsigned)ns, (unsigned)ga.n);
+  if constexpr (MI * RT <= 2) {
+    if (vec) {
+      hipLaunchKernelGGL((bneck_group_kernel<T, NW, MI, RT, true, true, true>), grid, dim3(NW * 64), 0, st, ga);
+      return true;
+    }
+  }
+  if (vec)
+    hipLaunchKernelGGL((bneck_group_kernel<T, NW, MI, RT, true, true>), grid, dim3(NW * 64), 0, st, ga);
+  else
+    hipLaunchKernelGGL((bneck_group_kernel<T, NW, MI, RT, false, false>), grid, dim3(NW * 64), 0, st, ga);
+  return true;
+}
+template <typename T>
+bool launch_bneck_group(BneckGroupArgs& ga, hipStream_t st) {
+  const BneckArgs& b = ga.p[0];
+  if (b.R > 32 || b.gat.mode != 0) return false;
+  const bool vec = b.f1k == 1 && (b.f1n % 4) == 0 && b.f2k == 1 && (b.f2n % 4) == 0 && (b.R % 4) == 0;
+  for (int i = 0; i < ga.n; ++i) {
+    const BneckArgs& q = ga.p[i];
+    if (q.M != b.M || q.K1 != b.K1 || q.R != b.R || q.N2 != b.N2 || q.f1n != b.f1n || q.f1k != b.f1k || q.f2n != b.f2n || q.f2k != b.f2k) return false;
+    if (vec && ((reinterpret_cast<uintptr_t>(q.F1) | reinterpret_cast<uintptr_t>(q.F2)) & 15u)) return false;
+  }
+  const int mi = b.M >= 8192 ? 2 : 1;
+  if (mi == 1 && b.K1 >= 8192) return false;  // (the 8-wave reduce of very long K: per layer)
+  if (b.R <= 16) return mi == 2 ? launch_bneck_group_v<T, 2, 1>(ga, vec, st) : launch_bneck_group_v<T, 1, 1>(ga, vec, st);
+  return mi == 2 ? launch_bneck_group_v<T, 2, 2>(ga, vec, st) : launch_bneck_group_v<T, 1, 2>(ga, vec, st);
+}
+
 void launch_bneck_dt(const BneckArgs& b, int dtype, hipStream_t st) {
   if ((dtype & 0xff) == LYC_BF16)
     launch_bneck<__bf16>(b, st);
@@ -1960,6 +2003,43 @@ int lyc_locon_linear_fwd(const void* x, const float* down, const float* up, floa
   s2.bn = r; s2.bk = 1; s2.os = O; s2.oj = 1; s2.alpha = alpha;
   DISPATCH_DTYPE(dtype, launch_expand_nt<T>(s2, st));
   return check_launch("locon_linear_fwd");
+}
+
+extern "C++" {
+namespace {
+int locon_linear_group(const LycLoconLinearGroupItem* items, int n, int I, int O, int r, int dtype, void* stream, bool backward) {
+  const char* who = backward ? "locon_linear_bwd_group" : "locon_linear_fwd_group";
+  if (n < 1 || n > BNECK_GROUP_MAX || !items) return fail(LYC_ERR_ARG, "%s: 1 .. %d items", who, BNECK_GROUP_MAX);
+  if (I < 1 || O < 1 || r < 1) return fail(LYC_ERR_ARG, "%s: bad dims", who);
+  const int dt = dtype & 0xff;
+  if ((dt != LYC_BF16 && dt != LYC_F16) || (dtype & ~0xff)) return fail(LYC_ERR_UNSUPPORTED, "%s: 16-bit activations, no dtype flags", who);
+  BneckGroupArgs ga{};
+  ga.n = n;
+  for (int k = 0; k < n; ++k) {
+    const LycLoconLinearGroupItem& it = items[k];
+    if (!it.in || !it.down || !it.up || !it.mid || !it.out || it.M < 1) return fail(LYC_ERR_ARG, "%s: item %d: null pointer or empty", who, k);
+    BneckArgs& b = ga.p[k];
+    if (!backward) {  // t = x down^T (kept for the backward pass), y = alpha * t up^T      (lyc_locon_linear_fwd)
+      b.A = it.in; b.lda = I; b.M = it.M; b.K1 = I; b.F1 = it.down; b.f1n = I; b.f1k = 1; b.R = r; b.mid = it.mid;
+      b.F2 = it.up; b.f2n = r; b.f2k = 1; b.N2 = O; b.out = it.out; b.ldo = O; b.out_f32 = 0; b.alpha1 = 1.0f; b.alpha2 = it.alpha;
+    } else {          // dt = alpha * g up (kept for d_down), dx = dt down                  (lyc_locon_linear_bwd, gradient pointers NULL)
+      b.A = it.in; b.lda = O; b.M = it.M; b.K1 = O; b.F1 = it.up; b.f1n = 1; b.f1k = r; b.R = r; b.mid = it.mid;
+      b.F2 = it.down; b.f2n = 1; b.f2k = I; b.N2 = I; b.out = it.out; b.ldo = I; b.out_f32 = 0; b.alpha1 = it.alpha; b.alpha2 = 1.0f;
+    }
+    if (!bneck_ok(b, dtype)) return fail(LYC_ERR_UNSUPPORTED, "%s: item %d is not on the fused rank-r path (16-bit, K %% 8 == 0, r <= 64, aligned rows)", who, k);
+  }
+  const bool ok = dt == LYC_BF16 ? launch_bneck_group<__bf16>(ga, (hipStream_t)stream) : launch_bneck_group<_Float16>(ga, (hipStream_t)stream);
+  if (!ok) return fail(LYC_ERR_UNSUPPORTED, "%s: this shape class has no grouped instantiation (r > 32, K >= 8192 at M < 8192, unequal shapes)", who);
+  return check_launch(who);
+}
+}  // namespace
+}  // extern "C++"
+
+int lyc_locon_linear_fwd_group(const LycLoconLinearGroupItem* items, int n, int I, int O, int r, int dtype, void* stream) {
+  return locon_linear_group(items, n, I, O, r, dtype, stream, false);
+}
+int lyc_locon_linear_bwd_group(const LycLoconLinearGroupItem* items, int n, int I, int O, int r, int dtype, void* stream) {
+  return locon_linear_group(items, n, I, O, r, dtype, stream, true);
 }
 
 int lyc_locon_linear_bwd(const void* g, const void* x, const float* down, const float* up, const float* t,

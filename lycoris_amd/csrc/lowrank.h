@@ -103,7 +103,7 @@ __host__ __device__ constexpr int bneck_lds_bytes() {
 // STG (needs F1V, not with GAT): stage 1 through a per-wave LDS stage with COALESCED global loads -- fragment-direct loads
 // give each lane of a quad a different cache line and cost the address unit ~64 cycles per wave instruction instead of 16.
 template <typename T, int NW, int MI, int RT, bool F1V, bool F2V, bool GAT = false, bool STG = false>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void bneck_kernel(BneckArgs a) {
+__device__ __forceinline__ void bneck_body(const BneckArgs& a, const int bx, const int by, const int nby) {
   static_assert(!STG || (F1V && !GAT), "staged stage 1: vector factor layout, no gather");
   constexpr int D = RT == 4 ? 2 : 3;  // stage-1 steps in flight per wave (register budget)
   constexpr int D2 = RT == 1 ? 8 : RT == 2 ? 4 : 2;  // stage-2 column tiles in flight per wave
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long m0 = (long)blockIdx.x * (16 * MI);
+  const long m0 = (long)bx * (16 * MI);
   const T* A = static_cast<const T*>(a.A);
   const int K1 = a.K1, R = a.R;
   LYC_TRACE_DECL;
@@ -368,8 +368,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 
   // this y slice's column tiles: [tbeg, ntiles)
   const int ntiles_all = (a.N2 + 15) >> 4;
-  const int tper = (ntiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
-  const int tbeg = (int)blockIdx.y * tper;
+  const int tper = (ntiles_all + nby - 1) / nby;
+  const int tbeg = by * tper;
   const int ntiles = tbeg + tper < ntiles_all ? tbeg + tper : ntiles_all;
   // F2 needs no masks: columns k >= R of mid are zero (their F1 rows were zeroed), tiles / columns past the end are never
   // stored; the loads only have to come from valid (clamped) addresses.
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     const int t = e >> 8, l = (e >> 2) & 63, q = e & 3;  // accumulator element: column l & 15, row 4 (l >> 4) + q
     const int m = 16 * (t / RT) + 4 * (l >> 4) + q, n = 16 * (t % RT) + (l & 15);
     mids[m * RP + n] = s;
-    if (a.mid != nullptr && blockIdx.y == 0 && m0 + m < a.M && n < R) a.mid[(m0 + m) * R + n] = s;
+    if (a.mid != nullptr && by == 0 && m0 + m < a.M && n < R) a.mid[(m0 + m) * R + n] = s;
   }
   if (a.out == nullptr) return;  // only mid wanted (no input gradient)
   __syncthreads();
@@ -494,6 +494,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     stage2(std::false_type{});
   LYC_STAMP(4);
   LYC_TRACE_FLUSH();
+}
+
+template <typename T, int NW, int MI, int RT, bool F1V, bool F2V, bool GAT = false, bool STG = false>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void bneck_kernel(BneckArgs a) {
+  bneck_body<T, NW, MI, RT, F1V, F2V, GAT, STG>(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+
+// Several problems of ONE shape in one launch (round 5: the to_q / to_k / to_v adapters of an attention block read one tensor --
+// reference: one LoConModule.forward per projection, modules/locon.py:309-332): blockIdx.z selects the problem.  A 1024-row LoCon layer
+// is 64 row tiles x 4 column slices; three of them planned together are 64 x 1-2 slices each and ONE launch instead of three.
+constexpr int BNECK_GROUP_MAX = 4;
+struct BneckGroupArgs {
+  int n;
+  BneckArgs p[BNECK_GROUP_MAX];
+};
+static_assert(sizeof(BneckGroupArgs) <= 3840, "kernel arguments are limited to 4 KiB");
+template <typename T, int NW, int MI, int RT, bool F1V, bool F2V, bool STG = false>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void bneck_group_kernel(BneckGroupArgs ga) {
+  bneck_body<T, NW, MI, RT, F1V, F2V, false, STG>(ga.p[blockIdx.z], (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

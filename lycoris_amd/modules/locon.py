@@ -12,10 +12,11 @@ import torch.nn as nn
 
 from .. import ops
 from ..functional.general import conv_args
+from . import siblings as _siblings
 from .base import LycorisBaseModule, _unsupported
 
 
-class LoConModule(LycorisBaseModule):
+class LoConModule(_siblings.SiblingMixin, LycorisBaseModule):
     name = "locon"
     _ws_algo = "locon"
     support_module = {"linear", "conv1d", "conv2d", "conv3d"}
@@ -138,6 +139,21 @@ class LoConModule(LycorisBaseModule):
         return scaled, orig_norm * ratio
 
     # ---- hot path --------------------------------------------------------------------------------------------------
+    def _sibling_eligible(self, x):
+        """on the plain `base + delta` path of a LoCon nn.Linear layer (what lyc_locon_linear_fwd_group takes)?"""
+        return (not self.isconv and not getattr(self, "wd", False) and x.is_cuda and not x.is_inference()
+                and x.dtype in (torch.bfloat16, torch.float16)
+                and not (self.training and (self.module_dropout or self.rank_dropout or (self.bypass_mode and self.dropout))))
+
+    def _sibling_key(self):
+        return ("locon", tuple(self.lora_down.weight.shape), tuple(self.lora_up.weight.shape))
+
+    @staticmethod
+    def _sibling_launch(members, x, bases):
+        deltas = ops.locon_linear_group(x, [m.lora_down.weight for m in members], [m._gate(m.lora_up.weight) for m in members],
+                                        [m.scale * m.multiplier for m in members])
+        return [b + d for b, d in zip(bases, deltas)]
+
     def bypass_forward_diff(self, x, scale=1):
         """delta = up(down(x)) * scalar * alpha/r * scale  (locon.py:286-304 and :309-332 compute the same function)."""
         alpha = self.scale * scale

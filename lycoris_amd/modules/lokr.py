@@ -28,7 +28,7 @@ def _warn_full_matrix(lora_dim, dim, factor):
         logger.warning(f"lora_dim {lora_dim} is too large for dim={dim} and factor={factor}, using full matrix mode.")
 
 
-class LokrModule(LycorisBaseModule):
+class LokrModule(_siblings.SiblingMixin, LycorisBaseModule):
     name = "kron"
     _ws_algo = "lokr"
     support_module = {"linear", "conv1d", "conv2d", "conv3d"}
@@ -88,7 +88,6 @@ class LokrModule(LycorisBaseModule):
             self.lokr_w2_a = nn.Parameter(torch.empty(out_k, lora_dim))
             self.lokr_w2_b = nn.Parameter(torch.empty(lora_dim, in_n * kprod))
         self._kron_dims = (out_l, in_m, out_k, in_n)
-        object.__setattr__(self, "_sib", None)  # the sibling set this module was found in (modules/siblings.py); not state, not a submodule
 
         self._init_scale(lora_dim, alpha, rs_lora, use_scalar, force_unit_scale=self.use_w1 and self.use_w2)
         if self.use_w2:
@@ -231,22 +230,17 @@ class LokrModule(LycorisBaseModule):
                 and x.dtype in (torch.bfloat16, torch.float16)
                 and not (self.training and (self.module_dropout or self.rank_dropout or (self.bypass_mode and self.dropout))))
 
-    def forward(self, x, *args, **kwargs):
-        # to_q / to_k / to_v called with one tensor run as ONE launch (modules/siblings.py); everything else is the per-layer path
-        # (is_compiling() first: under torch.compile the whole branch folds away and dynamo never sees the eligibility test)
-        if not torch.compiler.is_compiling() and not args and not kwargs and isinstance(x, torch.Tensor) and self._sibling_eligible(x):
-            y = _siblings.forward(self, x)
-            if y is not None:
-                return y
-        return super().forward(x, *args, **kwargs)
+    def _sibling_key(self):
+        w2 = (tuple(self.lokr_w2.shape),) if self.use_w2 else (tuple(self.lokr_w2_a.shape), tuple(self.lokr_w2_b.shape))
+        return ("lokr", tuple(self.lokr_w1.shape), w2)
 
-    def apply_to(self, **kwargs):
-        _siblings.forget(self)
-        return super().apply_to(**kwargs)
-
-    def restore(self):
-        _siblings.forget(self)
-        return super().restore()
+    @staticmethod
+    def _sibling_launch(members, x, bases):
+        w1s, alphas = [m._gate(m.lokr_w1) for m in members], [m.scale * m.multiplier for m in members]
+        if members[0].use_w2:
+            return ops.lokr_linear_group(x, w1s, [m.lokr_w2 for m in members], alphas, bases)
+        # low-rank second factor: the pairs go to the kernels as they are (planes from the factors, grouped chain rule)
+        return ops.lokr_linear_lr_group(x, w1s, [m.lokr_w2_a for m in members], [m.lokr_w2_b for m in members], alphas, bases)
 
     def _forward_fused(self, x, base):
         if self.module_type != "linear":

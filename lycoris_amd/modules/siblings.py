@@ -18,7 +18,9 @@ calls ``layer(x)`` three times.  This file makes the modules find their siblings
   so the numbers can never depend on the grouping -- only the launch count does.
 
 Scope: LoKr on nn.Linear with a full `lokr_w1` and either a full-matrix `lokr_w2` (the headline configuration) or the low-rank pair
-`lokr_w2_a @ lokr_w2_b` (BASELINE configs[3]); a set holds one kind only.  ``enable(False)`` switches the mechanism off.
+`lokr_w2_a @ lokr_w2_b` (BASELINE configs[3]), and LoCon on nn.Linear (`ops.locon_linear_group`); a set holds one kind only.  A module
+class takes part by deriving from ``SiblingMixin`` and supplying `_sibling_eligible(x)`, `_sibling_key()` and `_sibling_launch(members,
+x, bases)`.  ``enable(False)`` switches the mechanism off.
 """
 from __future__ import annotations
 
@@ -70,8 +72,7 @@ class SiblingSet:
 
 
 def _key(mod, x):
-    w2 = (tuple(mod.lokr_w2.shape),) if mod.use_w2 else (tuple(mod.lokr_w2_a.shape), tuple(mod.lokr_w2_b.shape))
-    return (tuple(mod.lokr_w1.shape), w2, x.dtype, x.device, tuple(x.shape))
+    return (mod._sibling_key(), x.dtype, x.device, tuple(x.shape))
 
 
 def forget(mod):
@@ -108,11 +109,7 @@ def forward(mod, x) -> Optional[torch.Tensor]:
                 return None
             st.pending.clear()  # (results nobody fetched: a sibling skipped its call in the last pass)
             bases = [m.org_forward(x) for m in members]
-            w1s, alphas = [m._gate(m.lokr_w1) for m in members], [m.scale * m.multiplier for m in members]
-            if mod.use_w2:
-                ys = ops.lokr_linear_group(x, w1s, [m.lokr_w2 for m in members], alphas, bases)
-            else:  # low-rank second factor: the pairs go to the kernels as they are (planes from the factors, grouped chain rule)
-                ys = ops.lokr_linear_lr_group(x, w1s, [m.lokr_w2_a for m in members], [m.lokr_w2_b for m in members], alphas, bases)
+            ys = mod._sibling_launch(members, x, bases)  # [base_i + delta_i]: one grouped launch of the algorithm's kernels
             ver = x._version
             for m, y in zip(members[1:], ys[1:]):
                 st.pending[id(m)] = (x, ver, y)
@@ -136,3 +133,35 @@ def forward(mod, x) -> Optional[torch.Tensor]:
         pst.members.append(weakref.ref(mod))
         object.__setattr__(mod, "_sib", pst)
     return None
+
+
+class SiblingMixin:
+    """forward / apply_to / restore of a module class whose instances can form sibling sets (put in front of LycorisBaseModule)"""
+    _sib = None  # the set this module was found in; per instance once it has joined one (not state, not a submodule)
+
+    def _sibling_eligible(self, x) -> bool:
+        raise NotImplementedError
+
+    def _sibling_key(self):
+        raise NotImplementedError
+
+    @staticmethod
+    def _sibling_launch(members, x, bases):
+        raise NotImplementedError
+
+    def forward(self, x, *args, **kwargs):
+        # projections called with one tensor run as ONE launch; everything else is the per-layer path
+        # (is_compiling() first: under torch.compile the whole branch folds away and dynamo never sees the eligibility test)
+        if not torch.compiler.is_compiling() and not args and not kwargs and isinstance(x, torch.Tensor) and self._sibling_eligible(x):
+            y = forward(self, x)
+            if y is not None:
+                return y
+        return super().forward(x, *args, **kwargs)
+
+    def apply_to(self, **kwargs):
+        forget(self)
+        return super().apply_to(**kwargs)
+
+    def restore(self):
+        forget(self)
+        return super().restore()

@@ -57,7 +57,7 @@ def _cpp() -> bool:
         except ImportError:  # very old torch: the end-of-backward mark alone
             pass
         ns = torch.ops.lycoris_amd  # the resolved overloads: skips the packet's per-call overload resolution (~1 us per call)
-        for name in ("lokr_linear", "lokr_linear_group", "lokr_linear_lr_group", "lokr_linear_lr", "lokr_linear_lr2", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d", "lokr_conv2d_lr"):
+        for name in ("lokr_linear", "lokr_linear_group", "lokr_linear_lr_group", "locon_linear_group", "lokr_linear_lr", "lokr_linear_lr2", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d", "lokr_conv2d_lr"):
             _OPS[name] = getattr(ns, name).default
     return True
 
@@ -743,6 +743,20 @@ def locon_linear(x, down, up, alpha=1.0):
     if _cpp():
         return _OPS["locon_linear"](x, down, up, float(alpha))
     return _AdapterLinear.apply(_LoconCore, alpha, _amp(x), down, up)
+
+
+def locon_linear_group(x, downs, ups, alphas):
+    """n LoCon projections of ONE input (to_q / to_k / to_v of an attention block: equal factor shapes) as one call: one forward launch,
+    one autograd node with n outputs, one backward dx launch + a one-pass sum (csrc/torch_ops.cpp LoconLinearGroupFn over
+    lyc_locon_linear_fwd_group / _bwd_group).  Returns the list of deltas; bit-identical to n locon_linear calls.  Host tensors,
+    tracing and the python dispatch run the n calls one by one."""
+    n = len(downs)
+    if len(ups) != n or len(alphas) != n:
+        raise ValueError("locon_linear_group: downs, ups and alphas must have one entry per problem")
+    if n == 1 or not x.is_cuda or not _cpp() or torch.compiler.is_compiling():
+        return [locon_linear(x, downs[i], ups[i], alphas[i]) for i in range(n)]
+    factors = [t for pair in zip(downs, ups) for t in pair]
+    return list(_OPS["locon_linear_group"](x, factors, [float(a) for a in alphas]))
 
 
 def loha_linear(x, w1a, w1b, w2a, w2b, alpha=1.0):

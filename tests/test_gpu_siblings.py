@@ -199,6 +199,58 @@ def test_low_rank_group_op_matches_the_oracle(case, dtype, training):
     check(f"sibling_group_lr[{case},{dtype},{training}]", errs, bounds)
 
 
+@pytest.mark.parametrize("training", [False, True], ids=["autograd", "training_configuration"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", [(1024, 1280, 1280, 16, 3), (77, 2048, 1280, 16, 2), (4096, 640, 640, 16, 3), (16384, 320, 320, 16, 3),
+                                  (130, 96, 40, 4, 4), (256, 640, 640, 32, 2)], ids=lambda c: f"M{c[0]}_I{c[1]}_O{c[2]}_r{c[3]}_n{c[4]}")
+def test_locon_group_op_matches_the_oracle_and_the_per_layer_op(case, dtype, training):
+    """locon_linear_group: n LoCon projections of one input as one forward launch / one backward dx launch (bneck_group_kernel) -- forward
+    bits equal to n locon_linear calls, every gradient against the float64 oracle; in the training configuration the factor gradients go
+    through the grouped launches into .grad"""
+    M, I, O, r, n = case
+    gen = torch.Generator().manual_seed(M + I + O + r + n)
+    x, x64 = rnd((M, I), dtype, gen)
+    downs, ups, gs, f64 = [], [], [], []
+    for i in range(n):
+        dn, d64 = rnd((r, I), torch.float32, gen, 0.05)
+        up, u64 = rnd((O, r), torch.float32, gen, 0.05)
+        g, g64 = rnd((M, O), dtype, gen, 1.0 / np.sqrt(O))
+        downs.append(torch.nn.Parameter(dn)); ups.append(torch.nn.Parameter(up)); gs.append(g); f64.append((d64, u64, g64))
+    params = [p for pair in zip(downs, ups) for p in pair]
+    alphas = [0.5, 1.0, 2.0, 0.25][:n]
+    xp = x.clone().requires_grad_(True)
+    ys_p = [ops.locon_linear(xp, downs[i], ups[i], alphas[i]) for i in range(n)]
+    if training:
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        ops.fused_grad_accumulation(True, callback=lambda p: None)
+    try:
+        xr = x.clone().requires_grad_(True)
+        ys = ops.locon_linear_group(xr, downs, ups, alphas)
+        if training:
+            torch.autograd.backward(ys, gs)
+            grads = [xr.grad] + [p.grad for p in params]
+        else:
+            grads = list(torch.autograd.grad(ys, [xr] + params, gs))
+        torch.cuda.synchronize()
+    finally:
+        if training:
+            ops.fused_grad_accumulation(False, None)
+    errs, bounds = {}, {}
+    dx_want = 0.0
+    for i in range(n):
+        assert torch.equal(ys[i], ys_p[i]), f"y[{i}] differs from the per-layer op"
+        d64, u64, g64 = f64[i]
+        errs[f"y{i}"], bounds[f"y{i}"] = err(ys[i], oracle.locon.forward(x64, d64, u64, alphas[i], None), dtype), TOL["store_out"][dtype]
+        dx_ref, dd_ref, du_ref = oracle.locon.backward(x64, g64, d64, u64, alphas[i], None)
+        dx_want = dx_want + dx_ref
+        errs[f"d_down{i}"], bounds[f"d_down{i}"] = err(grads[1 + 2 * i], dd_ref), TOL["f32_out"][dtype]
+        errs[f"d_up{i}"], bounds[f"d_up{i}"] = err(grads[2 + 2 * i], du_ref), TOL["f32_out"][dtype]
+    # n 16-bit results, summed in fp32 with one more rounding (training configuration) or added like autograd's accumulation
+    errs["dx"], bounds["dx"] = err(grads[0], dx_want), (3 if training else n + 1) * TOL["store_out"][dtype]
+    check(f"sibling_group_locon[{case},{dtype},{training}]", errs, bounds)
+
+
 class Attn(nn.Module):
     """diffusers' Attention call pattern: to_q(h), to_k(ctx), to_v(ctx), to_out(.)"""
 
@@ -226,20 +278,25 @@ class Block(nn.Module):
         return h + self.attn2(h, ctx)
 
 
-@pytest.mark.parametrize("rank", [10000, 16], ids=["full_matrix", "rank16"])
+@pytest.mark.parametrize("rank", [10000, 16, -16], ids=["lokr_full_matrix", "lokr_rank16", "locon_rank16"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 def test_adapted_attention_block_groups_its_projections_with_identical_results(dtype, rank):
+    from lycoris_amd.modules import LoConModule
     torch.manual_seed(0)
     block = Block().to(DEV, dtype).requires_grad_(False)
     gen = torch.Generator().manual_seed(1)
     mods = []
     for name, layer in block.named_modules():
         if isinstance(layer, nn.Linear):
-            m = LokrModule(name.replace(".", "_"), layer, 1.0, rank, 1, factor=8).to(DEV)
-            with torch.no_grad():  # (the zero-initialised factor would make every delta zero)
+            if rank < 0:
+                m = LoConModule(name.replace(".", "_"), layer, 1.0, -rank, 1).to(DEV)
+                tgt = m.lora_up.weight
+            else:
+                m = LokrModule(name.replace(".", "_"), layer, 1.0, rank, 1, factor=8).to(DEV)
                 tgt = m.lokr_w2 if m.use_w2 else m.lokr_w2_b
+                assert m.use_w2 == (rank == 10000)
+            with torch.no_grad():  # (the zero-initialised factor would make every delta zero)
                 tgt.copy_((torch.randn(tgt.shape, generator=gen) * 0.05).to(DEV))
-            assert m.use_w2 == (rank == 10000)
             m.apply_to()
             mods.append(m)
     params = [p for m in mods for p in m.parameters()]
