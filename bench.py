@@ -1155,22 +1155,64 @@ def roofline(insts, args, dtype, dev):
         from lycoris_amd import _native as N
         code = N.dtype_code(dtype)
         items = (N.LoconWgradItem * len(calls))()
-        dts, dxs = [], []
+        dts, dxs, ts_pre, ys_pre = [], [], [], []
         for k, (it, rows, g, fs, bufs) in enumerate(calls):
             r, I = fs[0].shape
             O = fs[1].shape[0]
             dts.append(torch.empty(rows.shape[0], r, device=dev))
             dxs.append(torch.empty_like(rows))
+            ts_pre.append(torch.empty(rows.shape[0], r, device=dev))
+            ys_pre.append(torch.empty(rows.shape[0], O, dtype=dtype, device=dev))
             assert N.load().lyc_locon_wgrad_deferrable(N.ptr(g), N.ptr(rows), rows.shape[0], I, O, r, code) == 1
-            items[k] = N.LoconWgradItem(N.ptr(g), N.ptr(rows), N.ptr(saved[id(it)][1][0]), N.ptr(dts[k]), N.ptr(bufs[0]), N.ptr(bufs[1]),
+            items[k] = N.LoconWgradItem(N.ptr(g), N.ptr(rows), N.ptr(ts_pre[k]), N.ptr(dts[k]), N.ptr(bufs[0]), N.ptr(bufs[1]),
                                         rows.shape[0], I, O, r, 1.0)
-        _KEEP.extend([items, dts, dxs])
+        # launch units of the step (round 5): a layer, or a sibling set as ONE lyc::bneck_group_kernel launch each way
+        k_of = {id(cl[0]): k for k, cl in enumerate(calls)}
+        units = []
+        for k, (it, rows, g, fs, bufs) in enumerate(calls):
+            if _groupable(it) and all(id(m) in k_of for m in it.sibs):
+                if it.sibs[0] is it:
+                    units.append([k_of[id(m)] for m in it.sibs])
+            else:
+                units.append([k])
+        fw_items, bw_items = {}, {}
+        for u in units:
+            if len(u) > 1:
+                fa, ba = (N.LoconGroupItem * len(u))(), (N.LoconGroupItem * len(u))()
+                for j, k in enumerate(u):
+                    it, rows, g, fs, bufs = calls[k]
+                    fa[j] = N.LoconGroupItem(N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(ts_pre[k]), N.ptr(ys_pre[k]), rows.shape[0], 1.0)
+                    ba[j] = N.LoconGroupItem(N.ptr(g), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(dts[k]), N.ptr(dxs[k]), rows.shape[0], 1.0)
+                fw_items[u[0]], bw_items[u[0]] = fa, ba
+        _KEEP.extend([items, dts, dxs, ts_pre, ys_pre, fw_items, bw_items])
+
+        def fwd_units():
+            for u in units:
+                it, rows, g, fs, bufs = calls[u[0]]
+                r, I = fs[0].shape
+                O = fs[1].shape[0]
+                if len(u) > 1:
+                    N.call("lyc_locon_linear_fwd_group", ctypes.cast(fw_items[u[0]], ctypes.c_void_p), len(u), I, O, r, code, N.stream_ptr(dev))
+                else:
+                    k = u[0]
+                    N.call("lyc_locon_linear_fwd", N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(ts_pre[k]), N.ptr(ys_pre[k]), rows.shape[0], I, O, r,
+                           1.0, code, N.stream_ptr(dev))
 
         def only_dx():
-            for k, (it, rows, g, fs, bufs) in enumerate(calls):
+            for u in units:
+                it, rows, g, fs, bufs = calls[u[0]]
                 r, I = fs[0].shape
-                N.call("lyc_locon_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(saved[id(it)][1][0]), N.ptr(dts[k]),
-                       N.ptr(dxs[k]), None, None, rows.shape[0], I, fs[1].shape[0], r, 1.0, code, N.stream_ptr(dev))
+                O = fs[1].shape[0]
+                if len(u) > 1:  # the set's dx launches as one, the n results summed in one pass
+                    N.call("lyc_locon_linear_bwd_group", ctypes.cast(bw_items[u[0]], ctypes.c_void_p), len(u), I, O, r, code, N.stream_ptr(dev))
+                    srcs = (ctypes.c_void_p * len(u))(*[dxs[k].data_ptr() for k in u])
+                    N.call("lyc_sum_rows", ctypes.cast(srcs, ctypes.c_void_p), len(u), N.ptr(dxs[u[0]]), dxs[u[0]].numel(), code, N.stream_ptr(dev))
+                else:
+                    k = u[0]
+                    N.call("lyc_locon_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(ts_pre[k]), N.ptr(dts[k]),
+                           N.ptr(dxs[k]), None, None, rows.shape[0], I, O, r, 1.0, code, N.stream_ptr(dev))
+
+        t_fwd = _graph_ms(fwd_units)
 
         def grouped_wgrad():
             N.call("lyc_locon_wgrad_group", ctypes.cast(items, ctypes.c_void_p), len(calls), code, N.stream_ptr(dev))
@@ -1183,10 +1225,14 @@ def roofline(insts, args, dtype, dev):
         ach = b2 / (k_ms * 1e-3) / 1e9
         out["families_ms"] = {"bneck_forward": round(t_fwd, 3), "bneck_backward_dx": round(t_dx, 3), "lowrank_tn_grouped": round(t_wg, 3),
                               "backward_one_call_per_layer": round(t_bwd, 3)}
-        out.update({"kernel": "lyc::bneck_kernel (LoCon forward + backward-dx launches of the Linear layers); the factor gradients run "
-                              "grouped (lyc::lowrank_tn_group_kernel, 18 layers per launch, re-reads g and x): families_ms",
-                    "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "launches_per_layer": 2,
-                    "avg_launch_us": round(k_ms * 1e3 / (2 * n_l), 2), "algorithmic_bytes_per_launch": int(b2 / (2 * n_l)),
+        n_launch = 2 * len(units)
+        out.update({"kernel": "lyc::bneck_kernel / lyc::bneck_group_kernel (LoCon forward + backward-dx launches of the Linear layers; a sibling "
+                              "set = one launch each way + a one-pass sum of its dx results); the factor gradients run grouped "
+                              "(lyc::lowrank_tn_group_kernel, 18 layers per launch, re-reads g and x): families_ms",
+                    "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "launches": n_launch,
+                    "launches_note": f"{sum(1 for u in units if len(u) > 1)} sibling sets ({sum(len(u) for u in units if len(u) > 1)} layers) as one launch "
+                                     f"each, {sum(1 for u in units if len(u) == 1)} layers on their own",
+                    "avg_launch_us": round(k_ms * 1e3 / n_launch, 2), "algorithmic_bytes_per_launch": int(b2 / n_launch),
                     "hot_path_gbs": round(hot, 1), "hot_path_frac": round(hot / HBM_PEAK_GBS, 4),
                     "backward_gbs": round(b_bwd / ((t_dx + t_wg) * 1e-3) / 1e9, 1)})
         return out

@@ -3,7 +3,7 @@
 # the N > 1 step at world_size 1, the full GPU suite, the five-file order that aborted in round 4 (twice, as a regression run)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 R="$(pwd)"; O=$R/gpurun_out; mkdir -p $O
-P=r05_final
+P=r05_final2
 WORKLOADS="lokr/sdxl/linear lokr/sdxl/conv locon/sdxl/linear loha/sdxl/linear" timeout 900 bash benchmarks/pmc_traffic.sh > $O/${P}_pmc.log 2>&1; echo "pmc rc=$?"; tail -2 $O/${P}_pmc.log | cut -c1-200
 [ -s $O/pmc_traffic.json ] && cp $O/pmc_traffic.json profiles/pmc_traffic.json
 timeout 900 python bench.py > $O/${P}_bench_default.json 2> $O/${P}_bench_default.err; echo "default rc=$?"
@@ -21,7 +21,7 @@ cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kstats && timeout 300 rocprofv3 --k
 f=$(find /tmp/kstats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${P}_bench_kernel_stats.csv && head -6 "$f" | cut -c1-160
 cd $R
 B="--no-reference --no-base --no-per-algo --no-cpu-baseline --no-roofline --steps 30 --warmup 5"
-for v in "plain:" "nosiblings:--no-siblings" "ws1:--rccl-ws1" "ws1_side:--rccl-ws1 --collectives-on-side-stream" "ws1_c10d:--rccl-ws1 --backend nccl" "eager:--eager" "rank16:--rank 16"; do
+for v in "plain:" "nosiblings:--no-siblings" "ws1:--rccl-ws1" "rank16:--rank 16" "rank16_nosiblings:--rank 16 --no-siblings"; do
   name=${v%%:*}; flags=${v#*:}
   MASTER_ADDR=127.0.0.1 MASTER_PORT=29581 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 400 python bench.py $B $flags > $O/${P}_bench_$name.json 2> $O/${P}_bench_$name.err
   echo "$name rc=$? $(tail -1 $O/${P}_bench_$name.json | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["value"])' 2>&1 | cut -c1-200)"
@@ -29,6 +29,6 @@ done 2>&1 | tee $O/${P}_variants.log
 timeout 200 python benchmarks/host_overhead.py > $O/${P}_host_overhead.log 2>&1; echo "host overhead rc=$?"; [ -s $O/host_overhead.json ] && cp $O/host_overhead.json $O/${P}_host_overhead.json; grep -v amdgpu $O/${P}_host_overhead.log | tail -3 | cut -c1-400
 timeout 1200 python -m pytest tests -m gpu -x -q > $O/${P}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/${P}_pytest_gpu.log | cut -c1-300
 F="tests/test_gpu_linear_ops.py tests/test_gpu_functional_api.py tests/test_gpu_fullsize_oracle.py tests/test_gpu_loha_conv_ops.py tests/test_gpu_modules_golden.py"
-for i in 1 2; do
+for i in 1; do
   timeout 600 python -m pytest $F -m gpu -x -q -s > $O/${P}_five_file_order_run$i.log 2>&1; echo "five-file order run $i rc=$?"; tail -1 $O/${P}_five_file_order_run$i.log | cut -c1-200
 done

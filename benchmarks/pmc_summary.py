@@ -25,7 +25,7 @@ def load(d, counter):
 
 
 def short(name):
-    for key in ("kron4_group_kernel", "kron4_sum_kernel", "kron4_kernel", "sum_rows_kernel", "gemm16_kernel", "loha_rebuild", "loha_factor_grad", "kron_dw2f_table_kernel", "kron_dw2f_group_kernel", "kron3_kernel", "kron_dw2s_conv_group_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "copy16", "kron_kernel", "kron_dw2_kernel",
+    for key in ("kron4_group_kernel", "kron4_sum_kernel", "kron4_kernel", "bneck_group_kernel", "sum_rows_kernel", "gemm16_kernel", "loha_rebuild", "loha_factor_grad", "kron_dw2f_table_kernel", "kron_dw2f_group_kernel", "kron3_kernel", "kron_dw2s_conv_group_kernel", "kron_dw2s_kernel", "kron_dw1_reduce", "copy16", "kron_kernel", "kron_dw2_kernel",
                 "kconv_dw2_group_kernel", "kconv_kernel", "kron_pack", "bneck_kernel", "lowrank_tn_kernel", "gexp_kernel"):
         if key in name:
             return key + name.split(key)[1][:34]
@@ -41,7 +41,7 @@ FAMILIES = {  # family -> (layers of the pass it is read from, kernel-name subst
     "lokr_linear": ("linear", ("kron3_kernel", "kron4_kernel", "kron4_group_kernel", "kron4_sum_kernel", "sum_rows_kernel", "kron_dw2s_kernel", "kron_dw2s_group_kernel",
                                "kron_dw2f_table_kernel", "kron_dw2f_group_kernel", "kron_dw2f_table_write_kernel", "kron_dw1_reduce", "kron_kernel",
                                "kron_dw2_kernel", "kron_pack")),
-    "locon_linear": ("linear", ("bneck_kernel", "lowrank_tn", "skinny_", "expand_nt")),
+    "locon_linear": ("linear", ("bneck_kernel", "bneck_group_kernel", "sum_rows_kernel", "lowrank_tn", "skinny_", "expand_nt")),
     "locon_conv": ("conv", ("bneck_kernel", "lowrank_tn", "gexp_kernel", "skinny_", "expand_nt", "nchw_rows")),
     "loha_linear": ("linear", ("gemm16_kernel", "loha_rebuild", "loha_factor_grad")),
     "lokr_kconv": ("conv", ("kconv_kernel",)),
