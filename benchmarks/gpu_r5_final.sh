@@ -9,7 +9,7 @@ WORKLOADS="lokr/sdxl/linear lokr/sdxl/conv locon/sdxl/linear loha/sdxl/linear" t
 timeout 900 python bench.py > $O/${P}_bench_default.json 2> $O/${P}_bench_default.err; echo "default rc=$?"
 python - <<'PY'
 import json
-j = json.loads(open("gpurun_out/r05_final_bench_default.json").read().strip().splitlines()[-1])
+j = json.loads(open("gpurun_out/r05_final2_bench_default.json").read().strip().splitlines()[-1])
 r = j["roofline"]
 print(j["value"], j["ms_per_step"], "| frac", r["frac"], "achieved", r["achieved"], "traffic", r.get("traffic"), r.get("traffic_over_algorithmic"), "| families", r["families_ms"])
 print("conv", r.get("conv", {}).get("families_ms"), r.get("conv", {}).get("frac"), r.get("conv", {}).get("traffic"), r.get("conv", {}).get("traffic_over_algorithmic"))
