@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from lycoris_amd.modules import LokrModule
+from lycoris_amd.modules import LoConModule, LokrModule
 from lycoris_amd.modules import siblings
 
 
@@ -36,7 +36,10 @@ class Block(nn.Module):
 @pytest.fixture()
 def host_eligible(monkeypatch):
     monkeypatch.setattr(LokrModule, "_sibling_eligible",
-                        lambda self, x: self.module_type == "linear" and self.use_w1 and self.use_w2 and not self.wd
+                        lambda self, x: self.module_type == "linear" and self.use_w1 and (self.use_w2 or not self.tucker) and not self.wd
+                        and not (self.training and (self.module_dropout or self.rank_dropout)))
+    monkeypatch.setattr(LoConModule, "_sibling_eligible",
+                        lambda self, x: not self.isconv and not getattr(self, "wd", False)
                         and not (self.training and (self.module_dropout or self.rank_dropout)))
     siblings.enable(True)
     for k in ("sets", "launches", "hits", "dissolved"):
@@ -152,3 +155,39 @@ def test_not_more_than_four_members_and_only_equal_shapes(host_eligible):
         l(x)
     assert len(mods[0]._sib.members) == 4 and mods[4]._sib is not mods[0]._sib
     assert mods[6]._sib is None or all(r() is not mods[6] for r in mods[0]._sib.members)
+
+
+def test_locon_and_low_rank_lokr_modules_form_sets_of_their_own_kind(host_eligible):
+    """the mechanism is algorithm-agnostic (SiblingMixin): LoCon sets run ops.locon_linear_group, low-rank LoKr sets
+    ops.lokr_linear_lr_group; modules of different algorithms or factor shapes never share a set"""
+    torch.manual_seed(4)
+    g = torch.Generator().manual_seed(4)
+    for make in (lambda n, l: LoConModule(n, l, 1.0, 4, 2), lambda n, l: LokrModule(n, l, 1.0, 2, 1, factor=4)):
+        attn = Attn()
+        mods = []
+        for name, layer in attn.named_modules():
+            if isinstance(layer, nn.Linear):
+                m = make(name, layer)
+                with torch.no_grad():
+                    for p in m.parameters():
+                        p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+                m.apply_to()
+                mods.append(m)
+        h = torch.randn(2, 6, 64)
+        siblings.enable(False)
+        want = attn(h)
+        siblings.enable(True)
+        attn(h)
+        assert mods[0]._sib is not None and len(mods[0]._sib.members) == 3, type(mods[0]).__name__
+        before = siblings.stats()["launches"]
+        got = attn(h)
+        assert siblings.stats()["launches"] == before + 1 and torch.allclose(got, want, atol=1e-6)
+        if isinstance(mods[0], LokrModule):
+            assert not mods[0].use_w2  # rank 2 < 16 / 2: the low-rank pair
+    # a LoCon layer and a LoKr layer called with the same tensor: two different keys, no set
+    a, b = nn.Linear(64, 64), nn.Linear(64, 64)
+    ma, mb = LoConModule("a", a, 1.0, 4, 2), LokrModule("b", b, 1.0, 10000, 1, factor=4)
+    ma.apply_to(); mb.apply_to()
+    x = torch.randn(3, 64)
+    a(x); b(x)
+    assert ma._sib is None and mb._sib is None
