@@ -11,16 +11,6 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-# Round 5: the abort that one five-file test order produced in round 4 is a GPU memory fault ("Memory access fault by GPU node-2 ... on
-# address 0x7bf56ca00000", a 2 MiB boundary; profiles/r05_abort_runA.log) raised while NOTHING of this repository was enqueued: the
-# test was between its previous torch.cuda.synchronize() and the FROZEN fp32 nn.Conv2d's own backward, i.e. inside MIOpen.  A
-# second run of the same order printed MIOpen's own complaint about those layers -- "Solver <GemmBwdRest>, workspace required: 41472,
-# provided ptr: ... size: 18432" (profiles/r05_abort_runB_malloc_check.log).  The frozen layers of the module tests are tiny fp32
-# convolutions whose only role is to be "the host model's op"; keep MIOpen's GEMM-lowered solvers (the ones that ask for that
-# workspace) out of them.  Must be set before MIOpen is initialised; an explicit setting in the environment wins.
-os.environ.setdefault("MIOPEN_DEBUG_CONV_GEMM", "0")
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the round-end driver)")
 
