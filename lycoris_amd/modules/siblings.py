@@ -72,7 +72,11 @@ class SiblingSet:
 
 
 def _key(mod, x):
-    return (mod._sibling_key(), x.dtype, x.device, tuple(x.shape))
+    k = mod.__dict__.get("_sib_key_cached")
+    if k is None:  # (factor shapes never change after construction: computed once per module)
+        k = mod._sibling_key()
+        object.__setattr__(mod, "_sib_key_cached", k)
+    return (k, x.dtype, x.device, x.shape)
 
 
 def forget(mod):
