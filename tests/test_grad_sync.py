@@ -497,3 +497,45 @@ def test_communicator_path_reduce_scatter_shapes_and_unique_id_exchange(monkeypa
     assert list(st) == ["lycoris_amd/rccl_uid/1"]
     with pytest.raises(ValueError, match="store"):
         gs.RcclCommunicator(0, 2, "cuda:0")
+
+
+_FROM_ENV_WORKER = '''
+import json, os, sys, types
+import torch
+sys.path.insert(0, {root!r})
+import lycoris_amd.grad_sync as gs
+from lycoris_amd import _native
+ext = _native.load_torch_ops()                       # the real extension: ncclGetUniqueId needs no GPU
+made = []
+fake = types.SimpleNamespace(rccl_unique_id=ext.rccl_unique_id,
+                             RcclComm=lambda uid, rank, world, idx, hp, stream, cur: made.append((uid, rank, world, idx, cur)))
+_native.load_torch_ops = lambda: fake
+torch.cuda.init = lambda: None
+a = gs.RcclCommunicator.from_env("cuda:%s" % os.environ["LOCAL_RANK"], on_current_stream=True)
+b = gs.RcclCommunicator.from_env("cuda:%s" % os.environ["LOCAL_RANK"])   # a second communicator of the process: its own key, its own id
+assert (a.rank, a.world) == (int(os.environ["RANK"]), 2) and not torch.distributed.is_initialized()
+with open(os.path.join({out!r}, "rank%d.json" % a.rank), "w") as f:
+    json.dump([[m[0].hex(), m[1], m[2], m[3], m[4]] for m in made], f)
+'''
+
+
+def test_from_env_under_the_launcher_two_ranks_agree_on_the_id_without_a_process_group(tmp_path):
+    """`bench.py --gpus N` as the driver starts it (python -m torch.distributed.run ... on 127.0.0.1) with --backend rccl: the 128-byte
+    id goes from rank 0 to the others through the LAUNCHER's store (torch.distributed.rendezvous("env://")), no process group is ever
+    created.  Two real ranks, the real ncclGetUniqueId; only ncclCommInitRank (needs two GPUs) is replaced by a recorder."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(_FROM_ENV_WORKER.format(root=root, out=str(tmp_path)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r0, r1 = (json.load(open(tmp_path / f"rank{r}.json")) for r in (0, 1))
+    assert len(r0) == len(r1) == 2
+    for (u0, k0, w0, i0, c0), (u1, k1, w1, i1, c1) in zip(r0, r1):
+        assert u0 == u1 and len(bytes.fromhex(u0)) == 128 and (k0, k1, w0, w1, i0, i1) == (0, 1, 2, 2, 0, 1) and c0 == c1
+    assert r0[0][0] != r0[1][0] and r0[0][4] is True and r0[1][4] is False   # two communicators, two ids
