@@ -141,8 +141,7 @@ class LoConModule(_siblings.SiblingMixin, LycorisBaseModule):
     # ---- hot path --------------------------------------------------------------------------------------------------
     def _sibling_eligible(self, x):
         """on the plain `base + delta` path of a LoCon nn.Linear layer (what lyc_locon_linear_fwd_group takes)?"""
-        return (not self.isconv and not getattr(self, "wd", False) and x.is_cuda and not x.is_inference()
-                and x.dtype in (torch.bfloat16, torch.float16)
+        return (not self.isconv and not getattr(self, "wd", False) and _siblings.activation_ok(x)
                 and not (self.training and (self.module_dropout or self.rank_dropout or (self.bypass_mode and self.dropout))))
 
     def _sibling_key(self):

@@ -226,8 +226,7 @@ class LokrModule(_siblings.SiblingMixin, LycorisBaseModule):
     def _sibling_eligible(self, x):
         """on the plain `base + delta` path of a LoKr nn.Linear layer with a full w1 and a full-matrix or low-rank (not Tucker) w2 -- what
         lyc_lokr_linear_fwd_group takes?"""
-        return (self.module_type == "linear" and self.use_w1 and (self.use_w2 or not self.tucker) and not self.wd and x.is_cuda and not x.is_inference()
-                and x.dtype in (torch.bfloat16, torch.float16)
+        return (self.module_type == "linear" and self.use_w1 and (self.use_w2 or not self.tucker) and not self.wd and _siblings.activation_ok(x)
                 and not (self.training and (self.module_dropout or self.rank_dropout or (self.bypass_mode and self.dropout))))
 
     def _sibling_key(self):

@@ -31,13 +31,18 @@ import torch
 
 from .. import ops
 
-_STATE = {"enabled": True, "prev": None, "sets": 0, "launches": 0, "hits": 0, "dissolved": 0}
+_STATE = {"enabled": True, "autocast": False, "prev": None, "sets": 0, "launches": 0, "hits": 0, "dissolved": 0}
 MAX_SET = 4  # K4_GROUP_MAX of csrc/kron4.h
 
 
-def enable(on: bool = True):
-    """switch sibling grouping on / off (off: existing sets stay but are not used or extended)"""
+def enable(on: bool = True, autocast=None):
+    """switch sibling grouping on / off (off: existing sets stay but are not used or extended).
+    `autocast=True` additionally lets sets form on fp32 activations under a 16-bit torch.autocast (see activation_ok); OFF by default:
+    that path is written and covered on the host side, but its GPU test (tests/test_gpu_siblings.py, LYC_TEST_AUTOCAST_SIBLINGS=1) has
+    not run on an MI355X yet -- round 5 ended before it could."""
     _STATE["enabled"] = bool(on)
+    if autocast is not None:
+        _STATE["autocast"] = bool(autocast)
     _STATE["prev"] = None
 
 
@@ -71,12 +76,28 @@ class SiblingSet:
         _STATE["dissolved"] += 1
 
 
+_SIXTEEN = (torch.bfloat16, torch.float16)
+
+
+def activation_ok(x) -> bool:
+    """a 16-bit HIP activation -- or, with enable(autocast=True), an fp32 one under a 16-bit torch.autocast: sd-scripts' mixed-precision
+    training hands the fp32 output of a LayerNorm to to_q / to_k / to_v, and the reference's F.linear runs in the autocast dtype
+    (modules/lokr.py:543-566 under autocast).  The grouped ops cast it ONCE for the whole set (csrc/torch_ops.cpp amp(x)), the
+    per-layer ops once per projection."""
+    if not x.is_cuda or x.is_inference():
+        return False
+    if x.dtype in _SIXTEEN:
+        return True
+    return (_STATE["autocast"] and x.dtype == torch.float32 and torch.is_autocast_enabled("cuda")
+            and torch.get_autocast_dtype("cuda") in _SIXTEEN)
+
+
 def _key(mod, x):
     k = mod.__dict__.get("_sib_key_cached")
     if k is None:  # (factor shapes never change after construction: computed once per module)
         k = mod._sibling_key()
         object.__setattr__(mod, "_sib_key_cached", k)
-    return (k, x.dtype, x.device, x.shape)
+    return (k, x.dtype, x.device, x.shape, torch.get_autocast_dtype("cuda") if (x.dtype == torch.float32 and x.is_cuda) else None)
 
 
 def forget(mod):

@@ -6,6 +6,8 @@
     the first forward pass (modules/siblings.py) and from the second pass on run them as grouped launches -- same bits in the
     outputs, same gradients, fewer launches.
 Reference call sites: one LokrModule.forward per projection, lycoris/modules/lokr.py:543-566."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -335,3 +337,80 @@ def test_adapted_attention_block_groups_its_projections_with_identical_results(d
     check(f"sibling_modules[{dtype},{rank}]", errs, bounds)
     for m in mods:
         m.restore()
+
+
+class NormedAttn(nn.Module):
+    """diffusers' BasicTransformerBlock in small: attn(norm(h)) -- under torch.autocast the LayerNorm's output is fp32"""
+
+    def __init__(self, d=1280):
+        super().__init__()
+        self.norm, self.attn = nn.LayerNorm(d), Attn(d, d)
+
+    def forward(self, h):
+        return h + self.attn(self.norm(h))
+
+
+@pytest.mark.skipif(not os.environ.get("LYC_TEST_AUTOCAST_SIBLINGS"),
+                    reason="opt-in path (siblings.enable(autocast=True)): not yet run on an MI355X; set LYC_TEST_AUTOCAST_SIBLINGS=1")
+@pytest.mark.parametrize("rank", [10000, -16], ids=["lokr_full_matrix", "locon_rank16"])
+@pytest.mark.parametrize("layer_dtype", [torch.float32, torch.bfloat16], ids=["layers_f32", "layers_bf16"])
+def test_sibling_sets_under_autocast_take_the_fp32_output_of_a_layernorm(layer_dtype, rank):
+    """sd-scripts mixed precision (tests/test_gpu_autocast.py for the single layer): fp32 adapter parameters, the frozen block under
+    torch.autocast(bf16), to_q / to_k / to_v called with the fp32 output of a LayerNorm.  The set forms on that fp32 tensor, the
+    grouped op casts it once (the per-layer ops: once per projection); outputs are the same bits as the per-layer path."""
+    from lycoris_amd.modules import LoConModule
+    torch.manual_seed(0)
+    block = NormedAttn().to(DEV, layer_dtype).requires_grad_(False)
+    gen = torch.Generator().manual_seed(2)
+    mods = []
+    for name, layer in block.named_modules():
+        if isinstance(layer, nn.Linear):
+            if rank < 0:
+                m = LoConModule(name.replace(".", "_"), layer, 1.0, -rank, 1).to(DEV)
+                tgt = m.lora_up.weight
+            else:
+                m = LokrModule(name.replace(".", "_"), layer, 1.0, rank, 1, factor=8).to(DEV)
+                tgt = m.lokr_w2
+            with torch.no_grad():
+                tgt.copy_((torch.randn(tgt.shape, generator=gen) * 0.05).to(DEV))
+            m.apply_to()
+            mods.append(m)
+    params = [p for m in mods for p in m.parameters()]
+    h0 = (torch.randn(1, 512, 1280, generator=gen) * 0.5).to(DEV)            # fp32 activations, as out of the fp32 residual stream
+    gout = (torch.randn(1, 512, 1280, generator=gen) * 0.05).to(DEV)
+
+    def run():
+        h = h0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = block(h)
+        grads = torch.autograd.grad(y, [h] + params, gout)
+        torch.cuda.synchronize()
+        return y.detach().clone(), [g.clone() for g in grads]
+
+    for k in ("sets", "launches", "hits", "dissolved"):
+        siblings._STATE[k] = 0
+    siblings.enable(False)
+    want = run()
+    try:
+        siblings.enable(True, autocast=True)
+        run()  # learning pass
+        q = {m.lora_name: m for m in mods}["attn_to_q"]
+        assert q._sib is not None and [r().lora_name for r in q._sib.members] == ["attn_to_q", "attn_to_k", "attn_to_v"]
+        got = run()
+        st = siblings.stats()
+        assert st["launches"] == 1 and st["hits"] == 2 and st["dissolved"] == 0, st
+        assert got[0].dtype == want[0].dtype and torch.equal(got[0], want[0])
+        errs = {"dh": float((got[1][0].float() - want[1][0].float()).norm() / want[1][0].float().norm())}
+        bounds = {"dh": 3 * TOL["store_out"][torch.bfloat16]}
+        for i, (a_, b_) in enumerate(zip(got[1][1:], want[1][1:])):
+            errs[f"g{i}"] = float((a_ - b_).norm() / (b_.norm() + 1e-30))
+            bounds[f"g{i}"] = 2e-3
+        check(f"sibling_modules_autocast[{layer_dtype},{rank}]", errs, bounds)
+        # outside autocast the same fp32 tensor is not a 16-bit activation: per-layer path, the set is kept for the next autocast pass
+        h = h0.clone()
+        y32 = block(h) if layer_dtype == torch.float32 else None
+        assert siblings.stats()["launches"] == 1 and (y32 is None or y32.dtype == torch.float32)
+        for m in mods:
+            m.restore()
+    finally:
+        siblings.enable(True, autocast=False)

@@ -191,3 +191,22 @@ def test_locon_and_low_rank_lokr_modules_form_sets_of_their_own_kind(host_eligib
     x = torch.randn(3, 64)
     a(x); b(x)
     assert ma._sib is None and mb._sib is None
+
+
+def test_fp32_activations_under_autocast_are_an_opt_in():
+    """siblings.enable(autocast=True): the eligibility test of the GPU path (activation_ok) -- host tensors never qualify, the flag is
+    off by default and survives enable(True) / enable(False) unless named"""
+    x = torch.randn(4, 64)
+    assert siblings._STATE["autocast"] is False and not siblings.activation_ok(x) and not siblings.activation_ok(x.bfloat16())
+    try:
+        siblings.enable(True, autocast=True)
+        assert siblings._STATE["autocast"] is True
+        siblings.enable(False)
+        siblings.enable(True)
+        assert siblings._STATE["autocast"] is True and not siblings.activation_ok(x)   # (a host tensor all the same)
+        # the set key tells autocast dtypes apart only for fp32 HIP tensors
+        m = LokrModule("k", nn.Linear(64, 64), 1.0, 10000, 1, factor=4)
+        assert siblings._key(m, x)[-1] is None
+    finally:
+        siblings.enable(True, autocast=False)
+    assert siblings._STATE["autocast"] is False
