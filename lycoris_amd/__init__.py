@@ -1,7 +1,7 @@
 """lycoris_amd -- MI355X (gfx950) native forward/backward for the LyCORIS adapter hot path.
 
-Scope: LoCon / LoHa / LoKr / (IA)^3 on nn.Linear and nn.Conv2d, forward + backward, plus the
-data-parallel adapter-gradient all-reduce.  Everything else of LyCORIS (wrappers, presets, tools) stays upstream:
+Scope: LoCon / LoHa / LoKr / (IA)^3 on nn.Linear and nn.Conv2d (nn.Conv1d through its Conv2d twin), forward + backward,
+plus the data-parallel adapter-gradient all-reduce; nn.Conv3d in the reference's rebuild form with ATen ops (no kernel).  Everything else of LyCORIS (wrappers, presets, tools) stays upstream:
 ``install()`` plugs the native module classes into the reference's own registries so ``create_lycoris`` /
 ``lycoris.kohya.create_network`` build native adapters without any change to the caller.
 """
@@ -26,9 +26,10 @@ def install(strict: bool = True) -> bool:
     Returns False (or raises when ``strict``) if the upstream ``lycoris`` package is not importable.  Presets and
     every other piece of upstream state are left untouched.  ``uninstall()`` restores the previous bindings.
 
-    A variant outside the native path (``use_tucker`` on k>1 convolutions, Conv1d/Conv3d, grouped convolutions)
-    raises NotImplementedError when the network is built -- nothing falls back silently, and there is no delegation to
-    the reference's torch implementation.
+    A variant outside the covered set (grouped convolutions, non-zero padding modes, torch parametrize integration) raises
+    NotImplementedError when the network is built -- nothing falls back silently, and there is no delegation to the reference's
+    torch implementation.  nn.Conv3d layers are adapted by these same classes, evaluated as ``F.conv3d(x, dW)`` with ATen ops
+    (modules/base.py ``_aten_only``).
     """
     try:
         import lycoris.modules as ref_modules

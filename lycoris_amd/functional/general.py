@@ -28,6 +28,14 @@ def factorization(dimension: int, factor: int = -1) -> tuple[int, int]:
     return (min(small, large), max(small, large))
 
 
+def conv3d_aten(x: torch.Tensor, dw: torch.Tensor, extra_args: dict | None) -> torch.Tensor:
+    """F.conv3d(x, dW): the reference's own evaluation for 5-D weights (FUNC_LIST[weight.dim()], functional/general.py:6), ATen ops on
+    any device -- SURVEY 8a row a2 keeps Conv3d off the kernels.  Promoted dtype, one rounding to x's (composite.py's rule)."""
+    ea = {k: v for k, v in (extra_args or {}).items() if k in ("stride", "padding", "dilation", "groups")}
+    ct = torch.promote_types(x.dtype, dw.dtype)
+    return torch.nn.functional.conv3d(x.to(ct), dw.to(ct), None, **ea).to(x.dtype)
+
+
 def rebuild_tucker(t: torch.Tensor, wa: torch.Tensor, wb: torch.Tensor) -> torch.Tensor:
     """W[p, q, ...] = sum_ij t[i, j, ...] wa[i, p] wb[j, q]  (functional/general.py:9-11) = wa^T @ fold(t, wb): on the device the
     fold is the tucker_core kernel (csrc/tucker.h, differentiable); CPU tensors (offline tools) take the einsum."""

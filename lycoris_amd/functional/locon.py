@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .general import conv_args, rebuild_tucker
+from .general import conv3d_aten, conv_args, rebuild_tucker
 
 
 def weight_gen(org_weight: torch.Tensor, rank: int, tucker: bool = True):
@@ -43,6 +43,8 @@ def diff_weight(*weights, gamma=1.0):
 def bypass_forward_diff(x, org_out, *weights, gamma=1.0, extra_args={}):
     """delta = up(down(x)) * gamma on the HIP path (functional/locon.py:64-85).  ``org_out`` is unused, as upstream."""
     down, up, mid = weights
+    if down.dim() == 5:  # nn.Conv3d weights: F.conv3d(x, dW) in ATen ops
+        return conv3d_aten(x, diff_weight(down, up, mid, gamma=gamma), extra_args)
     if mid is not None:  # conv-CP form: fold the k x k core into the 1x1 down-projection (csrc/tucker.h), then the plain path
         down = ops.tucker_core(mid, down)
     if down.dim() == 2:

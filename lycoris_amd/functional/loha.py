@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .general import conv_args
+from .general import conv3d_aten, conv_args
 
 
 def weight_gen(org_weight: torch.Tensor, rank: int, tucker: bool = True):
@@ -44,7 +44,7 @@ def diff_weight(*weights, gamma=1.0):
     w1d, w1u, w2d, w2u, t1, t2 = weights
     if t1 is not None:  # HadaWeightTucker (functional/loha.py:33-75): rebuild_k = w_k_u^T @ fold(t_k, w_k_d)
         rank, out_dim = w1u.shape
-        fold = lambda t, wd: torch.einsum("ijhw,jq->iqhw", t, wd) if not t.is_cuda else ops.tucker_core(t, wd)
+        fold = lambda t, wd: torch.einsum("ij...,jq->iq...", t, wd) if (not t.is_cuda or t.dim() != 4) else ops.tucker_core(t, wd)
         dw = (w1u.t() @ fold(t1, w1d).flatten(1)) * (w2u.t() @ fold(t2, w2d).flatten(1))
         return (dw * gamma).reshape(out_dim, w1d.shape[1], *t1.shape[2:])
     rank = w1d.shape[0]
@@ -57,6 +57,10 @@ def bypass_forward_diff(x, org_out, *weights, gamma=1.0, extra_args={}):
     """delta = op(x, dW) with dW rebuilt tile-by-tile on chip (functional/loha.py:150-165; works, unlike upstream D2)."""
     w1d, w1u, w2d, w2u, t1, t2 = weights
     g = _gamma_value(gamma)
+    shape5 = extra_args.get("_conv_shape") if len(extra_args.get("_conv_shape") or ()) == 5 else None
+    if (t1 is not None and t1.dim() == 5) or w1d.dim() == 5 or shape5:  # nn.Conv3d weights: F.conv3d(x, dW) in ATen ops
+        dw = diff_weight(w1d, w1u, w2d, w2u, t1, t2, gamma=gamma)  # (gamma may be a tensor: autograd-visible here)
+        return conv3d_aten(x, dw.reshape(shape5) if shape5 else dw, extra_args)
     if t1 is not None:  # Tucker: the plain form on (w_u^T, fold(t, w_d)), cores folded by csrc/tucker.h
         shape = (w1u.shape[1], w1d.shape[1], *t1.shape[2:])
         stride, padding, dilation = conv_args({k: v for k, v in extra_args.items() if not k.startswith("_")})

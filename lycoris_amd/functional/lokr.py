@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .general import conv_args, factorization
+from .general import conv3d_aten, conv_args, factorization
 
 
 def weight_gen(org_weight, rank, tucker=True, factor=-1, decompose_both=False, full_matrix=False,
@@ -66,7 +66,7 @@ def _resolve(weights, gamma):
     if w2 is not None:
         f2 = w2
     elif t is not None:  # rebuild_tucker(t, w2a, w2b) = w2a^T @ fold(t, w2b)   (functional/general.py:9-11, csrc/tucker.h)
-        fold = ops.tucker_core(t, w2b) if t.is_cuda else torch.einsum("ijhw,jq->iqhw", t, w2b)
+        fold = ops.tucker_core(t, w2b) if (t.is_cuda and t.dim() == 4) else torch.einsum("ij...,jq->iq...", t, w2b)
         f2 = (w2a.t() @ fold.flatten(1)).reshape(w2a.shape[1], w2b.shape[1], *t.shape[2:])
     else:
         f2 = (w2a @ w2b.reshape(w2b.shape[0], -1)).reshape(w2a.shape[0], *w2b.shape[1:])
@@ -95,4 +95,6 @@ def bypass_forward_diff(h, org_out, *weights, gamma=1.0, extra_args={}):
     if f2.dim() == 4:
         stride, padding, dilation = conv_args(extra_args)
         return ops.lokr_conv2d(h, f1, f2, scale, stride, padding, dilation)
-    raise NotImplementedError("lycoris_amd: LoKr native path covers Linear and Conv2d")
+    if f2.dim() == 5:  # nn.Conv3d weights: F.conv3d(x, kron(w1, w2)) in ATen ops
+        return conv3d_aten(h, make_kron(f1, f2, scale), extra_args)
+    raise NotImplementedError("lycoris_amd: LoKr covers Linear, Conv2d (kernels) and Conv3d (ATen)")

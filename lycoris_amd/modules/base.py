@@ -103,6 +103,10 @@ class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
     support_module: set = set()
     weight_list: list = []
     weight_list_det: list = []
+    # nn.Conv3d ("Linear + Conv2d native; Conv1d / 3d -> reference fallback"): the adapter is evaluated in the
+    # reference's own rebuild form, delta = F.conv3d(x, dW), with ATen ops on whatever device the tensors live on -- no HIP kernel,
+    # no weight-space kernels (modules/base.py:89-158 kw_dict dispatch, functional/general.py:6 FUNC_LIST)
+    _aten_only = False
 
     def __init__(self, lora_name, org_module: nn.Module, multiplier=1.0, dropout=0.0, rank_dropout=0.0,
                  module_dropout=0.0, rank_dropout_scale=False, bypass_mode=None, **kwargs):
@@ -133,6 +137,12 @@ class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
                 conv_args(self.kw_dict)
                 if getattr(org_module, "padding_mode", "zeros") != "zeros":
                     raise _unsupported(f"Conv2d padding_mode={org_module.padding_mode!r}")
+            if nd == 3:
+                if org_module.groups != 1:
+                    raise _unsupported("grouped nn.Conv3d layers")
+                if getattr(org_module, "padding_mode", "zeros") != "zeros":
+                    raise _unsupported(f"Conv3d padding_mode={org_module.padding_mode!r}")
+                self._aten_only = True
         elif isinstance(org_module, nn.LayerNorm):
             self.module_type = "layernorm"
             self.shape = tuple(org_module.normalized_shape)
@@ -362,7 +372,7 @@ class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
         raise NotImplementedError
 
     def _native_ws(self):
-        return self._ws_algo is not None and self.org_weight.is_cuda and next(self.parameters()).is_cuda
+        return self._ws_algo is not None and not self._aten_only and self.org_weight.is_cuda and next(self.parameters()).is_cuda
 
     def get_diff_weight(self, multiplier=1.0, shape=None, device=None):
         raise NotImplementedError
@@ -542,6 +552,8 @@ class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
         ignores it on the rebuild path and for LoHa / LoKr)."""
         if self.module_dropout and self.training and float(torch.rand(1)) < self.module_dropout:
             return self.org_forward(x, *args, **kwargs)
+        if self._aten_only:
+            return self._forward_aten(x, *args, **kwargs)
         # upstream consults bypass_mode first (modules/lokr.py:548-549, locon.py / loha.py alike): in bypass mode -- forced for
         # quantised base layers -- weight_decompose is ignored and the base weight is never read
         if getattr(self, "wd", False) and not self.bypass_mode:
@@ -557,6 +569,30 @@ class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
             from .. import ops
             chan_dim = 1 if self.module_type.startswith("conv") else -1
             delta = ops.chan_affine(delta.contiguous(), self._rank_dropout_mask(delta), None, 0.0, 1.0, chan_dim)
+        if self.bypass_mode and self.training and self.name in ("locon", "lora"):
+            delta = self.drop(delta)
+        return base + delta
+
+    # ---- nn.Conv3d: the reference's rebuild form in ATen ops (any device) -------------------------------------------------------
+    def _delta_aten(self, x, scale=1.0, dw=None):
+        """op(x, dW * scale) in the promoted dtype, rounded once to x's (locon.py:321-331 casts dW to the base weight's dtype first;
+        composite.py's rule -- one rounding -- is the tighter of the two)"""
+        if dw is None:
+            dw = self.get_diff_weight(scale, tuple(self.shape))[0]
+        ct = torch.promote_types(x.dtype, dw.dtype)
+        return self.op(x.to(ct), dw.to(ct), None, **self.kw_dict).to(x.dtype)
+
+    def _forward_aten(self, x, *args, **kwargs):
+        from .. import composite
+        base = self.org_forward(x, *args, **kwargs)
+        if getattr(self, "wd", False) and not self.bypass_mode:  # op(x, decompose(W + dW) - W)   (locon.py:318-332, apply_weight_decompose)
+            W = self._current_weight()
+            dw = self.get_diff_weight(1.0, tuple(W.shape))[0]
+            merged = self._dora_merge_host(W.to(torch.promote_types(W.dtype, dw.dtype)) + dw, self.multiplier)
+            return base + self._delta_aten(x, dw=merged - W)
+        delta = self.bypass_forward_diff(x, scale=self.multiplier)
+        if self.rank_dropout and self.training:
+            delta = composite.chan_affine(delta, self._rank_dropout_mask(delta), None, 0.0, 1.0, 1)
         if self.bypass_mode and self.training and self.name in ("locon", "lora"):
             delta = self.drop(delta)
         return base + delta

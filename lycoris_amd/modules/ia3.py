@@ -21,12 +21,12 @@ class IA3Module(LycorisBaseModule):
                          rank_dropout_scale, bypass_mode)
         if self.module_type not in self.support_module:
             raise ValueError(f"{self.module_type} is not supported in IA^3 algo.")
-        if self.module_type in ("conv1d", "conv3d"):
+        if self.module_type == "conv1d":  # (an nn.Conv1d layer arrives here as its Conv2d twin, base.py _TwinMeta)
             raise _unsupported(f"(IA)^3 on {self.module_type}")
-        self.isconv = self.module_type == "conv2d"
+        self.isconv = self.module_type in ("conv2d", "conv3d")
         train_dim = self.shape[1] if train_on_input else self.shape[0]
         if self.isconv:
-            self.weight = nn.Parameter(torch.zeros(1, train_dim, 1, 1))
+            self.weight = nn.Parameter(torch.zeros(1, train_dim, *(1 for _ in self.shape[2:])))  # ia3.py:59-62
         else:
             self.weight = nn.Parameter(torch.zeros(train_dim))
         self.train_input = train_on_input
@@ -56,22 +56,28 @@ class IA3Module(LycorisBaseModule):
         return self.make_weight(multiplier, shape, device), None
 
     # ---- hot path --------------------------------------------------------------------------------------------------
+    def _chan_affine(self, *args):
+        if self._aten_only:  # nn.Conv3d: ATen ops on any device (base.py _aten_only)
+            from .. import composite
+            return composite.chan_affine(*args)
+        return ops.chan_affine(*args)
+
     def bypass_forward_diff(self, x, scale=1):
         """op(x, W * (w*scale)) -- rebuild-path semantics: the layer bias is NOT scaled (ia3.py:91-102 vs the
         upstream bypass :114-121 which scales it)."""
         chan = 1 if self.isconv else -1
         if self.train_input:
-            xs = ops.chan_affine(x, self.weight, None, 0.0, scale, chan)
+            xs = self._chan_affine(x, self.weight, None, 0.0, scale, chan)
             return self.op(xs, self._current_weight(), None, **self.kw_dict)
         base_nobias = self.op(x, self._current_weight(), None, **self.kw_dict)
-        return ops.chan_affine(base_nobias, self.weight, None, 0.0, scale, chan)
+        return self._chan_affine(base_nobias, self.weight, None, 0.0, scale, chan)
 
     def forward(self, x, *args, **kwargs):
         base = self.org_forward(x, *args, **kwargs)
         chan = 1 if self.isconv else -1
         if self.train_input:
             # the dense op on the scaled input stays with rocBLAS / MIOpen (it is the frozen layer's own GEMM shape)
-            xs = ops.chan_affine(x, self.weight, None, 0.0, self.multiplier, chan)
+            xs = self._chan_affine(x, self.weight, None, 0.0, self.multiplier, chan)
             return base + self.op(xs, self._current_weight(), None, **self.kw_dict)
         # out-side: delta = (base - bias) * w*mult, fused as  y = base * (1 + w*mult) - bias * w*mult
-        return ops.chan_affine(base, self.weight, self._current_bias(), 1.0, self.multiplier, chan)
+        return self._chan_affine(base, self.weight, self._current_bias(), 1.0, self.multiplier, chan)

@@ -30,7 +30,7 @@ class LoConModule(_siblings.SiblingMixin, LycorisBaseModule):
                          rank_dropout_scale, bypass_mode)
         if self.module_type not in self.support_module:
             raise ValueError(f"{self.module_type} is not supported in LoRA/LoCon algo.")
-        if self.module_type in ("conv1d", "conv3d"):
+        if self.module_type == "conv1d":  # (an nn.Conv1d layer arrives here as its Conv2d twin, base.py _TwinMeta)
             raise _unsupported(f"LoCon on {self.module_type}")
         if weight_decompose and rank_dropout:
             raise _unsupported("rank_dropout together with weight_decompose")
@@ -38,17 +38,18 @@ class LoConModule(_siblings.SiblingMixin, LycorisBaseModule):
         self.rs_lora = rs_lora
         self._init_dora(org_module, weight_decompose, wd_on_out)
         self.tucker = False
-        if self.module_type == "conv2d":
+        if self.module_type in ("conv2d", "conv3d"):
             self.isconv = True
+            conv = nn.Conv3d if self.module_type == "conv3d" else nn.Conv2d  # (locon.py:74-95: `self.module(...)`)
             k = org_module.kernel_size
             self.tucker = bool(use_tucker) and any(i != 1 for i in k)
             if self.tucker:  # conv-CP form (locon.py:85-90): 1x1 down, k x k core r -> r, 1x1 up
-                self.lora_down = nn.Conv2d(org_module.in_channels, lora_dim, 1, bias=False)
-                self.lora_mid = nn.Conv2d(lora_dim, lora_dim, k, org_module.stride, org_module.padding, bias=False)
+                self.lora_down = conv(org_module.in_channels, lora_dim, 1, bias=False)
+                self.lora_mid = conv(lora_dim, lora_dim, k, org_module.stride, org_module.padding, bias=False)
             else:
-                self.lora_down = nn.Conv2d(org_module.in_channels, lora_dim, k, org_module.stride, org_module.padding,
-                                           bias=False)
-            self.lora_up = nn.Conv2d(lora_dim, org_module.out_channels, 1, bias=False)
+                self.lora_down = conv(org_module.in_channels, lora_dim, k, org_module.stride, org_module.padding,
+                                      bias=False)
+            self.lora_up = conv(lora_dim, org_module.out_channels, 1, bias=False)
         else:
             self.isconv = False
             self.lora_down = nn.Linear(org_module.in_features, lora_dim, bias=False)
@@ -89,9 +90,9 @@ class LoConModule(_siblings.SiblingMixin, LycorisBaseModule):
         core folded into the 1x1 down-projection (up(mid(down(x))) == up(conv(x, mid o down)): csrc/tucker.h)"""
         if not self.tucker:
             return self.lora_down.weight
-        if self.lora_mid.weight.is_cuda:
+        if self.lora_mid.weight.is_cuda and not self._aten_only:
             return ops.tucker_core(self.lora_mid.weight, self.lora_down.weight)
-        return torch.einsum("ijhw,jq->iqhw", self.lora_mid.weight, self.lora_down.weight.flatten(1))  # offline / CPU
+        return torch.einsum("ij...,jq->iq...", self.lora_mid.weight, self.lora_down.weight.flatten(1))  # offline / CPU / Conv3d
 
     def _ws_factors(self, gated=True):
         return (self._down_eff(), self._gate(self.lora_up.weight) if gated else self.lora_up.weight)
@@ -159,5 +160,7 @@ class LoConModule(_siblings.SiblingMixin, LycorisBaseModule):
         up = self._gate(self.lora_up.weight)
         if not self.isconv:
             return ops.locon_linear(x, self.lora_down.weight, up, alpha)
+        if self._aten_only:  # nn.Conv3d: F.conv3d(x, dW) in ATen ops
+            return self._delta_aten(x, scale)
         stride, padding, dilation = conv_args(self.kw_dict)
         return ops.locon_conv2d(x, self._down_eff(), up, alpha, stride, padding, dilation)

@@ -1,6 +1,8 @@
 """LoHa adapter module on the native path (interface of lycoris/modules/loha.py)."""
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.nn as nn
 
@@ -23,7 +25,7 @@ class LohaModule(LycorisBaseModule):
                          rank_dropout_scale, bypass_mode)
         if self.module_type not in self.support_module:
             raise ValueError(f"{self.module_type} is not supported in LoHa algo.")
-        if self.module_type in ("conv1d", "conv3d"):
+        if self.module_type == "conv1d":  # (an nn.Conv1d layer arrives here as its Conv2d twin, base.py _TwinMeta)
             raise _unsupported(f"LoHa on {self.module_type}")
         if weight_decompose and rank_dropout:
             raise _unsupported("rank_dropout together with weight_decompose")
@@ -32,10 +34,10 @@ class LohaModule(LycorisBaseModule):
         self._init_dora(org_module, weight_decompose, wd_on_out)
         self.tucker = False
         out_dim, in_flat = self.shape[0], self.shape[1]
-        if self.module_type == "conv2d":
+        if self.module_type in ("conv2d", "conv3d"):
             k = org_module.kernel_size
             self.tucker = bool(use_tucker) and any(i != 1 for i in k)
-            in_flat = self.shape[1] * k[0] * k[1]  # non-Tucker conv factors are [r, I*kh*kw] (loha.py:76)
+            in_flat = self.shape[1] * math.prod(k)  # non-Tucker conv factors are [r, I*kh*kw] (loha.py:76)
         if self.tucker:  # loha.py:78-93: cores [r, r, kh, kw], a-side [r, O] ("1-mode"), b-side [r, I] ("2-mode")
             self.hada_t1 = nn.Parameter(torch.empty(lora_dim, lora_dim, *self.shape[2:]))
             self.hada_w1_a = nn.Parameter(torch.empty(lora_dim, out_dim))
@@ -84,9 +86,9 @@ class LohaModule(LycorisBaseModule):
         return sd
 
     def _fold(self, t, wb):
-        if t.is_cuda:
+        if t.is_cuda and not self._aten_only:
             return ops.tucker_core(t, wb).flatten(1)
-        return torch.einsum("ijhw,jq->iqhw", t, wb).flatten(1)  # offline / CPU
+        return torch.einsum("ij...,jq->iq...", t, wb).flatten(1)  # offline / CPU / Conv3d
 
     def _ws_factors(self, gated=True):
         """(w1a [O, r], w1b [r, I*kh*kw], w2a, w2b) as the kernels take them.  Tucker (HadaWeightTucker, functional/loha.py:
@@ -144,5 +146,7 @@ class LohaModule(LycorisBaseModule):
         w1a, w1b, w2a, w2b = self._ws_factors()
         if self.module_type == "linear":
             return ops.loha_linear(x, w1a, w1b, w2a, w2b, alpha)
+        if self._aten_only:  # nn.Conv3d: F.conv3d(x, dW) in ATen ops
+            return self._delta_aten(x, scale)
         stride, padding, dilation = conv_args(self.kw_dict)
         return ops.loha_conv2d(x, w1a, w1b, w2a, w2b, alpha, tuple(self.shape), stride, padding, dilation)

@@ -44,7 +44,7 @@ class LokrModule(_siblings.SiblingMixin, LycorisBaseModule):
                          rank_dropout_scale, bypass_mode)
         if self.module_type not in self.support_module:
             raise ValueError(f"{self.module_type} is not supported in LoKr algo.")
-        if self.module_type in ("conv1d", "conv3d"):
+        if self.module_type == "conv1d":  # (an nn.Conv1d layer arrives here as its Conv2d twin, base.py _TwinMeta)
             raise _unsupported(f"LoKr on {self.module_type}")
         if weight_decompose and rank_dropout:
             raise _unsupported("rank_dropout together with weight_decompose")
@@ -54,7 +54,7 @@ class LokrModule(_siblings.SiblingMixin, LycorisBaseModule):
         self.rs_lora = rs_lora
         self._init_dora(org_module, weight_decompose, wd_on_out)
         self.tucker = False
-        is_conv = self.module_type == "conv2d"
+        is_conv = self.module_type in ("conv2d", "conv3d")
         out_dim, in_dim = self.shape[0], self.shape[1]
         ksize = tuple(self.shape[2:])
         in_m, in_n = factorization(in_dim, factor)
@@ -174,10 +174,10 @@ class LokrModule(_siblings.SiblingMixin, LycorisBaseModule):
             return self.lokr_w2
         out_k, in_n = self._kron_dims[2], self._kron_dims[3]
         if self.tucker:  # rebuild_tucker(t2, w2_a, w2_b) = w2_a^T @ fold(t2, w2_b)   (general.py:9-11, csrc/tucker.h)
-            if self.lokr_t2.is_cuda:
+            if self.lokr_t2.is_cuda and not self._aten_only:
                 fold = ops.tucker_core(self.lokr_t2, self.lokr_w2_b)
             else:
-                fold = torch.einsum("ijhw,jq->iqhw", self.lokr_t2, self.lokr_w2_b)  # offline / CPU
+                fold = torch.einsum("ij...,jq->iq...", self.lokr_t2, self.lokr_w2_b)  # offline / CPU / Conv3d
             return (self.lokr_w2_a.t() @ fold.flatten(1)).reshape(out_k, in_n, *self.shape[2:])
         return (self.lokr_w2_a @ self.lokr_w2_b).reshape(out_k, in_n, *self.shape[2:])
 
@@ -269,6 +269,8 @@ class LokrModule(_siblings.SiblingMixin, LycorisBaseModule):
         Unlike upstream's bypass (lokr.py:538) this includes ``self.scale``, i.e. it equals the rebuild
         path lokr.py:543-566, which is the canonical semantics."""
         alpha = self.scale * scale
+        if self._aten_only:  # nn.Conv3d: F.conv3d(x, kron(w1, w2)) in ATen ops
+            return self._delta_aten(h, scale)
         if self._w2_low_rank_native(h) and not self.use_w1:
             return ops.lokr_linear_lr2(h, self._gate(self.lokr_w1_a), self.lokr_w1_b, self.lokr_w2_a, self.lokr_w2_b, alpha)
         w1 = self._gate(self._w1_full())

@@ -80,7 +80,8 @@ def numeric_case(name, algo, layer_kw, mod_kw, xshape, seed, multiplier=0.7):
         ps = dict(params)
         dw = (rebuild_tucker(ps["hada_t1"], ps["hada_w1_a"], ps["hada_w1_b"])
               * rebuild_tucker(ps["hada_t2"], ps["hada_w2_a"], ps["hada_w2_b"]) * mod.scale * multiplier)
-        y2 = torch.nn.functional.conv2d(x, dw, None, layer.stride, layer.padding, layer.dilation)
+        conv = torch.nn.functional.conv3d if x.dim() == 5 else torch.nn.functional.conv2d
+        y2 = conv(x, dw, None, layer.stride, layer.padding, layer.dilation)
         assert torch.allclose(y2, (out - base).detach(), atol=1e-10)
         ga, gb = torch.autograd.grad((y2 * g).sum(), [ps["hada_w1_a"], ps["hada_w2_a"]])
         rec["gtrue.hada_w1_a"], rec["gtrue.hada_w2_a"] = ga, gb

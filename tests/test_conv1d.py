@@ -4,7 +4,7 @@ The adapter kernels are Conv2d kernels; a native module adapts an nn.Conv1d laye
 (`modules/base.py: _Conv1dTwin`: [B, C, L] <-> [B, C, 1, L], a 1 x k window, parameters shared as live views).  What must hold
 and is checked here on the CPU: checkpoints have the reference's Conv1d keys and shapes, load in both directions with equal
 dW, the REAL layer's forward is what gets patched / restored, the twin follows the real layer's parameters.  The numerics on the
-GPU are tests/test_gpu_conv1d.py.  Conv3d still raises when the network is built."""
+GPU are tests/test_gpu_conv1d.py.  Conv3d layers take the ATen form (tests/test_conv3d.py)."""
 import os
 import sys
 import types
@@ -28,7 +28,7 @@ def _layer():
     return nn.Conv1d(64, 128, 3, stride=2, padding=1)
 
 
-def test_conv1d_modules_build_with_conv1d_checkpoint_shapes_and_conv3d_still_raises():
+def test_conv1d_modules_build_with_conv1d_checkpoint_shapes_and_conv3d_takes_the_aten_form():
     layer = _layer()
     m = LoConModule("t", layer, 1.0, lora_dim=4, alpha=2)
     sd = m.state_dict()
@@ -37,8 +37,8 @@ def test_conv1d_modules_build_with_conv1d_checkpoint_shapes_and_conv3d_still_rai
     assert m.kw_dict["stride"] == (1, 2) and m.kw_dict["padding"] == (0, 1)
     m = LokrModule("t", layer, 1.0, lora_dim=100000, alpha=1, factor=8)
     assert tuple(m.state_dict()["lokr_w2"].shape) == (16, 8, 3)
-    with pytest.raises(NotImplementedError):
-        LoConModule("t", nn.Conv3d(8, 8, 3), 1.0, 2, 1)
+    m3 = LoConModule("t", nn.Conv3d(8, 8, 3), 1.0, 2, 1)   # no twin, no kernel: the reference's rebuild form in ATen ops (tests/test_conv3d.py)
+    assert m3._aten_only and m3._conv1d is None and tuple(m3.lora_down.weight.shape) == (2, 8, 3, 3, 3) and not m._aten_only
 
 
 def test_the_real_layer_is_patched_and_the_twin_follows_its_parameters():

@@ -194,8 +194,10 @@ def test_host_tensors_run_and_unsupported_features_fail_loudly():
     m = LoConModule("m", nn.Conv2d(8, 8, 3), 1.0, 2, 1, use_tucker=True)
     assert m.tucker and tuple(m.lora_mid.weight.shape) == (2, 2, 3, 3) and tuple(m.lora_down.weight.shape) == (2, 8, 1, 1)
     assert not LoConModule("m", nn.Conv2d(8, 8, 1), 1.0, 2, 1, use_tucker=True).tucker      # 1x1: nothing to factor
+    m = LohaModule("m", nn.Conv3d(8, 8, 3), 1.0, 2, 1)   # nn.Conv3d: the ATen rebuild form, reference shapes (tests/test_conv3d.py)
+    assert m._aten_only and tuple(m.hada_w1_b.shape) == (2, 8 * 27)
     with pytest.raises(NotImplementedError):
-        LohaModule("m", nn.Conv3d(8, 8, 3), 1.0, 2, 1)
+        LohaModule("m", nn.Conv3d(8, 8, 3, groups=2), 1.0, 2, 1)
     # nn.Conv1d is adapted through its Conv2d twin (1 x k window; modules/base.py _Conv1dTwin, tests/test_conv1d.py)
     m = LohaModule("m", nn.Conv1d(8, 8, 3), 1.0, 2, 1)
     assert tuple(m.state_dict()["hada_w1_b"].shape) == (2, 24) and m._conv1d is not None
