@@ -26,7 +26,7 @@ def install(strict: bool = True) -> bool:
     Returns False (or raises when ``strict``) if the upstream ``lycoris`` package is not importable.  Presets and
     every other piece of upstream state are left untouched.  ``uninstall()`` restores the previous bindings.
 
-    A variant outside the covered set (grouped convolutions, non-zero padding modes, torch parametrize integration) raises
+    A variant outside the covered set (grouped convolutions, non-zero padding modes) raises
     NotImplementedError when the network is built -- nothing falls back silently, and there is no delegation to the reference's
     torch implementation.  nn.Conv3d layers are adapted by these same classes, evaluated as ``F.conv3d(x, dW)`` with ATen ops
     (modules/base.py ``_aten_only``).

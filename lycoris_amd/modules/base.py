@@ -212,7 +212,46 @@ class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
 
     @classmethod
     def parametrize(cls, org_module, attr, *args, **kwargs):
-        raise _unsupported("torch parametrize integration")
+        """Register the adapter as a torch parametrization of `org_module.<attr>` (reference modules/base.py:199-234, docs/API.md): from
+        then on reading the attribute yields `W + dW * multiplier` (with weight_decompose: the decomposed weight), differentiable
+        with respect to the adapter's parameters.  This is a weight-space use by definition -- the merged weight is materialised at
+        every access -- so it runs as tensor math on whatever device the weight lives on, not through the activation kernels.
+
+        The proxy layer is built with the weight's own (out, in) orientation; the reference hands `shape[0]` to the constructor's
+        `in_features` / `in_channels` slot (base.py:209-229), which is the same thing only for square weights (reference defect:
+        a non-square target fails there with a shape error in `make_weight`)."""
+        import torch.nn.utils.parametrize as P
+        target = getattr(org_module, attr)
+        kwargs["bypass_mode"] = False
+        if target.dim() == 2:
+            proxy = nn.Linear(target.shape[1], target.shape[0], bias=False)
+        elif 3 <= target.dim() <= 5:
+            conv = {3: nn.Conv1d, 4: nn.Conv2d, 5: nn.Conv3d}[target.dim()]
+            proxy = conv(target.shape[1], target.shape[0], tuple(target.shape[2:]), bias=False)
+        else:
+            raise _unsupported(f"parametrize on a {target.dim()}-D tensor")
+        proxy.weight = target
+        mod = cls("", proxy, *args, **kwargs)
+        object.__setattr__(mod, "_force_tensor_math", True)  # weight-space functions stay autograd-visible (no in-place / no_grad kernels)
+        mod.forward = mod.parametrize_forward
+        mod.to(target)
+        P.register_parametrization(org_module, attr, mod)
+        return mod
+
+    def parametrize_forward(self, weight, *args, **kwargs):
+        """the parametrization: original weight -> adapted weight (reference base.py:392-395 via get_merged_weight)"""
+        shape = tuple(weight.shape)
+        if self._conv1d is not None:  # built on the Conv2d twin: factors are [.., 1, k]
+            shape = (shape[0], shape[1], 1, shape[2])
+        dw = self.get_diff_weight(1.0, shape)[0]
+        w = weight.reshape(shape).to(torch.promote_types(weight.dtype, dw.dtype))
+        if getattr(self, "wd", False):
+            merged = self._dora_merge_host(w + dw, self.multiplier)
+        elif self.name == "ia3":
+            merged = self.get_merged_weight(self.multiplier, shape)[0]
+        else:
+            merged = w + dw * self.multiplier
+        return merged.reshape(weight.shape).to(weight.dtype)
 
     # ---- small accessors ----------------------------------------------------------------------------------------
     @property
@@ -372,7 +411,8 @@ class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
         raise NotImplementedError
 
     def _native_ws(self):
-        return self._ws_algo is not None and not self._aten_only and self.org_weight.is_cuda and next(self.parameters()).is_cuda
+        return (self._ws_algo is not None and not self._aten_only and not getattr(self, "_force_tensor_math", False)
+                and self.org_weight.is_cuda and next(self.parameters()).is_cuda)
 
     def get_diff_weight(self, multiplier=1.0, shape=None, device=None):
         raise NotImplementedError
