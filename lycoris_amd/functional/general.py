@@ -2,6 +2,11 @@
 from __future__ import annotations
 
 import torch
+import torch.nn.functional as F
+
+# weight.dim() -> the dense op the reference evaluates dW with (functional/general.py:6); Linear and Conv2d (Conv1d as its twin) run on
+# the kernels here, this table is what the Conv3d / weight-space paths and callers of the functional API index
+FUNC_LIST = [None, None, F.linear, F.conv1d, F.conv2d, F.conv3d]
 
 
 def factorization(dimension: int, factor: int = -1) -> tuple[int, int]:
@@ -65,3 +70,36 @@ def conv_args(extra_args: dict | None):
     if isinstance(pad, str):
         raise NotImplementedError("lycoris_amd: string padding modes are not supported")
     return pair("stride", 1), pair("padding", 0), pair("dilation", 1)
+
+
+def power2factorization(dimension: int, factor: int = -1):
+    """(m, n) with m * n == dimension, m even, m <= factor and n a power of two -- the largest such m (functional/general.py:59-83, used
+    by BOFT upstream); (None, 0) when there is none.  Pinned by tests/golden/power2factorization.json."""
+    dimension, factor = int(dimension), int(factor)
+    if factor == -1:
+        factor = dimension
+    best = 0
+    for m in range(2, min(factor, dimension) + 1, 2):
+        n = dimension // m
+        if dimension % m == 0 and n & (n - 1) == 0:
+            best = m
+    return (best, dimension // best) if best else (None, 0)
+
+
+def tucker_weight_from_conv(up: torch.Tensor, down: torch.Tensor, mid: torch.Tensor) -> torch.Tensor:
+    """dW[o, i, ...] = sum_mn mid[m, n, ...] up[o, m] down[n, i] of a conv-CP LoCon triple given as conv weights (up / down 1x1:
+    functional/general.py:86-89)"""
+    return torch.einsum("mn...,om,ni->oi...", mid, up.flatten(1), down.flatten(1))
+
+
+def tucker_weight(wa: torch.Tensor, wb: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """rebuild_tucker with the arguments in (wa, wb, t) order (functional/general.py:92-94)"""
+    return rebuild_tucker(t, wa, wb)
+
+
+def apply_dora_scale(org_weight: torch.Tensor, rebuild: torch.Tensor, dora_scale: torch.Tensor, scale: float) -> torch.Tensor:
+    """W + ((W + dW) / ||W + dW||_in * dora_scale - W) * scale with the norm over each INPUT channel (functional/general.py:97-110: the
+    wd_on_out=False form, no epsilon).  Host-side helper in plain tensor math; the modules' own DoRA path is modules/base.py."""
+    merged = (org_weight + rebuild).to(dora_scale.dtype)
+    norm = merged.transpose(0, 1).flatten(1).norm(dim=1).reshape(1, merged.shape[1], *([1] * (merged.dim() - 2)))
+    return org_weight + (merged / norm * dora_scale - org_weight) * scale
