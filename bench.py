@@ -682,9 +682,11 @@ def main():
                                         "all_reduces_per_step": sync.collectives_launched / max(1, steps_run),
                                         "note": "RCCL returns early from an in-place collective of a 1-rank communicator: this run measures "
                                                 "the ordering / submission cost of the exchange, not ring time" if comm is not None else None}
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)  # RCCL's version banner sits in the C stdio buffer: the JSON line is the LAST line
+    if world > 1:
+        barrier()  # ... of the whole job: every rank has written what it had buffered before rank 0 prints
     if rank == 0:
-        sys.stdout.flush()
-        ctypes.CDLL(None).fflush(None)  # RCCL's version banner sits in the C stdio buffer: the JSON line is the LAST line
         print(json.dumps(result), flush=True)
     if comm is not None:
         comm.destroy()
