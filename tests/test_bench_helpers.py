@@ -40,3 +40,56 @@ def test_the_committed_traffic_file_names_the_library_it_was_collected_on():
     assert len(rec["lib_sha16"]) == 16 and "lokr/sdxl/linear" in rec["workloads"]
     for sha, also in rec.get("also_valid_for", {}).items():
         assert len(sha) == 16 and also["difference"] and set(also["workloads"]) <= set(rec["workloads"])
+
+
+def test_the_committed_traffic_file_is_keyed_to_the_library_in_the_tree():
+    """roofline.traffic is only reported for the build the PMC passes ran on: the in-tree library (it travels to the GPU box) must be that
+    build -- a kernel edit without new PMC passes shows up here, on the CPU, instead of as `traffic: null` in the round's bench line"""
+    import pytest
+    from lycoris_amd import _native
+    if not os.path.isfile(_native.lib_path()):
+        pytest.skip("library not built")
+    rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    sha = _bench().lib_sha()
+    assert sha == rec["lib_sha16"] or sha in rec.get("also_valid_for", {}), (sha, rec["lib_sha16"])
+
+
+def test_defaults_and_self_launch_command(monkeypatch):
+    """`python bench.py` = one GPU, a K / W that finish in minutes; `python bench.py --gpus N` without a launcher around it re-runs the
+    very command line as N ranks under torch.distributed.run on 127.0.0.1 (the driver's own form) and hands rank 0's exit code back"""
+    import subprocess
+    import sys
+    import pytest
+    b = _bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = b.parse()
+    assert (a.gpus, a.algo, a.model, a.dtype, a.backend) == (1, "lokr", "sdxl", "bf16", "rccl") and 1 <= a.warmup < a.steps <= 50
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    a = b.parse()
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 3)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    with pytest.raises(SystemExit) as e:
+        b.self_launch(a)
+    cmd = seen["cmd"]
+    assert e.value.code == 3 and cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def test_the_workload_tables_carry_the_sibling_sets_the_bench_line_quotes():
+    """SDXL: 788 adapted layers, 350 of them in 140 sets (q / k / v of a self-attention: 3, k / v of a cross-attention: 2)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+    import sdxl_shapes
+    specs = sdxl_shapes.sdxl_unet_layers()
+    assert sum(s["count"] for s in specs) == 788 and sum(s["count"] for s in specs if s["kind"] == "linear") == 739
+    in_sets = [(s["count"], s["sib"]) for s in specs if s.get("sib", 1) > 1]
+    assert all(c % n == 0 and n in (2, 3) for c, n in in_sets)
+    assert sum(c for c, _ in in_sets) == 350 and sum(c // n for c, n in in_sets) == 140
