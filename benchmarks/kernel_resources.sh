@@ -13,7 +13,8 @@ for line in sys.stdin:
     m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)", line)
     if m and cur: rows[cur][m.group(1).split()[0]] = int(m.group(2))
 names = list(rows)
-dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+# (binutils c++filt does not know DF16b / DF16_: hand it the vendor / half spellings)
+dem = subprocess.run(["c++filt"], input="\n".join(n.replace("DF16b", "u6__bf16").replace("DF16_", "Dh") for n in names), capture_output=True, text=True).stdout.split("\n")
 print("%5s %5s %7s %4s %7s  kernel" % ("VGPR", "AGPR", "scratch", "occ", "LDS"))
 for n, d in zip(names, dem):
     d = d.replace("lyc::", "").replace("void ", "")
