@@ -79,8 +79,12 @@ def numeric_case(name, algo, layer_kw, mod_kw, xshape, seed, multiplier=0.7):
         from lycoris.functional.general import rebuild_tucker
         ps = dict(params)
         dw = (rebuild_tucker(ps["hada_t1"], ps["hada_w1_a"], ps["hada_w1_b"])
-              * rebuild_tucker(ps["hada_t2"], ps["hada_w2_a"], ps["hada_w2_b"]) * mod.scale * multiplier)
-        conv = torch.nn.functional.conv3d if x.dim() == 5 else torch.nn.functional.conv2d
+              * rebuild_tucker(ps["hada_t2"], ps["hada_w2_a"], ps["hada_w2_b"]) * mod.scale * ps.get("scalar", 1.0))
+        if getattr(mod, "wd", False):  # (sweep cases: DoRA on top -- the reference's own decomposition of W + dW, loha.py:244-265)
+            dw = mod.apply_weight_decompose(layer.weight + dw, multiplier) - layer.weight
+        else:
+            dw = dw * multiplier
+        conv = {3: torch.nn.functional.conv1d, 4: torch.nn.functional.conv2d, 5: torch.nn.functional.conv3d}[x.dim()]
         y2 = conv(x, dw, None, layer.stride, layer.padding, layer.dilation)
         assert torch.allclose(y2, (out - base).detach(), atol=1e-10)
         ga, gb = torch.autograd.grad((y2 * g).sum(), [ps["hada_w1_a"], ps["hada_w2_a"]])
