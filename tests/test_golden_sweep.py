@@ -98,3 +98,11 @@ def test_module_matches_the_reference_on_a_sampled_configuration(name, cases):
     # float64 end to end; delta / dx are differences against `base` (cancellation), DoRA divides by norms
     bad = {k: v for k, v in errs.items() if v > (1e-8 if k in ("delta", "dx") else 1e-9)}
     assert not bad, (name, meta["mod"], bad)
+    # bypass_mode computes the same function here (the rebuild path is canonical; upstream's bypass forms deviate from its
+    # own rebuild path for LoKr -- no `scale`, D5 -- and (IA)^3 -- scaled bias, D9); with weight_decompose upstream's bypass ignores DoRA
+    if not meta["mod"].get("weight_decompose"):
+        mod.bypass_mode = True
+        mod.apply_to()
+        out_b = layer(x)
+        mod.restore()
+        assert _err(out_b - base, a["delta"]) < 1e-8, (name, "bypass")
