@@ -106,3 +106,12 @@ def test_module_matches_the_reference_on_a_sampled_configuration(name, cases):
         out_b = layer(x)
         mod.restore()
         assert _err(out_b - base, a["delta"]) < 1e-8, (name, "bypass")
+        mod.bypass_mode = None
+    # merging into the frozen weight reproduces the adapted forward (merge_to, modules/base.py:326-342 upstream), DoRA included
+    W0 = layer.weight.detach().clone()
+    mod.merge_to(meta["multiplier"])
+    with torch.no_grad():
+        out_m = layer(x)
+        assert not torch.equal(layer.weight, W0)
+        assert _err(out_m - base, a["delta"]) < 1e-8, (name, "merged")
+        layer.weight.copy_(W0)
