@@ -115,3 +115,54 @@ def test_module_matches_the_reference_on_a_sampled_configuration(name, cases):
         assert not torch.equal(layer.weight, W0)
         assert _err(out_m - base, a["delta"]) < 1e-8, (name, "merged")
         layer.weight.copy_(W0)
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "lycoris")), reason="reference tree not present")
+def test_apply_max_norm_equals_the_references_on_every_sampled_configuration(cases):
+    """scale_weight_norms of sd-scripts calls Module.apply_max_norm(max_norm, device) on every adapter after each step (kohya.py
+    apply_max_norm_regularization; locon.py:273-284, loha.py:281-292, lokr.py:442-466): same (scaled, norm) and the same parameters
+    afterwards as the reference's module holding the same tensors -- below, inside and above the clamp window."""
+    import sys
+    import types
+
+    import tomli
+    shim = types.ModuleType("toml")
+    shim.load = lambda f: tomli.load(open(f, "rb")) if isinstance(f, str) else tomli.load(f)
+    shim.loads = tomli.loads
+    sys.modules.setdefault("toml", shim)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import lycoris.modules as R
+    ref_cls = {"locon": R.LoConModule, "loha": R.LohaModule, "lokr": R.LokrModule}
+    checked = 0
+    for name, (meta, a) in sorted(cases.items()):
+        if meta["algo"] == "ia3":
+            continue
+        layer, mod = _build(meta, a)
+        lk = dict(meta["layer"])
+        kind = lk.pop("kind")
+        conv = {"conv1d": nn.Conv1d, "conv2d": nn.Conv2d}.get(kind)
+        rl = (nn.Linear(lk["cin"], lk["cout"], bias=lk["bias"]) if conv is None else
+              conv(lk["cin"], lk["cout"], lk["k"], lk["stride"], lk["padding"], lk["dilation"], bias=lk["bias"])).double()
+        with torch.no_grad():
+            rl.weight.copy_(torch.from_numpy(a["W"]))
+        rmod = ref_cls[meta["algo"]]("t", rl, meta["multiplier"], **meta["mod"]).double()
+        with torch.no_grad():
+            for n, p in rmod.named_parameters():
+                p.copy_(torch.from_numpy(a["p." + n]))
+        with torch.no_grad():
+            norm0 = float(rmod.apply_max_norm(1e30)[1])          # (nothing is scaled at this bound: the norm itself)
+        for bound in (0.5 * norm0, 1.5 * norm0, 4.0 * norm0):     # above the window, inside it, below max_norm / 2
+            s_ref, n_ref = rmod.apply_max_norm(bound, None)
+            s_nat, n_nat = mod.apply_max_norm(bound, None)
+            assert bool(s_ref) == bool(s_nat), (name, bound)
+            assert abs(float(n_ref) - float(n_nat)) <= 1e-9 * max(1.0, abs(float(n_ref))), (name, bound, float(n_ref), float(n_nat))
+            for (n, p), (_, q) in zip(sorted(rmod.named_parameters()), sorted(mod.named_parameters())):
+                assert _err(q, p.detach().numpy()) < 1e-10, (name, bound, n)
+            if hasattr(rmod, "scalar") and not isinstance(rmod.scalar, nn.Parameter):
+                assert abs(float(rmod.scalar) - float(mod.scalar)) < 1e-10, (name, bound)
+        checked += 1
+    assert checked >= 90
