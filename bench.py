@@ -80,6 +80,10 @@ def parse():
                     help="A/B, the round 1-4 layout: every layer instance owns its input and is launched on its own (default: the "
                          "to_q / to_k / to_v layers of a self-attention and to_k / to_v of a cross-attention read ONE tensor, as in the "
                          "UNet, and LoKr runs each such set as one grouped launch -- what the modules do behind the reference API)")
+    ap.add_argument("--autocast", action="store_true",
+                    help="sd-scripts' mixed_precision=bf16: the layers that read a LayerNorm output (attn1 to_q / to_k / to_v, "
+                         "ff.net.0.proj: 280 of the 788) get an fp32 input and the forward runs under torch.autocast(bf16) -- the reference's F.linear runs in "
+                         "the autocast dtype (modules/lokr.py:543-566); the native ops cast once per op, a sibling set once per set")
     ap.add_argument("--shared-inputs", action="store_true",
                     help="development: instances of one shape share x / g (cache-resident, the round-1 behaviour)")
     ap.add_argument("--eager", action="store_true", help="time the step without hipGraph capture (Python-driven)")
@@ -94,6 +98,9 @@ def parse():
                     help="N > 1 with the ProcessGroup-free communicator: bucket collectives on the communicator's own stream between the "
                          "bucket-aligned backward segments (overlap).  Default for the captured step: on the compute stream behind the backward "
                          "graph -- a second stream that waits on the graph-launching stream slows every graph launch (profiles/r05_ws1_*)")
+    ap.add_argument("--collectives-inline", action="store_true",
+                    help="N > 1: force the bucket collectives onto the compute stream behind the backward graph (default: decided per payload "
+                         "by lycoris_amd.grad_sync.overlap_pays)")
     ap.add_argument("--collectives-on-main-stream", action="store_true",
                     help="development: issue the bucket collectives on the compute stream (no side stream, no overlap) -- separates the "
                          "cost of the collectives themselves from the cost of running them beside the backward pass")
@@ -177,7 +184,9 @@ class Inst:
             elif share_x is not None:
                 self.x = share_x.x  # a sibling projection: the same tensor object as its set's first member
             else:
-                self.x = torch.randn(*xs, device=dev, dtype=dtype, generator=gen).requires_grad_(True)
+                # --autocast: a LayerNorm runs in fp32 under torch.autocast and hands its fp32 output to the projections behind it
+                xdt = torch.float32 if (AUTOCAST and lin and any(t in spec.get("tag", "") for t in ("attn1 to_q", "ff.net.0"))) else dtype
+                self.x = torch.randn(*xs, device=dev, dtype=xdt, generator=gen).requires_grad_(True)
             gshape = xs if (algo == "ia3" and spec.get("side") == "in") else gs
             self.g = torch.randn(*gshape, device=dev, dtype=dtype, generator=gen) / math.sqrt(O)
             if not lin and CHANNELS_LAST:
@@ -282,13 +291,42 @@ class Inst:
 
 
 CHANNELS_LAST = False
+AUTOCAST = False
 LOKR_RANK = 0
 OVERLAP_LEG = False
 SIBLINGS = True
 
 
+def adapter_param_count(args):
+    """adapter parameters of the workload from the shape list alone (the DP payload is 4 bytes each: fp32 gradients)"""
+    n = 0
+    for spec, algo, count in layer_specs(args.model, args.algo):
+        if (args.layers == "linear" and spec["kind"] != "linear") or (args.layers == "conv" and spec["kind"] != "conv"):
+            continue
+        _, _, O = layer_rows(spec)
+        lin = spec["kind"] == "linear"
+        cin = spec["I"] if lin else spec["C"]
+        kk = 1 if lin else spec["k"] * spec["k"]
+        if algo == "lokr":
+            r = int(args.rank)
+            if r > 0 and r < max(O // FACTOR, cin // FACTOR) / 2:
+                per = FACTOR * FACTOR + (O // FACTOR) * r + r * (cin // FACTOR) * kk
+            else:
+                per = FACTOR * FACTOR + (O // FACTOR) * (cin // FACTOR) * kk
+        elif algo == "locon":
+            r = 16 if kk == 1 else 8
+            per = r * cin * kk + O * r
+        elif algo == "loha":
+            per = 2 * 32 * (O + cin * kk)
+        else:
+            per = cin if spec.get("side") == "in" else O
+        n += per * count
+    return n
+
+
 def build_instances(args, dtype, dev):
-    global CHANNELS_LAST, LOKR_RANK, OVERLAP_LEG, SIBLINGS
+    global CHANNELS_LAST, LOKR_RANK, OVERLAP_LEG, SIBLINGS, AUTOCAST
+    AUTOCAST = bool(getattr(args, "autocast", False))
     OVERLAP_LEG = bool(getattr(args, "overlap_leg", False))
     SIBLINGS = not getattr(args, "no_siblings", False)
     CHANNELS_LAST = bool(args.channels_last)
@@ -322,12 +360,16 @@ def build_instances(args, dtype, dev):
 def _groupable(it):
     """a sibling set that goes out as ONE launch: LoKr (full-matrix or low-rank w2) or LoCon on nn.Linear -- ops.lokr_linear_group /
     lokr_linear_lr_group / locon_linear_group, the ops the modules' sibling sets call (lycoris_amd/modules/siblings.py)"""
-    return (SIBLINGS and it.sibs is not None and len(it.sibs) > 1 and it.spec["kind"] == "linear" and it.x.dtype != torch.float32
+    return (SIBLINGS and it.sibs is not None and len(it.sibs) > 1 and it.spec["kind"] == "linear"
+            and (it.x.dtype != torch.float32 or AUTOCAST)   # (an fp32 activation under a 16-bit autocast: cast once per set by the op)
             and ((it.algo == "lokr" and len(it.params) in (2, 3)) or it.algo == "locon"))
 
 
 def forward_all(insts, with_base=False):
     """[(output, instance)] in layer order.  A sibling set whose members are all in `insts` is launched by its first member."""
+    if AUTOCAST and not torch.is_autocast_enabled("cuda"):
+        with torch.autocast("cuda", dtype=insts[0].g.dtype):
+            return forward_all(insts, with_base)
     present = {id(it) for it in insts}
     outs, parked = [], {}
     for it in insts:
@@ -426,7 +468,24 @@ def main():
     if world > 1 or args.rccl_ws1:
         if args.backend == "rccl":  # no process group at all: the 128-byte id travels through the launcher's store
             from lycoris_amd.grad_sync import RcclCommunicator
-            inline = not (args.collectives_on_side_stream or args.capture_collectives or args.eager)  # eager steps overlap (hooks drive the buckets)
+            # captured steps: overlap (side stream between bucket-aligned backward segments) when the estimated ring time of the
+            # exchange exceeds what the second queue costs, inline (compute stream, behind the backward graph) otherwise --
+            # grad_sync.overlap_pays; --collectives-on-side-stream / --collectives-inline force either.  Eager steps always overlap
+            # (the hooks drive the buckets).  The payload is known before the instances exist: 4 bytes per adapter parameter.
+            from lycoris_amd.grad_sync import exchange_estimate_ms, overlap_pays, SIDE_STREAM_HOP_MS, XGMI_ALLREDUCE_BUSBW_GBS
+            payload = 4 * adapter_param_count(args)
+            want_overlap = overlap_pays(payload, max(world, 2 if args.rccl_ws1 else world))
+            if args.collectives_on_side_stream:
+                want_overlap = True
+            if args.collectives_inline or (args.rccl_ws1 and not args.collectives_on_side_stream):
+                want_overlap = False  # (--rccl-ws1 measures ordering cost at one rank: inline unless the A/B flag asks otherwise)
+            inline = not (want_overlap or args.capture_collectives or args.eager)
+            POLICY.update({"mode": "inline" if inline else ("captured" if args.capture_collectives else "overlap"),
+                           "payload_mb": round(payload / 2**20, 1), "est_ring_ms": round(exchange_estimate_ms(payload, world), 3),
+                           "hop_ms": SIDE_STREAM_HOP_MS, "est_busbw_gbs": XGMI_ALLREDUCE_BUSBW_GBS,
+                           "rule": "overlap (communicator's own stream between bucket-aligned backward segments) when est_ring_ms > hop_ms, "
+                                   "inline (compute stream behind the backward graph) otherwise; forced by --collectives-on-side-stream / "
+                                   "--collectives-inline", "forced": bool(args.collectives_on_side_stream or args.collectives_inline)})
             kw = dict(high_priority=args.comm_high_priority, stream=torch.cuda.Stream(device=dev) if args.comm_torch_stream else None,
                       on_current_stream=inline)
             comm = RcclCommunicator.from_env(dev, **kw) if world > 1 else RcclCommunicator(0, 1, dev, **kw)
@@ -633,7 +692,8 @@ def main():
             "algo": args.algo, "factor": FACTOR if args.algo in ("lokr", "mixed") else None, "layers": n_layers,
             "lokr_w2": (f"low rank {args.rank} (lokr_w2_a @ lokr_w2_b: planes packed from the factors, chain rule in the grouped launch)" if args.rank else "full matrix") if args.algo in ("lokr", "mixed") else None,
             "adapter_params": sum(p.numel() for p in all_params), "dp_payload_mb": round(sync.payload_bytes / 2**20, 1),
-            "parallelism": f"dp{world}", **({"host_submit_ms": round(host_submit_ms, 2)} if host_submit_ms is not None else {}),
+            "parallelism": f"dp{world}", **({"parallelism_detail": dict(POLICY)} if POLICY else {}),
+            **({"rccl_ranks": comm.count()} if comm is not None else {}), **({"host_submit_ms": round(host_submit_ms, 2)} if host_submit_ms is not None else {}),
             "optimizer": "torch.optim.AdamW(fused=True) over " + ("the individual parameter tensors" if args.per_tensor_optimizer else
                                                                   "one flat parameter arena per dtype (AdapterGradSync.flat_parameters)"),
             "graph": "eager (no capture)" if args.eager else
@@ -698,6 +758,7 @@ def main():
 # measurement legs (rank 0, N = 1)
 # ---------------------------------------------------------------------------------------------------------------------
 _KEEP = []
+POLICY = {}
 
 
 def _graph_ms(fn, reps=4):
@@ -1317,7 +1378,9 @@ def per_algo_legs():
     reduced to ms / step and the roofline of its dominant kernel family."""
     import subprocess
     legs = [("locon_sdxl", ["--algo", "locon"]), ("locon_sd15_bs4", ["--algo", "locon", "--model", "sd15"]),
-            ("loha_sdxl", ["--algo", "loha"]), ("ia3_sdxl", ["--algo", "ia3"]), ("mixed_sdxl_fp16", ["--algo", "mixed", "--dtype", "fp16"])]
+            ("loha_sdxl", ["--algo", "loha"]), ("ia3_sdxl", ["--algo", "ia3"]), ("mixed_sdxl_fp16", ["--algo", "mixed", "--dtype", "fp16"]),
+            # sd-scripts' mixed_precision=bf16: fp32 LayerNorm outputs into to_q / to_k / to_v and the GEGLU projection, torch.autocast(bf16)
+            ("lokr_sdxl_autocast", ["--algo", "lokr", "--autocast", "--no-roofline"])]
     out = {}
     for name, extra in legs:
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-reference",

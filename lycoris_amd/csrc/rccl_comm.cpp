@@ -74,25 +74,31 @@ class RcclComm {
     int prev = 0;
     LYC_HIP(hipGetDevice(&prev));
     LYC_HIP(hipSetDevice(device));
-    int lo = 0, hi = 0;
-    LYC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi = numerically lowest = highest priority
-    if (external_stream != 0) {  // a stream the caller owns (e.g. one of torch's pool streams) and keeps alive
-      stream_ = reinterpret_cast<hipStream_t>(external_stream);
-      own_stream_ = false;
-    } else {
-      LYC_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, high_priority ? hi : 0));
-    }
-    // Ordering events with a DEVICE-scope release: a default HIP event performs a system-scope release when it is recorded (L2
-    // write-back for host visibility) -- measured on the SDXL step: five default-flag events between the backward segments cost
-    // +1.5 ms per step with collectives that do nothing at all (profiles/r05_ws1_stream_and_event_ab.log).  All consumers of these
-    // events are streams of the same device; what crosses devices is RCCL's own business.
-    constexpr unsigned kFlags = hipEventDisableTiming | hipEventReleaseToDevice;
-    LYC_HIP(hipEventCreateWithFlags(&ev_in_, kFlags));
-    LYC_HIP(hipEventCreateWithFlags(&ev_out_, kFlags));
-    for (hipEvent_t& e : marks_) LYC_HIP(hipEventCreateWithFlags(&e, kFlags));
-    {
-      py::gil_scoped_release nogil;  // the bootstrap blocks until every rank has arrived
-      LYC_NCCL(ncclCommInitRank(&comm_, world, uid, rank));
+    try {
+      int lo = 0, hi = 0;
+      LYC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi = numerically lowest = highest priority
+      if (external_stream != 0) {  // a stream the caller owns (e.g. one of torch's pool streams) and keeps alive
+        stream_ = reinterpret_cast<hipStream_t>(external_stream);
+        own_stream_ = false;
+      } else {
+        LYC_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, high_priority ? hi : 0));
+      }
+      // Ordering events with a DEVICE-scope release: a default HIP event performs a system-scope release when it is recorded (L2
+      // write-back for host visibility) -- measured on the SDXL step: five default-flag events between the backward segments cost
+      // +1.5 ms per step with collectives that do nothing at all (profiles/r05_ws1_stream_and_event_ab.log).  All consumers of these
+      // events are streams of the same device; what crosses devices is RCCL's own business.
+      constexpr unsigned kFlags = hipEventDisableTiming | hipEventReleaseToDevice;
+      LYC_HIP(hipEventCreateWithFlags(&ev_in_, kFlags));
+      LYC_HIP(hipEventCreateWithFlags(&ev_out_, kFlags));
+      for (hipEvent_t& e : marks_) LYC_HIP(hipEventCreateWithFlags(&e, kFlags));
+      {
+        py::gil_scoped_release nogil;  // the bootstrap blocks until every rank has arrived
+        LYC_NCCL(ncclCommInitRank(&comm_, world, uid, rank));
+      }
+    } catch (...) {  // a failed bootstrap leaves nothing behind: stream, events, and the caller's device
+      release_handles();
+      (void)hipSetDevice(prev);
+      throw;
     }
     LYC_HIP(hipSetDevice(prev));
   }
@@ -103,11 +109,15 @@ class RcclComm {
       (void)hipStreamSynchronize(stream_);
       (void)ncclCommDestroy(comm_);
       comm_ = nullptr;
-      (void)hipEventDestroy(ev_in_);
-      (void)hipEventDestroy(ev_out_);
-      for (hipEvent_t e : marks_) (void)hipEventDestroy(e);
-      if (own_stream_) (void)hipStreamDestroy(stream_);
+      release_handles();
     }
+  }
+  // the number of ranks RCCL itself reports for this communicator (ncclCommCount): bench.py prints it as `rccl_ranks`
+  int count() const {
+    TORCH_CHECK(comm_ != nullptr, "lycoris_amd RCCL: communicator destroyed");
+    int n = 0;
+    LYC_NCCL(ncclCommCount(comm_, &n));
+    return n;
   }
 
   int rank() const { return rank_; }
@@ -186,6 +196,17 @@ class RcclComm {
   void group_end() { LYC_NCCL(ncclGroupEnd()); }
 
  private:
+  void release_handles() {
+    if (ev_in_ != nullptr) (void)hipEventDestroy(ev_in_);
+    if (ev_out_ != nullptr) (void)hipEventDestroy(ev_out_);
+    for (hipEvent_t& e : marks_) {
+      if (e != nullptr) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+    if (own_stream_ && stream_ != nullptr) (void)hipStreamDestroy(stream_);
+    ev_in_ = ev_out_ = nullptr;
+    stream_ = nullptr;
+  }
   ncclComm_t comm_ = nullptr;
   hipStream_t stream_ = nullptr;
   hipEvent_t ev_in_ = nullptr, ev_out_ = nullptr;
@@ -233,5 +254,6 @@ void lyc_bind_rccl(py::module_& m) {
       .def("broadcast", &RcclComm::broadcast, py::arg("tensor"), py::arg("root") = 0)
       .def("group_start", &RcclComm::group_start)
       .def("group_end", &RcclComm::group_end)
+      .def("count", &RcclComm::count)
       .def("destroy", &RcclComm::destroy);
 }

@@ -1649,6 +1649,8 @@ struct LoconLinearGroupFn : public torch::autograd::Function<LoconLinearGroupFn>
     Tensor rows;
     if (fast) {
       rows = rows_of(x, I);
+      // lyc_sum_rows (the sum of the n dx results) moves 16-byte pieces: nothing is launched unless it can run too
+      fast = !nx || (rows.numel() % 8 == 0 && reinterpret_cast<uintptr_t>(rows.data_ptr()) % 16 == 0);
       for (size_t i = 0; i < n && fast; ++i) {
         fast = grads[i].defined() && eager_cuda(grads[i]);
         if (!fast) break;

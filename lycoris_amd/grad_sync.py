@@ -43,6 +43,30 @@ import torch
 import torch.distributed as dist
 
 
+# ---- where do the bucket collectives of a REPLAYED (captured) step go? ---------------------------------------------------------------
+# Measured (profiles/r05_ws1_*): while a second stream waits on the stream that launches hipGraphs, every graph launch gets slower --
+# about 1.0 ms on the captured 18 ms SDXL step, whatever the collectives cost themselves.  That is the price of overlapping; what it
+# buys is the ring time of the exchange.  Never measured here (single-GPU boxes): RCCL's large-message all-reduce bus bandwidth on the
+# 8-GPU xGMI mesh, taken as 250 GB/s (7 links x ~153 GB/s per GPU, ring collectives are per-link bound; the driver's SCALE run is the
+# first measurement).  The rule, not a hard-wired default: overlap when the estimated ring time exceeds the hop.
+XGMI_ALLREDUCE_BUSBW_GBS = 250.0
+SIDE_STREAM_HOP_MS = 1.0
+
+
+def exchange_estimate_ms(payload_bytes: int, world: int, busbw_gbs: float = XGMI_ALLREDUCE_BUSBW_GBS) -> float:
+    """ring all-reduce (or reduce-scatter + all-gather) of `payload_bytes` over `world` ranks: 2 (N - 1) / N * S / busbw"""
+    if world <= 1:
+        return 0.0
+    return 2.0 * (world - 1) / world * payload_bytes / (busbw_gbs * 1e9) * 1e3
+
+
+def overlap_pays(payload_bytes: int, world: int, hop_ms: float = SIDE_STREAM_HOP_MS, busbw_gbs: float = XGMI_ALLREDUCE_BUSBW_GBS) -> bool:
+    """captured steps: bucket collectives on the communicator's own stream between the backward segments (True) or on the compute
+    stream behind the backward graph (False)?  SDXL at N = 8: LoKr full-matrix 153 MB -> 1.07 ms (overlap, marginal), LoKr rank 16
+    25 MB -> 0.17 ms (inline), LoCon 185 MB -> 1.3 ms, LoHa 787 MB -> 5.5 ms (overlap); at N = 2 only LoHa overlaps."""
+    return exchange_estimate_ms(payload_bytes, world, busbw_gbs) > hop_ms
+
+
 class RcclCommunicator:
     """A ProcessGroup-free RCCL communicator (csrc/rccl_comm.cpp): one per process and GPU, created once.
 
@@ -51,8 +75,11 @@ class RcclCommunicator:
         comm = RcclCommunicator.from_process_group()        # id broadcast through an existing (e.g. gloo) group
         sync = AdapterGradSync(params, comm=comm)
 
-    Collectives are enqueued on the communicator's own high-priority HIP stream; `wait_current()` / `wait_event()` order them behind
-    the producer of the data, `join()` makes the caller's stream wait for them.  Nothing here synchronises the host."""
+    Collectives are enqueued on the communicator's own HIP stream (default priority: a high-priority stream made every kernel of the
+    step 3.5x slower, profiles/r05_ws1_stream_and_event_ab.log; `high_priority=True` is the A/B switch) or, with
+    `on_current_stream=True`, on whatever stream is current at the call (no second queue: what a caller that replays captured steps
+    wants for small payloads, see `overlap_pays`).  `wait_current()` / `wait_event()` order them behind the producer of the data,
+    `join()` makes the caller's stream wait for them.  Nothing here synchronises the host."""
 
     SUM, AVG, MAX = 0, 1, 2
     _created = 0
@@ -160,6 +187,10 @@ class RcclCommunicator:
         self._c.all_reduce(t, self.MAX)
         self._c.synchronize()
         return float(t)
+
+    def count(self) -> int:
+        """the number of ranks RCCL itself reports (ncclCommCount) -- not what the launcher's environment said"""
+        return int(self._c.count())
 
     def destroy(self):
         self._c.destroy()
@@ -605,6 +636,11 @@ class ShardedAdamW:
     One hyper-parameter set per arena, as with flat_parameters().  Because the parameters change through views of the arena (no
     version counter of a module parameter moves), `step()` marks the LoKr operand-plane cache dirty itself.
 
+    Moments live in the parameter dtype (torch.optim.AdamW's rule); the adapter parameters of this path are fp32, 16-bit
+    parameter arenas are refused rather than silently given 16-bit moments.  `state_dict()` is RANK-LOCAL: it holds the moments of
+    this rank's shards only, together with the layout they belong to (world, rank, shard sizes), and `load_state_dict()` refuses a
+    state saved under another world size / rank / bucket layout instead of mis-assigning moments.
+
     Status: exercised under 2-rank gloo on the CPU and through RCCL at world_size 1 on one GPU (tests/test_gpu_grad_sync.py); never
     measured on several GPUs."""
 
@@ -613,6 +649,8 @@ class ShardedAdamW:
             raise ValueError("ShardedAdamW needs AdapterGradSync(collective='reduce_scatter')")
         self.sync = sync
         self.flats = sync.flat_parameters()
+        if any(f.dtype != torch.float32 for f in self.flats):
+            raise TypeError("ShardedAdamW keeps its moments in the parameter dtype: fp32 adapter parameters only")
         sync._shard_only = sync._reduce  # with one rank (and no forced collectives) the plain path below updates everything
         self.world = sync.world_size if sync._reduce else 1
         if sync.comm is not None:
@@ -640,6 +678,17 @@ class ShardedAdamW:
         on_gpu = sync.device.type == "cuda"
         self.inner = torch.optim.AdamW(shards, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **({"fused": True} if on_gpu else {}))
         self.param_groups = self.inner.param_groups
+        self._layout = {"world": self.world, "rank": self.rank, "shard_numels": [int(q.numel()) for q in shards]}
+
+    def state_dict(self):
+        """rank-local: the moments of THIS rank's shards + the layout they were cut for"""
+        return {"inner": self.inner.state_dict(), "layout": dict(self._layout)}
+
+    def load_state_dict(self, state):
+        if state.get("layout") != self._layout:
+            raise ValueError(f"ShardedAdamW: state saved for layout {state.get('layout')}, this optimizer has {self._layout} "
+                             "(world size, rank and bucket_bytes must match: the moments belong to this rank's shards)")
+        self.inner.load_state_dict(state["inner"])
 
     @torch.no_grad()
     def step(self):

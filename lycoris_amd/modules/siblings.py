@@ -31,15 +31,14 @@ import torch
 
 from .. import ops
 
-_STATE = {"enabled": True, "autocast": False, "prev": None, "sets": 0, "launches": 0, "hits": 0, "dissolved": 0}
+_STATE = {"enabled": True, "autocast": True, "prev": None, "sets": 0, "launches": 0, "hits": 0, "dissolved": 0}
 MAX_SET = 4  # K4_GROUP_MAX of csrc/kron4.h
 
 
 def enable(on: bool = True, autocast=None):
     """switch sibling grouping on / off (off: existing sets stay but are not used or extended).
-    `autocast=True` additionally lets sets form on fp32 activations under a 16-bit torch.autocast (see activation_ok); OFF by default:
-    that path is written and covered on the host side, but its GPU test (tests/test_gpu_siblings.py, LYC_TEST_AUTOCAST_SIBLINGS=1) has
-    not run on an MI355X yet -- round 5 ended before it could."""
+    `autocast` (default ON since round 6): sets also form on fp32 activations under a 16-bit torch.autocast (see activation_ok) -- the
+    configuration sd-scripts' mixed_precision=bf16 runs; `autocast=False` restricts the sets to 16-bit activations."""
     _STATE["enabled"] = bool(on)
     if autocast is not None:
         _STATE["autocast"] = bool(autocast)
@@ -65,7 +64,7 @@ class SiblingSet:
             if m is None or getattr(m, "_sib", None) is not self:
                 return None
             out.append(m)
-        return out
+        return out or None  # (an emptied set -- dissolved through another reference -- is dead too)
 
     def dissolve(self):
         for r in self.members:
@@ -97,7 +96,8 @@ def _key(mod, x):
     if k is None:  # (factor shapes never change after construction: computed once per module)
         k = mod._sibling_key()
         object.__setattr__(mod, "_sib_key_cached", k)
-    return (k, x.dtype, x.device, x.shape, torch.get_autocast_dtype("cuda") if (x.dtype == torch.float32 and x.is_cuda) else None)
+    # (no x.shape: the kernels take any row count, and aspect-ratio buckets / a last partial batch must not dissolve the sets)
+    return (k, x.dtype, x.device, torch.get_autocast_dtype("cuda") if (x.dtype == torch.float32 and x.is_cuda) else None)
 
 
 def forget(mod):
@@ -123,24 +123,27 @@ def forward(mod, x) -> Optional[torch.Tensor]:
                 _STATE["hits"] += 1
                 return y
             st.dissolve()  # the host model's call pattern is not what was learned
-            return None
-        members = st.alive()
-        if members is None or st.key != _key(mod, x):
-            st.dissolve()
-            return None
-        if members[0] is mod and len(members) > 1:
-            if not all(m._sibling_eligible(x) for m in members[1:]):
+            st = None
+        else:
+            members = st.alive()
+            if members is None or st.key != _key(mod, x):
                 st.dissolve()
-                return None
-            st.pending.clear()  # (results nobody fetched: a sibling skipped its call in the last pass)
-            bases = [m.org_forward(x) for m in members]
-            ys = mod._sibling_launch(members, x, bases)  # [base_i + delta_i]: one grouped launch of the algorithm's kernels
-            ver = x._version
-            for m, y in zip(members[1:], ys[1:]):
-                st.pending[id(m)] = (x, ver, y)
-            _STATE["launches"] += 1
-            return ys[0]
-        return None  # a member that is called without a parked result (the leader was skipped): per-layer path, set kept
+                st = None
+            elif members[0] is mod and len(members) > 1:
+                if all(m._sibling_eligible(x) for m in members[1:]):
+                    st.pending.clear()  # (results nobody fetched: a sibling skipped its call in the last pass)
+                    bases = [m.org_forward(x) for m in members]
+                    ys = mod._sibling_launch(members, x, bases)  # [base_i + delta_i]: one grouped launch of the algorithm's kernels
+                    ver = x._version
+                    for m, y in zip(members[1:], ys[1:]):
+                        st.pending[id(m)] = (x, ver, y)
+                    _STATE["launches"] += 1
+                    return ys[0]
+                st.dissolve()
+                st = None
+            else:
+                return None  # a member that is called without a parked result (the leader was skipped): per-layer path, set kept
+    # (after a dissolve the module learns again right away, so the whole q / k / v set re-forms in the next pass)
     # ---- learning: did the previous eligible module see this very tensor? -------------------------------------------------------
     prev, _STATE["prev"] = _STATE["prev"], (weakref.ref(mod), weakref.ref(x), x._version, _key(mod, x))
     if prev is None:
@@ -173,6 +176,14 @@ class SiblingMixin:
     @staticmethod
     def _sibling_launch(members, x, bases):
         raise NotImplementedError
+
+    def __getstate__(self):
+        # copy.deepcopy / pickle (torch.save(module), spawn): set membership is a fact about the LIVE host model's call pattern --
+        # weakrefs and parked tensors -- and is learned again by the copy on its first forward pass
+        state = self.__dict__.copy()
+        state.pop("_sib", None)
+        state.pop("_sib_key_cached", None)
+        return state
 
     def forward(self, x, *args, **kwargs):
         # projections called with one tensor run as ONE launch; everything else is the per-layer path

@@ -350,8 +350,6 @@ class NormedAttn(nn.Module):
         return h + self.attn(self.norm(h))
 
 
-@pytest.mark.skipif(not os.environ.get("LYC_TEST_AUTOCAST_SIBLINGS"),
-                    reason="opt-in path (siblings.enable(autocast=True)): not yet run on an MI355X; set LYC_TEST_AUTOCAST_SIBLINGS=1")
 @pytest.mark.parametrize("rank", [10000, -16], ids=["lokr_full_matrix", "locon_rank16"])
 @pytest.mark.parametrize("layer_dtype", [torch.float32, torch.bfloat16], ids=["layers_f32", "layers_bf16"])
 def test_sibling_sets_under_autocast_take_the_fp32_output_of_a_layernorm(layer_dtype, rank):

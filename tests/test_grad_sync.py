@@ -413,6 +413,45 @@ def test_sharded_adamw_single_process_is_plain_adamw():
         assert all(torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(mine, ref))
 
 
+def test_sharded_adamw_state_is_rank_local_and_refuses_another_layout():
+    """ADVICE r5: the moments belong to this rank's shards -- the state dict carries the layout it was cut for and a mismatching one
+    is refused; 16-bit parameter arenas are refused (the moments would silently be 16-bit)"""
+    from lycoris_amd.grad_sync import AdapterGradSync, ShardedAdamW
+    torch.manual_seed(2)
+    mine = [torch.nn.Parameter(torch.randn(s)) for s in [(8, 8), (33,)]]
+    sync = AdapterGradSync(mine, collective="reduce_scatter")
+    opt = ShardedAdamW(sync, lr=1e-2)
+    opt.zero_grad()
+    sum((p ** 2).sum() for p in mine).backward()
+    sync.finish(); opt.step()
+    st = opt.state_dict()
+    assert st["layout"] == {"world": 1, "rank": 0, "shard_numels": [97]}
+    other = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    sync2 = AdapterGradSync(other, collective="reduce_scatter")
+    opt2 = ShardedAdamW(sync2, lr=1e-2)
+    opt2.load_state_dict(st)                                   # same layout: accepted, moments restored
+    m1 = next(iter(opt.inner.state.values()))["exp_avg"]
+    m2 = next(iter(opt2.inner.state.values()))["exp_avg"]
+    assert torch.equal(m1, m2)
+    bad = dict(st, layout=dict(st["layout"], world=2))
+    with pytest.raises(ValueError, match="layout"):
+        opt2.load_state_dict(bad)
+    half = [torch.nn.Parameter(torch.randn(16).bfloat16())]
+    with pytest.raises(TypeError, match="fp32"):
+        ShardedAdamW(AdapterGradSync(half, collective="reduce_scatter"))
+
+
+def test_overlap_rule_is_payload_aware():
+    """VERDICT r5 weak #7: captured steps overlap their collectives when the estimated ring time exceeds the cost of the second queue"""
+    from lycoris_amd.grad_sync import exchange_estimate_ms, overlap_pays
+    assert exchange_estimate_ms(160 << 20, 1) == 0.0 and not overlap_pays(787 << 20, 1)
+    assert abs(exchange_estimate_ms(250_000_000, 8) - 1.75) < 1e-9
+    assert overlap_pays(787 << 20, 2) and overlap_pays(787 << 20, 8)          # LoHa: always
+    assert not overlap_pays(25 << 20, 8) and not overlap_pays(153 << 20, 2)    # LoKr rank 16; LoKr full matrix on two GPUs
+    assert overlap_pays(153 << 20, 8)                                          # ... on eight: marginal (1.1 ms against the 1.0 ms hop)
+    assert not overlap_pays(153 << 20, 8, hop_ms=2.0) and overlap_pays(153 << 20, 2, busbw_gbs=100.0)
+
+
 # ---- round 5: the ProcessGroup-free communicator path (host logic; the real thing runs in tests/test_gpu_grad_sync.py) -----------------
 class _FakeComm:
     """records what AdapterGradSync asks of a communicator; `world` ranks, this is rank `rank`"""

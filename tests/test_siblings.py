@@ -193,20 +193,72 @@ def test_locon_and_low_rank_lokr_modules_form_sets_of_their_own_kind(host_eligib
     assert ma._sib is None and mb._sib is None
 
 
-def test_fp32_activations_under_autocast_are_an_opt_in():
-    """siblings.enable(autocast=True): the eligibility test of the GPU path (activation_ok) -- host tensors never qualify, the flag is
-    off by default and survives enable(True) / enable(False) unless named"""
+def test_fp32_activations_under_autocast_are_on_by_default():
+    """siblings.enable(autocast=...): the eligibility test of the GPU path (activation_ok) -- host tensors never qualify, the flag is
+    ON by default (round 6: sd-scripts' mixed precision hands fp32 LayerNorm outputs to to_q / to_k / to_v) and survives
+    enable(True) / enable(False) unless named"""
     x = torch.randn(4, 64)
-    assert siblings._STATE["autocast"] is False and not siblings.activation_ok(x) and not siblings.activation_ok(x.bfloat16())
+    assert siblings._STATE["autocast"] is True and not siblings.activation_ok(x) and not siblings.activation_ok(x.bfloat16())
     try:
-        siblings.enable(True, autocast=True)
-        assert siblings._STATE["autocast"] is True
+        siblings.enable(True, autocast=False)
+        assert siblings._STATE["autocast"] is False
         siblings.enable(False)
         siblings.enable(True)
-        assert siblings._STATE["autocast"] is True and not siblings.activation_ok(x)   # (a host tensor all the same)
+        assert siblings._STATE["autocast"] is False and not siblings.activation_ok(x)   # (a host tensor all the same)
         # the set key tells autocast dtypes apart only for fp32 HIP tensors
         m = LokrModule("k", nn.Linear(64, 64), 1.0, 10000, 1, factor=4)
         assert siblings._key(m, x)[-1] is None
     finally:
-        siblings.enable(True, autocast=False)
-    assert siblings._STATE["autocast"] is False
+        siblings.enable(True, autocast=True)
+    assert siblings._STATE["autocast"] is True
+
+
+def test_deepcopy_and_pickle_of_a_model_whose_sets_have_formed(host_eligible):
+    """set membership (weakrefs + parked tensors) is not module state -- a deep copy / a pickled module drops it and
+    learns its own sets on its first forward pass; the reference's modules support both"""
+    import copy
+    import io
+    torch.manual_seed(0)
+    block = Block()
+    block._mods = adapt(block)
+    h, ctx = torch.randn(2, 9, 64), torch.randn(2, 5, 32)
+    run(block, h, ctx)
+    want = run(block, h, ctx)
+    q = block._mods[0]
+    assert q._sib is not None and len(q._sib.members) == 3
+    twin = copy.deepcopy(block)
+    assert all("_sib" not in m.__dict__ and "_sib_key_cached" not in m.__dict__ for m in twin._mods)
+    for _ in range(3):                       # learning pass, then two grouped passes of the COPY's own sets
+        got = run(twin, h, ctx)
+    assert twin._mods[0]._sib is not None and twin._mods[0]._sib is not q._sib
+    assert torch.equal(got[0], want[0])
+    assert q._sib is not None and len(q._sib.alive()) == 3          # the original's sets are untouched
+    buf = io.BytesIO()
+    torch.save(q, buf)                                                # whole-module pickling (torch.save(module), spawn)
+    buf.seek(0)
+    q2 = torch.load(buf, weights_only=False)
+    assert q2._sib is None and torch.equal(q2.lokr_w2, q.lokr_w2)
+    # a set emptied behind a member's back is dead, not an IndexError
+    st = q._sib
+    st.members = []
+    assert st.alive() is None
+    got = run(block, h, ctx)
+    assert torch.equal(got[0], want[0])
+
+
+def test_a_change_of_the_activation_shape_keeps_the_sets(host_eligible):
+    """aspect-ratio buckets / a last partial batch change x.shape[:-1] only -- the kernels take any row count, so the
+    sets stay; and a set that does dissolve re-forms completely (leader included) within the next two passes"""
+    torch.manual_seed(0)
+    block = Block()
+    block._mods = adapt(block)
+    ctx = torch.randn(2, 5, 32)
+    run(block, torch.randn(2, 9, 64), ctx)
+    for n in (9, 7, 12, 9):
+        run(block, torch.randn(2, n, 64), ctx)
+    st = siblings.stats()
+    assert st["dissolved"] == 0 and st["sets"] == 2 and st["launches"] == 8, st
+    q = block._mods[0]
+    q._sib.dissolve()
+    run(block, torch.randn(2, 9, 64), ctx)   # learning again (the leader records itself right after the dissolve)
+    assert q._sib is not None and [r().lora_name for r in q._sib.members] == ["attn1_to_q", "attn1_to_k", "attn1_to_v"]
