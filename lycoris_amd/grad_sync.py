@@ -711,8 +711,3 @@ class ShardedAdamW:
     def zero_grad(self, set_to_none: bool = False):
         self.sync.zero_grad()
 
-    def state_dict(self):
-        return self.inner.state_dict()
-
-    def load_state_dict(self, sd):
-        self.inner.load_state_dict(sd)
