@@ -2336,13 +2336,6 @@ void launch_gemm16_group(const Gemm16Group& ga, hipStream_t st) {
   const dim3 grid((unsigned)ga.wg_end[ga.n - 1]);
   hipLaunchKernelGGL((gemm16_kernel<T, G16_TM, A_KS, B_KS>), grid, dim3(NTHREADS), gemm16_lds_bytes<G16_TM>(), st, ga);
 }
-inline bool gemm16_ok(const Gemm16Prob& p, bool a_ks, bool b_ks) {
-  const bool al = ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15u) == 0 && (p.lda % 8) == 0 && (p.ldb % 8) == 0;
-  const bool kc = (a_ks && b_ks) || (p.K % 8) == 0;  // a K-contiguous operand is read in 16-byte vectors along K
-  const bool ks = (!a_ks || (p.M % 8) == 0) && (!b_ks || (p.N % 8) == 0);
-  const long ae = a_ks ? (long)p.K * p.lda : (long)p.M * p.lda, be = b_ks ? (long)p.K * p.ldb : (long)p.N * p.ldb;
-  return al && kc && ks && ae < (1L << 30) && be < (1L << 30);
-}
 // one problem; mode: 0 = NT, 1 = NN (B K-strided), 2 = TN (both K-strided)
 template <typename T>
 void launch_gemm16(const Gemm16Prob& p, int mode, int out_f32, hipStream_t st) {

@@ -38,6 +38,15 @@ struct Gemm16Group {
 };
 static_assert(sizeof(Gemm16Group) <= 3584, "kernel arguments are limited to 4 KiB");
 
+// can gemm16_kernel take this problem?  (16-byte vectors along the contiguous dimension of each operand, 32-bit offsets)
+inline bool gemm16_ok(const Gemm16Prob& p, bool a_ks, bool b_ks) {
+  const bool al = ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15u) == 0 && (p.lda % 8) == 0 && (p.ldb % 8) == 0;
+  const bool kc = (a_ks && b_ks) || (p.K % 8) == 0;  // a K-contiguous operand is read in 16-byte vectors along K
+  const bool ks = (!a_ks || (p.M % 8) == 0) && (!b_ks || (p.N % 8) == 0);
+  const long ae = a_ks ? (long)p.K * p.lda : (long)p.M * p.lda, be = b_ks ? (long)p.K * p.ldb : (long)p.N * p.ldb;
+  return al && kc && ks && ae < (1L << 30) && be < (1L << 30);
+}
+
 template <int TM>
 __host__ __device__ constexpr int gemm16_lds_bytes() {
   const int stage = 2 * (TM + 128) * G16_LD * 2;   // two buffers, A + B tiles
