@@ -61,6 +61,18 @@ static float bench(hipStream_t st, int nlaunch, int reps, F&& fn) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   float best = 1e30f;
+  if (getenv("G16_EAGER")) {  // plain stream launches (rocprofv3 cannot sample inside graph replays)
+    for (int r = 0; r < 2; ++r) {
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < nlaunch; ++i) fn(i);
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms = 0.f;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (ms < best) best = ms;
+    }
+    return best * 1e3f / nlaunch;
+  }
   hipGraph_t g;
   hipGraphExec_t ge;
   CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -227,6 +239,28 @@ int main(int argc, char** argv) {
         printf("   %-18s wgs %5d lds %3dK | %8.2f us %7.1f TF/s  x%.2f  relerr %.2e%s\n", v.name, wgs, lds >> 10, t, flops / t * 1e-6,
                t_old > 0 ? t_old / t : 0.0, e, (e > (f32 ? 1e-5 : 3e-3)) ? "  <<<< WRONG" : "");
       }
+    }
+    if (getenv("G16_ABLATE")) {  // where does a K step spend its time?  (mode 0 on this shape; results are garbage)
+      auto prob0 = [&](const Set& z) {
+        Gemm16Prob p{};
+        p.A = z.x; p.B = z.w; p.C = z.y; p.M = M; p.N = O; p.K = I; p.lda = I; p.ldb = I; p.ldc = O; p.alpha = 1.0f;
+        return p;
+      };
+#define ABL(BM_, BN_, D_, bits)                                                                                                          \
+      {                                                                                                                                  \
+        auto kern = gemm16d_kernel<__bf16, BM_, BN_, false, false, D_, bits>;                                                            \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));            \
+        const float t = bench(st, 30, 5, [&](int i) {                                                                                    \
+          Gemm16Group ga{};                                                                                                              \
+          ga.n = 1; ga.p[0] = prob0(sets[i % nsets]);                                                                                    \
+          ga.wg_end[0] = gemm16d_wgs((long)((M + BM_ - 1) / BM_) * ((O + BN_ - 1) / BN_));                                              \
+          hipLaunchKernelGGL(kern, dim3((unsigned)ga.wg_end[0]), dim3(NTHREADS), gemm16d_lds_bytes(BM_, BN_, D_), st, ga);              \
+        });                                                                                                                              \
+        printf("   ablate %dx%d D%d bits %2d (1 no refill, 2 no mfma, 4 no lds reads, 8 no barrier): %8.2f us\n", BM_, BN_, D_, bits, t);  \
+      }
+      ABL(128, 128, 3, 0) ABL(128, 128, 3, 1) ABL(128, 128, 3, 2) ABL(128, 128, 3, 4) ABL(128, 128, 3, 6) ABL(128, 128, 3, 7) ABL(128, 128, 3, 8)
+      ABL(128, 128, 3, 5) ABL(128, 128, 3, 3) ABL(128, 128, 3, 15)
+      ABL(64, 64, 3, 0) ABL(64, 64, 3, 1) ABL(64, 64, 3, 2) ABL(64, 64, 3, 4) ABL(64, 64, 3, 6) ABL(64, 64, 3, 7) ABL(64, 64, 3, 15)
     }
     for (Set& z : sets) { CK(hipFree(z.x)); CK(hipFree(z.g)); CK(hipFree(z.w)); CK(hipFree(z.y)); CK(hipFree(z.dx)); CK(hipFree(z.G)); }
     CK(hipFree(cref)); CK(hipFree(cout));

@@ -22,6 +22,7 @@
 #endif
 #include "loha_mfma.h"
 #include "gemm16.h"
+#include "gemm16d.h"
 #include "lokr_kernels.h"
 #include "lowrank.h"
 #include "skinny_kernels.h"
@@ -2336,11 +2337,63 @@ void launch_gemm16_group(const Gemm16Group& ga, hipStream_t st) {
   const dim3 grid((unsigned)ga.wg_end[ga.n - 1]);
   hipLaunchKernelGGL((gemm16_kernel<T, G16_TM, A_KS, B_KS>), grid, dim3(NTHREADS), gemm16_lds_bytes<G16_TM>(), st, ga);
 }
-// one problem; mode: 0 = NT, 1 = NN (B K-strided), 2 = TN (both K-strided)
+// ---- gemm16d.h (round 6): both operands by LDS-DMA, transposed LDS reads, register epilogue -------------------------------------
+// Tile classes (profiles/r06_c4_g16bench_two_phase_pipeline.log, every SDXL / SD1.5 shape x the three contractions): what bounds these
+// kernels is the operand delivery of a CU (16-25 B / clk through its L1: r06_c6_g16_pmc_tcc_sq_tcp.log), so a problem wants as many
+// CUs as it can get before it wants a bigger tile:
+//   >= 300 tiles of 128 x 128: 128 x 128, two-slot ring, two workgroups per CU        (FFN up, the grouped G = g^T x launches)
+//   >= 128                   : 128 x 128, three-slot ring                             (4096-row attention, FFN down of the 640 blocks)
+//   otherwise                : 128 x 64 if that gives >= 128 tiles, else 64 x 64      (1024-row attention, FFN down, text-context layers)
+enum { G16D_128_D2 = 0, G16D_128_D3 = 1, G16D_12864 = 2, G16D_64 = 3, G16D_CLASSES = 4 };
+inline int gemm16d_class(long M, long N) {
+  const long t128 = cdiv(M, 128) * cdiv(N, 128);
+  if (t128 >= 300) return G16D_128_D2;
+  if (t128 >= 128) return G16D_128_D3;
+  return cdiv(M, 128) * cdiv(N, 64) >= 128 ? G16D_12864 : G16D_64;
+}
+inline void gemm16d_tile(int cls, int& bm, int& bn) {
+  bm = cls == G16D_64 ? 64 : 128;
+  bn = (cls == G16D_64 || cls == G16D_12864) ? 64 : 128;
+}
+inline int gemm16d_problem_wgs(const Gemm16Prob& p, int cls) {
+  int bm, bn;
+  gemm16d_tile(cls, bm, bn);
+  return gemm16d_wgs(cdiv(p.M, bm) * cdiv(p.N, bn));
+}
+template <typename T, int BM, int BN, bool A_KS, bool B_KS, int D>
+void launch_gemm16d_inst(const Gemm16Group& ga, hipStream_t st) {
+  constexpr int lds = gemm16d_lds_bytes(BM, BN, D);
+  auto kern = gemm16d_kernel<T, BM, BN, A_KS, B_KS, D>;
+  if (lds > 64 * 1024) {  // more than the default dynamic-LDS window: opt in once per instantiation
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)once;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)ga.wg_end[ga.n - 1]), dim3(NTHREADS), lds, st, ga);
+}
+// every problem of `ga` is planned for tile class `cls` (wg_end from gemm16d_problem_wgs)
+template <typename T, bool A_KS, bool B_KS>
+void launch_gemm16d_group(const Gemm16Group& ga, int cls, hipStream_t st) {
+  switch (cls) {
+    case G16D_128_D2: launch_gemm16d_inst<T, 128, 128, A_KS, B_KS, 2>(ga, st); break;
+    case G16D_128_D3: launch_gemm16d_inst<T, 128, 128, A_KS, B_KS, 3>(ga, st); break;
+    case G16D_12864: launch_gemm16d_inst<T, 128, 64, A_KS, B_KS, 3>(ga, st); break;
+    default: launch_gemm16d_inst<T, 64, 64, A_KS, B_KS, 3>(ga, st); break;
+  }
+}
+
+// one problem; mode: 0 = NT, 1 = NN (B K-strided), 2 = TN (both K-strided).  gemm16d where the operands allow it, else gemm16.
 template <typename T>
 void launch_gemm16(const Gemm16Prob& p, int mode, int out_f32, hipStream_t st) {
   Gemm16Group ga{};
   ga.n = 1; ga.out_f32 = out_f32; ga.p[0] = p;
+  if (gemm16d_ok(p, mode == 2, mode >= 1, out_f32 != 0)) {
+    const int cls = gemm16d_class(p.M, p.N);
+    ga.wg_end[0] = gemm16d_problem_wgs(p, cls);
+    if (mode == 0) launch_gemm16d_group<T, false, false>(ga, cls, st);
+    else if (mode == 1) launch_gemm16d_group<T, false, true>(ga, cls, st);
+    else launch_gemm16d_group<T, true, true>(ga, cls, st);
+    return;
+  }
   ga.wg_end[0] = (int)(cdiv(p.M, G16_TM) * cdiv(p.N, 128));
   if (mode == 0) launch_gemm16_group<T, false, false>(ga, st);
   else if (mode == 1) launch_gemm16_group<T, false, true>(ga, st);
@@ -2538,40 +2591,53 @@ int lyc_loha_wgrad_group(const LycLohaWgradItem* items, int n, int dtype, void* 
     if (!lyc_loha_wgrad_deferrable(it.g, it.x, it.M, it.I, it.O, it.r, dtype))
       return fail(LYC_ERR_UNSUPPORTED, "loha_wgrad_group: item %d needs 16-bit activations", k);
   }
-  {  // G_k = g_k^T x_k (fp32, [O, I]) of ALL layers: gemm16 TN, up to 24 layers per launch (128 x 128 tiles: thousands of workgroups)
+  {  // G_k = g_k^T x_k (fp32, [O, I]) of ALL layers: gemm16d TN (gemm16 for operands it does not take), up to 24 layers per launch
     const bool bf = (dtype & 0xff) == LYC_BF16;
-    Gemm16Group ga{};
-    ga.out_f32 = 1;
-    auto flush = [&]() -> int {
-      if (ga.n == 0) return LYC_OK;
-      if (bf) launch_gemm16_group<__bf16, true, true>(ga, st);
-      else launch_gemm16_group<_Float16, true, true>(ga, st);
-      ga = Gemm16Group{};
+    // the batch supplies the parallelism: one tile class for the whole call, chosen for the sum of its problems
+    long t128 = 0;
+    for (int k = 0; k < n; ++k) t128 += cdiv(items[k].O, 128) * cdiv(items[k].I, 128);
+    const int cls = t128 >= 300 ? G16D_128_D2 : (t128 >= 128 ? G16D_128_D3 : G16D_64);
+    for (int pass = 0; pass < 2; ++pass) {  // pass 0: gemm16d problems, pass 1: the rest on gemm16
+      Gemm16Group ga{};
       ga.out_f32 = 1;
-      return check_launch("loha_wgrad_group(G)");
-    };
-    for (int k = 0; k < n; ++k) {
-      const LycLohaWgradItem& it = items[k];
-      Gemm16Prob gp{};
-      gp.A = it.g; gp.B = it.x; gp.C = it.gw; gp.M = it.O; gp.N = it.I; gp.K = (int)it.M; gp.lda = it.O; gp.ldb = it.I; gp.ldc = it.I;
-      gp.alpha = 1.0f;
-      if (!gemm16_ok(gp, true, true)) {  // odd dims: the generic TN kernel, one launch
-        GemmArgs ta{};
-        ta.A = it.g; ta.Bh = it.x; ta.out = it.gw; ta.M = it.O; ta.N = it.I; ta.K = it.M;
-        ta.lda = it.O; ta.ldb = it.I; ta.ldo = it.I; ta.alpha = 1.0f; ta.atomic = 0; ta.chunk = it.M;
-        dim3 gg((unsigned)cdiv(it.O, 128), (unsigned)cdiv(it.I, 128), 1);
-        if (bf) hipLaunchKernelGGL((gemm_tn_kernel<__bf16>), gg, dim3(NTHREADS), 0, st, ta);
-        else hipLaunchKernelGGL((gemm_tn_kernel<_Float16>), gg, dim3(NTHREADS), 0, st, ta);
-        continue;
+      auto flush = [&]() -> int {
+        if (ga.n == 0) return LYC_OK;
+        if (pass == 0) {
+          if (bf) launch_gemm16d_group<__bf16, true, true>(ga, cls, st);
+          else launch_gemm16d_group<_Float16, true, true>(ga, cls, st);
+        } else {
+          if (bf) launch_gemm16_group<__bf16, true, true>(ga, st);
+          else launch_gemm16_group<_Float16, true, true>(ga, st);
+        }
+        ga = Gemm16Group{};
+        ga.out_f32 = 1;
+        return check_launch("loha_wgrad_group(G)");
+      };
+      for (int k = 0; k < n; ++k) {
+        const LycLohaWgradItem& it = items[k];
+        Gemm16Prob gp{};
+        gp.A = it.g; gp.B = it.x; gp.C = it.gw; gp.M = it.O; gp.N = it.I; gp.K = (int)it.M; gp.lda = it.O; gp.ldb = it.I; gp.ldc = it.I;
+        gp.alpha = 1.0f;
+        const bool dma = gemm16d_ok(gp, true, true, true);
+        if (dma != (pass == 0)) continue;
+        if (!dma && !gemm16_ok(gp, true, true)) {  // odd dims: the generic TN kernel, one launch
+          GemmArgs ta{};
+          ta.A = it.g; ta.Bh = it.x; ta.out = it.gw; ta.M = it.O; ta.N = it.I; ta.K = it.M;
+          ta.lda = it.O; ta.ldb = it.I; ta.ldo = it.I; ta.alpha = 1.0f; ta.atomic = 0; ta.chunk = it.M;
+          dim3 gg((unsigned)cdiv(it.O, 128), (unsigned)cdiv(it.I, 128), 1);
+          if (bf) hipLaunchKernelGGL((gemm_tn_kernel<__bf16>), gg, dim3(NTHREADS), 0, st, ta);
+          else hipLaunchKernelGGL((gemm_tn_kernel<_Float16>), gg, dim3(NTHREADS), 0, st, ta);
+          continue;
+        }
+        const long wgs = dma ? gemm16d_problem_wgs(gp, cls) : cdiv(it.O, G16_TM) * cdiv(it.I, 128);
+        if (ga.n == G16_MAX || (ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs > (1L << 30))
+          if (int rc = flush()) return rc;
+        ga.p[ga.n] = gp;
+        ga.wg_end[ga.n] = (int)((ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs);
+        ++ga.n;
       }
-      const long wgs = cdiv(it.O, G16_TM) * cdiv(it.I, 128);
-      if (ga.n == G16_MAX || (ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs > (1L << 30))
-        if (int rc = flush()) return rc;
-      ga.p[ga.n] = gp;
-      ga.wg_end[ga.n] = (int)((ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs);
-      ++ga.n;
+      if (int rc = flush()) return rc;
     }
-    if (int rc = flush()) return rc;
   }
   for (int fast = 0; fast < 2; ++fast)
   for (int no = 1; no <= 2; no <<= 1) {  // one sequence of launches per kernel instantiation

@@ -57,6 +57,11 @@ __device__ __forceinline__ void g16d_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <typename F, int... Q>
+__device__ __forceinline__ void g16d_for_each(F&& f, std::integer_sequence<int, Q...>) {
+  (f(std::integral_constant<int, Q>{}), ...);
+}
+
 // XOR applied to the 16-byte chunk index of a row (K-contiguous image, 8 chunks per row)
 //   natural row order (lane i reads row 16 t + i):                     (r >> 1) & 7
 //   paired order (lane i reads row 32 q + 8 (i >> 2) + 4 e + (i & 3)):  ((r >> 1) & 1) | (((r >> 3) & 3) << 1)
@@ -152,13 +157,20 @@ struct G16DOperand {
     }
   }
 
-  __device__ __forceinline__ void issue(char* smem, int slot_off, int stage_off, int ks) const {
+  // piece J of this wave for K step ks (beyond K: the K-strided source is out of bounds -> zeros, a K-contiguous one reads on into the
+  // next row of a slot nobody reads: the refill is UNCONDITIONAL, so every K step issues the same number of DMA operations)
+  template <int J>
+  __device__ __forceinline__ void issue_piece(char* smem, int slot_off, int stage_off, int ks) const {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-      char* dst = smem + slot_off + stage_off + (wave + NWAVES * j) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (k4_lds_ptr)dst, 16, (int)voff[j], (int)((unsigned)ks * kstep), 0, 0);
-    }
+    char* dst = smem + slot_off + stage_off + (wave + NWAVES * J) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (k4_lds_ptr)dst, 16, (int)voff[J], (int)((unsigned)ks * kstep), 0, 0);
+  }
+  template <int... J>
+  __device__ __forceinline__ void issue(char* smem, int slot_off, int stage_off, int ks, std::integer_sequence<int, J...>) const {
+    (issue_piece<J>(smem, slot_off, stage_off, ks), ...);
+  }
+  __device__ __forceinline__ void issue(char* smem, int slot_off, int stage_off, int ks) const {
+    issue(smem, slot_off, stage_off, ks, std::make_integer_sequence<int, PPW>{});
   }
 
   // The fragments of K half KK (32 deep) of the stage at LDS byte address `sb`: lane (i, g) receives k = 32 KK + 8 g .. + 7 of its row.
@@ -198,9 +210,10 @@ struct G16DOperand {
 // is 8 * per workgroups (the surplus ones return).
 __host__ __device__ inline int gemm16d_wgs(long tiles) { return (int)(8 * ((tiles + 7) / 8)); }
 
-template <typename T, int BM, int BN, bool A_KS, bool B_KS, int D>
+// ABL != 0: ablation builds of benchmarks/g16bench.cpp (results are garbage): 1 = no refill DMA in the loop, 2 = no MFMAs, 4 = no LDS
+// fragment reads, 8 = no barrier
+template <typename T, int BM, int BN, bool A_KS, bool B_KS, int D, int ABL = 0>
 __device__ __forceinline__ void gemm16d_body(const Gemm16Prob& p, int out_f32, char* smem, int b) {
-  using F8 = typename TT<T>::frag;
   using OA = G16DOperand<T, BM, A_KS, false>;
   using OB = G16DOperand<T, BN, B_KS, true>;
   constexpr int MI = OA::NT, NI = OB::NT;
@@ -224,13 +237,23 @@ __device__ __forceinline__ void gemm16d_body(const Gemm16Prob& p, int out_f32, c
   oa.setup(p.A, p.lda, m0, p.M, p.K, 0, wr);
   ob.setup(p.B, p.ldb, n0, p.N, p.K, OFF_B, wc);
 
+  // Ring of D slots, two-phase register pipeline.  A K step is two 32-deep halves; the fragments of a half are read from LDS while the
+  // MFMAs of the half before run, the workgroup barrier sits in the MIDDLE of the step:
+  //
+  //     read half 1 (ks)            | MFMA half 0 (ks)                    [its fragments were read during the step before]
+  //     wait: half 1 landed, step ks + 1 landed (counted vmcnt) -- s_barrier: slot ks is free, slot ks + 1 is visible
+  //     read half 0 (ks + 1)        | MFMA half 1 (ks)  + the refill of slot ks with step ks + D, one DMA behind every STRIDE-th MFMA
+  //
+  // so the LDS pipe (a 128 x 128 step reads 64 KiB = 512 cycles at 128 B / clk) and the matrix pipe (32 MFMAs per wave = 512 cycles)
+  // run side by side instead of one after the other.  Measured history (profiles/r06_c2 / c3_g16bench.log): all refills of a step
+  // issued up front, reads, then MFMAs: ~1270 cycles per K step; refills interleaved: the same (the LDS reads were the exposed part).
+  // The refill is UNCONDITIONAL (beyond K it fetches zeros / dead rows), so "all but the newest D - 2 groups have landed" is one
+  // counted wait, the same in every step.
   const int nk = (p.K + G16D_BK - 1) / G16D_BK;
-  auto issue = [&](int ks, int slot) {
-    oa.issue(smem, slot * STAGE, 0, ks);
-    ob.issue(smem, slot * STAGE, OFF_B, ks);
-  };
-  const int npro = nk < D ? nk : D;
-  for (int s = 0; s < npro; ++s) issue(s, s);
+  for (int s = 0; s < D; ++s) {
+    oa.issue(smem, s * STAGE, 0, s);
+    ob.issue(smem, s * STAGE, OFF_B, s);
+  }
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -238,45 +261,68 @@ __device__ __forceinline__ void gemm16d_body(const Gemm16Prob& p, int out_f32, c
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = zero4();
 
+  constexpr int NH = MI * NI;          // MFMAs per wave and K half
+  constexpr int STRIDE = NH / C;       // one refill DMA behind every STRIDE-th MFMA of the second half
+  static_assert(STRIDE >= 1 && STRIDE * C <= NH, "refill interleave");
+  constexpr int R1 = OA::NRAW + OB::NRAW;  // LDS reads of one K half (lgkmcnt is a 4-bit counter: at most 15 are named)
   const unsigned sbase = (unsigned)(size_t)(k4_lds_ptr)smem;
-  int slot = 0, prev = 0;
+  typename OA::RawT a0[OA::NRAW], a1[OA::NRAW];
+  typename OB::RawT b0[OB::NRAW], b1[OB::NRAW];
+  k4_wait_vm<(D - 1) * C>();
+  __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain the DMA queue (vmcnt(0))
+  asm volatile("" ::: "memory");
+  ob.template read<0>(sbase, b0);
+  oa.template read<0>(sbase, a0);
+  int slot = 0;
   for (int ks = 0; ks < nk; ++ks) {
-    // groups issued so far: 0 .. min(nk - 1, max(D - 1, ks + D - 2)); all but those newer than `ks` must have landed
-    int newest = ks + D - 2;
-    if (newest < D - 1) newest = D - 1;
-    if (newest > nk - 1) newest = nk - 1;
-    k4_wait_groups<C>(newest - ks);
-    __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain the DMA queue (vmcnt(0))
-    asm volatile("" ::: "memory");
-    if (ks >= 1 && ks - 1 + D < nk) issue(ks - 1 + D, prev);  // every wave is past its reads of `prev` (it arrived at this barrier)
     const unsigned sb = sbase + (unsigned)(slot * STAGE);
-    typename OA::RawT a0[OA::NRAW], a1[OA::NRAW];
-    typename OB::RawT b0[OB::NRAW], b1[OB::NRAW];
-    ob.template read<0>(sb, b0);
-    oa.template read<0>(sb, a0);
-    ob.template read<1>(sb, b1);
-    oa.template read<1>(sb, a1);
-    constexpr int R1 = OA::NRAW + OB::NRAW;  // LDS reads of the second K half (lgkmcnt is a 4-bit counter: at most 15 are named)
+    const int fill_off = slot * STAGE, ksf = ks + D;
+    const int next = slot + 1 == D ? 0 : slot + 1;
+    if constexpr ((ABL & 4) == 0) {
+      ob.template read<1>(sb, b1);
+      oa.template read<1>(sb, a1);
+    }
     g16d_lgkm<(R1 > 15 ? 15 : R1)>();
     OB::tie(b0);
     OA::tie(a0);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT<T>::mma(OB::get(b0, ni), OA::get(a0, mi), acc[mi][ni]);
+    g16d_for_each([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      if constexpr ((ABL & 2) == 0) acc[Q % MI][Q / MI] = TT<T>::mma(OB::get(b0, Q / MI), OA::get(a0, Q % MI), acc[Q % MI][Q / MI]);
+    }, std::make_integer_sequence<int, NH>{});
     __builtin_amdgcn_sched_barrier(0);
     g16d_lgkm<0>();
     OB::tie(b1);
     OA::tie(a1);
+    if constexpr ((ABL & 1) == 0) k4_wait_vm<(D - 2) * C>();
+    if constexpr ((ABL & 8) == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned sn = sbase + (unsigned)(next * STAGE);
+    if constexpr ((ABL & 4) == 0) {
+      ob.template read<0>(sn, b0);
+      oa.template read<0>(sn, a0);
+    }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT<T>::mma(OB::get(b1, ni), OA::get(a1, mi), acc[mi][ni]);
-    prev = slot;
-    slot = slot + 1 == D ? 0 : slot + 1;
+    g16d_for_each([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      if constexpr ((ABL & 2) == 0) acc[Q % MI][Q / MI] = TT<T>::mma(OB::get(b1, Q / MI), OA::get(a1, Q % MI), acc[Q % MI][Q / MI]);
+      if constexpr ((Q + 1) % STRIDE == 0 && (Q + 1) / STRIDE <= C && (ABL & 1) == 0) {
+        constexpr int P = (Q + 1) / STRIDE - 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P < OA::PPW) oa.template issue_piece<P>(smem, fill_off, 0, ksf);
+        else ob.template issue_piece<P - OA::PPW>(smem, fill_off, OFF_B, ksf);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }, std::make_integer_sequence<int, NH>{});
+    slot = next;
   }
+  // the fragment reads of the step behind the last one and the surplus refills (zeros / dead rows) have landed before anything else
+  // is put into those registers / before the workgroup leaves
+  g16d_lgkm<0>();
+  OB::tie(b0);
+  OA::tie(a0);
+  k4_wait_vm<0>();
+  __builtin_amdgcn_sched_barrier(0);
 
   // ---- epilogue: straight from the accumulators.  acc[mi][2q + e] of lane (li, g): row m0 + wr WM + 16 mi + li, columns
   //      n0 + wc WN + 32 q + 8 g + 4 e + {0..3} -- a tile pair is 8 consecutive columns --------------------------------------------
@@ -314,14 +360,14 @@ __device__ __forceinline__ void gemm16d_body(const Gemm16Prob& p, int out_f32, c
 template <int BM, int BN, int D>
 __host__ __device__ constexpr int gemm16d_occupancy() { return 2 * gemm16d_lds_bytes(BM, BN, D) <= 160 * 1024 ? 2 : 1; }
 
-template <typename T, int BM, int BN, bool A_KS, bool B_KS, int D>
+template <typename T, int BM, int BN, bool A_KS, bool B_KS, int D, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS, (gemm16d_occupancy<BM, BN, D>())) void gemm16d_kernel(Gemm16Group ga) {
   extern __shared__ __attribute__((aligned(1024))) char g16d_smem[];
   const int b = (int)blockIdx.x;
   int p = 0;
   while (p + 1 < ga.n && b >= ga.wg_end[p]) ++p;
   const int b0 = p ? ga.wg_end[p - 1] : 0;  // a multiple of 8: every problem's range is gemm16d_wgs(tiles)
-  gemm16d_body<T, BM, BN, A_KS, B_KS, D>(ga.p[p], ga.out_f32, g16d_smem, b - b0);
+  gemm16d_body<T, BM, BN, A_KS, B_KS, D, ABL>(ga.p[p], ga.out_f32, g16d_smem, b - b0);
 }
 
 // can the DMA kernel take this problem?  (mode bits as gemm16.h: A_KS / B_KS)
