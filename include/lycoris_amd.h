@@ -41,7 +41,7 @@ enum { LYC_F32_ROWS = 0x100, LYC_DEFER_WGRAD = 0x200,
 #define LYC_KCONV_ROW_TILE(mi) (((mi) & 0xf) << 12)
 enum { LYC_OK = 0, LYC_ERR_ARG = 1, LYC_ERR_UNSUPPORTED = 2, LYC_ERR_LAUNCH = 3 };
 
-#define LYC_ABI_VERSION 11
+#define LYC_ABI_VERSION 12
 int lyc_abi_version(void);
 const char* lyc_last_error(void);
 
@@ -407,6 +407,18 @@ int lyc_im2col(const void* x, void* cols, int64_t B, int64_t C, int64_t H, int64
                int sw, int ph, int pw, int dh, int dw, int dtype, void* stream);
 int lyc_col2im(const void* dcols, void* dx, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw, int sh,
                int sw, int ph, int pw, int dh, int dw, int dtype, void* stream);
+/* Round 6 (ABI 12): the same lowering on NHWC ROW matrices with WINDOW-MAJOR columns
+ *   cols[(b,oh,ow), (i*kw + j)*C + c] = x_rows[(b, oh*sh-ph+i*dh, ow*sw-pw+j*dw), c]
+ * -- a channels_last tensor is its own row matrix and a tap's column block is a contiguous run of channels, so every access is a
+ * 16-byte vector (the NCHW forms above are element-wise gathers: 183 us per SDXL conv layer).  The factor that meets these columns is the
+ * reference's [r, C*kh*kw] one with its columns permuted to window-major order ([r, C, kh*kw] -> [r, kh*kw, C]; csrc/torch_ops.cpp does
+ * that for LoHa, whose Conv2d form is reference lycoris/modules/loha.py:301-322 with F.conv2d of functional/general.py:6).
+ * 16-bit tensors, C % 8 == 0, 16-byte aligned; LYC_ERR_UNSUPPORTED otherwise.  lyc_col2im_rows: gather form, fp32 accumulation, one
+ * rounding; `dtype | LYC_F32_ROWS`: dcols is fp32. */
+int lyc_im2col_rows(const void* x_rows, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int ph,
+                    int pw, int dh, int dw, int dtype, void* stream);
+int lyc_col2im_rows(const void* dcols, void* dx_rows, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int ph,
+                    int pw, int dh, int dw, int dtype, void* stream);
 int lyc_nchw_to_rows(const void* t, void* rows, int64_t B, int64_t C, int64_t P, int dtype, void* stream);
 int lyc_rows_to_nchw(const void* rows, void* t, int64_t B, int64_t C, int64_t P, int dtype, void* stream);
 

@@ -21,6 +21,7 @@
 #include "../../benchmarks/experiments/kron_conv_dw2.h"
 #endif
 #include "loha_mfma.h"
+#include "loha_grad16.h"
 #include "gemm16.h"
 #include "gemm16d.h"
 #include "lokr_kernels.h"
@@ -2433,9 +2434,16 @@ void plan_loha_grad(long O, long I, int r, bool grouped, int& no, int& nt) {
   }
 }
 
+// loha_grad16.h's kernels use 74 KiB of dynamic LDS: opt in once per instantiation
+template <typename K>
+void loha_grad16_optin(K kern) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, loha_grad16_lds_bytes());
+}
+// split16: the caller's activations are 16-bit (the factor gradients carry the 1e-4 bound of DESIGN.md 4): bf16 hi / lo operands on the
+// 16-bit matrix cores (loha_grad16.h) where the layer allows it.  fp32 callers (the weight-space path, fp32 activations) stay exact.
 void launch_loha_factor_grad(const float* gw, const float* w1a, const float* w1b, const float* w2a, const float* w2b,
                              float* d_w1a, float* d_w1b, float* d_w2a, float* d_w2b, long O, long I, int r, float alpha,
-                             hipStream_t st) {
+                             hipStream_t st, bool split16 = false) {
   LohaArgs la{};
   la.w1a = w1a; la.w1b = w1b; la.w2a = w2a; la.w2b = w2b; la.O = O; la.I = I; la.R = r; la.scale = alpha;
   la.G = gw; la.d_w1a = d_w1a; la.d_w1b = d_w1b; la.d_w2a = d_w2a; la.d_w2b = d_w2b;
@@ -2444,6 +2452,13 @@ void launch_loha_factor_grad(const float* gw, const float* w1a, const float* w1b
   plan_loha_grad(O, I, r, false, no, gm.nt);
   const long tiles_o = cdiv(O, LOHA_T), tiles_j = cdiv(I, LOHA_T);
   dim3 fg((unsigned)cdiv(tiles_o, no), (unsigned)cdiv(tiles_j, gm.nt));
+  if (split16 && loha_grad16_ok(w1a, w1b, w2a, w2b, gw, I, r)) {
+    static const int once = (loha_grad16_optin(loha_factor_grad16_kernel<1>), loha_grad16_optin(loha_factor_grad16_kernel<2>), 0);
+    (void)once;
+    if (no == 2) hipLaunchKernelGGL((loha_factor_grad16_kernel<2>), fg, dim3(NTHREADS), loha_grad16_lds_bytes(), st, la, gm);
+    else hipLaunchKernelGGL((loha_factor_grad16_kernel<1>), fg, dim3(NTHREADS), loha_grad16_lds_bytes(), st, la, gm);
+    return;
+  }
   if (loha_grad_fast(w1a, w1b, w2a, w2b, I, r)) {
     switch (no) {
       case 2: hipLaunchKernelGGL((loha_factor_grad_mfma_kernel<2, true>), fg, dim3(NTHREADS), 0, st, la, gm); break;
@@ -2477,7 +2492,12 @@ int lyc_loha_linear_fwd(const void* x, const float* w1a, const float* w1b, const
   la.Wn_h = pl.nh; la.Wn_l = pl.nl; la.Wt_h = pl.th; la.Wt_l = pl.tl; la.ldn = pl.ldn; la.ldt = pl.ldt;
   dim3 rg((unsigned)cdiv(O, LOHA_T), (unsigned)cdiv(I, LOHA_T));
   const bool wt16 = pl.th != nullptr;  // the transposed plane is read by the generic dx kernels only
-  switch (dtype & 0xff) {
+  const bool fast16 = !wt16 && (dtype & 0xff) != LYC_F32 && loha_rebuild16_ok(la);  // hi / lo operands on the 16-bit matrix cores
+  switch (fast16 ? -1 : (dtype & 0xff)) {
+    case -1:
+      if ((dtype & 0xff) == LYC_BF16) hipLaunchKernelGGL((loha_rebuild16_kernel<__bf16>), rg, dim3(NTHREADS), 0, st, la);
+      else hipLaunchKernelGGL((loha_rebuild16_kernel<_Float16>), rg, dim3(NTHREADS), 0, st, la);
+      break;
     case LYC_BF16:
       if (wt16) hipLaunchKernelGGL((loha_rebuild_mfma_kernel<__bf16, true>), rg, dim3(NTHREADS), 0, st, la);
       else hipLaunchKernelGGL((loha_rebuild_mfma_kernel<__bf16, false>), rg, dim3(NTHREADS), 0, st, la);
@@ -2567,7 +2587,7 @@ int lyc_loha_linear_bwd(const void* g, const void* x, const float* w1a, const fl
       dim3 gg((unsigned)cdiv(O, 128), (unsigned)cdiv(I, 128), 1);
       DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_tn_kernel<T>), gg, dim3(NTHREADS), 0, st, ga));
     }
-    launch_loha_factor_grad(gw, w1a, w1b, w2a, w2b, d_w1a, d_w1b, d_w2a, d_w2b, O, I, r, alpha, st);
+    launch_loha_factor_grad(gw, w1a, w1b, w2a, w2b, d_w1a, d_w1b, d_w2a, d_w2b, O, I, r, alpha, st, lib);
   }
   return check_launch("loha_linear_bwd");
 }
@@ -2639,13 +2659,19 @@ int lyc_loha_wgrad_group(const LycLohaWgradItem* items, int n, int dtype, void* 
       if (int rc = flush()) return rc;
     }
   }
-  for (int fast = 0; fast < 2; ++fast)
+  // fast: 0 = general form, 1 = one rank chunk + float4 staging on the fp32 matrix core, 2 = bf16 hi / lo split (loha_grad16.h)
+  for (int fast = 0; fast < 3; ++fast)
   for (int no = 1; no <= 2; no <<= 1) {  // one sequence of launches per kernel instantiation
     LohaGradGroupArgs ga{};
     auto flush = [&]() -> int {
       if (ga.n == 0) return LYC_OK;
       const dim3 grid((unsigned)ga.wg_end[ga.n - 1]);
-      if (fast) {
+      if (fast == 2) {
+        static const int once = (loha_grad16_optin(loha_factor_grad16_group_kernel<1>), loha_grad16_optin(loha_factor_grad16_group_kernel<2>), 0);
+        (void)once;
+        if (no == 2) hipLaunchKernelGGL((loha_factor_grad16_group_kernel<2>), grid, dim3(NTHREADS), loha_grad16_lds_bytes(), st, ga);
+        else hipLaunchKernelGGL((loha_factor_grad16_group_kernel<1>), grid, dim3(NTHREADS), loha_grad16_lds_bytes(), st, ga);
+      } else if (fast) {
         switch (no) {
           case 2: hipLaunchKernelGGL((loha_factor_grad_group_kernel<2, true>), grid, dim3(NTHREADS), 0, st, ga); break;
           default: hipLaunchKernelGGL((loha_factor_grad_group_kernel<1, true>), grid, dim3(NTHREADS), 0, st, ga); break;
@@ -2663,7 +2689,8 @@ int lyc_loha_wgrad_group(const LycLohaWgradItem* items, int n, int dtype, void* 
       const LycLohaWgradItem& it = items[k];
       int pno = 1, nt = 1;
       plan_loha_grad(it.O, it.I, it.r, n >= LYC_GROUP_MIN, pno, nt);
-      if (pno != no || (loha_grad_fast(it.w1a, it.w1b, it.w2a, it.w2b, it.I, it.r) ? 1 : 0) != fast) continue;
+      const int lvl = loha_grad16_ok(it.w1a, it.w1b, it.w2a, it.w2b, it.gw, it.I, it.r) ? 2 : (loha_grad_fast(it.w1a, it.w1b, it.w2a, it.w2b, it.I, it.r) ? 1 : 0);
+      if (pno != no || lvl != fast) continue;
       const long gx = cdiv(cdiv(it.O, LOHA_T), no), gy = cdiv(cdiv(it.I, LOHA_T), nt);
       const long before = ga.n ? ga.wg_end[ga.n - 1] : 0;
       if (ga.n == LHG_MAX || before + gx * gy > (1L << 30))
@@ -2831,6 +2858,46 @@ int lyc_col2im(const void* dcols, void* dx, int64_t B, int64_t C, int64_t H, int
                                              (hipStream_t)stream, static_cast<const T*>(dcols), static_cast<T*>(dx), cg));
   }
   return check_launch("col2im");
+}
+
+// NHWC row matrices, window-major columns (conv_kernels.h); 16-bit tensors, C % 8 == 0, 16-byte aligned
+int lyc_im2col_rows(const void* x_rows, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int ph,
+                    int pw, int dh, int dw, int dtype, void* stream) {
+  ConvGeom cg{};
+  if (int rc = conv_geom(cg, B, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw)) return rc;
+  if (!x_rows || !cols) return fail(LYC_ERR_ARG, "im2col_rows: null pointer");
+  const int dt = dtype & 0xff;
+  if ((dt != LYC_BF16 && dt != LYC_F16) || (C % 8) != 0 || ((reinterpret_cast<uintptr_t>(x_rows) | reinterpret_cast<uintptr_t>(cols)) & 15u))
+    return fail(LYC_ERR_UNSUPPORTED, "im2col_rows: 16-bit tensors, C %% 8 == 0, 16-byte aligned");
+  if (B == 0) return LYC_OK;
+  const long total = cg.B * cg.Ho * cg.Wo * kh * kw * (cg.C / 8);
+  if (dt == LYC_BF16) hipLaunchKernelGGL((im2col_rows_kernel<__bf16>), dim3(stream_blocks(total)), dim3(NTHREADS), 0, (hipStream_t)stream,
+                                         static_cast<const __bf16*>(x_rows), static_cast<__bf16*>(cols), cg);
+  else hipLaunchKernelGGL((im2col_rows_kernel<_Float16>), dim3(stream_blocks(total)), dim3(NTHREADS), 0, (hipStream_t)stream,
+                          static_cast<const _Float16*>(x_rows), static_cast<_Float16*>(cols), cg);
+  return check_launch("im2col_rows");
+}
+
+int lyc_col2im_rows(const void* dcols, void* dx_rows, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw, int sh, int sw, int ph,
+                    int pw, int dh, int dw, int dtype, void* stream) {
+  ConvGeom cg{};
+  if (int rc = conv_geom(cg, B, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw)) return rc;
+  if (!dcols || !dx_rows) return fail(LYC_ERR_ARG, "col2im_rows: null pointer");
+  const int dt = dtype & 0xff;
+  if ((dt != LYC_BF16 && dt != LYC_F16) || (C % 8) != 0 || ((reinterpret_cast<uintptr_t>(dcols) | reinterpret_cast<uintptr_t>(dx_rows)) & 15u))
+    return fail(LYC_ERR_UNSUPPORTED, "col2im_rows: 16-bit tensors, C %% 8 == 0, 16-byte aligned");
+  if (B == 0) return LYC_OK;
+  const long total = cg.B * cg.H * cg.W * (cg.C / 8);
+  const dim3 grid(stream_blocks(total));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype & LYC_F32_ROWS) {
+    if (dt == LYC_BF16) hipLaunchKernelGGL((col2im_rows_kernel<__bf16, float>), grid, dim3(NTHREADS), 0, st, static_cast<const float*>(dcols), static_cast<__bf16*>(dx_rows), cg);
+    else hipLaunchKernelGGL((col2im_rows_kernel<_Float16, float>), grid, dim3(NTHREADS), 0, st, static_cast<const float*>(dcols), static_cast<_Float16*>(dx_rows), cg);
+  } else {
+    if (dt == LYC_BF16) hipLaunchKernelGGL((col2im_rows_kernel<__bf16, __bf16>), grid, dim3(NTHREADS), 0, st, static_cast<const __bf16*>(dcols), static_cast<__bf16*>(dx_rows), cg);
+    else hipLaunchKernelGGL((col2im_rows_kernel<_Float16, _Float16>), grid, dim3(NTHREADS), 0, st, static_cast<const _Float16*>(dcols), static_cast<_Float16*>(dx_rows), cg);
+  }
+  return check_launch("col2im_rows");
 }
 
 extern "C++" {

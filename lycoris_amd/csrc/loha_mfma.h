@@ -13,6 +13,7 @@
 // every wave emits whole 64-byte runs.
 #pragma once
 #include "dense_kernels.h"
+#include "gemm16d.h"
 
 namespace lyc {
 
@@ -208,6 +209,114 @@ __global__ __launch_bounds__(NTHREADS) void loha_rebuild_mfma_kernel(LohaArgs a)
           }
       }
     }
+  }
+}
+
+// ---- round 6: the 16-bit operand plane on the 16-bit matrix cores ---------------------------------------------------------------------
+// loha_rebuild_mfma_kernel above forms W1 = w1a w1b and W2 = w2a w2b with v_mfma_f32_16x16x4_f32 (exact products, 1/16 of the 16-bit
+// matrix rate, one ds_read_b32 per operand value): 10.4 us per layer, 8.2 ms of the SDXL step for 5 GB of plane writes
+// (profiles/r06_c9_loha_kernel_stats.csv).  The rank is 32 = ONE K step of v_mfma_f32_16x16x32: with the fp32 factors split into hi + lo
+// parts (x = hi + lo up to 2^-17 relative; tile.h split_f) a 16 x 16 block of W is three MFMAs (hi hi + lo hi + hi lo; the dropped lo lo
+// term is 2^-18 relative) -- 2^-16 relative in W where the plane is then rounded to T at 2^-9 (bf16) / 2^-12 (fp16).
+//   * a-side factors [64 o][32 r] -> LDS as T hi / lo images, K-contiguous rows: ds_read_b128 fragments;
+//   * b-side factors [32 r][64 i] -> LDS as they lie in memory (k-major): ds_read_b64_tr_b16 fragments (gemm16d.h's scheme, paired
+//     column order), so that a lane ends up with 8 consecutive i of one row o: 16-byte stores of the K-contiguous plane.
+// Taken for T in {bf16, fp16}, R <= 32, R % 4 == 0, I % 8 == 0, 16-byte aligned factors and plane; everything else stays above.
+inline bool loha_rebuild16_ok(const LohaArgs& a) {
+  return a.R <= LOHA_RC && (a.R % 4) == 0 && (a.I % 8) == 0 && (a.ldn % 8) == 0 &&
+         (((reinterpret_cast<uintptr_t>(a.w1a) | reinterpret_cast<uintptr_t>(a.w2a) | reinterpret_cast<uintptr_t>(a.w1b) |
+            reinterpret_cast<uintptr_t>(a.w2b) | reinterpret_cast<uintptr_t>(a.Wn_h)) & 15u) == 0);
+}
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void loha_rebuild16_kernel(LohaArgs a) {
+  // images: A1h A1l A2h A2l [64 o][32 r] T (4 KiB each), B1h B1l B2h B2l [32 r][64 i] T (4 KiB each)
+  __shared__ __attribute__((aligned(16))) char sm[8 * 4096];
+  using F8 = typename TT<T>::frag;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const long o0 = (long)blockIdx.x * LOHA_T, i0 = (long)blockIdx.y * LOHA_T;
+  // ---- stage: every load issued before the first LDS write ---------------------------------------------------------------------
+  f32x4 va[2][2], vb[2][2];  // [factor 1 / 2][iteration]
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = tid + NTHREADS * it;
+    const int o = e >> 3, c4 = (e & 7) * 4;            // a: row o, ranks c4 .. c4 + 3
+    const bool ok = (o0 + o < a.O) && (c4 < a.R);
+    const long idx = ok ? (o0 + o) * a.R + c4 : 0;
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.w1a + idx), x2 = *reinterpret_cast<const f32x4*>(a.w2a + idx);
+    va[0][it] = ok ? x1 : z;
+    va[1][it] = ok ? x2 : z;
+    const int rb = e >> 4, i4 = (e & 15) * 4;          // b: rank rb, columns i4 .. i4 + 3
+    const bool okb = (rb < a.R) && (i0 + i4 < a.I);
+    const long idb = okb ? (long)rb * a.I + i0 + i4 : 0;
+    const f32x4 y1 = *reinterpret_cast<const f32x4*>(a.w1b + idb), y2 = *reinterpret_cast<const f32x4*>(a.w2b + idb);
+    vb[0][it] = okb ? y1 : z;
+    vb[1][it] = okb ? y2 : z;
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = tid + NTHREADS * it;
+    const int o = e >> 3, c4 = (e & 7) * 4, rb = e >> 4, i4 = (e & 15) * 4;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      T h[4], l[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) split_f<T>(va[f][it][q], h[q], l[q]);
+      *reinterpret_cast<u32x2*>(sm + (2 * f) * 4096 + o * 64 + c4 * 2) = *reinterpret_cast<const u32x2*>(h);
+      *reinterpret_cast<u32x2*>(sm + (2 * f + 1) * 4096 + o * 64 + c4 * 2) = *reinterpret_cast<const u32x2*>(l);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) split_f<T>(vb[f][it][q], h[q], l[q]);
+      *reinterpret_cast<u32x2*>(sm + (4 + 2 * f) * 4096 + rb * 128 + i4 * 2) = *reinterpret_cast<const u32x2*>(h);
+      *reinterpret_cast<u32x2*>(sm + (5 + 2 * f) * 4096 + rb * 128 + i4 * 2) = *reinterpret_cast<const u32x2*>(l);
+    }
+  }
+  __syncthreads();
+  // ---- a side (MFMA B operand): lane (o = 16 wave + li, g) holds ranks 8 g .. 8 g + 7 of A1h A1l A2h A2l ------------------------------
+  F8 af[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) af[p] = *reinterpret_cast<const F8*>(sm + p * 4096 + (16 * wave + li) * 64 + g * 16);
+  // ---- b side (MFMA A operand), transposed reads: lane t of a 16-lane group supplies (rank 8 g + (t >> 2) [+ 4], 4 columns); paired
+  //      column order: tile 2 q + e holds columns 32 q + 8 (t >> 2) + 4 e + (t & 3), so lane g owns 8 consecutive columns of the pair
+  const unsigned rdb = (unsigned)(size_t)(k4_lds_ptr)sm + 4 * 4096 + (unsigned)((8 * g + (li >> 2)) * 128 + (li & 3) * 16);
+  T* plane = static_cast<T*>(a.Wn_h);
+  const long o = o0 + 16 * wave + li;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    u32x2 r[2][4][2];  // [e][B1h B1l B2h B2l][k half]
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        r[e][p][0] = g16d_read_tr(rdb, p * 4096 + q * 64 + e * 8);
+        r[e][p][1] = g16d_read_tr(rdb, p * 4096 + q * 64 + e * 8 + 4 * 128);
+      }
+    g16d_lgkm<0>();
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        asm volatile("" : "+v"(r[e][p][0]));
+        asm volatile("" : "+v"(r[e][p][1]));
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    T ov[8];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      F8 bf[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) bf[p] = __builtin_bit_cast(F8, u32x4{r[e][p][0][0], r[e][p][0][1], r[e][p][1][0], r[e][p][1][1]});
+      f32x4 w1 = zero4(), w2 = zero4();
+      w1 = TT<T>::mma(bf[0], af[0], w1);
+      w2 = TT<T>::mma(bf[2], af[2], w2);
+      w1 = TT<T>::mma(bf[1], af[0], w1);
+      w2 = TT<T>::mma(bf[3], af[2], w2);
+      w1 = TT<T>::mma(bf[0], af[1], w1);
+      w2 = TT<T>::mma(bf[2], af[3], w2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ov[4 * e + j] = TT<T>::from_f(w1[j] * w2[j] * a.scale);
+    }
+    const long n = i0 + 32 * q + 8 * g;
+    if (o < a.O && n < a.I) *reinterpret_cast<u32x4*>(plane + o * a.ldn + n) = *reinterpret_cast<const u32x4*>(ov);
   }
 }
 

@@ -2615,6 +2615,26 @@ int64_t rows_out_features(int64_t algo, const Tensor& f0, const Tensor& f1) {
 int64_t rows_in_features(int64_t algo, const Tensor& f0, const Tensor& f1) {
   return algo == ALGO_LOKR ? f0.size(1) * f1.size(1) : algo == ALGO_LOCON ? f0.size(1) : f1.size(1);
 }
+// LoHa on a 16-bit Conv2d with C % 8 == 0 (round 6): the im2col matrix is built from the NHWC row matrix with WINDOW-MAJOR columns
+// (lyc_im2col_rows: 16-byte vectors, a channels_last tensor needs no copy at all) and meets the factors with their columns permuted the
+// same way.  The NCHW form (lyc_im2col: an element-wise gather, 183 us per SDXL layer; lyc_col2im: 165 us) cost 13 of LoHa's 88 ms.
+bool window_major_cols(const Tensor& x, int64_t algo, const Geom& gm, int64_t C) {
+  return algo == 2 /* ALGO_LOHA */ && x.scalar_type() != at::kFloat && (C % 8) == 0 && !(gm.kh == 1 && gm.kw == 1 && gm.sh == 1 && gm.sw == 1 && gm.ph == 0 && gm.pw == 0);
+}
+// [r, C*kk] (channel-major, the reference's layout) -> [r, kk*C] (window-major), fp32, contiguous
+Tensor to_window_major(const Tensor& f, int64_t C, int64_t kk) {
+  const int64_t r = f.size(0);
+  return f32c(f.detach()).view({r, C, kk}).transpose(1, 2).contiguous().view({r, kk * C});
+}
+Tensor im2col_rows_wm(const Tensor& x, const Geom& gm) {
+  const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+  bool copied;
+  Tensor xr = rows_view(x, &copied);
+  Tensor cols = at::empty({B * gm.Ho * gm.Wo, gm.kh * gm.kw * C}, x.options());
+  check_rc(lyc_im2col_rows(cptr(xr), mptr(cols), B, C, H, W, gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw, dtype_code(x.scalar_type()),
+                           stream_of(x)), "lyc_im2col_rows");
+  return cols;
+}
 Tensor im2col_rows(const Tensor& x, const Geom& gm) {
   const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
   Tensor xc = x.contiguous();
@@ -2638,19 +2658,24 @@ std::tuple<Tensor, Tensor, Tensor> adapter_conv2d_fwd(const Tensor& x, const Ten
   const int64_t I = rows_in_features(algo, f0, f1), O = rows_out_features(algo, f0, f1);
   TORCH_CHECK(I == C * gm.kh * gm.kw, "adapter expects ", I, " = C*kh*kw im2col features, input has C=", C, ", kernel=", kernel);
   const bool pw = pointwise(gm);
+  const bool wm = window_major_cols(x, algo, gm, C);
   bool copied = true;
-  Tensor rows = pw ? rows_view(x, &copied) : im2col_rows(x, gm);
+  Tensor rows = pw ? rows_view(x, &copied) : (wm ? im2col_rows_wm(x, gm) : im2col_rows(x, gm));
   Tensor y_rows, saved;
   if (algo == ALGO_LOKR) {
     y_rows = lokr_linear_fwd(rows, f0, f1, alpha, c10::nullopt);
     saved = at::empty({0}, x.options());
   } else if (algo == ALGO_LOCON) {
     std::tie(y_rows, saved) = locon_linear_fwd(rows, f0, f1, alpha);
+  } else if (wm) {
+    const int64_t kk = gm.kh * gm.kw;
+    std::tie(y_rows, saved) = loha_linear_fwd(rows, f0, to_window_major(f1, C, kk), *f2, to_window_major(*f3, C, kk), alpha);
   } else {
     std::tie(y_rows, saved) = loha_linear_fwd(rows, f0, f1, *f2, *f3, alpha);
   }
   (void)O;
-  return {from_rows(y_rows, B, gm.Ho, gm.Wo, pw && !copied), pw ? at::empty({0}, x.options()) : rows, saved};
+  // (window-major path: the layer output of a channels_last input is handed back channels_last -- a free view of the row matrix)
+  return {from_rows(y_rows, B, gm.Ho, gm.Wo, (pw && !copied) || (wm && rows_are_free(x))), pw ? at::empty({0}, x.options()) : rows, saved};
 }
 
 // dx and the factor gradients accumulated into the defined d[i]
@@ -2663,11 +2688,29 @@ Tensor adapter_conv2d_bwd_into(const Tensor& g, const Tensor& x_or_cols, bool is
   Tensor rows = is_cols ? x_or_cols : rows_view(x_or_cols, &cp);
   const bool f32_rows = is_cols && g.scalar_type() != at::kFloat;  // col2im sums up to kh*kw row entries per pixel: fp32, rounded once
   Tensor dx_rows;
+  const int64_t C = xshape[1];
+  const bool wm = is_cols && window_major_cols(g, algo, gm, C);
   if (algo == ALGO_LOKR) dx_rows = lokr_linear_bwd_into(g_rows, rows, *f[0], *f[1], alpha, need_dx, d[0], d[1], f32_rows);
   else if (algo == ALGO_LOCON) dx_rows = locon_linear_bwd_into(g_rows, rows, *f[0], *f[1], saved, alpha, need_dx, d[0], d[1], f32_rows);
-  else dx_rows = loha_linear_bwd_into(g_rows, rows, *f[0], *f[1], *f[2], *f[3], saved, alpha, need_dx, d, f32_rows);
+  else if (wm) {
+    // window-major columns: the b-side factors and their gradients in the permuted layout; un-permuted into the callers' buffers
+    const int64_t kk = gm.kh * gm.kw, r = f[1]->size(0);
+    Tensor b1 = to_window_major(*f[1], C, kk), b2 = to_window_major(*f[3], C, kk);
+    Tensor dw[4] = {d[0], Tensor(), d[2], Tensor()};
+    if (d[1].defined()) dw[1] = at::zeros({r, kk * C}, b1.options());
+    if (d[3].defined()) dw[3] = at::zeros({r, kk * C}, b2.options());
+    dx_rows = loha_linear_bwd_into(g_rows, rows, *f[0], b1, *f[2], b2, saved, alpha, need_dx, dw, f32_rows);
+    if (d[1].defined()) d[1].view({r, C, kk}).add_(dw[1].view({r, kk, C}).transpose(1, 2));
+    if (d[3].defined()) d[3].view({r, C, kk}).add_(dw[3].view({r, kk, C}).transpose(1, 2));
+  } else dx_rows = loha_linear_bwd_into(g_rows, rows, *f[0], *f[1], *f[2], *f[3], saved, alpha, need_dx, d, f32_rows);
   if (!need_dx) return Tensor();
   if (!is_cols) return from_rows(dx_rows, B, H, W, x_cl);
+  if (wm) {
+    Tensor dxr = at::empty({B * H * W, C}, g.options());
+    check_rc(lyc_col2im_rows(cptr(dx_rows), mptr(dxr), B, C, H, W, gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw,
+                             dtype_code(g.scalar_type()) | (f32_rows ? LYC_F32_ROWS : 0), stream_of(g)), "lyc_col2im_rows");
+    return from_rows(dxr, B, H, W, x_cl);
+  }
   Tensor dx = at::empty(xshape, g.options());
   check_rc(lyc_col2im(cptr(dx_rows), mptr(dx), B, xshape[1], H, W, gm.kh, gm.kw, gm.sh, gm.sw, gm.ph, gm.pw, gm.dh, gm.dw,
                       dtype_code(g.scalar_type()) | (f32_rows ? LYC_F32_ROWS : 0), stream_of(g)), "lyc_col2im");
@@ -2774,7 +2817,8 @@ std::tuple<Tensor, Tensor, Tensor> adapter_conv2d_fwd_meta(const Tensor& x, cons
   const int64_t B = x.size(0), C = x.size(1), O = rows_out_features(algo, f0, f1), M = B * gm.Ho * gm.Wo;
   const bool pw = pointwise(gm);
   Tensor y = at::empty({B, O, gm.Ho, gm.Wo},
-                       x.options().memory_format(pw && rows_are_free(x) ? at::MemoryFormat::ChannelsLast : at::MemoryFormat::Contiguous));
+                       x.options().memory_format((pw || window_major_cols(x, algo, gm, C)) && rows_are_free(x) ? at::MemoryFormat::ChannelsLast
+                                                                                                           : at::MemoryFormat::Contiguous));
   Tensor cols = pw ? x.new_empty({0}) : x.new_empty({M, C * gm.kh * gm.kw});
   Tensor saved;
   if (algo == ALGO_LOKR) saved = x.new_empty({0});

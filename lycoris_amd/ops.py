@@ -345,6 +345,37 @@ def _col2im(dcols, xshape, dtype, geom):
     return dx
 
 
+# round 6: LoHa on a 16-bit Conv2d with C % 8 == 0 -- im2col / col2im on the NHWC row matrix with window-major columns
+# (lyc_im2col_rows / lyc_col2im_rows: 16-byte vectors), factors with their columns permuted the same way (csrc/torch_ops.cpp)
+def _window_major(core, x, geom):
+    return core is _LohaCore and x.dtype != torch.float32 and x.shape[1] % 8 == 0 and not _is_pointwise(geom)
+
+
+def _to_window_major(f, C, kk):
+    r = f.shape[0]
+    return _f32c(f.detach()).view(r, C, kk).transpose(1, 2).contiguous().view(r, kk * C)
+
+
+def _im2col_rows(x_rows, xshape, geom):
+    k, s, p, d = geom
+    B, C, H, W = xshape
+    Ho, Wo = _conv_out(H, W, k, s, p, d)
+    cols = torch.empty((B * Ho * Wo, k[0] * k[1] * C), dtype=x_rows.dtype, device=x_rows.device)
+    N.call("lyc_im2col_rows", N.ptr(x_rows), N.ptr(cols), B, C, H, W, k[0], k[1], s[0], s[1], p[0], p[1], d[0], d[1],
+           N.dtype_code(x_rows.dtype), N.stream_ptr(x_rows.device))
+    return cols
+
+
+def _col2im_rows(dcols, xshape, dtype, geom):
+    k, s, p, d = geom
+    B, C, H, W = xshape
+    dx_rows = torch.empty((B * H * W, C), dtype=dtype, device=dcols.device)
+    code = N.dtype_code(dtype) | (F32_ROWS if dcols.dtype == torch.float32 else 0)
+    N.call("lyc_col2im_rows", N.ptr(dcols), N.ptr(dx_rows), B, C, H, W, k[0], k[1], s[0], s[1], p[0], p[1], d[0], d[1], code,
+           N.stream_ptr(dcols.device))
+    return dx_rows
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # generic autograd Functions
 # ---------------------------------------------------------------------------------------------------------------
@@ -391,14 +422,21 @@ class _AdapterConv2d(torch.autograd.Function):
         if I != C * k[0] * k[1]:
             raise ValueError(f"adapter expects {I} = C*kh*kw im2col features, input has C={C}, kernel={k}")
         x_cl = False
+        wm = _window_major(core, x, geom)
         if _is_pointwise(geom):  # a 1x1 conv IS the row op on the NHWC pixel rows: free for a channels_last tensor
             rows, copied = _rows_view(x)
             x_cl = not copied
+        elif wm:
+            xr, copied = _rows_view(x)
+            x_cl = not copied
+            rows = _im2col_rows(xr, x.shape, geom)
+            kk = k[0] * k[1]
+            fs = [fs[0], _to_window_major(fs[1], C, kk), fs[2], _to_window_major(fs[3], C, kk)]
         else:
             rows = _im2col(x.contiguous(), geom)
         y_rows, saved = core.fwd(rows, fs, float(alpha))
         ctx.save_for_backward(rows, *factors, *saved)
-        ctx.meta = (core, float(alpha), geom, x.shape, len(factors), x_cl)
+        ctx.meta = (core, float(alpha), geom, x.shape, len(factors), x_cl, wm)
         sp = _conv_out(H, W, k, s, p, d)
         if x_cl:  # keep the caller's memory format: the row matrix is the channels_last tensor
             return y_rows.view(B, sp[0], sp[1], O).permute(0, 3, 1, 2)
@@ -406,7 +444,7 @@ class _AdapterConv2d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        core, alpha, geom, xshape, nf, x_cl = ctx.meta
+        core, alpha, geom, xshape, nf, x_cl, wm = ctx.meta
         rows, factors, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + nf], ctx.saved_tensors[1 + nf:]
         fs = [_f32c(t) for t in factors]
         g_rows, _ = _rows_view(g)
@@ -414,6 +452,23 @@ class _AdapterConv2d(torch.autograd.Function):
         pointwise = _is_pointwise(geom)
         # k > 1: col2im sums up to kh*kw row entries per pixel -> keep them in fp32 and round once
         bufs, hand_back = _grad_targets(factors, need_f)
+        if wm:  # the b-side factors and their gradients in the window-major layout; un-permuted into the callers' buffers
+            C, kk, r = xshape[1], geom[0][0] * geom[0][1], fs[1].shape[0]
+            fs = [fs[0], _to_window_major(fs[1], C, kk), fs[2], _to_window_major(fs[3], C, kk)]
+            wbufs = list(bufs)
+            for i in (1, 3):
+                if bufs[i] is not None:
+                    wbufs[i] = torch.zeros((r, kk * C), dtype=torch.float32, device=g.device)
+            dx_rows = core.bwd(g_rows, rows, fs, saved, alpha, need_x, need_f, True, wbufs)
+            for i in (1, 3):
+                if bufs[i] is not None:
+                    bufs[i].view(r, C, kk).add_(wbufs[i].view(r, kk, C).transpose(1, 2))
+            dx = None
+            if need_x:
+                dxr = _col2im_rows(dx_rows, xshape, rows.dtype, geom)
+                dx = (dxr.view(xshape[0], xshape[2], xshape[3], xshape[1]).permute(0, 3, 1, 2) if x_cl
+                      else _from_rows(dxr, xshape[0], xshape[2:]))
+            return (None, None, None, dx, *_finish_grads(factors, bufs, hand_back))
         dx_rows = core.bwd(g_rows, rows, fs, saved, alpha, need_x, need_f, not pointwise, bufs)
         dx = None
         if need_x and pointwise and x_cl:
