@@ -734,6 +734,27 @@ def main():
         result["per_algo"] = per_algo_legs()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.algo in ("lokr", "locon", "loha"):
         result["cpu_baseline"] = cpu_baseline(args.algo, args.model)
+    # the figures a reader needs from the line's scalars / `roofline` alone (the driver keeps those): eager-vs-eager speedup over the
+    # reference's torch call sequence, the contract step with the frozen layers in it, one {ms, frac} pair per BASELINE configuration
+    ref, bpa, pa = result.get("reference_rocm_eager"), result.get("base_plus_adapter"), result.get("per_algo")
+    if ref:
+        result["speedup_eager_vs_eager"] = ref["speedup_eager_vs_eager"]
+        result["native_eager_ms"], result["reference_eager_ms"] = ref["native_eager_ms"], ref["reference_eager_ms"]
+        result["speedup_native_graph_vs_reference_eager"] = ref["speedup_native_graph_vs_reference_eager"]
+    if bpa:
+        result["adapter_share"], result["base_plus_adapter_step_ms"] = bpa["adapter_share"], bpa["step_ms"]
+    if pa:
+        for name, leg in pa.items():
+            if "ms_per_step" in leg:
+                result[f"ms_{name}"] = leg["ms_per_step"]
+                if leg.get("roofline", {}).get("frac") is not None:
+                    result[f"frac_{name}"] = leg["roofline"]["frac"]
+    if result.get("roofline") is not None:
+        hl = {k: result[k] for k in ("speedup_eager_vs_eager", "native_eager_ms", "reference_eager_ms", "value_base_plus_adapter",
+                                     "adapter_share") if k in result}
+        if pa:
+            hl["per_algo"] = {name: {"ms": leg.get("ms_per_step"), "frac": leg.get("roofline", {}).get("frac")} for name, leg in pa.items()}
+        result["roofline"]["headline"] = hl
     if args.rccl_ws1:
         steps_run = args.warmup + args.steps
         sync.collectives_launched -= c0
@@ -852,7 +873,8 @@ def roofline(insts, args, dtype, dev):
         # reads its shared input once per pass: the x term is counted for the set's first member only (fewer algorithmic bytes)
         own_x = not (_groupable(it) and it.sibs[0] is not it)
         b_fwd += esz * ((M * I if own_x else 0) + M * O) + nfac
-        b_bwd += esz * (M * O + (2 if own_x else 1) * M * I) + 2 * nfac
+        # ... and in the backward the set reads x once and stores ONE summed dx: a non-leading member adds its g only (strict count)
+        b_bwd += esz * (M * O + (2 if own_x else 0) * M * I) + 2 * nfac
         flops += 3 * 2 * M * O * I
     saved = {}
 
