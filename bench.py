@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--no-base", action="store_true", help="skip the base+adapter leg")
     ap.add_argument("--no-per-algo", action="store_true",
                     help="skip the per_algo object (short runs of the other BASELINE configs in child processes)")
+    ap.add_argument("--no-own-base", action="store_true",
+                    help="base + adapter leg: F.linear and the adapter as two autograd nodes (rounds 1-5) instead of ops.lokr_adapted_linear")
     ap.add_argument("--no-siblings", action="store_true",
                     help="A/B, the round 1-4 layout: every layer instance owns its input and is launched on its own (default: the "
                          "to_q / to_k / to_v layers of a self-attention and to_k / to_v of a cross-attention read ONE tensor, as in the "
@@ -295,6 +297,7 @@ AUTOCAST = False
 LOKR_RANK = 0
 OVERLAP_LEG = False
 SIBLINGS = True
+OWN_BASE = True   # base + adapter leg: the frozen nn.Linear inside the LoKr adapter's autograd node (ops.lokr_adapted_linear); --no-own-base: two nodes
 
 
 def adapter_param_count(args):
@@ -325,10 +328,11 @@ def adapter_param_count(args):
 
 
 def build_instances(args, dtype, dev):
-    global CHANNELS_LAST, LOKR_RANK, OVERLAP_LEG, SIBLINGS, AUTOCAST
+    global CHANNELS_LAST, LOKR_RANK, OVERLAP_LEG, SIBLINGS, AUTOCAST, OWN_BASE
     AUTOCAST = bool(getattr(args, "autocast", False))
     OVERLAP_LEG = bool(getattr(args, "overlap_leg", False))
     SIBLINGS = not getattr(args, "no_siblings", False)
+    OWN_BASE = not getattr(args, "no_own_base", False)
     CHANNELS_LAST = bool(args.channels_last)
     LOKR_RANK = int(args.rank)
     gen = torch.Generator(device=dev).manual_seed(1234)
@@ -378,6 +382,13 @@ def forward_all(insts, with_base=False):
             continue
         grp = it.sibs
         if grp is not None and grp[0] is it and _groupable(it) and all(id(m) in present for m in grp):
+            if with_base and OWN_BASE and it.algo == "lokr" and len(it.params) == 2:  # frozen layers + adapters of the set: ONE autograd node
+                ys = it.ops.lokr_adapted_linear(it.x, [m.ensure_weight() for m in grp], [None] * len(grp), [m.params[0] for m in grp],
+                                                [m.params[1] for m in grp], [1.0] * len(grp))
+                for m, y in zip(grp[1:], ys[1:]):
+                    parked[id(m)] = y
+                outs.append((ys[0], it))
+                continue
             bases = [m.base_forward() for m in grp] if with_base else None
             if it.algo == "locon":  # (no fused epilogue: base + delta is an elementwise add, as in the modules)
                 ys = it.ops.locon_linear_group(it.x, [m.params[0] for m in grp], [m.params[1] for m in grp], [1.0] * len(grp))
@@ -391,6 +402,8 @@ def forward_all(insts, with_base=False):
             for m, y in zip(grp[1:], ys[1:]):
                 parked[id(m)] = y
             outs.append((ys[0], it))
+        elif with_base and OWN_BASE and it.algo == "lokr" and len(it.params) == 2 and it.spec["kind"] == "linear":
+            outs.append((it.ops.lokr_adapted_linear(it.x, [it.ensure_weight()], [None], [it.params[0]], [it.params[1]], [1.0])[0], it))
         else:
             outs.append((it.forward(base=it.base_forward()) if with_base else it.forward(), it))
     return outs

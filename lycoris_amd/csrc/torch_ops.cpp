@@ -1010,14 +1010,29 @@ std::vector<Tensor> lokr_linear_lr_group_fwd(const Tensor& x, at::TensorList fac
 
 struct LokrLinearGroupFn : public torch::autograd::Function<LokrLinearGroupFn> {
   // vars = [x, F factors per problem ..., base_0 ... base_{n-1} (optional)]
-  static variable_list forward(AutogradContext* ctx, at::TensorList vars, std::vector<double> alphas, int64_t F_) {
+  // own != 0 (round 6, lokr_adapted_linear): vars = [x, F factors per problem ..., W_0 ... W_{n-1}, bias_0 ... bias_{n-1} (undefined: none)]
+  // -- the node OWNS the frozen layers: base_i = x W_i^T + bias_i is formed here (library GEMM), and the backward adds g_i W_i into the
+  // adapter's dx with the GEMM's accumulate epilogue (dx.addmm_): x has ONE consumer, the engine's `dx_base + dx_adapter` pass is gone.
+  // (`frozen` = [W_0 ... W_{n-1}, bias_0 ... bias_{n-1}]: a std::vector<Tensor> argument is not an autograd input -- they have no gradient)
+  static variable_list forward(AutogradContext* ctx, at::TensorList vars, std::vector<double> alphas, int64_t F_, std::vector<Tensor> frozen = {}) {
     at::AutoDispatchBelowADInplaceOrView guard;
     const size_t n = alphas.size(), F = (size_t)F_;
-    const bool has_base = vars.size() == 1 + (F + 1) * n;
-    TORCH_CHECK(vars.size() == 1 + F * n || has_base, "lokr_linear_group: bad argument list");
+    const bool own = !frozen.empty();
+    const bool has_base = !own && vars.size() == 1 + (F + 1) * n;
+    TORCH_CHECK(own ? (vars.size() == 1 + F * n && frozen.size() == 2 * n) : (vars.size() == 1 + F * n || has_base), "lokr_linear_group: bad argument list");
     const Tensor& x = vars[0];
     at::TensorList factors = vars.slice(1, F * n);
-    at::TensorList bases = has_base ? vars.slice(1 + F * n, n) : at::TensorList();
+    std::vector<Tensor> own_bases;
+    if (own) {
+      TORCH_CHECK(eager_cuda(x), "lycoris_amd::lokr_adapted_linear is an eager op on device tensors");
+      for (size_t i = 0; i < n; ++i) {
+        const Tensor &W = frozen[i], &bias = frozen[n + i];
+        TORCH_CHECK(W.dim() == 2 && W.scalar_type() == x.scalar_type() && !W.requires_grad() && !(bias.defined() && bias.requires_grad()),
+                    "lokr_adapted_linear: frozen 2-D weights in the activation dtype");
+        own_bases.push_back(at::linear(x, W, bias.defined() ? c10::optional<Tensor>(bias) : c10::nullopt).contiguous());
+      }
+    }
+    at::TensorList bases = own ? at::TensorList(own_bases) : (has_base ? vars.slice(1 + F * n, n) : at::TensorList());
     std::vector<Tensor> ys;
     if (eager_cuda(x)) {
       ys = lokr_group_fwd_impl(x, factors, alphas, bases, F);
@@ -1032,6 +1047,8 @@ struct LokrLinearGroupFn : public torch::autograd::Function<LokrLinearGroupFn> {
     ctx->saved_data["has_base"] = has_base;
     ctx->saved_data["n"] = (int64_t)n;
     ctx->saved_data["F"] = F_;
+    ctx->saved_data["own"] = own;
+    if (own) ctx->saved_data["lyc_frozen_w"] = c10::List<Tensor>(std::vector<Tensor>(frozen.begin(), frozen.begin() + n));
     // (saved by reference in saved_data where they are leaves: save_vars' identity rule, for up to 1 + 3 * 4 tensors)
     variable_list keep(vars.begin(), vars.begin() + 1 + F * n);
     for (size_t i = 1; i < keep.size(); ++i)
@@ -1051,6 +1068,7 @@ struct LokrLinearGroupFn : public torch::autograd::Function<LokrLinearGroupFn> {
     const size_t n = (size_t)ctx->saved_data["n"].toInt(), F = (size_t)ctx->saved_data["F"].toInt();
     const std::vector<double> alphas = ctx->saved_data["alphas"].toDoubleVector();
     const bool has_base = ctx->saved_data["has_base"].toBool();
+    const bool own = ctx->saved_data["own"].toBool();
     const Tensor& x = s[0];
     const bool nx = ctx->needs_input_grad(0);
     variable_list out(1 + (F + (has_base ? 1 : 0)) * n);
@@ -1180,7 +1198,27 @@ struct LokrLinearGroupFn : public torch::autograd::Function<LokrLinearGroupFn> {
     if (has_base)
       for (size_t i = 0; i < n; ++i)
         if (ctx->needs_input_grad(1 + F * n + i)) out[1 + F * n + i] = grads[i];  // d(base + delta)/d base = 1
-    out.resize(out.size() + 3);  // `alphas` and `F` are non-tensor inputs (surplus undefined entries are dropped by the engine)
+    if (own && nx) {  // dx += g_i W_i: the frozen layers' input gradients, accumulated by the library GEMM's own epilogue
+      const int64_t I = x.size(-1);
+      Tensor acc;
+      if (out[0].defined()) acc = out[0].is_contiguous() ? out[0].view({-1, I}) : Tensor();
+      if (out[0].defined() && !acc.defined()) {
+        out[0] = out[0].contiguous();
+        acc = out[0].view({-1, I});
+      }
+      for (size_t i = 0; i < n; ++i) {
+        if (!grads[i].defined()) continue;
+        const Tensor W = ctx->saved_data["lyc_frozen_w"].toTensorList().get(i);
+        Tensor gi = rows_of(grads[i], W.size(0));
+        if (acc.defined()) {
+          acc.addmm_(gi, W);
+        } else {
+          acc = at::mm(gi, W);
+          out[0] = shaped_like(acc, x);
+        }
+      }
+    }
+    out.resize(out.size() + 4);  // `alphas` and `F` are non-tensor inputs (surplus undefined entries are dropped by the engine)
     return out;
   }
 };
@@ -1199,6 +1237,23 @@ std::vector<Tensor> lokr_linear_group_autograd(const Tensor& x, at::TensorList f
 }
 std::vector<Tensor> lokr_linear_lr_group_autograd(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList bases) {
   return lokr_group_autograd_impl(x, factors, alphas, bases, 3);
+}
+// round 6: the frozen nn.Linear layers of the set inside the node (n >= 1; a single layer is a set of one).  factors = [w1_0, w2_0, ...]
+std::vector<Tensor> lokr_adapted_linear_autograd(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList weights,
+                                                 const c10::List<c10::optional<Tensor>>& biases) {
+  const GradAtApply ga_;
+  const size_t n = alphas.size();
+  TORCH_CHECK(weights.size() == n && biases.size() == n && factors.size() == 2 * n, "lokr_adapted_linear: n alphas, 2n factors, n weights, n biases");
+  variable_list vars;
+  vars.reserve(1 + 2 * n);
+  vars.push_back(amp(x));
+  for (const Tensor& t : factors) vars.push_back(t);
+  std::vector<Tensor> frozen(weights.begin(), weights.end());
+  for (size_t i = 0; i < n; ++i) {
+    c10::optional<Tensor> b = biases.get(i);
+    frozen.push_back(b.has_value() ? *b : Tensor());
+  }
+  return LokrLinearGroupFn::apply(at::TensorList(vars), alphas.vec(), (int64_t)2, std::move(frozen));
 }
 std::vector<Tensor> lokr_linear_group_meta(const Tensor& x, at::TensorList factors, at::ArrayRef<double> alphas, at::TensorList bases) {
   auto oshape = x.sym_sizes().vec();
@@ -2851,6 +2906,7 @@ TORCH_LIBRARY(lycoris_amd, m) {
   m.def("lokr_linear(Tensor x, Tensor w1, Tensor w2, float alpha, Tensor? base=None) -> Tensor");
   m.def("lokr_linear_group(Tensor x, Tensor[] factors, float[] alphas, Tensor[] bases) -> Tensor[]");
   m.def("lokr_linear_lr_group(Tensor x, Tensor[] factors, float[] alphas, Tensor[] bases) -> Tensor[]");
+  m.def("lokr_adapted_linear(Tensor x, Tensor[] factors, float[] alphas, Tensor[] weights, Tensor?[] biases) -> Tensor[]");
   m.def("lokr_linear_lr(Tensor x, Tensor w1, Tensor w2a, Tensor w2b, float alpha, Tensor? base=None) -> Tensor");
   m.def("lokr_linear_lr2(Tensor x, Tensor w1a, Tensor w1b, Tensor w2a, Tensor w2b, float alpha, Tensor? base=None) -> Tensor");
   m.def("locon_linear(Tensor x, Tensor down, Tensor up, float alpha) -> Tensor");
@@ -2944,6 +3000,7 @@ TORCH_LIBRARY_IMPL(lycoris_amd, Autograd, m) {
   m.impl("lokr_linear", lokr_linear_autograd);
   m.impl("lokr_linear_group", lokr_linear_group_autograd);
   m.impl("lokr_linear_lr_group", lokr_linear_lr_group_autograd);
+  m.impl("lokr_adapted_linear", lokr_adapted_linear_autograd);
   m.impl("lokr_linear_lr", lokr_linear_lr_autograd);
   m.impl("lokr_linear_lr2", lokr_linear_lr2_autograd);
   m.impl("locon_linear", locon_linear_autograd);

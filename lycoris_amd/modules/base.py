@@ -598,8 +598,12 @@ class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
         # quantised base layers -- weight_decompose is ignored and the base weight is never read
         if getattr(self, "wd", False) and not self.bypass_mode:
             return self._forward_dora(x, *args, **kwargs)
-        base = self.org_forward(x, *args, **kwargs)
         plain = not (self.training and (self.rank_dropout or (self.bypass_mode and self.dropout)))
+        if plain and not args and not kwargs:
+            owned = self._forward_owned(x)  # frozen layer + adapter as ONE autograd node, where the algorithm offers that (round 6)
+            if owned is not None:
+                return owned
+        base = self.org_forward(x, *args, **kwargs)
         if plain:
             fused = self._forward_fused(x, base)  # `base + delta` formed in the adapter kernel's epilogue, where it can be
             if fused is not None:
@@ -636,6 +640,32 @@ class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
         if self.bypass_mode and self.training and self.name in ("locon", "lora"):
             delta = self.drop(delta)
         return base + delta
+
+    def _frozen_linear(self):
+        """(weight, bias) of the bare nn.Linear right below this adapter when its forward is the stock `F.linear(x, W, b)` and it is frozen
+        -- what an op that owns the layer's forward and input gradient may replace -- else None (another adapter below, a quantised or
+        otherwise subclassed layer, a trainable base weight, a re-parametrised weight)"""
+        if self.module_type != "linear" or self._conv1d is not None:
+            return None
+        layer = self.org_module[0]
+        if type(layer) is not nn.Linear or getattr(type(layer), "forward", None) is not nn.Linear.forward:
+            return None
+        if "forward" in vars(layer) and getattr(layer, _ORIG, None) is None:  # an instance-level forward that is not ours
+            return None
+        if self.org_forward != getattr(layer, _ORIG, None) and self.org_forward != layer.forward:
+            return None
+        if getattr(self.org_forward, "__func__", None) is not nn.Linear.forward or getattr(self.org_forward, "__self__", None) is not layer:
+            return None
+        if "weight" not in layer._parameters or getattr(layer, "parametrizations", None):
+            return None
+        W, b = layer.weight, layer.bias
+        if W is None or W.requires_grad or (b is not None and b.requires_grad):
+            return None
+        return W, b
+
+    def _forward_owned(self, x):
+        """`base + delta` with the frozen layer's forward and input gradient inside the adapter's autograd node; None = not available"""
+        return None
 
     def _forward_fused(self, x, base):
         """Algorithms whose kernels can add the frozen layer's output in their epilogue return `base + delta` here

@@ -241,6 +241,32 @@ class LokrModule(_siblings.SiblingMixin, LycorisBaseModule):
         # low-rank second factor: the pairs go to the kernels as they are (planes from the factors, grouped chain rule)
         return ops.lokr_linear_lr_group(x, w1s, [m.lokr_w2_a for m in members], [m.lokr_w2_b for m in members], alphas, bases)
 
+    def _owned_args(self, x):
+        """(W, bias, w1, w2, alpha) when ops.lokr_adapted_linear can hold this layer and its adapter in one node, else None"""
+        if self.module_type != "linear" or not (self.use_w1 and self.use_w2) or not isinstance(x, torch.Tensor):
+            return None
+        fl = self._frozen_linear()
+        if fl is None:
+            return None
+        w1 = self._gate(self.lokr_w1)
+        if not ops.lokr_linear_ownable(x, w1, self.lokr_w2, fl[0], fl[1]):
+            return None
+        return fl[0], fl[1], w1, self.lokr_w2, self.scale * self.multiplier
+
+    def _forward_owned(self, x):
+        oa = self._owned_args(x)
+        if oa is None:
+            return None
+        return ops.lokr_adapted_linear(x, [oa[0]], [oa[1]], [oa[2]], [oa[3]], [oa[4]])[0]
+
+    @staticmethod
+    def _sibling_launch_owned(members, x):
+        oas = [m._owned_args(x) for m in members]
+        if any(oa is None for oa in oas):
+            return None
+        return ops.lokr_adapted_linear(x, [oa[0] for oa in oas], [oa[1] for oa in oas], [oa[2] for oa in oas], [oa[3] for oa in oas],
+                                       [oa[4] for oa in oas])
+
     def _forward_fused(self, x, base):
         if self.module_type != "linear":
             return None

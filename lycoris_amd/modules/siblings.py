@@ -132,8 +132,11 @@ def forward(mod, x) -> Optional[torch.Tensor]:
             elif members[0] is mod and len(members) > 1:
                 if all(m._sibling_eligible(x) for m in members[1:]):
                     st.pending.clear()  # (results nobody fetched: a sibling skipped its call in the last pass)
-                    bases = [m.org_forward(x) for m in members]
-                    ys = mod._sibling_launch(members, x, bases)  # [base_i + delta_i]: one grouped launch of the algorithm's kernels
+                    owned = getattr(mod, "_sibling_launch_owned", None)
+                    ys = owned(members, x) if owned is not None else None  # frozen layers + adapters of the set as ONE node (round 6)
+                    if ys is None:
+                        bases = [m.org_forward(x) for m in members]
+                        ys = mod._sibling_launch(members, x, bases)  # [base_i + delta_i]: one grouped launch of the algorithm's kernels
                     ver = x._version
                     for m, y in zip(members[1:], ys[1:]):
                         st.pending[id(m)] = (x, ver, y)

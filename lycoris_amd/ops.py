@@ -57,7 +57,7 @@ def _cpp() -> bool:
         except ImportError:  # very old torch: the end-of-backward mark alone
             pass
         ns = torch.ops.lycoris_amd  # the resolved overloads: skips the packet's per-call overload resolution (~1 us per call)
-        for name in ("lokr_linear", "lokr_linear_group", "lokr_linear_lr_group", "locon_linear_group", "lokr_linear_lr", "lokr_linear_lr2", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d", "lokr_conv2d_lr"):
+        for name in ("lokr_linear", "lokr_adapted_linear", "lokr_linear_group", "lokr_linear_lr_group", "locon_linear_group", "lokr_linear_lr", "lokr_linear_lr2", "locon_linear", "loha_linear", "chan_affine", "lokr_conv2d", "locon_conv2d", "adapter_conv2d", "lokr_conv2d_lr"):
             _OPS[name] = getattr(ns, name).default
     return True
 
@@ -744,6 +744,40 @@ def lokr_linear_group(x, w1s, w2s, alphas, bases=None):
         return [b + y for b, y in zip(bases, ys)]
     factors = [t for pair in zip(w1s, w2s) for t in pair]
     return list(_OPS["lokr_linear_group"](x, factors, [float(a) for a in alphas], [] if bases is None else list(bases)))
+
+
+def lokr_linear_ownable(x, w1, w2, weight, bias=None):
+    """can ONE autograd node hold the frozen nn.Linear layer and its LoKr adapter (lokr_adapted_linear)?  A frozen 16-bit weight in the
+    dtype the activation has (or is autocast to), eager device tensors, the fused `base + delta` epilogue's shape rules."""
+    if not (x.is_cuda and _DISPATCH["mode"] == "cpp") or torch.compiler.is_compiling() or torch.is_inference_mode_enabled():
+        return False
+    if weight.dtype not in (torch.bfloat16, torch.float16) or weight.requires_grad or weight.dim() != 2 or not weight.is_cuda:
+        return False
+    if bias is not None and (bias.requires_grad or bias.dtype != weight.dtype):
+        return False
+    act = x.dtype
+    if act == torch.float32 and torch.is_autocast_enabled("cuda"):
+        act = torch.get_autocast_dtype("cuda")
+    a, b = w1.shape
+    return (act == weight.dtype and a == b and 16 % a == 0 and w2.shape[1] % 8 == 0 and w2.shape[0] % 4 == 0
+            and weight.shape[0] == a * w2.shape[0] and weight.shape[1] == b * w2.shape[1] and x.shape[-1] == weight.shape[1])
+
+
+def lokr_adapted_linear(x, weights, biases, w1s, w2s, alphas):
+    """[x W_i^T + bias_i + (w1_i (x) w2_i) x * alpha_i]: n frozen nn.Linear layers that read ONE tensor, together with their LoKr adapters,
+    as ONE autograd node (round 6; reference modules/lokr.py:551-566 `base + delta` per layer).  Forward: the library GEMMs, then the
+    adapter launch with the fused `base + delta` epilogue (one grouped launch for n >= 2).  Backward: the adapter's dx (summed in registers
+    over the set), then `dx += g_i W_i` through the library GEMM's accumulate epilogue -- the input has one consumer in the graph, so the
+    engine's elementwise `dx_base + dx_adapter` pass (and the n - 1 more of a set) does not exist.  The weights must be frozen
+    (lokr_linear_ownable); callers fall back to F.linear + lokr_linear_group otherwise."""
+    n = len(w1s)
+    if len(weights) != n or len(biases) != n or len(w2s) != n or len(alphas) != n:
+        raise ValueError("lokr_adapted_linear: weights, biases, w1s, w2s, alphas must have one entry per layer")
+    if not all(lokr_linear_ownable(x, w1s[i], w2s[i], weights[i], biases[i]) for i in range(n)) or not _cpp():
+        bases = [torch.nn.functional.linear(x, weights[i], biases[i]) for i in range(n)]
+        return lokr_linear_group(x, w1s, w2s, alphas, bases)
+    factors = [t for pair in zip(w1s, w2s) for t in pair]
+    return list(_OPS["lokr_adapted_linear"](x, factors, [float(a) for a in alphas], list(weights), list(biases)))
 
 
 def lokr_linear_lr_group(x, w1s, w2as, w2bs, alphas, bases=None):
