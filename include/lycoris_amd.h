@@ -332,6 +332,10 @@ int lyc_chan_scale(const void* in, const float* w, const float* bias, void* out,
                    int64_t inner, float s0, float mult, int dtype, void* stream);
 int lyc_chan_reduce(const void* a, const void* b, const float* bias, float* dw, int64_t outer, int64_t C,
                     int64_t inner, float mult, int dtype, void* stream);
+/* Round 6: the backward of lyc_chan_scale in ONE pass over g (ia3.py's autograd of `x * w` / `base + (base - bias) * w`):
+ *   da = g * (s0 + w[c]*mult)   and   dw[c] += mult * sum g * (a - bias[c])         (da or dw may be NULL: that half is skipped)  */
+int lyc_chan_bwd(const void* g, const void* a, const float* w, const float* bias, void* da, float* dw, int64_t outer, int64_t C,
+                 int64_t inner, float s0, float mult, int dtype, void* stream);
 
 /* ---- LoHa on nn.Linear -------------------------------------------------------------------------
  * replaces lycoris/modules/loha.py:301-322 (forward) and lycoris/functional/loha.py:10-30

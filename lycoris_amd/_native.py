@@ -46,6 +46,7 @@ SIGNATURES = {
     "lyc_locon_conv2d_bwd": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _fp, _fp, _i64, _i64, _i64] + [_i32] * 11 + [_f32, _i32, _vp],
     "lyc_chan_scale": [_vp, _fp, _fp, _vp, _i64, _i64, _i64, _f32, _f32, _i32, _vp],
     "lyc_chan_reduce": [_vp, _vp, _fp, _fp, _i64, _i64, _i64, _f32, _i32, _vp],
+    "lyc_chan_bwd": [_vp, _vp, _fp, _fp, _vp, _fp, _i64, _i64, _i64, _f32, _f32, _i32, _vp],
     "lyc_loha_linear_fwd": [_vp, _fp, _fp, _fp, _fp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_loha_linear_bwd": [_vp, _vp, _fp, _fp, _fp, _fp, _vp, _fp, _vp, _fp, _fp, _fp, _fp, _i64, _i32, _i32, _i32,
                             _f32, _i32, _vp],

@@ -2272,11 +2272,51 @@ int lyc_chan_scale(const void* in, const float* w, const float* bias, void* out,
   ChanArgs ca{};
   ca.a_in = in; ca.out = out; ca.w = w; ca.bias = bias; ca.outer = outer; ca.C = C; ca.inner = inner;
   ca.s0 = s0; ca.mult = mult;
+  {  // rows of 16-byte vectors (nn.Linear activations, channels_last tensors): the slab layout of chan_bwd_kernel, factors in registers
+    const int vec = (dtype & 0xff) == LYC_F32 ? 4 : 8;
+    if (inner == 1 && (C % vec) == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0) {
+      const long ct = cdiv(C, 64 * vec);
+      long slabs = cdiv(1024, ct);
+      const long max_slabs = cdiv(outer, 16);
+      if (slabs > max_slabs) slabs = max_slabs;
+      if (slabs < 1) slabs = 1;
+      DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((chan_bwd_kernel<T, true>), dim3((unsigned)ct, (unsigned)slabs), dim3(NTHREADS), 0,
+                                               (hipStream_t)stream, ca));
+      return check_launch("chan_scale(rows)");
+    }
+  }
   long blocks = cdiv(total, (long)NTHREADS * 8);
   if (blocks > 256 * 8) blocks = 256 * 8;
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((chan_scale_kernel<T>), dim3((unsigned)blocks), dim3(NTHREADS), 0,
                                            (hipStream_t)stream, ca));
   return check_launch("chan_scale");
+}
+
+// the backward of lyc_chan_scale in one pass: da = g * (s0 + w*mult), dw += mult * sum g * (a - bias).  inner == 1 with 16-byte rows:
+// chan_bwd_kernel; every other layout: the two kernels above, back to back (same results)
+int lyc_chan_bwd(const void* g, const void* a, const float* w, const float* bias, void* da, float* dw, int64_t outer, int64_t C,
+                 int64_t inner, float s0, float mult, int dtype, void* stream) {
+  if (outer < 0 || C < 1 || inner < 1) return fail(LYC_ERR_ARG, "chan_bwd: bad dims");
+  if (!g || !a || !w || (!da && !dw)) return fail(LYC_ERR_ARG, "chan_bwd: null pointer");
+  if (outer == 0) return LYC_OK;
+  const int vec = (dtype & 0xff) == LYC_F32 ? 4 : 8;
+  const bool vec_ok = inner == 1 && (C % vec) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(da)) & 15u) == 0;
+  if (!vec_ok) {
+    if (da) if (int rc = lyc_chan_scale(g, w, nullptr, da, outer, C, inner, s0, mult, dtype, stream)) return rc;
+    if (dw) if (int rc = lyc_chan_reduce(g, a, bias, dw, outer, C, inner, mult, dtype, stream)) return rc;
+    return LYC_OK;
+  }
+  ChanArgs ca{};
+  ca.a_in = g; ca.b_in = a; ca.out = da; ca.w = w; ca.bias = bias; ca.dw = dw; ca.outer = outer; ca.C = C; ca.inner = 1;
+  ca.s0 = s0; ca.mult = mult; ca.vec = 1;
+  const long ct = cdiv(C, 64 * vec);
+  long slabs = cdiv(1024, ct);
+  const long max_slabs = cdiv(outer, 16);  // 16 rows = one round of 4 rows per wave
+  if (slabs > max_slabs) slabs = max_slabs;
+  if (slabs < 1) slabs = 1;
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((chan_bwd_kernel<T>), dim3((unsigned)ct, (unsigned)slabs), dim3(NTHREADS), 0, (hipStream_t)stream, ca));
+  return check_launch("chan_bwd");
 }
 
 int lyc_chan_reduce(const void* a, const void* b, const float* bias, float* dw, int64_t outer, int64_t C,

@@ -205,4 +205,80 @@ __global__ __launch_bounds__(NTHREADS) void chan_reduce_kernel(ChanArgs a) {
   }
 }
 
+// ---- round 6: the whole backward of the per-channel scale in ONE pass (inner == 1, vector layout) -----------------------------------
+//   da[r, c]  = g[r, c] * (s0 + w[c] * mult)                      (chan_scale_kernel on g)
+//   dw[c]    += mult * sum_r g[r, c] * (a[r, c] - bias[c])        (chan_reduce_kernel)
+// The two-launch form reads g twice and pays two launch floors per layer (350 layers x 2 in the SDXL (IA)^3 step: chan_scale 7.9 us,
+// chan_reduce 6.0 us per call, profiles/r06_c14_ia3_kernel_stats.csv).  Block (x, y): 64 * VEC channels x a slab of rows; a lane owns VEC
+// consecutive channels (16-byte accesses), the 4 waves take interleaved rows, 4 rows per wave in flight (8 loads per lane before the
+// first use); LDS sum over the waves, one atomic per channel and workgroup.
+// FWD: the forward in the same layout (round 6: chan_scale_kernel pays a 64-bit modulo and VEC gathered factor loads per vector; here
+// a lane's channels are fixed, its scale / offset live in registers): out = in * (s0 + w mult) - bias w mult, no reduction, `b_in` unused.
+template <typename T, bool FWD = false>
+__global__ __launch_bounds__(NTHREADS) void chan_bwd_kernel(ChanArgs a) {
+  constexpr int VEC = TT<T>::VEC, RU = 4;
+  const T* G = static_cast<const T*>(a.a_in);
+  const T* A = static_cast<const T*>(a.b_in);
+  T* DA = static_cast<T*>(a.out);
+  __shared__ float redv[NWAVES][64 * VEC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long c0 = ((long)blockIdx.x * 64 + lane) * VEC;
+  const long rows_per = (a.outer + gridDim.y - 1) / gridDim.y;
+  const long rbeg = (long)blockIdx.y * rows_per;
+  long rend = rbeg + rows_per;
+  if (rend > a.outer) rend = a.outer;
+  float s[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+  if (c0 < a.C) {
+    float bv[VEC], sc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float wm = a.w[c0 + e] * a.mult;
+      bv[e] = a.bias ? a.bias[c0 + e] : 0.f;
+      sc[e] = a.s0 + wm;
+      if constexpr (FWD) bv[e] *= wm;  // the forward's offset bias[c] * w[c] * mult
+    }
+    for (long r0 = rbeg + wave; r0 < rend; r0 += RU * NWAVES) {
+      u32x4 gr[RU], ar[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const long r = r0 + u * NWAVES;
+        const long rr = r < rend ? r : r0;  // (rows past the slab re-read row r0 and are dropped below)
+        gr[u] = *reinterpret_cast<const u32x4*>(G + rr * a.C + c0);
+        if constexpr (!FWD) ar[u] = *reinterpret_cast<const u32x4*>(A + rr * a.C + c0);
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const long r = r0 + u * NWAVES;
+        if (r >= rend) break;
+        T gv[VEC], av[VEC], ov[VEC];
+        *reinterpret_cast<u32x4*>(gv) = gr[u];
+        if constexpr (!FWD) *reinterpret_cast<u32x4*>(av) = ar[u];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float gf = TT<T>::to_f(gv[e]);
+          if constexpr (FWD) {
+            ov[e] = TT<T>::from_f(gf * sc[e] - bv[e]);
+          } else {
+            s[e] = fmaf(gf, TT<T>::to_f(av[e]) - bv[e], s[e]);
+            ov[e] = TT<T>::from_f(gf * sc[e]);
+          }
+        }
+        if (DA != nullptr) *reinterpret_cast<u32x4*>(DA + r * a.C + c0) = *reinterpret_cast<u32x4*>(ov);
+      }
+    }
+  }
+  if (FWD || a.dw == nullptr) return;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) redv[wave][lane * VEC + e] = s[e];
+  __syncthreads();
+  for (int i = tid; i < 64 * VEC; i += NTHREADS) {
+    const long c = (long)blockIdx.x * 64 * VEC + i;
+    if (c < a.C)
+      __hip_atomic_fetch_add(a.dw + c, a.mult * (redv[0][i] + redv[1][i] + redv[2][i] + redv[3][i]), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 }  // namespace lyc

@@ -1993,6 +1993,25 @@ void chan_reduce_into(const Tensor& g_in, const Tensor& a_in, const c10::optiona
   check_rc(lyc_chan_reduce(cptr(g), cptr(a), cfp(bf), mfp(dw), outer, C, inner, (float)mult, dtype_code(a.scalar_type()),
                            stream_of(a)), "lyc_chan_reduce");
 }
+// the whole backward in one pass over g (lyc_chan_bwd): da (when wanted) returned, dw accumulated into `dw` (when defined)
+Tensor chan_bwd_into(const Tensor& g_in, const Tensor& a_in, const Tensor& w, const c10::optional<Tensor>& bias, double s0, double mult,
+                     int64_t chan_dim, bool need_da, const Tensor& dw) {
+  const c10::DeviceGuard guard(a_in.device());
+  const bool cl = chan_is_cl(a_in, chan_dim);
+  Tensor a = cl ? a_in.permute({0, 2, 3, 1}) : a_in.contiguous();
+  Tensor g = cl ? g_in.permute({0, 2, 3, 1}).contiguous() : g_in.contiguous();
+  if (cl) chan_dim = 3;
+  chan_dim = at::maybe_wrap_dim(chan_dim, a.dim());
+  int64_t outer, C, inner;
+  chan_dims(a, chan_dim, outer, C, inner);
+  Tensor wf = f32c(w).reshape({-1});
+  Tensor bf = (bias.has_value() && bias->defined()) ? f32c(*bias).reshape({-1}) : Tensor();
+  Tensor da = need_da ? at::empty_like(g) : Tensor();
+  check_rc(lyc_chan_bwd(cptr(g), cptr(a), cfp(wf), cfp(bf), need_da ? mptr(da) : nullptr, dw.defined() ? mfp(dw) : nullptr, outer, C, inner,
+                        (float)s0, (float)mult, dtype_code(a.scalar_type()), stream_of(a)), "lyc_chan_bwd");
+  if (!need_da) return Tensor();
+  return cl ? da.permute({0, 3, 1, 2}) : da;
+}
 Tensor chan_reduce(const Tensor& g, const Tensor& a, const c10::optional<Tensor>& bias, const Tensor& w_like, double mult,
                    int64_t chan_dim) {
   Tensor dw = at::zeros(w_like.sizes(), w_like.options().dtype(at::kFloat));
@@ -2023,6 +2042,12 @@ struct ChanAffineFn : public torch::autograd::Function<ChanAffineFn> {
     Tensor g = grads[0], da, dw;
     static auto scale = c10::Dispatcher::singleton().findSchemaOrThrow("lycoris_amd::chan_affine", "")
                             .typed<Tensor(const Tensor&, const Tensor&, const c10::optional<Tensor>&, double, double, int64_t)>();
+    if (eager_cuda(g) && eager_cuda(a) && g.scalar_type() == a.scalar_type() && (ctx->needs_input_grad(0) || ctx->needs_input_grad(1))) {
+      // eager device tensors: da and dw in ONE pass over g (round 6)
+      GradTarget t = grad_target(w, ctx->needs_input_grad(1));
+      da = chan_bwd_into(g, a, w, bias, s0, mult, chan_dim, ctx->needs_input_grad(0), t.buf);
+      return {da, finish_grad(w, t), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
     if (ctx->needs_input_grad(0)) da = scale.call(g, w, c10::nullopt, s0, mult, chan_dim);
     if (ctx->needs_input_grad(1)) {
       if (eager_cuda(g) && eager_cuda(a)) {

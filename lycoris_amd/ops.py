@@ -696,10 +696,12 @@ class _ChanAffine(torch.autograd.Function):
         da = dw = None
         if ctx.needs_input_grad[0]:
             da = torch.empty_like(g)
-            N.call("lyc_chan_scale", N.ptr(g), N.ptr(wf), None, N.ptr(da), outer, C, inner, s0, mult, code, st)
+        dwf = hb = None
         if ctx.needs_input_grad[1]:
-            (dwf,), hb = _grad_targets([w], [True])  # the reduction kernel adds into its output: straight into w.grad
-            N.call("lyc_chan_reduce", N.ptr(g), N.ptr(a), N.ptr(bf), N.ptr(dwf), outer, C, inner, mult, code, st)
+            (dwf,), hb = _grad_targets([w], [True])  # the kernel adds into its output: straight into w.grad
+        if da is not None or dwf is not None:  # da and dw in ONE pass over g (lyc_chan_bwd, round 6)
+            N.call("lyc_chan_bwd", N.ptr(g), N.ptr(a), N.ptr(wf), N.ptr(bf), N.ptr(da), N.ptr(dwf), outer, C, inner, s0, mult, code, st)
+        if dwf is not None:
             dw = _finish_grads([w], [dwf], hb)[0]
         return da, dw, None, None, None, None
 

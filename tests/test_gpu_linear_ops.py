@@ -145,3 +145,34 @@ def test_chan_affine(case, dtype, with_bias):
     errs = {"out": err(out, out_ref, dtype), "da": err(da, da_ref, dtype), "dw": err(dw, dw_ref)}
     bounds = {"out": TOL["store_out"][dtype], "da": TOL["store_out"][dtype], "dw": TOL["f32_out"][dtype]}
     check(f"chan_affine[{shape},{dtype},{with_bias}]", errs, bounds)
+
+
+BWD_SHAPES = [(1024, 1280), (1024, 5120), (77, 1280), (333, 640), (1, 1280), (19, 72)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape", BWD_SHAPES, ids=[f"{m}x{c}" for m, c in BWD_SHAPES])
+@pytest.mark.parametrize("half", ["both", "da_only", "dw_only"])
+def test_chan_bwd_one_pass_through_the_c_abi(shape, dtype, half):
+    """lyc_chan_bwd (round 6): da = g * (s0 + w mult) and dw += mult * sum g * (a - bias) in one pass over g, either half optional;
+    SDXL (IA)^3 layer shapes at full size (to_k / to_v 1024 x 1280 and 77 x 1280, ff.net.2's input 1024 x 5120) and ragged rows"""
+    from lycoris_amd import _native as N
+    M, C = shape
+    gen = torch.Generator().manual_seed(M + C)
+    a, a64 = rnd((M, C), dtype, gen)
+    g, g64 = rnd((M, C), dtype, gen, 0.2)
+    w, w64 = rnd((C,), torch.float32, gen, 0.3)
+    bias, b64 = rnd((C,), torch.float32, gen, 0.5)
+    s0, mult = 1.0, 0.7
+    da = torch.full((M, C), float("nan"), dtype=dtype, device=a.device) if half != "dw_only" else None
+    dw0, dw0_64 = rnd((C,), torch.float32, gen)  # the kernel ADDS into dw
+    dw = dw0.clone() if half != "da_only" else None
+    N.call("lyc_chan_bwd", N.ptr(g), N.ptr(a), N.ptr(w), N.ptr(bias), N.ptr(da), N.ptr(dw), M, C, 1, s0, mult, N.dtype_code(dtype),
+           N.stream_ptr(a.device))
+    torch.cuda.synchronize()
+    errs, bounds = {}, {}
+    if da is not None:
+        errs["da"], bounds["da"] = err(da, g64 * (s0 + w64 * mult), dtype), TOL["store_out"][dtype]
+    if dw is not None:
+        errs["dw"], bounds["dw"] = err(dw, dw0_64 + (g64 * (a64 - b64)).sum(axis=0) * mult), TOL["f32_out"][dtype]
+    check(f"chan_bwd[{shape},{dtype},{half}]", errs, bounds)
