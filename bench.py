@@ -560,6 +560,9 @@ def main():
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         eager_step()  # warm-up (allocator, lazy init)
+        # the second step of a training run refreshes every cached operand plane in one launch and writes the descriptor table of that
+        # launch (csrc/torch_ops.cpp refresh_planes_locked); done here so that the capture below holds the pack launch only
+        _ops.refresh_lokr_planes(force=True)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
 

@@ -184,6 +184,12 @@ typedef struct LycLokrPackItem {
   int rank;
 } LycLokrPackItem;
 int lyc_lokr_pack_group(const LycLokrPackItem* items, int n, int dtype, void* stream);
+/* Round 6: the same refresh as ONE launch over all layers, through a caller-owned device table of lyc_lokr_pack_table_bytes(items, n)
+ * bytes (16-byte aligned, alive until the launch has run).  table_valid != 0: the table already holds exactly these items (written by
+ * an earlier call with the same list) -- only the pack launch is enqueued; otherwise the descriptors are written first (28 per
+ * launch, from kernel arguments: capturable).  Same results as lyc_lokr_pack_group. */
+int64_t lyc_lokr_pack_table_bytes(const LycLokrPackItem* items, int n);
+int lyc_lokr_pack_group_ws(const LycLokrPackItem* items, int n, int dtype, void* table, int64_t table_bytes, int table_valid, void* stream);
 /* Low-rank w2 = w2a @ w2b: the activation path needs only the planes (packed straight from the two factors); the weight
  * gradient dW2 [c, d] is taken in a caller-owned fp32 scratch (lyc_lokr_linear_bwd / lyc_lokr_wgrad_group with dw2 = scratch,
  * zero-filled) and pushed through the product by ONE launch per 56 layers:

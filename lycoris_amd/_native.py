@@ -34,6 +34,7 @@ SIGNATURES = {
     "lyc_lokr_conv2d_bwd": [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_lokr_conv_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LokrConvWgradItem
     "lyc_lokr_pack_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LokrPackItem
+    "lyc_lokr_pack_group_ws": [_vp, _i32, _i32, _vp, _i64, _i32, _vp],  # + device table of lyc_lokr_pack_table_bytes(items, n)
     "lyc_lokr_lr_chain_group": [_vp, _i32, _vp],  # items: pointer to an array of LokrLrChainItem
     "lyc_lokr_linear_fwd_planes": [_vp, _fp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "lyc_lokr_linear_bwd_planes": [_vp, _vp, _fp, _vp, _vp, _fp, _fp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
@@ -78,6 +79,7 @@ VALUE_SIGNATURES = {
     "lyc_lokr_conv2d_dx_blocks": ([_i64, _i64, _i64] + [_i32] * 14, ctypes.c_int64),
     "lyc_lokr_conv2d_planes_ok": ([_i64, _i64, _i64] + [_i32] * 14, ctypes.c_int),
     "lyc_lokr_wgrad_table_bytes": ([_i32], ctypes.c_int64),
+    "lyc_lokr_pack_table_bytes": ([_vp, _i32], ctypes.c_int64),
     "lyc_lokr_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32], ctypes.c_int),  # 1 / 0, not an error code
     "lyc_locon_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32], ctypes.c_int),
     "lyc_loha_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32], ctypes.c_int),

@@ -952,6 +952,95 @@ int lyc_lokr_pack_group(const LycLokrPackItem* items, int n, int dtype, void* st
   return flush();
 }
 
+// ---- every layer in ONE launch through a device table (kron_conv.h: kron_pack_table_kernel) ----------------------------------------
+extern "C++" {
+namespace {
+// KronPackArgs of item `it` and its unit count (rounded to whole workgroups); false: nothing to pack
+bool pack_args_of(const LycLokrPackItem& it, KronPackArgs& pa, long& units) {
+  if (!it.planes_fwd && !it.planes_bwd) return false;
+  pa = KronPackArgs{};
+  pa.w2 = it.w2; pa.sq = it.sq; pa.sv = it.sv; pa.st = it.st; pa.c = it.c; pa.d = it.d; pa.taps = it.taps;
+  pa.fwd = it.planes_fwd; pa.bwd = it.planes_bwd;
+  if (!it.w2) {
+    pa.w2a = it.w2a; pa.w2b = it.w2b; pa.rank = it.rank; pa.a_sq = it.rank; pa.a_sr = 1;
+    pa.b_sr = (long)it.d * it.taps; pa.b_sv = it.taps; pa.b_st = 1;
+  }
+  pa.units_fwd = kron_plane_bytes(it.c, it.taps, it.d) / 2048;
+  units = round_up(pa.units_fwd + kron_plane_bytes(it.d, it.taps, it.c) / 2048, NWAVES);
+  return true;
+}
+int pack_item_check(const LycLokrPackItem& it, int k) {
+  if ((!it.w2 && !(it.w2a && it.w2b && it.rank >= 1)) || it.c < 1 || it.d < 1 || it.taps < 1 || (it.c % 8) != 0 || (it.d % 8) != 0)
+    return fail(LYC_ERR_ARG, "lokr_pack_group: item %d: bad factor (c, d must be positive multiples of 8)", k);
+  return LYC_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int64_t lyc_lokr_pack_table_bytes(const LycLokrPackItem* items, int n) {
+  if (n < 0 || (n > 0 && !items)) return 0;
+  long wgs = 0;
+  int m = 0;
+  for (int k = 0; k < n; ++k) {
+    KronPackArgs pa;
+    long units = 0;
+    if (items[k].c < 1 || items[k].d < 1 || items[k].taps < 1) continue;
+    if (!pack_args_of(items[k], pa, units)) continue;
+    wgs += units / NWAVES;
+    ++m;
+  }
+  return kron_pack_table_bytes(m, wgs);
+}
+
+int lyc_lokr_pack_group_ws(const LycLokrPackItem* items, int n, int dtype, void* table, int64_t table_bytes, int table_valid, void* stream) {
+  if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "lokr_pack_group_ws: bad item list");
+  const int dt = dtype & 0xff;
+  if (n > 0 && dt != LYC_BF16 && dt != LYC_F16) return fail(LYC_ERR_UNSUPPORTED, "lokr_pack_group_ws: 16-bit planes only");
+  if (n == 0) return LYC_OK;
+  if (!table || (reinterpret_cast<uintptr_t>(table) & 15u)) return fail(LYC_ERR_ARG, "lokr_pack_group_ws: the table must be 16-byte aligned device memory");
+  int m = 0;
+  long wgs = 0;
+  for (int k = 0; k < n; ++k) {
+    if (int rc = pack_item_check(items[k], k)) return rc;
+    KronPackArgs pa;
+    long units = 0;
+    if (!pack_args_of(items[k], pa, units)) continue;
+    wgs += units / NWAVES;
+    ++m;
+  }
+  if (m == 0) return LYC_OK;
+  if (wgs >= (1L << 31)) return fail(LYC_ERR_UNSUPPORTED, "lokr_pack_group_ws: too many units for one grid");
+  if (table_bytes < kron_pack_table_bytes(m, wgs)) return fail(LYC_ERR_ARG, "lokr_pack_group_ws: table of %ld bytes, need %ld", (long)table_bytes, (long)kron_pack_table_bytes(m, wgs));
+  hipStream_t st = (hipStream_t)stream;
+  if (!table_valid) {  // descriptors: 28 per launch, from kernel arguments (capturable: no host memory is read at replay)
+    KronPackGroupArgs ga{};
+    int base = 0;
+    long wg_base = 0;
+    auto flush = [&]() -> int {
+      if (ga.n == 0) return LYC_OK;
+      hipLaunchKernelGGL(kron_pack_table_write_kernel, dim3((unsigned)ga.n), dim3(NTHREADS), 0, st, ga, static_cast<char*>(table), m, base, wg_base);
+      base += ga.n;
+      wg_base += ga.unit_end[ga.n - 1] / NWAVES;
+      ga = KronPackGroupArgs{};
+      return check_launch("lokr_pack_group_ws(table)");
+    };
+    for (int k = 0; k < n; ++k) {
+      KronPackArgs pa;
+      long units = 0;
+      if (!pack_args_of(items[k], pa, units)) continue;
+      if (ga.n == KPG_MAX)
+        if (int rc = flush()) return rc;
+      ga.p[ga.n] = pa;
+      ga.unit_end[ga.n] = (ga.n ? ga.unit_end[ga.n - 1] : 0) + units;
+      ++ga.n;
+    }
+    if (int rc = flush()) return rc;
+  }
+  if (dt == LYC_BF16) hipLaunchKernelGGL((kron_pack_table_kernel<__bf16>), dim3((unsigned)wgs), dim3(NTHREADS), 0, st, static_cast<const char*>(table), m);
+  else hipLaunchKernelGGL((kron_pack_table_kernel<_Float16>), dim3((unsigned)wgs), dim3(NTHREADS), 0, st, static_cast<const char*>(table), m);
+  return check_launch("lokr_pack_group_ws");
+}
+
 int lyc_lokr_lr_chain_group(const LycLokrLrChainItem* items, int n, void* stream) {
   if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "lokr_lr_chain_group: bad item list");
   KronLrGroupArgs ga{};

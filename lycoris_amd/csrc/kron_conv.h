@@ -147,6 +147,41 @@ __global__ __launch_bounds__(NTHREADS) void kron_pack_group_kernel(KronPackGroup
   kron_pack_units<T>(ga.p[p], u - u0);
 }
 
+// Round 6: EVERY layer in ONE launch.  The refresh above is one launch per 28 layers (4 KiB of kernel arguments): 52 launches of 12 us
+// for the 788 layers of the SDXL step (profiles/r06_c14: 0.63 ms for 0.5 GB of traffic -- each launch is one short round of
+// workgroups).  Here the descriptors live in a caller-owned device table (written by kron_pack_table_write_kernel from kernel arguments,
+// 28 per launch, and only when the set of layers changed -- a training run writes it once) and the pack kernel finds its layer through a
+// workgroup -> layer map: one grid over all units of all layers.
+//   table layout: KronPackArgs items[n] | int first_wg[n] | int wg_layer[total_wgs]
+__host__ __device__ inline long kron_pack_table_items_bytes(int n) { return ((long)n * (long)sizeof(KronPackArgs) + 15) / 16 * 16; }
+__host__ __device__ inline long kron_pack_table_bytes(int n, long total_wgs) {
+  return kron_pack_table_items_bytes(n) + ((long)n * 4 + 15) / 16 * 16 + (total_wgs * 4 + 15) / 16 * 16;
+}
+// one workgroup per layer of `ga` (global index base + p; its workgroups start at wg_base + unit_end[p - 1] / NWAVES)
+__global__ __launch_bounds__(NTHREADS) void kron_pack_table_write_kernel(KronPackGroupArgs ga, char* table, int n_total, int base, long wg_base) {
+  const int p = (int)blockIdx.x;
+  if (p >= ga.n) return;
+  KronPackArgs* items = reinterpret_cast<KronPackArgs*>(table);
+  int* first_wg = reinterpret_cast<int*>(table + kron_pack_table_items_bytes(n_total));
+  int* wg_layer = reinterpret_cast<int*>(table + kron_pack_table_items_bytes(n_total) + ((long)n_total * 4 + 15) / 16 * 16);
+  const long w0 = wg_base + (p ? ga.unit_end[p - 1] : 0) / NWAVES, w1 = wg_base + ga.unit_end[p] / NWAVES;
+  if (threadIdx.x == 0) {
+    items[base + p] = ga.p[p];
+    first_wg[base + p] = (int)w0;
+  }
+  for (long w = w0 + threadIdx.x; w < w1; w += NTHREADS) wg_layer[w] = base + p;
+}
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void kron_pack_table_kernel(const char* table, int n_total) {
+  const KronPackArgs* items = reinterpret_cast<const KronPackArgs*>(table);
+  const int* first_wg = reinterpret_cast<const int*>(table + kron_pack_table_items_bytes(n_total));
+  const int* wg_layer = reinterpret_cast<const int*>(table + kron_pack_table_items_bytes(n_total) + ((long)n_total * 4 + 15) / 16 * 16);
+  const int p = __builtin_amdgcn_readfirstlane(wg_layer[blockIdx.x]);
+  const long u = ((long)blockIdx.x - first_wg[p]) * NWAVES + (threadIdx.x >> 6);
+  const KronPackArgs a = items[p];
+  kron_pack_units<T>(a, u);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Low-rank w2 = w2a @ w2b (reference modules/lokr.py:131-136, 370; functional/lokr.py:124-151): the chain rule of the product
 //     d_w2a[q, r] += sum_v dW2[q, v] * w2b[r, v]        d_w2b[r, v] += sum_q w2a[q, r] * dW2[q, v]

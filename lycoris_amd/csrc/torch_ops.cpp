@@ -643,7 +643,32 @@ void refresh_planes_locked(c10::DeviceIndex device, void* stream, bool force) {
     }
     if (items.empty()) continue;
     const c10::DeviceGuard guard(c10::Device(c10::kCUDA, device));
-    check_rc(lyc_lokr_pack_group(items.data(), (int)items.size(), slot == 0 ? LYC_BF16 : LYC_F16, stream), "lyc_lokr_pack_group");
+    if (items.size() > 28) {
+      // round 6: ONE launch over all layers through a device table of the descriptors; the table is rewritten only when the list of
+      // layers (pointers, shapes) differs from the one it was written for -- a training run writes it once
+      struct PackTable {
+        std::vector<LycLokrPackItem> last;
+        Tensor table;
+      };
+      static std::unordered_map<int, PackTable> tables;  // (device, slot); guarded by g_planes.mu (the caller holds it)
+      PackTable& pt = tables[(int)device * 2 + slot];
+      auto same = [](const LycLokrPackItem& a, const LycLokrPackItem& b) {
+        return a.w2 == b.w2 && a.sq == b.sq && a.sv == b.sv && a.st == b.st && a.c == b.c && a.d == b.d && a.taps == b.taps &&
+               a.planes_fwd == b.planes_fwd && a.planes_bwd == b.planes_bwd && a.w2a == b.w2a && a.w2b == b.w2b && a.rank == b.rank;
+      };
+      bool valid = pt.table.defined() && pt.last.size() == items.size();
+      for (size_t i = 0; valid && i < items.size(); ++i) valid = same(pt.last[i], items[i]);
+      const int64_t tbytes = lyc_lokr_pack_table_bytes(items.data(), (int)items.size());
+      if (!valid) {
+        const c10::hip::HIPStreamGuard sguard(c10::hip::getStreamFromExternal((hipStream_t)stream, device));
+        pt.table = at::empty({tbytes}, at::TensorOptions().device(c10::Device(c10::kCUDA, device)).dtype(at::kByte));
+        pt.last = items;
+      }
+      check_rc(lyc_lokr_pack_group_ws(items.data(), (int)items.size(), slot == 0 ? LYC_BF16 : LYC_F16, pt.table.mutable_data_ptr(), tbytes,
+                                      valid ? 1 : 0, stream), "lyc_lokr_pack_group_ws");
+    } else {
+      check_rc(lyc_lokr_pack_group(items.data(), (int)items.size(), slot == 0 ? LYC_BF16 : LYC_F16, stream), "lyc_lokr_pack_group");
+    }
     for (size_t i = 0; i < who.size(); ++i) {
       who[i]->version[slot] = vers[i];
       who[i]->version_b[slot] = versb[i];

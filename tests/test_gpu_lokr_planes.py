@@ -491,3 +491,60 @@ def test_planes_skipped_for_inference_tensors():
         y = _lin(x, w1, w2)
     ref = oracle.lokr.forward(x64, w1=w1.double().cpu().numpy(), w2=w2.double().cpu().numpy(), scale=0.5)
     assert err(y, ref, dtype) < TOL["store_out"][dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_one_launch_refresh_through_a_table_equals_the_grouped_launches(dtype):
+    """lyc_lokr_pack_group_ws (round 6): every layer in ONE pack launch through a device table of the descriptors -- the same plane bytes
+    as lyc_lokr_pack_group (one launch per 28 layers); a second call on the written table (table_valid = 1) after the factors changed in
+    place packs the NEW values.  70 layers: nn.Linear factors, a channels_last Conv2d factor, low-rank pairs, one item without planes."""
+    import ctypes
+    lib = N.load()
+    code = N.dtype_code(dtype)
+    gen = torch.Generator().manual_seed(123)
+    st = N.stream_ptr(dev())
+    keep, ref_items, new_items, planes = [], [], [], []
+    n = 70
+    for k in range(n):
+        c, d = [(40, 40), (160, 160), (80, 640), (160, 40), (1280, 160)][k % 5]
+        taps = 9 if k % 11 == 3 else 1
+        lowrank = k % 7 == 5 and taps == 1
+        nf, nb = int(lib.lyc_lokr_planes_bytes(c, d, taps, 0)), int(lib.lyc_lokr_planes_bytes(c, d, taps, 1))
+        bufs = [torch.full((nf,), 0xCD, dtype=torch.uint8, device=dev()) for _ in range(2)] + [torch.full((nb,), 0xCD, dtype=torch.uint8, device=dev()) for _ in range(2)]
+        if k == 17:  # nothing to pack for this one (its buffers keep their fill pattern in both runs)
+            w = (torch.randn(c, d, generator=gen) * 0.1).to(dev())
+            it = lambda pf, pb, w=w: N.LokrPackItem(N.ptr(w), d, 1, 0, c, d, 1, None, None, None, None, 0)
+            taps = 1
+            srcs = [w]
+        elif lowrank:
+            wa = (torch.randn(c, 16, generator=gen) * 0.1).to(dev())
+            wb = (torch.randn(16, d, generator=gen) * 0.1).to(dev())
+            it = lambda pf, pb, wa=wa, wb=wb: N.LokrPackItem(None, 0, 0, 0, c, d, 1, N.ptr(pf), N.ptr(pb), N.ptr(wa), N.ptr(wb), 16)
+            srcs = [wa, wb]
+        elif taps == 9:
+            w = (torch.randn(c, d, 3, 3, generator=gen) * 0.1).to(dev()).contiguous(memory_format=torch.channels_last)
+            it = lambda pf, pb, w=w: N.LokrPackItem(N.ptr(w), w.stride(0), w.stride(1), w.stride(3), c, d, 9, N.ptr(pf), N.ptr(pb), None, None, 0)
+            srcs = [w]
+        else:
+            w = (torch.randn(c, d, generator=gen) * 0.1).to(dev())
+            it = lambda pf, pb, w=w: N.LokrPackItem(N.ptr(w), d, 1, 0, c, d, 1, N.ptr(pf), N.ptr(pb), None, None, 0)
+            srcs = [w]
+        ref_items.append(it(bufs[0], bufs[2]))
+        new_items.append(it(bufs[1], bufs[3]))
+        planes.append(bufs)
+        keep += srcs
+    ra, na = (N.LokrPackItem * n)(*ref_items), (N.LokrPackItem * n)(*new_items)
+    tb = int(lib.lyc_lokr_pack_table_bytes(ctypes.cast(na, ctypes.c_void_p), n))
+    assert tb > 0
+    table = torch.empty(tb, dtype=torch.uint8, device=dev())
+    for valid in (0, 1):
+        N.call("lyc_lokr_pack_group", ctypes.cast(ra, ctypes.c_void_p), n, code, st)
+        N.call("lyc_lokr_pack_group_ws", ctypes.cast(na, ctypes.c_void_p), n, code, N.ptr(table), tb, valid, st)
+        torch.cuda.synchronize()
+        for k, b in enumerate(planes):
+            assert torch.equal(b[0], b[1]) and torch.equal(b[2], b[3]), (k, valid)
+        for t in keep:  # the factors move (an optimizer step): the second round packs the new values through the SAME table
+            t.mul_(1.25).add_(0.01)
+        for b in planes:
+            for t in b:
+                t.fill_(0xCD)
