@@ -62,6 +62,10 @@ __global__ __launch_bounds__(NTHREADS) void sum_rows_kernel(SumArgs a) {
   }
 }
 
+// x * s - b * wm with ONE evaluation order in every kernel and layout (the product b * wm rounded, then one fused multiply-add): an
+// NCHW tensor and its channels_last twin give the same bits (tests/test_gpu_custom_ops.py), whatever the compiler would contract
+__device__ __forceinline__ float chan_affine_f(float x, float s, float b, float wm) { return __fmaf_rn(x, s, -__fmul_rn(b, wm)); }
+
 // out[o, c, i] = a[o, c, i] * (s0 + w[c] * mult) - bias[c] * w[c] * mult
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void chan_scale_kernel(ChanArgs a) {
@@ -96,14 +100,14 @@ __global__ __launch_bounds__(NTHREADS) void chan_scale_kernel(ChanArgs a) {
           for (int e = 0; e < VEC; ++e) {
             const float wm = a.w[c0 + e] * a.mult;
             const float b = a.bias ? a.bias[c0 + e] : 0.f;
-            ov[e] = TT<T>::from_f(TT<T>::to_f(iv[e]) * (a.s0 + wm) - b * wm);
+            ov[e] = TT<T>::from_f(chan_affine_f(TT<T>::to_f(iv[e]), a.s0 + wm, b, wm));
           }
         } else {
           const long c = (e0 / a.inner) % a.C;
           const float wm = a.w[c] * a.mult;
           const float b = a.bias ? a.bias[c] : 0.f;
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) ov[e] = TT<T>::from_f(TT<T>::to_f(iv[e]) * (a.s0 + wm) - b * wm);
+          for (int e = 0; e < VEC; ++e) ov[e] = TT<T>::from_f(chan_affine_f(TT<T>::to_f(iv[e]), a.s0 + wm, b, wm));
         }
         *reinterpret_cast<u32x4*>(out + e0) = *reinterpret_cast<u32x4*>(ov);
       }
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(NTHREADS) void chan_scale_kernel(ChanArgs a) {
       const long c = (e / a.inner) % a.C;
       const float wm = a.w[c] * a.mult;
       const float b = a.bias ? a.bias[c] : 0.f;
-      out[e] = TT<T>::from_f(TT<T>::to_f(in[e]) * (a.s0 + wm) - b * wm);
+      out[e] = TT<T>::from_f(chan_affine_f(TT<T>::to_f(in[e]), a.s0 + wm, b, wm));
     }
   }
 }
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(NTHREADS) void chan_bwd_kernel(ChanArgs a) {
       const float wm = a.w[c0 + e] * a.mult;
       bv[e] = a.bias ? a.bias[c0 + e] : 0.f;
       sc[e] = a.s0 + wm;
-      if constexpr (FWD) bv[e] *= wm;  // the forward's offset bias[c] * w[c] * mult
+      if constexpr (FWD) bv[e] = __fmul_rn(bv[e], wm);  // the forward's offset bias[c] * w[c] * mult (chan_affine_f's order)
     }
     for (long r0 = rbeg + wave; r0 < rend; r0 += RU * NWAVES) {
       u32x4 gr[RU], ar[RU];
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(NTHREADS) void chan_bwd_kernel(ChanArgs a) {
         for (int e = 0; e < VEC; ++e) {
           const float gf = TT<T>::to_f(gv[e]);
           if constexpr (FWD) {
-            ov[e] = TT<T>::from_f(gf * sc[e] - bv[e]);
+            ov[e] = TT<T>::from_f(__fmaf_rn(gf, sc[e], -bv[e]));
           } else {
             s[e] = fmaf(gf, TT<T>::to_f(av[e]) - bv[e], s[e]);
             ov[e] = TT<T>::from_f(gf * sc[e]);

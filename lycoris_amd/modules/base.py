@@ -599,7 +599,8 @@ class LycorisBaseModule(nn.Module, metaclass=_TwinMeta):
         if getattr(self, "wd", False) and not self.bypass_mode:
             return self._forward_dora(x, *args, **kwargs)
         plain = not (self.training and (self.rank_dropout or (self.bypass_mode and self.dropout)))
-        if plain and not args and not kwargs:
+        # (is_compiling() first: under torch.compile the branch folds away and dynamo never traces the ownership test)
+        if not torch.compiler.is_compiling() and plain and not args and not kwargs:
             owned = self._forward_owned(x)  # frozen layer + adapter as ONE autograd node, where the algorithm offers that (round 6)
             if owned is not None:
                 return owned

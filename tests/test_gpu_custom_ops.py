@@ -203,6 +203,12 @@ def test_adapted_linear_layer_under_torch_compile(algo):
     got = run(compiled)
     mod.restore()
     for i, (u, v) in enumerate(zip(got, eager)):
+        if i == 1:
+            # dx = g W + dx_adapter.  Eager LoKr holds the frozen layer in the adapter's node (round 6: g W joins the adapter's dx inside the
+            # library GEMM's fp32 epilogue, one rounding); the traced graph adds two rounded tensors.  Where the two terms cancel the
+            # results differ by an ulp of the LARGER term: compare norm-wise
+            assert float((u.float() - v.float()).norm() / v.float().norm()) <= 1e-2, (algo, i)
+            continue
         assert torch.allclose(u.float(), v.float(), rtol=2e-2 if i < 2 else 1e-3, atol=1e-3), (algo, i)
 
 
@@ -339,16 +345,21 @@ def test_lokr_module_forward_uses_the_fused_epilogue():
     x = torch.randn(5, 7, 64, device=DEV, dtype=torch.bfloat16)
     base = layer(x)
     want = base.float() + mod.bypass_forward_diff(x, scale=mod.multiplier).float()
-    calls = []
-    orig = ops.lokr_linear
+    calls, owned = [], []
+    orig, orig_owned = ops.lokr_linear, ops.lokr_adapted_linear
     ops.lokr_linear = lambda *a, **k: (calls.append(k.get("base") is not None), orig(*a, **k))[1]
+    ops.lokr_adapted_linear = lambda *a, **k: (owned.append(len(a[1])), orig_owned(*a, **k))[1]
     try:
         mod.apply_to()
-        out = layer(x)
+        out_owned = layer(x)          # a frozen 16-bit nn.Linear: layer + adapter in ONE node (round 6), base + delta fused in it
+        layer.weight.requires_grad_(True)
+        out = layer(x)                # a trainable base weight: F.linear, then the adapter kernel with the fused epilogue
+        layer.weight.requires_grad_(False)
         mod.restore()
     finally:
-        ops.lokr_linear = orig
-    assert calls == [True]  # one call, with base
+        ops.lokr_linear, ops.lokr_adapted_linear = orig, orig_owned
+    assert owned == [1] and calls == [True]  # one call each; the second with base
+    assert torch.equal(out_owned, out)
     assert torch.allclose(out.float(), want, rtol=2e-2, atol=2e-2)
 
 
