@@ -34,7 +34,10 @@ enum { LYC_F32_ROWS = 0x100, LYC_DEFER_WGRAD = 0x200,
        LYC_WGRAD_TILE_S = 0x400,
        /* lyc_lokr_conv_wgrad_group, experiment builds (-DLYC_EXPERIMENT_CONV_DW2_PATCH) only: the LDS-patch weight-gradient kernel of
         * benchmarks/experiments/kron_conv_dw2.h where its plan covers the layer; ignored by the product library */
-       LYC_CONV_WGRAD_PATCH = 0x800 };
+       LYC_CONV_WGRAD_PATCH = 0x800,
+       /* lyc_loha_linear_fwd only (round 6): `wplanes` already holds the operand plane of these factors (lyc_loha_rebuild_group: the
+        * caller's once-per-optimizer-step plane cache) -- the entry point skips its rebuild launch */
+       LYC_PLANE_READY = 0x10000 };
 /* The *_planes Conv2d entry points and lyc_lokr_conv2d_planes_ok / _dx_blocks: pin the patch kernel's row tile (mi = 2, 4 or 8: 64 * mi
  * stage-1 rows per workgroup) instead of letting the host plan it -- for tests, which otherwise reach only the smallest tile with
  * their small problems (rounds 2-3 read an environment variable for this). */
@@ -353,6 +356,19 @@ int lyc_chan_bwd(const void* g, const void* a, const float* w, const float* bias
  * activations -- and bwd reads it (pass the same buffer).
  * `gw` is [O,I] fp32 scratch (no need to clear).  d_w* +=                                              */
 int64_t lyc_loha_workspace_bytes(int O, int I, int dtype);
+/* Round 6: the operand planes of MANY layers in one launch per 48 layers -- the refresh of a plane cache keyed on the parameters
+ * (csrc/torch_ops.cpp: the factors change once per optimizer step, not per layer call; reference lycoris/functional/loha.py:10-16
+ * HadaWeight.forward rebuilds dW in every forward).  `plane`: lyc_loha_workspace_bytes(O, I, dtype) bytes, 16-byte aligned; the layer must
+ * satisfy lyc_loha_plane_cacheable (16-bit activations, rank <= 32, rank % 4 == 0, O % 8 == I % 8 == 0, 16-byte aligned factors).
+ * The plane written is bit-identical to the one lyc_loha_linear_fwd writes for the same factors. */
+typedef struct LycLohaPlaneItem {
+  const float *w1a, *w1b, *w2a, *w2b;   /* w*a:[O, r]  w*b:[r, I] */
+  void* plane;
+  int O, I, r;
+  float alpha;
+} LycLohaPlaneItem;
+int lyc_loha_plane_cacheable(const float* w1a, const float* w1b, const float* w2a, const float* w2b, int I, int O, int r, int dtype);
+int lyc_loha_rebuild_group(const LycLohaPlaneItem* items, int n, int dtype, void* stream);
 int lyc_loha_linear_fwd(const void* x, const float* w1a, const float* w1b, const float* w2a, const float* w2b,
                         void* wplanes, void* y, int64_t M, int I, int O, int r, float alpha, int dtype,
                         void* stream);

@@ -33,6 +33,7 @@ SIGNATURES = {
     "lyc_lokr_conv2d_fwd": [_vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_lokr_conv2d_bwd": [_vp, _vp, _fp, _fp, _fp, _vp, _fp, _fp, _vp, _i64, _i64, _i64] + [_i32] * 12 + [_f32, _i32, _vp],
     "lyc_lokr_conv_wgrad_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LokrConvWgradItem
+    "lyc_loha_rebuild_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LohaPlaneItem
     "lyc_lokr_pack_group": [_vp, _i32, _i32, _vp],  # items: pointer to an array of LokrPackItem
     "lyc_lokr_pack_group_ws": [_vp, _i32, _i32, _vp, _i64, _i32, _vp],  # + device table of lyc_lokr_pack_table_bytes(items, n)
     "lyc_lokr_lr_chain_group": [_vp, _i32, _vp],  # items: pointer to an array of LokrLrChainItem
@@ -83,6 +84,7 @@ VALUE_SIGNATURES = {
     "lyc_lokr_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32], ctypes.c_int),  # 1 / 0, not an error code
     "lyc_locon_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32], ctypes.c_int),
     "lyc_loha_wgrad_deferrable": ([_vp, _vp, _i64, _i32, _i32, _i32, _i32], ctypes.c_int),
+    "lyc_loha_plane_cacheable": ([_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32], ctypes.c_int),
 }
 
 
@@ -90,6 +92,11 @@ class LohaWgradItem(ctypes.Structure):
     """LycLohaWgradItem (include/lycoris_amd.h)"""
     _fields_ = [("g", _vp), ("x", _vp), ("w1a", _vp), ("w1b", _vp), ("w2a", _vp), ("w2b", _vp), ("d_w1a", _vp), ("d_w1b", _vp),
                 ("d_w2a", _vp), ("d_w2b", _vp), ("gw", _vp), ("M", _i64), ("I", _i32), ("O", _i32), ("r", _i32), ("alpha", _f32)]
+
+
+class LohaPlaneItem(ctypes.Structure):
+    """LycLohaPlaneItem (include/lycoris_amd.h)"""
+    _fields_ = [("w1a", _vp), ("w1b", _vp), ("w2a", _vp), ("w2b", _vp), ("plane", _vp), ("O", _i32), ("I", _i32), ("r", _i32), ("alpha", _f32)]
 
 
 class LoconWgradItem(ctypes.Structure):

@@ -2622,6 +2622,9 @@ int lyc_loha_linear_fwd(const void* x, const float* w1a, const float* w1b, const
   dim3 rg((unsigned)cdiv(O, LOHA_T), (unsigned)cdiv(I, LOHA_T));
   const bool wt16 = pl.th != nullptr;  // the transposed plane is read by the generic dx kernels only
   const bool fast16 = !wt16 && (dtype & 0xff) != LYC_F32 && loha_rebuild16_ok(la);  // hi / lo operands on the 16-bit matrix cores
+  if (dtype & LYC_PLANE_READY) {  // the caller's plane cache holds the operand plane of these factors (lyc_loha_rebuild_group)
+    if (!fast16) return fail(LYC_ERR_ARG, "loha_linear_fwd: LYC_PLANE_READY needs a layer lyc_loha_plane_cacheable accepts");
+  } else
   switch (fast16 ? -1 : (dtype & 0xff)) {
     case -1:
       if ((dtype & 0xff) == LYC_BF16) hipLaunchKernelGGL((loha_rebuild16_kernel<__bf16>), rg, dim3(NTHREADS), 0, st, la);
@@ -2664,6 +2667,47 @@ int lyc_loha_linear_fwd(const void* x, const float* w1a, const float* w1b, const
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_nt_kernel<T>), gg, dim3(NTHREADS), 0, st, ga));
   }
   return check_launch("loha_linear_fwd");
+}
+
+// ---- operand planes of many layers in one launch (the plane cache's refresh) -----------------------------------------------------
+int lyc_loha_plane_cacheable(const float* w1a, const float* w1b, const float* w2a, const float* w2b, int I, int O, int r, int dtype) {
+  const int dt = dtype & 0xff;
+  if ((dt != LYC_BF16 && dt != LYC_F16) || I < 1 || O < 1 || r < 1 || !loha_dims_fast(O, I)) return 0;
+  LohaArgs la{};
+  la.w1a = w1a; la.w1b = w1b; la.w2a = w2a; la.w2b = w2b; la.O = O; la.I = I; la.R = r; la.ldn = round_up(I, 8);
+  la.Wn_h = nullptr;
+  return loha_rebuild16_ok(la) ? 1 : 0;
+}
+int lyc_loha_rebuild_group(const LycLohaPlaneItem* items, int n, int dtype, void* stream) {
+  if (n < 0 || (n > 0 && !items)) return fail(LYC_ERR_ARG, "loha_rebuild_group: bad item list");
+  const int dt = dtype & 0xff;
+  if (n > 0 && dt != LYC_BF16 && dt != LYC_F16) return fail(LYC_ERR_UNSUPPORTED, "loha_rebuild_group: 16-bit planes only");
+  hipStream_t st = (hipStream_t)stream;
+  LohaRebuildGroupArgs ga{};
+  auto flush = [&]() -> int {
+    if (ga.n == 0) return LYC_OK;
+    const dim3 grid((unsigned)ga.wg_end[ga.n - 1]);
+    if (dt == LYC_BF16) hipLaunchKernelGGL((loha_rebuild16_group_kernel<__bf16>), grid, dim3(NTHREADS), 0, st, ga);
+    else hipLaunchKernelGGL((loha_rebuild16_group_kernel<_Float16>), grid, dim3(NTHREADS), 0, st, ga);
+    ga = LohaRebuildGroupArgs{};
+    return check_launch("loha_rebuild_group");
+  };
+  for (int k = 0; k < n; ++k) {
+    const LycLohaPlaneItem& it = items[k];
+    if (!it.w1a || !it.w1b || !it.w2a || !it.w2b || !it.plane || (reinterpret_cast<uintptr_t>(it.plane) & 15u))
+      return fail(LYC_ERR_ARG, "loha_rebuild_group: item %d: null / unaligned pointer", k);
+    if (!lyc_loha_plane_cacheable(it.w1a, it.w1b, it.w2a, it.w2b, it.I, it.O, it.r, dtype))
+      return fail(LYC_ERR_UNSUPPORTED, "loha_rebuild_group: item %d: rank <= 32, rank %% 4 == 0, I %% 8 == O %% 8 == 0, 16-byte aligned factors", k);
+    const long gx = cdiv(it.O, 128), wgs = gx * cdiv(cdiv(it.I, LOHA_T), LRG_NCT);
+    if (ga.n == LRG_MAX || (ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs > (1L << 30))
+      if (int rc = flush()) return rc;
+    LohaRebuildItem& q = ga.p[ga.n];
+    q.w1a = it.w1a; q.w1b = it.w1b; q.w2a = it.w2a; q.w2b = it.w2b; q.plane = it.plane;
+    q.O = it.O; q.I = it.I; q.R = it.r; q.ldn = (int)round_up(it.I, 8); q.gx = (int)gx; q.scale = it.alpha;
+    ga.wg_end[ga.n] = (int)((ga.n ? ga.wg_end[ga.n - 1] : 0) + wgs);
+    ++ga.n;
+  }
+  return flush();
 }
 
 int lyc_loha_linear_bwd(const void* g, const void* x, const float* w1a, const float* w1b, const float* w2a,

@@ -228,12 +228,11 @@ inline bool loha_rebuild16_ok(const LohaArgs& a) {
             reinterpret_cast<uintptr_t>(a.w2b) | reinterpret_cast<uintptr_t>(a.Wn_h)) & 15u) == 0);
 }
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void loha_rebuild16_kernel(LohaArgs a) {
+__device__ __forceinline__ void loha_rebuild16_body(const LohaArgs& a, char* sm, const int bx, const int by) {
   // images: A1h A1l A2h A2l [64 o][32 r] T (4 KiB each), B1h B1l B2h B2l [32 r][64 i] T (4 KiB each)
-  __shared__ __attribute__((aligned(16))) char sm[8 * 4096];
   using F8 = typename TT<T>::frag;
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4, wave = tid >> 6;
-  const long o0 = (long)blockIdx.x * LOHA_T, i0 = (long)blockIdx.y * LOHA_T;
+  const long o0 = (long)bx * LOHA_T, i0 = (long)by * LOHA_T;
   // ---- stage: every load issued before the first LDS write ---------------------------------------------------------------------
   f32x4 va[2][2], vb[2][2];  // [factor 1 / 2][iteration]
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -318,6 +317,176 @@ __global__ __launch_bounds__(NTHREADS) void loha_rebuild16_kernel(LohaArgs a) {
     const long n = i0 + 32 * q + 8 * g;
     if (o < a.O && n < a.I) *reinterpret_cast<u32x4*>(plane + o * a.ldn + n) = *reinterpret_cast<const u32x4*>(ov);
   }
+}
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void loha_rebuild16_kernel(LohaArgs a) {
+  __shared__ __attribute__((aligned(16))) char sm[8 * 4096];
+  loha_rebuild16_body<T>(a, sm, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ---- round 6: the operand planes of MANY layers in one launch (the once-per-optimizer-step refresh of the plane cache) -----------------
+// The factors change once per optimizer step, not per layer call: csrc/torch_ops.cpp keeps the plane of every layer whose four factors
+// are leaf parameters (5 GB for the SDXL preset, of 288) and refreshes all of them with this kernel when a step has passed -- one
+// throughput-bound grid per 48 layers instead of 788 latency-bound launches of 7 us inside the forward pass.
+// Grouped form: a workgroup owns 128 rows x LRG_NCT column tiles.  The a-side factors of its rows are staged once (their fragments stay in
+// registers), the b-side tile of column tile t + 1 is fetched into registers while tile t is computed and lands in the other half of a
+// double-buffered LDS image: one barrier per tile, every b fragment read serves two row strips.  The first version ran the per-layer
+// body once per 64 x 64 tile (32 KB of fp32 factors fetched per 8 KB written, two barriers, nothing in flight): 3.6 ms per refresh of the
+// SDXL preset's 5 GB (profiles/r06_c22_loha_kernel_stats.csv) -- SLOWER than the 788 per-layer launches it replaced.
+// Same MFMA sequence per element as loha_rebuild16_body: the planes are bit-identical.
+constexpr int LRG_NCT = 4;
+template <typename T>
+__device__ __forceinline__ void loha_rebuild16_strip_body(const LohaArgs& a, char* sm, const int bx, const int by0) {
+  // images: A1h A1l A2h A2l [128 o][32 r] T (8 KiB each) | 2 x { B1h B1l B2h B2l [32 r][64 i] T (4 KiB each) }
+  using F8 = typename TT<T>::frag;
+  constexpr int OFF_B = 4 * 8192, BUF = 4 * 4096;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4, wave = tid >> 6;
+  const long o0 = (long)bx * 128;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 vb[2][2];  // [factor 1 / 2][iteration]
+  auto load_b = [&](long i0) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int e = tid + NTHREADS * it;
+      const int rb = e >> 4, i4 = (e & 15) * 4;
+      const bool okb = (rb < a.R) && (i0 + i4 < a.I);
+      const long idb = okb ? (long)rb * a.I + i0 + i4 : 0;
+      const f32x4 y1 = *reinterpret_cast<const f32x4*>(a.w1b + idb), y2 = *reinterpret_cast<const f32x4*>(a.w2b + idb);
+      vb[0][it] = okb ? y1 : z;
+      vb[1][it] = okb ? y2 : z;
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int e = tid + NTHREADS * it;
+      const int rb = e >> 4, i4 = (e & 15) * 4;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        T h[4], l[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split_f<T>(vb[f][it][q], h[q], l[q]);
+        *reinterpret_cast<u32x2*>(sm + OFF_B + buf * BUF + (2 * f) * 4096 + rb * 128 + i4 * 2) = *reinterpret_cast<const u32x2*>(h);
+        *reinterpret_cast<u32x2*>(sm + OFF_B + buf * BUF + (2 * f + 1) * 4096 + rb * 128 + i4 * 2) = *reinterpret_cast<const u32x2*>(l);
+      }
+    }
+  };
+  // ---- a side: 128 rows, staged once ---------------------------------------------------------------------------------------------
+  {
+    f32x4 va[2][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = tid + NTHREADS * it;
+      const int o = e >> 3, c4 = (e & 7) * 4;
+      const bool ok = (o0 + o < a.O) && (c4 < a.R);
+      const long idx = ok ? (o0 + o) * a.R + c4 : 0;
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.w1a + idx), x2 = *reinterpret_cast<const f32x4*>(a.w2a + idx);
+      va[0][it] = ok ? x1 : z;
+      va[1][it] = ok ? x2 : z;
+    }
+    load_b((long)by0 * LOHA_T);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = tid + NTHREADS * it;
+      const int o = e >> 3, c4 = (e & 7) * 4;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        T h[4], l[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split_f<T>(va[f][it][q], h[q], l[q]);
+        *reinterpret_cast<u32x2*>(sm + (2 * f) * 8192 + o * 64 + c4 * 2) = *reinterpret_cast<const u32x2*>(h);
+        *reinterpret_cast<u32x2*>(sm + (2 * f + 1) * 8192 + o * 64 + c4 * 2) = *reinterpret_cast<const u32x2*>(l);
+      }
+    }
+    store_b(0);
+  }
+  __syncthreads();
+  F8 af[2][4];  // [row strip][A1h A1l A2h A2l]: rows 64 s + 16 wave + li, ranks 8 g .. 8 g + 7
+#pragma unroll
+  for (int sI = 0; sI < 2; ++sI)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) af[sI][p] = *reinterpret_cast<const F8*>(sm + p * 8192 + (64 * sI + 16 * wave + li) * 64 + g * 16);
+  const unsigned rdb0 = (unsigned)(size_t)(k4_lds_ptr)sm + OFF_B + (unsigned)((8 * g + (li >> 2)) * 128 + (li & 3) * 16);
+  T* plane = static_cast<T*>(a.Wn_h);
+  const long tiles_j = (a.I + LOHA_T - 1) / LOHA_T;
+  for (int ct = 0; ct < LRG_NCT; ++ct) {
+    const long jt = by0 + ct;
+    if (jt >= tiles_j) break;
+    const long i0 = jt * LOHA_T;
+    const bool more = ct + 1 < LRG_NCT && jt + 1 < tiles_j;
+    if (more) load_b(i0 + LOHA_T);  // in flight behind the MFMAs of this tile
+    const unsigned rdb = rdb0 + (unsigned)((ct & 1) * BUF);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      u32x2 r[2][4][2];  // [e][B1h B1l B2h B2l][k half]
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          r[e][p][0] = g16d_read_tr(rdb, p * 4096 + q * 64 + e * 8);
+          r[e][p][1] = g16d_read_tr(rdb, p * 4096 + q * 64 + e * 8 + 4 * 128);
+        }
+      g16d_lgkm<0>();
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          asm volatile("" : "+v"(r[e][p][0]));
+          asm volatile("" : "+v"(r[e][p][1]));
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int sI = 0; sI < 2; ++sI) {
+        T ov[8];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          F8 bf[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) bf[p] = __builtin_bit_cast(F8, u32x4{r[e][p][0][0], r[e][p][0][1], r[e][p][1][0], r[e][p][1][1]});
+          f32x4 w1 = zero4(), w2 = zero4();
+          w1 = TT<T>::mma(bf[0], af[sI][0], w1);
+          w2 = TT<T>::mma(bf[2], af[sI][2], w2);
+          w1 = TT<T>::mma(bf[1], af[sI][0], w1);
+          w2 = TT<T>::mma(bf[3], af[sI][2], w2);
+          w1 = TT<T>::mma(bf[0], af[sI][1], w1);
+          w2 = TT<T>::mma(bf[2], af[sI][3], w2);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ov[4 * e + j] = TT<T>::from_f(w1[j] * w2[j] * a.scale);
+        }
+        const long o = o0 + 64 * sI + 16 * wave + li, n = i0 + 32 * q + 8 * g;
+        if (o < a.O && n < a.I) *reinterpret_cast<u32x4*>(plane + o * a.ldn + n) = *reinterpret_cast<const u32x4*>(ov);
+      }
+    }
+    if (more) store_b((ct + 1) & 1);
+    __syncthreads();  // the next tile's image is complete; this tile's readers are done before it is overwritten two tiles on
+  }
+}
+
+constexpr int LRG_MAX = 48;
+struct LohaRebuildItem {
+  const float *w1a, *w1b, *w2a, *w2b;
+  void* plane;
+  int O, I, R, ldn, gx;  // gx: 128-row blocks (block index = by * gx + bx; by: strip of LRG_NCT column tiles)
+  float scale;
+};
+struct LohaRebuildGroupArgs {
+  int n;
+  int wg_end[LRG_MAX];
+  LohaRebuildItem p[LRG_MAX];
+};
+static_assert(sizeof(LohaRebuildGroupArgs) <= 3840, "kernel arguments are limited to 4 KiB");
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void loha_rebuild16_group_kernel(LohaRebuildGroupArgs ga) {
+  __shared__ __attribute__((aligned(16))) char sm[4 * 8192 + 2 * 4 * 4096];
+  const int b = (int)blockIdx.x;
+  int q = 0;
+  while (q + 1 < ga.n && b >= ga.wg_end[q]) ++q;
+  const int bl = b - (q ? ga.wg_end[q - 1] : 0);
+  const LohaRebuildItem& it = ga.p[q];
+  LohaArgs a{};
+  a.w1a = it.w1a; a.w1b = it.w1b; a.w2a = it.w2a; a.w2b = it.w2b; a.Wn_h = it.plane;
+  a.O = it.O; a.I = it.I; a.R = it.R; a.ldn = it.ldn; a.scale = it.scale;
+  loha_rebuild16_strip_body<T>(a, sm, bl % it.gx, (bl / it.gx) * LRG_NCT);
 }
 
 struct LohaGradGeom {

@@ -789,6 +789,140 @@ Tensor planes_for_lr(const Tensor& w2a, const Tensor& w2b, at::ScalarType act, v
   }
   return e.planes[slot];
 }
+// =====================================================================================================================
+// LoHa operand planes (round 6): the same cache for dW = (w1a w1b) * (w2a w2b) * alpha, keyed on w1a
+// =====================================================================================================================
+// HadaWeight.forward (reference lycoris/functional/loha.py:10-16) rebuilds dW in every layer call; natively that was one 7 us launch per
+// layer inside the forward pass (788 per SDXL step: 5.7 ms, profiles/r06_c13_loha_kernel_stats.csv).  The four factors are parameters:
+// they change once per optimizer step.  Layers whose factors are contiguous fp32 leaves keep their 16-bit plane here (one per layer:
+// 5 GB for the SDXL preset, of 288) and ALL stale planes of a device are rebuilt by one grouped launch per 48 layers
+// (lyc_loha_rebuild_group) at the first layer call after a step boundary -- the staleness rules are the LoKr cache's (version counters
+// of all four factors, the step epoch, `refresh_planes(force)` for captured steps).  The backward reads the same tensor.
+struct LohaPlaneEntry {
+  c10::weak_intrusive_ptr<c10::TensorImpl> owner[4];
+  const float* ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+  Tensor plane[2];               // [bf16, f16]
+  int64_t version[2][4];
+  int64_t epoch[2] = {-1, -1};
+  float alpha[2] = {0.f, 0.f};
+  int O = 0, I = 0, r = 0;
+  c10::DeviceIndex device = 0;
+  LohaPlaneEntry()
+      : owner{c10::weak_intrusive_ptr<c10::TensorImpl>(c10::intrusive_ptr<c10::TensorImpl>()),
+              c10::weak_intrusive_ptr<c10::TensorImpl>(c10::intrusive_ptr<c10::TensorImpl>()),
+              c10::weak_intrusive_ptr<c10::TensorImpl>(c10::intrusive_ptr<c10::TensorImpl>()),
+              c10::weak_intrusive_ptr<c10::TensorImpl>(c10::intrusive_ptr<c10::TensorImpl>())} {
+    for (auto& v : version)
+      for (auto& x : v) x = -1;
+  }
+};
+std::unordered_map<const void*, LohaPlaneEntry> g_loha_planes;  // guarded by g_planes.mu
+
+// must hold g_planes.mu.  Rebuilds every stale plane of `device` (all with `force`), one launch per 48 layers and dtype.
+void refresh_loha_planes_locked(c10::DeviceIndex device, void* stream, bool force) {
+  for (int slot = 0; slot < 2; ++slot) {
+    std::vector<LycLohaPlaneItem> items;
+    std::vector<LohaPlaneEntry*> who;
+    std::vector<std::array<int64_t, 4>> vers;
+    for (auto it = g_loha_planes.begin(); it != g_loha_planes.end();) {
+      LohaPlaneEntry& e = it->second;
+      bool ok = true;
+      std::array<int64_t, 4> v{};
+      for (int k = 0; k < 4 && ok; ++k) {
+        auto t = e.owner[k].lock();  // (raw pointers into the parameters' storage: validate the live owners, as the LoKr cache does)
+        ok = t && t->device_type() == c10::DeviceType::CUDA && t->device().index() == e.device && t->has_storage() &&
+             t->dtype() == caffe2::TypeMeta::Make<float>() && t->data() == e.ptr[k] && t->is_contiguous();
+        if (ok) v[k] = (int64_t)t->version_counter().current_version();
+      }
+      if (!ok) {
+        it = g_loha_planes.erase(it);
+        continue;
+      }
+      if (e.device == device && e.plane[slot].defined()) {
+        bool stale = force || e.epoch[slot] != g_planes.epoch;
+        for (int k = 0; k < 4; ++k) stale = stale || v[k] != e.version[slot][k];
+        if (stale) {
+          items.push_back(LycLohaPlaneItem{e.ptr[0], e.ptr[1], e.ptr[2], e.ptr[3], e.plane[slot].mutable_data_ptr(), e.O, e.I, e.r, e.alpha[slot]});
+          who.push_back(&e);
+          vers.push_back(v);
+        }
+      }
+      ++it;
+    }
+    if (items.empty()) continue;
+    const c10::DeviceGuard guard(c10::Device(c10::kCUDA, device));
+    check_rc(lyc_loha_rebuild_group(items.data(), (int)items.size(), slot == 0 ? LYC_BF16 : LYC_F16, stream), "lyc_loha_rebuild_group");
+    for (size_t i = 0; i < who.size(); ++i) {
+      for (int k = 0; k < 4; ++k) who[i]->version[slot][k] = vers[i][k];
+      who[i]->epoch[slot] = g_planes.epoch;
+    }
+  }
+}
+
+// the cached operand plane of a layer whose four factors are contiguous fp32 leaf parameters, for activations of `act`; or undefined
+Tensor loha_plane_for(const Tensor& w1a, const Tensor& w1b, const Tensor& w2a, const Tensor& w2b, double alpha, at::ScalarType act,
+                      void* stream, bool fwd_role) {
+  if (!g_planes.enabled || (act != at::kBFloat16 && act != at::kHalf)) return Tensor();
+  const Tensor* f[4] = {&w1a, &w1b, &w2a, &w2b};
+  for (const Tensor* t : f) {
+    if (!t->defined() || !t->is_cuda() || !t->is_leaf() || t->scalar_type() != at::kFloat || !t->is_contiguous() || t->dim() != 2 ||
+        t->is_inference() || t->device() != w1a.device())
+      return Tensor();
+    const c10::DispatchKeySet ks = t->key_set();
+    if (ks.has(c10::DispatchKey::Python) || ks.has(c10::DispatchKey::Meta) || ks.has(c10::DispatchKey::Functionalize)) return Tensor();
+  }
+  const int64_t O = w1a.size(0), r = w1a.size(1), I = w1b.size(1);
+  if (w2a.size(0) != O || w2a.size(1) != r || w1b.size(0) != r || w2b.size(0) != r || w2b.size(1) != I || O >= (1 << 30) || I >= (1 << 30))
+    return Tensor();
+  const int slot = act == at::kBFloat16 ? 0 : 1;
+  const int code = slot == 0 ? LYC_BF16 : LYC_F16;
+  const float* ptr[4];
+  for (int k = 0; k < 4; ++k) ptr[k] = f[k]->const_data_ptr<float>();
+  if (!lyc_loha_plane_cacheable(ptr[0], ptr[1], ptr[2], ptr[3], (int)I, (int)O, (int)r, code)) return Tensor();
+  c10::TensorImpl* impl = w1a.unsafeGetTensorImpl();
+  std::lock_guard<std::mutex> lk(g_planes.mu);
+  auto it = g_loha_planes.find(impl);
+  if (it == g_loha_planes.end()) it = g_loha_planes.emplace(impl, LohaPlaneEntry()).first;
+  LohaPlaneEntry& e = it->second;
+  bool same_view = e.O == O && e.I == I && e.r == r;
+  for (int k = 0; k < 4 && same_view; ++k) {
+    auto o = e.owner[k].lock();
+    same_view = o && o.get() == f[k]->unsafeGetTensorImpl() && e.ptr[k] == ptr[k];
+  }
+  if (!same_view) {  // first use, or a parameter's storage changed: start over
+    e.plane[0] = e.plane[1] = Tensor();
+    for (int k = 0; k < 4; ++k) {
+      e.owner[k] = c10::weak_intrusive_ptr<c10::TensorImpl>(f[k]->getIntrusivePtr());
+      e.ptr[k] = ptr[k];
+    }
+    e.O = (int)O; e.I = (int)I; e.r = (int)r; e.device = w1a.device().index();
+  }
+  planes_new_epoch_if_dirty_locked(fwd_role);
+  int64_t v[4];
+  for (int k = 0; k < 4; ++k) v[k] = (int64_t)f[k]->_version();
+  auto build_one = [&]() {
+    LycLohaPlaneItem item{ptr[0], ptr[1], ptr[2], ptr[3], e.plane[slot].mutable_data_ptr(), (int)O, (int)I, (int)r, (float)alpha};
+    check_rc(lyc_loha_rebuild_group(&item, 1, code, stream), "lyc_loha_rebuild_group");
+    for (int k = 0; k < 4; ++k) e.version[slot][k] = v[k];
+    e.epoch[slot] = g_planes.epoch;
+    e.alpha[slot] = (float)alpha;
+  };
+  if (!e.plane[slot].defined()) {
+    e.plane[slot] = at::empty({lyc_loha_workspace_bytes((int)O, (int)I, code)}, w1a.options().dtype(at::kByte));
+    build_one();
+  } else if (e.alpha[slot] != (float)alpha) {  // another multiplier / alpha: this layer alone, now
+    build_one();
+  } else {
+    bool stale = e.epoch[slot] != g_planes.epoch;
+    for (int k = 0; k < 4; ++k) stale = stale || e.version[slot][k] != v[k];
+    if (stale) {
+      refresh_loha_planes_locked(e.device, stream, false);
+      if (g_loha_planes.find(impl) == g_loha_planes.end()) return Tensor();
+    }
+  }
+  return e.plane[slot];
+}
+
 const void* planes_bwd_ptr(const Tensor& planes, int64_t c, int64_t d, int taps) {
   return static_cast<const char*>(planes.const_data_ptr()) + lyc_lokr_planes_bytes((int)c, (int)d, taps, 0);
 }
@@ -1836,10 +1970,13 @@ std::tuple<Tensor, Tensor> loha_linear_fwd(const Tensor& x, const Tensor& w1a, c
   TORCH_CHECK(x.size(-1) == I, "adapter expects ", I, " input features, got ", x.sizes());
   Tensor rows = rows_of(x, I), a1 = f32c(w1a), b1 = f32c(w1b), a2 = f32c(w2a), b2 = f32c(w2b);
   const int code = dtype_code(x.scalar_type());
-  Tensor ws = at::empty({lyc_loha_workspace_bytes((int)O, (int)I, code)}, x.options().dtype(at::kByte));
+  // leaf-parameter factors: the operand plane comes from the cache (rebuilt once per optimizer step, all layers in grouped launches)
+  Tensor ws = loha_plane_for(w1a, w1b, w2a, w2b, alpha, x.scalar_type(), stream_of(x), /*fwd_role=*/true);
+  const bool cached = ws.defined();
+  if (!cached) ws = at::empty({lyc_loha_workspace_bytes((int)O, (int)I, code)}, x.options().dtype(at::kByte));
   Tensor y = at::empty({rows.size(0), O}, x.options());
   check_rc(lyc_loha_linear_fwd(cptr(rows), cfp(a1), cfp(b1), cfp(a2), cfp(b2), mptr(ws), mptr(y), rows.size(0), (int)I, (int)O,
-                               (int)r, (float)alpha, code, stream_of(x)), "lyc_loha_linear_fwd");
+                               (int)r, (float)alpha, code | (cached ? LYC_PLANE_READY : 0), stream_of(x)), "lyc_loha_linear_fwd");
   auto oshape = x.sizes().vec();
   oshape.back() = O;
   return {y.view(oshape), ws};
@@ -1911,6 +2048,7 @@ struct LohaLinearFn : public torch::autograd::Function<LohaLinearFn> {
     return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    planes_mark_dirty_after_backward();  // the end of this backward pass is a step boundary for the operand-plane cache (LoHa: round 6)
     auto s = saved_vars(ctx);
     const double alpha = ctx->saved_data["alpha"].toDouble();
     const bool nx = ctx->needs_input_grad(0);
@@ -2865,7 +3003,7 @@ struct AdapterConv2dFn : public torch::autograd::Function<AdapterConv2dFn> {
     auto s = saved_vars(ctx);
     const Tensor &x = s[0], &cols = s[1], &saved = s[2];
     const int64_t algo = ctx->saved_data["algo"].toInt();
-    if (algo == ALGO_LOKR) planes_mark_dirty_after_backward();
+    if (algo == ALGO_LOKR || algo == 2 /* ALGO_LOHA */) planes_mark_dirty_after_backward();
     const double alpha = ctx->saved_data["alpha"].toDouble();
     auto gv = ctx->saved_data["geom"].toIntVector();
     const std::vector<int64_t> kernel{gv[0], gv[1]}, stride{gv[2], gv[3]}, padding{gv[4], gv[5]}, dilation{gv[6], gv[7]};
@@ -3096,10 +3234,18 @@ PYBIND11_MODULE(_lyc_torch, m) {
   });
   m.def("refresh_planes", [](bool force) {  // every cached plane set whose parameter changed (force: all), on the current streams
     std::lock_guard<std::mutex> lk(g_planes.mu);
+    // an explicit refresh in front of a forward pass IS the step boundary: take the pending "dirty" mark here, so that the first layer
+    // call behind it does not find a new epoch and refresh everything a second time (round 6: every replay of a captured step did)
+    planes_new_epoch_if_dirty_locked(true);
     std::vector<c10::DeviceIndex> devs;
     for (auto& kv : g_planes.map)
       if (std::find(devs.begin(), devs.end(), kv.second.device) == devs.end()) devs.push_back(kv.second.device);
-    for (c10::DeviceIndex dv : devs) refresh_planes_locked(dv, c10::hip::getCurrentHIPStream(dv).stream(), force);
+    for (auto& kv : g_loha_planes)
+      if (std::find(devs.begin(), devs.end(), kv.second.device) == devs.end()) devs.push_back(kv.second.device);
+    for (c10::DeviceIndex dv : devs) {
+      refresh_planes_locked(dv, c10::hip::getCurrentHIPStream(dv).stream(), force);
+      refresh_loha_planes_locked(dv, c10::hip::getCurrentHIPStream(dv).stream(), force);
+    }
   }, py::arg("force") = false);
   m.def("reset_use_counts", []() {  // once per optimizer step (AdapterGradSync.zero_grad / finish): drop counts of forwards
     std::lock_guard<std::mutex> lk(g_accum.mu);  // whose backward never ran

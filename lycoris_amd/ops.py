@@ -107,7 +107,8 @@ def discard_deferred() -> int:
 
 
 def refresh_lokr_planes(force: bool = False):
-    """Repack the cached LoKr operand planes (csrc/torch_ops.cpp `planes_for`) of every parameter that changed since they were
+    """Repack the cached operand planes -- LoKr's packed w2 planes (csrc/torch_ops.cpp `planes_for`) and, since round 6, LoHa's dW planes
+    (`loha_plane_for`) -- of every parameter that changed since they were
     written -- `force`: of every cached parameter -- in grouped launches on the current stream.  Eager training never needs to
     call this (the first layer call after optimizer.step() does it); a caller that REPLAYS captured graphs must capture this
     call (with force=True) in front of the forward pass, so that each replay sees the parameters of its own step."""

@@ -149,7 +149,8 @@ def test_ctypes_item_structs_match_the_header_layout(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
     mirrors = {"LycLokrWgradItem": N.WgradItem, "LycLoconWgradItem": N.LoconWgradItem, "LycLohaWgradItem": N.LohaWgradItem,
-               "LycLokrConvWgradItem": N.LokrConvWgradItem, "LycLokrPackItem": N.LokrPackItem, "LycLokrLrChainItem": N.LokrLrChainItem}
+               "LycLokrConvWgradItem": N.LokrConvWgradItem, "LycLokrPackItem": N.LokrPackItem, "LycLokrLrChainItem": N.LokrLrChainItem,
+               "LycLohaPlaneItem": N.LohaPlaneItem}
     lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{HEADER}"', "int main(void) {"]
     for cname, cls in mirrors.items():
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
