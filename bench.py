@@ -739,6 +739,9 @@ def main():
     sync._sync_enabled = False  # the measurement legs below repeat passes without finish(): no bucket bookkeeping there
     if extra and not args.no_roofline and not args.rank:  # (the low-rank leg reports the step only: its Linear kernels are the same)
         result["roofline"] = roofline(insts, args, dtype, dev)
+        mb = pmc_mfma(f"{args.algo}/{args.model}/linear")  # north_star: "MFMA utilisation reported against gfx950 peak" (counter pass)
+        if mb and result["roofline"] is not None:
+            result["roofline"]["mfma_busy"] = mb
     if extra and not args.no_reference and args.algo in ("lokr", "locon", "loha"):
         result["reference_rocm_eager"] = reference_leg(insts, sync, ms_per_step)
     if extra and not args.no_base and args.algo in ("lokr", "locon", "loha"):
@@ -856,6 +859,24 @@ def pmc_traffic(family, workload):
         return None, f"profiles/pmc_traffic.json has no pass for workload {workload}"
     fam = wl.get(family)
     return (fam if fam else None), rec.get("source", "profiles/pmc_traffic.json") + note
+
+
+def pmc_mfma(workload):
+    """MFMA utilisation of the workload's kernels from the committed counter pass (profiles/pmc_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES over
+    the dispatch duration, benchmarks/pmc_mfma.py), trusted only when it was collected on THIS build of the library"""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_mfma.json")) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if rec.get("lib_sha16") != lib_sha():
+        return {"note": f"profiles/pmc_mfma.json was collected on build {rec.get('lib_sha16')}, this is {lib_sha()}"}
+    wl = rec.get("workloads", {}).get(workload)
+    if not wl:
+        return None
+    top = sorted(wl["kernels"].items(), key=lambda kv: -kv[1]["total_us"])[:6]
+    return {"time_weighted_mfma_util": wl["time_weighted_mfma_util"], "source": rec.get("source"),
+            "kernels": {k.split("lyc")[-1][:70]: {"avg_us": v["avg_us"], "mfma_util": v["mfma_util"], "launches": v["launches"]} for k, v in top}}
 
 
 def roofline(insts, args, dtype, dev):

@@ -76,7 +76,9 @@ struct Variant {
   {"k4 " #MI "x" #NI " D" #D " P" #NP, MI, NI, D, NP,                                                        \
    {kron4_kernel<__bf16, MI, NI, D, 0, NP != 0>, kron4_kernel<__bf16, MI, NI, D, 1, NP != 0>, kron4_kernel<__bf16, MI, NI, D, 2, NP != 0>}}
 static Variant VARIANTS[] = {V(1, 2, 3, 0), V(1, 2, 3, 1), V(2, 2, 2, 0), V(2, 2, 2, 1), V(2, 4, 3, 0), V(2, 4, 3, 1), V(2, 5, 2, 0), V(2, 5, 2, 1),
-                             V(2, 5, 3, 0), V(2, 5, 3, 1), V(1, 4, 3, 1), V(1, 5, 3, 1), V(2, 4, 2, 1), V(4, 4, 2, 1)};
+                             V(2, 5, 3, 0), V(2, 5, 3, 1), V(1, 4, 3, 1), V(1, 5, 3, 1), V(2, 4, 2, 1), V(4, 4, 2, 1),
+                             // round 6 (VERDICT r5 #6b): the whole K = 160 (five k steps) in flight from the prologue
+                             V(1, 2, 4, 1), V(1, 2, 5, 1), V(1, 2, 6, 1), V(2, 2, 5, 1), V(1, 4, 5, 1), V(1, 5, 5, 1)};
 
 struct RVariant {
   const char* name;
