@@ -52,6 +52,10 @@ int main() {
   CK(hipMalloc(&sink, 64));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int m = 0; m < 3; ++m) {
+    const void* f = m == 0 ? (const void*)stream_kernel<0> : m == 1 ? (const void*)stream_kernel<1> : (const void*)stream_kernel<2>;
+    CK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
   const unsigned spans[] = {2u << 20, 16u << 20, 128u << 20, 1u << 30};
   const char* names[] = {"DMA linear 1KiB", "DMA 16 rows x 64B", "VGPR linear 16B/lane"};
   for (int mode = 0; mode < 3; ++mode)
@@ -60,7 +64,8 @@ int main() {
         const int bt = wpc >= 4 ? 256 : 64 * wpc;
         const int blocks = 256 * (wpc >= 4 ? wpc / 4 : 1);
         const int iters = 400;
-        const int lds = (bt / 64) * 8 * 1024;
+        const int lds = getenv("DMB_LDS") ? atoi(getenv("DMB_LDS")) : (bt / 64) * 8 * 1024;  // DMB_LDS: a larger allocation (occupancy limit by LDS)
+        if (getenv("DMB_QUICK") && (span != (2u << 20) || (wpc != 4 && wpc != 8))) continue;
         auto go = [&]() {
           if (mode == 0) hipLaunchKernelGGL(stream_kernel<0>, dim3(blocks), dim3(bt), lds, st, src, span, iters, sink);
           if (mode == 1) hipLaunchKernelGGL(stream_kernel<1>, dim3(blocks), dim3(bt), lds, st, src, span, iters, sink);

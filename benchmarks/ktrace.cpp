@@ -98,7 +98,8 @@ int main(int argc, char** argv) {
         if (!bw) hipLaunchKernelGGL((bneck_kernel<__bf16, 8, 1, 1, true, true>), grid, dim3(512), 0, 0, b);
         else hipLaunchKernelGGL((bneck_kernel<__bf16, 8, 1, 1, false, false>), grid, dim3(512), 0, 0, b);
       } else {
-        if (!bw) hipLaunchKernelGGL((bneck_kernel<__bf16, 4, 1, 1, true, true>), grid, dim3(256), 0, 0, b);
+        if (!bw && getenv("KT_STG")) hipLaunchKernelGGL((bneck_kernel<__bf16, 4, 1, 1, true, true, false, true>), grid, dim3(256), 0, 0, b);  // production forward
+        else if (!bw) hipLaunchKernelGGL((bneck_kernel<__bf16, 4, 1, 1, true, true>), grid, dim3(256), 0, 0, b);
         else hipLaunchKernelGGL((bneck_kernel<__bf16, 4, 1, 1, false, false>), grid, dim3(256), 0, 0, b);
       }
       if (rep == 0) printf("grid %u x %u, %d waves\n", grid.x, grid.y, nw);
