@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--nchw", dest="channels_last", action="store_false",
                     help="Conv2d activations in contiguous NCHW memory: two layout transposes per conv layer and pass on top (A/B leg)")
     ap.add_argument("--overlap-leg", action="store_true",
-                    help="development: also time base + adapter with every layer's adapter on a side HIP stream (negative result, DESIGN.md 7.4)")
+                    help="development: also time base + adapter with every layer's adapter on a side HIP stream (negative result, HISTORY.md 7.4)")
     ap.add_argument("--no-defer", action="store_true",
                     help="A/B: one LoKr weight-gradient launch per layer instead of the grouped launches")
     ap.add_argument("--rank", type=int, default=0,

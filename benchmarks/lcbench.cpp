@@ -149,6 +149,28 @@ static void launch_new(const Bneck4Args& a, const Plan& p, hipStream_t st) {
   }
 }
 
+template <bool FT>
+static void launch_group(const Bneck4GroupArgs& ga, const Plan& p, long M, hipStream_t st) {
+  const dim3 grid((unsigned)cdivl(M, 16 * p.mi), (unsigned)p.ns, (unsigned)ga.n);
+  if (p.nw == 8) hipLaunchKernelGGL((bneck4_group_kernel<__bf16, 8, 1, FT>), grid, dim3(512), p.lds, st, ga);
+  else hipLaunchKernelGGL((bneck4_group_kernel<__bf16, 4, 2, FT>), grid, dim3(256), p.lds, st, ga);
+}
+template <bool FT>
+static void launch_sum(const Bneck4GroupArgs& ga, void* out_sum, const Plan& p, long M, hipStream_t st) {
+  const dim3 grid((unsigned)cdivl(M, 16 * p.mi), (unsigned)p.ns);
+  if (p.nw == 8) hipLaunchKernelGGL((bneck4_sum_kernel<__bf16, 8, 1, FT>), grid, dim3(512), p.lds, st, ga, out_sum);
+  else hipLaunchKernelGGL((bneck4_sum_kernel<__bf16, 4, 2, FT>), grid, dim3(256), p.lds, st, ga, out_sum);
+}
+__global__ void sum_bf16(const unsigned short* a, const unsigned short* b, const unsigned short* c, unsigned short* o, size_t n) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float v = __uint_as_float((unsigned)a[i] << 16) + __uint_as_float((unsigned)b[i] << 16) + (c ? __uint_as_float((unsigned)c[i] << 16) : 0.f);
+    unsigned u = __float_as_uint(v);
+    o[i] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  }
+}
+
 static float bf2f(unsigned short v) {
   unsigned u = (unsigned)v << 16;
   float f;
@@ -166,6 +188,8 @@ int main(int argc, char** argv) {
   CK(hipStreamCreate(&st));
 #define ATTR(NW_, MI_, FT_) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck4_kernel<__bf16, NW_, MI_, FT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
   ATTR(4, 1, false); ATTR(4, 1, true); ATTR(4, 2, false); ATTR(4, 2, true); ATTR(8, 1, false); ATTR(8, 1, true); ATTR(8, 2, false); ATTR(8, 2, true); ATTR(16, 1, false); ATTR(16, 1, true);
+#define ATTRG(K_, NW_, MI_) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K_<__bf16, NW_, MI_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+  ATTRG(bneck4_group_kernel, 8, 1); ATTRG(bneck4_group_kernel, 4, 2); ATTRG(bneck4_sum_kernel, 8, 1); ATTRG(bneck4_sum_kernel, 4, 2);
   {
     float us = bench(st, 200, 5, [&](int) { hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, st, nullptr); });
     printf("# empty 256-workgroup launch inside a graph: %.2f us\n", us);
@@ -269,6 +293,59 @@ int main(int argc, char** argv) {
              s.tag, M, I, O, bw ? "bwd" : "fwd", t_old, bytes / t_old * 1e-3, p.nw, p.mi, p.ns, p.D, p.D2, p.lds >> 10, cdivl(M, 16 * p.mi) * p.ns, t_new, bytes / t_new * 1e-3,
              t_old / t_new, mdiff, mmax, odiff, omax, ok ? "ok" : "MISMATCH");
       fflush(stdout);
+    }
+    // ---- the input gradient of a tensor that n sibling projections read: n problems + a summation pass vs bneck4_sum_kernel ----
+    const int nsib = getenv("LCB_SUM") ? atoi(getenv("LCB_SUM")) : 0;
+    if (nsib >= 2 && nsib <= 4 && nsets >= nsib) {
+      float* ups[4]; float* downs[4];
+      for (int i = 0; i < nsib; ++i) {
+        CK(hipMalloc(&ups[i], (size_t)O * R * 4)); CK(hipMalloc(&downs[i], (size_t)R * I * 4));
+        hipLaunchKernelGGL(fill_f32, dim3(64), dim3(256), 0, st, downs[i], (size_t)R * I, 50u + i, 0.05f);
+        hipLaunchKernelGGL(fill_f32, dim3(64), dim3(256), 0, st, ups[i], (size_t)O * R, 60u + i, 0.2f);
+      }
+      const int K1 = O, N2 = I;
+      Plan pg{}, ps{};
+      if (!bneck4_make_plan(M, K1, N2, true, nsib, pg) || !bneck4_make_plan(M, K1, N2, true, 1, ps, nsib)) { fprintf(stderr, "no plan\n"); exit(1); }
+      auto garg = [&](int set0, const Plan& p, bool own_out) {
+        Bneck4GroupArgs ga{};
+        ga.n = nsib;
+        for (int i = 0; i < nsib; ++i) {
+          const Set& z = sets[(set0 + i) % nsets];
+          Bneck4Args& a = ga.p[i];
+          a.A = z.g; a.mid = z.dt; a.out = own_out ? z.dx : oref; a.M = (int)M; a.R = R; a.K1 = K1; a.KS = (int)cdivl(K1, 32); a.N2 = N2; a.lda = K1; a.ldo = N2;
+          a.a_bytes = (unsigned)((size_t)M * K1 * 2); a.out_bytes = (unsigned)((size_t)M * N2 * 2);
+          a.F1 = ups[i]; a.F2 = downs[i]; a.alpha1 = 0.5f; a.alpha2 = 1.f;
+          a.f1_bytes = (unsigned)((size_t)R * K1 * 4); a.f2_bytes = (unsigned)((size_t)R * N2 * 4);
+          a.D = p.D; a.D2 = p.D2;
+        }
+        return ga;
+      };
+      // agreement: group launch + sum of the rounded results vs the fused sum (one rounding): a few units in the last place of the range
+      launch_group<true>(garg(0, pg, true), pg, M, st);
+      hipLaunchKernelGGL(sum_bf16, dim3(1024), dim3(256), 0, st, (const unsigned short*)sets[0].dx, (const unsigned short*)sets[1 % nsets].dx,
+                         nsib > 2 ? (const unsigned short*)sets[2 % nsets].dx : nullptr, (unsigned short*)oref, xb / 2);
+      CK(hipMemcpyAsync(hm_ref.data(), sets[1 % nsets].dt, (size_t)M * R * 4, hipMemcpyDeviceToHost, st));
+      CK(hipStreamSynchronize(st));
+      CK(hipMemsetAsync(sets[1 % nsets].dt, 0xff, (size_t)M * R * 4, st));
+      launch_sum<true>(garg(0, ps, true), onew, ps, M, st);
+      CK(hipStreamSynchronize(st));
+      CK(hipGetLastError());
+      CK(hipMemcpy(h_ref.data(), oref, xb, hipMemcpyDeviceToHost)); CK(hipMemcpy(h_new.data(), onew, xb, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hm_new.data(), sets[1 % nsets].dt, (size_t)M * R * 4, hipMemcpyDeviceToHost));
+      double omax = 0, odiff = 0, mdiff = 0;
+      for (size_t i = 0; i < xb / 2; ++i) { const double r = bf2f(h_ref[i]), n = bf2f(h_new[i]); omax = fmax(omax, fabs(r)); odiff = fmax(odiff, fabs(r - n)); if (n != n) odiff = 1e30; }
+      for (size_t i = 0; i < (size_t)M * R; ++i) mdiff = fmax(mdiff, fabs((double)hm_ref[i] - hm_new[i]));
+      const int nl = nsets * 2;
+      const float t_grp = bench(st, nl, 5, [&](int i) { launch_group<true>(garg(i * nsib, pg, true), pg, M, st); });
+      const float t_add = bench(st, nl, 5, [&](int i) {
+        hipLaunchKernelGGL(sum_bf16, dim3(1024), dim3(256), 0, st, (const unsigned short*)sets[i % nsets].dx, (const unsigned short*)sets[(i + 1) % nsets].dx,
+                           nsib > 2 ? (const unsigned short*)sets[(i + 2) % nsets].dx : nullptr, (unsigned short*)sets[(i + 3) % nsets].x, xb / 2);
+      });
+      const float t_sum = bench(st, nl, 5, [&](int i) { launch_sum<true>(garg(i * nsib, ps, true), sets[(i * nsib + 1) % nsets].dx, ps, M, st); });
+      printf("%-10s M=%-6ld %5d->%-5d dx of %d siblings | group (ns%d D%d D2 %d) %7.2f us + sum pass %6.2f us | fused ns%d D%d D2 %d lds %3dK %7.2f us x%.2f | out %.1e/%.1e mid %.1e %s\n",
+             s.tag, M, I, O, nsib, pg.ns, pg.D, pg.D2, t_grp, t_add, ps.ns, ps.D, ps.D2, ps.lds >> 10, t_sum, (t_grp + t_add) / t_sum, odiff, omax, mdiff,
+             odiff <= omax / 64.0 && mdiff <= 1e-6 ? "ok" : "MISMATCH");
+      for (int i = 0; i < nsib; ++i) { CK(hipFree(ups[i])); CK(hipFree(downs[i])); }
     }
     for (Set& z : sets) { CK(hipFree(z.x)); CK(hipFree(z.g)); CK(hipFree(z.y)); CK(hipFree(z.dx)); CK(hipFree(z.t)); CK(hipFree(z.dt)); }
     CK(hipFree(down)); CK(hipFree(up)); CK(hipFree(oref)); CK(hipFree(onew)); CK(hipFree(mref)); CK(hipFree(mnew));

@@ -37,14 +37,18 @@ enum { LYC_F32_ROWS = 0x100, LYC_DEFER_WGRAD = 0x200,
        LYC_CONV_WGRAD_PATCH = 0x800,
        /* lyc_loha_linear_fwd only (round 6): `wplanes` already holds the operand plane of these factors (lyc_loha_rebuild_group: the
         * caller's once-per-optimizer-step plane cache) -- the entry point skips its rebuild launch */
-       LYC_PLANE_READY = 0x10000 };
+       LYC_PLANE_READY = 0x10000,
+       /* the rank-r (LoCon) entry points, round 6: keep the reduce / expand launch on the register-staged kernel of rounds 1-5
+        * (bneck_kernel, lowrank.h) instead of the LDS-DMA kernel (bneck4_kernel, lowrank4.h) where both cover the problem -- the
+        * A/B and regression-test switch (an argument, not getenv) */
+       LYC_BNECK_REG = 0x20000 };
 /* The *_planes Conv2d entry points and lyc_lokr_conv2d_planes_ok / _dx_blocks: pin the patch kernel's row tile (mi = 2, 4 or 8: 64 * mi
  * stage-1 rows per workgroup) instead of letting the host plan it -- for tests, which otherwise reach only the smallest tile with
  * their small problems (rounds 2-3 read an environment variable for this). */
 #define LYC_KCONV_ROW_TILE(mi) (((mi) & 0xf) << 12)
 enum { LYC_OK = 0, LYC_ERR_ARG = 1, LYC_ERR_UNSUPPORTED = 2, LYC_ERR_LAUNCH = 3 };
 
-#define LYC_ABI_VERSION 12
+#define LYC_ABI_VERSION 13
 int lyc_abi_version(void);
 const char* lyc_last_error(void);
 
@@ -314,6 +318,12 @@ typedef struct LycLoconLinearGroupItem {
 } LycLoconLinearGroupItem;
 int lyc_locon_linear_fwd_group(const LycLoconLinearGroupItem* items, int n, int I, int O, int r, int dtype, void* stream);
 int lyc_locon_linear_bwd_group(const LycLoconLinearGroupItem* items, int n, int I, int O, int r, int dtype, void* stream);
+/* The same backward for 2 <= n <= 4 problems that read ONE tensor (equal M; round 6): dx_sum [M, I] = sum_i dt_i down_i, formed as ONE
+ * expand stage over the n `mid` tiles of a workgroup (lowrank4.h: bneck4_sum_kernel) -- fp32 sum, one rounding, no dx_i written (`out`
+ * of the items is ignored), every dt_i still goes to its `mid`.  Replaces lyc_locon_linear_bwd_group + lyc_sum_rows for
+ * locon.py:309-332 called n times on one tensor.  LYC_ERR_UNSUPPORTED (nothing launched) where bneck4_kernel does not cover the
+ * shape (r > 16, r % 4, I % 8, O % 8, unaligned pointers) or the n tiles do not fit the LDS: use the two calls above. */
+int lyc_locon_linear_bwd_group_sum(const LycLoconLinearGroupItem* items, int n, int I, int O, int r, void* dx_sum, int dtype, void* stream);
 
 /* LoCon on nn.Conv2d without im2col (reference: lycoris/modules/locon.py:286-332 with F.conv2d -- lora_down is the
  * kh x kw convolution [r, C, kh, kw], lora_up the 1x1 convolution [O, r, 1, 1]; functional/locon.py:64-85).

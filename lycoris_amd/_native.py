@@ -13,7 +13,7 @@ import torch
 
 _LIB_NAME = "liblycoris_amd.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 LYC_F32, LYC_F16, LYC_BF16 = 0, 1, 2
 _DTYPE_CODE = {torch.float32: LYC_F32, torch.float16: LYC_F16, torch.bfloat16: LYC_BF16}
@@ -66,6 +66,7 @@ SIGNATURES = {
     "lyc_sum_rows": [_vp, _i32, _vp, _i64, _i32, _vp],
     "lyc_locon_linear_fwd_group": [_vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "lyc_locon_linear_bwd_group": [_vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "lyc_locon_linear_bwd_group_sum": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "lyc_lokr_linear_bwd_group_sum": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "lyc_nchw_to_rows": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "lyc_rows_to_nchw": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],

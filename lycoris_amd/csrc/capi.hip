@@ -26,6 +26,7 @@
 #include "gemm16d.h"
 #include "lokr_kernels.h"
 #include "lowrank.h"
+#include "lowrank4.h"
 #include "skinny_kernels.h"
 #include "tucker.h"
 #include "wspace.h"
@@ -651,7 +652,118 @@ bool launch_bneck_group(BneckGroupArgs& ga, hipStream_t st) {
   return mi == 2 ? launch_bneck_group_v<T, 2, 2>(ga, vec, st) : launch_bneck_group_v<T, 1, 2>(ga, vec, st);
 }
 
+// ---- round 6: the LDS-DMA form of the launch (lowrank4.h) where its conditions hold ------------------------------------------------
+// BneckArgs -> Bneck4Args; false when the problem is outside bneck4_kernel (rank above 16, fp32 output rows, gathers, strided or
+// unaligned factors, a tensor of 2 GiB or more): the caller keeps bneck_kernel.
+bool bneck4_args(const BneckArgs& b, Bneck4Args& a, bool& ft) {
+  if (b.gat.mode != 0 || b.out_f32 || b.R < 4 || b.R > 16 || (b.R % 4) != 0 || (b.K1 % 8) != 0 || (b.N2 % 8) != 0 || b.M < 1) return false;
+  if (b.f1k == 1 && b.f1n == b.K1 && b.f2k == 1 && b.f2n == b.R) ft = false;         // forward: F1 = down [R, K1], F2 = up [N2, R]
+  else if (b.f1n == 1 && b.f1k == b.R && b.f2n == 1 && b.f2k == b.N2) ft = true;     // backward: F1 = up [K1, R], F2 = down [R, N2]
+  else return false;
+  if ((b.lda % 8) != 0 || (b.out != nullptr && (b.ldo % 8) != 0)) return false;
+  if (((reinterpret_cast<uintptr_t>(b.A) | reinterpret_cast<uintptr_t>(b.out) | reinterpret_cast<uintptr_t>(b.F1) | reinterpret_cast<uintptr_t>(b.F2)) & 15u) != 0) return false;
+  const long lim = (1L << 31) - 1;
+  if (b.M * b.lda * 2 > lim || (b.out != nullptr && b.M * b.ldo * 2 > lim) || (long)b.R * b.K1 * 4 > lim || (long)b.R * b.N2 * 4 > lim) return false;
+  a.A = b.A; a.F1 = b.F1; a.F2 = b.F2; a.mid = b.mid; a.out = b.out;
+  a.a_bytes = (unsigned)((b.M - 1) * b.lda * 2 + (long)b.K1 * 2); a.out_bytes = b.out ? (unsigned)((b.M - 1) * b.ldo * 2 + (long)b.N2 * 2) : 0u;
+  a.f1_bytes = (unsigned)((long)b.R * b.K1 * 4); a.f2_bytes = (unsigned)((long)b.R * b.N2 * 4);
+  a.lda = (int)b.lda; a.ldo = (int)b.ldo; a.M = (int)b.M; a.K1 = b.K1; a.KS = (b.K1 + 31) / 32; a.R = b.R; a.N2 = b.N2;
+  a.alpha1 = b.alpha1; a.alpha2 = b.alpha2;
+  return true;
+}
+template <typename T, int NW, int MI, bool FT>
+void launch_bneck4_inst(const Bneck4Args& a, dim3 grid, int lds, hipStream_t st) {
+  static bool attr_set = false;  // dynamic LDS above 64 KiB needs the opt-in (per instantiation)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck4_kernel<T, NW, MI, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bneck4_kernel<T, NW, MI, FT>), grid, dim3(NW * 64), lds, st, a);
+}
+template <typename T, int NW, int MI, bool FT>
+void launch_bneck4_group_inst(const Bneck4GroupArgs& ga, dim3 grid, int lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck4_group_kernel<T, NW, MI, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bneck4_group_kernel<T, NW, MI, FT>), grid, dim3(NW * 64), lds, st, ga);
+}
+template <typename T>
+bool launch_bneck4(const BneckArgs& b, hipStream_t st) {
+  Bneck4Args a{};
+  bool ft = false;
+  Bneck4Plan p{};
+  if (!bneck4_args(b, a, ft) || !bneck4_make_plan(b.M, b.K1, b.N2, b.out != nullptr, 1, p)) return false;
+  a.D = p.D; a.D2 = p.D2;
+  const dim3 grid((unsigned)cdiv(b.M, 16 * p.mi), (unsigned)p.ns);
+  if (p.nw == 8) ft ? launch_bneck4_inst<T, 8, 1, true>(a, grid, p.lds, st) : launch_bneck4_inst<T, 8, 1, false>(a, grid, p.lds, st);
+  else ft ? launch_bneck4_inst<T, 4, 2, true>(a, grid, p.lds, st) : launch_bneck4_inst<T, 4, 2, false>(a, grid, p.lds, st);
+  return true;
+}
+template <typename T>
+bool launch_bneck4_group(const BneckGroupArgs& ga, hipStream_t st) {
+  Bneck4GroupArgs g4{};
+  if (ga.n > BNECK4_GROUP_MAX) return false;
+  g4.n = ga.n;
+  bool ft0 = false;
+  for (int i = 0; i < ga.n; ++i) {
+    bool ft = false;
+    if (!bneck4_args(ga.p[i], g4.p[i], ft)) return false;
+    if (i == 0) ft0 = ft;
+    else if (ft != ft0) return false;
+    const BneckArgs &q = ga.p[i], &b0 = ga.p[0];
+    if (q.M != b0.M || q.K1 != b0.K1 || q.R != b0.R || q.N2 != b0.N2 || (q.out == nullptr) != (b0.out == nullptr)) return false;
+  }
+  const BneckArgs& b = ga.p[0];
+  Bneck4Plan p{};
+  if (!bneck4_make_plan(b.M, b.K1, b.N2, b.out != nullptr, ga.n, p)) return false;
+  for (int i = 0; i < ga.n; ++i) { g4.p[i].D = p.D; g4.p[i].D2 = p.D2; }
+  const dim3 grid((unsigned)cdiv(b.M, 16 * p.mi), (unsigned)p.ns, (unsigned)ga.n);
+  if (p.nw == 8) ft0 ? launch_bneck4_group_inst<T, 8, 1, true>(g4, grid, p.lds, st) : launch_bneck4_group_inst<T, 8, 1, false>(g4, grid, p.lds, st);
+  else ft0 ? launch_bneck4_group_inst<T, 4, 2, true>(g4, grid, p.lds, st) : launch_bneck4_group_inst<T, 4, 2, false>(g4, grid, p.lds, st);
+  return true;
+}
+
+template <typename T, int NW, int MI, bool FT>
+void launch_bneck4_sum_inst(const Bneck4GroupArgs& ga, void* out_sum, dim3 grid, int lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bneck4_sum_kernel<T, NW, MI, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bneck4_sum_kernel<T, NW, MI, FT>), grid, dim3(NW * 64), lds, st, ga, out_sum);
+}
+// the n problems of `ga` (equal shapes, `out` unused) in one workgroup per tile, stage-2 results summed into out_sum [M, N2] (row pitch N2)
+template <typename T>
+bool launch_bneck4_sum(BneckGroupArgs& ga, void* out_sum, hipStream_t st) {
+  Bneck4GroupArgs g4{};
+  if (ga.n < 2 || ga.n > BNECK4_GROUP_MAX || (reinterpret_cast<uintptr_t>(out_sum) & 15u)) return false;
+  g4.n = ga.n;
+  bool ft0 = false;
+  for (int i = 0; i < ga.n; ++i) {
+    bool ft = false;
+    ga.p[i].out = out_sum;  // (alignment / extent checks of bneck4_args)
+    if (!bneck4_args(ga.p[i], g4.p[i], ft)) return false;
+    if (i == 0) ft0 = ft;
+    else if (ft != ft0) return false;
+    const BneckArgs &q = ga.p[i], &b0 = ga.p[0];
+    if (q.M != b0.M || q.K1 != b0.K1 || q.R != b0.R || q.N2 != b0.N2) return false;
+  }
+  const BneckArgs& b = ga.p[0];
+  Bneck4Plan p{};
+  if (!bneck4_make_plan(b.M, b.K1, b.N2, true, 1, p, ga.n)) return false;
+  for (int i = 0; i < ga.n; ++i) { g4.p[i].D = p.D; g4.p[i].D2 = p.D2; }
+  const dim3 grid((unsigned)cdiv(b.M, 16 * p.mi), (unsigned)p.ns);
+  if (p.nw == 8) ft0 ? launch_bneck4_sum_inst<T, 8, 1, true>(g4, out_sum, grid, p.lds, st) : launch_bneck4_sum_inst<T, 8, 1, false>(g4, out_sum, grid, p.lds, st);
+  else ft0 ? launch_bneck4_sum_inst<T, 4, 2, true>(g4, out_sum, grid, p.lds, st) : launch_bneck4_sum_inst<T, 4, 2, false>(g4, out_sum, grid, p.lds, st);
+  return true;
+}
+
 void launch_bneck_dt(const BneckArgs& b, int dtype, hipStream_t st) {
+  if (!(dtype & LYC_BNECK_REG)) {
+    if ((dtype & 0xff) == LYC_BF16 ? launch_bneck4<__bf16>(b, st) : launch_bneck4<_Float16>(b, st)) return;
+  }
   if ((dtype & 0xff) == LYC_BF16)
     launch_bneck<__bf16>(b, st);
   else
@@ -2103,7 +2215,7 @@ int locon_linear_group(const LycLoconLinearGroupItem* items, int n, int I, int O
   if (n < 1 || n > BNECK_GROUP_MAX || !items) return fail(LYC_ERR_ARG, "%s: 1 .. %d items", who, BNECK_GROUP_MAX);
   if (I < 1 || O < 1 || r < 1) return fail(LYC_ERR_ARG, "%s: bad dims", who);
   const int dt = dtype & 0xff;
-  if ((dt != LYC_BF16 && dt != LYC_F16) || (dtype & ~0xff)) return fail(LYC_ERR_UNSUPPORTED, "%s: 16-bit activations, no dtype flags", who);
+  if ((dt != LYC_BF16 && dt != LYC_F16) || (dtype & ~(0xff | LYC_BNECK_REG))) return fail(LYC_ERR_UNSUPPORTED, "%s: 16-bit activations, no dtype flags but LYC_BNECK_REG", who);
   BneckGroupArgs ga{};
   ga.n = n;
   for (int k = 0; k < n; ++k) {
@@ -2119,12 +2231,35 @@ int locon_linear_group(const LycLoconLinearGroupItem* items, int n, int I, int O
     }
     if (!bneck_ok(b, dtype)) return fail(LYC_ERR_UNSUPPORTED, "%s: item %d is not on the fused rank-r path (16-bit, K %% 8 == 0, r <= 64, aligned rows)", who, k);
   }
+  if (!(dtype & LYC_BNECK_REG)) {  // round 6: the LDS-DMA kernel where it covers the set
+    if (dt == LYC_BF16 ? launch_bneck4_group<__bf16>(ga, (hipStream_t)stream) : launch_bneck4_group<_Float16>(ga, (hipStream_t)stream)) return check_launch(who);
+  }
   const bool ok = dt == LYC_BF16 ? launch_bneck_group<__bf16>(ga, (hipStream_t)stream) : launch_bneck_group<_Float16>(ga, (hipStream_t)stream);
   if (!ok) return fail(LYC_ERR_UNSUPPORTED, "%s: this shape class has no grouped instantiation (r > 32, K >= 8192 at M < 8192, unequal shapes)", who);
   return check_launch(who);
 }
 }  // namespace
 }  // extern "C++"
+
+int lyc_locon_linear_bwd_group_sum(const LycLoconLinearGroupItem* items, int n, int I, int O, int r, void* dx_sum, int dtype, void* stream) {
+  const char* who = "locon_linear_bwd_group_sum";
+  if (n < 2 || n > BNECK4_GROUP_MAX || !items || !dx_sum) return fail(LYC_ERR_ARG, "%s: 2 .. %d items and dx_sum", who, BNECK4_GROUP_MAX);
+  if (I < 1 || O < 1 || r < 1) return fail(LYC_ERR_ARG, "%s: bad dims", who);
+  const int dt = dtype & 0xff;
+  if ((dt != LYC_BF16 && dt != LYC_F16) || (dtype & ~0xff)) return fail(LYC_ERR_UNSUPPORTED, "%s: 16-bit activations, no dtype flags", who);
+  BneckGroupArgs ga{};
+  ga.n = n;
+  for (int k = 0; k < n; ++k) {
+    const LycLoconLinearGroupItem& it = items[k];
+    if (!it.in || !it.down || !it.up || !it.mid || it.M < 1) return fail(LYC_ERR_ARG, "%s: item %d: null pointer or empty", who, k);
+    BneckArgs& b = ga.p[k];  // dt = alpha * g up (kept for d_down), dx += dt down
+    b.A = it.in; b.lda = O; b.M = it.M; b.K1 = O; b.F1 = it.up; b.f1n = 1; b.f1k = r; b.R = r; b.mid = it.mid;
+    b.F2 = it.down; b.f2n = 1; b.f2k = I; b.N2 = I; b.out = dx_sum; b.ldo = I; b.out_f32 = 0; b.alpha1 = it.alpha; b.alpha2 = 1.0f;
+  }
+  const bool ok = dt == LYC_BF16 ? launch_bneck4_sum<__bf16>(ga, dx_sum, (hipStream_t)stream) : launch_bneck4_sum<_Float16>(ga, dx_sum, (hipStream_t)stream);
+  if (!ok) return fail(LYC_ERR_UNSUPPORTED, "%s: outside the LDS-DMA rank-r kernel (r <= 16, r %% 4 == 0, I %% 8 == 0, O %% 8 == 0, aligned, n tiles in the LDS)", who);
+  return check_launch(who);
+}
 
 int lyc_locon_linear_fwd_group(const LycLoconLinearGroupItem* items, int n, int I, int O, int r, int dtype, void* stream) {
   return locon_linear_group(items, n, I, O, r, dtype, stream, false);

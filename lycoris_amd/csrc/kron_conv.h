@@ -211,7 +211,7 @@ static_assert(sizeof(KronLrGroupArgs) <= 3840, "kernel arguments are limited to 
 //   d_w2b tile (16 ranks x 16 columns): A = w2a[q.., rank]  B = dW2[q.., col]     16 rows q per step
 // History (round 3, SDXL rank-16 step, 739 Linear layers): one thread per output element with a serial contraction loop: 2.0 ms;
 // a wave per row with 16 register accumulators + butterfly reductions: 1.25 ms (181 k waves of ~3 loop trips); this version: see
-// DESIGN.md 7.4.
+// HISTORY.md 7.4.
 constexpr int KLR_CA = 512;   // columns of dW2 per d_w2a work item
 constexpr int KLR_CB = 256;   // rows of dW2 per d_w2b work item
 __host__ __device__ inline long kron_lr_waves_a(int c, int d, int r, int taps) {

@@ -46,6 +46,11 @@ int dtype_code(at::ScalarType t) {
   }
 }
 
+// A/B and regression-test switch (torch.ops.lycoris_amd.locon_reg_staged): the rank-r launches stay on the register-staged kernel of
+// rounds 1-5 (LYC_BNECK_REG in the dtype argument of the C ABI) instead of the LDS-DMA kernel of round 6
+bool g_locon_reg = false;
+inline int lc(int code) { return g_locon_reg ? (code | LYC_BNECK_REG) : code; }
+
 void* stream_of(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 
 void check_rc(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed (code ", rc, "): ", lyc_last_error()); }
@@ -1670,7 +1675,7 @@ std::tuple<Tensor, Tensor> locon_linear_fwd(const Tensor& x, const Tensor& down,
   Tensor t = at::empty({M, r}, x.options().dtype(at::kFloat));
   Tensor y = at::empty({M, O}, x.options());
   check_rc(lyc_locon_linear_fwd(cptr(rows), cfp(fd), cfp(fu), mfp(t), mptr(y), M, (int)I, (int)O, (int)r, (float)alpha,
-                                dtype_code(x.scalar_type()), stream_of(x)), "lyc_locon_linear_fwd");
+                                lc(dtype_code(x.scalar_type())), stream_of(x)), "lyc_locon_linear_fwd");
   auto oshape = x.sizes().vec();
   oshape.back() = O;
   return {y.view(oshape), t};
@@ -1685,7 +1690,7 @@ Tensor locon_linear_bwd_into(const Tensor& g, const Tensor& x, const Tensor& dow
   Tensor dt = at::empty({M, r}, x.options().dtype(at::kFloat));
   Tensor dx = need_dx ? at::empty(rows.sizes(), f32_rows ? x.options().dtype(at::kFloat) : x.options()) : Tensor();
   check_rc(lyc_locon_linear_bwd(cptr(g2), cptr(rows), cfp(fd), cfp(fu), cfp(t), mfp(dt), mptr(dx), mfp(dd), mfp(du), M, (int)I,
-                                (int)O, (int)r, (float)alpha, dtype_code(x.scalar_type()) | (f32_rows ? LYC_F32_ROWS : 0), stream_of(x)),
+                                (int)O, (int)r, (float)alpha, lc(dtype_code(x.scalar_type())) | (f32_rows ? LYC_F32_ROWS : 0), stream_of(x)),
            "lyc_locon_linear_bwd");
   return need_dx ? shaped_like(dx, x) : Tensor();
 }
@@ -1703,7 +1708,7 @@ bool locon_linear_bwd_deferred(const Tensor& g, const Tensor& x, const Tensor& d
   Tensor dt = at::empty({M, r}, x.options().dtype(at::kFloat));
   Tensor dx = need_dx ? at::empty(rows.sizes(), x.options()) : Tensor();
   check_rc(lyc_locon_linear_bwd(cptr(g2), cptr(rows), cfp(fd), cfp(fu), cfp(t), mfp(dt), mptr(dx), nullptr, nullptr, M, (int)I,
-                                (int)O, (int)r, (float)alpha, code, stream_of(x)), "lyc_locon_linear_bwd(dx)");
+                                (int)O, (int)r, (float)alpha, lc(code), stream_of(x)), "lyc_locon_linear_bwd(dx)");
   park_deferred(DeferredLocon{g2, rows, t, dt, down, up, dd, du, M, (int)I, (int)O, (int)r, code, (float)alpha, stream_of(x),
                               x.device().index()});
   dx_out = need_dx ? shaped_like(dx, x) : Tensor();
@@ -1796,7 +1801,7 @@ std::vector<Tensor> locon_linear_group_fwd_ts(const Tensor& x, at::TensorList fa
     }
     for (size_t lo = 0; lo < n && grouped; lo += 4) {
       const int cnt = (int)std::min<size_t>(4, n - lo);
-      const int rc = lyc_locon_linear_fwd_group(items.data() + lo, cnt, (int)I, (int)O, (int)r, code, stream_of(x));
+      const int rc = lyc_locon_linear_fwd_group(items.data() + lo, cnt, (int)I, (int)O, (int)r, lc(code), stream_of(x));
       if (rc == LYC_ERR_UNSUPPORTED && lo == 0) grouped = false;  // nothing was launched: layer by layer below
       else check_rc(rc, "lyc_locon_linear_fwd_group");
     }
@@ -1884,10 +1889,27 @@ struct LoconLinearGroupFn : public torch::autograd::Function<LoconLinearGroupFn>
         fds[i] = f32c(DOWN(i));
         fus[i] = f32c(UP(i));
         dts[i] = at::empty({M, r}, x.options().dtype(at::kFloat));
-        dxs[i] = at::empty(rows.sizes(), x.options());
-        items[i] = LycLoconLinearGroupItem{cptr(g2[i]), cfp(fds[i]), cfp(fus[i]), mfp(dts[i]), mptr(dxs[i]), M, (float)alphas[i]};
+        items[i] = LycLoconLinearGroupItem{cptr(g2[i]), cfp(fds[i]), cfp(fus[i]), mfp(dts[i]), nullptr, M, (float)alphas[i]};
       }
-      const int rc = lyc_locon_linear_bwd_group(items.data(), (int)n, (int)I, (int)O, (int)r, code, stream_of(x));
+      // round 6: the shared input's gradient as ONE expand stage over the n `mid` tiles (bneck4_sum_kernel): no dx_i, no summation pass
+      bool summed = false;
+      if (nx) {
+        Tensor dx = at::empty(rows.sizes(), x.options());
+        const int rs = lyc_locon_linear_bwd_group_sum(items.data(), (int)n, (int)I, (int)O, (int)r, mptr(dx), lc(code), stream_of(x));
+        if (rs != LYC_ERR_UNSUPPORTED) {
+          check_rc(rs, "lyc_locon_linear_bwd_group_sum");
+          summed = true;
+          out[0] = shaped_like(dx, x);
+        }
+      }
+      int rc = LYC_OK;
+      if (!summed) {
+        for (size_t i = 0; i < n; ++i) {
+          dxs[i] = at::empty(rows.sizes(), x.options());
+          items[i].out = mptr(dxs[i]);
+        }
+        rc = lyc_locon_linear_bwd_group(items.data(), (int)n, (int)I, (int)O, (int)r, lc(code), stream_of(x));
+      }
       if (rc == LYC_ERR_UNSUPPORTED) {
         fast = false;  // nothing was launched
       } else {
@@ -1895,7 +1917,7 @@ struct LoconLinearGroupFn : public torch::autograd::Function<LoconLinearGroupFn>
         for (size_t i = 0; i < n; ++i)
           park_deferred(DeferredLocon{g2[i], rows, T_(i), dts[i], DOWN(i), UP(i), td[i].buf, tu[i].buf, M, (int)I, (int)O, (int)r, code,
                                       (float)alphas[i], stream_of(x), x.device().index()});
-        if (nx) {  // the shared input's gradient: the n results in ONE pass, fp32 accumulation, one more rounding
+        if (nx && !summed) {  // the shared input's gradient: the n results in ONE pass, fp32 accumulation, one more rounding
           const void* src[4] = {nullptr, nullptr, nullptr, nullptr};
           for (size_t i = 0; i < n; ++i) src[i] = cptr(dxs[i]);
           check_rc(lyc_sum_rows(src, (int)n, mptr(dxs[0]), dxs[0].numel(), code, stream_of(x)), "lyc_sum_rows");
@@ -3297,4 +3319,5 @@ PYBIND11_MODULE(_lyc_torch, m) {
     return n;
   });
   m.def("abi_version", []() { return lyc_abi_version(); });
+  m.def("locon_reg_staged", [](bool on) { const bool was = g_locon_reg; g_locon_reg = on; return was; });
 }

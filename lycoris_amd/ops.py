@@ -77,6 +77,14 @@ def fused_grad_accumulation(enabled: bool = True, callback=None, batch_callback=
         _DISPATCH["ext"].set_accum(bool(enabled), callback, _ACCUM["batch_callback"])
 
 
+def locon_reg_staged(enabled: bool = True) -> bool:
+    """A/B and regression-test switch: keep the rank-r (LoCon) reduce / expand launches on the register-staged kernel of rounds 1-5
+    (csrc/lowrank.h: bneck_kernel) instead of the LDS-DMA kernel of round 6 (csrc/lowrank4.h: bneck4_kernel, and the fused sibling
+    sum bneck4_sum_kernel).  Returns the previous setting.  `LYC_BNECK_REG` in the dtype argument of the C ABI."""
+    _cpp()
+    return bool(_DISPATCH["ext"].locon_reg_staged(bool(enabled)))
+
+
 def fused_reports(param) -> bool:
     """True when the kernels themselves report `param` to the fused-accumulation callback in the running backward pass (its
     autograd post-accumulate hook, which fires on the undefined gradient the backward node returned, must then stay silent)."""
