@@ -28,11 +28,12 @@ int main(int argc, char** argv) {
          lyc_lokr_conv2d_planes_ok(B, H, H, G, G, c, d, 3, 3, 1, 1, 1, 1, 1, 1, LYC_BF16, 1));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const bool timing = getenv("KT_TIME") != nullptr;
+  const int DT = LYC_BF16 | (getenv("KT_W4") ? LYC_KCONV_W4 : 0);  // KT_W4=1: the 4-wave workgroups of rounds 3 - 5
   for (int rep = 0; rep < (timing ? 103 : 3); ++rep) {
     if (timing && rep == 3) CK(hipEventRecord(e0, 0));
     int rc;
-    if (!bwd) rc = lyc_lokr_conv2d_fwd_planes(x, w1, pf, y, B, H, H, G, G, c, d, 3, 3, 1, 1, 1, 1, 1, 1, 1.0f, LYC_BF16, nullptr);
-    else rc = lyc_lokr_conv2d_bwd_planes(g, x, w1, nullptr, pb, dx, dw1, nullptr, ws, B, H, H, G, G, c, d, 3, 3, 1, 1, 1, 1, 1, 1, 1.0f, LYC_BF16 | LYC_DEFER_WGRAD, nullptr);
+    if (!bwd) rc = lyc_lokr_conv2d_fwd_planes(x, w1, pf, y, B, H, H, G, G, c, d, 3, 3, 1, 1, 1, 1, 1, 1, 1.0f, DT, nullptr);
+    else rc = lyc_lokr_conv2d_bwd_planes(g, x, w1, nullptr, pb, dx, dw1, nullptr, ws, B, H, H, G, G, c, d, 3, 3, 1, 1, 1, 1, 1, 1, 1.0f, DT | LYC_DEFER_WGRAD, nullptr);
     if (rc) { fprintf(stderr, "%s\n", lyc_last_error()); return 1; }
     if (!timing) {
       CK(hipDeviceSynchronize());

@@ -41,7 +41,10 @@ enum { LYC_F32_ROWS = 0x100, LYC_DEFER_WGRAD = 0x200,
        /* the rank-r (LoCon) entry points, round 6: keep the reduce / expand launch on the register-staged kernel of rounds 1-5
         * (bneck_kernel, lowrank.h) instead of the LDS-DMA kernel (bneck4_kernel, lowrank4.h) where both cover the problem -- the
         * A/B and regression-test switch (an argument, not getenv) */
-       LYC_BNECK_REG = 0x20000 };
+       LYC_BNECK_REG = 0x20000,
+       /* the *_planes Conv2d entry points of LoKr, round 6: run the patch kernel with the 4-wave workgroups of rounds 3 - 5 instead of
+        * 8 waves (two per SIMD) -- the A/B and regression-test switch */
+       LYC_KCONV_W4 = 0x40000 };
 /* The *_planes Conv2d entry points and lyc_lokr_conv2d_planes_ok / _dx_blocks: pin the patch kernel's row tile (mi = 2, 4 or 8: 64 * mi
  * stage-1 rows per workgroup) instead of letting the host plan it -- for tests, which otherwise reach only the smallest tile with
  * their small problems (rounds 2-3 read an environment variable for this). */

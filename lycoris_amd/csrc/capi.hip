@@ -1723,28 +1723,34 @@ bool plan_kconv(const KronArgs& ka, int64_t B, KconvGeom& gm, int& mi, int& ni, 
   return true;
 }
 
-template <typename T, int MI, int NI, bool DW1>
-void launch_kconv_inst(const KconvArgs& ca, dim3 grid, int lds, hipStream_t st) {
+template <typename T, int MI, int NI, bool DW1, int NW>
+void launch_kconv_nw(const KconvArgs& ca, dim3 grid, int lds, hipStream_t st) {
   static bool attr_set = false;  // dynamic LDS above 64 KiB needs the opt-in (per instantiation)
   if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kconv_kernel<T, MI, NI, DW1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kconv_kernel<T, MI, NI, DW1, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((kconv_kernel<T, MI, NI, DW1>), grid, dim3(NTHREADS), lds, st, ca);
+  hipLaunchKernelGGL((kconv_kernel<T, MI, NI, DW1, NW>), grid, dim3(NW * 64), lds, st, ca);
+}
+// w4: the 4-wave workgroups of rounds 3 - 5 (LYC_KCONV_W4 in the call's dtype argument: A/B and regression tests); default: 8 waves
+template <typename T, int MI, int NI, bool DW1>
+void launch_kconv_inst(const KconvArgs& ca, dim3 grid, int lds, hipStream_t st, bool w4) {
+  if (w4) launch_kconv_nw<T, MI, NI, DW1, 4>(ca, grid, lds, st);
+  else launch_kconv_nw<T, MI, NI, DW1, 8>(ca, grid, lds, st);
 }
 template <typename T, int MI, bool DW1>
-void launch_kconv_ni(int ni, const KconvArgs& ca, dim3 grid, int lds, hipStream_t st) {
+void launch_kconv_ni(int ni, const KconvArgs& ca, dim3 grid, int lds, hipStream_t st, bool w4) {
   switch (ni) {
-    case 2: launch_kconv_inst<T, MI, 2, DW1>(ca, grid, lds, st); break;
-    case 3: launch_kconv_inst<T, MI, 3, DW1>(ca, grid, lds, st); break;
-    default: launch_kconv_inst<T, MI, 4, DW1>(ca, grid, lds, st); break;
+    case 2: launch_kconv_inst<T, MI, 2, DW1>(ca, grid, lds, st, w4); break;
+    case 3: launch_kconv_inst<T, MI, 3, DW1>(ca, grid, lds, st, w4); break;
+    default: launch_kconv_inst<T, MI, 4, DW1>(ca, grid, lds, st, w4); break;
   }
 }
 
 // returns the number of workgroups, or -1 when the problem is not plannable
 template <typename T>
-long launch_kconv(const KronArgs& ka, const void* planes, int64_t B, hipStream_t st, int pin_mi) {
+long launch_kconv(const KronArgs& ka, const void* planes, int64_t B, hipStream_t st, int pin_mi, bool w4 = false) {
   KconvArgs ca{};
   int mi = 0, ni = 0, ksteps = 0;
   if (!plan_kconv(ka, B, ca.gm, mi, ni, ksteps, pin_mi)) return -1;
@@ -1754,10 +1760,13 @@ long launch_kconv(const KronArgs& ka, const void* planes, int64_t B, hipStream_t
   dim3 grid((unsigned)(B * ca.gm.tiles_h * ca.gm.tiles_w), (unsigned)cdiv(ka.N, 16 * ni));
   const int lds = kconv_lds_bytes(ni, ca.gm);
   const bool dw1 = ka.dw1 != nullptr || ka.dw1_ws != nullptr;
+  // 8 waves (two per SIMD) by default: -10 % on the 1280-channel layers, -11 % on the 320-channel backward; the 256-row x 48-column
+  // tile of the 640-channel layers (8 x 1 split, two row tiles per wave) measured 3 % slower and keeps 4 (profiles/r06_c37_kconv_waves.log)
+  if (mi == 4 && ni == 3) w4 = true;
   switch (mi) {
-    case 8: dw1 ? launch_kconv_ni<T, 8, true>(ni, ca, grid, lds, st) : launch_kconv_ni<T, 8, false>(ni, ca, grid, lds, st); break;
-    case 4: dw1 ? launch_kconv_ni<T, 4, true>(ni, ca, grid, lds, st) : launch_kconv_ni<T, 4, false>(ni, ca, grid, lds, st); break;
-    default: dw1 ? launch_kconv_ni<T, 2, true>(ni, ca, grid, lds, st) : launch_kconv_ni<T, 2, false>(ni, ca, grid, lds, st); break;
+    case 8: dw1 ? launch_kconv_ni<T, 8, true>(ni, ca, grid, lds, st, w4) : launch_kconv_ni<T, 8, false>(ni, ca, grid, lds, st, w4); break;
+    case 4: dw1 ? launch_kconv_ni<T, 4, true>(ni, ca, grid, lds, st, w4) : launch_kconv_ni<T, 4, false>(ni, ca, grid, lds, st, w4); break;
+    default: dw1 ? launch_kconv_ni<T, 2, true>(ni, ca, grid, lds, st, w4) : launch_kconv_ni<T, 2, false>(ni, ca, grid, lds, st, w4); break;
   }
   return (long)grid.x * grid.y;
 }
@@ -1825,8 +1834,8 @@ int lyc_lokr_conv2d_fwd_planes(const void* x_rows, const float* w1, const void* 
   ka.M = B * cd.Ho * cd.Wo; ka.Gin = b; ka.K = d; ka.Gout = a; ka.N = c;
   ka.s1o = b; ka.s1i = 1; ka.alpha = alpha;
   ka.gat = make_gather(1, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
-  const long n = (dtype & 0xff) == LYC_BF16 ? launch_kconv<__bf16>(ka, planes_fwd, B, (hipStream_t)stream, kconv_pin(dtype))
-                                            : launch_kconv<_Float16>(ka, planes_fwd, B, (hipStream_t)stream, kconv_pin(dtype));
+  const long n = (dtype & 0xff) == LYC_BF16 ? launch_kconv<__bf16>(ka, planes_fwd, B, (hipStream_t)stream, kconv_pin(dtype), (dtype & LYC_KCONV_W4) != 0)
+                                            : launch_kconv<_Float16>(ka, planes_fwd, B, (hipStream_t)stream, kconv_pin(dtype), (dtype & LYC_KCONV_W4) != 0);
   if (n < 0) return fail(LYC_ERR_UNSUPPORTED, "lokr_conv2d_fwd_planes: geometry outside the patch kernel (see lyc_lokr_conv2d_planes_ok)");
   return check_launch("lokr_conv2d_fwd_planes");
 }
@@ -1872,7 +1881,7 @@ int lokr_conv2d_bwd_impl(const void* g_rows, const void* x_rows, const float* w1
     ka.gat = make_gather(2, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
     long nblk = -1;
     if (planes_bwd) {  // LDS source patch + pre-packed operand planes (kron_conv.h)
-      nblk = bf ? launch_kconv<__bf16>(ka, planes_bwd, B, st, kconv_pin(dtype)) : launch_kconv<_Float16>(ka, planes_bwd, B, st, kconv_pin(dtype));
+      nblk = bf ? launch_kconv<__bf16>(ka, planes_bwd, B, st, kconv_pin(dtype), (dtype & LYC_KCONV_W4) != 0) : launch_kconv<_Float16>(ka, planes_bwd, B, st, kconv_pin(dtype), (dtype & LYC_KCONV_W4) != 0);
       if (nblk < 0 && !w2p)
         return fail(LYC_ERR_UNSUPPORTED, "lokr_conv2d_bwd_planes: geometry outside the patch kernel (see lyc_lokr_conv2d_planes_ok)");
     }

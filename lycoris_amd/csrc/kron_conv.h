@@ -339,14 +339,15 @@ constexpr int KC_ZERO_BYTES = 16;  // a 16-byte slot of zeros behind the patch (
 __host__ __device__ inline int kconv_stage_bytes(int NI, int kss) { return NI * kss * 2048; }
 __host__ __device__ inline int kconv_lds_bytes(int NI, const KconvGeom& gm) {
   const int ring = 2 * kconv_stage_bytes(NI, gm.kss);
-  return gm.patch_bytes + 1024 + (ring > 4096 ? ring : 4096);
+  return gm.patch_bytes + 1024 + (ring > 8192 ? ring : 8192);  // (the dW1 reduction scratch of 8 waves: 8 KiB)
 }
 
 // kron3.h's register epilogue for a caller that supplies the row bookkeeping: stage 2 on the matrix cores, optional fused
 // `base + delta`, optional dW1 partial (per-workgroup block of a.dw1_ws, or atomics).
 //   row_ok[mi], rofs[mi]: validity and element offset (into y / xref / base) of this lane's output row 16 mi + li of the wave
 //   (MI 16-row tiles per wave: the workgroup owns 64 MI stage-1 rows)
-template <typename T, int MI, int NI, bool WITH_DW1>
+//   NW: waves of the workgroup (the dW1 partial sums over all of them; red_smem holds NW KiB)
+template <typename T, int MI, int NI, bool WITH_DW1, int NW = NWAVES>
 __device__ __forceinline__ void k3_epilogue_rows(const KronArgs& a, char* red_smem, f32x4 (&acc)[MI][NI], const float (&w1raw)[4],
                                                  const bool (&row_ok)[MI], const long (&rofs)[MI], long n0, long wg_index) {
   using F4 = typename Mma16<T>::frag;
@@ -433,7 +434,8 @@ __device__ __forceinline__ void k3_epilogue_rows(const KronArgs& a, char* red_sm
       float s = 0.f;
       for (int b = 0; b < (16 >> lg); ++b) {
         const int e = ((b << lg) + u) * 16 + (b << lg) + po;
-        s += red[e] + red[256 + e] + red[512 + e] + red[768 + e];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += red[256 * w + e];
       }
       const long e = (long)po * a.s1o + (long)u * a.s1i;
       if (a.dw1_ws != nullptr)
@@ -451,13 +453,22 @@ struct KconvArgs {
   int ksteps;          // k steps of 32 over the flat (tap, k) index
 };
 
-template <typename T, int MI, int NI, bool WITH_DW1>
-__global__ __launch_bounds__(NTHREADS, (MI * NI <= 24) ? 2 : 1) void kconv_kernel(KconvArgs ca) {
+// NW = 4: rounds 3 - 5, every wave owns MI row tiles x all NI column tiles.  NW = 8 (round 6): a kconv workgroup is alone on its CU
+// (its patch takes 60 - 140 KiB of LDS), so with 4 waves every SIMD runs ONE wave whose fragment reads, MFMAs and operand DMAs follow
+// each other (profiles/r06_c26_ktrace_conv.log: 5 250 cycles per stage of 4 k steps for 1 024 cycles of MFMAs and 1 250 of LDS reads).
+// Two waves per SIMD overlap them: the 64 MI rows x 16 NI columns of the workgroup are split 4 x 2 over the waves (NI even: each wave
+// MI x NI / 2 tiles) or 8 x 1 (NI = 3: MI / 2 x NI).  Operand ring, patch and tile plan are unchanged.
+template <typename T, int MI, int NI, bool WITH_DW1, int NW = NWAVES>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && MI * NI <= 24) ? 2 : 1) void kconv_kernel(KconvArgs ca) {
+  constexpr int WN = (NW == 8 && NI % 2 == 0) ? 2 : 1;  // waves along the columns
+  constexpr int WM = NW / WN;                              // ... along the rows
+  constexpr int MW = MI * 4 / WM, NIW = NI / WN;           // row / column tiles of one wave
   extern __shared__ __attribute__((aligned(1024))) char kc_smem[];
   const KronArgs& a = ca.k;
   const KconvGeom& gm = ca.gm;
   using F8 = typename TT<T>::frag;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wm = wave % WM, wn = wave / WM;
   const int G = a.Gin, K = a.K, N = a.N;
   const int lg = 31 - __builtin_clz((unsigned)G);
   const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(NTHREADS, (MI * NI <= 24) ? 2 : 1) void kconv_kerne
   auto issue_stage = [&](int s, char* buf) {
     // NI * kss units of 2 KiB = 2 * NI * kss pieces of 1 KiB; piece p -> wave p % 4 (wave-uniform loop)
     const int npiece = 2 * NI * gm.kss;
-    for (int p = wave; p < npiece; p += NWAVES) {
+    for (int p = wave; p < npiece; p += NW) {
       const int unit = p >> 1, half = p & 1;
       const int ni = unit / gm.kss, kk = unit - ni * gm.kss;
       const int ks = s * gm.kss + kk;
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(NTHREADS, (MI * NI <= 24) ? 2 : 1) void kconv_kerne
     const float inv_spp = 1.0f / (float)spp, inv_spg = 1.0f / (float)spg, inv_pw = 1.0f / (float)gm.PW;
     const int OOR = 0x7ffffff0;
     const int npiece = gm.patch_bytes >> 10;
-    for (int pc = wave; pc < npiece; pc += NWAVES) {
+    for (int pc = wave; pc < npiece; pc += NW) {
       const int sl = pc * 64 + lane;  // slot index in the patch image
       int pp = (int)(((float)sl + 0.5f) * inv_spp);
       int q = sl - pp * spp;
@@ -570,12 +581,12 @@ __global__ __launch_bounds__(NTHREADS, (MI * NI <= 24) ? 2 : 1) void kconv_kerne
 
   LYC_STAMP(1);  // stage 0 of the ring and the whole patch requested
   // ---- this lane's two stage-1 rows: local pixel (ly, lx), group u; byte offset of (pixel, u) in the patch ----------------
-  int rowbase[MI];
-  bool row_ok[MI];
-  long rofs[MI];
+  int rowbase[MW];
+  bool row_ok[MW];
+  long rofs[MW];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int r = wave * (16 * MI) + mi * 16 + li;  // local stage-1 row
+  for (int mi = 0; mi < MW; ++mi) {
+    const int r = wm * (16 * MW) + mi * 16 + li;  // local stage-1 row
     const int lp = r >> lg, u = r & (G - 1);
     const int ly = lp / gm.TW, lx = lp - ly * gm.TW;
     rowbase[mi] = ((ly * gm.sy * gm.PW + lx * gm.sx) * gm.CP + u * gm.GP) * (int)sizeof(T);
@@ -585,11 +596,11 @@ __global__ __launch_bounds__(NTHREADS, (MI * NI <= 24) ? 2 : 1) void kconv_kerne
     rofs[mi] = dpix * ((long)G * N) + (long)u * N;
   }
 
-  f32x4 acc[MI][NI];
+  f32x4 acc[MW][NIW];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+  for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = zero4();
+    for (int ni = 0; ni < NIW; ++ni) acc[mi][ni] = zero4();
 
   const int Kflat = a.gat.taps * K;
   const float inv_k = 1.0f / (float)K;
@@ -612,24 +623,24 @@ __global__ __launch_bounds__(NTHREADS, (MI * NI <= 24) ? 2 : 1) void kconv_kerne
       if (v >= K) { v -= K; ++tap; }
       const bool kok = k < Kflat;
       const int toff = kc_tapoff[kok ? tap : 0] + v * (int)sizeof(T);
-      F8 af[MI];
+      F8 af[MW];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const F8*>(kc_smem + (kok ? rowbase[mi] + toff : zero_ofs));
-      F8 bh[NI], bl[NI];
+      for (int mi = 0; mi < MW; ++mi) af[mi] = *reinterpret_cast<const F8*>(kc_smem + (kok ? rowbase[mi] + toff : zero_ofs));
+      F8 bh[NIW], bl[NIW];
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const char* up = buf + (ni * kss_ + kk) * 2048 + lane * 16;
+      for (int ni = 0; ni < NIW; ++ni) {
+        const char* up = buf + ((wn * NIW + ni) * kss_ + kk) * 2048 + lane * 16;
         bh[ni] = *reinterpret_cast<const F8*>(up);
         bl[ni] = *reinterpret_cast<const F8*>(up + 1024);
       }
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+      for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT<T>::mma(af[mi], bh[ni], acc[mi][ni]);
+        for (int mi = 0; mi < MW; ++mi) acc[mi][ni] = TT<T>::mma(af[mi], bh[ni], acc[mi][ni]);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+      for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = TT<T>::mma(af[mi], bl[ni], acc[mi][ni]);
+        for (int mi = 0; mi < MW; ++mi) acc[mi][ni] = TT<T>::mma(af[mi], bl[ni], acc[mi][ni]);
     };
     // ONE code region updates the accumulators: four guarded steps (kss <= 4).  Two alternative regions (a straight-line body for
     // full stages, a loop for the rest) made the register allocator copy every AGPR accumulator at their join -- 318 / 478 / 638
@@ -643,7 +654,7 @@ __global__ __launch_bounds__(NTHREADS, (MI * NI <= 24) ? 2 : 1) void kconv_kerne
   }
   LYC_STAMP(28);
 
-  k3_epilogue_rows<T, MI, NI, WITH_DW1>(a, ring, acc, w1raw, row_ok, rofs, n0, (long)by * gridDim.x + bx);
+  k3_epilogue_rows<T, MW, NIW, WITH_DW1, NW>(a, ring, acc, w1raw, row_ok, rofs, n0 + 16 * (wn * NIW), (long)by * gridDim.x + bx);
   LYC_STAMP(29);
   LYC_TRACE_FLUSH();
 }

@@ -107,15 +107,17 @@ GEOMS = [
 ]
 
 
+@pytest.mark.parametrize("waves", [8, 4], ids=["w8", "w4"])
 @pytest.mark.parametrize("row_tile", [0, 4, 8], ids=["mi_auto", "mi4", "mi8"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("geom", GEOMS, ids=[f"B{g[0]}_{g[1]}x{g[2]}_a{g[3]}_c{g[4]}_d{g[5]}_k{g[6]}s{g[7]}p{g[8]}d{g[9]}" for g in GEOMS])
-def test_conv_planes_vs_oracle(geom, dtype, row_tile):
+def test_conv_planes_vs_oracle(geom, dtype, row_tile, waves):
     B, H, W, a, c, d, k, s, p, dl = geom
     lib = N.load()
     # LYC_KCONV_ROW_TILE(mi) in the dtype argument pins the patch kernel's row tile (64 * mi stage-1 rows per workgroup): the host
     # otherwise picks the smallest one for these small problems (include/lycoris_amd.h; an environment variable until round 3)
-    code = N.dtype_code(dtype) | (row_tile << 12)
+    # LYC_KCONV_W4: the 4-wave workgroups of rounds 3 - 5 (default since round 6: 8 waves, two per SIMD, where the plan pays)
+    code = N.dtype_code(dtype) | (row_tile << 12) | (0x40000 if waves == 4 else 0)
     taps = k * k
     Ho, Wo = (H + 2 * p - dl * (k - 1) - 1) // s + 1, (W + 2 * p - dl * (k - 1) - 1) // s + 1
     gen = torch.Generator().manual_seed(sum(geom))
