@@ -1271,7 +1271,7 @@ def roofline(insts, args, dtype, dev):
             out["conv"] = conv
         return out
     if lin[0].algo == "locon":
-        # production backward: the fused dx launch per layer (lyc::bneck_kernel, also writes dt) + the factor gradients of ALL
+        # production backward: the fused dx launch per layer (lyc::bneck4_kernel, also writes dt) + the factor gradients of ALL
         # layers in grouped launches (lyc::lowrank_tn_group_kernel, lyc_locon_wgrad_group: 18 layers per launch)
         import ctypes
         from lycoris_amd import _native as N
@@ -1288,7 +1288,7 @@ def roofline(insts, args, dtype, dev):
             assert N.load().lyc_locon_wgrad_deferrable(N.ptr(g), N.ptr(rows), rows.shape[0], I, O, r, code) == 1
             items[k] = N.LoconWgradItem(N.ptr(g), N.ptr(rows), N.ptr(ts_pre[k]), N.ptr(dts[k]), N.ptr(bufs[0]), N.ptr(bufs[1]),
                                         rows.shape[0], I, O, r, 1.0)
-        # launch units of the step (round 5): a layer, or a sibling set as ONE lyc::bneck_group_kernel launch each way
+        # launch units of the step (round 5): a layer, or a sibling set as ONE lyc::bneck4_group_kernel / bneck4_sum_kernel launch each way
         k_of = {id(cl[0]): k for k, cl in enumerate(calls)}
         units = []
         for k, (it, rows, g, fs, bufs) in enumerate(calls):
@@ -1325,10 +1325,16 @@ def roofline(insts, args, dtype, dev):
                 it, rows, g, fs, bufs = calls[u[0]]
                 r, I = fs[0].shape
                 O = fs[1].shape[0]
-                if len(u) > 1:  # the set's dx launches as one, the n results summed in one pass
-                    N.call("lyc_locon_linear_bwd_group", ctypes.cast(bw_items[u[0]], ctypes.c_void_p), len(u), I, O, r, code, N.stream_ptr(dev))
-                    srcs = (ctypes.c_void_p * len(u))(*[dxs[k].data_ptr() for k in u])
-                    N.call("lyc_sum_rows", ctypes.cast(srcs, ctypes.c_void_p), len(u), N.ptr(dxs[u[0]]), dxs[u[0]].numel(), code, N.stream_ptr(dev))
+                if len(u) > 1:  # the set's dx as ONE expand stage over its n mid tiles (round 6: lyc::bneck4_sum_kernel) where the plan covers
+                    # it; else the n dx launches as one + the one-pass sum (what torch_ops.cpp LoconLinearGroupFn::backward does)
+                    rc = N.load().lyc_locon_linear_bwd_group_sum(ctypes.cast(bw_items[u[0]], ctypes.c_void_p), len(u), I, O, r, N.ptr(dxs[u[0]]), code,
+                                                                 N.stream_ptr(dev))
+                    if rc == 2:  # LYC_ERR_UNSUPPORTED: nothing launched
+                        N.call("lyc_locon_linear_bwd_group", ctypes.cast(bw_items[u[0]], ctypes.c_void_p), len(u), I, O, r, code, N.stream_ptr(dev))
+                        srcs = (ctypes.c_void_p * len(u))(*[dxs[k].data_ptr() for k in u])
+                        N.call("lyc_sum_rows", ctypes.cast(srcs, ctypes.c_void_p), len(u), N.ptr(dxs[u[0]]), dxs[u[0]].numel(), code, N.stream_ptr(dev))
+                    else:
+                        assert rc == 0, N.load().lyc_last_error()
                 else:
                     k = u[0]
                     N.call("lyc_locon_linear_bwd", N.ptr(g), N.ptr(rows), N.ptr(fs[0]), N.ptr(fs[1]), N.ptr(ts_pre[k]), N.ptr(dts[k]),
@@ -1348,8 +1354,9 @@ def roofline(insts, args, dtype, dev):
         out["families_ms"] = {"bneck_forward": round(t_fwd, 3), "bneck_backward_dx": round(t_dx, 3), "lowrank_tn_grouped": round(t_wg, 3),
                               "backward_one_call_per_layer": round(t_bwd, 3)}
         n_launch = 2 * len(units)
-        out.update({"kernel": "lyc::bneck_kernel / lyc::bneck_group_kernel (LoCon forward + backward-dx launches of the Linear layers; a sibling "
-                              "set = one launch each way + a one-pass sum of its dx results); the factor gradients run grouped "
+        out.update({"kernel": "lyc::bneck4_kernel / lyc::bneck4_group_kernel / lyc::bneck4_sum_kernel (LoCon forward + backward-dx launches of the Linear "
+                              "layers, every operand by LDS-DMA into wave-private rings; a sibling set = one launch each way, its dx the SUM of the n "
+                              "results formed in registers); the factor gradients run grouped "
                               "(lyc::lowrank_tn_group_kernel, 18 layers per launch, re-reads g and x): families_ms",
                     "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "launches": n_launch,
                     "launches_note": f"{sum(1 for u in units if len(u) > 1)} sibling sets ({sum(len(u) for u in units if len(u) > 1)} layers) as one launch "
