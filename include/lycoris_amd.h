@@ -44,7 +44,10 @@ enum { LYC_F32_ROWS = 0x100, LYC_DEFER_WGRAD = 0x200,
        LYC_BNECK_REG = 0x20000,
        /* the *_planes Conv2d entry points of LoKr, round 6: run the patch kernel with the 4-wave workgroups of rounds 3 - 5 instead of
         * 8 waves (two per SIMD) -- the A/B and regression-test switch */
-       LYC_KCONV_W4 = 0x40000 };
+       LYC_KCONV_W4 = 0x40000,
+       /* same entry points, round 6: keep the k loop of the 8-wave patch kernel in its serial form (one basic block per k step) instead of
+        * the software-pipelined loop (next k step's fragments read before this one's MFMAs) -- the A/B and regression-test switch */
+       LYC_KCONV_SERIAL = 0x80000 };
 /* The *_planes Conv2d entry points and lyc_lokr_conv2d_planes_ok / _dx_blocks: pin the patch kernel's row tile (mi = 2, 4 or 8: 64 * mi
  * stage-1 rows per workgroup) instead of letting the host plan it -- for tests, which otherwise reach only the smallest tile with
  * their small problems (rounds 2-3 read an environment variable for this). */

@@ -1723,34 +1723,38 @@ bool plan_kconv(const KronArgs& ka, int64_t B, KconvGeom& gm, int& mi, int& ni, 
   return true;
 }
 
-template <typename T, int MI, int NI, bool DW1, int NW>
+template <typename T, int MI, int NI, bool DW1, int NW, bool PIPE = false>
 void launch_kconv_nw(const KconvArgs& ca, dim3 grid, int lds, hipStream_t st) {
   static bool attr_set = false;  // dynamic LDS above 64 KiB needs the opt-in (per instantiation)
   if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kconv_kernel<T, MI, NI, DW1, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kconv_kernel<T, MI, NI, DW1, NW, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((kconv_kernel<T, MI, NI, DW1, NW>), grid, dim3(NW * 64), lds, st, ca);
+  hipLaunchKernelGGL((kconv_kernel<T, MI, NI, DW1, NW, PIPE>), grid, dim3(NW * 64), lds, st, ca);
 }
-// w4: the 4-wave workgroups of rounds 3 - 5 (LYC_KCONV_W4 in the call's dtype argument: A/B and regression tests); default: 8 waves
+// w4: the 4-wave workgroups of rounds 3 - 5 (LYC_KCONV_W4 in the call's dtype argument: A/B and regression tests); default: 8 waves,
+// with the software-pipelined k loop where the plan has 4 k steps per ring stage (LYC_KCONV_SERIAL: the serial loop, A/B and tests)
 template <typename T, int MI, int NI, bool DW1>
-void launch_kconv_inst(const KconvArgs& ca, dim3 grid, int lds, hipStream_t st, bool w4) {
+void launch_kconv_inst(const KconvArgs& ca, dim3 grid, int lds, hipStream_t st, bool w4, bool serial) {
   if (w4) launch_kconv_nw<T, MI, NI, DW1, 4>(ca, grid, lds, st);
+  else if (!serial && ca.gm.kss == 4) launch_kconv_nw<T, MI, NI, DW1, 8, true>(ca, grid, lds, st);
   else launch_kconv_nw<T, MI, NI, DW1, 8>(ca, grid, lds, st);
 }
 template <typename T, int MI, bool DW1>
-void launch_kconv_ni(int ni, const KconvArgs& ca, dim3 grid, int lds, hipStream_t st, bool w4) {
+void launch_kconv_ni(int ni, const KconvArgs& ca, dim3 grid, int lds, hipStream_t st, bool w4, bool serial) {
   switch (ni) {
-    case 2: launch_kconv_inst<T, MI, 2, DW1>(ca, grid, lds, st, w4); break;
-    case 3: launch_kconv_inst<T, MI, 3, DW1>(ca, grid, lds, st, w4); break;
-    default: launch_kconv_inst<T, MI, 4, DW1>(ca, grid, lds, st, w4); break;
+    case 2: launch_kconv_inst<T, MI, 2, DW1>(ca, grid, lds, st, w4, serial); break;
+    case 3: launch_kconv_inst<T, MI, 3, DW1>(ca, grid, lds, st, w4, serial); break;
+    default: launch_kconv_inst<T, MI, 4, DW1>(ca, grid, lds, st, w4, serial); break;
   }
 }
 
 // returns the number of workgroups, or -1 when the problem is not plannable
 template <typename T>
-long launch_kconv(const KronArgs& ka, const void* planes, int64_t B, hipStream_t st, int pin_mi, bool w4 = false) {
+long launch_kconv(const KronArgs& ka, const void* planes, int64_t B, hipStream_t st, int pin_mi, int flags = 0) {
+  bool w4 = (flags & LYC_KCONV_W4) != 0;
+  const bool serial = (flags & LYC_KCONV_SERIAL) != 0;
   KconvArgs ca{};
   int mi = 0, ni = 0, ksteps = 0;
   if (!plan_kconv(ka, B, ca.gm, mi, ni, ksteps, pin_mi)) return -1;
@@ -1762,11 +1766,11 @@ long launch_kconv(const KronArgs& ka, const void* planes, int64_t B, hipStream_t
   const bool dw1 = ka.dw1 != nullptr || ka.dw1_ws != nullptr;
   // 8 waves (two per SIMD) by default: -10 % on the 1280-channel layers, -11 % on the 320-channel backward; the 256-row x 48-column
   // tile of the 640-channel layers (8 x 1 split, two row tiles per wave) measured 3 % slower and keeps 4 (profiles/r06_c37_kconv_waves.log)
-  if (mi == 4 && ni == 3) w4 = true;
+  if (mi == 4 && ni == 3 && (serial || ca.gm.kss != 4)) w4 = true;
   switch (mi) {
-    case 8: dw1 ? launch_kconv_ni<T, 8, true>(ni, ca, grid, lds, st, w4) : launch_kconv_ni<T, 8, false>(ni, ca, grid, lds, st, w4); break;
-    case 4: dw1 ? launch_kconv_ni<T, 4, true>(ni, ca, grid, lds, st, w4) : launch_kconv_ni<T, 4, false>(ni, ca, grid, lds, st, w4); break;
-    default: dw1 ? launch_kconv_ni<T, 2, true>(ni, ca, grid, lds, st, w4) : launch_kconv_ni<T, 2, false>(ni, ca, grid, lds, st, w4); break;
+    case 8: dw1 ? launch_kconv_ni<T, 8, true>(ni, ca, grid, lds, st, w4, serial) : launch_kconv_ni<T, 8, false>(ni, ca, grid, lds, st, w4, serial); break;
+    case 4: dw1 ? launch_kconv_ni<T, 4, true>(ni, ca, grid, lds, st, w4, serial) : launch_kconv_ni<T, 4, false>(ni, ca, grid, lds, st, w4, serial); break;
+    default: dw1 ? launch_kconv_ni<T, 2, true>(ni, ca, grid, lds, st, w4, serial) : launch_kconv_ni<T, 2, false>(ni, ca, grid, lds, st, w4, serial); break;
   }
   return (long)grid.x * grid.y;
 }
@@ -1834,8 +1838,8 @@ int lyc_lokr_conv2d_fwd_planes(const void* x_rows, const float* w1, const void* 
   ka.M = B * cd.Ho * cd.Wo; ka.Gin = b; ka.K = d; ka.Gout = a; ka.N = c;
   ka.s1o = b; ka.s1i = 1; ka.alpha = alpha;
   ka.gat = make_gather(1, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
-  const long n = (dtype & 0xff) == LYC_BF16 ? launch_kconv<__bf16>(ka, planes_fwd, B, (hipStream_t)stream, kconv_pin(dtype), (dtype & LYC_KCONV_W4) != 0)
-                                            : launch_kconv<_Float16>(ka, planes_fwd, B, (hipStream_t)stream, kconv_pin(dtype), (dtype & LYC_KCONV_W4) != 0);
+  const long n = (dtype & 0xff) == LYC_BF16 ? launch_kconv<__bf16>(ka, planes_fwd, B, (hipStream_t)stream, kconv_pin(dtype), dtype & (LYC_KCONV_W4 | LYC_KCONV_SERIAL))
+                                            : launch_kconv<_Float16>(ka, planes_fwd, B, (hipStream_t)stream, kconv_pin(dtype), dtype & (LYC_KCONV_W4 | LYC_KCONV_SERIAL));
   if (n < 0) return fail(LYC_ERR_UNSUPPORTED, "lokr_conv2d_fwd_planes: geometry outside the patch kernel (see lyc_lokr_conv2d_planes_ok)");
   return check_launch("lokr_conv2d_fwd_planes");
 }
@@ -1881,7 +1885,7 @@ int lokr_conv2d_bwd_impl(const void* g_rows, const void* x_rows, const float* w1
     ka.gat = make_gather(2, cd, H, W, kw, sh, sw, ph, pw, dh, dw, d);
     long nblk = -1;
     if (planes_bwd) {  // LDS source patch + pre-packed operand planes (kron_conv.h)
-      nblk = bf ? launch_kconv<__bf16>(ka, planes_bwd, B, st, kconv_pin(dtype), (dtype & LYC_KCONV_W4) != 0) : launch_kconv<_Float16>(ka, planes_bwd, B, st, kconv_pin(dtype), (dtype & LYC_KCONV_W4) != 0);
+      nblk = bf ? launch_kconv<__bf16>(ka, planes_bwd, B, st, kconv_pin(dtype), dtype & (LYC_KCONV_W4 | LYC_KCONV_SERIAL)) : launch_kconv<_Float16>(ka, planes_bwd, B, st, kconv_pin(dtype), dtype & (LYC_KCONV_W4 | LYC_KCONV_SERIAL));
       if (nblk < 0 && !w2p)
         return fail(LYC_ERR_UNSUPPORTED, "lokr_conv2d_bwd_planes: geometry outside the patch kernel (see lyc_lokr_conv2d_planes_ok)");
     }

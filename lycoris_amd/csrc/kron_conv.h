@@ -458,7 +458,17 @@ struct KconvArgs {
 // each other (profiles/r06_c26_ktrace_conv.log: 5 250 cycles per stage of 4 k steps for 1 024 cycles of MFMAs and 1 250 of LDS reads).
 // Two waves per SIMD overlap them: the 64 MI rows x 16 NI columns of the workgroup are split 4 x 2 over the waves (NI even: each wave
 // MI x NI / 2 tiles) or 8 x 1 (NI = 3: MI / 2 x NI).  Operand ring, patch and tile plan are unchanged.
-template <typename T, int MI, int NI, bool WITH_DW1, int NW = NWAVES>
+//
+// PIPE (round 6, second step; needs gm.kss == 4): the k loop as a software pipeline.  The loop above it (kept: PIPE = false, the
+// LYC_KCONV_SERIAL switch, and every plan with fewer than 4 k steps per stage) runs each k step as its own basic block -- tap-table
+// ds_read_b32 -> wait -> 6 fragment ds_read_b128 -> wait -> 8 MFMAs (`hipcc -S`: one s_waitcnt lgkmcnt(0) in front of every MFMA pair), a
+// dependent chain of ~550 cycles around 128 cycles of matrix-core issue, and every stage ends in a full drain (vmcnt(0) + barrier) before
+// the first read of the next one.  Here a stage is ONE straight-line region of four unguarded k steps: the fragments of k step i + 1 are
+// read (into a second register set) before the MFMAs of k step i issue, the tap offset is arithmetic (no LDS table on the chain), the
+// stage barrier sits in FRONT of the last k step's MFMAs (the next stage's first fragments are requested behind it, so the barrier
+// latency is covered by 8 MFMAs) and the operand DMA of stage s + 2 is issued there -- a whole stage before anybody waits for it.
+// K steps beyond the flat K run on a zero A fragment and a finite duplicate B unit.
+template <typename T, int MI, int NI, bool WITH_DW1, int NW = NWAVES, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && MI * NI <= 24) ? 2 : 1) void kconv_kernel(KconvArgs ca) {
   constexpr int WN = (NW == 8 && NI % 2 == 0) ? 2 : 1;  // waves along the columns
   constexpr int WM = NW / WN;                              // ... along the rows
@@ -495,6 +505,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && MI * NI <= 24) ? 2 : 1) void k
   const __amdgpu_buffer_rsrc_t rs_planes =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(planes), 0, (int)((long)ntiles_n * ca.ksteps * 2048), 0x00020000);
   auto issue_stage = [&](int s, char* buf) {
+    if constexpr (PIPE) {  // kss == 4: 8 NI pieces, 8 NI / NW per wave, fully unrolled; k steps past the end re-load the last unit
+      if (4 * s >= ca.ksteps) return;  // (wave-uniform)
+      constexpr int NPW = 8 * NI / NW;
+      static_assert(NPW * NW == 8 * NI, "pieces divide over the waves");
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) {
+        const int p = wave + i * NW;
+        const int unit = p >> 1, half = p & 1;
+        const int ni = unit >> 2, kk = unit & 3;
+        int ks = 4 * s + kk;
+        if (ks >= ca.ksteps) ks = ca.ksteps - 1;
+        long nt = n0 / 16 + ni;
+        if (nt >= ntiles_n) nt = ntiles_n - 1;
+        const unsigned off = (unsigned)(((nt * ca.ksteps + ks) * 2 + half) * 1024 + lane * 16);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_planes, (__attribute__((address_space(3))) void*)(buf + p * 1024), 16, (int)off, 0, 0, 0);
+      }
+      return;
+    }
     // NI * kss units of 2 KiB = 2 * NI * kss pieces of 1 KiB; piece p -> wave p % 4 (wave-uniform loop)
     const int npiece = 2 * NI * gm.kss;
     for (int p = wave; p < npiece; p += NW) {
@@ -579,6 +607,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && MI * NI <= 24) ? 2 : 1) void k
     }
   }
 
+  if constexpr (PIPE) issue_stage(1, ring + kconv_stage_bytes(NI, 4));  // (behind the patch: stage 1 is not needed before k step 3)
   LYC_STAMP(1);  // stage 0 of the ring and the whole patch requested
   // ---- this lane's two stage-1 rows: local pixel (ly, lx), group u; byte offset of (pixel, u) in the patch ----------------
   int rowbase[MW];
@@ -609,6 +638,72 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && MI * NI <= 24) ? 2 : 1) void k
   __syncthreads();  // patch, tap table, zero slot, stage 0
   LYC_STAMP(2);
 
+  if constexpr (PIPE) {
+    const int kh_ = a.gat.taps / a.gat.kw;
+    const int sgn = a.gat.mode == 1 ? 1 : -1;  // forward: tap (i, j) reads patch (py + i dh, px + j dw); backward: the flipped window
+    const int ci = sgn * a.gat.dh * gm.PW * gm.CP * (int)sizeof(T);
+    const int cj = sgn * a.gat.dw * gm.CP * (int)sizeof(T);
+    const int c0 = a.gat.mode == 1 ? 0 : ((kh_ - 1) * a.gat.dh * gm.PW + (a.gat.kw - 1) * a.gat.dw) * gm.CP * (int)sizeof(T);
+    const float inv_kw = 1.0f / (float)a.gat.kw;
+    // LDS byte offsets of this lane's A fragments of flat k step ksf
+    auto a_offsets = [&](int ksf, int (&ao)[MW]) {
+      const int k = 32 * ksf + 8 * g;
+      int tap = (int)(((float)k + 0.5f) * inv_k);
+      int v = k - tap * K;
+      if (v < 0) { v += K; --tap; }
+      if (v >= K) { v -= K; ++tap; }
+      const int ti = (int)(((float)tap + 0.5f) * inv_kw);  // tap <= 64: exact
+      const int tj = tap - ti * a.gat.kw;
+      const int toff = c0 + ti * ci + tj * cj + v * (int)sizeof(T);
+      const bool kok = k < Kflat;
+#pragma unroll
+      for (int mi = 0; mi < MW; ++mi) ao[mi] = kok ? rowbase[mi] + toff : zero_ofs;
+    };
+    F8 af[2][MW], bh[2][NIW], bl[2][NIW];
+    auto load_frags = [&](F8 (&fa)[MW], F8 (&fh)[NIW], F8 (&fl)[NIW], const char* buf, int kk, const int (&ao)[MW]) {
+#pragma unroll
+      for (int mi = 0; mi < MW; ++mi) fa[mi] = *reinterpret_cast<const F8*>(kc_smem + ao[mi]);
+#pragma unroll
+      for (int ni = 0; ni < NIW; ++ni) {
+        const char* up = buf + ((wn * NIW + ni) * 4 + kk) * 2048 + lane * 16;
+        fh[ni] = *reinterpret_cast<const F8*>(up);
+        fl[ni] = *reinterpret_cast<const F8*>(up + 1024);
+      }
+    };
+    auto mfmas = [&](const F8 (&fa)[MW], const F8 (&fh)[NIW], const F8 (&fl)[NIW]) {
+#pragma unroll
+      for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) acc[mi][ni] = TT<T>::mma(fa[mi], fh[ni], acc[mi][ni]);
+#pragma unroll
+      for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) acc[mi][ni] = TT<T>::mma(fa[mi], fl[ni], acc[mi][ni]);
+    };
+    int ao[MW];
+    a_offsets(0, ao);
+    load_frags(af[0], bh[0], bl[0], ring, 0, ao);
+    for (int s = 0; s < nstage; ++s) {
+      char* buf = ring + (s & 1) * stage_bytes;
+      const char* nbuf = ring + ((s + 1) & 1) * stage_bytes;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        a_offsets(4 * s + kk + 1, ao);
+        if (kk < 3) {
+          load_frags(af[nxt], bh[nxt], bl[nxt], buf, kk + 1, ao);
+        } else {
+          // stage boundary: this wave's reads of `buf` have returned and its share of stage s + 1 has landed; behind the barrier
+          // everybody's has, and `buf` is free for stage s + 2
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          issue_stage(s + 2, buf);
+          load_frags(af[nxt], bh[nxt], bl[nxt], nbuf, 0, ao);  // (behind the last stage: never consumed)
+        }
+        mfmas(af[cur], bh[cur], bl[cur]);
+      }
+      if (s < 17) LYC_STAMP(3 + s);
+    }
+  } else
   for (int s = 0; s < nstage; ++s) {
     char* buf = ring + (s & 1) * stage_bytes;
     if (s + 1 < nstage) issue_stage(s + 1, ring + ((s + 1) & 1) * stage_bytes);
