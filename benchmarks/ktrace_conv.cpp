@@ -1,4 +1,5 @@
-// ktrace_conv.cpp -- phase timeline of workgroup 0 of kconv_kernel (development tool; built with -DLYC_TRACE).
+// ktrace_conv.cpp -- phase timeline of workgroup 0 of kconv_kernel (development tool; built with -DLYC_TRACE), or -- built without it as
+// benchmarks/kcbench, KT_TIME=1 -- the plain launch time of the library's patch kernel.
 //   benchmarks/ktrace_conv B C H O [bwd]        (3x3, stride 1, pad 1, bf16, factor 8)
 // Includes the library's translation unit so that the production host plans (plan_kconv) drive the launch.
 #include "../lycoris_amd/csrc/capi.hip"
@@ -12,6 +13,7 @@ int main(int argc, char** argv) {
   const int C = argc > 2 ? atoi(argv[2]) : 320, H = argc > 3 ? atoi(argv[3]) : 128, O = argc > 4 ? atoi(argv[4]) : 320;
   const bool bwd = argc > 5 && !strcmp(argv[5], "bwd");
   const int G = 8, c = O / G, d = C / G, taps = 9;
+  if (getenv("KT_RAND")) srand(1);
   void *x, *y, *g, *dx, *pf, *pb, *ws; float *w1, *w2, *dw1;
   const size_t nx = (size_t)B * H * H * C * 2, ny = (size_t)B * H * H * O * 2;
   CK(hipMalloc(&x, nx)); CK(hipMalloc(&dx, nx)); CK(hipMalloc(&y, ny)); CK(hipMalloc(&g, ny));
@@ -28,13 +30,15 @@ int main(int argc, char** argv) {
          lyc_lokr_conv2d_planes_ok(B, H, H, G, G, c, d, 3, 3, 1, 1, 1, 1, 1, 1, LYC_BF16, 1));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const bool timing = getenv("KT_TIME") != nullptr;
-  const int DT = LYC_BF16 | (getenv("KT_W4") ? LYC_KCONV_W4 : 0);  // KT_W4=1: the 4-wave workgroups of rounds 3 - 5
+  // KT_W4=1: the 4-wave workgroups of rounds 3 - 5; KT_SERIAL=1: 8 waves, serial k loop; KT_MI=2/4/8: pin the row tile
+  const int DT = LYC_BF16 | (getenv("KT_W4") ? LYC_KCONV_W4 : 0) | (getenv("KT_SERIAL") ? LYC_KCONV_SERIAL : 0) | (getenv("KT_MI") ? LYC_KCONV_ROW_TILE(atoi(getenv("KT_MI"))) : 0);
   for (int rep = 0; rep < (timing ? 103 : 3); ++rep) {
     if (timing && rep == 3) CK(hipEventRecord(e0, 0));
     int rc;
     if (!bwd) rc = lyc_lokr_conv2d_fwd_planes(x, w1, pf, y, B, H, H, G, G, c, d, 3, 3, 1, 1, 1, 1, 1, 1, 1.0f, DT, nullptr);
     else rc = lyc_lokr_conv2d_bwd_planes(g, x, w1, nullptr, pb, dx, dw1, nullptr, ws, B, H, H, G, G, c, d, 3, 3, 1, 1, 1, 1, 1, 1, 1.0f, DT | LYC_DEFER_WGRAD, nullptr);
     if (rc) { fprintf(stderr, "%s\n", lyc_last_error()); return 1; }
+#ifdef LYC_TRACE
     if (!timing) {
       CK(hipDeviceSynchronize());
       unsigned long long t[32];
@@ -43,6 +47,7 @@ int main(int argc, char** argv) {
       for (int i = 0; i < 32; ++i) if (t[i]) printf(" [%d]+%llu", i, t[i] - t[0]);
       printf("\n");
     }
+#endif
   }
   if (timing) {
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));

@@ -245,7 +245,7 @@ __device__ __forceinline__ void gemm16d_body(const Gemm16Prob& p, int out_f32, c
   //     read half 0 (ks + 1)        | MFMA half 1 (ks)  + the refill of slot ks with step ks + D, one DMA behind every STRIDE-th MFMA
   //
   // so the LDS pipe (a 128 x 128 step reads 64 KiB = 512 cycles at 128 B / clk) and the matrix pipe (32 MFMAs per wave = 512 cycles)
-  // run side by side instead of one after the other.  Measured history (profiles/r06_c2 / c3_g16bench.log): all refills of a step
+  // run side by side instead of one after the other.  Measured history (profiles/r06_c2_g16bench_first_version.log, r06_c4_g16bench_two_phase_pipeline.log): all refills of a step
   // issued up front, reads, then MFMAs: ~1270 cycles per K step; refills interleaved: the same (the LDS reads were the exposed part).
   // The refill is UNCONDITIONAL (beyond K it fetches zeros / dead rows), so "all but the newest D - 2 groups have landed" is one
   // counted wait, the same in every step.

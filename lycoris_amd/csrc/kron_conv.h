@@ -455,7 +455,7 @@ struct KconvArgs {
 
 // NW = 4: rounds 3 - 5, every wave owns MI row tiles x all NI column tiles.  NW = 8 (round 6): a kconv workgroup is alone on its CU
 // (its patch takes 60 - 140 KiB of LDS), so with 4 waves every SIMD runs ONE wave whose fragment reads, MFMAs and operand DMAs follow
-// each other (profiles/r06_c26_ktrace_conv.log: 5 250 cycles per stage of 4 k steps for 1 024 cycles of MFMAs and 1 250 of LDS reads).
+// each other (profiles/r06_c37_kconv_waves.log: 5 250 cycles per stage of 4 k steps for 1 024 cycles of MFMAs and 1 250 of LDS reads).
 // Two waves per SIMD overlap them: the 64 MI rows x 16 NI columns of the workgroup are split 4 x 2 over the waves (NI even: each wave
 // MI x NI / 2 tiles) or 8 x 1 (NI = 3: MI / 2 x NI).  Operand ring, patch and tile plan are unchanged.
 //
@@ -699,7 +699,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && MI * NI <= 24) ? 2 : 1) void k
           issue_stage(s + 2, buf);
           load_frags(af[nxt], bh[nxt], bl[nxt], nbuf, 0, ao);  // (behind the last stage: never consumed)
         }
+        // (without the fences the machine scheduler sinks every fragment read to its first use again -- `hipcc -S`: 76 VGPRs, one
+        // s_waitcnt lgkmcnt(0..1) in front of every MFMA pair -- i.e. it undoes the pipeline to save the second register set)
+        __builtin_amdgcn_sched_barrier(0);
         mfmas(af[cur], bh[cur], bl[cur]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (s < 17) LYC_STAMP(3 + s);
     }

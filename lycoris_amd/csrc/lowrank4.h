@@ -5,7 +5,7 @@
 //
 // The math, the tile ownership (a workgroup = 16 MI rows x one slice of the output columns, every slice repeats stage 1) and
 // the accumulator layouts are bneck_kernel's (lowrank.h; reference: lycoris/functional/locon.py:64-85, modules/locon.py:286-332).
-// What changed is how the operands travel (profiles/r06_c26_ktrace_bneck.log: a bneck workgroup of the 1024 x 1280 -> 1280
+// What changed is how the operands travel (shader-clock stamps of benchmarks/lctrace, round 6 call 26: a bneck workgroup of the 1024 x 1280 -> 1280
 // layer lives 5.7 us, 4.0 of them in stage 1 with THREE 6 KiB steps in flight per wave, 1.35 in a stage 2 of five serial
 // tiles per wave):
 //
@@ -54,7 +54,7 @@ __host__ __device__ inline int bneck4_lds_bytes(int NW, int MI, int D, int D2, i
   return NW * (D * (MI + 2) * 1024 + nsum * D2 * 2048) + NW * MI * 1024 + nsum * MI * 2048;
 }
 
-// Host-side tile plan (capi.hip, benchmarks/lcbench.cpp).  Measured on the SDXL / SD1.5 shapes (profiles/r06_c3x_lcbench_*.log):
+// Host-side tile plan (capi.hip, benchmarks/lcbench.cpp).  Measured on the SDXL / SD1.5 shapes (profiles/r06_c30_lcbench_library_plan.log, r06_c34_lcbench_sibling_sum.log):
 //   * 8 waves of 16 rows below 8192 rows (one wave's DMA issue overlaps another wave's fragment reads and MFMAs: 7.5 -> 6.3 us on the
 //     1024 x 1280 -> 1280 layer), 4 waves of 32 rows above (many row tiles: the factor traffic per row halves);
 //   * as many column slices as keep the grid within one round of 256 workgroups, and at least as many as make a wave's share of the

@@ -107,7 +107,7 @@ GEOMS = [
 ]
 
 
-@pytest.mark.parametrize("waves", [8, 4], ids=["w8", "w4"])
+@pytest.mark.parametrize("waves", [8, 80, 4], ids=["w8", "w8serial", "w4"])
 @pytest.mark.parametrize("row_tile", [0, 4, 8], ids=["mi_auto", "mi4", "mi8"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("geom", GEOMS, ids=[f"B{g[0]}_{g[1]}x{g[2]}_a{g[3]}_c{g[4]}_d{g[5]}_k{g[6]}s{g[7]}p{g[8]}d{g[9]}" for g in GEOMS])
@@ -117,7 +117,8 @@ def test_conv_planes_vs_oracle(geom, dtype, row_tile, waves):
     # LYC_KCONV_ROW_TILE(mi) in the dtype argument pins the patch kernel's row tile (64 * mi stage-1 rows per workgroup): the host
     # otherwise picks the smallest one for these small problems (include/lycoris_amd.h; an environment variable until round 3)
     # LYC_KCONV_W4: the 4-wave workgroups of rounds 3 - 5 (default since round 6: 8 waves, two per SIMD, where the plan pays)
-    code = N.dtype_code(dtype) | (row_tile << 12) | (0x40000 if waves == 4 else 0)
+    # LYC_KCONV_SERIAL: the 8-wave kernel with the serial k loop (default: the software-pipelined loop where the plan has 4 k steps per stage)
+    code = N.dtype_code(dtype) | (row_tile << 12) | {8: 0, 80: 0x80000, 4: 0x40000}[waves]
     taps = k * k
     Ho, Wo = (H + 2 * p - dl * (k - 1) - 1) // s + 1, (W + 2 * p - dl * (k - 1) - 1) // s + 1
     gen = torch.Generator().manual_seed(sum(geom))
