@@ -1738,7 +1738,7 @@ void launch_kconv_nw(const KconvArgs& ca, dim3 grid, int lds, hipStream_t st) {
 template <typename T, int MI, int NI, bool DW1>
 void launch_kconv_inst(const KconvArgs& ca, dim3 grid, int lds, hipStream_t st, bool w4, bool serial) {
   if (w4) launch_kconv_nw<T, MI, NI, DW1, 4>(ca, grid, lds, st);
-  else if (!serial && ca.gm.kss == 4) launch_kconv_nw<T, MI, NI, DW1, 8, true>(ca, grid, lds, st);
+  else if (!serial && ca.gm.kss == 4 && ca.k.K >= 32) launch_kconv_nw<T, MI, NI, DW1, 8, true>(ca, grid, lds, st);
   else launch_kconv_nw<T, MI, NI, DW1, 8>(ca, grid, lds, st);
 }
 template <typename T, int MI, bool DW1>
@@ -1766,7 +1766,7 @@ long launch_kconv(const KronArgs& ka, const void* planes, int64_t B, hipStream_t
   const bool dw1 = ka.dw1 != nullptr || ka.dw1_ws != nullptr;
   // 8 waves (two per SIMD) by default: -10 % on the 1280-channel layers, -11 % on the 320-channel backward; the 256-row x 48-column
   // tile of the 640-channel layers (8 x 1 split, two row tiles per wave) measured 3 % slower and keeps 4 (profiles/r06_c37_kconv_waves.log)
-  if (mi == 4 && ni == 3 && (serial || ca.gm.kss != 4)) w4 = true;
+  if (mi == 4 && ni == 3 && (serial || ca.gm.kss != 4 || ka.K < 32)) w4 = true;
   switch (mi) {
     case 8: dw1 ? launch_kconv_ni<T, 8, true>(ni, ca, grid, lds, st, w4, serial) : launch_kconv_ni<T, 8, false>(ni, ca, grid, lds, st, w4, serial); break;
     case 4: dw1 ? launch_kconv_ni<T, 4, true>(ni, ca, grid, lds, st, w4, serial) : launch_kconv_ni<T, 4, false>(ni, ca, grid, lds, st, w4, serial); break;

@@ -459,7 +459,7 @@ struct KconvArgs {
 // Two waves per SIMD overlap them: the 64 MI rows x 16 NI columns of the workgroup are split 4 x 2 over the waves (NI even: each wave
 // MI x NI / 2 tiles) or 8 x 1 (NI = 3: MI / 2 x NI).  Operand ring, patch and tile plan are unchanged.
 //
-// PIPE (round 6, second step; needs gm.kss == 4): the k loop as a software pipeline.  The loop above it (kept: PIPE = false, the
+// PIPE (round 6, second step; needs gm.kss == 4 and K >= 32): the k loop as a software pipeline.  The loop above it (kept: PIPE = false, the
 // LYC_KCONV_SERIAL switch, and every plan with fewer than 4 k steps per stage) runs each k step as its own basic block -- tap-table
 // ds_read_b32 -> wait -> 6 fragment ds_read_b128 -> wait -> 8 MFMAs (`hipcc -S`: one s_waitcnt lgkmcnt(0) in front of every MFMA pair), a
 // dependent chain of ~550 cycles around 128 cycles of matrix-core issue, and every stage ends in a full drain (vmcnt(0) + barrier) before
@@ -607,7 +607,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && MI * NI <= 24) ? 2 : 1) void k
     }
   }
 
-  if constexpr (PIPE) issue_stage(1, ring + kconv_stage_bytes(NI, 4));  // (behind the patch: stage 1 is not needed before k step 3)
   LYC_STAMP(1);  // stage 0 of the ring and the whole patch requested
   // ---- this lane's two stage-1 rows: local pixel (ly, lx), group u; byte offset of (pixel, u) in the patch ----------------
   int rowbase[MW];
@@ -644,20 +643,27 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && MI * NI <= 24) ? 2 : 1) void k
     const int ci = sgn * a.gat.dh * gm.PW * gm.CP * (int)sizeof(T);
     const int cj = sgn * a.gat.dw * gm.CP * (int)sizeof(T);
     const int c0 = a.gat.mode == 1 ? 0 : ((kh_ - 1) * a.gat.dh * gm.PW + (a.gat.kw - 1) * a.gat.dw) * gm.CP * (int)sizeof(T);
-    const float inv_kw = 1.0f / (float)a.gat.kw;
-    // LDS byte offsets of this lane's A fragments of flat k step ksf
-    auto a_offsets = [&](int ksf, int (&ao)[MW]) {
-      const int k = 32 * ksf + 8 * g;
-      int tap = (int)(((float)k + 0.5f) * inv_k);
-      int v = k - tap * K;
-      if (v < 0) { v += K; --tap; }
-      if (v >= K) { v -= K; ++tap; }
-      const int ti = (int)(((float)tap + 0.5f) * inv_kw);  // tap <= 64: exact
-      const int tj = tap - ti * a.gat.kw;
-      const int toff = c0 + ti * ci + tj * cj + v * (int)sizeof(T);
-      const bool kok = k < Kflat;
+    // LDS byte offsets of this lane's A fragments, k step by k step (K >= 32: at most one tap boundary per step of 32).  The state
+    // (flat k, channel v, window column tj, byte offset of (tap, v)) advances with adds, compares and selects only -- the closed form
+    // (two float divisions with fix-ups and four v_mul_lo_u32 per k step, as the serial loop has it) is ~45 VALU operations per k step
+    // and wave, several of them quarter rate: as many SIMD cycles as the k step's 8 MFMAs
+    const int d_j = cj - K * (int)sizeof(T);
+    const int d_i = ci - (a.gat.kw - 1) * cj - K * (int)sizeof(T);
+    const int kw1 = a.gat.kw - 1;
+    int kf = 8 * g, v_ = 8 * g, tj_ = 0, toff = c0 + 8 * g * (int)sizeof(T);
+    auto a_offsets = [&](int (&ao)[MW]) {
+      const bool kok = kf < Kflat;
 #pragma unroll
       for (int mi = 0; mi < MW; ++mi) ao[mi] = kok ? rowbase[mi] + toff : zero_ofs;
+    };
+    auto advance = [&]() {
+      kf += 32;
+      v_ += 32;
+      const bool wrap = v_ >= K;
+      const bool wrapj = wrap && tj_ == kw1;
+      toff += 32 * (int)sizeof(T) + (wrap ? (wrapj ? d_i : d_j) : 0);
+      v_ -= wrap ? K : 0;
+      tj_ = wrap ? (wrapj ? 0 : tj_ + 1) : tj_;
     };
     F8 af[2][MW], bh[2][NIW], bl[2][NIW];
     auto load_frags = [&](F8 (&fa)[MW], F8 (&fh)[NIW], F8 (&fl)[NIW], const char* buf, int kk, const int (&ao)[MW]) {
@@ -681,7 +687,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && MI * NI <= 24) ? 2 : 1) void k
         for (int mi = 0; mi < MW; ++mi) acc[mi][ni] = TT<T>::mma(fa[mi], fl[ni], acc[mi][ni]);
     };
     int ao[MW];
-    a_offsets(0, ao);
+    a_offsets(ao);
     load_frags(af[0], bh[0], bl[0], ring, 0, ao);
     for (int s = 0; s < nstage; ++s) {
       char* buf = ring + (s & 1) * stage_bytes;
@@ -689,7 +695,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && MI * NI <= 24) ? 2 : 1) void k
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int cur = kk & 1, nxt = cur ^ 1;
-        a_offsets(4 * s + kk + 1, ao);
+        // stage 1 is requested behind the prologue, not in it: the prologue is fill-rate bound (every CU's workgroup bursts its
+        // patch at once, ~12 B / clk / CU), and hipcc drains vmcnt at the loop header whatever was counted before it
+        if (kk == 0 && s == 0) issue_stage(1, ring + stage_bytes);
+        advance();
+        a_offsets(ao);
         if (kk < 3) {
           load_frags(af[nxt], bh[nxt], bl[nxt], buf, kk + 1, ao);
         } else {

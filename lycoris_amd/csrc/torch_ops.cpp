@@ -938,7 +938,9 @@ const void* planes_bwd_ptr(const Tensor& planes, int64_t c, int64_t d, int taps)
 Tensor lokr_linear_fwd(const Tensor& x, const Tensor& w1, const Tensor& w2, double alpha, const c10::optional<Tensor>& base) {
   require_device(x, "input");
   const c10::DeviceGuard guard(x.device());
-  TORCH_CHECK(w1.dim() == 2 && w2.dim() == 2, "lokr_linear: w1 [a, b], w2 [c, d]");
+  // (w2 [c, d, 1, 1]: the factor of a 1x1 convolution, contiguous -- [c, d] in memory; ops.lokr_conv2d hands the leaf over unreshaped)
+  TORCH_CHECK(w1.dim() == 2 && (w2.dim() == 2 || (w2.dim() == 4 && w2.size(2) == 1 && w2.size(3) == 1 && w2.is_contiguous())),
+              "lokr_linear: w1 [a, b], w2 [c, d] (or the contiguous [c, d, 1, 1] of a 1x1 convolution)");
   const int64_t a = w1.size(0), b = w1.size(1), c = w2.size(0), d = w2.size(1);
   TORCH_CHECK(x.size(-1) == b * d, "adapter expects ", b * d, " input features, got ", x.sizes());
   Tensor rows = rows_of(x, b * d), f1 = f32c(w1);

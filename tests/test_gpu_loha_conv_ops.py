@@ -221,3 +221,49 @@ def test_loha_conv2d(shape, dtype):
         bounds[n] = TOL["f32_out"][dtype]
     loha_cast_pair(errs, bounds, dtype, y, grads[0], x64, g64, (a1, b1, a2, b2), 0.5, wshape, _ca(s, p, d))
     check(f"loha_conv2d[{shape},{dtype}]", errs, bounds)
+
+
+@pytest.mark.parametrize("layout", ["contiguous", "channels_last"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "f16", "f32"])
+@pytest.mark.parametrize("shape", [(2, 64, 9, 7, 128, 8), (1, 320, 16, 16, 640, 8), (3, 48, 5, 5, 32, 4)], ids=str)
+def test_lokr_conv2d_pointwise_is_the_linear_op(shape, dtype, layout):
+    """A 1x1 LoKr convolution runs the nn.Linear op on the NHWC pixel rows with the 4-D LEAF w2 [c, d, 1, 1] itself (round 6): packed
+    operand planes, and -- in the training configuration -- the factor gradients accumulated straight into .grad by the grouped launch.
+    Reference: lycoris/functional/lokr.py:154-247 (conv branch), modules/lokr.py:543-566."""
+    from lycoris_amd import ops
+    B, C, H, W, O, f = shape
+    gen = torch.Generator().manual_seed(sum(shape) + 11)
+    x, x64 = rnd((B, C, H, W), dtype, gen)
+    w1, w1_64 = rnd((f, f), torch.float32, gen, 0.3)
+    w2, w2_64 = rnd((O // f, C // f, 1, 1), torch.float32, gen, 0.1)
+    if layout == "channels_last":
+        x = x.contiguous(memory_format=torch.channels_last)
+    ca = _ca(1, 0, 1)
+    y_ref = oracle.lokr.forward(x64, w1=w1_64, w2=w2_64, scale=0.9, kshape=(1, 1), conv_args=ca)
+    g, g64 = rnd(y_ref.shape, dtype, gen, 1.0 / np.sqrt(O))
+    if layout == "channels_last":
+        g = g.contiguous(memory_format=torch.channels_last)
+    gr = oracle.lokr.backward(x64, g64, w1=w1_64, w2=w2_64, scale=0.9, kshape=(1, 1), conv_args=ca)
+    bounds = {"y": TOL["store_out"][dtype], "dx": TOL["store_out"][dtype], "dw1": TOL["f32_out"][dtype], "dw2": TOL["f32_out"][dtype]}
+    # plain autograd
+    xs, w1s, w2s = x.clone().requires_grad_(True), w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    y = ops.lokr_conv2d(xs, w1s, w2s, 0.9, (1, 1), (0, 0), (1, 1))
+    assert y.shape == (B, O, H, W)
+    dx, dw1, dw2 = torch.autograd.grad(y, [xs, w1s, w2s], g)
+    torch.cuda.synchronize()
+    assert dw2.shape == w2.shape and dx.shape == x.shape
+    check(f"lokr_pointwise[{shape},{dtype},{layout}]",
+          {"y": err(y, y_ref, dtype), "dx": err(dx, gr["dx"], dtype), "dw1": err(dw1, gr["w1"]), "dw2": err(dw2, gr["w2"])}, bounds)
+    # training configuration: leaves with fp32 .grad buffers, fused accumulation, deferred + grouped weight gradients
+    w1p, w2p = torch.nn.Parameter(w1.clone()), torch.nn.Parameter(w2.clone())
+    w1p.grad, w2p.grad = torch.zeros_like(w1p), torch.zeros_like(w2p)
+    xe = x.clone().requires_grad_(True)
+    ops.fused_grad_accumulation(True, None)
+    try:
+        ops.lokr_conv2d(xe, w1p, w2p, 0.9, (1, 1), (0, 0), (1, 1)).backward(g)
+        torch.cuda.synchronize()
+    finally:
+        ops.fused_grad_accumulation(False, None)
+    check(f"lokr_pointwise_fused[{shape},{dtype},{layout}]",
+          {"dx": err(xe.grad, gr["dx"], dtype), "dw1": err(w1p.grad, gr["w1"]), "dw2": err(w2p.grad, gr["w2"])},
+          {k: bounds[k] for k in ("dx", "dw1", "dw2")})

@@ -104,6 +104,10 @@ GEOMS = [
     (1, 8, 8, 16, 8, 8, 3, 1, 1, 1),        # factor 16: 2 x 4 pixel tiles
     (1, 6, 6, 8, 40, 40, 3, 1, 0, 1),       # no padding: output smaller than the input
     (3, 5, 5, 8, 8, 8, 1, 1, 0, 1),         # 1x1 window through the conv entry points
+    # K >= 32 in both roles: the software-pipelined k loop of round 6 (tap offsets advanced incrementally) on the odd windows too
+    (1, 10, 10, 8, 40, 32, 3, 1, 2, 2),     # dilation 2
+    (1, 9, 9, 8, 32, 40, 5, 1, 2, 1),       # 5x5 window: 25 taps
+    (2, 7, 9, 8, 48, 32, 3, 1, 1, 1),       # K = 32: a tap boundary on every k step
 ]
 
 
