@@ -1669,7 +1669,10 @@ Tensor lokr_linear_lr2_meta(const Tensor& x, const Tensor& w1a, const Tensor& w1
 std::tuple<Tensor, Tensor> locon_linear_fwd(const Tensor& x, const Tensor& down, const Tensor& up, double alpha) {
   require_device(x, "input");
   const c10::DeviceGuard guard(x.device());
-  TORCH_CHECK(down.dim() == 2 && up.dim() == 2 && down.size(0) == up.size(1), "locon_linear: down [r, I], up [O, r]");
+  // (4-D factors of a 1x1 convolution, contiguous: [r, C, 1, 1] / [O, r, 1, 1] are [r, C] / [O, r] in memory; ops.locon_conv2d hands the
+  // leaves over unreshaped)
+  auto mat = [](const Tensor& f) { return f.dim() == 2 || (f.dim() == 4 && f.size(2) == 1 && f.size(3) == 1 && f.is_contiguous()); };
+  TORCH_CHECK(mat(down) && mat(up) && down.size(0) == up.size(1), "locon_linear: down [r, I], up [O, r] (or the contiguous 1x1 conv factors)");
   const int64_t r = down.size(0), I = down.size(1), O = up.size(0);
   TORCH_CHECK(x.size(-1) == I, "adapter expects ", I, " input features, got ", x.sizes());
   Tensor rows = rows_of(x, I), fd = f32c(down), fu = f32c(up);

@@ -904,6 +904,11 @@ def locon_conv2d(x, down, up, alpha, stride, padding, dilation):
         if _cpp():
             return _OPS["locon_conv2d"](x, down, up, float(alpha), list(geom[1]), list(geom[2]), list(geom[3]))
         return _LoconConv2dImplicit.apply(alpha, geom, x, down, up)
+    if (x.dim() == 4 and _is_pointwise(geom) and _cpp() and down.is_contiguous() and up.is_contiguous()
+            and not torch.compiler.is_compiling() and x.permute(0, 2, 3, 1).is_contiguous()):
+        # 1x1 lora_down on a channels_last tensor: the nn.Linear op on the NHWC pixel rows with the 4-D LEAVES [r, C, 1, 1] / [O, r, 1, 1]
+        # (as ops.lokr_conv2d, round 6: a reshaped parameter is a non-leaf view -- no fused accumulation, one factor-gradient launch per layer)
+        return _OPS["locon_linear"](x.permute(0, 2, 3, 1), down, up, float(alpha)).permute(0, 3, 1, 2)
     return _rows_conv2d(_LoconCore, alpha, geom, x, down.reshape(r, -1), up.reshape(O, r))
 
 
@@ -926,15 +931,13 @@ def lokr_conv2d(x, w1, w2, alpha, stride, padding, dilation):
         if _cpp():
             return _OPS["lokr_conv2d"](x, w1, w2, float(alpha), list(geom[1]), list(geom[2]), list(geom[3]))
         return _LokrConv2dImplicit.apply(alpha, geom, x, w1, w2)
-    if x.dim() == 4 and _is_pointwise(geom) and _cpp() and w2.is_contiguous() and not torch.compiler.is_compiling():
+    if (x.dim() == 4 and _is_pointwise(geom) and _cpp() and w2.is_contiguous() and not torch.compiler.is_compiling()
+            and x.permute(0, 2, 3, 1).is_contiguous()):  # channels_last (the documented layout); NCHW keeps the lowering's copies and formats
         # a 1x1 convolution IS nn.Linear on the NHWC pixel rows (a free view of a channels_last tensor), and [c, d, 1, 1] is [c, d] in
         # memory: the Linear op takes the 4-D LEAF itself (round 6), so the layer gets everything a Linear layer has -- packed operand
         # planes (kron4 instead of the row kernel), weight gradients accumulated into .grad by the grouped launch.  Reshaping the
         # parameter first (rounds 1 - 5) handed the op a non-leaf view: no planes, no fused accumulation, one dW2 launch per layer.
-        rows = x.permute(0, 2, 3, 1)
-        free = rows.is_contiguous()  # channels_last in -> channels_last out, NCHW in -> NCHW out (as F.conv2d, and as rounds 1 - 5)
-        y = _OPS["lokr_linear"](rows if free else rows.contiguous(), w1, w2, float(alpha), None).permute(0, 3, 1, 2)
-        return y if free else y.contiguous()
+        return _OPS["lokr_linear"](x.permute(0, 2, 3, 1), w1, w2, float(alpha), None).permute(0, 3, 1, 2)
     return _rows_conv2d(_LokrCore, alpha, geom, x, w1, w2.reshape(w2.shape[0], -1))
 
 

@@ -267,3 +267,47 @@ def test_lokr_conv2d_pointwise_is_the_linear_op(shape, dtype, layout):
     check(f"lokr_pointwise_fused[{shape},{dtype},{layout}]",
           {"dx": err(xe.grad, gr["dx"], dtype), "dw1": err(w1p.grad, gr["w1"]), "dw2": err(w2p.grad, gr["w2"])},
           {k: bounds[k] for k in ("dx", "dw1", "dw2")})
+
+
+@pytest.mark.parametrize("layout", ["contiguous", "channels_last"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "f16", "f32"])
+@pytest.mark.parametrize("shape", [(2, 64, 9, 7, 128, 8), (1, 320, 16, 16, 640, 16), (3, 48, 5, 5, 32, 4)], ids=str)
+def test_locon_conv2d_pointwise_is_the_linear_op(shape, dtype, layout):
+    """A 1x1 LoCon convolution on a channels_last tensor runs the nn.Linear op on the NHWC pixel rows with the 4-D LEAVES lora_down
+    [r, C, 1, 1] / lora_up [O, r, 1, 1] (round 6) -- fused accumulation into .grad and the grouped factor-gradient launch included.
+    Reference: lycoris/functional/locon.py:64-85, modules/locon.py:286-332."""
+    from lycoris_amd import ops
+    B, C, H, W, O, r = shape
+    gen = torch.Generator().manual_seed(sum(shape) + 13)
+    x, x64 = rnd((B, C, H, W), dtype, gen)
+    down, d64 = rnd((r, C, 1, 1), torch.float32, gen, 0.1)
+    up, u64 = rnd((O, r, 1, 1), torch.float32, gen, 0.1)
+    if layout == "channels_last":
+        x = x.contiguous(memory_format=torch.channels_last)
+    ca = _ca(1, 0, 1)
+    y_ref = oracle.locon.forward(x64, d64, u64, 1.25, ca)
+    g, g64 = rnd(y_ref.shape, dtype, gen, 1.0 / np.sqrt(O))
+    if layout == "channels_last":
+        g = g.contiguous(memory_format=torch.channels_last)
+    dx_r, dd_r, du_r = oracle.locon.backward(x64, g64, d64, u64, 1.25, ca)
+    bounds = {"y": TOL["store_out"][dtype], "dx": TOL["store_out"][dtype], "d_down": TOL["f32_out"][dtype], "d_up": TOL["f32_out"][dtype]}
+    xs, ds, us = x.clone().requires_grad_(True), down.clone().requires_grad_(True), up.clone().requires_grad_(True)
+    y = ops.locon_conv2d(xs, ds, us, 1.25, (1, 1), (0, 0), (1, 1))
+    assert y.shape == (B, O, H, W)
+    dx, dd, du = torch.autograd.grad(y, [xs, ds, us], g)
+    torch.cuda.synchronize()
+    assert dd.shape == down.shape and du.shape == up.shape and dx.shape == x.shape
+    check(f"locon_pointwise[{shape},{dtype},{layout}]",
+          {"y": err(y, y_ref, dtype), "dx": err(dx, dx_r, dtype), "d_down": err(dd, dd_r), "d_up": err(du, du_r)}, bounds)
+    dp, upp = torch.nn.Parameter(down.clone()), torch.nn.Parameter(up.clone())
+    dp.grad, upp.grad = torch.zeros_like(dp), torch.zeros_like(upp)
+    xe = x.clone().requires_grad_(True)
+    ops.fused_grad_accumulation(True, None)
+    try:
+        ops.locon_conv2d(xe, dp, upp, 1.25, (1, 1), (0, 0), (1, 1)).backward(g)
+        torch.cuda.synchronize()
+    finally:
+        ops.fused_grad_accumulation(False, None)
+    check(f"locon_pointwise_fused[{shape},{dtype},{layout}]",
+          {"dx": err(xe.grad, dx_r, dtype), "d_down": err(dp.grad, dd_r), "d_up": err(upp.grad, du_r)},
+          {k: bounds[k] for k in ("dx", "d_down", "d_up")})
