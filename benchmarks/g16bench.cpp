@@ -226,7 +226,7 @@ int main(int argc, char** argv) {
         auto launch = [&](const Gemm16Prob& p) {
           Gemm16Group ga{};
           ga.n = 1; ga.out_f32 = f32; ga.p[0] = p;
-          ga.wg_end[0] = gemm16d_wgs((long)((p.M + v.BM - 1) / v.BM) * ((p.N + v.BN - 1) / v.BN));
+          ga.wg_end[0] = gemm16d_wgs(p.M, p.N, v.BM, v.BN);
           hipLaunchKernelGGL(v.fn[mode], dim3((unsigned)ga.wg_end[0]), dim3(NTHREADS), lds, st, ga);
         };
         CK(hipMemsetAsync(cout, 0xff, nout * (f32 ? 4 : 2), st));
@@ -253,7 +253,7 @@ int main(int argc, char** argv) {
         const float t = bench(st, 30, 5, [&](int i) {                                                                                    \
           Gemm16Group ga{};                                                                                                              \
           ga.n = 1; ga.p[0] = prob0(sets[i % nsets]);                                                                                    \
-          ga.wg_end[0] = gemm16d_wgs((long)((M + BM_ - 1) / BM_) * ((O + BN_ - 1) / BN_));                                              \
+          ga.wg_end[0] = gemm16d_wgs(M, O, BM_, BN_);                                              \
           hipLaunchKernelGGL(kern, dim3((unsigned)ga.wg_end[0]), dim3(NTHREADS), gemm16d_lds_bytes(BM_, BN_, D_), st, ga);              \
         });                                                                                                                              \
         printf("   ablate %dx%d D%d bits %2d (1 no refill, 2 no mfma, 4 no lds reads, 8 no barrier): %8.2f us\n", BM_, BN_, D_, bits, t);  \

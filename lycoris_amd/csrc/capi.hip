@@ -2636,7 +2636,7 @@ inline void gemm16d_tile(int cls, int& bm, int& bn) {
 inline int gemm16d_problem_wgs(const Gemm16Prob& p, int cls) {
   int bm, bn;
   gemm16d_tile(cls, bm, bn);
-  return gemm16d_wgs(cdiv(p.M, bm) * cdiv(p.N, bn));
+  return gemm16d_wgs(p.M, p.N, bm, bn);
 }
 template <typename T, int BM, int BN, bool A_KS, bool B_KS, int D>
 void launch_gemm16d_inst(const Gemm16Group& ga, hipStream_t st) {

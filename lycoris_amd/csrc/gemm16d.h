@@ -205,10 +205,37 @@ struct G16DOperand {
   }
 };
 
-// tile -> (tm, tn) in an XCD-contiguous order: consecutive workgroup ids go round-robin over the 8 XCDs (one L2 each), so XCD x takes
-// the logical tiles [x * per, (x + 1) * per) -- row tiles fastest: one range shares its B panels and all of A.  The grid of a problem
-// is 8 * per workgroups (the surplus ones return).
-__host__ __device__ inline int gemm16d_wgs(long tiles) { return (int)(8 * ((tiles + 7) / 8)); }
+// tile -> (tm, tn): consecutive workgroup ids go round-robin over the 8 XCDs (one L2 each), so XCD x takes the workgroups x, x + 8, ...
+// Round 6 (first version): XCD x owned a contiguous range of the column-major tile list -- every XCD read ALL of A and 1 / 8 of B
+// (measured fabric reads of a 1024 x 1280 x 1280 problem: 36 - 50 MB for 6 MB of operands, profiles/r06_interim_pmc_traffic_loha_*.txt).
+// Now the 8 XCDs form a gm x gn grid over the output (gm * gn = 8) and XCD (xm, xn) owns the block of tm_per x tn_per tiles at
+// (xm * tm_per, xn * tn_per), row tiles fastest inside it: its L2 holds M / gm rows of A and N / gn rows of B.  gm minimises the
+// first-touch traffic 8 * (M / gm + N / gn) * K = (M * gn + N * gm) * K (ties: the smaller gm).  -DG16D_MAP1D: the first version (A/B).
+struct G16DMap {
+  int lgm, tm_per, tn_per;  // gm = 1 << lgm, gn = 8 >> lgm
+};
+__host__ __device__ inline G16DMap gemm16d_map(int tiles_m, int tiles_n, long M, long N) {
+  G16DMap best{0, tiles_m, (tiles_n + 7) >> 3};
+#ifndef G16D_MAP1D
+  long cost = M * 8 + N;
+#pragma unroll
+  for (int lg = 1; lg <= 3; ++lg) {  // (shifts only: this runs in every workgroup's prologue)
+    const int gm = 1 << lg, gn = 8 >> lg;
+    const long c = M * gn + N * gm;
+    if (gm <= tiles_m && gn <= tiles_n && c < cost) {
+      cost = c;
+      best = G16DMap{lg, (tiles_m + gm - 1) >> lg, (tiles_n + gn - 1) >> (3 - lg)};
+    }
+  }
+#endif
+  return best;
+}
+// workgroups of a problem (a multiple of 8; the surplus ones return)
+__host__ __device__ inline int gemm16d_wgs(long M, long N, int bm, int bn) {
+  const int tiles_m = (int)((M + bm - 1) / bm), tiles_n = (int)((N + bn - 1) / bn);
+  const G16DMap mp = gemm16d_map(tiles_m, tiles_n, M, N);
+  return 8 * mp.tm_per * mp.tn_per;
+}
 
 // ABL != 0: ablation builds of benchmarks/g16bench.cpp (results are garbage): 1 = no refill DMA in the loop, 2 = no MFMAs, 4 = no LDS
 // fragment reads, 8 = no barrier
@@ -222,10 +249,11 @@ __device__ __forceinline__ void gemm16d_body(const Gemm16Prob& p, int out_f32, c
   static_assert(D >= 2 && D <= 7 && (D - 1) * C <= 63, "ring depth");
 
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int per = (tiles_m * tiles_n + 7) >> 3;
-  const int logical = (b & 7) * per + (b >> 3);
-  if (logical >= tiles_m * tiles_n) return;
-  const int tm = logical % tiles_m, tn = logical / tiles_m;
+  const G16DMap mp = gemm16d_map(tiles_m, tiles_n, p.M, p.N);
+  const int xcd = b & 7, idx = b >> 3;
+  const int ln = idx / mp.tm_per, lm = idx - ln * mp.tm_per;
+  const int tm = (xcd & ((1 << mp.lgm) - 1)) * mp.tm_per + lm, tn = (xcd >> mp.lgm) * mp.tn_per + ln;
+  if (ln >= mp.tn_per || tm >= tiles_m || tn >= tiles_n) return;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
@@ -366,7 +394,7 @@ __global__ __launch_bounds__(NTHREADS, (gemm16d_occupancy<BM, BN, D>())) void ge
   const int b = (int)blockIdx.x;
   int p = 0;
   while (p + 1 < ga.n && b >= ga.wg_end[p]) ++p;
-  const int b0 = p ? ga.wg_end[p - 1] : 0;  // a multiple of 8: every problem's range is gemm16d_wgs(tiles)
+  const int b0 = p ? ga.wg_end[p - 1] : 0;  // a multiple of 8: every problem's range is gemm16d_wgs(M, N, BM, BN)
   gemm16d_body<T, BM, BN, A_KS, B_KS, D, ABL>(ga.p[p], ga.out_f32, g16d_smem, b - b0);
 }
 

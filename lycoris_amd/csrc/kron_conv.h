@@ -481,7 +481,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && MI * NI <= 24) ? 2 : 1) void k
   const int wm = wave % WM, wn = wave / WM;
   const int G = a.Gin, K = a.K, N = a.N;
   const int lg = 31 - __builtin_clz((unsigned)G);
-  const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+  // workgroup -> tile: consecutive workgroup ids go round-robin over the 8 XCDs (one L2 each).  With the identity map the neighbours of
+  // a tile -- which share its halo rows -- sit on 8 different L2s (measured traffic of the family: 2.1x its algorithmic bytes); XCD x
+  // takes the contiguous band of tiles [x * nt / 8, (x + 1) * nt / 8) instead, so a halo row is fetched by one L2, at most two.  (The
+  // column tiles `by` of a pixel tile share its XCD either way: the grid's x extent is a multiple of 8 when this applies.)
+  int bx = (int)blockIdx.x;
+  if ((gridDim.x & 7u) == 0) bx = (bx & 7) * (int)(gridDim.x >> 3) + (bx >> 3);
+  const int by = (int)blockIdx.y;
   const long n0 = (long)by * (16 * NI);
 
   // ---- tile -> (image, tile row, tile column) -------------------------------------------------------------------------
