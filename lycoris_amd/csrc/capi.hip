@@ -812,7 +812,14 @@ void launch_tn_rt(LowrankTnArgs& a, int cv, hipStream_t st) {
 #define LYC_TNG_CVMAX 2
 #endif
 int plan_lowrank_tn(LowrankTnArgs& a, int dtype, bool grouped = false) {
-  constexpr int atomic_budget = 800000, wave_target = 1400;  // measured (profiles/r01_ktrace_lowrank.log)
+  // measured (profiles/r01_ktrace_lowrank.log); the implicit-Conv2d form (gathered rows: one load per tap and row) has its own target
+#ifndef LYC_TN_WAVE_TARGET_GAT
+#define LYC_TN_WAVE_TARGET_GAT 1400
+#endif
+#ifndef LYC_TN_ATOMIC_BUDGET_GAT
+#define LYC_TN_ATOMIC_BUDGET_GAT 800000
+#endif
+  const int atomic_budget = a.gat.mode ? LYC_TN_ATOMIC_BUDGET_GAT : 800000, wave_target = a.gat.mode ? LYC_TN_WAVE_TARGET_GAT : 1400;
   const int dt = dtype & 0xff;
   if ((dt != LYC_BF16 && dt != LYC_F16) || a.R > 64) return 0;
   long csum = 0;

@@ -481,12 +481,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && MI * NI <= 24) ? 2 : 1) void k
   const int wm = wave % WM, wn = wave / WM;
   const int G = a.Gin, K = a.K, N = a.N;
   const int lg = 31 - __builtin_clz((unsigned)G);
-  // workgroup -> tile: consecutive workgroup ids go round-robin over the 8 XCDs (one L2 each).  With the identity map the neighbours of
-  // a tile -- which share its halo rows -- sit on 8 different L2s (measured traffic of the family: 2.1x its algorithmic bytes); XCD x
-  // takes the contiguous band of tiles [x * nt / 8, (x + 1) * nt / 8) instead, so a halo row is fetched by one L2, at most two.  (The
-  // column tiles `by` of a pixel tile share its XCD either way: the grid's x extent is a multiple of 8 when this applies.)
-  int bx = (int)blockIdx.x;
-  if ((gridDim.x & 7u) == 0) bx = (bx & 7) * (int)(gridDim.x >> 3) + (bx >> 3);
+  // (An XCD-band tile order -- XCD x takes a contiguous eighth of the pixel tiles, so that a halo row is fetched by one L2 -- was measured in
+  // round 6 and changed neither the launch time nor the family's fabric traffic, profiles/r06_c45_kcbench_xcd_band_order.log: the 2.1x
+  // over the algorithmic bytes is the operand planes and the dW1 partials, not halo duplication.  Identity order.)
+  const int bx = (int)blockIdx.x;
   const int by = (int)blockIdx.y;
   const long n0 = (long)by * (16 * NI);
 
