@@ -1396,13 +1396,17 @@ def conv_leg(insts, args, dtype):
     workload = f"lokr/{args.model}/conv"
     tr, src = pmc_traffic("lokr_conv", workload)
     out = {"layers": len(conv), "kernel": "lyc::kconv_kernel (LDS source patch + packed operand planes; forward, backward dx / dW1) + the "
-                                           "grouped weight-gradient launches (lyc::kron_dw2s_conv_group_kernel); 1x1 convs run the row kernels",
+                                           "grouped weight-gradient launches (lyc::kron_dw2f_group_kernel, Conv2d form); round 6: 8 waves + software-pipelined k loop; 1x1 convs run "
+                                           "the Linear kernels (lyc::kron4_kernel, grouped weight gradients)",
            "families_ms": {"forward": round(t_f, 3), "backward_dx_and_grouped_dw2": round(t_b, 3)},
            "algorithmic_bytes_per_step": int(nbytes), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(ach / HBM_PEAK_GBS, 4), "memory_format": "channels_last" if args.channels_last else "contiguous (NCHW: + two row transposes per pass)",
            "traffic": int(tr["bytes_per_pass"]) if tr else None, "traffic_source": src, "traffic_workload": workload}
     if tr:
         out["traffic_over_algorithmic"] = round(tr["bytes_per_pass"] / nbytes, 2)
+    mb = pmc_mfma(workload)  # the family is matrix-core / latency bound rather than HBM bound: its MFMA-busy share beside the HBM figure
+    if mb:
+        out["mfma_busy"] = {k: v for k, v in mb.items() if k != "kernels"} if "time_weighted_mfma_util" in mb else mb
     return out
 
 
