@@ -12,7 +12,10 @@ IDS = ["f32", "bf16", "f16"]
 
 LOHA_SHAPES = [(64, 64, 128, 8), (200, 320, 640, 32), (77, 200, 72, 5), (33, 50, 70, 40), (1, 128, 128, 4),
                (48, 2560, 2048, 16),   # 1280 tiles: 2 row tiles per workgroup in the factor-gradient kernel
-               (40, 4160, 4096, 8)]    # 4160 tiles: 4 x 2 tiles per workgroup, ragged last column group
+               (40, 4160, 4096, 8),    # 4160 tiles: 4 x 2 tiles per workgroup, ragged last column group
+               # gemm16d's 2-D tile -> XCD map (round 6): XCD grids 4 x 2, 8 x 1 and 2 x 4 over the output with RAGGED blocks (tile counts
+               # that do not divide by the grid: surplus workgroups return) and ragged last row / column tiles, in all three contractions
+               (1000, 320, 704, 8), (2200, 192, 128, 4), (520, 1344, 320, 8)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
