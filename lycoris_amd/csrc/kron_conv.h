@@ -464,7 +464,7 @@ struct KconvArgs {
 // ds_read_b32 -> wait -> 6 fragment ds_read_b128 -> wait -> 8 MFMAs (`hipcc -S`: one s_waitcnt lgkmcnt(0) in front of every MFMA pair), a
 // dependent chain of ~550 cycles around 128 cycles of matrix-core issue, and every stage ends in a full drain (vmcnt(0) + barrier) before
 // the first read of the next one.  Here a stage is ONE straight-line region of four unguarded k steps: the fragments of k step i + 1 are
-// read (into a second register set) before the MFMAs of k step i issue, the tap offset is arithmetic (no LDS table on the chain), the
+// read (into a second register set) before the MFMAs of k step i issue, the tap offset advances incrementally (no LDS table, no division), the
 // stage barrier sits in FRONT of the last k step's MFMAs (the next stage's first fragments are requested behind it, so the barrier
 // latency is covered by 8 MFMAs) and the operand DMA of stage s + 2 is issued there -- a whole stage before anybody waits for it.
 // K steps beyond the flat K run on a zero A fragment and a finite duplicate B unit.
