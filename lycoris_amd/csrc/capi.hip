@@ -1712,6 +1712,9 @@ bool plan_kconv(const KronArgs& ka, int64_t B, KconvGeom& gm, int& mi, int& ni, 
     if (padded * 4 <= (long)ka.N * 5) { ni = cand; break; }
     if (padded < best) { best = padded; ni = cand; }
   }
+#ifdef LYC_KCONV_NI_FILL  // experiment builds (benchmarks/kcbench_nifill): prefer the column tile that fills one round of 256 CUs
+  if (ni == 4 && B * cdiv(gt.Hd, 4) * cdiv(gt.Wd, 4) * cdiv(ka.N, 64) < 256 && B * cdiv(gt.Hd, 4) * cdiv(gt.Wd, 4) * cdiv(ka.N, 48) <= 256) ni = 3;
+#endif
   // row tile: every workgroup streams the operand planes of its column tile once, so their traffic goes with 1 / MI -- take the
   // largest pixel tile that fits the LDS and still leaves about one workgroup per CU; else the smallest (most workgroups)
   const long ctiles = cdiv(ka.N, 16 * ni);
